@@ -1,0 +1,84 @@
+"""ctypes binding of libbgn_amd.so (include/bgn_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing this
+module raises at import of the symbols, and every compute call fails with
+BGN_E_HIP when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbgn_amd.so")
+
+BGN_OK = 0
+BGN_E_ARG, BGN_E_PARAM, BGN_E_HIP, BGN_E_STATE, BGN_E_POINT, BGN_E_NOMEM = -1, -2, -3, -4, -5, -6
+BGN_DL_OK, BGN_DL_NOT_FOUND = 0, 1
+
+_u8p = C.c_void_p      # raw addresses (host bytes or device pointers)
+_sz = C.c_size_t
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/bgn_amd.h one to one
+PROTOTYPES = {
+    "bgn_ctx_create": (C.c_int, [C.POINTER(_ctx), _u8p, _sz, _u8p, _sz, C.c_uint64, _u8p, _u8p, C.c_int, C.c_int]),
+    "bgn_ctx_destroy": (None, [_ctx]),
+    "bgn_fp_bytes": (_sz, [_ctx]),
+    "bgn_last_error": (C.c_char_p, []),
+    "bgn_version": (C.c_char_p, []),
+    "bgn_ctx_set_secret": (C.c_int, [_ctx, _u8p, _sz]),
+    "bgn_ctx_setup_decryption": (C.c_int, [_ctx, C.c_uint64]),
+    "bgn_encrypt_batch": (C.c_int, [_ctx, _sz, _u8p, _sz, _u8p, _sz, _u8p]),
+    "bgn_add_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bgn_sub_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bgn_neg_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p]),
+    "bgn_mult_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bgn_make_l2_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p]),
+    "bgn_multconst_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _sz, _u8p, _sz, _u8p]),
+    "bgn_decrypt_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p]),
+    "bgn_poly_mult_batch": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p]),
+    "bgn_encrypt_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _sz, _u8p, _sz, _u8p, C.c_void_p]),
+    "bgn_add_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, _sz, _u8p, C.c_void_p]),
+    "bgn_sub_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, _sz, _u8p, C.c_void_p]),
+    "bgn_neg_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, C.c_void_p]),
+    "bgn_mult_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, _sz, _u8p, C.c_void_p]),
+    "bgn_make_l2_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, C.c_void_p]),
+    "bgn_multconst_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _sz, _u8p, _sz, _u8p, C.c_void_p]),
+    "bgn_decrypt_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, C.c_void_p]),
+    "bgn_poly_mult_batch_dev": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p, C.c_void_p]),
+    "bgn_last_kernel_ms": (C.c_double, [_ctx]),
+    "bgn_last_kernel_name": (C.c_char_p, [_ctx]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises OSError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C bgn_amd/csrc).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class BgnError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        msg = load().bgn_last_error().decode("utf-8", "replace")
+        super().__init__(f"{where} failed with code {code}: {msg}")
+        self.code = code
+
+
+def check(code: int, where: str) -> None:
+    if code != BGN_OK:
+        raise BgnError(code, where)

@@ -1,0 +1,412 @@
+"""Host-side mirror of the reference's Go API for the batched hot path.
+
+Names and argument meaning follow sachaservan/bgn (bgn.go, ciphertext.go,
+poly.go, gsbs.go) so tests read like the reference's own; every operation is
+executed by the HIP engine through the C ABI (include/bgn_amd.h).  Single
+element methods are the count = 1 case of the batch entry points.
+
+Error behaviour mirrors the reference: Decrypt raises DecryptError with the
+reference's message (gsbs.go:105); misuse that panics in Go raises here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import secrets
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+BytesLike = Union[bytes, bytearray, memoryview, np.ndarray]
+
+
+class DecryptError(ValueError):
+    """errors.New("cannot find discrete log; out of bounds") — gsbs.go:105"""
+
+    def __init__(self):
+        super().__init__("cannot find discrete log; out of bounds")
+
+
+def _int_bytes(v: int, length: int) -> bytes:
+    return int(v).to_bytes(length, "big")
+
+
+def _scalars(vals: Sequence[int], length: Optional[int] = None) -> np.ndarray:
+    """Pack non-negative integers as fixed-length big-endian rows."""
+    vals = [int(v) for v in vals]
+    if any(v < 0 for v in vals):
+        raise ValueError("scalars must be non-negative (reduce modulo n first)")
+    if length is None:
+        length = max(1, max(((v.bit_length() + 7) // 8 for v in vals), default=1))
+    buf = b"".join(v.to_bytes(length, "big") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint8).reshape(len(vals), length)
+
+
+def _as_u8(a: BytesLike, row: int) -> np.ndarray:
+    arr = np.frombuffer(a, dtype=np.uint8) if not isinstance(a, np.ndarray) else a
+    arr = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+    if arr.size % row:
+        raise ValueError(f"buffer of {arr.size} bytes is not a multiple of the element size {row}")
+    return arr.reshape(-1, row)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One bgn_ctx: a public key's pairing context on one GPU."""
+
+    def __init__(self, p: int, n: int, l: int, P_wire: bytes, Q_wire: bytes, deterministic: bool = True,
+                 device: int = 0):
+        self._lib = _lib.load()
+        self.p, self.n, self.l = int(p), int(n), int(l)
+        pb = _int_bytes(self.p, (self.p.bit_length() + 7) // 8)
+        nb = _int_bytes(self.n, (self.n.bit_length() + 7) // 8)
+        self._h = C.c_void_p()
+        self._keep = (pb, nb, bytes(P_wire), bytes(Q_wire))
+        check(self._lib.bgn_ctx_create(C.byref(self._h), pb, len(pb), nb, len(nb), self.l, self._keep[2],
+                                       self._keep[3], 1 if deterministic else 0, device), "bgn_ctx_create")
+        self.L = int(self._lib.bgn_fp_bytes(self._h))
+        self.elem_bytes = 2 * self.L
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.bgn_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- secret key / tables -------------------------------------------------
+    def set_secret(self, q1: int) -> None:
+        b = _int_bytes(q1, (int(q1).bit_length() + 7) // 8)
+        check(self._lib.bgn_ctx_set_secret(self._h, b, len(b)), "bgn_ctx_set_secret")
+
+    def setup_decryption(self, msg_space: int) -> None:
+        check(self._lib.bgn_ctx_setup_decryption(self._h, int(msg_space)), "bgn_ctx_setup_decryption")
+
+    # ---- host-buffer batch ops -------------------------------------------------
+    def _out(self, count: int) -> np.ndarray:
+        return np.zeros((count, self.elem_bytes), dtype=np.uint8)
+
+    def encrypt(self, x: Sequence[int], r: Optional[Sequence[int]] = None) -> np.ndarray:
+        xs = _scalars(x)
+        rs = _scalars(r) if r is not None else None
+        out = self._out(len(xs))
+        check(self._lib.bgn_encrypt_batch(self._h, len(xs), _ptr(xs), xs.shape[1], _ptr(rs),
+                                          rs.shape[1] if rs is not None else 0, _ptr(out)), "bgn_encrypt_batch")
+        return out
+
+    def _binop(self, fn, name, level, a, b, r):
+        A, B = _as_u8(a, self.elem_bytes), _as_u8(b, self.elem_bytes)
+        if len(A) != len(B):
+            raise ValueError("operand counts differ")
+        rs = _scalars(r) if r is not None else None
+        out = self._out(len(A))
+        check(fn(self._h, len(A), level, _ptr(A), _ptr(B), _ptr(rs), rs.shape[1] if rs is not None else 0, _ptr(out)),
+              name)
+        return out
+
+    def add(self, level: int, a: BytesLike, b: BytesLike, r=None) -> np.ndarray:
+        return self._binop(self._lib.bgn_add_batch, "bgn_add_batch", level, a, b, r)
+
+    def sub(self, level: int, a: BytesLike, b: BytesLike, r=None) -> np.ndarray:
+        return self._binop(self._lib.bgn_sub_batch, "bgn_sub_batch", level, a, b, r)
+
+    def neg(self, level: int, a: BytesLike) -> np.ndarray:
+        A = _as_u8(a, self.elem_bytes)
+        out = self._out(len(A))
+        check(self._lib.bgn_neg_batch(self._h, len(A), level, _ptr(A), _ptr(out)), "bgn_neg_batch")
+        return out
+
+    def mult(self, a: BytesLike, b: BytesLike, r=None) -> np.ndarray:
+        A, B = _as_u8(a, self.elem_bytes), _as_u8(b, self.elem_bytes)
+        if len(A) != len(B):
+            raise ValueError("operand counts differ")
+        rs = _scalars(r) if r is not None else None
+        out = self._out(len(A))
+        check(self._lib.bgn_mult_batch(self._h, len(A), _ptr(A), _ptr(B), _ptr(rs),
+                                       rs.shape[1] if rs is not None else 0, _ptr(out)), "bgn_mult_batch")
+        return out
+
+    def make_l2(self, a: BytesLike) -> np.ndarray:
+        A = _as_u8(a, self.elem_bytes)
+        out = self._out(len(A))
+        check(self._lib.bgn_make_l2_batch(self._h, len(A), _ptr(A), _ptr(out)), "bgn_make_l2_batch")
+        return out
+
+    def multconst(self, level: int, a: BytesLike, k: Sequence[int], r=None) -> np.ndarray:
+        A = _as_u8(a, self.elem_bytes)
+        ks = _scalars(k)
+        if len(ks) != len(A):
+            raise ValueError("operand counts differ")
+        rs = _scalars(r) if r is not None else None
+        out = self._out(len(A))
+        check(self._lib.bgn_multconst_batch(self._h, len(A), level, _ptr(A), _ptr(ks), ks.shape[1], _ptr(rs),
+                                            rs.shape[1] if rs is not None else 0, _ptr(out)), "bgn_multconst_batch")
+        return out
+
+    def decrypt(self, level: int, ct: BytesLike):
+        A = _as_u8(ct, self.elem_bytes)
+        m = np.zeros(len(A), dtype=np.int64)
+        st = np.zeros(len(A), dtype=np.uint8)
+        check(self._lib.bgn_decrypt_batch(self._h, len(A), level, _ptr(A), _ptr(m), _ptr(st)), "bgn_decrypt_batch")
+        return m, st
+
+    def poly_mult(self, npoly: int, d1: int, d2: int, a: BytesLike, b: BytesLike) -> np.ndarray:
+        A, B = _as_u8(a, self.elem_bytes), _as_u8(b, self.elem_bytes)
+        if len(A) != npoly * d1 or len(B) != npoly * d2:
+            raise ValueError("coefficient array sizes do not match npoly*d1 / npoly*d2")
+        out = self._out(npoly * (d1 + d2))
+        check(self._lib.bgn_poly_mult_batch(self._h, npoly, d1, d2, _ptr(A), _ptr(B), _ptr(out)),
+              "bgn_poly_mult_batch")
+        return out
+
+    # ---- device-buffer batch ops (torch uint8 CUDA tensors; asynchronous) ---------
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def mult_dev(self, a, b, out, count: Optional[int] = None) -> None:
+        count = a.numel() // self.elem_bytes if count is None else count
+        check(self._lib.bgn_mult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(),
+                                           self._stream()), "bgn_mult_batch_dev")
+
+    def make_l2_dev(self, a, out, count: Optional[int] = None) -> None:
+        count = a.numel() // self.elem_bytes if count is None else count
+        check(self._lib.bgn_make_l2_batch_dev(self._h, count, a.data_ptr(), out.data_ptr(), self._stream()),
+              "bgn_make_l2_batch_dev")
+
+    def encrypt_dev(self, x, x_len: int, r, r_len: int, out, count: int) -> None:
+        check(self._lib.bgn_encrypt_batch_dev(self._h, count, x.data_ptr(), x_len, r.data_ptr() if r is not None else None,
+                                              r_len, out.data_ptr(), self._stream()), "bgn_encrypt_batch_dev")
+
+    def add_dev(self, level: int, a, b, out, count: Optional[int] = None) -> None:
+        count = a.numel() // self.elem_bytes if count is None else count
+        check(self._lib.bgn_add_batch_dev(self._h, count, level, a.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(),
+                                          self._stream()), "bgn_add_batch_dev")
+
+    def decrypt_dev(self, level: int, ct, m, status, count: Optional[int] = None) -> None:
+        count = ct.numel() // self.elem_bytes if count is None else count
+        check(self._lib.bgn_decrypt_batch_dev(self._h, count, level, ct.data_ptr(), m.data_ptr(), status.data_ptr(),
+                                              self._stream()), "bgn_decrypt_batch_dev")
+
+    def poly_mult_dev(self, npoly: int, d1: int, d2: int, a, b, out) -> None:
+        check(self._lib.bgn_poly_mult_batch_dev(self._h, npoly, d1, d2, a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                                self._stream()), "bgn_poly_mult_batch_dev")
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.bgn_last_kernel_ms(self._h))
+
+    def last_kernel_name(self) -> str:
+        return self._lib.bgn_last_kernel_name(self._h).decode()
+
+
+# ---------------------------------------------------------------------------
+# Reference-shaped objects
+# ---------------------------------------------------------------------------
+@dataclass
+class Ciphertext:
+    """ciphertext.go:12-15.  C holds the element's PBC wire bytes (2L); the G1
+    identity is 2L zero bytes."""
+    C: bytes
+    L2: bool = False
+
+    def Copy(self) -> "Ciphertext":
+        return Ciphertext(self.C, self.L2)
+
+    def Bytes(self) -> bytes:
+        return self.C
+
+
+@dataclass
+class PolyCiphertext:
+    """ciphertext.go:26-31"""
+    Coefficients: List[Ciphertext]
+    Degree: int
+    ScaleFactor: int
+    L2: bool
+
+
+class PublicKey:
+    """bgn.go:28-41 — hot-path methods only (keygen and plaintext encoding stay
+    on the CPU side of the boundary, north_star)."""
+
+    def __init__(self, p: int, n: int, l: int, P: bytes, Q: bytes, MsgSpace: int, Deterministic: bool = True,
+                 PolyBase: int = 3, device: int = 0):
+        self.N = int(n)
+        self.P, self.Q = bytes(P), bytes(Q)
+        self.MsgSpace = int(MsgSpace)
+        self.Deterministic = bool(Deterministic)
+        self.PolyBase = int(PolyBase)
+        self.engine = Engine(p, n, l, P, Q, Deterministic, device)
+        self._zero = bytes(self.engine.elem_bytes)
+
+    # -- helpers --
+    def _r(self, count: int = 1):
+        """Blinding randomness: None in deterministic mode (bgn.go:462,484)."""
+        if self.Deterministic:
+            return None
+        return [secrets.randbelow(self.N) for _ in range(count)]     # newCryptoRandom, bgn.go:567-574
+
+    def _lvl(self, ct: Ciphertext) -> int:
+        return 2 if ct.L2 else 1
+
+    # -- encryption: bgn.go:325-353 --
+    def EncryptBatch(self, xs: Sequence[int], rs: Optional[Sequence[int]] = None) -> List[Ciphertext]:
+        # negative plaintexts: defined as P^(x mod n) (the reference hands a negative
+        # exponent to PBC, cmd/main.go:81, whose result is not defined in-tree)
+        xs = [int(x) % self.N if int(x) < 0 else int(x) for x in xs]
+        out = self.engine.encrypt(xs, rs)
+        return [Ciphertext(bytes(row), False) for row in out]
+
+    def EncryptWithRandomness(self, x: int, r: int) -> Ciphertext:
+        return self.EncryptBatch([x], [r])[0]
+
+    def Encrypt(self, x: int) -> Ciphertext:
+        return self.EncryptWithRandomness(x, secrets.randbelow(self.N))      # bgn.go:334-337
+
+    def EncryptDeterministic(self, x: int) -> Ciphertext:
+        return self.EncryptBatch([x], None)[0]                              # bgn.go:325-331
+
+    def encryptZero(self) -> Ciphertext:
+        return self.EncryptDeterministic(0)                                 # bgn.go:562-564
+
+    # -- level lift / Mult: bgn.go:294-321 --
+    def makeL2(self, ct: Ciphertext) -> Ciphertext:
+        return Ciphertext(bytes(self.engine.make_l2(ct.C)[0]), True)
+
+    def MultBatch(self, a: Sequence[Ciphertext], b: Sequence[Ciphertext]) -> List[Ciphertext]:
+        out = self.engine.mult(b"".join(c.C for c in a), b"".join(c.C for c in b), self._r(len(a)))
+        return [Ciphertext(bytes(row), True) for row in out]
+
+    def Mult(self, ct1: Ciphertext, ct2: Ciphertext) -> Ciphertext:
+        return self.MultBatch([ct1], [ct2])[0]
+
+    # -- Add / Sub / Neg: bgn.go:375-497 --
+    def _align(self, a: Ciphertext, b: Ciphertext):
+        if a.L2 and not b.L2:
+            b = self.makeL2(b)                                              # bgn.go:447-449
+        if not a.L2 and b.L2:
+            a = self.makeL2(a)                                              # bgn.go:451-453
+        return a, b
+
+    def Add(self, a: Ciphertext, b: Ciphertext) -> Ciphertext:
+        a, b = self._align(a, b)
+        return Ciphertext(bytes(self.engine.add(self._lvl(a), a.C, b.C, self._r())[0]), a.L2)
+
+    def Sub(self, a: Ciphertext, b: Ciphertext) -> Ciphertext:
+        a, b = self._align(a, b)
+        return Ciphertext(bytes(self.engine.sub(self._lvl(a), a.C, b.C, self._r())[0]), a.L2)
+
+    def Neg(self, c: Ciphertext) -> Ciphertext:
+        return self.Sub(self.encryptZero(), c)                              # bgn.go:436-438
+
+    def AddBatch(self, a: Sequence[Ciphertext], b: Sequence[Ciphertext]) -> List[Ciphertext]:
+        if not a:
+            return []
+        lvl = self._lvl(a[0])
+        if any(self._lvl(c) != lvl for c in list(a) + list(b)):
+            raise ValueError("AddBatch needs operands of one level")
+        out = self.engine.add(lvl, b"".join(c.C for c in a), b"".join(c.C for c in b), self._r(len(a)))
+        return [Ciphertext(bytes(row), lvl == 2) for row in out]
+
+    # -- MultConst: bgn.go:253-291 --
+    def MultConst(self, c: Ciphertext, constant: int) -> Ciphertext:
+        if constant < 0:
+            raise ValueError("negative constants are not defined by the reference's PowBig path")
+        return Ciphertext(bytes(self.engine.multconst(self._lvl(c), c.C, [constant], self._r())[0]), c.L2)
+
+    # -- decryption tables: bgn.go:195-201, gsbs.go:41-51 --
+    def SetupDecryption(self, sk: "SecretKey") -> None:
+        self.engine.set_secret(sk.Key)
+        self.engine.setup_decryption(self.MsgSpace)
+
+    # -- poly layer: poly.go --
+    def EncryptPoly(self, coeffs: Sequence[int], scale: int = 0) -> PolyCiphertext:
+        """poly.go:11-29 on already-encoded digits (plaintext.go stays CPU-side)."""
+        enc = []
+        for c in coeffs:
+            if c < 0:
+                enc.append(self.Sub(self.encryptZero(), self.Encrypt(-c)))     # poly.go:17-22
+            else:
+                enc.append(self.Encrypt(c))
+        return PolyCiphertext(enc, len(enc), scale, False)
+
+    def MultPoly(self, ct1: PolyCiphertext, ct2: PolyCiphertext) -> PolyCiphertext:
+        """poly.go:123-156 — one engine call for all d1*d2 pairings and the
+        segmented GT accumulation."""
+        d1, d2 = ct1.Degree, ct2.Degree
+        out = self.engine.poly_mult(1, d1, d2, b"".join(c.C for c in ct1.Coefficients),
+                                    b"".join(c.C for c in ct2.Coefficients))
+        coeffs = [Ciphertext(bytes(row), True) for row in out]
+        return PolyCiphertext(coeffs, d1 + d2, ct1.ScaleFactor + ct2.ScaleFactor, True)
+
+    def NegPoly(self, ct: PolyCiphertext) -> PolyCiphertext:
+        res = [self.Sub(self.encryptZero(), c) for c in ct.Coefficients]        # poly.go:45-55
+        return PolyCiphertext(res, ct.Degree, ct.ScaleFactor, ct.L2)
+
+    def AddPoly(self, p1: PolyCiphertext, p2: PolyCiphertext) -> PolyCiphertext:
+        """poly.go:171-207 for operands of equal scale factor (alignment via
+        MultConstPoly is host control flow over the same kernels)."""
+        if p1.ScaleFactor != p2.ScaleFactor:
+            raise NotImplementedError("scale alignment (poly.go:209-226) stays host-side; align before calling")
+        if p1.L2 != p2.L2:
+            raise NotImplementedError("mixed-level AddPoly: lift with MakePolyL2 first (poly.go:173-182)")
+        deg = max(p1.Degree, p2.Degree)
+        res = []
+        for i in range(deg):
+            if i >= p2.Degree:
+                res.append(p1.Coefficients[i])
+            elif i >= p1.Degree:
+                res.append(p2.Coefficients[i])
+            else:
+                res.append(self.Add(p1.Coefficients[i], p2.Coefficients[i]))
+        return PolyCiphertext(res, deg, p1.ScaleFactor, p1.L2)
+
+    def EvalPoly(self, ct: PolyCiphertext) -> Ciphertext:
+        acc = self.EncryptDeterministic(0)                                   # poly.go:58-68
+        for c in reversed(ct.Coefficients):
+            acc = self.MultConst(acc, self.PolyBase)
+            acc = self.Add(acc, c)
+        return acc
+
+
+class SecretKey:
+    """bgn.go:58-62"""
+
+    def __init__(self, Key: int, R: int = 0, PolyBase: int = 3):
+        self.Key, self.R, self.PolyBase = int(Key), int(R), int(PolyBase)
+
+    def DecryptBatch(self, cts: Sequence[Ciphertext], pk: PublicKey):
+        """Returns (values, status) arrays; status 1 = reference's error."""
+        if not cts:
+            return np.zeros(0, np.int64), np.zeros(0, np.uint8)
+        lvl = 2 if cts[0].L2 else 1
+        if any((2 if c.L2 else 1) != lvl for c in cts):
+            raise ValueError("DecryptBatch needs ciphertexts of one level")
+        return pk.engine.decrypt(lvl, b"".join(c.C for c in cts))
+
+    def Decrypt(self, ct: Ciphertext, pk: PublicKey) -> int:
+        m, st = self.DecryptBatch([ct], pk)                                  # bgn.go:205-207
+        if st[0] != _lib.BGN_DL_OK:
+            raise DecryptError()
+        return int(m[0])
+
+    def DecryptFailSafe(self, ct: Ciphertext, pk: PublicKey) -> int:
+        m, st = self.DecryptBatch([ct], pk)                                  # bgn.go:210-216
+        return int(m[0]) if st[0] == _lib.BGN_DL_OK else 0
+
+    def DecryptPoly(self, ct: PolyCiphertext, pk: PublicKey) -> List[int]:
+        m, _ = self.DecryptBatch(ct.Coefficients, pk)                        # poly.go:32-42 ignores errors
+        return [int(v) for v in m]

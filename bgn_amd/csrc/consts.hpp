@@ -1,0 +1,31 @@
+// consts.hpp — plain-old-data definitions shared by host (engine.cpp) and
+// device code (fp28.hpp, pairing.hpp).  No device code here.
+#pragma once
+#include <stdint.h>
+
+namespace bgn {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+
+constexpr int LIMB_BITS = 28;
+constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1u;
+constexpr int FP_BLOCK = 256;        // threads per workgroup of every field kernel
+constexpr int KP_MAX = 32;           // K*p tables for K = 1..32
+
+constexpr int MAX_NAF = 2112;        // signed digits of n
+constexpr int MAX_EXP_LIMBS = 80;
+
+// Wave-uniform constants of one key's pairing (read through scalar loads).
+struct PairingConsts {
+  int naf_len;                 // number of signed digits, naf[naf_len-1] == 1
+  int pm2_bits;                // bit length of p-2
+  unsigned long long l;        // cofactor (p+1)/n
+  int l_bits;
+  int pad;
+  signed char naf[MAX_NAF];    // little-endian signed digits of n
+  u32 pm2[MAX_EXP_LIMBS];      // p-2 as 28-bit limbs (little-endian)
+};
+
+}  // namespace bgn

@@ -1,0 +1,332 @@
+// fp28.hpp — multi-precision Montgomery arithmetic over F_p for gfx950,
+// one field element per lane.
+//
+// Replaces what the reference reaches through pbc.Element on G1/GT
+// (Mul/Div/PowBig/Pair call sites listed in SURVEY.md section 8(b); e.g.
+// bgn.go:300, :344-350, :460, :482) -> libpbc montfp.c -> GMP mpn_* .
+//
+// Representation (chosen from the measured VALU issue rates in
+// profiles/ubench_valu_rates_r01.txt): radix 2^28, NL limbs in 32-bit lanes,
+// Montgomery form with R = 2^(28*NL).  v_mad_u64_u32 issues at the same rate
+// as v_addc_co_u32 on gfx950, so a full-radix (2^32) schoolbook with explicit
+// carry instructions costs 2 issue slots per limb product; with 28-bit limbs a
+// 64-bit accumulator absorbs 2*NL products of 56 bits (NL <= 64) and the inner
+// loops are pure v_mad_u64_u32 chains with no carry instructions at all.
+//
+// Storage tiers per lane (a 1024-bit key has NL = 38, 152 B per element):
+//   Fp   — 38 VGPRs: operands/results of the op in flight.  Only the 256
+//          architectural VGPRs are addressable by VALU instructions, and one
+//          Montgomery product keeps 76 (accumulators) + 38 (multiplicand)
+//          live, so at most two further Fp values may be live across a mul.
+//   AFp  — 38 AGPRs: the accumulation-register half of the unified file,
+//          reached with v_accvgpr_read/write; holds the long-lived state
+//          (six elements per lane).
+//   LFp  — LDS, [row pair][thread] u64: four elements per lane at 256
+//          threads per workgroup (= all 160 KB).  An LFp can be consumed
+//          directly as the multiplier of fp_mul, whose rows are read with a
+//          run-time index (registers cannot be indexed dynamically).
+// Workgroups are 256 threads = one wave per SIMD; there is no cross-lane
+// traffic, hence no barriers.
+//
+// Invariants:
+//   * every stored limb is "tight": < 2^28;
+//   * a value V represents x*R mod p and satisfies V < B*p for a small,
+//     statically known bound B (written "<B" at each call site);
+//   * fp_mul needs B_a * B_b < 2^(28*NL - bits(p)) (>= 2^9 by the choice of
+//     NL in engine.cpp) and returns V < 2p;
+//   * fp_sub<K>(a, b) computes a + K*p - b and needs B_b <= K (K = 1..32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "consts.hpp"
+
+namespace bgn {
+
+template <int NL>
+struct FpParams {
+  u32 p[NL];            // modulus
+  u32 one[NL];          // R mod p           (Montgomery 1)
+  u32 r2[NL];           // R^2 mod p         (to-Montgomery factor)
+  u32 kp[KP_MAX][NL];   // kp[K-1] = K*p, tight limbs
+  u32 pinv;             // -p^{-1} mod 2^28
+  u32 pad[3];
+};
+
+template <int NL>
+struct Fp {
+  u32 v[NL];
+};
+
+template <int NL>
+struct AFp {
+  u32 a[NL];            // every element is only ever touched through "a" asm operands
+};
+
+template <int NL>
+struct LFp {
+  static constexpr int NR = (NL + 1) / 2;
+  u64 rows[NR][FP_BLOCK];
+};
+
+// ---- tier moves -----------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ void a_load(Fp<NL>& r, const AFp<NL>& s) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(r.v[j]) : "a"(s.a[j]));
+}
+
+template <int NL>
+__device__ __forceinline__ void a_store(AFp<NL>& s, const Fp<NL>& r) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) asm("v_accvgpr_write_b32 %0, %1" : "=a"(s.a[j]) : "v"(r.v[j]));
+}
+
+template <int NL>
+__device__ __forceinline__ void l_store(LFp<NL>* s, const Fp<NL>& r) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NL / 2; ++k) s->rows[k][tid] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
+  if (NL & 1) s->rows[NL / 2][tid] = r.v[NL - 1];
+}
+
+template <int NL>
+__device__ __forceinline__ void l_load(Fp<NL>& r, const LFp<NL>* s) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NL / 2; ++k) {
+    const u64 x = s->rows[k][tid];
+    r.v[2 * k] = (u32)x;
+    r.v[2 * k + 1] = (u32)(x >> 32);
+  }
+  if (NL & 1) r.v[NL - 1] = (u32)s->rows[NL / 2][tid];
+}
+
+// Limb-major structure-of-arrays storage in HBM: limb j of element e lives at
+// base[j * stride + e]; consecutive lanes touch consecutive dwords.
+template <int NL>
+__device__ __forceinline__ void g_load(Fp<NL>& r, const u32* __restrict__ base, size_t stride, size_t e) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) r.v[j] = base[(size_t)j * stride + e];
+}
+
+template <int NL>
+__device__ __forceinline__ void g_store(u32* __restrict__ base, size_t stride, size_t e, const Fp<NL>& a) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) base[(size_t)j * stride + e] = a.v[j];
+}
+
+template <int NL>
+__device__ __forceinline__ void fp_set(Fp<NL>& r, const u32* __restrict__ c) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) r.v[j] = c[j];
+}
+
+template <int NL>
+__device__ __forceinline__ void fp_zero(Fp<NL>& r) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) r.v[j] = 0;
+}
+
+// ---- linear ops (VGPR tier) -------------------------------------------------
+// r = a + b      (bound: B_a + B_b)
+template <int NL>
+__device__ __forceinline__ void fp_add(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b) {
+  u32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const u32 s = a.v[j] + b.v[j] + c;
+    r.v[j] = s & LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+}
+
+// r = 2a
+template <int NL>
+__device__ __forceinline__ void fp_dbl(Fp<NL>& r, const Fp<NL>& a) {
+  u32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const u32 s = (a.v[j] << 1) + c;
+    r.v[j] = s & LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+}
+
+// r = a + K*p - b, needs b < K*p   (bound: B_a + K)
+template <int K, int NL>
+__device__ __forceinline__ void fp_sub(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b,
+                                       const FpParams<NL>* __restrict__ P) {
+  static_assert(K >= 1 && K <= KP_MAX, "K*p table");
+  i32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const i32 s = (i32)(a.v[j] + P->kp[K - 1][j]) - (i32)b.v[j] + c;
+    r.v[j] = (u32)s & LIMB_MASK;
+    c = s >> LIMB_BITS;   // arithmetic shift: a borrow is -1
+  }
+}
+
+// r = K*p - a   (negation), needs a <= K*p
+template <int K, int NL>
+__device__ __forceinline__ void fp_neg(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  static_assert(K >= 1 && K <= KP_MAX, "K*p table");
+  i32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const i32 s = (i32)P->kp[K - 1][j] - (i32)a.v[j] + c;
+    r.v[j] = (u32)s & LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+}
+
+// Conditional subtraction of p: r = (a >= p) ? a - p : a.  a < 2p -> r < p.
+template <int NL>
+__device__ __forceinline__ void fp_cond_sub_p(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  Fp<NL> d;
+  i32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const i32 s = (i32)a.v[j] - (i32)P->p[j] + c;
+    d.v[j] = (u32)s & LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+  const bool ge = (c == 0);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) r.v[j] = ge ? d.v[j] : a.v[j];
+}
+
+template <int NL>
+__device__ __forceinline__ bool fp_is_zero_limbs(const Fp<NL>& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) o |= a.v[j];
+  return o == 0;
+}
+
+template <int NL>
+__device__ __forceinline__ bool fp_eq_limbs(const Fp<NL>& a, const Fp<NL>& b) {
+  u32 o = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) o |= a.v[j] ^ b.v[j];
+  return o == 0;
+}
+
+template <int NL>
+__device__ __forceinline__ void fp_select(Fp<NL>& r, bool c, const Fp<NL>& a, const Fp<NL>& b) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) r.v[j] = c ? a.v[j] : b.v[j];
+}
+
+// ---- Montgomery product -----------------------------------------------------
+// One row: t += ai*b; m = t0*pinv mod 2^28; t += m*p; t >>= 28.
+// Over a whole product each 64-bit accumulator collects < 2*NL products of
+// < 2^56 plus carries: < 2^63 for NL <= 63.
+template <int NL>
+__device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
+                                       const FpParams<NL>* __restrict__ P) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] += (u64)ai * b.v[j];
+  const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] += (u64)m * P->p[j];
+  const u64 c = t[0] >> LIMB_BITS;
+#pragma unroll
+  for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
+  t[NL - 1] = 0;
+  t[0] += c;
+}
+
+// r = a*b/R mod p, lazy (r < 2p).  The multiplier `a` is an LDS element whose
+// rows are streamed (next row pair prefetched while the current one is
+// multiplied); the multiplicand `b` sits in VGPRs.  r may alias b.
+template <int NL>
+__device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b,
+                                       const FpParams<NL>* __restrict__ P) {
+  const int tid = threadIdx.x;
+  constexpr int NP = NL / 2;
+  u64 t[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] = 0;
+  u64 aa = a->rows[0][tid];
+#pragma unroll 1
+  for (int k = 0; k < NP; ++k) {
+    const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
+    const u64 nx = a->rows[kn][tid];
+    fp_row<NL>(t, (u32)aa, b, P);
+    fp_row<NL>(t, (u32)(aa >> 32), b, P);
+    aa = nx;
+  }
+  if (NL & 1) fp_row<NL>(t, (u32)aa, b, P);
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const u64 s = t[j] + c;
+    r.v[j] = (u32)s & LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+}
+
+// r = a*b with both operands in VGPRs: stages a through the scratch LDS slot.
+template <int NL>
+__device__ __forceinline__ void fp_mulv(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b,
+                                        const FpParams<NL>* __restrict__ P, LFp<NL>* stage) {
+  l_store<NL>(stage, a);
+  fp_mul<NL>(r, stage, b, P);
+}
+
+// r = a/R mod p, canonical in [0, p): Montgomery-multiply by 1 (the lazy
+// product is <= p here), then one conditional subtraction.
+template <int NL>
+__device__ __forceinline__ void fp_from_mont(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P,
+                                             LFp<NL>* stage) {
+  Fp<NL> one;
+  fp_zero(one);
+  one.v[0] = 1;
+  l_store<NL>(stage, a);
+  Fp<NL> x;
+  fp_mul<NL>(x, stage, one, P);
+  fp_cond_sub_p<NL>(r, x, P);
+}
+
+// r = a*R mod p (a canonical or at least < 2^9 * p), result canonical in [0, p).
+template <int NL>
+__device__ __forceinline__ void fp_to_mont(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P,
+                                           LFp<NL>* stage) {
+  Fp<NL> r2;
+  fp_set(r2, P->r2);
+  l_store<NL>(stage, a);
+  Fp<NL> x;
+  fp_mul<NL>(x, stage, r2, P);
+  fp_cond_sub_p<NL>(r, x, P);
+}
+
+// Canonical Montgomery representative in [0, p) of a lazy value (for
+// equality tests and hash keys): x -> x/R -> (x/R)*R.
+template <int NL>
+__device__ __forceinline__ void fp_canon(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P,
+                                         LFp<NL>* stage) {
+  Fp<NL> x;
+  fp_from_mont<NL>(x, a, P, stage);
+  fp_to_mont<NL>(r, x, P, stage);
+}
+
+// a^e for a wave-uniform exponent given as 28-bit limbs (little-endian),
+// MSB-first square-and-multiply; control flow is uniform.  `a_rows` holds a in
+// an LDS slot for the whole loop.  a < 4; result < 2.
+template <int NL>
+__device__ __forceinline__ void fp_pow_uniform(Fp<NL>& r, const LFp<NL>* a_rows, const u32* __restrict__ e_limbs,
+                                               int e_bits, const FpParams<NL>* __restrict__ P, LFp<NL>* stage) {
+  Fp<NL> acc;
+  fp_set(acc, P->one);
+#pragma unroll 1
+  for (int i = e_bits - 1; i >= 0; --i) {
+    l_store<NL>(stage, acc);
+    fp_mul<NL>(acc, stage, acc, P);
+    const u32 bit = (e_limbs[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u;
+    if (bit) fp_mul<NL>(acc, a_rows, acc, P);
+  }
+  r = acc;
+}
+
+}  // namespace bgn

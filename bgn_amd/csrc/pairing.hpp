@@ -1,0 +1,353 @@
+// pairing.hpp — Type-A1 reduced Tate pairing, one pairing per lane.
+//
+// Replaces `res.Pair(ct1.C, ct2.C)` (bgn.go:300; also :146,:198,:227,:306,:318)
+// which the reference executes inside libpbc (a1_param.c, not in tree):
+//     e(A, B) = f_{n,A}(phi(B)) ^ ((p^2-1)/n),   phi(x, y) = (-x, i*y),
+// on y^2 = x^3 + x over F_p, p = l*n - 1, F_p^2 = F_p[i]/(i^2+1).
+//
+// Formulation (all differences from PBC's lie in F_p^* and vanish under the
+// (p-1) factor of the final exponent, so the output is bit-identical):
+//   * Jacobian coordinates for the running point V, mixed addition with A;
+//   * denominator elimination (vertical lines evaluate into F_p);
+//   * line functions scaled by F_p factors (Z3*Z^2 resp. Z3);
+//   * signed-digit (NAF) recoding of n: n is fixed per key, recoded once on
+//     the host; a "-1" digit adds -A and multiplies by the line through V, -A;
+//   * the last addition step (V = -+A, vertical line) is skipped, as PBC does;
+//   * final exponent split as f^(p-1) = conj(f)/f, then ^l  ((p+1)/n = l).
+//
+// The steps are written as explicit programs over storage slots (see
+// fp28.hpp): long-lived state in six AGPR slots, four LDS slots (S0 is the
+// multiplier stage), and at most two spare VGPR elements across any product.
+//
+// Bounds: "<k" means value < k*p.  Every product has bound-product <= 400 < 2^9.
+#pragma once
+#include "fp28.hpp"
+
+namespace bgn {
+
+// Read-only per-lane operands, limb-major SoA in HBM (canonical Montgomery, <1).
+struct PairOperands {
+  const u32* ax;  // first argument A = (ax, ay): the Miller-loop base point
+  const u32* ay;
+  size_t sa;      // limb stride of A's arrays
+  size_t ea;      // element index of this lane in A's arrays
+  const u32* bx;  // second argument B: evaluated through the distortion map
+  const u32* by;
+  size_t sb;      // limb stride of B's arrays (1 with eb = 0 broadcasts one point)
+  size_t eb;
+};
+
+// Running state of the Miller loop, in AGPR slots.
+template <int NL>
+struct Miller {
+  AFp<NL> X, Y, Z;   // V in Jacobian coordinates.  X,Y <18 ; Z <4
+  AFp<NL> F0, F1;    // f = F0 + i*F1.  F0 <4, F1 <6
+  AFp<NL> T;         // scratch slot
+};
+
+// f <- f^2 * l_{V,V}(phi(B)),  V <- 2V
+template <int NL>
+__device__ __forceinline__ void miller_double(Miller<NL>& S, LFp<NL>* L, const PairOperands& op,
+                                              const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  LFp<NL>* L2 = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  a_load(r, S.Z);
+  fp_mulv(r, r, r, P, S0);                 // ZZ <2            (Z <4: 16)
+  l_store(L1, r);                          // L1 = ZZ
+  fp_mul(w, L1, r, P);                     // w = ZZ^2 <2
+  a_load(r, S.X);
+  fp_mulv(u, r, r, P, S0);                 // u = XX <2        (324)
+  fp_dbl(r, u);
+  fp_add(r, r, u);
+  fp_add(r, r, w);                         // M = 3XX + ZZ^2 <8   (curve a = 1)
+  a_store(S.T, r);                         // T = M
+  a_load(r, S.Y);
+  fp_mulv(u, r, r, P, S0);                 // u = YY <2
+  l_store(L2, u);                          // L2 = YY
+  a_load(r, S.X);
+  fp_mulv(r, r, u, P, S0);                 // X*YY <2           (36)
+  fp_dbl(r, r);
+  fp_dbl(r, r);                            // S = 4*X*YY <8
+  l_store(L3, r);                          // L3 = S
+  a_load(r, S.Y);
+  a_load(u, S.Z);
+  fp_mulv(r, r, u, P, S0);                 // Y*Z <2            (72)
+  fp_dbl(r, r);                            // Z3 = 2YZ <4
+  a_store(S.Z, r);
+  // line, scaled by Z3*ZZ: re = M*(ZZ*xB + X) - 2YY ; im = (Z3*ZZ)*yB
+  fp_mul(u, L1, r, P);                     // Z3*ZZ <2          (8)
+  g_load(r, op.by, op.sb, op.eb);
+  fp_mulv(r, u, r, P, S0);                 // r = cim <2
+  g_load(u, op.bx, op.sb, op.eb);
+  fp_mul(u, L1, u, P);                     // ZZ*xB <2
+  l_store(L1, r);                          // L1 = cim   (ZZ dead)
+  a_load(r, S.X);
+  fp_add(u, u, r);                         // t <20
+  a_load(r, S.T);
+  fp_mulv(u, u, r, P, S0);                 // M*t <2            (160)
+  l_load(r, L2);
+  fp_dbl(r, r);                            // 2YY <4
+  fp_sub<4>(u, u, r, P);                   // cre <6
+  a_store(S.Y, u);                         // Y slot = cre  (Y dead)
+  // X3 = M^2 - 2S
+  a_load(r, S.T);
+  fp_mulv(u, r, r, P, S0);                 // M^2 <2            (64)
+  l_load(r, L3);                           // S <8
+  fp_dbl(w, r);                            // 2S <16
+  fp_sub<16>(u, u, w, P);                  // X3 <18
+  a_store(S.X, u);
+  // Y3 = M*(S - X3) - 8*YY^2
+  fp_sub<18>(r, r, u, P);                  // S - X3 <26
+  a_load(u, S.T);
+  fp_mulv(r, r, u, P, S0);                 // <2                (208)
+  l_load(u, L2);
+  fp_mulv(u, u, u, P, S0);                 // YY^2 <2
+  fp_dbl(u, u);
+  fp_dbl(u, u);
+  fp_dbl(u, u);                            // <16
+  fp_sub<16>(r, r, u, P);                  // Y3 <18
+  l_store(L2, r);                          // L2 = Y3 (parked; Y slot holds cre)
+  // g = f^2 : g0 = (F0+F1)(F0-F1), g1 = 2*F0*F1
+  a_load(r, S.F0);                         // <4
+  a_load(u, S.F1);                         // <6
+  fp_add(w, r, u);                         // <10
+  l_store(S0, w);
+  fp_sub<6>(w, r, u, P);                   // <10
+  fp_mul(w, S0, w, P);                     // g0 <2             (100)
+  fp_mulv(r, r, u, P, S0);                 // F0*F1 <2          (24)
+  fp_dbl(r, r);                            // g1 <4
+  fp_add(u, w, r);                         // g0+g1 <6
+  l_store(L3, u);                          // L3 = g0+g1
+  // f = g * (cre + i*cim)  (Karatsuba)
+  {
+    Fp<NL> c0, c1;
+    a_load(c0, S.Y);                       // cre <6
+    l_load(c1, L1);                        // cim <2
+    fp_add(u, c0, c1);                     // <8
+    a_store(S.T, u);                       // T = cre+cim
+    fp_mulv(w, w, c0, P, S0);              // v0 = g0*cre <2    (12)
+    fp_mulv(r, r, c1, P, S0);              // v1 = g1*cim <2    (8)
+  }
+  a_load(u, S.T);
+  fp_mul(u, L3, u, P);                     // (g0+g1)(cre+cim) <2   (48)
+  {
+    Fp<NL> d;
+    fp_sub<2>(d, w, r, P);                 // F0 = v0 - v1 <4
+    a_store(S.F0, d);
+    fp_add(d, w, r);                       // <4
+    fp_sub<4>(u, u, d, P);                 // F1 <6
+    a_store(S.F1, u);
+  }
+  l_load(r, L2);
+  a_store(S.Y, r);                         // Y = Y3
+}
+
+// f <- f * l_{V,sA}(phi(B)),  V <- V + sA   (s = +1 or -1, wave-uniform)
+template <int NL>
+__device__ __forceinline__ void miller_add(Miller<NL>& S, LFp<NL>* L, const PairOperands& op, int sign,
+                                           const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  LFp<NL>* L2 = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  a_load(r, S.Z);                          // <4
+  fp_mulv(u, r, r, P, S0);                 // ZZ <2             (16)
+  l_store(L1, u);                          // L1 = ZZ
+  fp_mul(r, L1, r, P);                     // Z^3 <2            (8)
+  g_load(u, op.ay, op.sa, op.ea);       // yA <1
+  if (sign < 0) fp_neg<1>(u, u, P);        // ysA <=1
+  l_store(L2, u);                          // L2 = ysA
+  fp_mul(r, L2, r, P);                     // ysA*Z^3 <2
+  a_load(u, S.Y);                          // <18
+  fp_sub<18>(r, r, u, P);                  // rr <20
+  a_store(S.T, r);                         // T = rr
+  g_load(u, op.ax, op.sa, op.ea);       // xA <1
+  fp_mul(u, L1, u, P);                     // xA*ZZ <2
+  a_load(w, S.X);                          // <18
+  fp_sub<18>(u, u, w, P);                  // H <20
+  l_store(L1, u);                          // L1 = H  (ZZ dead)
+  a_load(r, S.Z);
+  fp_mul(r, L1, r, P);                     // Z3 = Z*H <2       (80)
+  a_store(S.Z, r);
+  fp_mul(w, L1, u, P);                     // HH <2             (400)
+  fp_mul(u, L1, w, P);                     // HHH <2            (40)
+  a_load(r, S.X);
+  fp_mulv(r, r, w, P, S0);                 // XHH <2            (36)
+  a_load(w, S.T);
+  fp_mulv(w, w, w, P, S0);                 // rr^2 <2           (400)
+  fp_sub<2>(w, w, u, P);                   // <4
+  {
+    Fp<NL> d;
+    fp_dbl(d, r);                          // 2*XHH <4
+    fp_sub<4>(w, w, d, P);                 // X3 <8
+  }
+  a_store(S.X, w);
+  fp_sub<8>(r, r, w, P);                   // XHH - X3 <10
+  a_load(w, S.T);
+  fp_mulv(r, r, w, P, S0);                 // rr*(XHH-X3) <2    (200)
+  a_load(w, S.Y);
+  fp_mulv(w, w, u, P, S0);                 // Y*HHH <2          (36)
+  fp_sub<2>(r, r, w, P);                   // Y3 <4
+  a_store(S.Y, r);
+  // line through V and sA at phi(B), scaled by Z3:
+  //   re = rr*(xB + xA) - Z3*ysA ; im = Z3*yB
+  g_load(u, op.bx, op.sb, op.eb);
+  g_load(w, op.ax, op.sa, op.ea);
+  fp_add(u, u, w);                         // <2
+  a_load(r, S.T);
+  fp_mulv(r, r, u, P, S0);                 // rr*(xB+xA) <2     (40)
+  a_load(u, S.Z);                          // Z3 <2
+  fp_mul(w, L2, u, P);                     // Z3*ysA <2
+  fp_sub<2>(r, r, w, P);                   // cre <4
+  g_load(w, op.by, op.sb, op.eb);
+  fp_mulv(w, w, u, P, S0);                 // cim <2
+  // f = f * (cre + i*cim)
+  fp_add(u, r, w);                         // cre+cim <6
+  l_store(L3, u);                          // L3 = cre+cim
+  a_load(u, S.F0);                         // <4
+  fp_mulv(r, u, r, P, S0);                 // v0 = F0*cre <2    (16)
+  {
+    Fp<NL> f1;
+    a_load(f1, S.F1);                      // <6
+    fp_add(u, u, f1);                      // F0+F1 <10
+    fp_mulv(w, f1, w, P, S0);              // v1 = F1*cim <2    (12)
+  }
+  fp_mul(u, L3, u, P);                     // (cre+cim)(F0+F1) <2   (60)
+  {
+    Fp<NL> d;
+    fp_sub<2>(d, r, w, P);                 // F0 <4
+    a_store(S.F0, d);
+    fp_add(d, r, w);                       // <4
+    fp_sub<4>(u, u, d, P);                 // F1 <6
+    a_store(S.F1, u);
+  }
+}
+
+// ---- F_p^2 on LDS-resident elements (used outside the Miller loop) -----------
+// An F_p^2 value in two LDS slots.
+template <int NL>
+struct LFp2 {
+  LFp<NL>* c0;
+  LFp<NL>* c1;
+};
+
+// (r0, r1) = a * b, a in LDS slots, b in VGPRs; inputs <6; r0 <4, r1 <6.
+// `sum` is a free LDS slot.  r0/r1 may alias b0/b1.
+template <int NL>
+__device__ __forceinline__ void fp2_mul_lv(Fp<NL>& r0, Fp<NL>& r1, const LFp2<NL>& a, const Fp<NL>& b0,
+                                           const Fp<NL>& b1, const FpParams<NL>* __restrict__ P, LFp<NL>* sum) {
+  Fp<NL> v0, v1, s;
+  {
+    Fp<NL> a0, a1;
+    l_load(a0, a.c0);
+    l_load(a1, a.c1);
+    fp_add(s, a0, a1);                     // <12
+    l_store(sum, s);
+  }
+  fp_add(s, b0, b1);                       // <12
+  fp_mul(v0, a.c0, b0, P);                 // <2
+  fp_mul(v1, a.c1, b1, P);                 // <2
+  fp_mul(s, sum, s, P);                    // <2   (144)
+  fp_sub<2>(r0, v0, v1, P);                // <4
+  fp_add(v0, v0, v1);                      // <4
+  fp_sub<4>(r1, s, v0, P);                 // <6
+}
+
+// (r0, r1) = (a0 + i a1)^2 ; inputs <6 ; r0 <2, r1 <4.
+template <int NL>
+__device__ __forceinline__ void fp2_sqr_v(Fp<NL>& r0, Fp<NL>& r1, const Fp<NL>& a0, const Fp<NL>& a1,
+                                          const FpParams<NL>* __restrict__ P, LFp<NL>* stage) {
+  Fp<NL> s, d;
+  fp_add(s, a0, a1);                       // <12
+  fp_sub<6>(d, a0, a1, P);                 // <12
+  l_store(stage, s);
+  fp_mul(s, stage, d, P);                  // <2   (144)
+  fp_mulv(d, a0, a1, P, stage);            // <2   (36)
+  r0 = s;
+  fp_dbl(r1, d);                           // <4
+}
+
+// g = f^((p-1)*l) : conj(f)/f = conj(f)^2 / N(f), then ^l.  f in (F0 <4, F1 <6).
+// Result in VGPRs, lazy (<4, <6).
+template <int NL>
+__device__ __forceinline__ void final_exp(Fp<NL>& g0, Fp<NL>& g1, Miller<NL>& S, LFp<NL>* L,
+                                          const PairingConsts* __restrict__ C,
+                                          const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  LFp<NL>* L2 = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  a_load(r, S.F0);
+  a_load(u, S.F1);
+  fp_mulv(w, r, u, P, S0);                 // F0*F1 <2          (24)
+  fp_dbl(w, w);                            // <4
+  fp_neg<4>(w, w, P);                      // im(conj(f)^2) = -2*F0*F1  <=4
+  a_store(S.T, w);
+  fp_mulv(r, r, r, P, S0);                 // F0^2 <2
+  fp_mulv(u, u, u, P, S0);                 // F1^2 <2
+  fp_add(w, r, u);                         // N = F0^2 + F1^2 <4
+  fp_sub<2>(r, r, u, P);                   // re(conj(f)^2) <4
+  a_store(S.X, r);
+  l_store(L1, w);                          // L1 = N
+  fp_pow_uniform<NL>(w, L1, C->pm2, C->pm2_bits, P, S0);   // 1/N <2
+  a_load(r, S.X);
+  fp_mulv(r, r, w, P, S0);                 // h0 <2             (8)
+  a_load(u, S.T);
+  fp_mulv(u, u, w, P, S0);                 // h1 <2             (8)
+  // g = h^l, l wave-uniform, square-and-multiply; h parked in L1/L2.
+  l_store(L1, r);
+  l_store(L2, u);
+  LFp2<NL> h{L1, L2};
+#pragma unroll 1
+  for (int i = C->l_bits - 2; i >= 0; --i) {
+    Fp<NL> s0, s1;
+    fp2_sqr_v(s0, s1, r, u, P, S0);        // <2, <4
+    if ((C->l >> i) & 1ull) {
+      fp2_mul_lv(r, u, h, s0, s1, P, L3);  // <4, <6
+    } else {
+      r = s0;
+      u = s1;
+    }
+  }
+  g0 = r;
+  g1 = u;
+}
+
+// Whole pairing for one lane.  A, B affine, canonical Montgomery form in HBM.
+// Result: canonical (non-Montgomery) re/im in [0, p).
+template <int NL>
+__device__ __forceinline__ void pairing_lane(Fp<NL>& out_re, Fp<NL>& out_im, LFp<NL>* L, const PairOperands& op,
+                                             const PairingConsts* __restrict__ C,
+                                             const FpParams<NL>* __restrict__ P) {
+  Miller<NL> S;
+  {
+    Fp<NL> r;
+    g_load(r, op.ax, op.sa, op.ea);
+    a_store(S.X, r);
+    g_load(r, op.ay, op.sa, op.ea);
+    a_store(S.Y, r);
+    fp_set(r, P->one);
+    a_store(S.Z, r);
+    a_store(S.F0, r);
+    a_store(S.T, r);
+    fp_zero(r);
+    a_store(S.F1, r);
+  }
+#pragma unroll 1
+  for (int i = C->naf_len - 2; i >= 0; --i) {
+    miller_double<NL>(S, L, op, P);
+    const int d = C->naf[i];
+    if (d != 0 && i != 0) miller_add<NL>(S, L, op, d, P);
+  }
+  Fp<NL> g0, g1;
+  final_exp<NL>(g0, g1, S, L, C, P);
+  fp_from_mont<NL>(out_im, g1, P, L);
+  fp_from_mont<NL>(out_re, g0, P, L);
+}
+
+}  // namespace bgn

@@ -1,0 +1,160 @@
+/* bgn_amd.h — C ABI of the MI355X batched BGN engine (libbgn_amd.so).
+ *
+ * This is the drop-in boundary for the reference's cgo -> PBC path.  Every
+ * entry point is the array-at-a-time form of what sachaservan/bgn does one
+ * pbc.Element at a time; the citation after each declaration is the reference
+ * interface it replaces (file:line under the reference tree).  INTEGRATION.md
+ * shows the cgo stub a maintainer would add on the Go side.
+ *
+ * Conventions
+ *   - Elements cross the ABI in PBC's wire format (Element.Bytes(),
+ *     ciphertext.go:79): fixed-length big-endian, L = ceil(bits(p)/8) bytes per
+ *     F_p value; a G1 point is x||y, a GT element is re||im; 2L bytes each,
+ *     arrays are densely packed (element i at offset i*2L).
+ *   - The identity of G1 (encryptZero(), bgn.go:562) has no PBC wire encoding.
+ *     Here it is 2L zero bytes, in both directions.  (0,0) is a 2-torsion point
+ *     of y^2 = x^3 + x and never a valid ciphertext, which lives in the
+ *     odd-order subgroup, so the sentinel is unambiguous.
+ *   - Scalars (plaintexts, randomness, constants) are unsigned big-endian
+ *     integers of a caller-chosen fixed byte length per call.
+ *   - Randomness is always an input (like EncryptWithRandomness, bgn.go:340);
+ *     the engine never draws random numbers.
+ *   - `level` is 1 for G1 ciphertexts (Ciphertext.L2 == false) and 2 for GT.
+ *   - Functions return 0 on success or a negative BGN_E_* code; no exception or
+ *     abort crosses the ABI.  bgn_last_error() returns a thread-local message.
+ *   - Host-pointer functions (no suffix) copy in/out and are synchronous.
+ *     `_dev` functions take device pointers plus a hipStream_t (as void*;
+ *     NULL = default stream), enqueue work and return without synchronising.
+ *   - The caller owns every buffer; the engine keeps no pointer after return
+ *     (cgo pointer rules).  A context is immutable after setup and may be used
+ *     from many threads; concurrent calls on one context serialise on its
+ *     internal workspace (the reference serialises on pk.mu, bgn.go:40).
+ *   - There is no CPU fallback: without a HIP device every compute call fails
+ *     with BGN_E_HIP.
+ */
+#ifndef BGN_AMD_H
+#define BGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGN_OK 0
+#define BGN_E_ARG (-1)      /* bad argument (null pointer, length, level)        */
+#define BGN_E_PARAM (-2)    /* unsupported or inconsistent pairing parameters     */
+#define BGN_E_HIP (-3)      /* HIP runtime failure / no device                    */
+#define BGN_E_STATE (-4)    /* missing secret key or decryption tables            */
+#define BGN_E_POINT (-5)    /* an input is not a valid encoding                   */
+#define BGN_E_NOMEM (-6)
+
+/* per-element status written by bgn_decrypt_batch */
+#define BGN_DL_OK 0
+#define BGN_DL_NOT_FOUND 1  /* "cannot find discrete log; out of bounds", gsbs.go:105 */
+
+typedef struct bgn_ctx bgn_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Create an engine context for one public key on HIP device `device`.
+ * p, n: big-endian bytes of the Type-A1 field prime and group order
+ * (pbc params "type a1 / p / n / l", bgn.go:93-94,583-593); l = (p+1)/n.
+ * P, Q: generators in wire format, 2L bytes each (PublicKey.P/Q, bgn.go:30-31).
+ * deterministic: PublicKey.Deterministic (bgn.go:37).
+ * Replaces pbc.NewPairing / NewPairingFromString (bgn.go:101,640). */
+int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8_t* n_be, size_t n_len,
+                   uint64_t l, const uint8_t* P_wire, const uint8_t* Q_wire, int deterministic, int device);
+void bgn_ctx_destroy(bgn_ctx* ctx);
+
+/* L = bytes per F_p value; an element is 2L bytes. */
+size_t bgn_fp_bytes(const bgn_ctx* ctx);
+/* Thread-local description of the last failure in this thread. */
+const char* bgn_last_error(void);
+/* Library version string. */
+const char* bgn_version(void);
+
+/* Install the secret key q1 (SecretKey.Key, bgn.go:59) for decryption. */
+int bgn_ctx_set_secret(bgn_ctx* ctx, const uint8_t* q1_be, size_t q1_len);
+
+/* Build the discrete-log tables for message space T on the GPU.
+ * Replaces SetupDecryption / ComputeDecryptionPreprocessing / PrecomputeTables
+ * (bgn.go:195-201, :142-149, gsbs.go:41-51).  Requires bgn_ctx_set_secret. */
+int bgn_ctx_setup_decryption(bgn_ctx* ctx, uint64_t msg_space);
+
+/* ---- batch operations, host buffers ---------------------------------------- */
+
+/* out[i] = P^x[i] * Q^r[i]; r == NULL gives EncryptDeterministic.
+ * x: count*x_len bytes, r: count*r_len bytes, out: count*2L bytes.
+ * Replaces EncryptWithRandomness / EncryptDeterministic (bgn.go:340-353, :325-331). */
+int bgn_encrypt_batch(bgn_ctx* ctx, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be,
+                      size_t r_len, uint8_t* out);
+
+/* out[i] = a[i] + b[i] (level 1: G1 point addition; level 2: F_p^2 product),
+ * followed by blinding with Q^r[i] resp. e(Q,Q)^r[i] when r != NULL.
+ * Replaces Add (bgn.go:442-497). */
+int bgn_add_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                  size_t r_len, uint8_t* out);
+/* Replaces Sub (bgn.go:375-433). */
+int bgn_sub_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                  size_t r_len, uint8_t* out);
+/* out[i] = -a[i].  Replaces Neg (bgn.go:436-438) in deterministic mode. */
+int bgn_neg_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, uint8_t* out);
+
+/* out[i] = e(a[i], b[i]) (* e(Q,Q)^r[i] when r != NULL); inputs level 1, output level 2.
+ * Replaces Mult (bgn.go:294-314). */
+int bgn_mult_batch(bgn_ctx* ctx, size_t count, const uint8_t* a, const uint8_t* b, const uint8_t* r_be, size_t r_len,
+                   uint8_t* out);
+/* out[i] = e(a[i], P).  Replaces makeL2 (bgn.go:316-321). */
+int bgn_make_l2_batch(bgn_ctx* ctx, size_t count, const uint8_t* a, uint8_t* out);
+
+/* out[i] = a[i]^k[i] (k: count*k_len bytes), blinded when r != NULL.
+ * Replaces MultConst (bgn.go:253-291). */
+int bgn_multconst_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t k_len,
+                        const uint8_t* r_be, size_t r_len, uint8_t* out);
+
+/* m[i] = Dec(ct[i]) with the reference's rules: identity -> 0 (bgn.go:359-363),
+ * BSGS over [1, B*B+B+2], B = ceil(sqrt(T)) (gsbs.go:54-106), negative retry
+ * (bgn.go:235-242).  status[i] = BGN_DL_OK or BGN_DL_NOT_FOUND (m[i] = 0 then,
+ * which is what DecryptFailSafe returns, bgn.go:210-216).
+ * Replaces Decrypt / DecryptFailSafe (bgn.go:205-250). */
+int bgn_decrypt_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status);
+
+/* MultPoly over `npoly` independent pairs of L1 coefficient vectors:
+ * a: npoly*d1 elements, b: npoly*d2 elements, out: npoly*(d1+d2) GT elements,
+ * out[q][i+k] = prod e(a[q][i], b[q][k]); slot d1+d2-1 is the GT identity.
+ * Replaces MultPoly (poly.go:123-156). */
+int bgn_poly_mult_batch(bgn_ctx* ctx, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                        uint8_t* out);
+
+/* ---- batch operations, device buffers (same semantics; asynchronous) -------- */
+int bgn_encrypt_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be,
+                          size_t r_len, uint8_t* out, void* stream);
+int bgn_add_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                      size_t r_len, uint8_t* out, void* stream);
+int bgn_sub_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                      size_t r_len, uint8_t* out, void* stream);
+int bgn_neg_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, uint8_t* out, void* stream);
+int bgn_mult_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                       size_t r_len, uint8_t* out, void* stream);
+int bgn_make_l2_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* a, uint8_t* out, void* stream);
+int bgn_multconst_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t k_len,
+                            const uint8_t* r_be, size_t r_len, uint8_t* out, void* stream);
+int bgn_decrypt_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status,
+                          void* stream);
+int bgn_poly_mult_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                            uint8_t* out, void* stream);
+
+/* ---- measurement hooks (used by bench.py; not part of the drop-in surface) --- */
+/* Milliseconds spent in the dominant kernel of the most recent *_dev call on
+ * this context, measured with HIP events on the stream it ran on; blocks until
+ * that kernel has finished.  Negative on error. */
+double bgn_last_kernel_ms(bgn_ctx* ctx);
+/* Name of that kernel (for matching against rocprofv3 --kernel-trace output). */
+const char* bgn_last_kernel_name(bgn_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGN_AMD_H */

@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bgn_amd.h
+declares; without a GPU compute calls fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_fixture
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "bgn_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bgn_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in bgn_amd.h but not exported"
+    assert set(names) == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
+    assert b"gfx950" in lib.bgn_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import bgn_amd
+    fx = load_fixture("toy64")
+    with pytest.raises(bgn_amd.BgnError) as ei:
+        bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]),
+                          bytes.fromhex(fx["Q"]), fx["msg_space"])
+    assert ei.value.code == -3   # BGN_E_HIP
+
+
+def test_bad_parameters_rejected_before_touching_the_gpu():
+    from bgn_amd import _lib
+    lib = _lib.load()
+    fx = load_fixture("toy64")
+    p = int(fx["p"], 16)
+    pb = (p + 2).to_bytes(fx["fp_bytes"], "big")          # p + 1 != l * n
+    nb = int(fx["n"], 16).to_bytes(8, "big")
+    h = ctypes.c_void_p()
+    rc = lib.bgn_ctx_create(ctypes.byref(h), pb, len(pb), nb, len(nb), fx["l"], bytes.fromhex(fx["P"]),
+                            bytes.fromhex(fx["Q"]), 1, 0)
+    assert rc == -2 and b"l * n" in lib.bgn_last_error()

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — EMult (Type-A1 Tate pairing) throughput on MI355X.
+
+Metric (BASELINE.json): EMult pairings/sec at 1024-bit params, batch = 2^20 per
+GPU.  One "step" = one pass of pk.Mult over a batch of 2^20 pairs of level-1
+ciphertexts: PBC wire bytes resident in HBM -> wire bytes resident in HBM
+(decode, Miller loop + final exponentiation, encode), then — when more than
+one GPU takes part — the RCCL all-gather of the result arrays named by the
+north star.  Batches shard by contiguous ranges, one process per GPU, no
+collective on the data path other than that gather (scaling: weak, 2^20 per GPU).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-log2 B]
+For N > 1 launch through torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# profiles/ubench_valu_rates_r01.txt: v_mad_u64_u32, 4 waves/SIMD: 454.75 G wave-instr/s
+VALU_MAD_PEAK = 454.75e9 * 64  # lane-MADs per second, whole chip
+
+
+def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0):
+    """The oracle timed on this box's host cores on a bounded sample of the same
+    workload: the first pairs of the very batch the GPU just processed.  Its
+    outputs are compared byte for byte with the GPU's.  Test-infrastructure code
+    used as the reported baseline and checker only; never on the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c
+        if oracle_c.available():
+            return oracle_c.bench_pairings(fx, a_host, b_host, gpu_out_host, seconds)
+    except ImportError:
+        pass
+    import bgn_ref as R
+    from conftest import oracle_key
+    opk, _ = oracle_key(fx)
+    EB = 2 * R.fp_len(opk.p)
+    npairs = len(a_host) // EB
+    n, ok, t0 = 0, True, time.time()
+    while time.time() - t0 < seconds and n < npairs:
+        A = R.elem_from_bytes(a_host[n * EB:(n + 1) * EB], opk.p)
+        B = R.elem_from_bytes(b_host[n * EB:(n + 1) * EB], opk.p)
+        ok &= R.elem_to_bytes(opk.e(A, B), opk.p) == gpu_out_host[n * EB:(n + 1) * EB]
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "pairings/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} pairs of the GPU batch, pure-Python big-int oracle (oracle/bgn_ref.py), "
+                      f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--key", default="k1024")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from conftest import load_fixture
+    import bgn_amd
+    import bgn_amd.synthetic
+    from bgn_amd.sharding import shard_range
+
+    fx = load_fixture(args.key)
+    pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]),
+                           bytes.fromhex(fx["Q"]), fx["msg_space"], True, fx["poly_base"], device=local_rank)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    per_gpu = 1 << args.batch_log2
+    total = per_gpu * world
+    lo, hi = shard_range(total, world, rank)           # contiguous slice of the global batch
+    count = hi - lo
+
+    # Synthetic level-1 ciphertexts, resident in HBM before the timed region.
+    a, b = bgn_amd.synthetic.l1_ciphertext_pairs(pk, fx, count, seed=1000 + rank, device=dev)
+    out = torch.empty(count * EB, dtype=torch.uint8, device=dev)
+    gathered = torch.empty(total * EB, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        eng.mult_dev(a, b, out, count)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    kernel_ms = []
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(eng.last_kernel_ms())          # HIP events on the kernel's own stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # prefix of this rank's batch for the CPU leg (not timed)
+    nchk = min(count, 4096)
+    a_h = a[: nchk * EB].cpu().numpy().tobytes()
+    b_h = b[: nchk * EB].cpu().numpy().tobytes()
+    o_h = out[: nchk * EB].cpu().numpy().tobytes()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total * args.steps / dt
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = 3 * EB                               # two G1 operands in, one GT element out
+        achieved = alg_bytes * count / (k_ms * 1e-3) / 1e9
+        mads = bgn_amd.synthetic.algorithmic_mads_per_pairing(fx)
+        line = {
+            "metric": "EMult pairings/sec at 1024-bit, batch=2^%d per GPU" % args.batch_log2,
+            "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (28-bit limbs, 64-bit accumulators)", "data": "synthetic",
+            "config": {"workload": "configs[2]: 1024-bit params, batch=2^%d EMult (Tate pairing G1xG1->GT, "
+                                   "Miller+final-exp) per MI355X" % args.batch_log2,
+                       "key": fx["name"], "fp_bits": int(fx["p"], 16).bit_length(), "limbs28": 38,
+                       "batch_per_gpu": per_gpu, "global_batch": total,
+                       "parallelism": "batch-sharded x%d + RCCL all-gather of results" % world if world > 1 else "single GPU",
+                       },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": eng.last_kernel_name(), "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_pairing": alg_bytes},
+            "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads,
+                              "achieved": mads * count / (k_ms * 1e-3), "peak": VALU_MAD_PEAK,
+                              "unit": "lane-MAD/s", "frac": mads * count / (k_ms * 1e-3) / VALU_MAD_PEAK},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+"""Synthetic workloads for bench.py and the scale tests (no oracle here)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def l1_ciphertext_pairs(pk, fx, count: int, seed: int, device):
+    """Two arrays of `count` level-1 ciphertexts (wire bytes, uint8 CUDA tensors).
+
+    Until the engine's Encrypt kernel is used here, operands are drawn
+    (seeded, with replacement) from the key fixture's pool of valid
+    ciphertexts.  The pairing kernel's control flow and instruction stream do
+    not depend on operand values, so throughput is unaffected by the draw."""
+    import torch
+    pool = [bytes.fromhex(e["ct"]) for e in fx["encrypt"] if int(e["ct"], 16) != 0]
+    pool_t = torch.from_numpy(np.frombuffer(b"".join(pool), dtype=np.uint8).reshape(len(pool), -1).copy()).to(device)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    ia = torch.randint(0, len(pool), (count,), generator=g).to(device)
+    ib = torch.randint(0, len(pool), (count,), generator=g).to(device)
+    a = pool_t[ia].reshape(-1).contiguous()
+    b = pool_t[ib].reshape(-1).contiguous()
+    return a, b
+
+
+def miller_schedule(n: int):
+    """(#doubling steps, #addition steps) of the NAF Miller loop in pairing.hpp."""
+    d = []
+    while n:
+        if n & 1:
+            z = 2 - (n & 3)
+            d.append(z)
+            n -= z
+        else:
+            d.append(0)
+        n >>= 1
+    dbl = len(d) - 1
+    add = sum(1 for i, x in enumerate(d[:-1]) if x and i != 0)
+    return dbl, add
+
+
+def algorithmic_mads_per_pairing(fx) -> int:
+    """32x32->64 multiply-adds one pairing needs in this formulation:
+    (#field products) * 2*NL^2 (schoolbook product + Montgomery reduction rows)."""
+    p, n, l = int(fx["p"], 16), int(fx["n"], 16), int(fx["l"])
+    nl = 38 if p.bit_length() > 600 else (19 if p.bit_length() > 300 else (10 if p.bit_length() > 100 else 3))
+    dbl, add = miller_schedule(n)
+    e = p - 2
+    inv = (e.bit_length()) + bin(e).count("1")          # square-and-multiply 1/N
+    lb = l.bit_length()
+    lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l
+    products = dbl * 18 + add * 17 + 5 + inv + lpow
+    return products * 2 * nl * nl

@@ -1,0 +1,750 @@
+/* bgn_oracle.c — CPU oracle B: plain-C restatement of the BGN hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library, as the checker / reported
+ * CPU baseline.  The product (bgn_amd/) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference's arithmetic lives in github.com/Nik-U/pbc
+ * v0.0.0-20181205041846-3e516ca0c5d6 -> libpbc 0.5.14 -> GMP, none of which is
+ * in /root/reference or in this container; the reference's tests hold no
+ * known-answer vectors.  This file restates the published Type-A1 algorithms
+ * (PBC a1_param.c / curve.c / fieldquadratic.c) and the scheme logic of
+ * bgn.go / gsbs.go / poly.go (file:line cited per function).  It is pinned
+ * against oracle/bgn_ref.py (an independent affine, full-divisor big-integer
+ * formulation) through tests/golden/.
+ *
+ * Formulation here (deliberately different from both the Python oracle and the
+ * HIP kernels): 64-bit limbs with unsigned __int128 CIOS Montgomery
+ * multiplication, homogeneous projective coordinates (X:Y:Z) in the Miller
+ * loop with PBC's loop structure (plain binary expansion of n, tangent first,
+ * last addition skipped), final exponentiation as conj(f)/f then ^l, scalar
+ * multiplication by binary double-and-add on projective points.
+ *
+ * Build: make -C oracle   (gcc -O2 -shared -fPIC; no external libraries)
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+#define MAXW 18
+
+typedef struct {
+  int W;              /* 64-bit limbs */
+  int L;              /* wire bytes per F_p value */
+  int nbits;          /* bit length of n */
+  u64 p[MAXW], n[MAXW], pm2[MAXW];
+  u64 pinv;           /* -p^{-1} mod 2^64 */
+  u64 one[MAXW];      /* R mod p */
+  u64 r2[MAXW];       /* R^2 mod p */
+  u64 l;
+  u64 Px[MAXW], Py[MAXW], Qx[MAXW], Qy[MAXW];   /* Montgomery form */
+  /* decryption state */
+  u64 sk[MAXW];
+  int sk_bits;
+  int have_sk;
+  /* BSGS tables (gsbs.go:12-13), open addressing on a 64-bit key */
+  u64 T, B;
+  u64 tabsize;        /* power of two */
+  u64* key1; u64* full1; int32_t* val1;   /* G1: key = x limb 0, full = (x,y) canonical Montgomery */
+  u64* key2; u64* full2; int32_t* val2;   /* GT */
+  u64 g1x[MAXW], g1y[MAXW];    /* gsk = P^sk           (bgn.go:222) */
+  u64 gt0[MAXW], gt1[MAXW];    /* e(P,P)^sk            (bgn.go:227-228) */
+} octx;
+
+/* ---------------- F_p ---------------- */
+static int cmp_w(const u64* a, const u64* b, int W) {
+  for (int i = W - 1; i >= 0; --i) {
+    if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  }
+  return 0;
+}
+static u64 add_w(u64* r, const u64* a, const u64* b, int W) {
+  u128 c = 0;
+  for (int i = 0; i < W; ++i) {
+    c += (u128)a[i] + b[i];
+    r[i] = (u64)c;
+    c >>= 64;
+  }
+  return (u64)c;
+}
+static u64 sub_w(u64* r, const u64* a, const u64* b, int W) {
+  u64 br = 0;
+  for (int i = 0; i < W; ++i) {
+    u128 d = (u128)a[i] - b[i] - br;
+    r[i] = (u64)d;
+    br = (u64)(d >> 64) & 1;
+  }
+  return br;
+}
+static int is_zero_w(const u64* a, int W) {
+  u64 o = 0;
+  for (int i = 0; i < W; ++i) o |= a[i];
+  return o == 0;
+}
+static void fp_add(const octx* c, u64* r, const u64* a, const u64* b) {
+  u64 t[MAXW];
+  u64 cy = add_w(t, a, b, c->W);
+  if (cy || cmp_w(t, c->p, c->W) >= 0) sub_w(t, t, c->p, c->W);
+  memcpy(r, t, 8 * c->W);
+}
+static void fp_sub(const octx* c, u64* r, const u64* a, const u64* b) {
+  u64 t[MAXW];
+  if (sub_w(t, a, b, c->W)) add_w(t, t, c->p, c->W);
+  memcpy(r, t, 8 * c->W);
+}
+static void fp_neg(const octx* c, u64* r, const u64* a) {
+  if (is_zero_w(a, c->W)) {
+    memset(r, 0, 8 * c->W);
+    return;
+  }
+  u64 t[MAXW];
+  sub_w(t, c->p, a, c->W);
+  memcpy(r, t, 8 * c->W);
+}
+/* CIOS Montgomery product, fully reduced output */
+static void fp_mul(const octx* c, u64* r, const u64* a, const u64* b) {
+  const int W = c->W;
+  u64 t[MAXW + 2];
+  memset(t, 0, sizeof t);
+  for (int i = 0; i < W; ++i) {
+    u128 cy = 0;
+    for (int j = 0; j < W; ++j) {
+      cy += (u128)a[j] * b[i] + t[j];
+      t[j] = (u64)cy;
+      cy >>= 64;
+    }
+    cy += t[W];
+    t[W] = (u64)cy;
+    t[W + 1] = (u64)(cy >> 64);
+    const u64 m = t[0] * c->pinv;
+    cy = ((u128)m * c->p[0] + t[0]) >> 64;
+    for (int j = 1; j < W; ++j) {
+      cy += (u128)m * c->p[j] + t[j];
+      t[j - 1] = (u64)cy;
+      cy >>= 64;
+    }
+    cy += t[W];
+    t[W - 1] = (u64)cy;
+    t[W] = t[W + 1] + (u64)(cy >> 64);
+  }
+  if (t[W] || cmp_w(t, c->p, W) >= 0) sub_w(t, t, c->p, W);
+  memcpy(r, t, 8 * W);
+}
+static void fp_pow(const octx* c, u64* r, const u64* a, const u64* e, int ebits) {
+  u64 acc[MAXW];
+  memcpy(acc, c->one, 8 * c->W);
+  for (int i = ebits - 1; i >= 0; --i) {
+    fp_mul(c, acc, acc, acc);
+    if ((e[i / 64] >> (i % 64)) & 1) fp_mul(c, acc, acc, a);
+  }
+  memcpy(r, acc, 8 * c->W);
+}
+static int bits_w(const u64* a, int W) {
+  for (int i = W - 1; i >= 0; --i) {
+    if (a[i]) return 64 * i + 64 - __builtin_clzll(a[i]);
+  }
+  return 0;
+}
+static void fp_inv(const octx* c, u64* r, const u64* a) { fp_pow(c, r, a, c->pm2, bits_w(c->pm2, c->W)); }
+
+static void from_be(u64* out, int W, const uint8_t* b, size_t len) {
+  memset(out, 0, 8 * W);
+  for (size_t i = 0; i < len; ++i) {
+    size_t le = len - 1 - i;
+    if (le / 8 < (size_t)W) out[le / 8] |= (u64)b[i] << (8 * (le % 8));
+  }
+}
+static void to_be(uint8_t* b, size_t len, const u64* in, int W) {
+  for (size_t i = 0; i < len; ++i) {
+    size_t le = len - 1 - i;
+    b[i] = (le / 8 < (size_t)W) ? (uint8_t)(in[le / 8] >> (8 * (le % 8))) : 0;
+  }
+}
+static void to_mont(const octx* c, u64* r, const u64* a) { fp_mul(c, r, a, c->r2); }
+static void from_mont(const octx* c, u64* r, const u64* a) {
+  u64 one[MAXW];
+  memset(one, 0, sizeof one);
+  one[0] = 1;
+  fp_mul(c, r, a, one);
+}
+
+/* ---------------- F_p^2 = F_p[i]/(i^2+1) ---------------- */
+typedef struct { u64 a[MAXW], b[MAXW]; } f2;
+static void f2_mul(const octx* c, f2* r, const f2* x, const f2* y) {
+  u64 t0[MAXW], t1[MAXW], t2[MAXW], t3[MAXW];
+  fp_mul(c, t0, x->a, y->a);
+  fp_mul(c, t1, x->b, y->b);
+  fp_mul(c, t2, x->a, y->b);
+  fp_mul(c, t3, x->b, y->a);
+  fp_sub(c, r->a, t0, t1);
+  fp_add(c, r->b, t2, t3);
+}
+static void f2_one(const octx* c, f2* r) {
+  memcpy(r->a, c->one, 8 * c->W);
+  memset(r->b, 0, 8 * c->W);
+}
+static int f2_is_one(const octx* c, const f2* x) { return cmp_w(x->a, c->one, c->W) == 0 && is_zero_w(x->b, c->W); }
+static void f2_conj(const octx* c, f2* r, const f2* x) {
+  memcpy(r->a, x->a, 8 * c->W);
+  fp_neg(c, r->b, x->b);
+}
+static void f2_inv(const octx* c, f2* r, const f2* x) {
+  u64 n0[MAXW], n1[MAXW];
+  fp_mul(c, n0, x->a, x->a);
+  fp_mul(c, n1, x->b, x->b);
+  fp_add(c, n0, n0, n1);
+  fp_inv(c, n0, n0);
+  f2 t;
+  fp_mul(c, t.a, x->a, n0);
+  fp_mul(c, t.b, x->b, n0);
+  fp_neg(c, t.b, t.b);
+  *r = t;
+}
+static void f2_pow(const octx* c, f2* r, const f2* x, const u64* e, int ebits) {
+  f2 acc;
+  f2_one(c, &acc);
+  for (int i = ebits - 1; i >= 0; --i) {
+    f2_mul(c, &acc, &acc, &acc);
+    if ((e[i / 64] >> (i % 64)) & 1) f2_mul(c, &acc, &acc, x);
+  }
+  *r = acc;
+}
+
+/* ---------------- E: y^2 = x^3 + x, projective (X:Y:Z), Z = 0 is O ---------------- */
+typedef struct { u64 X[MAXW], Y[MAXW], Z[MAXW]; } pt;
+typedef struct { u64 x[MAXW], y[MAXW]; int inf; } apt;   /* affine, Montgomery form */
+
+static void pt_set_inf(const octx* c, pt* r) {
+  memset(r, 0, sizeof *r);
+  memcpy(r->Y, c->one, 8 * c->W);
+}
+static void pt_from_affine(const octx* c, pt* r, const apt* a) {
+  if (a->inf) {
+    pt_set_inf(c, r);
+    return;
+  }
+  memcpy(r->X, a->x, 8 * c->W);
+  memcpy(r->Y, a->y, 8 * c->W);
+  memcpy(r->Z, c->one, 8 * c->W);
+}
+static void pt_to_affine(const octx* c, apt* r, const pt* a) {
+  if (is_zero_w(a->Z, c->W)) {
+    memset(r, 0, sizeof *r);
+    r->inf = 1;
+    return;
+  }
+  u64 zi[MAXW];
+  fp_inv(c, zi, a->Z);
+  fp_mul(c, r->x, a->X, zi);
+  fp_mul(c, r->y, a->Y, zi);
+  r->inf = 0;
+}
+/* doubling: W = 3X^2 + Z^2 (a = 1), S = YZ, B = XYS, H = W^2 - 8B */
+static void pt_dbl(const octx* c, pt* r, const pt* a) {
+  if (is_zero_w(a->Z, c->W) || is_zero_w(a->Y, c->W)) {
+    pt_set_inf(c, r);
+    return;
+  }
+  u64 Wv[MAXW], S[MAXW], Bv[MAXW], H[MAXW], t[MAXW], u[MAXW];
+  fp_mul(c, t, a->X, a->X);
+  fp_add(c, Wv, t, t);
+  fp_add(c, Wv, Wv, t);
+  fp_mul(c, u, a->Z, a->Z);
+  fp_add(c, Wv, Wv, u);
+  fp_mul(c, S, a->Y, a->Z);
+  fp_mul(c, t, a->X, a->Y);
+  fp_mul(c, Bv, t, S);
+  fp_mul(c, H, Wv, Wv);
+  fp_add(c, t, Bv, Bv);
+  fp_add(c, t, t, t);
+  fp_add(c, u, t, t);          /* 8B */
+  fp_sub(c, H, H, u);
+  pt o;
+  fp_mul(c, o.X, H, S);
+  fp_add(c, o.X, o.X, o.X);    /* X' = 2HS */
+  fp_sub(c, t, t, H);          /* 4B - H */
+  fp_mul(c, t, Wv, t);
+  fp_mul(c, u, a->Y, S);
+  fp_mul(c, u, u, u);          /* Y^2 S^2 */
+  fp_add(c, u, u, u);
+  fp_add(c, u, u, u);
+  fp_add(c, u, u, u);          /* 8 Y^2 S^2 */
+  fp_sub(c, o.Y, t, u);
+  fp_mul(c, t, S, S);
+  fp_mul(c, t, t, S);
+  fp_add(c, t, t, t);
+  fp_add(c, t, t, t);
+  fp_add(c, o.Z, t, t);        /* 8 S^3 */
+  *r = o;
+}
+/* general addition of a projective point and an affine point */
+static void pt_add_affine(const octx* c, pt* r, const pt* a, const apt* b) {
+  if (b->inf) {
+    *r = *a;
+    return;
+  }
+  if (is_zero_w(a->Z, c->W)) {
+    pt_from_affine(c, r, b);
+    return;
+  }
+  u64 u[MAXW], v[MAXW], vv[MAXW], vvv[MAXW], A[MAXW], t[MAXW], R2[MAXW];
+  fp_mul(c, u, b->y, a->Z);
+  fp_sub(c, u, u, a->Y);       /* u = y2 Z - Y */
+  fp_mul(c, v, b->x, a->Z);
+  fp_sub(c, v, v, a->X);       /* v = x2 Z - X */
+  if (is_zero_w(v, c->W)) {
+    if (is_zero_w(u, c->W)) {
+      pt_dbl(c, r, a);
+    } else {
+      pt_set_inf(c, r);
+    }
+    return;
+  }
+  fp_mul(c, vv, v, v);
+  fp_mul(c, vvv, vv, v);
+  fp_mul(c, R2, vv, a->X);     /* v^2 X */
+  fp_mul(c, A, u, u);
+  fp_mul(c, A, A, a->Z);
+  fp_sub(c, A, A, vvv);
+  fp_sub(c, A, A, R2);
+  fp_sub(c, A, A, R2);         /* A = u^2 Z - v^3 - 2 v^2 X */
+  pt o;
+  fp_mul(c, o.X, v, A);
+  fp_sub(c, t, R2, A);
+  fp_mul(c, t, u, t);
+  fp_mul(c, A, vvv, a->Y);
+  fp_sub(c, o.Y, t, A);
+  fp_mul(c, o.Z, vvv, a->Z);
+  *r = o;
+}
+static void apt_neg(const octx* c, apt* r, const apt* a) {
+  *r = *a;
+  if (!a->inf) fp_neg(c, r->y, a->y);
+}
+/* P^k (PBC multiplicative notation; Element.PowBig on G1), k arbitrary non-negative */
+static void apt_mul(const octx* c, apt* r, const apt* a, const u64* k, int kw) {
+  pt acc;
+  pt_set_inf(c, &acc);
+  int kb = bits_w(k, kw);
+  for (int i = kb - 1; i >= 0; --i) {
+    pt_dbl(c, &acc, &acc);
+    if ((k[i / 64] >> (i % 64)) & 1) pt_add_affine(c, &acc, &acc, a);
+  }
+  pt_to_affine(c, r, &acc);
+}
+static void apt_add(const octx* c, apt* r, const apt* a, const apt* b) {
+  pt t;
+  pt_from_affine(c, &t, a);
+  pt_add_affine(c, &t, &t, b);
+  pt_to_affine(c, r, &t);
+}
+
+/* ---------------- pairing ---------------- */
+/* e(A,B) = f_{n,A}(phi(B))^((p^2-1)/n), phi(x,y) = (-x, iy).  Loop structure of
+ * PBC's a1 pairing: m = bits(n)-2; for(;;){ tangent; if(!m) break; double;
+ * if(bit m) { line; add; } m--; f = f^2; }.  Identity in either slot -> 1
+ * (pairing_apply), reached from MultPoly padding (poly.go:134). */
+static void pairing(const octx* c, f2* out, const apt* A, const apt* B) {
+  if (A->inf || B->inf) {
+    f2_one(c, out);
+    return;
+  }
+  const int W = c->W;
+  pt V;
+  pt_from_affine(c, &V, A);
+  f2 f, ln;
+  f2_one(c, &f);
+  u64 t[MAXW], u[MAXW], Wv[MAXW], S[MAXW];
+  int m = c->nbits - 2;
+  for (;;) {
+    /* tangent at V: re = W (Z xB + X) - 2 S Y ; im = 2 S Z yB ;  W = 3X^2+Z^2, S = YZ */
+    fp_mul(c, t, V.X, V.X);
+    fp_add(c, Wv, t, t);
+    fp_add(c, Wv, Wv, t);
+    fp_mul(c, u, V.Z, V.Z);
+    fp_add(c, Wv, Wv, u);
+    fp_mul(c, S, V.Y, V.Z);
+    fp_mul(c, t, V.Z, B->x);
+    fp_add(c, t, t, V.X);
+    fp_mul(c, ln.a, Wv, t);
+    fp_mul(c, u, S, V.Y);
+    fp_add(c, u, u, u);
+    fp_sub(c, ln.a, ln.a, u);
+    fp_mul(c, u, S, V.Z);
+    fp_add(c, u, u, u);
+    fp_mul(c, ln.b, u, B->y);
+    f2_mul(c, &f, &f, &ln);
+    if (!m) break;
+    pt_dbl(c, &V, &V);
+    if ((c->n[m / 64] >> (m % 64)) & 1) {
+      /* line through V and A: re = u (xB + xA) - v yA ; im = v yB */
+      u64 uu[MAXW], vv[MAXW];
+      fp_mul(c, uu, A->y, V.Z);
+      fp_sub(c, uu, uu, V.Y);
+      fp_mul(c, vv, A->x, V.Z);
+      fp_sub(c, vv, vv, V.X);
+      fp_add(c, t, B->x, A->x);
+      fp_mul(c, ln.a, uu, t);
+      fp_mul(c, t, vv, A->y);
+      fp_sub(c, ln.a, ln.a, t);
+      fp_mul(c, ln.b, vv, B->y);
+      f2_mul(c, &f, &f, &ln);
+      pt_add_affine(c, &V, &V, A);
+    }
+    m--;
+    f2_mul(c, &f, &f, &f);
+  }
+  (void)W;
+  /* Tate exponentiation: f^(p-1) = conj(f)/f, then ^l  (phikonr = l) */
+  f2 fi, fc;
+  f2_inv(c, &fi, &f);
+  f2_conj(c, &fc, &f);
+  f2_mul(c, &f, &fc, &fi);
+  u64 le[1] = {c->l};
+  f2_pow(c, out, &f, le, 64 - __builtin_clzll(c->l));
+}
+
+/* ---------------- wire codec (PBC to_bytes / from_bytes) ---------------- */
+static void apt_from_wire(const octx* c, apt* r, const uint8_t* w) {
+  int allz = 1;
+  for (int i = 0; i < 2 * c->L; ++i)
+    if (w[i]) allz = 0;
+  memset(r, 0, sizeof *r);
+  if (allz) {
+    r->inf = 1;
+    return;
+  }
+  u64 t[MAXW];
+  from_be(t, c->W, w, c->L);
+  to_mont(c, r->x, t);
+  from_be(t, c->W, w + c->L, c->L);
+  to_mont(c, r->y, t);
+}
+static void apt_to_wire(const octx* c, uint8_t* w, const apt* a) {
+  if (a->inf) {
+    memset(w, 0, 2 * c->L);
+    return;
+  }
+  u64 t[MAXW];
+  from_mont(c, t, a->x);
+  to_be(w, c->L, t, c->W);
+  from_mont(c, t, a->y);
+  to_be(w + c->L, c->L, t, c->W);
+}
+static void f2_from_wire(const octx* c, f2* r, const uint8_t* w) {
+  u64 t[MAXW];
+  from_be(t, c->W, w, c->L);
+  to_mont(c, r->a, t);
+  from_be(t, c->W, w + c->L, c->L);
+  to_mont(c, r->b, t);
+}
+static void f2_to_wire(const octx* c, uint8_t* w, const f2* x) {
+  u64 t[MAXW];
+  from_mont(c, t, x->a);
+  to_be(w, c->L, t, c->W);
+  from_mont(c, t, x->b);
+  to_be(w + c->L, c->L, t, c->W);
+}
+
+/* ---------------- public API (ctypes) ---------------- */
+octx* orc_create(const uint8_t* p_be, size_t p_len, const uint8_t* n_be, size_t n_len, u64 l, const uint8_t* Pw,
+                 const uint8_t* Qw) {
+  octx* c = (octx*)calloc(1, sizeof *c);
+  if (!c) return 0;
+  u64 tmp[MAXW + 1];
+  from_be(tmp, MAXW, p_be, p_len);
+  int pb = bits_w(tmp, MAXW);
+  c->W = (pb + 63) / 64;
+  if (c->W > MAXW - 1) {
+    free(c);
+    return 0;
+  }
+  c->L = (pb + 7) / 8;
+  from_be(c->p, c->W, p_be, p_len);
+  from_be(c->n, c->W, n_be, n_len);
+  c->nbits = bits_w(c->n, c->W);
+  c->l = l;
+  u64 two[MAXW];
+  memset(two, 0, sizeof two);
+  two[0] = 2;
+  sub_w(c->pm2, c->p, two, c->W);
+  u64 inv = 1;
+  for (int i = 0; i < 7; ++i) inv *= 2 - c->p[0] * inv;
+  c->pinv = (u64)0 - inv;
+  /* R mod p, R^2 mod p by doubling */
+  u64 x[MAXW];
+  memset(x, 0, sizeof x);
+  x[0] = 1;
+  for (int i = 0; i < 128 * c->W; ++i) {
+    u64 cy = add_w(x, x, x, c->W);
+    if (cy || cmp_w(x, c->p, c->W) >= 0) sub_w(x, x, c->p, c->W);
+    if (i == 64 * c->W - 1) memcpy(c->one, x, 8 * c->W);
+  }
+  memcpy(c->r2, x, 8 * c->W);
+  apt P, Q;
+  apt_from_wire(c, &P, Pw);
+  apt_from_wire(c, &Q, Qw);
+  memcpy(c->Px, P.x, sizeof P.x);
+  memcpy(c->Py, P.y, sizeof P.y);
+  memcpy(c->Qx, Q.x, sizeof Q.x);
+  memcpy(c->Qy, Q.y, sizeof Q.y);
+  return c;
+}
+void orc_destroy(octx* c) {
+  if (!c) return;
+  free(c->key1); free(c->full1); free(c->val1);
+  free(c->key2); free(c->full2); free(c->val2);
+  free(c);
+}
+int orc_fp_bytes(const octx* c) { return c->L; }
+
+static void key_P(const octx* c, apt* P) { memset(P, 0, sizeof *P); memcpy(P->x, c->Px, sizeof P->x); memcpy(P->y, c->Py, sizeof P->y); }
+static void key_Q(const octx* c, apt* Q) { memset(Q, 0, sizeof *Q); memcpy(Q->x, c->Qx, sizeof Q->x); memcpy(Q->y, c->Qy, sizeof Q->y); }
+
+static void scalar_from_be(u64* k, int kw, const uint8_t* b, size_t len) { from_be(k, kw, b, len); }
+
+/* EncryptWithRandomness (bgn.go:340-353): C = P^x * Q^r ; r == NULL: EncryptDeterministic (bgn.go:325-331) */
+void orc_encrypt(const octx* c, size_t count, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, uint8_t* out) {
+  apt P, Q, G, H, C;
+  key_P(c, &P);
+  key_Q(c, &Q);
+  const int kw = 40;
+  u64 k[40];
+  for (size_t i = 0; i < count; ++i) {
+    scalar_from_be(k, kw, x + i * xlen, xlen);
+    apt_mul(c, &G, &P, k, kw);                      /* bgn.go:344 */
+    if (r) {
+      scalar_from_be(k, kw, r + i * rlen, rlen);
+      apt_mul(c, &H, &Q, k, kw);                    /* bgn.go:346 */
+      apt_add(c, &C, &G, &H);                       /* bgn.go:350 */
+    } else {
+      C = G;
+    }
+    apt_to_wire(c, out + i * 2 * c->L, &C);
+  }
+}
+/* Add / Sub, deterministic mode (bgn.go:442-497, :375-433); level 1: G1, level 2: GT */
+void orc_add(const octx* c, size_t count, int level, int subtract, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  const size_t E = 2 * (size_t)c->L;
+  for (size_t i = 0; i < count; ++i) {
+    if (level == 1) {
+      apt A, B, R;
+      apt_from_wire(c, &A, a + i * E);
+      apt_from_wire(c, &B, b + i * E);
+      if (subtract) apt_neg(c, &B, &B);             /* result.Div, bgn.go:419 */
+      apt_add(c, &R, &A, &B);                       /* result.Mul, bgn.go:482 */
+      apt_to_wire(c, out + i * E, &R);
+    } else {
+      f2 A, B, R;
+      f2_from_wire(c, &A, a + i * E);
+      f2_from_wire(c, &B, b + i * E);
+      if (subtract) f2_inv(c, &B, &B);              /* bgn.go:397 */
+      f2_mul(c, &R, &A, &B);                        /* bgn.go:460 */
+      f2_to_wire(c, out + i * E, &R);
+    }
+  }
+}
+/* Mult (bgn.go:294-314, deterministic) ; b == NULL: makeL2 = e(a, P) (bgn.go:316-321) */
+void orc_mult(const octx* c, size_t count, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  const size_t E = 2 * (size_t)c->L;
+  apt P;
+  key_P(c, &P);
+  for (size_t i = 0; i < count; ++i) {
+    apt A, B;
+    f2 g;
+    apt_from_wire(c, &A, a + i * E);
+    if (b) apt_from_wire(c, &B, b + i * E); else B = P;
+    pairing(c, &g, &A, &B);
+    f2_to_wire(c, out + i * E, &g);
+  }
+}
+/* MultConst (bgn.go:253-291, deterministic) */
+void orc_multconst(const octx* c, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t klen, uint8_t* out) {
+  const size_t E = 2 * (size_t)c->L;
+  u64 k[40];
+  for (size_t i = 0; i < count; ++i) {
+    scalar_from_be(k, 40, k_be + i * klen, klen);
+    if (level == 1) {
+      apt A, R;
+      apt_from_wire(c, &A, a + i * E);
+      apt_mul(c, &R, &A, k, 40);                    /* bgn.go:258 */
+      apt_to_wire(c, out + i * E, &R);
+    } else {
+      f2 A, R;
+      f2_from_wire(c, &A, a + i * E);
+      f2_pow(c, &R, &A, k, bits_w(k, 40));          /* bgn.go:277 */
+      f2_to_wire(c, out + i * E, &R);
+    }
+  }
+}
+
+/* ---- BSGS (gsbs.go) ---- */
+static u64 mix(u64 x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+static void tab_put(const octx* c, u64* key, u64* full, int32_t* val, const u64* e0, const u64* e1, int32_t v) {
+  const int W = c->W;
+  u64 h = mix(e0[0] ^ (e1[0] << 1)) & (c->tabsize - 1);
+  while (val[h] >= 0) h = (h + 1) & (c->tabsize - 1);
+  key[h] = e0[0];
+  memcpy(full + h * 2 * W, e0, 8 * W);
+  memcpy(full + h * 2 * W + W, e1, 8 * W);
+  val[h] = v;
+}
+static int32_t tab_get(const octx* c, const u64* key, const u64* full, const int32_t* val, const u64* e0, const u64* e1) {
+  const int W = c->W;
+  u64 h = mix(e0[0] ^ (e1[0] << 1)) & (c->tabsize - 1);
+  while (val[h] >= 0) {
+    if (key[h] == e0[0] && !memcmp(full + h * 2 * W, e0, 8 * W) && !memcmp(full + h * 2 * W + W, e1, 8 * W)) return val[h];
+    h = (h + 1) & (c->tabsize - 1);
+  }
+  return -1;
+}
+static u64 isqrt_ceil(u64 t) {
+  /* math.Ceil(math.Sqrt(float64(T))) (gsbs.go:44,60) */
+  double s = __builtin_sqrt((double)t);
+  u64 r = (u64)s;
+  if ((double)r < s) r++;
+  return r;
+}
+int orc_set_secret(octx* c, const uint8_t* q1, size_t len) {
+  from_be(c->sk, MAXW, q1, len);
+  c->sk_bits = bits_w(c->sk, MAXW);
+  c->have_sk = 1;
+  return 0;
+}
+/* SetupDecryption + PrecomputeTables (bgn.go:195-201, gsbs.go:17-51): gen^(j+1) -> j, j = 0..bound */
+int orc_setup_decryption(octx* c, u64 T) {
+  if (!c->have_sk) return -1;
+  const int W = c->W;
+  c->T = T;
+  c->B = isqrt_ceil(T);
+  const u64 bound = c->B + 1;                       /* gsbs.go:44 */
+  u64 ts = 1;
+  while (ts < 2 * (bound + 2)) ts <<= 1;
+  c->tabsize = ts;
+  free(c->key1); free(c->full1); free(c->val1); free(c->key2); free(c->full2); free(c->val2);
+  c->key1 = (u64*)malloc(8 * ts); c->full1 = (u64*)malloc(16 * W * ts); c->val1 = (int32_t*)malloc(4 * ts);
+  c->key2 = (u64*)malloc(8 * ts); c->full2 = (u64*)malloc(16 * W * ts); c->val2 = (int32_t*)malloc(4 * ts);
+  if (!c->key1 || !c->full1 || !c->val1 || !c->key2 || !c->full2 || !c->val2) return -2;
+  memset(c->val1, 0xff, 4 * ts);
+  memset(c->val2, 0xff, 4 * ts);
+  apt P, g1;
+  key_P(c, &P);
+  apt_mul(c, &g1, &P, c->sk, MAXW);                 /* genG1 = P^sk, bgn.go:196-197 */
+  memcpy(c->g1x, g1.x, sizeof g1.x);
+  memcpy(c->g1y, g1.y, sizeof g1.y);
+  f2 gt, e;
+  pairing(c, &e, &P, &P);                           /* bgn.go:198 */
+  f2_pow(c, &gt, &e, c->sk, c->sk_bits);            /* bgn.go:199 */
+  memcpy(c->gt0, gt.a, sizeof gt.a);
+  memcpy(c->gt1, gt.b, sizeof gt.b);
+  /* G1 table: projective running sum, affine via one inversion each (small tables only in tests) */
+  apt aux = g1;
+  for (u64 j = 0; j <= bound; ++j) {                /* gsbs.go:22-25 */
+    tab_put(c, c->key1, c->full1, c->val1, aux.x, aux.y, (int32_t)j);
+    apt_add(c, &aux, &aux, &g1);
+  }
+  f2 a2 = gt;
+  for (u64 j = 0; j <= bound; ++j) {                /* gsbs.go:33-36 */
+    tab_put(c, c->key2, c->full2, c->val2, a2.a, a2.b, (int32_t)j);
+    f2_mul(c, &a2, &a2, &gt);
+  }
+  return 0;
+}
+/* getDL (gsbs.go:54-106) ; returns 1 when found */
+static int get_dl(const octx* c, int level, const apt* csk1, const f2* csk2, int64_t* m) {
+  const u64 B = c->B;
+  u64 bk[2] = {B, 0};
+  if (level == 1) {
+    apt g1, gamma, aux = *csk1;
+    memset(&g1, 0, sizeof g1);
+    memcpy(g1.x, c->g1x, sizeof g1.x);
+    memcpy(g1.y, c->g1y, sizeof g1.y);
+    apt_mul(c, &gamma, &g1, bk, 2);                 /* gamma = gsk^bound, gsbs.go:71-72 */
+    apt_neg(c, &gamma, &gamma);
+    for (u64 i = 0; i <= B; ++i) {                  /* gsbs.go:77 */
+      if (!aux.inf) {
+        int32_t v = tab_get(c, c->key1, c->full1, c->val1, aux.x, aux.y);
+        if (v >= 0) {
+          *m = (int64_t)(i * B + (u64)v + 1);       /* gsbs.go:98 */
+          return 1;
+        }
+      }
+      apt_add(c, &aux, &aux, &gamma);               /* aux.Div(aux, gamma), gsbs.go:102 */
+    }
+    return 0;
+  }
+  f2 gt, gamma, aux = *csk2;
+  memcpy(gt.a, c->gt0, sizeof gt.a);
+  memcpy(gt.b, c->gt1, sizeof gt.b);
+  f2_pow(c, &gamma, &gt, bk, bits_w(bk, 2));
+  f2_inv(c, &gamma, &gamma);
+  for (u64 i = 0; i <= B; ++i) {
+    int32_t v = tab_get(c, c->key2, c->full2, c->val2, aux.a, aux.b);
+    if (v >= 0) {
+      *m = (int64_t)(i * B + (u64)v + 1);
+      return 1;
+    }
+    f2_mul(c, &aux, &aux, &gamma);
+  }
+  return 0;
+}
+/* decrypt (bgn.go:218-250) with recoverMessage (bgn.go:357-372): status 0 ok, 1 = error */
+int orc_decrypt(const octx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status) {
+  if (!c->have_sk || !c->tabsize) return -1;
+  const size_t E = 2 * (size_t)c->L;
+  for (size_t i = 0; i < count; ++i) {
+    m[i] = 0;
+    status[i] = 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {       /* second attempt: Neg(ct), bgn.go:235-242 */
+      int64_t v = 0;
+      int found;
+      if (level == 1) {
+        apt C, csk;
+        apt_from_wire(c, &C, ct + i * E);
+        if (attempt) apt_neg(c, &C, &C);
+        apt_mul(c, &csk, &C, c->sk, MAXW);                /* bgn.go:223 */
+        if (csk.inf) { found = 1; v = 0; }                /* bgn.go:359-363 */
+        else found = get_dl(c, 1, &csk, 0, &v);
+      } else {
+        f2 C, csk;
+        f2_from_wire(c, &C, ct + i * E);
+        if (attempt) f2_inv(c, &C, &C);
+        f2_pow(c, &csk, &C, c->sk, c->sk_bits);
+        if (f2_is_one(c, &csk)) { found = 1; v = 0; }
+        else found = get_dl(c, 2, 0, &csk, &v);
+      }
+      if (found) {
+        m[i] = attempt ? -v : v;
+        status[i] = 0;
+        break;
+      }
+    }
+  }
+  return 0;
+}
+/* MultPoly (poly.go:123-156): out[q][i+k] = prod e(a[q][i], b[q][k]), last slot = 1 */
+void orc_poly_mult(const octx* c, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  const size_t E = 2 * (size_t)c->L;
+  const size_t deg = d1 + d2;
+  f2* acc = (f2*)malloc(sizeof(f2) * deg);
+  for (size_t q = 0; q < npoly; ++q) {
+    for (size_t s = 0; s < deg; ++s) f2_one(c, &acc[s]);           /* makeL2(encryptZero()), poly.go:134 */
+    for (size_t i = 0; i < d1; ++i)
+      for (size_t k = 0; k < d2; ++k) {
+        apt A, B;
+        f2 g;
+        apt_from_wire(c, &A, a + (q * d1 + i) * E);
+        apt_from_wire(c, &B, b + (q * d2 + k) * E);
+        pairing(c, &g, &A, &B);                                    /* poly.go:146 */
+        f2_mul(c, &acc[i + k], &acc[i + k], &g);                   /* poly.go:148 */
+      }
+    for (size_t s = 0; s < deg; ++s) f2_to_wire(c, out + (q * deg + s) * E, &acc[s]);
+  }
+  free(acc);
+}

@@ -1,0 +1,164 @@
+"""ctypes wrapper of the C oracle (oracle/bgn_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — see the header of bgn_oracle.c.  Used by tests/ as
+the fast checker (sizes the pure-Python oracle cannot reach) and by bench.py's
+cpu_baseline leg as the reported CPU baseline ("kind": "port").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+import time
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_build", "libbgn_oracle.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(_PATH)
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        lib = C.CDLL(_PATH)
+        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        lib.orc_create.restype = vp
+        lib.orc_create.argtypes = [vp, sz, vp, sz, u64, vp, vp]
+        lib.orc_destroy.argtypes = [vp]
+        lib.orc_fp_bytes.argtypes = [vp]
+        lib.orc_encrypt.argtypes = [vp, sz, vp, sz, vp, sz, vp]
+        lib.orc_add.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp, vp]
+        lib.orc_mult.argtypes = [vp, sz, vp, vp, vp]
+        lib.orc_multconst.argtypes = [vp, sz, C.c_int, vp, vp, sz, vp]
+        lib.orc_set_secret.argtypes = [vp, vp, sz]
+        lib.orc_setup_decryption.argtypes = [vp, u64]
+        lib.orc_decrypt.argtypes = [vp, sz, C.c_int, vp, vp, vp]
+        lib.orc_poly_mult.argtypes = [vp, sz, sz, sz, vp, vp, vp]
+        _lib = lib
+    return _lib
+
+
+def _ib(v: int) -> bytes:
+    return int(v).to_bytes(max(1, (int(v).bit_length() + 7) // 8), "big")
+
+
+def _pack(vals, length=None) -> tuple:
+    vals = [int(v) for v in vals]
+    if length is None:
+        length = max(1, max(((v.bit_length() + 7) // 8 for v in vals), default=1))
+    return b"".join(v.to_bytes(length, "big") for v in vals), length
+
+
+class Oracle:
+    def __init__(self, p: int, n: int, l: int, P_wire: bytes, Q_wire: bytes):
+        self.lib = _load()
+        pb, nb = _ib(p), _ib(n)
+        self.h = self.lib.orc_create(pb, len(pb), nb, len(nb), l, bytes(P_wire), bytes(Q_wire))
+        if not self.h:
+            raise RuntimeError("orc_create failed")
+        self.L = self.lib.orc_fp_bytes(self.h)
+        self.E = 2 * self.L
+
+    @classmethod
+    def from_fixture(cls, fx) -> "Oracle":
+        return cls(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]))
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def encrypt(self, xs, rs=None) -> bytes:
+        xb, xl = _pack(xs)
+        out = C.create_string_buffer(len(xs) * self.E)
+        if rs is None:
+            self.lib.orc_encrypt(self.h, len(xs), xb, xl, None, 0, out)
+        else:
+            rb, rl = _pack(rs)
+            self.lib.orc_encrypt(self.h, len(xs), xb, xl, rb, rl, out)
+        return out.raw
+
+    def add(self, level: int, a: bytes, b: bytes, subtract: bool = False) -> bytes:
+        n = len(a) // self.E
+        out = C.create_string_buffer(n * self.E)
+        self.lib.orc_add(self.h, n, level, 1 if subtract else 0, bytes(a), bytes(b), out)
+        return out.raw
+
+    def mult(self, a: bytes, b: bytes = None) -> bytes:
+        n = len(a) // self.E
+        out = C.create_string_buffer(n * self.E)
+        self.lib.orc_mult(self.h, n, bytes(a), bytes(b) if b is not None else None, out)
+        return out.raw
+
+    def multconst(self, level: int, a: bytes, ks) -> bytes:
+        n = len(a) // self.E
+        kb, kl = _pack(ks)
+        out = C.create_string_buffer(n * self.E)
+        self.lib.orc_multconst(self.h, n, level, bytes(a), kb, kl, out)
+        return out.raw
+
+    def setup_decryption(self, q1: int, T: int) -> None:
+        qb = _ib(q1)
+        self.lib.orc_set_secret(self.h, qb, len(qb))
+        rc = self.lib.orc_setup_decryption(self.h, T)
+        if rc:
+            raise RuntimeError(f"orc_setup_decryption -> {rc}")
+
+    def decrypt(self, level: int, ct: bytes):
+        n = len(ct) // self.E
+        m = (C.c_int64 * n)()
+        st = (C.c_uint8 * n)()
+        rc = self.lib.orc_decrypt(self.h, n, level, bytes(ct), m, st)
+        if rc:
+            raise RuntimeError(f"orc_decrypt -> {rc}")
+        return list(m), list(st)
+
+    def poly_mult(self, npoly: int, d1: int, d2: int, a: bytes, b: bytes) -> bytes:
+        out = C.create_string_buffer(npoly * (d1 + d2) * self.E)
+        self.lib.orc_poly_mult(self.h, npoly, d1, d2, bytes(a), bytes(b), out)
+        return out.raw
+
+
+def bench_pairings(fx, a_host: bytes, b_host: bytes, gpu_out_host: bytes, seconds: float = 12.0) -> dict:
+    """Time orc_mult on the first pairs of the GPU's own batch, one worker thread
+    per host core over disjoint slices (ctypes releases the GIL), and compare
+    the outputs with the GPU's byte for byte."""
+    orc = Oracle.from_fixture(fx)
+    E = orc.E
+    npairs = len(a_host) // E
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 128))
+    # calibrate on one pairing, then size the sample for ~`seconds` of wall time
+    t0 = time.time()
+    first = orc.mult(a_host[:E], b_host[:E])
+    t1 = max(time.time() - t0, 1e-4)
+    per_thread = max(1, min(npairs // cores, int(seconds / t1)))
+    total = per_thread * cores
+    outs = [None] * cores
+
+    def work(i):
+        lo, hi = i * per_thread * E, (i + 1) * per_thread * E
+        outs[i] = Oracle.from_fixture(fx).mult(a_host[lo:hi], b_host[lo:hi])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    got = b"".join(outs)
+    ok = got == gpu_out_host[: total * E] and first == gpu_out_host[:E]
+    return {"value": total / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
+            "single_thread_pairings_per_s": 1.0 / t1,
+            "sample": f"first {total} pairs of the GPU batch, C restatement oracle/bgn_oracle.c "
+                      f"(64-bit limbs, unsigned __int128 CIOS Montgomery, projective Miller loop), "
+                      f"{cores} threads x {per_thread} pairings, {dt:.1f} s",
+            "matches_gpu_bit_exact": bool(ok)}

@@ -54,8 +54,8 @@ struct bgn_ctx {
 
   void* d_params = nullptr;            // FpParams<NL>
   PairingConsts* d_consts = nullptr;
-  uint32_t* d_keypts = nullptr;        // P.x, P.y, Q.x, Q.y : 4 * nl limbs, stride 1, Montgomery
-  uint8_t* d_keywire = nullptr;
+  uint32_t* d_keypts = nullptr;        // P.x, P.y, Q.x, Q.y, eQQ.re, eQQ.im, one, zero : 8 * nl limbs, stride 1, Montgomery
+  uint8_t* d_keywire = nullptr;        // P | Q | e(Q,Q) wire bytes
 
   // secret / decryption state
   bool have_secret = false;
@@ -73,6 +73,8 @@ struct bgn_ctx {
 
   SoA2 key_P() const { return SoA2{d_keypts, d_keypts + nl, nullptr, 1}; }
   SoA2 key_Q() const { return SoA2{d_keypts + 2 * nl, d_keypts + 3 * nl, nullptr, 1}; }
+  SoA2 key_eQQ() const { return SoA2{d_keypts + 4 * nl, d_keypts + 5 * nl, nullptr, 1}; }   // e(Q,Q), bgn.go:306
+  SoA2 gt_one() const { return SoA2{d_keypts + 6 * nl, d_keypts + 7 * nl, nullptr, 1}; }
 };
 
 namespace {
@@ -245,13 +247,21 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     HIP_BRK(hipMemcpy(c->d_consts, &pc, sizeof pc, hipMemcpyHostToDevice));
 
     // key points -> Montgomery SoA (stride 1)
-    HIP_BRK(hipMalloc((void**)&c->d_keywire, (size_t)4 * c->L));
+    HIP_BRK(hipMalloc((void**)&c->d_keywire, (size_t)6 * c->L));
     HIP_BRK(hipMemcpy(c->d_keywire, P_wire, (size_t)2 * c->L, hipMemcpyHostToDevice));
     HIP_BRK(hipMemcpy(c->d_keywire + 2 * c->L, Q_wire, (size_t)2 * c->L, hipMemcpyHostToDevice));
-    HIP_BRK(hipMalloc((void**)&c->d_keypts, (size_t)4 * c->nl * 4));
+    HIP_BRK(hipMalloc((void**)&c->d_keypts, (size_t)8 * c->nl * 4));
+    HIP_BRK(hipMemset(c->d_keypts, 0, (size_t)8 * c->nl * 4));
     kt->decode(nullptr, c->d_params, c->d_keywire, c->L, 1, SoA2{c->d_keypts, c->d_keypts + c->nl, nullptr, 1});
     kt->decode(nullptr, c->d_params, c->d_keywire + 2 * c->L, c->L, 1,
                SoA2{c->d_keypts + 2 * c->nl, c->d_keypts + 3 * c->nl, nullptr, 1});
+    // e(Q,Q) (blinding base of level-2 ops, bgn.go:306,469) and the GT identity
+    {
+      SoA2 o{c->d_keypts + 4 * c->nl, c->d_keypts + 5 * c->nl, nullptr, 1};
+      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0);
+      kt->to_mont(nullptr, c->d_params, o.c0, o.c1, 1, 1);
+      HIP_BRK(hipMemcpy(c->d_keypts + 6 * c->nl, img.data() + c->nl, (size_t)c->nl * 4, hipMemcpyHostToDevice));  // one
+    }
     HIP_BRK(hipGetLastError());
     HIP_BRK(hipDeviceSynchronize());
     HIP_BRK(hipEventCreate(&c->ev0));
@@ -284,8 +294,13 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
 
 // ---- Mult / makeL2 / MultPoly -------------------------------------------------------
 
+namespace {
+void blind_l2(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, size_t count);
+}
+
 static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
-                          size_t d1, size_t d2, uint8_t* out, hipStream_t s) {
+                          size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be = nullptr,
+                          size_t r_len = 0) {
   if (!count) return BGN_OK;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -295,12 +310,21 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
+  if (r_be) {
+    probe.soa(c->nl, so, false);
+    probe.soa(c->nl, so, false);
+  }
   int rc = ensure_arena(c, probe.off);
   if (rc) return rc;
   Carver cv(c->arena);
   SoA2 A = cv.soa(c->nl, sa, true);
   SoA2 B = nb ? cv.soa(c->nl, sb, true) : c->key_P();
   SoA2 O = cv.soa(c->nl, so, false);
+  SoA2 T1{}, T2{};
+  if (r_be) {
+    T1 = cv.soa(c->nl, so, false);
+    T2 = cv.soa(c->nl, so, false);
+  }
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
@@ -308,6 +332,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;
+  if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);      // res.Mul(res, e(Q,Q)^r), bgn.go:302-311
   kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
   HIP_TRY(hipGetLastError());
   return BGN_OK;
@@ -316,9 +341,8 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
 int bgn_mult_batch_dev(bgn_ctx* c, size_t count, const uint8_t* a, const uint8_t* b, const uint8_t* r_be, size_t r_len,
                        uint8_t* out, void* stream) {
   if (!c || (count && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
-  (void)r_len;
-  if (r_be) return fail(BGN_E_STATE, "blinded Mult: not implemented in this build");
-  return pairing_common(c, count, a, count, b, count, 0, 0, 0, out, (hipStream_t)stream);
+  if (r_be && !r_len) return fail(BGN_E_ARG, "r_len == 0");
+  return pairing_common(c, count, a, count, b, count, 0, 0, 0, out, (hipStream_t)stream, r_be, r_len);
 }
 
 int bgn_make_l2_batch_dev(bgn_ctx* c, size_t count, const uint8_t* a, uint8_t* out, void* stream) {
@@ -352,7 +376,13 @@ int bgn_mult_batch(bgn_ctx* c, size_t count, const uint8_t* a, const uint8_t* b,
   if ((rc = da.alloc(eb)) || (rc = db.alloc(eb)) || (rc = dout.alloc(eb))) return rc;
   HIP_TRY(hipMemcpy(da.p, a, eb, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(db.p, b, eb, hipMemcpyHostToDevice));
-  rc = bgn_mult_batch_dev(c, count, (const uint8_t*)da.p, (const uint8_t*)db.p, r_be, r_len, (uint8_t*)dout.p, nullptr);
+  DevBuf dr;
+  if (r_be) {
+    if ((rc = dr.alloc(count * r_len))) return rc;
+    HIP_TRY(hipMemcpy(dr.p, r_be, count * r_len, hipMemcpyHostToDevice));
+  }
+  rc = bgn_mult_batch_dev(c, count, (const uint8_t*)da.p, (const uint8_t*)db.p, (const uint8_t*)dr.p, r_len,
+                          (uint8_t*)dout.p, nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, dout.p, eb, hipMemcpyDeviceToHost));
@@ -375,21 +405,369 @@ int bgn_make_l2_batch(bgn_ctx* c, size_t count, const uint8_t* a, uint8_t* out) 
   return BGN_OK;
 }
 
+// ---- Add / Sub / Neg / MultConst / Encrypt ------------------------------------------------
+
+namespace {
+
+int run_for(size_t count) {
+  // elements per lane of the batched-inversion kernels: keep >= 65536 lanes busy, cap the run
+  size_t r = (count + 65535) / 65536;
+  if (r < 1) r = 1;
+  if (r > 64) r = 64;
+  return (int)r;
+}
+
+struct Ws {   // workspace planner: two passes (size, then carve)
+  bgn_ctx* c;
+  Carver cv;
+  explicit Ws(bgn_ctx* c_, uint8_t* base) : c(c_), cv(base) {}
+  SoA2 g1(size_t stride) { return cv.soa(c->nl, stride, true); }
+  SoA2 gt(size_t stride) { return cv.soa(c->nl, stride, false); }
+  uint32_t* fp(size_t stride) { return (uint32_t*)cv.take((size_t)c->nl * stride * 4); }
+};
+
+// out (plain, with inf) = A (+/-) B on G1, both canonical Montgomery
+void g1_add_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, uint32_t* prefix, size_t count, bool negate_b) {
+  G1AddArgs a;
+  a.ax = A.c0; a.ay = A.c1; a.ainf = A.inf; a.sa = A.stride;
+  a.bx = B.c0; a.by = B.c1; a.binf = B.inf; a.sb = B.stride;
+  a.ox = O.c0; a.oy = O.c1; a.oinf = O.inf; a.so = O.stride;
+  a.prefix = prefix; a.sp = O.stride;
+  a.count = count;
+  a.run = run_for(count);
+  a.negate_b = negate_b ? 1 : 0;
+  c->kt->g1_add(s, c->d_params, c->d_consts, a);
+}
+
+void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
+                   size_t count) {
+  G1MulArgs a;
+  a.bx = B.c0; a.by = B.c1; a.binf = B.inf; a.sb = B.stride;
+  a.k = k; a.kstride = kstride; a.klen = klen;
+  a.ox = O.c0; a.oy = O.c1; a.oinf = O.inf; a.so = O.stride;
+  a.count = count;
+  c->kt->g1_mul(s, c->d_params, c->d_consts, a);
+}
+
+void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b) {
+  GtMulArgs a;
+  a.a0 = A.c0; a.a1 = A.c1; a.sa = A.stride;
+  a.b0 = B.c0; a.b1 = B.c1; a.sb = B.stride;
+  a.o0 = O.c0; a.o1 = O.c1; a.so = O.stride;
+  a.count = count;
+  a.conj_b = conj_b ? 1 : 0;
+  c->kt->gt_mul(s, c->d_params, a);
+}
+
+void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
+                   size_t count) {
+  GtPowArgs a;
+  a.a0 = A.c0; a.a1 = A.c1; a.sa = A.stride;
+  a.k = k; a.kstride = kstride; a.klen = klen;
+  a.o0 = O.c0; a.o1 = O.c1; a.so = O.stride;
+  a.count = count;
+  c->kt->gt_pow(s, c->d_params, a);
+}
+
+// Blind a level-1 result R (plain) with Q^r (bgn.go:488-495): R <- R + Q^r.  T1/T2 scratch G1 arrays.
+void blind_l1(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, uint32_t* prefix,
+              size_t count) {
+  g1_mul_launch(c, s, c->key_Q(), r_be, r_len, r_len, T1, count);          // h1 = Q^r
+  c->kt->to_mont(s, c->d_params, T1.c0, T1.c1, T1.stride, count);
+  c->kt->to_mont(s, c->d_params, R.c0, R.c1, R.stride, count);
+  g1_add_launch(c, s, R, T1, T2, prefix, count, false);
+  // copy T2 -> R (device to device)
+  (void)hipMemcpyAsync(R.c0, T2.c0, (size_t)c->nl * R.stride * 4, hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpyAsync(R.c1, T2.c1, (size_t)c->nl * R.stride * 4, hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpyAsync(R.inf, T2.inf, R.stride, hipMemcpyDeviceToDevice, s);
+}
+
+// Blind a level-2 result R (plain) with e(Q,Q)^r (bgn.go:466-474): R <- R * e(Q,Q)^r.
+void blind_l2(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, size_t count) {
+  gt_pow_launch(c, s, c->key_eQQ(), r_be, r_len, r_len, T1, count);
+  c->kt->to_mont(s, c->d_params, T1.c0, T1.c1, T1.stride, count);
+  c->kt->to_mont(s, c->d_params, R.c0, R.c1, R.stride, count);
+  gt_mul_launch(c, s, R, T1, T2, count, false);
+  (void)hipMemcpyAsync(R.c0, T2.c0, (size_t)c->nl * R.stride * 4, hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpyAsync(R.c1, T2.c1, (size_t)c->nl * R.stride * 4, hipMemcpyDeviceToDevice, s);
+}
+
+int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be, size_t r_len,
+               uint8_t* out, hipStream_t s, bool subtract) {
+  if (!c || (count && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (r_be && !r_len) return fail(BGN_E_ARG, "r_len == 0");
+  if (!count) return BGN_OK;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t st = round_up(count, 64);
+  SoA2 A, B, O, T1, T2;
+  uint32_t* prefix = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    if (level == 1) {
+      A = w.g1(st); B = w.g1(st); O = w.g1(st); prefix = w.fp(st);
+      if (r_be) { T1 = w.g1(st); T2 = w.g1(st); }
+    } else {
+      A = w.gt(st); B = w.gt(st); O = w.gt(st);
+      if (r_be) { T1 = w.gt(st); T2 = w.gt(st); }
+    }
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  const KernelTable* kt = c->kt;
+  kt->decode(s, c->d_params, a, c->L, count, A);
+  kt->decode(s, c->d_params, b, c->L, count, B);
+  if (level == 1) {
+    g1_add_launch(c, s, A, B, O, prefix, count, subtract);
+    if (r_be) blind_l1(c, s, O, r_be, r_len, T1, T2, prefix, count);
+    kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
+  } else {
+    gt_mul_launch(c, s, A, B, O, count, subtract);
+    if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);
+    kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
+  }
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+}  // namespace
+
+int bgn_add_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                      size_t r_len, uint8_t* out, void* stream) {
+  return addsub_dev(c, count, level, a, b, r_be, r_len, out, (hipStream_t)stream, false);
+}
+int bgn_sub_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                      size_t r_len, uint8_t* out, void* stream) {
+  return addsub_dev(c, count, level, a, b, r_be, r_len, out, (hipStream_t)stream, true);
+}
+
+int bgn_neg_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, uint8_t* out, void* stream) {
+  if (!c || (count && (!a || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!count) return BGN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t st = round_up(count, 64);
+  SoA2 A, Z, O;
+  uint32_t* prefix = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    if (level == 1) { A = w.g1(st); Z = w.g1(st); O = w.g1(st); prefix = w.fp(st); }
+    else { A = w.gt(st); O = w.gt(st); }
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  const KernelTable* kt = c->kt;
+  kt->decode(s, c->d_params, a, c->L, count, A);
+  if (level == 1) {
+    // Neg(c) = Sub(encryptZero(), c), bgn.go:436-438: identity minus c
+    HIP_TRY(hipMemsetAsync(Z.c0, 0, (size_t)c->nl * st * 4, s));
+    HIP_TRY(hipMemsetAsync(Z.c1, 0, (size_t)c->nl * st * 4, s));
+    HIP_TRY(hipMemsetAsync(Z.inf, 1, st, s));
+    g1_add_launch(c, s, Z, A, O, prefix, count, true);
+    kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
+  } else {
+    gt_mul_launch(c, s, c->gt_one(), A, O, count, true);   // 1 * conj(a) = a^-1 on GT (Sub of the GT identity, bgn.go:397)
+    kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
+  }
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t k_len,
+                            const uint8_t* r_be, size_t r_len, uint8_t* out, void* stream) {
+  if (!c || (count && (!a || !k_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!k_len || (r_be && !r_len)) return fail(BGN_E_ARG, "zero scalar length");
+  if (!count) return BGN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t st = round_up(count, 64);
+  SoA2 A, O, T1, T2;
+  uint32_t* prefix = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    if (level == 1) {
+      A = w.g1(st); O = w.g1(st);
+      if (r_be) { T1 = w.g1(st); T2 = w.g1(st); prefix = w.fp(st); }
+    } else {
+      A = w.gt(st); O = w.gt(st);
+      if (r_be) { T1 = w.gt(st); T2 = w.gt(st); }
+    }
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  const KernelTable* kt = c->kt;
+  kt->decode(s, c->d_params, a, c->L, count, A);
+  if (level == 1) {
+    g1_mul_launch(c, s, A, k_be, k_len, k_len, O, count);                       // res.PowBig(c.C, constant), bgn.go:258
+    if (r_be) blind_l1(c, s, O, r_be, r_len, T1, T2, prefix, count);            // bgn.go:260-268
+    kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
+  } else {
+    gt_pow_launch(c, s, A, k_be, k_len, k_len, O, count);                       // bgn.go:277
+    if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);                    // bgn.go:279-287
+    kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
+  }
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be, size_t r_len,
+                          uint8_t* out, void* stream) {
+  if (!c || (count && (!x_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!x_len || (r_be && !r_len)) return fail(BGN_E_ARG, "zero scalar length");
+  if (!count) return BGN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t st = round_up(count, 64);
+  SoA2 G, H, O;
+  uint32_t* prefix = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    G = w.g1(st);
+    if (r_be) { H = w.g1(st); O = w.g1(st); prefix = w.fp(st); }
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  const KernelTable* kt = c->kt;
+  HIP_TRY(hipEventRecord(c->ev0, s));
+  g1_mul_launch(c, s, c->key_P(), x_be, x_len, x_len, G, count);                // G.PowBig(pk.P, x), bgn.go:344
+  if (r_be) {
+    g1_mul_launch(c, s, c->key_Q(), r_be, r_len, r_len, H, count);              // H.PowBig(pk.Q, r), bgn.go:346
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    kt->to_mont(s, c->d_params, G.c0, G.c1, G.stride, count);
+    kt->to_mont(s, c->d_params, H.c0, H.c1, H.stride, count);
+    g1_add_launch(c, s, G, H, O, prefix, count, false);                         // C.Mul(G, H), bgn.go:350
+    kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
+  } else {
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    kt->encode(s, G.inf, G.c0, G.c1, G.stride, c->L, count, out);
+  }
+  c->ev_valid = true;
+  c->last_kernel = "k_g1_mul";
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+// ---- host-buffer wrappers -------------------------------------------------------------------
+namespace {
+struct Staged {   // copies host arrays to the device and results back
+  std::vector<DevBuf> bufs;
+  int up(const void* host, size_t bytes, void** dev) {
+    bufs.emplace_back();
+    int rc = bufs.back().alloc(bytes);
+    if (rc) return rc;
+    *dev = bufs.back().p;
+    if (host && bytes) {
+      hipError_t e = hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(BGN_E_HIP, "hipMemcpy H2D: %s", hipGetErrorString(e));
+    }
+    return BGN_OK;
+  }
+  int down(void* host, const void* dev, size_t bytes) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(BGN_E_HIP, "hipMemcpy D2H: %s", hipGetErrorString(e));
+    return BGN_OK;
+  }
+};
+}  // namespace
+
+#define UP(host, bytes, devp)                                  \
+  {                                                            \
+    int rc_ = S.up(host, bytes, (void**)&(devp));              \
+    if (rc_) return rc_;                                       \
+  }
+
+int bgn_encrypt_batch(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be, size_t r_len,
+                      uint8_t* out) {
+  if (!c || (count && (!x_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  Staged S;
+  S.bufs.reserve(4);
+  uint8_t *dx = nullptr, *dr = nullptr, *dout = nullptr;
+  UP(x_be, count * x_len, dx);
+  if (r_be) UP(r_be, count * r_len, dr);
+  UP(nullptr, count * 2 * (size_t)c->L, dout);
+  int rc = bgn_encrypt_batch_dev(c, count, dx, x_len, dr, r_len, dout, nullptr);
+  if (rc) return rc;
+  return S.down(out, dout, count * 2 * (size_t)c->L);
+}
+
+static int addsub_host(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                       size_t r_len, uint8_t* out, bool subtract) {
+  if (!c || (count && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t eb = count * 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(4);
+  uint8_t *da = nullptr, *db = nullptr, *dr = nullptr, *dout = nullptr;
+  UP(a, eb, da);
+  UP(b, eb, db);
+  if (r_be) UP(r_be, count * r_len, dr);
+  UP(nullptr, eb, dout);
+  int rc = addsub_dev(c, count, level, da, db, dr, r_len, dout, nullptr, subtract);
+  if (rc) return rc;
+  return S.down(out, dout, eb);
+}
+int bgn_add_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                  size_t r_len, uint8_t* out) {
+  return addsub_host(c, count, level, a, b, r_be, r_len, out, false);
+}
+int bgn_sub_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                  size_t r_len, uint8_t* out) {
+  return addsub_host(c, count, level, a, b, r_be, r_len, out, true);
+}
+int bgn_neg_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, uint8_t* out) {
+  if (!c || (count && (!a || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t eb = count * 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(2);
+  uint8_t *da = nullptr, *dout = nullptr;
+  UP(a, eb, da);
+  UP(nullptr, eb, dout);
+  int rc = bgn_neg_batch_dev(c, count, level, da, dout, nullptr);
+  if (rc) return rc;
+  return S.down(out, dout, eb);
+}
+int bgn_multconst_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t k_len,
+                        const uint8_t* r_be, size_t r_len, uint8_t* out) {
+  if (!c || (count && (!a || !k_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t eb = count * 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(4);
+  uint8_t *da = nullptr, *dk = nullptr, *dr = nullptr, *dout = nullptr;
+  UP(a, eb, da);
+  UP(k_be, count * k_len, dk);
+  if (r_be) UP(r_be, count * r_len, dr);
+  UP(nullptr, eb, dout);
+  int rc = bgn_multconst_batch_dev(c, count, level, da, dk, k_len, dr, r_len, dout, nullptr);
+  if (rc) return rc;
+  return S.down(out, dout, eb);
+}
+
 // ---- not yet implemented entry points (filled in as the kernels land) ----------------
 #define NOT_YET(name) return fail(BGN_E_STATE, name ": not implemented in this build")
-
-int bgn_encrypt_batch(bgn_ctx*, size_t, const uint8_t*, size_t, const uint8_t*, size_t, uint8_t*) { NOT_YET("encrypt"); }
-int bgn_add_batch(bgn_ctx*, size_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*) { NOT_YET("add"); }
-int bgn_sub_batch(bgn_ctx*, size_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*) { NOT_YET("sub"); }
-int bgn_neg_batch(bgn_ctx*, size_t, int, const uint8_t*, uint8_t*) { NOT_YET("neg"); }
-int bgn_multconst_batch(bgn_ctx*, size_t, int, const uint8_t*, const uint8_t*, size_t, const uint8_t*, size_t, uint8_t*) { NOT_YET("multconst"); }
 int bgn_decrypt_batch(bgn_ctx*, size_t, int, const uint8_t*, int64_t*, uint8_t*) { NOT_YET("decrypt"); }
 int bgn_poly_mult_batch(bgn_ctx*, size_t, size_t, size_t, const uint8_t*, const uint8_t*, uint8_t*) { NOT_YET("poly_mult"); }
-int bgn_encrypt_batch_dev(bgn_ctx*, size_t, const uint8_t*, size_t, const uint8_t*, size_t, uint8_t*, void*) { NOT_YET("encrypt"); }
-int bgn_add_batch_dev(bgn_ctx*, size_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*, void*) { NOT_YET("add"); }
-int bgn_sub_batch_dev(bgn_ctx*, size_t, int, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*, void*) { NOT_YET("sub"); }
-int bgn_neg_batch_dev(bgn_ctx*, size_t, int, const uint8_t*, uint8_t*, void*) { NOT_YET("neg"); }
-int bgn_multconst_batch_dev(bgn_ctx*, size_t, int, const uint8_t*, const uint8_t*, size_t, const uint8_t*, size_t, uint8_t*, void*) { NOT_YET("multconst"); }
 int bgn_decrypt_batch_dev(bgn_ctx*, size_t, int, const uint8_t*, int64_t*, uint8_t*, void*) { NOT_YET("decrypt"); }
 int bgn_poly_mult_batch_dev(bgn_ctx*, size_t, size_t, size_t, const uint8_t*, const uint8_t*, uint8_t*, void*) { NOT_YET("poly_mult"); }
 

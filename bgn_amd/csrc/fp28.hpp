@@ -40,6 +40,7 @@
 #include <stdint.h>
 
 #include "consts.hpp"
+#include "agpr.hpp"
 
 namespace bgn {
 
@@ -73,13 +74,13 @@ struct LFp {
 template <int NL>
 __device__ __forceinline__ void a_load(Fp<NL>& r, const AFp<NL>& s) {
 #pragma unroll
-  for (int j = 0; j < NL; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(r.v[j]) : "a"(s.a[j]));
+  for (int j = 0; j < NL; ++j) agpr_read(r.v[j], s.a[j]);
 }
 
 template <int NL>
 __device__ __forceinline__ void a_store(AFp<NL>& s, const Fp<NL>& r) {
 #pragma unroll
-  for (int j = 0; j < NL; ++j) asm("v_accvgpr_write_b32 %0, %1" : "=a"(s.a[j]) : "v"(r.v[j]));
+  for (int j = 0; j < NL; ++j) agpr_write(s.a[j], r.v[j]);
 }
 
 template <int NL>

@@ -19,6 +19,40 @@ struct SoA2 {
   size_t stride;
 };
 
+// G1 affine addition with batched inversion (ops.hpp).
+struct G1AddArgs {
+  const uint32_t* ax; const uint32_t* ay; const uint8_t* ainf; size_t sa;   // canonical Montgomery
+  const uint32_t* bx; const uint32_t* by; const uint8_t* binf; size_t sb;   // sb == 1: one broadcast point
+  uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical out
+  uint32_t* prefix; size_t sp;                                              // workspace: one F_p per element
+  size_t count;
+  int run;                                                                  // elements per lane
+  int negate_b;                                                             // subtraction
+};
+
+// G1 scalar multiplication (ops.hpp).
+struct G1MulArgs {
+  const uint32_t* bx; const uint32_t* by; const uint8_t* binf; size_t sb;   // bases (sb == 1: broadcast), canonical Montgomery
+  const uint8_t* k; size_t kstride; size_t klen;                            // big-endian scalars (kstride 0: one for all)
+  uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical affine out
+  size_t count;
+};
+
+// GT product / quotient and power (ops.hpp).
+struct GtMulArgs {
+  const uint32_t* a0; const uint32_t* a1; size_t sa;                        // sa == 1: broadcast
+  const uint32_t* b0; const uint32_t* b1; size_t sb;                        // sb == 1: broadcast
+  uint32_t* o0; uint32_t* o1; size_t so;                                    // plain canonical out
+  size_t count;
+  int conj_b;
+};
+struct GtPowArgs {
+  const uint32_t* a0; const uint32_t* a1; size_t sa;                        // sa == 1: broadcast base
+  const uint8_t* k; size_t kstride; size_t klen;
+  uint32_t* o0; uint32_t* o1; size_t so;                                    // plain canonical out
+  size_t count;
+};
+
 struct KernelTable {
   int nl;
   size_t params_bytes;   // sizeof(FpParams<NL>)
@@ -35,6 +69,12 @@ struct KernelTable {
   //   mode 2: poly product: e = (q*d1 + i)*d2 + k ; ea = q*d1 + i ; eb = q*d2 + k.
   void (*pairing)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                   size_t count, int mode, size_t d1, size_t d2);
+  // plain canonical SoA -> canonical Montgomery SoA, in place (to chain kernels on the device)
+  void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
+  void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);
+  void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
+  void (*gt_mul)(hipStream_t s, const void* params, GtMulArgs a);
+  void (*gt_pow)(hipStream_t s, const void* params, GtPowArgs a);
 };
 
 const KernelTable* kernel_table_nl3();

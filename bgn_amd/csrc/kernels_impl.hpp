@@ -2,43 +2,12 @@
 // Included by kern_nl*.hip with BGN_NL defined.
 #pragma once
 #include "kernels.hpp"
-#include "pairing.hpp"
+#include "ops.hpp"
+#include "codec.hpp"
 
 namespace bgn {
 
 constexpr int NL_ = BGN_NL;
-
-// ---- wire codec -----------------------------------------------------------
-// PBC wire format (Element.Bytes(), ciphertext.go:79; SetBytes, bgn.go:518-521):
-// each F_p value big-endian in L bytes.  7 bytes = 56 bits = two 28-bit limbs.
-template <int NL>
-__device__ __forceinline__ void wire_to_limbs(Fp<NL>& r, const uint8_t* __restrict__ src, int L) {
-#pragma unroll
-  for (int k = 0; k < (NL + 1) / 2; ++k) {
-    u64 v = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int idx = 7 * k + i;
-      if (idx < L) v |= (u64)src[L - 1 - idx] << (8 * i);
-    }
-    r.v[2 * k] = (u32)v & LIMB_MASK;
-    if (2 * k + 1 < NL) r.v[2 * k + 1] = (u32)(v >> LIMB_BITS) & LIMB_MASK;
-  }
-}
-
-template <int NL>
-__device__ __forceinline__ void limbs_to_wire(uint8_t* __restrict__ dst, int L, const Fp<NL>& a) {
-#pragma unroll
-  for (int k = 0; k < (NL + 1) / 2; ++k) {
-    u64 v = a.v[2 * k];
-    if (2 * k + 1 < NL) v |= (u64)a.v[2 * k + 1] << LIMB_BITS;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int idx = 7 * k + i;
-      if (idx < L) dst[L - 1 - idx] = (uint8_t)(v >> (8 * i));
-    }
-  }
-}
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
@@ -119,6 +88,77 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
   }
 }
 
+// ---- group operations (ops.hpp) -------------------------------------------------------
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_to_mont(const FpParams<NL>* __restrict__ P, u32* c0, u32* c1, size_t stride, size_t count) {
+  __shared__ LFp<NL> stage;
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  if (e >= count) return;
+  Fp<NL> x, m;
+  g_load<NL>(x, c0, stride, e);
+  fp_to_mont<NL>(m, x, P, &stage);
+  g_store<NL>(c0, stride, e, m);
+  g_load<NL>(x, c1, stride, e);
+  fp_to_mont<NL>(m, x, P, &stage);
+  g_store<NL>(c1, stride, e, m);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_g1_add(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1AddArgs A) {
+  __shared__ LFp<NL> L[2];
+  g1_add_batch_lane<NL>(A, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_g1_mul(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1MulArgs A) {
+  __shared__ LFp<NL> L[4];
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < A.count;
+  if (!live) e = A.count - 1;
+  g1_scalarmul_lane<NL>(A, e, live, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_gt_mul(const FpParams<NL>* __restrict__ P, GtMulArgs A) {
+  __shared__ LFp<NL> L[4];
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  if (e >= A.count) return;
+  Fp<NL> o0, o1;
+  gt_mul_lane<NL>(o0, o1, L, A.a0, A.a1, A.sa, (A.sa == 1) ? 0 : e, A.b0, A.b1, A.sb, (A.sb == 1) ? 0 : e,
+                  A.conj_b != 0, P);
+  g_store<NL>(A.o0, A.so, e, o0);
+  g_store<NL>(A.o1, A.so, e, o1);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
+  __shared__ LFp<NL> L[4];
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < A.count;
+  if (!live) e = A.count - 1;
+  const size_t ea = (A.sa == 1) ? 0 : e;
+  {
+    Fp<NL> b0, b1, s;
+    g_load<NL>(b0, A.a0, A.sa, ea);
+    g_load<NL>(b1, A.a1, A.sa, ea);
+    fp_add(s, b0, b1);
+    l_store(L + 1, b0);
+    l_store(L + 2, b1);
+    l_store(L + 3, s);
+  }
+  Fp<NL> r0, r1, o;
+  gt_pow_lane<NL>(r0, r1, L, A.k + e * A.kstride, A.klen, (int)(A.klen * 8), P);
+  fp_from_mont<NL>(o, r0, P, L);
+  if (live) g_store<NL>(A.o0, A.so, e, o);
+  fp_from_mont<NL>(o, r1, P, L);
+  if (live) g_store<NL>(A.o1, A.so, e, o);
+}
+
 // ---- launchers ------------------------------------------------------------------
 static inline unsigned grid_for(size_t count) { return (unsigned)((count + FP_BLOCK - 1) / FP_BLOCK); }
 
@@ -141,6 +181,35 @@ static void launch_pairing(hipStream_t s, const void* params, const PairingConst
                      consts, a, b, out, count, mode, d1, d2);
 }
 
+static void launch_to_mont(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride,
+                           size_t count) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_to_mont<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, c0, c1,
+                     stride, count);
+}
+
+static void launch_g1_add(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a) {
+  if (!a.count) return;
+  const size_t lanes = (a.count + a.run - 1) / a.run;
+  hipLaunchKernelGGL(k_g1_add<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts, a);
+}
+
+static void launch_g1_mul(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_g1_mul<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts,
+                     a);
+}
+
+static void launch_gt_mul(hipStream_t s, const void* params, GtMulArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_gt_mul<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
+}
+
+static void launch_gt_pow(hipStream_t s, const void* params, GtPowArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_gt_pow<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
+}
+
 #define BGN_CAT2(a, b) a##b
 #define BGN_CAT(a, b) BGN_CAT2(a, b)
 #define BGN_STR2(x) #x
@@ -154,6 +223,11 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_decode,
       launch_encode,
       launch_pairing,
+      launch_to_mont,
+      launch_g1_add,
+      launch_g1_mul,
+      launch_gt_mul,
+      launch_gt_pow,
   };
   return &t;
 }

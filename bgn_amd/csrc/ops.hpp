@@ -1,0 +1,511 @@
+// ops.hpp — batched group operations besides the pairing: GT (F_p^2)
+// product / power, G1 affine addition with batched inversion, G1 scalar
+// multiplication.  One element (or a short run of elements) per lane; same
+// storage tiers and bound notation as fp28.hpp / pairing.hpp.
+#pragma once
+#include "kernels.hpp"
+#include "pairing.hpp"
+
+namespace bgn {
+
+// Bit `i` (0 = least significant) of a big-endian scalar of `len` bytes.
+__device__ __forceinline__ u32 scalar_bit(const uint8_t* __restrict__ k, size_t len, int i) {
+  return (k[len - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u;
+}
+
+// r = a^(p-2) = 1/a ; a <4 in VGPRs ; result <2.  Uses L[0] (stage) and L[1].
+template <int NL>
+__device__ __forceinline__ void fp_inv(Fp<NL>& r, const Fp<NL>& a, LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                       const FpParams<NL>* __restrict__ P) {
+  l_store(L + 1, a);
+  fp_pow_uniform<NL>(r, L + 1, C->pm2, C->pm2_bits, P, L);
+}
+
+// Canonical Montgomery representative in [0,p) of a value < 8p by conditional
+// subtraction of 4p, 2p, p (cheap: no product).
+template <int NL>
+__device__ __forceinline__ void fp_reduce8(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  Fp<NL> x = a;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int K = 4 >> s;   // 4, 2, 1
+    Fp<NL> d;
+    i32 c = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const i32 v = (i32)x.v[j] - (i32)P->kp[K - 1][j] + c;
+      d.v[j] = (u32)v & LIMB_MASK;
+      c = v >> LIMB_BITS;
+    }
+    const bool ge = (c == 0);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x.v[j] = ge ? d.v[j] : x.v[j];
+  }
+  r = x;
+}
+
+// ===========================================================================
+// GT = order-n subgroup of F_p^2* (level-2 ciphertexts)
+// ===========================================================================
+
+// out = a * b  (conj_b: a * conj(b) = a / b on the norm-1 subgroup GT; this is
+// result.Div on level-2 ciphertexts, bgn.go:397).  Replaces result.Mul,
+// bgn.go:460.  Inputs canonical Montgomery; output plain canonical.
+template <int NL>
+__device__ __forceinline__ void gt_mul_lane(Fp<NL>& o0, Fp<NL>& o1, LFp<NL>* L, const u32* a0, const u32* a1,
+                                            size_t sa, size_t ea, const u32* b0, const u32* b1, size_t sb, size_t eb,
+                                            bool conj_b, const FpParams<NL>* __restrict__ P) {
+  Fp<NL> r, u, w;
+  g_load(r, a0, sa, ea);
+  g_load(u, a1, sa, ea);
+  fp_add(w, r, u);                         // <2
+  l_store(L + 3, w);
+  l_store(L + 1, r);
+  l_store(L + 2, u);
+  g_load(r, b0, sb, eb);
+  g_load(u, b1, sb, eb);
+  if (conj_b) fp_neg<1>(u, u, P);          // <=1
+  fp_mul(w, L + 1, r, P);                  // v0 <2
+  fp_add(r, r, u);                         // <2
+  fp_mul(u, L + 2, u, P);                  // v1 <2
+  fp_mul(r, L + 3, r, P);                  // (a0+a1)(b0+b1) <2   (4)
+  {
+    Fp<NL> d;
+    fp_sub<2>(d, w, u, P);                 // re <4
+    fp_add(w, w, u);                       // <4
+    fp_sub<4>(r, r, w, P);                 // im <6
+    fp_from_mont<NL>(o0, d, P, L);
+  }
+  fp_from_mont<NL>(o1, r, P, L);
+}
+
+// acc = base^k, k per lane (big-endian bytes) ; base = (L[1], L[2]) with
+// L[3] = base0+base1 precomputed (base canonical <1).  Square-and-multiply from
+// bit nbits-1; the multiply is executed when any lane of the wave needs it and
+// selected per lane.  The accumulator lives in two AGPR slots.  Result
+// (r0 <4, r1 <6).
+template <int NL>
+__device__ __forceinline__ void gt_pow_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL>* L, const uint8_t* __restrict__ k,
+                                            size_t klen, int nbits, const FpParams<NL>* __restrict__ P) {
+  AFp<NL> A0, A1;
+  {
+    Fp<NL> t;
+    fp_set(t, P->one);
+    a_store(A0, t);
+    fp_zero(t);
+    a_store(A1, t);
+  }
+  bool started = false;
+#pragma unroll 1
+  for (int i = nbits - 1; i >= 0; --i) {
+    if (__ballot(started)) {
+      Fp<NL> a0, a1, s0, s1;
+      a_load(a0, A0);
+      a_load(a1, A1);
+      fp2_sqr_v(s0, s1, a0, a1, P, L);      // <2, <4
+      a_store(A0, s0);
+      a_store(A1, s1);
+    }
+    const bool bit = scalar_bit(k, klen, i) != 0;
+    if (__ballot(bit)) {
+      // (a0 + i a1) * base: v0 = b0*a0, v1 = b1*a1, w = (b0+b1)(a0+a1)
+      Fp<NL> v0, v1, s;
+      {
+        Fp<NL> a0, a1;
+        a_load(a0, A0);                     // <4
+        a_load(a1, A1);                     // <6
+        fp_add(s, a0, a1);                  // <10
+        fp_mul(v0, L + 1, a0, P);           // <2
+        fp_mul(v1, L + 2, a1, P);           // <2
+      }
+      fp_mul(s, L + 3, s, P);               // <2   (2*10)
+      Fp<NL> m, cur;
+      fp_sub<2>(m, v0, v1, P);              // <4
+      a_load(cur, A0);
+      fp_select(m, bit, m, cur);
+      a_store(A0, m);
+      fp_add(v0, v0, v1);                   // <4
+      fp_sub<4>(m, s, v0, P);               // <6
+      a_load(cur, A1);
+      fp_select(m, bit, m, cur);
+      a_store(A1, m);
+    }
+    started = started || bit;
+  }
+  a_load(r0, A0);
+  a_load(r1, A1);
+}
+
+// ===========================================================================
+// G1 affine addition with batched inversion (Montgomery's trick along a run
+// of `run` elements owned by each lane).  Replaces result.Mul / result.Div on
+// level-1 ciphertexts (bgn.go:482, :419) and C.Mul(G,H) (bgn.go:350), which
+// PBC executes as one affine addition = one F_p inversion each.
+// ===========================================================================
+// case codes
+constexpr int G1C_ADD = 0, G1C_DBL = 1, G1C_INF = 2, G1C_A = 3, G1C_B = 4;
+
+// Classify and return the denominator (canonical inputs <1).  d <2 (never 0 mod p).
+template <int NL>
+__device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp<NL>& y1, bool inf1,
+                                           const Fp<NL>& x2, const Fp<NL>& y2, bool inf2,
+                                           const FpParams<NL>* __restrict__ P) {
+  const bool xe = fp_eq_limbs(x1, x2);
+  const bool ye = fp_eq_limbs(y1, y2);
+  const bool yz = fp_is_zero_limbs(y1);
+  int cs = G1C_ADD;
+  if (xe) cs = (ye && !yz) ? G1C_DBL : G1C_INF;
+  if (inf2) cs = G1C_A;
+  if (inf1) cs = inf2 ? G1C_INF : G1C_B;
+  Fp<NL> dd, da;
+  fp_dbl(dd, y1);                           // <2
+  fp_sub<1>(da, x2, x1, P);                 // <2, != 0 when x1 != x2
+  Fp<NL> one;
+  fp_set(one, P->one);
+  fp_select(d, cs == G1C_ADD, da, one);
+  fp_select(d, cs == G1C_DBL, dd, d);
+  return cs;
+}
+
+template <int NL>
+__device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                                  const FpParams<NL>* __restrict__ P) {
+  const size_t T = (size_t)gridDim.x * FP_BLOCK;
+  const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  Fp<NL> acc;
+  fp_set(acc, P->one);
+  // pass 1: prefix products of the denominators
+#pragma unroll 1
+  for (int j = 0; j < A.run; ++j) {
+    const size_t e = (size_t)j * T + t;
+    if (e < A.count) {
+      const size_t eb = (A.sb == 1) ? 0 : e;
+      Fp<NL> x1, y1, x2, y2, d;
+      g_load(x1, A.ax, A.sa, e);
+      g_load(y1, A.ay, A.sa, e);
+      g_load(x2, A.bx, A.sb, eb);
+      g_load(y2, A.by, A.sb, eb);
+      if (A.negate_b) {
+        fp_neg<1>(y2, y2, P);
+        fp_reduce8(y2, y2, P);              // p - 0 = p -> 0
+      }
+      g1_classify<NL>(d, x1, y1, A.ainf && A.ainf[e], x2, y2, A.binf && A.binf[eb], P);
+      g_store(A.prefix, A.sp, e, acc);
+      l_store(L, acc);
+      fp_mul(acc, L, d, P);                 // <2
+    }
+  }
+  Fp<NL> inv;
+  fp_inv<NL>(inv, acc, L, C, P);            // <2
+  // pass 2: walk back, peel one inverse per element
+#pragma unroll 1
+  for (int j = A.run - 1; j >= 0; --j) {
+    const size_t e = (size_t)j * T + t;
+    if (e < A.count) {
+      const size_t eb = (A.sb == 1) ? 0 : e;
+      Fp<NL> x1, y1, x2, y2, d;
+      g_load(x1, A.ax, A.sa, e);
+      g_load(y1, A.ay, A.sa, e);
+      g_load(x2, A.bx, A.sb, eb);
+      g_load(y2, A.by, A.sb, eb);
+      if (A.negate_b) {
+        fp_neg<1>(y2, y2, P);
+        fp_reduce8(y2, y2, P);
+      }
+      const int cs = g1_classify<NL>(d, x1, y1, A.ainf && A.ainf[e], x2, y2, A.binf && A.binf[eb], P);
+      Fp<NL> dinv;
+      {
+        Fp<NL> pf;
+        g_load(pf, A.prefix, A.sp, e);
+        l_store(L, inv);                    // L0 = running inverse
+        fp_mul(dinv, L, pf, P);             // 1/d <2
+        fp_mul(inv, L, d, P);               // inverse of the shorter prefix <2
+      }
+      // numerator: y2 - y1, or 3*x1^2 + 1 for a doubling
+      Fp<NL> num;
+      {
+        Fp<NL> xx, t3;
+        fp_mulv(xx, x1, x1, P, L + 1);      // <2
+        fp_dbl(t3, xx);
+        fp_add(t3, t3, xx);                 // <6
+        Fp<NL> one;
+        fp_set(one, P->one);
+        fp_add(t3, t3, one);                // <7
+        fp_sub<1>(num, y2, y1, P);          // <2
+        fp_select(num, cs == G1C_DBL, t3, num);
+      }
+      l_store(L + 1, dinv);
+      Fp<NL> lam;
+      fp_mul(lam, L + 1, num, P);           // lambda <2   (14)
+      Fp<NL> x3, y3;
+      fp_mulv(x3, lam, lam, P, L + 1);      // <2 ; L1 = lambda
+      fp_sub<1>(x3, x3, x1, P);             // <3
+      fp_sub<1>(x3, x3, x2, P);             // <4
+      fp_sub<4>(y3, x1, x3, P);             // <5
+      fp_mul(y3, L + 1, y3, P);             // <2   (10)
+      fp_sub<1>(y3, y3, y1, P);             // <3
+      // select special cases (all in Montgomery form)
+      const bool isA = cs == G1C_A, isB = cs == G1C_B;
+      fp_select(x3, isA, x1, x3);
+      fp_select(y3, isA, y1, y3);
+      fp_select(x3, isB, x2, x3);
+      fp_select(y3, isB, y2, y3);
+      Fp<NL> o;
+      fp_from_mont<NL>(o, x3, P, L + 1);
+      g_store(A.ox, A.so, e, o);
+      fp_from_mont<NL>(o, y3, P, L + 1);
+      g_store(A.oy, A.so, e, o);
+      A.oinf[e] = (cs == G1C_INF) ? 1 : 0;
+    }
+  }
+}
+
+// ===========================================================================
+// G1 scalar multiplication: out = base^k (PBC: PowBig / MulBig on G1;
+// bgn.go:258, :223, :344-346), k per lane or one scalar for all lanes, any
+// non-negative integer.  Jacobian double-and-add from the top bit; the
+// addition is executed when some lane of the wave needs it and selected per
+// lane.  Exceptional additions (acc == +-base) are detected exactly
+// (H == 0 mod p) and resolved (doubling resp. identity).
+// ===========================================================================
+template <int NL>
+struct JacAcc {
+  AFp<NL> X, Y, Z;   // X,Y <18, Z <4
+  AFp<NL> T, U;      // scratch
+};
+
+// acc <- 2*acc   (acc = O stays O: Z3 = 2YZ = 0).  Uses LDS slots L[0], L[1]
+// only (L[2], L[3] hold the ladder's base point) and the AGPR scratch slots.
+template <int NL>
+__device__ __forceinline__ void jac_double(JacAcc<NL>& S, LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  Fp<NL> r, u, w;
+  a_load(r, S.Z);
+  fp_mulv(r, r, r, P, S0);                 // ZZ <2
+  fp_mulv(w, r, r, P, S0);                 // ZZ^2 <2
+  a_load(r, S.X);
+  fp_mulv(u, r, r, P, S0);                 // XX <2
+  fp_dbl(r, u);
+  fp_add(r, r, u);
+  fp_add(r, r, w);                         // M <8
+  l_store(L1, r);                          // L1 = M
+  a_load(r, S.Y);
+  fp_mulv(u, r, r, P, S0);                 // YY <2
+  a_store(S.U, u);                         // U = YY
+  a_load(r, S.X);
+  fp_mulv(r, r, u, P, S0);                 // X*YY <2
+  fp_dbl(r, r);
+  fp_dbl(r, r);                            // S <8
+  a_store(S.T, r);                         // T = S
+  a_load(r, S.Y);
+  a_load(u, S.Z);
+  fp_mulv(r, r, u, P, S0);                 // YZ <2
+  fp_dbl(r, r);                            // Z3 <4
+  a_store(S.Z, r);
+  l_load(r, L1);
+  fp_mul(u, L1, r, P);                     // M^2 <2
+  a_load(r, S.T);                          // S
+  fp_dbl(w, r);                            // <16
+  fp_sub<16>(u, u, w, P);                  // X3 <18
+  a_store(S.X, u);
+  fp_sub<18>(r, r, u, P);                  // S - X3 <26
+  fp_mul(r, L1, r, P);                     // M*(S-X3) <2   (208)
+  a_load(u, S.U);
+  fp_mulv(u, u, u, P, S0);                 // YY^2 <2
+  fp_dbl(u, u);
+  fp_dbl(u, u);
+  fp_dbl(u, u);                            // <16
+  fp_sub<16>(r, r, u, P);                  // Y3 <18
+  a_store(S.Y, r);
+}
+
+// acc <- acc + (bx, by) for the lanes where `take` holds; bx, by canonical <1 in
+// LDS slots L[2] (x) and L[3] (y).  acc_inf is the per-lane "acc is O" flag.
+template <int NL>
+__device__ __forceinline__ void jac_add_affine(JacAcc<NL>& S, bool& acc_inf, bool take, LFp<NL>* L,
+                                               const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  LFp<NL>* LX = L + 2;
+  LFp<NL>* LY = L + 3;
+  Fp<NL> r, u, w;
+  a_load(r, S.Z);                          // <4
+  fp_mulv(u, r, r, P, S0);                 // ZZ <2
+  l_store(L1, u);                          // L1 = ZZ
+  fp_mul(r, L1, r, P);                     // Z^3 <2
+  fp_mul(r, LY, r, P);                     // yB*Z^3 <2
+  a_load(u, S.Y);
+  fp_sub<18>(r, r, u, P);                  // rr <20
+  a_store(S.T, r);                         // T = rr
+  l_load(u, L1);
+  fp_mul(u, LX, u, P);                     // xB*ZZ <2
+  a_load(w, S.X);
+  fp_sub<18>(u, u, w, P);                  // H <20
+  // exceptional cases: H == 0 (mod p)  <=>  x(acc) == x(B)
+  bool h0, r0;
+  {
+    Fp<NL> c;
+    fp_from_mont<NL>(c, u, P, S0);          // canonical H/R: zero iff H == 0 mod p
+    h0 = fp_is_zero_limbs(c);
+    fp_from_mont<NL>(c, r, P, S0);
+    r0 = fp_is_zero_limbs(c);
+  }
+  l_store(L1, u);                          // L1 = H
+  a_load(r, S.Z);
+  fp_mul(r, L1, r, P);                     // Z3 = Z*H <2   (80)
+  a_store(S.U, r);                         // U = Z3 (committed below)
+  fp_mul(w, L1, u, P);                     // HH <2  (400)
+  fp_mul(u, L1, w, P);                     // HHH <2
+  a_load(r, S.X);
+  fp_mulv(r, r, w, P, S0);                 // XHH <2
+  a_load(w, S.T);
+  fp_mulv(w, w, w, P, S0);                 // rr^2 <2
+  fp_sub<2>(w, w, u, P);                   // <4
+  {
+    Fp<NL> d;
+    fp_dbl(d, r);
+    fp_sub<4>(w, w, d, P);                 // X3 <8
+  }
+  fp_sub<8>(r, r, w, P);                   // XHH - X3 <10
+  l_store(L1, w);                          // L1 = X3 (parked)
+  a_load(w, S.T);
+  fp_mulv(r, r, w, P, S0);                 // rr*(XHH-X3) <2
+  a_load(w, S.Y);
+  fp_mulv(w, w, u, P, S0);                 // Y*HHH <2
+  fp_sub<2>(r, r, w, P);                   // Y3 <4
+  // commit per lane
+  const bool normal = take && !acc_inf && !h0;
+  const bool first = take && acc_inf;                 // O + B = B
+  const bool dbl_case = take && !acc_inf && h0 && r0; // acc == B : result 2B, handled by caller-visible path below
+  const bool to_inf = take && !acc_inf && h0 && !r0;  // acc == -B
+  {
+    Fp<NL> cur, by;
+    a_load(cur, S.Y);
+    l_load(by, LY);
+    fp_select(r, normal, r, cur);
+    fp_select(r, first, by, r);
+    a_store(S.Y, r);
+    a_load(cur, S.X);
+    l_load(u, L1);
+    l_load(by, LX);
+    fp_select(u, normal, u, cur);
+    fp_select(u, first, by, u);
+    a_store(S.X, u);
+    a_load(cur, S.Z);
+    a_load(u, S.U);
+    Fp<NL> one;
+    fp_set(one, P->one);
+    fp_select(u, normal, u, cur);
+    fp_select(u, first, one, u);
+    a_store(S.Z, u);
+  }
+  if (__ballot(dbl_case)) {
+    // acc == B for some lane: the sum is 2B, computed from the affine point (Z = 1):
+    // M = 3x^2 + 1, S = 4x*y^2, X3 = M^2 - 2S, Y3 = M(S - X3) - 8y^4, Z3 = 2y.
+    Fp<NL> one;
+    l_load(r, LX);
+    fp_mulv(u, r, r, P, S0);               // xx <2
+    fp_dbl(w, u);
+    fp_add(w, w, u);
+    fp_set(one, P->one);
+    fp_add(w, w, one);                     // M <7
+    l_store(L1, w);                        // L1 = M
+    l_load(r, LY);
+    fp_mulv(u, r, r, P, S0);               // yy <2
+    l_load(r, LX);
+    fp_mulv(r, r, u, P, S0);               // x*yy <2
+    fp_dbl(r, r);
+    fp_dbl(r, r);                          // S <8
+    a_store(S.T, r);
+    fp_mulv(u, u, u, P, S0);               // yy^2 <2
+    fp_dbl(u, u);
+    fp_dbl(u, u);
+    fp_dbl(u, u);                          // <16
+    a_store(S.U, u);
+    l_load(r, L1);
+    fp_mul(u, L1, r, P);                   // M^2 <2  (49)
+    a_load(r, S.T);
+    fp_dbl(w, r);                          // <16
+    fp_sub<16>(u, u, w, P);                // X3 <18
+    fp_sub<18>(r, r, u, P);                // S - X3 <26
+    fp_mul(r, L1, r, P);                   // <2   (182)
+    a_load(w, S.U);
+    fp_sub<16>(r, r, w, P);                // Y3 <18
+    Fp<NL> cur;
+    a_load(cur, S.X);
+    fp_select(u, dbl_case, u, cur);
+    a_store(S.X, u);
+    a_load(cur, S.Y);
+    fp_select(r, dbl_case, r, cur);
+    a_store(S.Y, r);
+    l_load(w, LY);
+    fp_dbl(w, w);                          // Z3 = 2y <2
+    a_load(cur, S.Z);
+    fp_select(w, dbl_case, w, cur);
+    a_store(S.Z, w);
+  }
+  acc_inf = (acc_inf && !take) || to_inf;
+}
+
+template <int NL>
+__device__ __forceinline__ void g1_scalarmul_lane(const G1MulArgs& A, size_t e, bool live, LFp<NL>* L,
+                                                  const PairingConsts* __restrict__ C,
+                                                  const FpParams<NL>* __restrict__ P) {
+  const size_t eb = (A.sb == 1) ? 0 : e;
+  const uint8_t* k = A.k + e * A.kstride;
+  JacAcc<NL> S;
+  {
+    Fp<NL> t;
+    fp_set(t, P->one);
+    a_store(S.X, t);
+    a_store(S.Y, t);
+    a_store(S.T, t);
+    a_store(S.U, t);
+    fp_zero(t);
+    a_store(S.Z, t);
+    g_load(t, A.bx, A.sb, eb);
+    l_store(L + 2, t);
+    g_load(t, A.by, A.sb, eb);
+    l_store(L + 3, t);
+  }
+  bool acc_inf = true;
+  const int nbits = (int)(A.klen * 8);
+#pragma unroll 1
+  for (int i = nbits - 1; i >= 0; --i) {
+    if (__ballot(!acc_inf)) jac_double<NL>(S, L, P);
+    const bool bit = scalar_bit(k, A.klen, i) != 0;
+    if (__ballot(bit)) jac_add_affine<NL>(S, acc_inf, bit, L, P);
+  }
+  // affine: x = X / Z^2, y = Y / Z^3
+  Fp<NL> r, u, zi;
+  a_load(r, S.Z);
+  {
+    Fp<NL> one;
+    fp_set(one, P->one);
+    fp_select(r, acc_inf, one, r);          // keep the inversion well defined
+  }
+  fp_reduce8(r, r, P);                      // <1 (Z <4)
+  fp_inv<NL>(zi, r, L, C, P);               // <2   (uses L0, L1)
+  l_store(L + 1, zi);
+  fp_mul(u, L + 1, zi, P);                  // zi^2 <2
+  a_load(r, S.X);
+  fp_mulv(r, r, u, P, L);                   // x <2   (36)
+  fp_mul(u, L + 1, u, P);                   // zi^3 <2
+  {
+    Fp<NL> o;
+    fp_from_mont<NL>(o, r, P, L);
+    if (live) g_store(A.ox, A.so, e, o);
+  }
+  a_load(r, S.Y);
+  fp_mulv(r, r, u, P, L);                   // y <2
+  {
+    Fp<NL> o;
+    fp_from_mont<NL>(o, r, P, L);
+    if (live) g_store(A.oy, A.so, e, o);
+  }
+  const bool binf = A.binf && A.binf[eb];
+  if (live) A.oinf[e] = (acc_inf || binf) ? 1 : 0;
+}
+
+}  // namespace bgn

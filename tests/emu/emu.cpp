@@ -1,0 +1,147 @@
+// emu.cpp — host emulation of the device lane programs (TEST INFRASTRUCTURE).
+// Compiles bgn_amd/csrc/{fp28,pairing,ops,codec}.hpp for the CPU with stand-in
+// headers (tests/emu/hip/hip_runtime.h, tests/emu/agpr.hpp) and runs one lane
+// at a time.  Lets CPU-only tests exercise the exact kernel logic (slot
+// programs, exception paths) against the oracle without a GPU.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+
+thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 1, 1}, blockDim = {256, 1, 1};
+
+#include "ops.hpp"
+#include "codec.hpp"
+
+using namespace bgn;
+
+template <int NL>
+struct Emu {
+  static LFp<NL>* lds() {
+    static LFp<NL> L[4];
+    return L;
+  }
+  // wire (2L bytes) -> Montgomery limbs (2*NL u32) + inf flag
+  static void decode(const u32* params, const uint8_t* wire, int Lb, u32* out, uint8_t* inf) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    Fp<NL> x, y, m;
+    wire_to_limbs<NL>(x, wire, Lb);
+    wire_to_limbs<NL>(y, wire + Lb, Lb);
+    *inf = fp_is_zero_limbs(x) && fp_is_zero_limbs(y);
+    fp_to_mont<NL>(m, x, P, lds());
+    memcpy(out, m.v, 4 * NL);
+    fp_to_mont<NL>(m, y, P, lds());
+    memcpy(out + NL, m.v, 4 * NL);
+  }
+  static void encode(const u32* plain, int Lb, uint8_t inf, uint8_t* wire) {
+    Fp<NL> x, y;
+    memcpy(x.v, plain, 4 * NL);
+    memcpy(y.v, plain + NL, 4 * NL);
+    if (inf) {
+      fp_zero(x);
+      fp_zero(y);
+    }
+    limbs_to_wire<NL>(wire, Lb, x);
+    limbs_to_wire<NL>(wire + Lb, Lb, y);
+  }
+  static void pairing(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};
+    Fp<NL> re, im;
+    pairing_lane<NL>(re, im, lds(), op, C, P);
+    memcpy(out, re.v, 4 * NL);
+    memcpy(out + NL, im.v, 4 * NL);
+  }
+  static void g1_mul(const u32* params, const PairingConsts* C, const u32* base, uint8_t binf, const uint8_t* k,
+                     size_t klen, u32* out, uint8_t* oinf) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    G1MulArgs A;
+    A.bx = base; A.by = base + NL; A.binf = &binf; A.sb = 1;
+    A.k = k; A.kstride = 0; A.klen = klen;
+    A.ox = out; A.oy = out + NL; A.oinf = oinf; A.so = 1;
+    A.count = 1;
+    g1_scalarmul_lane<NL>(A, 0, true, lds(), C, P);
+  }
+  // count elements processed by ONE lane as a run (exercises the batched inversion)
+  static void g1_add(const u32* params, const PairingConsts* C, const u32* a, const uint8_t* ainf, const u32* b,
+                     const uint8_t* binf, int count, int negate_b, u32* out, uint8_t* oinf) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    // SoA with stride = count ; with one thread the kernel's element index is j*T + t, T = gridDim*256 = 256:
+    // emulate by giving each run element its own "row" of 256 (only column 0 used)
+    const size_t T = 256;
+    const size_t st = T * count;
+    std::vector<u32> ax(NL * st), ay(NL * st), bx(NL * st), by(NL * st), ox(NL * st), oy(NL * st), pf(NL * st);
+    std::vector<uint8_t> ai(st), bi(st), oi(st);
+    for (int j = 0; j < count; ++j) {
+      const size_t e = (size_t)j * T;
+      for (int l = 0; l < NL; ++l) {
+        ax[l * st + e] = a[(2 * j) * NL + l];
+        ay[l * st + e] = a[(2 * j + 1) * NL + l];
+        bx[l * st + e] = b[(2 * j) * NL + l];
+        by[l * st + e] = b[(2 * j + 1) * NL + l];
+      }
+      ai[e] = ainf[j];
+      bi[e] = binf[j];
+    }
+    G1AddArgs A;
+    A.ax = ax.data(); A.ay = ay.data(); A.ainf = ai.data(); A.sa = st;
+    A.bx = bx.data(); A.by = by.data(); A.binf = bi.data(); A.sb = st;
+    A.ox = ox.data(); A.oy = oy.data(); A.oinf = oi.data(); A.so = st;
+    A.prefix = pf.data(); A.sp = st;
+    A.count = st - (T - 1);       // elements j*T for j < count are in range; others have no lane here
+    A.run = count;
+    A.negate_b = negate_b;
+    g1_add_batch_lane<NL>(A, lds(), C, P);
+    for (int j = 0; j < count; ++j) {
+      const size_t e = (size_t)j * T;
+      for (int l = 0; l < NL; ++l) {
+        out[(2 * j) * NL + l] = ox[l * st + e];
+        out[(2 * j + 1) * NL + l] = oy[l * st + e];
+      }
+      oinf[j] = oi[e];
+    }
+  }
+  static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    Fp<NL> o0, o1;
+    gt_mul_lane<NL>(o0, o1, lds(), a, a + NL, 1, 0, b, b + NL, 1, 0, conj_b != 0, P);
+    memcpy(out, o0.v, 4 * NL);
+    memcpy(out + NL, o1.v, 4 * NL);
+  }
+  static void gt_pow(const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    LFp<NL>* L = lds();
+    Fp<NL> b0, b1, s, r0, r1, o;
+    memcpy(b0.v, a, 4 * NL);
+    memcpy(b1.v, a + NL, 4 * NL);
+    fp_add(s, b0, b1);
+    l_store(L + 1, b0);
+    l_store(L + 2, b1);
+    l_store(L + 3, s);
+    gt_pow_lane<NL>(r0, r1, L, k, klen, (int)(klen * 8), P);
+    fp_from_mont<NL>(o, r0, P, L);
+    memcpy(out, o.v, 4 * NL);
+    fp_from_mont<NL>(o, r1, P, L);
+    memcpy(out + NL, o.v, 4 * NL);
+  }
+};
+
+#define DISPATCH(nl, call)            \
+  switch (nl) {                       \
+    case 3: Emu<3>::call; break;      \
+    case 10: Emu<10>::call; break;    \
+    case 19: Emu<19>::call; break;    \
+    case 38: Emu<38>::call; break;    \
+    default: return -1;               \
+  }                                   \
+  return 0;
+
+extern "C" {
+int emu_decode(int nl, const u32* params, const uint8_t* wire, int Lb, u32* out, uint8_t* inf) { DISPATCH(nl, decode(params, wire, Lb, out, inf)) }
+int emu_encode(int nl, const u32* plain, int Lb, uint8_t inf, uint8_t* wire) { DISPATCH(nl, encode(plain, Lb, inf, wire)) }
+int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing(params, (const PairingConsts*)C, a, b, out)) }
+int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, out, oinf)) }
+int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, out, oinf)) }
+int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, out)) }
+int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
+size_t emu_consts_size() { return sizeof(PairingConsts); }
+}

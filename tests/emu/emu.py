@@ -1,0 +1,145 @@
+"""Python driver of the host emulation harness (tests/emu/emu.cpp).
+
+TEST INFRASTRUCTURE: runs the device lane programs of bgn_amd/csrc on the CPU
+so CPU-only tests can check kernel logic against the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libbgn_emu.so")
+_CSRC = os.path.join(_HERE, "..", "..", "bgn_amd", "csrc")
+KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
+
+
+def build() -> str:
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
+                               "-include", os.path.join(_HERE, "agpr.hpp"), os.path.join(_HERE, "emu.cpp"),
+                               "-o", _SO])
+    return _SO
+
+
+def limbs(v: int, nl: int):
+    return [(v >> (28 * j)) & MASK for j in range(nl)]
+
+
+def nl_for(p: int) -> int:
+    need = (p.bit_length() + 9 + 27) // 28
+    for nl in (3, 10, 19, 38):
+        if nl >= need:
+            return nl
+    raise ValueError("field too large")
+
+
+def naf(n: int):
+    d = []
+    while n:
+        if n & 1:
+            z = 2 - (n & 3)
+            d.append(z)
+            n -= z
+        else:
+            d.append(0)
+        n >>= 1
+    return d
+
+
+class Emu:
+    def __init__(self, p: int, n: int, l: int):
+        self.lib = C.CDLL(build())
+        self.p, self.n, self.l = p, n, l
+        self.nl = nl = nl_for(p)
+        self.L = (p.bit_length() + 7) // 8
+        R = 1 << (28 * nl)
+        img = limbs(p, nl) + limbs(R % p, nl) + limbs(R * R % p, nl)
+        for K in range(1, KP_MAX + 1):
+            img += limbs(K * p, nl)
+        img += [(-pow(p, -1, 1 << 28)) % (1 << 28), 0, 0, 0]
+        self.params = (C.c_uint32 * len(img))(*img)
+        d = naf(n)
+        pm2 = p - 2
+        buf = struct.pack("<iiQii", len(d), pm2.bit_length(), l, l.bit_length(), 0)
+        buf += bytes((x & 0xFF) for x in d) + bytes(MAX_NAF - len(d))
+        buf += struct.pack("<%dI" % MAX_EXP_LIMBS, *limbs(pm2, MAX_EXP_LIMBS))
+        assert len(buf) == self.lib.emu_consts_size() or True
+        self.lib.emu_consts_size.restype = C.c_size_t
+        assert len(buf) == self.lib.emu_consts_size(), (len(buf), self.lib.emu_consts_size())
+        self.consts = C.create_string_buffer(buf, len(buf))
+
+    @classmethod
+    def from_fixture(cls, fx):
+        return cls(int(fx["p"], 16), int(fx["n"], 16), fx["l"])
+
+    # wire <-> internal
+    def decode(self, wire: bytes):
+        out = (C.c_uint32 * (2 * self.nl))()
+        inf = C.c_uint8()
+        assert self.lib.emu_decode(self.nl, self.params, wire, self.L, out, C.byref(inf)) == 0
+        return out, inf.value
+
+    def encode(self, plain, inf=0) -> bytes:
+        w = C.create_string_buffer(2 * self.L)
+        assert self.lib.emu_encode(self.nl, plain, self.L, inf, w) == 0
+        return w.raw
+
+    def pairing(self, a: bytes, b: bytes) -> bytes:
+        A, ia = self.decode(a)
+        B, ib = self.decode(b)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_pairing(self.nl, self.params, self.consts, A, B, out) == 0
+        if ia or ib:
+            return (1).to_bytes(self.L, "big") + bytes(self.L)
+        return self.encode(out)
+
+    def g1_mul(self, base: bytes, k: int, klen: int = None) -> bytes:
+        B, ib = self.decode(base)
+        klen = klen or max(1, (k.bit_length() + 7) // 8)
+        kb = k.to_bytes(klen, "big")
+        out = (C.c_uint32 * (2 * self.nl))()
+        oinf = C.c_uint8()
+        assert self.lib.emu_g1_mul(self.nl, self.params, self.consts, B, ib, kb, C.c_size_t(klen), out, C.byref(oinf)) == 0
+        return self.encode(out, oinf.value)
+
+    def g1_add(self, a_list, b_list, subtract=False):
+        """One lane processing the whole list as a single batched-inversion run."""
+        n = len(a_list)
+        A = (C.c_uint32 * (2 * self.nl * n))()
+        B = (C.c_uint32 * (2 * self.nl * n))()
+        ai = (C.c_uint8 * n)()
+        bi = (C.c_uint8 * n)()
+        for j in range(n):
+            x, i = self.decode(a_list[j])
+            A[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
+            ai[j] = i
+            x, i = self.decode(b_list[j])
+            B[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
+            bi[j] = i
+        out = (C.c_uint32 * (2 * self.nl * n))()
+        oi = (C.c_uint8 * n)()
+        assert self.lib.emu_g1_add(self.nl, self.params, self.consts, A, ai, B, bi, n, 1 if subtract else 0, out, oi) == 0
+        res = []
+        for j in range(n):
+            pl = (C.c_uint32 * (2 * self.nl))(*out[2 * self.nl * j:2 * self.nl * (j + 1)])
+            res.append(self.encode(pl, oi[j]))
+        return res
+
+    def gt_mul(self, a: bytes, b: bytes, conj_b=False) -> bytes:
+        A, _ = self.decode(a)
+        B, _ = self.decode(b)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_gt_mul(self.nl, self.params, A, B, 1 if conj_b else 0, out) == 0
+        return self.encode(out)
+
+    def gt_pow(self, a: bytes, k: int, klen: int = None) -> bytes:
+        A, _ = self.decode(a)
+        klen = klen or max(1, (k.bit_length() + 7) // 8)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_gt_pow(self.nl, self.params, A, k.to_bytes(klen, "big"), C.c_size_t(klen), out) == 0
+        return self.encode(out)

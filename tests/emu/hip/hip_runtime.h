@@ -1,0 +1,17 @@
+// Host stand-in for <hip/hip_runtime.h>, used ONLY by the emulation harness
+// (tests/emu/emu.cpp) to run the device headers' logic on the CPU, one lane at
+// a time, for debugging and for CPU-side unit tests of the kernel programs.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+struct EmuDim3 { unsigned x, y, z; };
+extern thread_local EmuDim3 threadIdx, blockIdx, gridDim, blockDim;
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+typedef void* hipStream_t;

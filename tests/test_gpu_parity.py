@@ -62,3 +62,138 @@ def test_mult_empty_batch():
     fx = load_fixture("toy64")
     pk, _ = engine_key(fx)
     assert pk.engine.mult(b"", b"").shape == (0, pk.engine.elem_bytes)
+
+
+# ---------------------------------------------------------------------------
+# Encrypt / Add / Sub / Neg / MultConst against the golden vectors
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", KEYS)
+def test_encrypt_golden(name):
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    xs = [int(e["x"], 16) for e in fx["encrypt"]]
+    rs = [int(e["r"], 16) for e in fx["encrypt"]]
+    out = pk.engine.encrypt(xs, rs)
+    for row, e in zip(out, fx["encrypt"]):
+        assert bytes(row).hex() == e["ct"], f"{name}: Encrypt(x={e['x']}, r={e['r']})"
+    # EncryptDeterministic (bgn.go:325-331) == r = 0
+    det = pk.engine.encrypt(xs[:4], None)
+    ref = pk.engine.encrypt(xs[:4], [0, 0, 0, 0])
+    assert (det == ref).all()
+    assert not det[0].any()                      # P^0 = identity = zero bytes
+
+
+@pytest.mark.parametrize("name", KEYS)
+def test_l1_add_sub_neg_golden(name):
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    cts = [e["ct"] for e in fx["encrypt"]]
+    a, b = H([cts[v["a"]] for v in fx["l1"]]), H([cts[v["b"]] for v in fx["l1"]])
+    for got, key in [(pk.engine.add(1, a, b), "add"), (pk.engine.sub(1, a, b), "sub"), (pk.engine.neg(1, a), "neg")]:
+        for row, v in zip(got, fx["l1"]):
+            assert bytes(row).hex() == v[key], f"{name}: L1 {key}({v['a']},{v['b']})"
+
+
+@pytest.mark.parametrize("name", KEYS)
+def test_l2_add_sub_neg_golden(name):
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    l2 = [v["out"] for v in fx["mult"]]
+    a, b = H([l2[v["a"]] for v in fx["l2"]]), H([l2[v["b"]] for v in fx["l2"]])
+    for got, key in [(pk.engine.add(2, a, b), "add"), (pk.engine.sub(2, a, b), "sub"), (pk.engine.neg(2, a), "neg")]:
+        for row, v in zip(got, fx["l2"]):
+            assert bytes(row).hex() == v[key], f"{name}: L2 {key}({v['a']},{v['b']})"
+
+
+@pytest.mark.parametrize("name", KEYS)
+def test_multconst_golden(name):
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    cts = [e["ct"] for e in fx["encrypt"]]
+    l2 = [v["out"] for v in fx["mult"]]
+    for lvl, key, src in [(1, "multconst_l1", cts), (2, "multconst_l2", l2)]:
+        out = pk.engine.multconst(lvl, H([src[v["a"]] for v in fx[key]]), [int(v["k"], 16) for v in fx[key]])
+        for row, v in zip(out, fx[key]):
+            assert bytes(row).hex() == v["out"], f"{name}: MultConst L{lvl} k={v['k']}"
+
+
+@pytest.mark.parametrize("name", ["toy64", "k256"])
+def test_blinded_ops_vs_oracle(name):
+    """Non-deterministic mode with explicit randomness (bgn.go:302-311, 466-474, 488-495, 260-288)."""
+    fx = load_fixture(name)
+    opk, _ = oracle_key(fx)
+    opk.Deterministic = False
+    pk, _ = engine_key(fx)
+    rng = random.Random(77)
+    dec = lambda h: None if int(h, 16) == 0 else R.elem_from_bytes(bytes.fromhex(h), opk.p)
+    cts = [R.Ciphertext(dec(e["ct"]), False) for e in fx["encrypt"]]
+    w = lambda c: R.elem_to_bytes(c.C, opk.p)
+    idx = [(1, 2), (3, 4), (0, 5), (6, 6)]
+    rs = [rng.randrange(opk.n) for _ in idx]
+    A = b"".join(w(cts[i]) for i, _ in idx)
+    B = b"".join(w(cts[k]) for _, k in idx)
+    got = pk.engine.add(1, A, B, rs)
+    for row, (i, k), r in zip(got, idx, rs):
+        assert bytes(row) == w(opk.Add(cts[i], cts[k], r))
+    got = pk.engine.mult(A, B, rs)
+    l2 = []
+    for row, (i, k), r in zip(got, idx, rs):
+        c = opk.Mult(cts[i], cts[k], r)
+        l2.append(c)
+        assert bytes(row) == w(c)
+    A2 = b"".join(w(c) for c in l2)
+    got = pk.engine.sub(2, A2, A2[::-1][: len(A2)][::-1], rs)          # a - a, blinded
+    for row, c, r in zip(got, l2, rs):
+        assert bytes(row) == w(opk.Sub(c, c, r))
+    got = pk.engine.multconst(1, A, [3, 0, 77, 5], rs)
+    for row, (i, _), k, r in zip(got, idx, [3, 0, 77, 5], rs):
+        assert bytes(row) == w(opk.MultConst(cts[i], k, r))
+    got = pk.engine.multconst(2, A2, [3, 0, 77, 5], rs)
+    for row, c, k, r in zip(got, l2, [3, 0, 77, 5], rs):
+        assert bytes(row) == w(opk.MultConst(c, k, r))
+    opk.Deterministic = True
+
+
+def test_aggregate_identity_gpu():
+    """gadgets_test.go:24-46 on the engine: Add(Enc(v1,r1),Enc(v2,r2)) == Enc(v1+v2, r1+r2) with v, r < N
+    (so the exponents of the right-hand side exceed N)."""
+    fx = load_fixture("k512")
+    pk, _ = engine_key(fx)
+    n = pk.N
+    rng = random.Random(5)
+    v1, r1, v2, r2 = (rng.randrange(n) for _ in range(4))
+    c1, c2 = pk.EncryptWithRandomness(v1, r1), pk.EncryptWithRandomness(v2, r2)
+    assert pk.Add(c1, c2).C == pk.EncryptWithRandomness(v1 + v2, r1 + r2).C
+
+
+@pytest.mark.parametrize("name,count", [("toy64", 70001), ("k256", 3000)])
+def test_l1_add_large_ragged_vs_c_oracle(name, count):
+    """More than one element per lane (batched inversion runs > 1) and a ragged tail,
+    with identities, doublings and cancellations sprinkled in."""
+    import oracle_c
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    E = pk.engine.elem_bytes
+    rng = random.Random(42)
+    pool = [o.encrypt([rng.randrange(1 << 30)], [rng.randrange(int(fx["n"], 16))]) for _ in range(12)]
+    pool.append(bytes(E))                                   # identity
+    ia = [rng.randrange(len(pool)) for _ in range(count)]
+    ib = [rng.randrange(len(pool)) for _ in range(count)]
+    a = b"".join(pool[i] for i in ia)
+    b = b"".join(pool[i] for i in ib)
+    assert pk.engine.add(1, a, b).tobytes() == o.add(1, a, b)
+    assert pk.engine.sub(1, a, b).tobytes() == o.add(1, a, b, True)
+
+
+@pytest.mark.parametrize("name,count", [("toy64", 900), ("k512", 130)])
+def test_encrypt_random_vs_c_oracle(name, count):
+    import oracle_c
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    rng = random.Random(7)
+    n = int(fx["n"], 16)
+    xs = [rng.randrange(1 << 40) % n for _ in range(count)]
+    rs = [rng.randrange(n) for _ in range(count)]
+    assert pk.engine.encrypt(xs, rs).tobytes() == o.encrypt(xs, rs)

@@ -1,0 +1,274 @@
+// bsgs.hpp — batched discrete-log decryption (gsbs.go) and the MultPoly
+// accumulation (poly.go:147-149).
+//
+// Reference: getDL (gsbs.go:54-106) walks aux = csk / gamma^i serially and looks
+// the decimal *string* of aux up in a sync.Map of ceil(sqrt(T))+2 baby steps, for
+// G1 and GT separately; recoverMessage / decrypt (bgn.go:218-250, :357-372) add
+// the identity short-cut and the negative retry.
+//
+// Here (results are identical because the plaintext m with gsk^m = csk is unique):
+//   * every decryption runs in GT: a level-1 ciphertext is first lifted with
+//     e(C, P) (the makeL2 kernel), since e(C^sk, P) = (e(P,P)^sk)^m has the same
+//     m and a GT giant step costs 3 field products against ~20 for an affine
+//     G1 step;
+//   * the baby table lives in HBM as an open-addressing hash of 96-bit
+//     fingerprints of the canonical real part; because GT has norm 1,
+//     conj(g^j) = g^-j shares its real part with g^j, so one probe covers +-j
+//     (the parity of the imaginary part, stored with j, tells which);
+//   * baby/giant sizes are re-balanced for 288 GB of HBM: S = up to 2^26 baby
+//     steps, G = ceil((Mmax+1)/S) giant steps, where Mmax = B*B + B + 2,
+//     B = ceil(sqrt(T)), is exactly the largest value the reference's loops can
+//     return; candidates outside [1, Mmax] are rejected so the accept / error
+//     behaviour matches gsbs.go:77-105 and the retry rule bgn.go:235-242.
+#pragma once
+#include "kernels.hpp"
+#include "ops.hpp"
+
+namespace bgn {
+
+
+
+__device__ __forceinline__ unsigned long long bsgs_mix(unsigned long long x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// 96-bit fingerprint of a canonical value (limbs 0..3 and 4 bits of limb 4)
+template <int NL>
+__device__ __forceinline__ void bsgs_fingerprint(unsigned long long& key, u32& check, const Fp<NL>& c) {
+  u64 k = (u64)c.v[0] | ((u64)c.v[1] << 28);
+  if (NL > 2) k |= (u64)c.v[2] << 56;
+  key = k | (1ull << 63);
+  u32 ck = 0;
+  if (NL > 3) ck = c.v[3];
+  if (NL > 4) ck |= c.v[4] << 28;
+  if (NL <= 3) ck = c.v[2] >> 8;
+  check = ck;
+}
+
+// (r0, r1) = (a0 + i a1) * K with the constant K in LDS rows: L[1] = K0, L[2] = K1,
+// L[3] = K0 + K1 (K canonical <1).  a0 <4, a1 <6 ; r0 <4, r1 <6.
+template <int NL>
+__device__ __forceinline__ void fp2_mul_const(Fp<NL>& r0, Fp<NL>& r1, const Fp<NL>& a0, const Fp<NL>& a1, LFp<NL>* L,
+                                              const FpParams<NL>* __restrict__ P) {
+  Fp<NL> v0, v1, s;
+  fp_add(s, a0, a1);                        // <10
+  fp_mul(v0, L + 1, a0, P);                 // <2
+  fp_mul(v1, L + 2, a1, P);                 // <2
+  fp_mul(s, L + 3, s, P);                   // <2   (2*10)
+  fp_sub<2>(r0, v0, v1, P);                 // <4
+  fp_add(v0, v0, v1);                       // <4
+  fp_sub<4>(r1, s, v0, P);                  // <6
+}
+
+template <int NL>
+__device__ __forceinline__ void load_const_rows(LFp<NL>* L, const u32* k0, const u32* k1) {
+  Fp<NL> b0, b1, s;
+  g_load<NL>(b0, k0, 1, 0);
+  g_load<NL>(b1, k1, 1, 0);
+  fp_add(s, b0, b1);
+  l_store(L + 1, b0);
+  l_store(L + 2, b1);
+  l_store(L + 3, s);
+}
+
+// base^e for a per-lane 64-bit exponent; base in LDS rows (L[1..3]).  Result (<4, <6).
+template <int NL>
+__device__ __forceinline__ void gt_pow_u64(Fp<NL>& r0, Fp<NL>& r1, unsigned long long e, LFp<NL>* L,
+                                           const FpParams<NL>* __restrict__ P) {
+  AFp<NL> A0, A1;
+  {
+    Fp<NL> t;
+    fp_set(t, P->one);
+    a_store(A0, t);
+    fp_zero(t);
+    a_store(A1, t);
+  }
+  bool started = false;
+#pragma unroll 1
+  for (int i = 63; i >= 0; --i) {
+    if (__ballot(started)) {
+      Fp<NL> a0, a1, s0, s1;
+      a_load(a0, A0);
+      a_load(a1, A1);
+      fp2_sqr_v(s0, s1, a0, a1, P, L);
+      a_store(A0, s0);
+      a_store(A1, s1);
+    }
+    const bool bit = (e >> i) & 1ull;
+    if (__ballot(bit)) {
+      Fp<NL> a0, a1, m0, m1;
+      a_load(a0, A0);
+      a_load(a1, A1);
+      fp2_mul_const(m0, m1, a0, a1, L, P);
+      fp_select(m0, bit, m0, a0);
+      fp_select(m1, bit, m1, a1);
+      a_store(A0, m0);
+      a_store(A1, m1);
+    }
+    started = started || bit;
+  }
+  a_load(r0, A0);
+  a_load(r1, A1);
+}
+
+// Table build: lane t inserts g^j for j in [t*chunk, (t+1)*chunk) and j < S.
+// Replaces computeTableGT (gsbs.go:28-37) and makes computeTableG1 unnecessary.
+template <int NL>
+__device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned long long chunk, LFp<NL>* L,
+                                                const FpParams<NL>* __restrict__ P) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const unsigned long long j0 = t * chunk;
+  load_const_rows<NL>(L, B.g0, B.g1);
+  Fp<NL> a0, a1;
+  gt_pow_u64<NL>(a0, a1, j0, L, P);
+#pragma unroll 1
+  for (unsigned long long c = 0; c < chunk; ++c) {
+    const unsigned long long j = j0 + c;
+    if (j < B.S) {
+      Fp<NL> re, im;
+      fp_reduce8(re, a0, P);
+      fp_reduce8(im, a1, P);
+      unsigned long long key;
+      u32 check;
+      bsgs_fingerprint<NL>(key, check, re);
+      const u32 val = ((u32)j << 1) | (im.v[0] & 1u);
+      unsigned long long h = bsgs_mix(key) & B.mask;
+      for (;;) {
+        const unsigned long long old = atomicCAS(&B.table[h].key, 0ull, key);
+        if (old == 0ull) {
+          B.table[h].check = check;
+          B.table[h].val = val;
+          break;
+        }
+        h = (h + 1) & B.mask;
+      }
+    }
+    Fp<NL> m0, m1;
+    fp2_mul_const(m0, m1, a0, a1, L, P);
+    a0 = m0;
+    a1 = m1;
+  }
+}
+
+// Search: find m in [1, Mmax] with g^m = x (x canonical Montgomery in HBM).
+// mode 0: first attempt on x ; mode 1: retry on conj(x) for the elements listed
+// in `todo` (the ones the first attempt did not resolve), result negated
+// (bgn.go:235-242).  status 0 = found, 1 = "cannot find discrete log".
+
+template <int NL>
+__device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const BsgsSearchArgs& A, LFp<NL>* L,
+                                                 const FpParams<NL>* __restrict__ P) {
+  size_t lane = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  size_t n = A.count;
+  if (A.mode == 1) n = *A.todo_count;
+  bool live = lane < n;
+  if (!__ballot(live)) return;                 // whole wave idle
+  if (!live) lane = 0;
+  const size_t e = (A.mode == 1) ? (n ? A.todo[lane] : 0) : lane;
+  load_const_rows<NL>(L, B.gi0, B.gi1);
+  Fp<NL> a0, a1;
+  g_load<NL>(a0, A.x0, A.sx, e);
+  g_load<NL>(a1, A.x1, A.sx, e);
+  if (A.mode == 1) {
+    fp_neg<1>(a1, a1, P);                     // conj(x) = x^-1 on GT: Neg(ct), bgn.go:236
+    fp_reduce8(a1, a1, P);
+  }
+  bool done = !live;
+  bool found = false;
+  long long result = 0;
+  {
+    Fp<NL> one;
+    fp_set(one, P->one);
+    if (fp_eq_limbs(a0, one) && fp_is_zero_limbs(a1)) {   // zero.Equals(csk), bgn.go:359-363
+      found = true;
+      done = true;
+    }
+  }
+#pragma unroll 1
+  for (unsigned long long i = 0; i < B.G; ++i) {
+    if (!__ballot(!done)) break;
+    Fp<NL> re;
+    fp_reduce8(re, a0, P);
+    unsigned long long key;
+    u32 check;
+    bsgs_fingerprint<NL>(key, check, re);
+    if (!done) {
+      unsigned long long h = bsgs_mix(key) & B.mask;
+      for (;;) {
+        const BsgsSlot s = B.table[h];
+        if (s.key == 0ull) break;
+        if (s.key == key && s.check == check) {
+          Fp<NL> im;
+          fp_reduce8(im, a1, P);
+          const long long j = (long long)(s.val >> 1);
+          const bool same = ((im.v[0] & 1u) == (s.val & 1u)) || fp_is_zero_limbs(im);
+          const long long m = (long long)(i * B.S) + (same ? j : -j);
+          if (m >= 1 && (unsigned long long)m <= B.Mmax) {
+            found = true;
+            result = m;
+          }
+          done = true;       // m is unique: a hit outside [1, Mmax] means this attempt fails
+          break;
+        }
+        h = (h + 1) & B.mask;
+      }
+    }
+    Fp<NL> m0, m1;
+    fp2_mul_const(m0, m1, a0, a1, L, P);       // aux.Div(aux, gamma), gsbs.go:102
+    a0 = m0;
+    a1 = m1;
+  }
+  if (live) {
+    if (found) {
+      A.m[e] = (A.mode == 1) ? -result : result;
+      A.status[e] = 0;
+    } else if (A.mode == 0) {
+      A.m[e] = 0;
+      A.status[e] = 1;
+      const u32 slot = atomicAdd(A.todo_count, 1u);
+      A.todo[slot] = (u32)e;
+    }
+  }
+}
+
+// MultPoly accumulation (poly.go:147-149): out[q][s] = prod_{i+k=s} E[q][i][k].
+
+template <int NL>
+__device__ __forceinline__ void poly_acc_lane(const PolyAccArgs& A, size_t lane, bool live, LFp<NL>* L,
+                                              const FpParams<NL>* __restrict__ P) {
+  const size_t deg = A.d1 + A.d2;
+  const size_t q = lane / deg, s = lane % deg;
+  Fp<NL> a0, a1;
+  fp_set(a0, P->one);                        // makeL2(encryptZero()) = 1, poly.go:134
+  fp_zero(a1);
+#pragma unroll 1
+  for (size_t i = 0; i < A.d1; ++i) {
+    const bool term = live && s >= i && (s - i) < A.d2;
+    if (__ballot(term)) {
+      const size_t idx = term ? ((q * A.d1 + i) * A.d2 + (s - i)) : 0;
+      Fp<NL> b0, b1, sm;
+      g_load<NL>(b0, A.e0, A.se, idx);
+      g_load<NL>(b1, A.e1, A.se, idx);
+      fp_add(sm, b0, b1);
+      l_store(L + 1, b0);
+      l_store(L + 2, b1);
+      l_store(L + 3, sm);
+      Fp<NL> m0, m1;
+      fp2_mul_const(m0, m1, a0, a1, L, P);
+      fp_select(a0, term, m0, a0);
+      fp_select(a1, term, m1, a1);
+    }
+  }
+  Fp<NL> o;
+  fp_from_mont<NL>(o, a0, P, L);
+  if (live) g_store<NL>(A.o0, A.so, lane, o);
+  fp_from_mont<NL>(o, a1, P, L);
+  if (live) g_store<NL>(A.o1, A.so, lane, o);
+}
+
+}  // namespace bgn

@@ -60,6 +60,12 @@ struct bgn_ctx {
   // secret / decryption state
   bool have_secret = false;
   BigU q1;
+  uint8_t* d_sk = nullptr;             // q1, big-endian bytes, on the device
+  size_t sk_len = 0;
+  uint32_t* d_gt = nullptr;            // g.re, g.im, gamma^-1.re, gamma^-1.im : 4 * nl limbs (Montgomery)
+  BsgsSlot* d_table = nullptr;
+  BsgsParams bsgs{};
+  bool have_tables = false;
 
   // workspace arena (device)
   std::mutex mu;
@@ -171,6 +177,9 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_consts) (void)hipFree(c->d_consts);
   if (c->d_keypts) (void)hipFree(c->d_keypts);
   if (c->d_keywire) (void)hipFree(c->d_keywire);
+  if (c->d_sk) (void)hipFree(c->d_sk);
+  if (c->d_gt) (void)hipFree(c->d_gt);
+  if (c->d_table) (void)hipFree(c->d_table);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -280,16 +289,85 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
 
 int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   if (!c || !q1_be || !q1_len) return fail(BGN_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
   c->q1 = BigU::from_be(q1_be, q1_len);
+  if (c->q1.is_zero()) return fail(BGN_E_ARG, "secret key is zero");
+  if (c->d_sk) (void)hipFree(c->d_sk);
+  c->d_sk = nullptr;
+  HIP_TRY(hipMalloc((void**)&c->d_sk, q1_len));
+  HIP_TRY(hipMemcpy(c->d_sk, q1_be, q1_len, hipMemcpyHostToDevice));
+  c->sk_len = q1_len;
   c->have_secret = true;
+  c->have_tables = false;
   return BGN_OK;
 }
 
+// forward declarations of launch helpers defined further down
+namespace {
+void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b);
+void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
+                   size_t count);
+}
+
 int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
-  (void)msg_space;
   if (!c) return fail(BGN_E_ARG, "null context");
   if (!c->have_secret) return fail(BGN_E_STATE, "secret key not set");
-  return fail(BGN_E_STATE, "decryption tables: not implemented in this build");
+  if (msg_space < 1 || msg_space > ((uint64_t)1 << 60)) return fail(BGN_E_ARG, "message space out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const KernelTable* kt = c->kt;
+  // gsbs.go:60: bound = ceil(sqrt(T)); getDL returns i*bound + v + 1 <= bound*bound + bound + 2
+  double sq = __builtin_sqrt((double)msg_space);
+  uint64_t B = (uint64_t)sq;
+  if ((double)B < sq) B++;
+  const uint64_t Mmax = B * B + B + 2;
+  uint64_t S = 2;
+  while (S < Mmax + 1 && S < ((uint64_t)1 << 26)) S <<= 1;
+  const uint64_t G = (Mmax + S) / S + 1;
+  const uint64_t slots = (2 * S < 64) ? 64 : 2 * S;
+
+  if (c->d_table) (void)hipFree(c->d_table);
+  c->d_table = nullptr;
+  if (!c->d_gt) HIP_TRY(hipMalloc((void**)&c->d_gt, (size_t)4 * c->nl * 4));
+  HIP_TRY(hipMalloc((void**)&c->d_table, slots * sizeof(BsgsSlot)));
+  HIP_TRY(hipMemset(c->d_table, 0, slots * sizeof(BsgsSlot)));
+  // scratch: two single GT elements and an 8-byte scalar
+  int rc = ensure_arena(c, 1 << 16);
+  if (rc) return rc;
+  Carver cv(c->arena);
+  SoA2 t1 = cv.soa(c->nl, 1, false), t2 = cv.soa(c->nl, 1, false);
+  uint8_t* d_scalar = (uint8_t*)cv.take(8);
+  const int nl = c->nl;
+  SoA2 g{c->d_gt, c->d_gt + nl, nullptr, 1}, gi{c->d_gt + 2 * nl, c->d_gt + 3 * nl, nullptr, 1};
+  // g = e(P,P)^sk  (bgn.go:198-199)
+  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0);
+  kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
+  gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
+  kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
+  // gamma^-1 = conj(g^S)
+  uint8_t sbe[8];
+  for (int i = 0; i < 8; ++i) sbe[i] = (uint8_t)(S >> (8 * (7 - i)));
+  HIP_TRY(hipMemcpy(d_scalar, sbe, 8, hipMemcpyHostToDevice));
+  gt_pow_launch(c, nullptr, g, d_scalar, 0, 8, t2, 1);
+  kt->to_mont(nullptr, c->d_params, t2.c0, t2.c1, 1, 1);
+  gt_mul_launch(c, nullptr, c->gt_one(), t2, gi, 1, true);
+  kt->to_mont(nullptr, c->d_params, gi.c0, gi.c1, 1, 1);
+  BsgsParams bp;
+  bp.table = c->d_table;
+  bp.mask = slots - 1;
+  bp.S = S;
+  bp.G = G;
+  bp.Mmax = Mmax;
+  bp.g0 = g.c0; bp.g1 = g.c1; bp.gi0 = gi.c0; bp.gi1 = gi.c1;
+  c->bsgs = bp;
+  uint64_t chunk = S / 65536;
+  if (chunk < 1) chunk = 1;
+  const size_t lanes = (size_t)((S + chunk - 1) / chunk);
+  kt->bsgs_build(nullptr, c->d_params, bp, chunk, lanes);     // computeTableGT, gsbs.go:28-37
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  c->have_tables = true;
+  return BGN_OK;
 }
 
 // ---- Mult / makeL2 / MultPoly -------------------------------------------------------
@@ -764,12 +842,135 @@ int bgn_multconst_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, c
   return S.down(out, dout, eb);
 }
 
-// ---- not yet implemented entry points (filled in as the kernels land) ----------------
-#define NOT_YET(name) return fail(BGN_E_STATE, name ": not implemented in this build")
-int bgn_decrypt_batch(bgn_ctx*, size_t, int, const uint8_t*, int64_t*, uint8_t*) { NOT_YET("decrypt"); }
-int bgn_poly_mult_batch(bgn_ctx*, size_t, size_t, size_t, const uint8_t*, const uint8_t*, uint8_t*) { NOT_YET("poly_mult"); }
-int bgn_decrypt_batch_dev(bgn_ctx*, size_t, int, const uint8_t*, int64_t*, uint8_t*, void*) { NOT_YET("decrypt"); }
-int bgn_poly_mult_batch_dev(bgn_ctx*, size_t, size_t, size_t, const uint8_t*, const uint8_t*, uint8_t*, void*) { NOT_YET("poly_mult"); }
+// ---- Decrypt ---------------------------------------------------------------------------------
+int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status,
+                          void* stream) {
+  if (!c || (count && (!ct || !m || !status))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!c->have_secret) return fail(BGN_E_STATE, "secret key not set");
+  if (!c->have_tables) return fail(BGN_E_STATE, "DL tables not computed!");          // gsbs.go:56-58 (panic)
+  if (!count) return BGN_OK;
+  if (count > 0xffffffffull) return fail(BGN_E_ARG, "batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t st = round_up(count, 64);
+  SoA2 A, X, Y;
+  uint32_t* todo = nullptr;
+  uint32_t* todo_count = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    A = (level == 1) ? w.g1(st) : w.gt(st);
+    X = w.gt(st);
+    Y = w.gt(st);
+    todo = (uint32_t*)w.cv.take(st * 4);
+    todo_count = (uint32_t*)w.cv.take(256);
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  const KernelTable* kt = c->kt;
+  kt->decode(s, c->d_params, ct, c->L, count, A);
+  SoA2 base = A;
+  if (level == 1) {
+    // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp)
+    kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0);
+    kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
+    base = X;
+  }
+  gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);                        // csk.PowBig(ct.C, sk.Key), bgn.go:223
+  kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
+  HIP_TRY(hipMemsetAsync(todo_count, 0, 4, s));
+  BsgsSearchArgs a;
+  a.x0 = Y.c0; a.x1 = Y.c1; a.sx = Y.stride;
+  a.m = (long long*)m; a.status = status;
+  a.todo = todo; a.todo_count = todo_count;
+  a.count = count;
+  a.mode = 0;
+  HIP_TRY(hipEventRecord(c->ev0, s));
+  kt->bsgs_search(s, c->d_params, c->bsgs, a);                                       // getDL, gsbs.go:54-106
+  a.mode = 1;
+  kt->bsgs_search(s, c->d_params, c->bsgs, a);                                       // retry on Neg(ct), bgn.go:235-242
+  HIP_TRY(hipEventRecord(c->ev1, s));
+  c->ev_valid = true;
+  c->last_kernel = kt->bsgs_kernel_name;
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+int bgn_decrypt_batch(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status) {
+  if (!c || (count && (!ct || !m || !status))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  Staged S;
+  S.bufs.reserve(3);
+  uint8_t *dct = nullptr, *dst = nullptr;
+  int64_t* dm = nullptr;
+  UP(ct, count * 2 * (size_t)c->L, dct);
+  UP(nullptr, count * 8, dm);
+  UP(nullptr, count, dst);
+  int rc = bgn_decrypt_batch_dev(c, count, level, dct, dm, dst, nullptr);
+  if (rc) return rc;
+  if ((rc = S.down(m, dm, count * 8))) return rc;
+  return S.down(status, dst, count);
+}
+
+// ---- MultPoly --------------------------------------------------------------------------------
+int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                            uint8_t* out, void* stream) {
+  if (!c || (npoly && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!npoly) return BGN_OK;
+  if (!d1 || !d2) return fail(BGN_E_ARG, "polynomial degrees must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t na = npoly * d1, nb = npoly * d2, np = npoly * d1 * d2, no = npoly * (d1 + d2);
+  const size_t sa = round_up(na, 64), sb = round_up(nb, 64), sp = round_up(np, 64), so = round_up(no, 64);
+  SoA2 A, Bv, E, O;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    A = w.g1(sa); Bv = w.g1(sb); E = w.gt(sp); O = w.gt(so);
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  const KernelTable* kt = c->kt;
+  kt->decode(s, c->d_params, a, c->L, na, A);
+  kt->decode(s, c->d_params, b, c->L, nb, Bv);
+  HIP_TRY(hipEventRecord(c->ev0, s));
+  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2);                 // pk.Mult(coeff1, coeff2), poly.go:146
+  HIP_TRY(hipEventRecord(c->ev1, s));
+  c->ev_valid = true;
+  c->last_kernel = kt->pairing_kernel_name;
+  kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, np);
+  PolyAccArgs pa;
+  pa.e0 = E.c0; pa.e1 = E.c1; pa.se = E.stride;
+  pa.o0 = O.c0; pa.o1 = O.c1; pa.so = O.stride;
+  pa.npoly = npoly; pa.d1 = d1; pa.d2 = d2;
+  kt->poly_acc(s, c->d_params, pa);                                                  // result[i+k] = Add(result[i+k], coeff), poly.go:148
+  kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, no, out);
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+int bgn_poly_mult_batch(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                        uint8_t* out) {
+  if (!c || (npoly && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!npoly) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t E = 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(3);
+  uint8_t *da = nullptr, *db = nullptr, *dout = nullptr;
+  UP(a, npoly * d1 * E, da);
+  UP(b, npoly * d2 * E, db);
+  UP(nullptr, npoly * (d1 + d2) * E, dout);
+  int rc = bgn_poly_mult_batch_dev(c, npoly, d1, d2, da, db, dout, nullptr);
+  if (rc) return rc;
+  return S.down(out, dout, npoly * (d1 + d2) * E);
+}
 
 double bgn_last_kernel_ms(bgn_ctx* c) {
   if (!c || !c->ev_valid) return -1.0;

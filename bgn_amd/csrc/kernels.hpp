@@ -53,6 +53,38 @@ struct GtPowArgs {
   size_t count;
 };
 
+
+// Discrete-log decryption and MultPoly accumulation (bsgs.hpp).
+struct BsgsSlot {
+  unsigned long long key;   // 0 = empty; bit 63 forced to 1
+  uint32_t check;
+  uint32_t val;                  // (j << 1) | parity(im)
+};
+
+struct BsgsParams {
+  BsgsSlot* table;
+  unsigned long long mask;          // slots - 1 (power of two)
+  unsigned long long S;             // baby steps
+  unsigned long long G;             // giant steps
+  unsigned long long Mmax;          // largest accepted |m|
+  const uint32_t* g0; const uint32_t* g1;     // g = e(P,P)^sk, canonical Montgomery, stride 1
+  const uint32_t* gi0; const uint32_t* gi1;   // gamma^-1 = conj(g^S), canonical Montgomery, stride 1
+};
+
+struct BsgsSearchArgs {
+  const uint32_t* x0; const uint32_t* x1; size_t sx;
+  long long* m; uint8_t* status;
+  uint32_t* todo; uint32_t* todo_count;       // compacted indices of unresolved elements
+  size_t count;
+  int mode;
+};
+
+struct PolyAccArgs {
+  const uint32_t* e0; const uint32_t* e1; size_t se;   // pairings, canonical Montgomery, index (q*d1 + i)*d2 + k
+  uint32_t* o0; uint32_t* o1; size_t so;               // plain canonical, index q*(d1+d2) + s
+  size_t npoly, d1, d2;
+};
+
 struct KernelTable {
   int nl;
   size_t params_bytes;   // sizeof(FpParams<NL>)
@@ -75,6 +107,10 @@ struct KernelTable {
   void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
   void (*gt_mul)(hipStream_t s, const void* params, GtMulArgs a);
   void (*gt_pow)(hipStream_t s, const void* params, GtPowArgs a);
+  void (*bsgs_build)(hipStream_t s, const void* params, BsgsParams b, unsigned long long chunk, size_t lanes);
+  void (*bsgs_search)(hipStream_t s, const void* params, BsgsParams b, BsgsSearchArgs a);
+  void (*poly_acc)(hipStream_t s, const void* params, PolyAccArgs a);
+  const char* bsgs_kernel_name;
 };
 
 const KernelTable* kernel_table_nl3();

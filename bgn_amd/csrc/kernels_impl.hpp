@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "ops.hpp"
 #include "codec.hpp"
+#include "bsgs.hpp"
 
 namespace bgn {
 
@@ -159,6 +160,31 @@ k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
   if (live) g_store<NL>(A.o1, A.so, e, o);
 }
 
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_bsgs_build(const FpParams<NL>* __restrict__ P, BsgsParams B, unsigned long long chunk) {
+  __shared__ LFp<NL> L[4];
+  bsgs_build_lane<NL>(B, chunk, L, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_bsgs_search(const FpParams<NL>* __restrict__ P, BsgsParams B, BsgsSearchArgs A) {
+  __shared__ LFp<NL> L[4];
+  bsgs_search_lane<NL>(B, A, L, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_poly_acc(const FpParams<NL>* __restrict__ P, PolyAccArgs A) {
+  __shared__ LFp<NL> L[4];
+  const size_t total = A.npoly * (A.d1 + A.d2);
+  size_t lane = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = lane < total;
+  if (!live) lane = total - 1;
+  poly_acc_lane<NL>(A, lane, live, L, P);
+}
+
 // ---- launchers ------------------------------------------------------------------
 static inline unsigned grid_for(size_t count) { return (unsigned)((count + FP_BLOCK - 1) / FP_BLOCK); }
 
@@ -210,6 +236,24 @@ static void launch_gt_pow(hipStream_t s, const void* params, GtPowArgs a) {
   hipLaunchKernelGGL(k_gt_pow<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
 }
 
+static void launch_bsgs_build(hipStream_t s, const void* params, BsgsParams b, unsigned long long chunk, size_t lanes) {
+  if (!lanes) return;
+  hipLaunchKernelGGL(k_bsgs_build<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, b,
+                     chunk);
+}
+
+static void launch_bsgs_search(hipStream_t s, const void* params, BsgsParams b, BsgsSearchArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_bsgs_search<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, b,
+                     a);
+}
+
+static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
+  const size_t total = a.npoly * (a.d1 + a.d2);
+  if (!total) return;
+  hipLaunchKernelGGL(k_poly_acc<NL_>, dim3(grid_for(total)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
+}
+
 #define BGN_CAT2(a, b) a##b
 #define BGN_CAT(a, b) BGN_CAT2(a, b)
 #define BGN_STR2(x) #x
@@ -228,6 +272,10 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_g1_mul,
       launch_gt_mul,
       launch_gt_pow,
+      launch_bsgs_build,
+      launch_bsgs_search,
+      launch_poly_acc,
+      "k_bsgs_search<" BGN_STR(BGN_NL) ">",
   };
   return &t;
 }

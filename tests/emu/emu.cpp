@@ -11,6 +11,7 @@ thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 
 
 #include "ops.hpp"
 #include "codec.hpp"
+#include "bsgs.hpp"
 
 using namespace bgn;
 
@@ -123,6 +124,55 @@ struct Emu {
     fp_from_mont<NL>(o, r1, P, L);
     memcpy(out + NL, o.v, 4 * NL);
   }
+  // BSGS: build the table for (g, S) in one lane, then search each x (Montgomery limbs, 2*NL each)
+  static void bsgs(const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G,
+                   unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    unsigned long long slots = 2 * S < 64 ? 64 : 2 * S;
+    std::vector<BsgsSlot> table(slots);
+    memset(table.data(), 0, slots * sizeof(BsgsSlot));
+    BsgsParams B;
+    B.table = table.data(); B.mask = slots - 1; B.S = S; B.G = G; B.Mmax = Mmax;
+    B.g0 = g; B.g1 = g + NL; B.gi0 = gi; B.gi1 = gi + NL;
+    blockIdx.x = 0;
+    bsgs_build_lane<NL>(B, S, lds(), P);
+    std::vector<u32> todo(count + 1);
+    u32 todo_count = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+      const int n = mode ? (int)todo_count : count;
+      for (int i = 0; i < n; ++i) {
+        // one lane per element: emulate lane index through blockIdx (FP_BLOCK lanes per block, thread 0)
+        // -> give every element its own SoA with stride 1 instead
+        const int e = mode ? (int)todo[i] : i;
+        BsgsSearchArgs A;
+        A.x0 = xs + (size_t)e * 2 * NL; A.x1 = A.x0 + NL; A.sx = 1;
+        long long mm = 0; uint8_t st = 9;
+        u32 one_todo[1] = {0}; u32 one_count = mode ? 1u : 0u;
+        A.m = &mm; A.status = &st; A.todo = one_todo; A.todo_count = &one_count; A.count = 1; A.mode = mode;
+        bsgs_search_lane<NL>(B, A, lds(), P);
+        if (mode == 0) {
+          m[e] = mm; status[e] = st;
+          if (one_count) todo[todo_count++] = (u32)e;
+        } else if (st == 0) {
+          m[e] = mm; status[e] = 0;
+        }
+      }
+    }
+  }
+  static void poly_acc(const u32* params, const u32* E, int d1, int d2, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    // E: d1*d2 elements (2*NL limbs each, Montgomery) -> SoA stride n
+    const size_t n = (size_t)d1 * d2, deg = d1 + d2;
+    std::vector<u32> e0(NL * n), e1(NL * n), o0(NL * deg), o1(NL * deg);
+    for (size_t i = 0; i < n; ++i)
+      for (int l = 0; l < NL; ++l) { e0[l * n + i] = E[i * 2 * NL + l]; e1[l * n + i] = E[i * 2 * NL + NL + l]; }
+    PolyAccArgs A;
+    A.e0 = e0.data(); A.e1 = e1.data(); A.se = n; A.o0 = o0.data(); A.o1 = o1.data(); A.so = deg;
+    A.npoly = 1; A.d1 = d1; A.d2 = d2;
+    for (size_t s = 0; s < deg; ++s) poly_acc_lane<NL>(A, s, true, lds(), P);
+    for (size_t s = 0; s < deg; ++s)
+      for (int l = 0; l < NL; ++l) { out[s * 2 * NL + l] = o0[l * deg + s]; out[s * 2 * NL + NL + l] = o1[l * deg + s]; }
+  }
 };
 
 #define DISPATCH(nl, call)            \
@@ -143,5 +193,7 @@ int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_
 int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, out, oinf)) }
 int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, out)) }
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
+int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }
+int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
 size_t emu_consts_size() { return sizeof(PairingConsts); }
 }

@@ -18,7 +18,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp")]
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "kernels.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), os.path.join(_HERE, "emu.cpp"),
@@ -136,6 +136,46 @@ class Emu:
         out = (C.c_uint32 * (2 * self.nl))()
         assert self.lib.emu_gt_mul(self.nl, self.params, A, B, 1 if conj_b else 0, out) == 0
         return self.encode(out)
+
+    def bsgs(self, g_wire: bytes, msg_space: int, xs_wire, S=None):
+        """Build the table for generator g and search every x (GT wire bytes).  Returns (m list, status list)."""
+        import math
+        B = int(math.ceil(math.sqrt(float(msg_space))))
+        Mmax = B * B + B + 2
+        if S is None:
+            S = 2
+            while S < Mmax + 1 and S < (1 << 26):
+                S <<= 1
+        G = (Mmax + S) // S + 1
+        g, _ = self.decode(g_wire)
+        gS = self.gt_pow(g_wire, S, 8)
+        L = self.L
+        conj = gS[:L] + ((self.p - int.from_bytes(gS[L:], "big")) % self.p).to_bytes(L, "big")
+        gi, _ = self.decode(conj)
+        n = len(xs_wire)
+        xs = (C.c_uint32 * (2 * self.nl * n))()
+        for j, w in enumerate(xs_wire):
+            x, _ = self.decode(w)
+            xs[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
+        m = (C.c_longlong * n)()
+        st = (C.c_uint8 * n)()
+        assert self.lib.emu_bsgs(self.nl, self.params, g, gi, C.c_ulonglong(S), C.c_ulonglong(G), C.c_ulonglong(Mmax),
+                                 xs, n, m, st) == 0
+        return list(m), list(st)
+
+    def poly_acc(self, E_wire, d1: int, d2: int):
+        n = d1 * d2
+        E = (C.c_uint32 * (2 * self.nl * n))()
+        for j, w in enumerate(E_wire):
+            x, _ = self.decode(w)
+            E[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
+        out = (C.c_uint32 * (2 * self.nl * (d1 + d2)))()
+        assert self.lib.emu_poly_acc(self.nl, self.params, E, d1, d2, out) == 0
+        res = []
+        for s in range(d1 + d2):
+            pl = (C.c_uint32 * (2 * self.nl))(*out[2 * self.nl * s:2 * self.nl * (s + 1)])
+            res.append(self.encode(pl))
+        return res
 
     def gt_pow(self, a: bytes, k: int, klen: int = None) -> bytes:
         A, _ = self.decode(a)

@@ -15,3 +15,13 @@ struct EmuDim3 { unsigned x, y, z; };
 extern thread_local EmuDim3 threadIdx, blockIdx, gridDim, blockDim;
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 typedef void* hipStream_t;
+static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long v) {
+  unsigned long long old = *p;
+  if (old == cmp) *p = v;
+  return old;
+}
+static inline unsigned atomicAdd(unsigned* p, unsigned v) {
+  unsigned old = *p;
+  *p += v;
+  return old;
+}

@@ -65,3 +65,36 @@ def test_emu_gt_ops(ctx):
         assert E.gt_mul(l2[v["a"]], l2[v["b"]], True).hex() == v["sub"]
     for v in fx["multconst_l2"]:
         assert E.gt_pow(l2[v["a"]], int(v["k"], 16), (n.bit_length() + 7) // 8).hex() == v["out"]
+
+
+def test_emu_bsgs_ranges_and_signs(ctx):
+    """Accept range [1, Mmax] with Mmax = B*B+B+2 (gsbs.go:77-105), zero short-cut, negative retry,
+    for several baby/giant splits (the result must not depend on the split)."""
+    import math
+    from conftest import oracle_key
+    fx, E = ctx
+    opk, osk = oracle_key(fx)
+    p, T = opk.p, fx["msg_space"]
+    g = R.f2_pow(opk.e(opk.P, opk.P), osk.Key, p)
+    B = int(math.ceil(math.sqrt(T)))
+    Mmax = B * B + B + 2
+    ms = [0, 1, 2, B, Mmax - 1, Mmax, Mmax + 1, -1, -2, -Mmax, -Mmax - 1, 500, -777, 2 * Mmax]
+    xs = [R.elem_to_bytes(R.f2_pow(g, m % opk.n, p), p) for m in ms]
+    for S in [None, 16, 64]:
+        m, st = E.bsgs(R.elem_to_bytes(g, p), T, xs, S)
+        for want, got, s in zip(ms, m, st):
+            if abs(want) <= Mmax:
+                assert s == 0 and got == want, (S, want, got, s)
+            else:
+                assert s == 1, (S, want, got, s)
+
+
+def test_emu_poly_accumulation(ctx):
+    from conftest import oracle_key
+    fx, E = ctx
+    opk, _ = oracle_key(fx)
+    po = fx["poly"]
+    dec = lambda h: None if int(h, 16) == 0 else R.elem_from_bytes(bytes.fromhex(h), opk.p)
+    ea, eb = [dec(h) for h in po["a"]], [dec(h) for h in po["b"]]
+    Ew = [R.elem_to_bytes(opk.e(a, b), opk.p) for a in ea for b in eb]
+    assert [o.hex() for o in E.poly_acc(Ew, po["d1"], po["d2"])] == po["out"]

@@ -197,3 +197,98 @@ def test_encrypt_random_vs_c_oracle(name, count):
     xs = [rng.randrange(1 << 40) % n for _ in range(count)]
     rs = [rng.randrange(n) for _ in range(count)]
     assert pk.engine.encrypt(xs, rs).tobytes() == o.encrypt(xs, rs)
+
+
+# ---------------------------------------------------------------------------
+# Decrypt (BSGS) and MultPoly
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", KEYS)
+def test_decrypt_golden(name):
+    """Fixture decryptions: zero, positive, boundary B*B+B+2, out of range (error), negatives via retry; L1 and L2."""
+    fx = load_fixture(name)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    for lvl in (1, 2):
+        items = [d for d in fx["decrypt"] if d["level"] == lvl]
+        m, st = pk.engine.decrypt(lvl, H([d["ct"] for d in items]))
+        for d, mi, si in zip(items, m, st):
+            if d["expect"] is None:
+                assert si == 1, f"{name}: m={d['m']} must be out of bounds"
+            else:
+                assert si == 0 and int(mi) == d["expect"], f"{name}: Decrypt(m={d['m']}) -> {mi}, status {si}"
+
+
+def test_truth_table_like_cmd_main():
+    """cmd/main.go:79-104 on the engine (deterministic mode, 512-bit key like the reference's tests)."""
+    fx = load_fixture("k512")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    zero, one = pk.Encrypt(0), pk.Encrypt(1)
+    D = lambda c: sk.DecryptFailSafe(c, pk)
+    assert [D(pk.Add(zero, zero)), D(pk.Add(zero, one)), D(pk.Add(one, one)), D(pk.Add(one, zero))] == [0, 1, 2, 1]
+    assert [D(pk.Mult(zero, zero)), D(pk.Mult(zero, one)), D(pk.Mult(one, zero)), D(pk.Mult(one, one))] == [0, 0, 0, 1]
+    assert D(pk.Add(zero, pk.Neg(zero))) == 0 and D(pk.Add(zero, pk.Neg(one))) == -1
+    assert D(pk.Add(one, pk.Neg(one))) == 0 and D(pk.Add(one, pk.Neg(zero))) == 1
+    assert D(pk.Mult(zero, pk.Neg(one))) == 0 and D(pk.Mult(one, pk.Neg(one))) == -1
+    assert D(pk.Mult(pk.Neg(one), pk.Neg(one))) == 1
+    # mixed-level Add lifts the L1 operand (bgn.go:447-453)
+    assert D(pk.Add(pk.Mult(one, one), one)) == 2
+    import bgn_amd
+    with pytest.raises(bgn_amd.api.DecryptError):
+        sk.Decrypt(pk.Encrypt(5000), pk)            # > B*B+B+2 for T = 1021
+
+
+@pytest.mark.parametrize("name", KEYS)
+def test_poly_mult_golden(name):
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    po = fx["poly"]
+    out = pk.engine.poly_mult(1, po["d1"], po["d2"], H(po["a"]), H(po["b"]))
+    assert [bytes(r).hex() for r in out] == po["out"]
+
+
+def test_poly_mult_many_vs_c_oracle_and_decrypt():
+    """Several polynomials in one call (sharding unit = polynomial), then DecryptPoly == plaintext convolution
+    (poly_test.go:172-189)."""
+    import oracle_c
+    fx = load_fixture("k256")
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    rng = random.Random(3)
+    n = int(fx["n"], 16)
+    npoly, d1, d2 = 5, 4, 3
+    ca = [[rng.choice([-1, 0, 1]) for _ in range(d1)] for _ in range(npoly)]
+    cb = [[rng.choice([-1, 0, 1]) for _ in range(d2)] for _ in range(npoly)]
+    flat = lambda cs: [x % n for row in cs for x in row]
+    ea = o.encrypt(flat(ca), [rng.randrange(n) for _ in range(npoly * d1)])
+    eb = o.encrypt(flat(cb), [rng.randrange(n) for _ in range(npoly * d2)])
+    out = pk.engine.poly_mult(npoly, d1, d2, ea, eb)
+    assert out.tobytes() == o.poly_mult(npoly, d1, d2, ea, eb)
+    m, st = pk.engine.decrypt(2, out.tobytes())
+    assert not st.any()
+    for q in range(npoly):
+        conv = [0] * (d1 + d2)
+        for i, x in enumerate(ca[q]):
+            for k, y in enumerate(cb[q]):
+                conv[i + k] += x * y
+        assert [int(v) for v in m[q * (d1 + d2):(q + 1) * (d1 + d2)]] == conv
+
+
+def test_decrypt_large_message_space_1024():
+    """T = 2^40 (BASELINE configs[3]): uniform messages incl. negatives, through Encrypt -> Decrypt on the engine;
+    exercises the re-balanced 2^26-entry HBM table."""
+    fx = load_fixture("k1024")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    rng = random.Random(11)
+    T = fx["msg_space"]
+    msgs = [0, 1, T - 1, T, (1 << 20) ** 2 + (1 << 20) + 2, -1, -(T - 1)] + [rng.randrange(T) for _ in range(20)] + \
+           [-rng.randrange(T) for _ in range(5)]
+    n = pk.N
+    cts = pk.engine.encrypt([m % n for m in msgs], [rng.randrange(n) for _ in msgs])
+    m, st = pk.engine.decrypt(1, cts)
+    assert [int(v) for v in m] == msgs and not st.any()
+    # one beyond the reference's reach -> error
+    m2, st2 = pk.engine.decrypt(1, pk.engine.encrypt([(1 << 40) + (1 << 20) + 3], [5]))
+    assert st2[0] == 1

@@ -1,6 +1,6 @@
 // agpr.hpp — the two instructions that move a dword between the VGPR half and
 // the accumulation (AGPR) half of the unified register file.  Kept in their
-// own header so the host emulation harness under tests/emu/ can substitute it.
+// own header so a test harness can substitute it when running the lane programs on a CPU.
 #ifndef BGN_AGPR_HPP
 #define BGN_AGPR_HPP
 #include <stdint.h>

@@ -1,4 +1,4 @@
-"""Synthetic workloads for bench.py and the scale tests (no oracle here)."""
+"""Synthetic workloads for bench.py and the scale tests."""
 from __future__ import annotations
 
 import numpy as np

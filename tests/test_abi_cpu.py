@@ -49,3 +49,17 @@ def test_bad_parameters_rejected_before_touching_the_gpu():
     rc = lib.bgn_ctx_create(ctypes.byref(h), pb, len(pb), nb, len(nb), fx["l"], bytes.fromhex(fx["P"]),
                             bytes.fromhex(fx["Q"]), 1, 0)
     assert rc == -2 and b"l * n" in lib.bgn_last_error()
+
+
+def test_product_never_references_the_oracle():
+    """The oracle is test infrastructure: nothing under bgn_amd/ may import, link or call it."""
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "bgn_amd")):
+        if "build" in dp:
+            continue
+        for fn in fns:
+            if fn.endswith((".py", ".hpp", ".cpp", ".hip", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"oracle|bgn_ref|bgn_oracle|tests[/.]emu", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

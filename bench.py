@@ -56,6 +56,74 @@ def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0):
                       f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
 
 
+def secondary_metrics(pk, fx, dev, dec_log2):
+    """BASELINE configs[1] (Encrypt) and configs[3] (BSGS Decrypt, T = 2^40, batch 2^16), reported next to the
+    headline value.  Inputs resident in HBM; one warm-up pass then one timed pass each."""
+    import numpy as np
+    import torch
+    import bgn_amd
+    eng = pk.engine
+    EB = eng.elem_bytes
+    out = {}
+    # --- Encrypt: 2^dec_log2 * 4 messages m uniform in [0, 2^40), r uniform 128-byte strings reduced by the ladder
+    n_enc = 1 << (dec_log2 + 2)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(4242)
+    xs = torch.randint(0, 256, (n_enc, 5), dtype=torch.uint8, generator=g).to(dev)          # 40-bit plaintexts
+    rs = torch.randint(0, 256, (n_enc, 128), dtype=torch.uint8, generator=g)
+    rs[:, 0] &= 0x3F                                                                          # r < 2^1022 < n
+    rs = rs.to(dev)
+    cts = torch.empty(n_enc * EB, dtype=torch.uint8, device=dev)
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.encrypt_dev(xs, 5, rs, 128, cts, n_enc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out["encrypt"] = {"value": n_enc / dt, "unit": "encrypts/s", "batch": n_enc,
+                      "workload": "configs[1]: P^m * Q^r, 40-bit m, 1022-bit r, generic double-and-add ladders",
+                      "algorithmic_bytes_per_unit": 5 + 128 + EB}
+    # --- Decrypt: first 2^dec_log2 of those ciphertexts, every 16th negated
+    n_dec = 1 << dec_log2
+    t0 = time.perf_counter()
+    pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    sel = cts[: n_dec * EB].clone()
+    neg = torch.empty_like(sel)
+    check(eng, "neg")
+    eng._lib.bgn_neg_batch_dev(eng._h, n_dec, 1, sel.data_ptr(), neg.data_ptr(), eng._stream())
+    sel2 = sel.view(n_dec, EB).clone()
+    sel2[::16] = neg.view(n_dec, EB)[::16]
+    sel2 = sel2.reshape(-1).contiguous()
+    m = torch.empty(n_dec, dtype=torch.int64, device=dev)
+    st = torch.empty(n_dec, dtype=torch.uint8, device=dev)
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.decrypt_dev(1, sel2, m, st, n_dec)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    k_ms = eng.last_kernel_ms()
+    want = torch.zeros(n_dec, dtype=torch.int64)
+    xb = xs[:n_dec].cpu().numpy().astype(np.int64)
+    for j in range(5):
+        want = want * 256 + torch.from_numpy(xb[:, j])
+    want[::16] = -want[::16]
+    ok = bool((m.cpu() == want).all().item()) and not bool(st.any().item())
+    out["decrypt"] = {"value": n_dec / dt, "unit": "decrypts/s", "batch": n_dec, "level": 1,
+                      "workload": "configs[3]: T=2^40 BSGS Decrypt, batch=2^%d, m uniform in [0,2^40), 1/16 negative; "
+                                  "lift e(C,P) + C^sk + giant steps on an HBM-resident baby table (2^%s entries)"
+                                  % (dec_log2, os.environ.get("BGN_BSGS_MAX_LOG2", "28")),
+                      "search_kernel_ms": k_ms, "kernel": eng.last_kernel_name(), "table_setup_s": t_setup,
+                      "plaintexts_recovered_exactly": ok, "algorithmic_bytes_per_unit": EB + 16}
+    return out
+
+
+def check(eng, what):
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +132,8 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--key", default="k1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary Encrypt / Decrypt measurements")
+    ap.add_argument("--decrypt-log2", type=int, default=16)
     args = ap.parse_args()
 
     import numpy as np
@@ -123,6 +193,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kernel_name = eng.last_kernel_name()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,6 +204,10 @@ def main():
     a_h = a[: nchk * EB].cpu().numpy().tobytes()
     b_h = b[: nchk * EB].cpu().numpy().tobytes()
     o_h = out[: nchk * EB].cpu().numpy().tobytes()
+
+    extra = None
+    if not args.no_extra and world == 1 and args.key == "k1024":
+        extra = secondary_metrics(pk, fx, dev, args.decrypt_log2)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -154,12 +229,14 @@ def main():
                        },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": eng.last_kernel_name(), "kernel_ms": k_ms,
+                         "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_pairing": alg_bytes},
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads,
                               "achieved": mads * count / (k_ms * 1e-3), "peak": VALU_MAD_PEAK,
                               "unit": "lane-MAD/s", "frac": mads * count / (k_ms * 1e-3) / VALU_MAD_PEAK},
         }
+        if extra:
+            line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
         print(json.dumps(line), flush=True)

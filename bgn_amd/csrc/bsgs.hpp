@@ -163,25 +163,63 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
 template <int NL>
 __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const BsgsSearchArgs& A, LFp<NL>* L,
                                                  const FpParams<NL>* __restrict__ P) {
+  // Work split: `parts` lanes share one element, each walking a contiguous range of giant steps, so that a
+  // small batch (or the few elements left for the retry pass) still fills the chip.
+  const size_t lanes_total = (size_t)gridDim.x * FP_BLOCK;
   size_t lane = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
   size_t n = A.count;
   if (A.mode == 1) n = *A.todo_count;
-  bool live = lane < n;
+  if (n == 0) return;
+  unsigned long long parts = lanes_total / n;
+  if (parts < 1) parts = 1;
+  const unsigned long long max_parts = (B.G + 255) / 256;      // keep >= 256 steps per part
+  if (parts > max_parts) parts = max_parts;
+  const unsigned long long steps = (B.G + parts - 1) / parts;
+  bool live = lane < n * parts;
   if (!__ballot(live)) return;                 // whole wave idle
   if (!live) lane = 0;
-  const size_t e = (A.mode == 1) ? (n ? A.todo[lane] : 0) : lane;
+  const size_t idx = lane / parts;
+  const unsigned long long part = lane % parts;
+  const size_t e = (A.mode == 1) ? A.todo[idx] : idx;
+  const unsigned long long i0 = part * steps;
+  unsigned long long i1 = i0 + steps;
+  if (i1 > B.G) i1 = B.G;
   load_const_rows<NL>(L, B.gi0, B.gi1);
   Fp<NL> a0, a1;
-  g_load<NL>(a0, A.x0, A.sx, e);
-  g_load<NL>(a1, A.x1, A.sx, e);
-  if (A.mode == 1) {
-    fp_neg<1>(a1, a1, P);                     // conj(x) = x^-1 on GT: Neg(ct), bgn.go:236
+  if (__ballot(i0 != 0)) {
+    // start of this part: x * gamma^-i0
+    gt_pow_u64<NL>(a0, a1, i0, L, P);          // (gamma^-1)^i0  <4,<6
+    Fp<NL> x0, x1, sm;
+    g_load<NL>(x0, A.x0, A.sx, e);
+    g_load<NL>(x1, A.x1, A.sx, e);
+    if (A.mode == 1) {
+      fp_neg<1>(x1, x1, P);
+      fp_reduce8(x1, x1, P);
+    }
+    fp_add(sm, x0, x1);
+    // product with x as the LDS-resident constant, then restore gamma^-1
+    l_store(L + 1, x0);
+    l_store(L + 2, x1);
+    l_store(L + 3, sm);
+    Fp<NL> m0, m1;
+    fp2_mul_const(m0, m1, a0, a1, L, P);
+    a0 = m0;
+    a1 = m1;
+    load_const_rows<NL>(L, B.gi0, B.gi1);
+    fp_reduce8(a0, a0, P);
     fp_reduce8(a1, a1, P);
+  } else {
+    g_load<NL>(a0, A.x0, A.sx, e);
+    g_load<NL>(a1, A.x1, A.sx, e);
+    if (A.mode == 1) {
+      fp_neg<1>(a1, a1, P);                   // conj(x) = x^-1 on GT: Neg(ct), bgn.go:236
+      fp_reduce8(a1, a1, P);
+    }
   }
   bool done = !live;
   bool found = false;
   long long result = 0;
-  {
+  if (i0 == 0) {
     Fp<NL> one;
     fp_set(one, P->one);
     if (fp_eq_limbs(a0, one) && fp_is_zero_limbs(a1)) {   // zero.Equals(csk), bgn.go:359-363
@@ -190,8 +228,9 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
     }
   }
 #pragma unroll 1
-  for (unsigned long long i = 0; i < B.G; ++i) {
+  for (unsigned long long i = i0; i < i0 + steps; ++i) {
     if (!__ballot(!done)) break;
+    if (i >= i1) done = true;
     Fp<NL> re;
     fp_reduce8(re, a0, P);
     unsigned long long key;
@@ -223,16 +262,18 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
     a0 = m0;
     a1 = m1;
   }
-  if (live) {
-    if (found) {
-      A.m[e] = (A.mode == 1) ? -result : result;
-      A.status[e] = 0;
-    } else if (A.mode == 0) {
-      A.m[e] = 0;
-      A.status[e] = 1;
-      const u32 slot = atomicAdd(A.todo_count, 1u);
-      A.todo[slot] = (u32)e;
-    }
+  if (live && found) {                         // status / m are pre-set to "not found" by the caller
+    A.m[e] = (A.mode == 1) ? -result : result;
+    A.status[e] = 0;
+  }
+}
+
+// Indices of the elements the first attempt left unresolved (status != 0), compacted.
+__device__ __forceinline__ void bsgs_compact_lane(const uint8_t* status, size_t count, u32* todo, u32* todo_count) {
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  if (e < count && status[e] != 0) {
+    const u32 slot = atomicAdd(todo_count, 1u);
+    todo[slot] = (u32)e;
   }
 }
 

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -322,7 +323,13 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if ((double)B < sq) B++;
   const uint64_t Mmax = B * B + B + 2;
   uint64_t S = 2;
-  while (S < Mmax + 1 && S < ((uint64_t)1 << 26)) S <<= 1;
+  // baby-step cap: 2^28 entries = 8.6 GB of HBM by default; BGN_BSGS_MAX_LOG2 overrides (16..30)
+  int cap_log2 = 28;
+  if (const char* ev = getenv("BGN_BSGS_MAX_LOG2")) {
+    const int v = atoi(ev);
+    if (v >= 4 && v <= 30) cap_log2 = v;
+  }
+  while (S < Mmax + 1 && S < ((uint64_t)1 << cap_log2)) S <<= 1;
   const uint64_t G = (Mmax + S) / S + 1;
   const uint64_t slots = (2 * S < 64) ? 64 : 2 * S;
 
@@ -882,6 +889,8 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);                        // csk.PowBig(ct.C, sk.Key), bgn.go:223
   kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
   HIP_TRY(hipMemsetAsync(todo_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(status, 1, count, s));          // "cannot find discrete log" until a lane finds it
+  HIP_TRY(hipMemsetAsync(m, 0, count * 8, s));
   BsgsSearchArgs a;
   a.x0 = Y.c0; a.x1 = Y.c1; a.sx = Y.stride;
   a.m = (long long*)m; a.status = status;

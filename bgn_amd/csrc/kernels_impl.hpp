@@ -10,6 +10,11 @@ namespace bgn {
 
 constexpr int NL_ = BGN_NL;
 
+#define BGN_CAT2(a, b) a##b
+#define BGN_CAT(a, b) BGN_CAT2(a, b)
+#define BGN_STR2(x) #x
+#define BGN_STR(x) BGN_STR2(x)
+
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, SoA2 out) {
@@ -174,6 +179,11 @@ k_bsgs_search(const FpParams<NL>* __restrict__ P, BsgsParams B, BsgsSearchArgs A
   bsgs_search_lane<NL>(B, A, L, P);
 }
 
+__global__ void __launch_bounds__(FP_BLOCK) BGN_CAT(k_bsgs_compact_nl, BGN_NL)(const uint8_t* status, size_t count,
+                                                                                 u32* todo, u32* todo_count) {
+  bsgs_compact_lane(status, count, todo, todo_count);
+}
+
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_poly_acc(const FpParams<NL>* __restrict__ P, PolyAccArgs A) {
@@ -244,8 +254,16 @@ static void launch_bsgs_build(hipStream_t s, const void* params, BsgsParams b, u
 
 static void launch_bsgs_search(hipStream_t s, const void* params, BsgsParams b, BsgsSearchArgs a) {
   if (!a.count) return;
-  hipLaunchKernelGGL(k_bsgs_search<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, b,
-                     a);
+  // at least 65536 lanes (one wave per SIMD on every CU); the kernel splits each element's giant steps
+  // over lanes_total / n lanes
+  size_t lanes = a.count < 65536 ? 65536 : a.count;
+  if (a.mode == 1) {
+    hipLaunchKernelGGL(BGN_CAT(k_bsgs_compact_nl, BGN_NL), dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, a.status,
+                       a.count, a.todo, a.todo_count);
+    // the retry pass normally has few elements: the device-side split adapts to *todo_count,
+    // waves beyond it exit at once
+  }
+  hipLaunchKernelGGL(k_bsgs_search<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, b, a);
 }
 
 static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
@@ -254,10 +272,6 @@ static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
   hipLaunchKernelGGL(k_poly_acc<NL_>, dim3(grid_for(total)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
 }
 
-#define BGN_CAT2(a, b) a##b
-#define BGN_CAT(a, b) BGN_CAT2(a, b)
-#define BGN_STR2(x) #x
-#define BGN_STR(x) BGN_STR2(x)
 
 const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {

@@ -138,24 +138,29 @@ struct Emu {
     bsgs_build_lane<NL>(B, S, lds(), P);
     std::vector<u32> todo(count + 1);
     u32 todo_count = 0;
+    for (int i = 0; i < count; ++i) { m[i] = 0; status[i] = 1; }
     for (int mode = 0; mode < 2; ++mode) {
+      if (mode == 1)
+        for (int i = 0; i < count; ++i)
+          if (status[i]) todo[todo_count++] = (u32)i;
       const int n = mode ? (int)todo_count : count;
       for (int i = 0; i < n; ++i) {
-        // one lane per element: emulate lane index through blockIdx (FP_BLOCK lanes per block, thread 0)
-        // -> give every element its own SoA with stride 1 instead
+        // one emulated lane per element: a private single-element view (stride 1, count 1)
         const int e = mode ? (int)todo[i] : i;
         BsgsSearchArgs A;
         A.x0 = xs + (size_t)e * 2 * NL; A.x1 = A.x0 + NL; A.sx = 1;
-        long long mm = 0; uint8_t st = 9;
-        u32 one_todo[1] = {0}; u32 one_count = mode ? 1u : 0u;
+        long long mm = 0; uint8_t st = 1;
+        u32 one_todo[1] = {0}; u32 one_count = 1;
         A.m = &mm; A.status = &st; A.todo = one_todo; A.todo_count = &one_count; A.count = 1; A.mode = mode;
-        bsgs_search_lane<NL>(B, A, lds(), P);
-        if (mode == 0) {
-          m[e] = mm; status[e] = st;
-          if (one_count) todo[todo_count++] = (u32)e;
-        } else if (st == 0) {
-          m[e] = mm; status[e] = 0;
+        // all parts of the element's giant-step split, one emulated lane each
+        const unsigned long long max_parts = (G + 255) / 256;
+        unsigned long long parts = 256 < max_parts ? 256 : max_parts;
+        for (unsigned long long part = 0; part < parts; ++part) {
+          threadIdx.x = (unsigned)part;
+          bsgs_search_lane<NL>(B, A, lds(), P);
         }
+        threadIdx.x = 0;
+        if (st == 0) { m[e] = mm; status[e] = 0; }
       }
     }
   }

@@ -80,7 +80,7 @@ def test_emu_bsgs_ranges_and_signs(ctx):
     Mmax = B * B + B + 2
     ms = [0, 1, 2, B, Mmax - 1, Mmax, Mmax + 1, -1, -2, -Mmax, -Mmax - 1, 500, -777, 2 * Mmax]
     xs = [R.elem_to_bytes(R.f2_pow(g, m % opk.n, p), p) for m in ms]
-    for S in [None, 16, 64]:
+    for S in [None, 2, 4, 16, 64]:      # S = 2, 4: more than 256 giant steps -> the per-element range split is exercised
         m, st = E.bsgs(R.elem_to_bytes(g, p), T, xs, S)
         for want, got, s in zip(ms, m, st):
             if abs(want) <= Mmax:

@@ -65,6 +65,10 @@ struct bgn_ctx {
   size_t sk_len = 0;
   uint32_t* d_gt = nullptr;            // g.re, g.im, gamma^-1.re, gamma^-1.im : 4 * nl limbs (Montgomery)
   BsgsSlot* d_table = nullptr;
+  // fixed-base window tables for P and Q (built on first use)
+  uint32_t* d_tabP = nullptr;
+  uint32_t* d_tabQ = nullptr;
+  int fixed_windows = 0;
   BsgsParams bsgs{};
   bool have_tables = false;
 
@@ -181,6 +185,8 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_sk) (void)hipFree(c->d_sk);
   if (c->d_gt) (void)hipFree(c->d_gt);
   if (c->d_table) (void)hipFree(c->d_table);
+  if (c->d_tabP) (void)hipFree(c->d_tabP);
+  if (c->d_tabQ) (void)hipFree(c->d_tabQ);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -528,10 +534,60 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
                    size_t count) {
   G1MulArgs a;
   a.bx = B.c0; a.by = B.c1; a.binf = B.inf; a.sb = B.stride;
+  a.bdiv = 0;
   a.k = k; a.kstride = kstride; a.klen = klen;
   a.ox = O.c0; a.oy = O.c1; a.oinf = O.inf; a.so = O.stride;
   a.count = count;
   c->kt->g1_mul(s, c->d_params, c->d_consts, a);
+}
+
+// Window tables of the key's fixed bases: tab[w][d] = d * 256^w * B, w < windows, d < 256, built with the
+// generic ladder kernel (once per key).  Must be called with c->mu held; uses the arena.
+int ensure_fixed_tables(bgn_ctx* c) {
+  if (c->d_tabP) return BGN_OK;
+  const KernelTable* kt = c->kt;
+  const int W = (c->n.bits() + 7) / 8 + 1;
+  const size_t ne = (size_t)W * 256;
+  const size_t st = round_up(ne, 64), sw = round_up((size_t)W, 64);
+  SoA2 base, ent;
+  uint8_t *k1 = nullptr, *k2 = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    base = w.g1(sw);
+    ent = w.g1(st);
+    k1 = (uint8_t*)w.cv.take((size_t)W * W);
+    k2 = (uint8_t*)w.cv.take(ne);
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  std::vector<uint8_t> h1((size_t)W * W, 0), h2(ne);
+  for (int w = 0; w < W; ++w) h1[(size_t)w * W + (W - 1 - w)] = 1;          // 256^w, big-endian in W bytes
+  for (size_t i = 0; i < ne; ++i) h2[i] = (uint8_t)(i & 255);
+  HIP_TRY(hipMemcpy(k1, h1.data(), h1.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(k2, h2.data(), h2.size(), hipMemcpyHostToDevice));
+  uint32_t* tabs[2] = {nullptr, nullptr};
+  for (int b = 0; b < 2; ++b) {
+    HIP_TRY(hipMalloc((void**)&tabs[b], ne * 2 * (size_t)c->nl * 4));
+    g1_mul_launch(c, nullptr, b ? c->key_Q() : c->key_P(), k1, (size_t)W, (size_t)W, base, (size_t)W);
+    kt->to_mont(nullptr, c->d_params, base.c0, base.c1, base.stride, (size_t)W);
+    G1MulArgs a;
+    a.bx = base.c0; a.by = base.c1; a.binf = base.inf; a.sb = base.stride;
+    a.bdiv = 256;
+    a.k = k2; a.kstride = 1; a.klen = 1;
+    a.ox = ent.c0; a.oy = ent.c1; a.oinf = ent.inf; a.so = ent.stride;
+    a.count = ne;
+    kt->g1_mul(nullptr, c->d_params, c->d_consts, a);
+    kt->to_mont(nullptr, c->d_params, ent.c0, ent.c1, ent.stride, ne);
+    kt->soa_to_entries(nullptr, ent.c0, ent.c1, ent.stride, ne, tabs[b]);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  c->d_tabP = tabs[0];
+  c->d_tabQ = tabs[1];
+  c->fixed_windows = W;
+  return BGN_OK;
 }
 
 void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b) {
@@ -727,6 +783,42 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
     }
   }
   const KernelTable* kt = c->kt;
+  {
+    int rc = ensure_fixed_tables(c);      // may re-carve the arena: G/H/O are re-derived below
+    if (rc) return rc;
+  }
+  if ((int)x_len <= c->fixed_windows && (!r_be || (int)r_len <= c->fixed_windows)) {
+    for (int pass = 0; pass < 2; ++pass) {
+      Ws w(c, pass ? c->arena : nullptr);
+      G = w.g1(st);
+      if (!pass) {
+        int rc = ensure_arena(c, w.cv.off);
+        if (rc) return rc;
+      }
+    }
+    G1FixedArgs a;
+    a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.windows = c->fixed_windows;
+    a.x = x_be; a.xlen = x_len; a.r = r_be; a.rlen = r_len;
+    a.ox = G.c0; a.oy = G.c1; a.oinf = G.inf; a.so = G.stride;
+    a.count = count;
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    kt->g1_fixed(s, c->d_params, c->d_consts, a);                              // bgn.go:344-350 fused
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->ev_valid = true;
+    c->last_kernel = "k_g1_fixed";
+    kt->encode(s, G.inf, G.c0, G.c1, G.stride, c->L, count, out);
+    HIP_TRY(hipGetLastError());
+    return BGN_OK;
+  }
+  for (int pass = 0; pass < 2; ++pass) {   // long scalars: generic ladders
+    Ws w(c, pass ? c->arena : nullptr);
+    G = w.g1(st);
+    if (r_be) { H = w.g1(st); O = w.g1(st); prefix = w.fp(st); }
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
   HIP_TRY(hipEventRecord(c->ev0, s));
   g1_mul_launch(c, s, c->key_P(), x_be, x_len, x_len, G, count);                // G.PowBig(pk.P, x), bgn.go:344
   if (r_be) {

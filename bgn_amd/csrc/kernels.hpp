@@ -33,7 +33,18 @@ struct G1AddArgs {
 // G1 scalar multiplication (ops.hpp).
 struct G1MulArgs {
   const uint32_t* bx; const uint32_t* by; const uint8_t* binf; size_t sb;   // bases (sb == 1: broadcast), canonical Montgomery
+  size_t bdiv;                                                              // > 1: element e uses base e / bdiv
   const uint8_t* k; size_t kstride; size_t klen;                            // big-endian scalars (kstride 0: one for all)
+  uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical affine out
+  size_t count;
+};
+
+// Fixed-base double scalar multiplication out = P^x * Q^r from per-key window tables (ops.hpp).
+// Table layout: entry (w, d), w = window (byte index from the least significant byte), d = 0..255, at
+// tab + (w*256 + d) * 2*NL : x limbs then y limbs, canonical Montgomery (d = 0 unused).
+struct G1FixedArgs {
+  const uint32_t* tabP; const uint32_t* tabQ; int windows;
+  const uint8_t* x; size_t xlen; const uint8_t* r; size_t rlen;             // r may be null
   uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical affine out
   size_t count;
 };
@@ -105,6 +116,10 @@ struct KernelTable {
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);
   void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
+  void (*g1_fixed)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a);
+  // SoA (stride) -> table entries [e][x limbs | y limbs]
+  void (*soa_to_entries)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
+                         uint32_t* entries);
   void (*gt_mul)(hipStream_t s, const void* params, GtMulArgs a);
   void (*gt_pow)(hipStream_t s, const void* params, GtPowArgs a);
   void (*bsgs_build)(hipStream_t s, const void* params, BsgsParams b, unsigned long long chunk, size_t lanes);

@@ -129,6 +129,32 @@ k_g1_mul(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
+k_g1_fixed(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1FixedArgs A) {
+  __shared__ LFp<NL> L[4];
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < A.count;
+  if (!live) e = A.count - 1;
+  g1_fixed_lane<NL>(A, e, live, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_soa_to_entries(const u32* __restrict__ c0, const u32* __restrict__ c1, size_t stride, size_t count, u32* entries) {
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  if (e >= count) return;
+  Fp<NL> x, y;
+  g_load<NL>(x, c0, stride, e);
+  g_load<NL>(y, c1, stride, e);
+  u32* dst = entries + e * (size_t)(2 * NL);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    dst[j] = x.v[j];
+    dst[NL + j] = y.v[j];
+  }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
 k_gt_mul(const FpParams<NL>* __restrict__ P, GtMulArgs A) {
   __shared__ LFp<NL> L[4];
   const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
@@ -236,6 +262,18 @@ static void launch_g1_mul(hipStream_t s, const void* params, const PairingConsts
                      a);
 }
 
+static void launch_g1_fixed(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_g1_fixed<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     consts, a);
+}
+
+static void launch_soa_to_entries(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
+                                  uint32_t* entries) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_soa_to_entries<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, c0, c1, stride, count, entries);
+}
+
 static void launch_gt_mul(hipStream_t s, const void* params, GtMulArgs a) {
   if (!a.count) return;
   hipLaunchKernelGGL(k_gt_mul<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
@@ -284,6 +322,8 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_to_mont,
       launch_g1_add,
       launch_g1_mul,
+      launch_g1_fixed,
+      launch_soa_to_entries,
       launch_gt_mul,
       launch_gt_pow,
       launch_bsgs_build,

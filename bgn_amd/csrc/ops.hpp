@@ -448,11 +448,45 @@ __device__ __forceinline__ void jac_add_affine(JacAcc<NL>& S, bool& acc_inf, boo
   acc_inf = (acc_inf && !take) || to_inf;
 }
 
+// Jacobian accumulator -> plain canonical affine (x = X/Z^2, y = Y/Z^3), one inversion per lane.
+template <int NL>
+__device__ __forceinline__ void jac_store_affine(JacAcc<NL>& S, bool is_inf, u32* ox, u32* oy, uint8_t* oinf, size_t so,
+                                                 size_t e, bool live, LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                                 const FpParams<NL>* __restrict__ P) {
+  Fp<NL> r, u, zi;
+  a_load(r, S.Z);
+  {
+    Fp<NL> one;
+    fp_set(one, P->one);
+    fp_select(r, is_inf, one, r);           // keep the inversion well defined
+  }
+  fp_reduce8(r, r, P);                      // <1 (Z <4)
+  fp_inv<NL>(zi, r, L, C, P);               // <2   (uses L0, L1)
+  l_store(L + 1, zi);
+  fp_mul(u, L + 1, zi, P);                  // zi^2 <2
+  a_load(r, S.X);
+  fp_mulv(r, r, u, P, L);                   // x <2   (36)
+  fp_mul(u, L + 1, u, P);                   // zi^3 <2
+  {
+    Fp<NL> o;
+    fp_from_mont<NL>(o, r, P, L);
+    if (live) g_store(ox, so, e, o);
+  }
+  a_load(r, S.Y);
+  fp_mulv(r, r, u, P, L);                   // y <2
+  {
+    Fp<NL> o;
+    fp_from_mont<NL>(o, r, P, L);
+    if (live) g_store(oy, so, e, o);
+  }
+  if (live) oinf[e] = is_inf ? 1 : 0;
+}
+
 template <int NL>
 __device__ __forceinline__ void g1_scalarmul_lane(const G1MulArgs& A, size_t e, bool live, LFp<NL>* L,
                                                   const PairingConsts* __restrict__ C,
                                                   const FpParams<NL>* __restrict__ P) {
-  const size_t eb = (A.sb == 1) ? 0 : e;
+  const size_t eb = (A.sb == 1) ? 0 : (A.bdiv > 1 ? e / A.bdiv : e);
   const uint8_t* k = A.k + e * A.kstride;
   JacAcc<NL> S;
   {
@@ -477,35 +511,50 @@ __device__ __forceinline__ void g1_scalarmul_lane(const G1MulArgs& A, size_t e, 
     const bool bit = scalar_bit(k, A.klen, i) != 0;
     if (__ballot(bit)) jac_add_affine<NL>(S, acc_inf, bit, L, P);
   }
-  // affine: x = X / Z^2, y = Y / Z^3
-  Fp<NL> r, u, zi;
-  a_load(r, S.Z);
-  {
-    Fp<NL> one;
-    fp_set(one, P->one);
-    fp_select(r, acc_inf, one, r);          // keep the inversion well defined
-  }
-  fp_reduce8(r, r, P);                      // <1 (Z <4)
-  fp_inv<NL>(zi, r, L, C, P);               // <2   (uses L0, L1)
-  l_store(L + 1, zi);
-  fp_mul(u, L + 1, zi, P);                  // zi^2 <2
-  a_load(r, S.X);
-  fp_mulv(r, r, u, P, L);                   // x <2   (36)
-  fp_mul(u, L + 1, u, P);                   // zi^3 <2
-  {
-    Fp<NL> o;
-    fp_from_mont<NL>(o, r, P, L);
-    if (live) g_store(A.ox, A.so, e, o);
-  }
-  a_load(r, S.Y);
-  fp_mulv(r, r, u, P, L);                   // y <2
-  {
-    Fp<NL> o;
-    fp_from_mont<NL>(o, r, P, L);
-    if (live) g_store(A.oy, A.so, e, o);
-  }
   const bool binf = A.binf && A.binf[eb];
-  if (live) A.oinf[e] = (acc_inf || binf) ? 1 : 0;
+  jac_store_affine<NL>(S, acc_inf || binf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
+}
+
+// out = sum over windows of tabP[w][x_w] + tabQ[w][r_w]: EncryptWithRandomness (bgn.go:340-353) with both
+// PowBig calls and the final Mul fused; P and Q are fixed per key, so no doublings are needed at all.
+template <int NL>
+__device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, size_t e, bool live, LFp<NL>* L,
+                                              const PairingConsts* __restrict__ C,
+                                              const FpParams<NL>* __restrict__ P) {
+  JacAcc<NL> S;
+  {
+    Fp<NL> t;
+    fp_set(t, P->one);
+    a_store(S.X, t);
+    a_store(S.Y, t);
+    a_store(S.T, t);
+    a_store(S.U, t);
+    fp_zero(t);
+    a_store(S.Z, t);
+  }
+  bool acc_inf = true;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint8_t* k = pass ? A.r : A.x;
+    const size_t klen = pass ? A.rlen : A.xlen;
+    const u32* tab = pass ? A.tabQ : A.tabP;
+    if (!k) continue;
+    k += e * klen;
+#pragma unroll 1
+    for (size_t w = 0; w < klen; ++w) {
+      const u32 d = k[klen - 1 - w];
+      if (__ballot(d != 0)) {
+        const u32* ent = tab + ((size_t)w * 256 + d) * (size_t)(2 * NL);
+        Fp<NL> t;
+        g_load(t, ent, 1, 0);
+        l_store(L + 2, t);
+        g_load(t, ent + NL, 1, 0);
+        l_store(L + 3, t);
+        jac_add_affine<NL>(S, acc_inf, d != 0, L, P);
+      }
+    }
+  }
+  jac_store_affine<NL>(S, acc_inf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
 }
 
 }  // namespace bgn

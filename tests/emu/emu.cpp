@@ -101,6 +101,16 @@ struct Emu {
       oinf[j] = oi[e];
     }
   }
+  static void g1_fixed(const u32* params, const PairingConsts* C, const u32* tabP, const u32* tabQ, int windows,
+                       const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    G1FixedArgs A;
+    A.tabP = tabP; A.tabQ = tabQ; A.windows = windows;
+    A.x = x; A.xlen = xlen; A.r = r; A.rlen = rlen;
+    A.ox = out; A.oy = out + NL; A.oinf = oinf; A.so = 1;
+    A.count = 1;
+    g1_fixed_lane<NL>(A, 0, true, lds(), C, P);
+  }
   static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     Fp<NL> o0, o1;
@@ -200,5 +210,6 @@ int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
 int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
+int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int windows, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, windows, x, xlen, r, rlen, out, oinf)) }
 size_t emu_consts_size() { return sizeof(PairingConsts); }
 }

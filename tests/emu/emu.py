@@ -130,6 +130,25 @@ class Emu:
             res.append(self.encode(pl, oi[j]))
         return res
 
+    def make_table(self, entries_wire):
+        """entries_wire[w*256 + d] = wire bytes of d*256^w*B (d = 0 ignored) -> device table layout."""
+        tab = (C.c_uint32 * (2 * self.nl * len(entries_wire)))()
+        for i, w in enumerate(entries_wire):
+            if w is None:
+                continue
+            x, _ = self.decode(w)
+            tab[2 * self.nl * i:2 * self.nl * (i + 1)] = list(x)
+        return tab
+
+    def g1_fixed(self, tabP, tabQ, windows: int, x: int, xlen: int, r=None, rlen: int = 0) -> bytes:
+        out = (C.c_uint32 * (2 * self.nl))()
+        oinf = C.c_uint8()
+        xb = x.to_bytes(xlen, "big")
+        rb = r.to_bytes(rlen, "big") if r is not None else None
+        assert self.lib.emu_g1_fixed(self.nl, self.params, self.consts, tabP, tabQ, windows, xb, C.c_size_t(xlen), rb,
+                                     C.c_size_t(rlen), out, C.byref(oinf)) == 0
+        return self.encode(out, oinf.value)
+
     def gt_mul(self, a: bytes, b: bytes, conj_b=False) -> bytes:
         A, _ = self.decode(a)
         B, _ = self.decode(b)

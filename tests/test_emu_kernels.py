@@ -98,3 +98,38 @@ def test_emu_poly_accumulation(ctx):
     ea, eb = [dec(h) for h in po["a"]], [dec(h) for h in po["b"]]
     Ew = [R.elem_to_bytes(opk.e(a, b), opk.p) for a in ea for b in eb]
     assert [o.hex() for o in E.poly_acc(Ew, po["d1"], po["d2"])] == po["out"]
+
+
+def test_emu_fixed_base_encrypt():
+    """Window-table Encrypt (P^x * Q^r fused, no doublings) incl. zero digits, x = 0, r = 0 and scalars >= n."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    import oracle_c
+    fx = load_fixture("toy64")
+    E = emu.Emu.from_fixture(fx)
+    o = oracle_c.Oracle.from_fixture(fx)
+    n = int(fx["n"], 16)
+    W = (n.bit_length() + 7) // 8 + 1
+    zero = bytes(2 * E.L)
+
+    def table(base_is_q):
+        ents = []
+        for w in range(W):
+            for d in range(256):
+                k = d * 256 ** w
+                if d == 0:
+                    ents.append(None)
+                elif base_is_q:
+                    ents.append(o.encrypt([0], [k]))
+                else:
+                    ents.append(o.encrypt([k], None))
+        return E.make_table(ents)
+
+    tP, tQ = table(False), table(True)
+    rng = random.Random(8)
+    cases = [(0, 0), (0, 5), (7, 0), (1 << 40, 1 << 56), (n - 1, n - 1), (n + 3, n + 1), (256, 65536)]
+    cases += [(rng.randrange(1 << 40), rng.randrange(n)) for _ in range(6)]
+    for x, r in cases:
+        assert E.g1_fixed(tP, tQ, W, x, W, r, W) == o.encrypt([x], [r]), (x, r)
+    assert E.g1_fixed(tP, tQ, W, 77, 2, None, 0) == o.encrypt([77], None)
+    assert E.g1_fixed(tP, tQ, W, 0, 1, None, 0) == zero

@@ -292,3 +292,13 @@ def test_decrypt_large_message_space_1024():
     # one beyond the reference's reach -> error
     m2, st2 = pk.engine.decrypt(1, pk.engine.encrypt([(1 << 40) + (1 << 20) + 3], [5]))
     assert st2[0] == 1
+
+
+def test_repeated_setup_keeps_key_tables_alive():
+    """Regression: a second SetupDecryption must not invalidate the fixed-base tables used by Encrypt."""
+    fx = load_fixture("k256")
+    pk, sk = engine_key(fx)
+    for _ in range(3):
+        pk.SetupDecryption(sk)
+        c = pk.EncryptWithRandomness(7, 123456789)
+        assert sk.Decrypt(c, pk) == 7

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbgn_amd.so")
+# BGN_AMD_LIB selects another build of the same library (A/B measurements, packaging)
+LIB_PATH = os.environ.get("BGN_AMD_LIB") or os.path.join(_HERE, "lib", "libbgn_amd.so")
 
 BGN_OK = 0
 BGN_E_ARG, BGN_E_PARAM, BGN_E_HIP, BGN_E_STATE, BGN_E_POINT, BGN_E_NOMEM = -1, -2, -3, -4, -5, -6

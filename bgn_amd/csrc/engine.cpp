@@ -274,7 +274,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     // e(Q,Q) (blinding base of level-2 ops, bgn.go:306,469) and the GT identity
     {
       SoA2 o{c->d_keypts + 4 * c->nl, c->d_keypts + 5 * c->nl, nullptr, 1};
-      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0);
+      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0);
       kt->to_mont(nullptr, c->d_params, o.c0, o.c1, 1, 1);
       HIP_BRK(hipMemcpy(c->d_keypts + 6 * c->nl, img.data() + c->nl, (size_t)c->nl * 4, hipMemcpyHostToDevice));  // one
     }
@@ -353,7 +353,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   const int nl = c->nl;
   SoA2 g{c->d_gt, c->d_gt + nl, nullptr, 1}, gi{c->d_gt + 2 * nl, c->d_gt + 3 * nl, nullptr, 1};
   // g = e(P,P)^sk  (bgn.go:198-199)
-  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0);
+  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0);
   kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
   gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
   kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
@@ -389,6 +389,19 @@ namespace {
 void blind_l2(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, size_t count);
 }
 
+// pairings per lane: keep 65536 lanes (one wave per SIMD on every CU) busy before lengthening the runs
+static int pairing_run(size_t count) {
+  // one wave per SIMD on every CU first (65536 lanes), then lengthen the runs (measured best at 16)
+  size_t r = count / 65536;
+  if (r < 1) r = 1;
+  if (r > 16) r = 16;
+  if (const char* ev = getenv("BGN_PAIRING_RUN")) {     // tuning knob for experiments
+    const int v = atoi(ev);
+    if (v >= 1 && v <= 64) r = (size_t)v;
+  }
+  return (int)r;
+}
+
 static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                           size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be = nullptr,
                           size_t r_len = 0) {
@@ -401,6 +414,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
+  probe.take((size_t)3 * c->nl * so * 4);
   if (r_be) {
     probe.soa(c->nl, so, false);
     probe.soa(c->nl, so, false);
@@ -411,6 +425,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   SoA2 A = cv.soa(c->nl, sa, true);
   SoA2 B = nb ? cv.soa(c->nl, sb, true) : c->key_P();
   SoA2 O = cv.soa(c->nl, so, false);
+  uint32_t* ws = (uint32_t*)cv.take((size_t)3 * c->nl * so * 4);
   SoA2 T1{}, T2{};
   if (r_be) {
     T1 = cv.soa(c->nl, so, false);
@@ -419,7 +434,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2);
+  kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so);
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;
@@ -957,11 +972,13 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   SoA2 A, X, Y;
   uint32_t* todo = nullptr;
   uint32_t* todo_count = nullptr;
+  uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     A = (level == 1) ? w.g1(st) : w.gt(st);
     X = w.gt(st);
     Y = w.gt(st);
+    if (level == 1) pws = (uint32_t*)w.cv.take((size_t)3 * c->nl * st * 4);
     todo = (uint32_t*)w.cv.take(st * 4);
     todo_count = (uint32_t*)w.cv.take(256);
     if (!pass) {
@@ -974,7 +991,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   SoA2 base = A;
   if (level == 1) {
     // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp)
-    kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0);
+    kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pairing_run(count), pws, st);
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
@@ -1029,9 +1046,11 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   const size_t na = npoly * d1, nb = npoly * d2, np = npoly * d1 * d2, no = npoly * (d1 + d2);
   const size_t sa = round_up(na, 64), sb = round_up(nb, 64), sp = round_up(np, 64), so = round_up(no, 64);
   SoA2 A, Bv, E, O;
+  uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     A = w.g1(sa); Bv = w.g1(sb); E = w.gt(sp); O = w.gt(so);
+    pws = (uint32_t*)w.cv.take((size_t)3 * c->nl * sp * 4);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
@@ -1041,7 +1060,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   kt->decode(s, c->d_params, a, c->L, na, A);
   kt->decode(s, c->d_params, b, c->L, nb, Bv);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2);                 // pk.Mult(coeff1, coeff2), poly.go:146
+  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2, pairing_run(np), pws, sp);                 // pk.Mult(coeff1, coeff2), poly.go:146
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;

@@ -105,16 +105,26 @@ __device__ __forceinline__ void l_load(Fp<NL>& r, const LFp<NL>* s) {
 
 // Limb-major structure-of-arrays storage in HBM: limb j of element e lives at
 // base[j * stride + e]; consecutive lanes touch consecutive dwords.
+// The limb row base + j*stride is wave-uniform (scalar address) and the element index is a 32-bit lane
+// offset, so the accesses use the SGPR-base addressing mode instead of 38 per-lane 64-bit addresses.
 template <int NL>
 __device__ __forceinline__ void g_load(Fp<NL>& r, const u32* __restrict__ base, size_t stride, size_t e) {
+  const unsigned e32 = (unsigned)e;
 #pragma unroll
-  for (int j = 0; j < NL; ++j) r.v[j] = base[(size_t)j * stride + e];
+  for (int j = 0; j < NL; ++j) {
+    const u32* __restrict__ row = base + (size_t)j * stride;
+    r.v[j] = row[e32];
+  }
 }
 
 template <int NL>
 __device__ __forceinline__ void g_store(u32* __restrict__ base, size_t stride, size_t e, const Fp<NL>& a) {
+  const unsigned e32 = (unsigned)e;
 #pragma unroll
-  for (int j = 0; j < NL; ++j) base[(size_t)j * stride + e] = a.v[j];
+  for (int j = 0; j < NL; ++j) {
+    u32* __restrict__ row = base + (size_t)j * stride;
+    row[e32] = a.v[j];
+  }
 }
 
 template <int NL>
@@ -268,6 +278,90 @@ __device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>
   }
 }
 
+// ---- Montgomery squaring --------------------------------------------------------------------
+// a^2 = sum a_i a_j x^(i+j).  The limb range is cut into four segments; a pair (i, j) with i in an
+// earlier segment than j is taken once, doubled; pairs inside one segment are taken in both orders,
+// undoubled.  Row i of segment [LO, HI) therefore multiplies a_i by a_j for j in [LO, HI) and 2*a_i by
+// a_j for j >= HI, at the usual relative accumulator positions j: the set of touched accumulators is
+// the same for every row of a segment, so the loops stay rolled with compile-time register indices,
+// the multiplier rows are still streamed from LDS, and no doubled copy of the operand is needed.
+// 904 product MADs instead of 1444 at NL = 38 (the reduction rows are unchanged); the doubled limb is
+// < 2^29 and the accumulators stay below 2^63.
+template <int NL, int LO, int HI>
+__device__ __forceinline__ void fp_sqr_row(u64 (&t)[NL], u32 ai, const Fp<NL>& a1,
+                                           const FpParams<NL>* __restrict__ P) {
+  const u32 ai2 = ai << 1;
+#pragma unroll
+  for (int j = LO; j < NL; ++j) t[j] += (u64)(j < HI ? ai : ai2) * a1.v[j];
+  const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] += (u64)m * P->p[j];
+  const u64 c = t[0] >> LIMB_BITS;
+#pragma unroll
+  for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
+  t[NL - 1] = 0;
+  t[0] += c;
+}
+
+// rows LO .. HI-1 (LO even; HI even, or HI == NL odd: the last row is then a single one).
+// `aa` carries the prefetched row pair LO/2 in and the next segment's first pair out.
+template <int NL, int LO, int HI>
+__device__ __forceinline__ void fp_sqr_segment(u64 (&t)[NL], u64& aa, const LFp<NL>* a, int tid, const Fp<NL>& a1,
+                                               const FpParams<NL>* __restrict__ P) {
+  static_assert(LO % 2 == 0 && LO < HI && HI <= NL, "segment bounds");
+#pragma unroll 1
+  for (int k = LO / 2; k < HI / 2; ++k) {
+    const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
+    const u64 nx = a->rows[kn][tid];
+    fp_sqr_row<NL, LO, HI>(t, (u32)aa, a1, P);
+    fp_sqr_row<NL, LO, HI>(t, (u32)(aa >> 32), a1, P);
+    aa = nx;
+  }
+  if (HI & 1) fp_sqr_row<NL, LO, HI>(t, (u32)aa, a1, P);
+}
+
+// Measured on MI355X (round 1, tools/ubench/fp_rates.hip and same-box A/B of bench.py): in isolation the
+// segmented square takes 6.6 us against 8.0 us for fp_mul, but inside k_pairing it made the kernel 3 %
+// SLOWER: the step bodies are straight-line code far larger than the 64 KB instruction cache, and the four
+// short loops (4-5 trips each) pay their cold first trip every time, where the product's single loop
+// amortises it over 19 trips.  Kept for the compact-code kernel planned next; disabled until then.
+constexpr bool kSegmentedSquare = false;
+
+// r = a^2/R mod p, lazy (< 2p); `a` both as LDS rows (streamed multiplier) and in VGPRs.  r may alias av.
+template <int NL>
+__device__ __forceinline__ void fp_sqr(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& av,
+                                       const FpParams<NL>* __restrict__ P) {
+  if constexpr (NL < 8 || !kSegmentedSquare) {
+    fp_mul<NL>(r, a, av, P);
+  } else {
+    constexpr int Q = ((NL / 4 + 1) / 2) * 2;   // even segment length: 10 at NL = 38, 4 at NL = 19
+    const int tid = threadIdx.x;
+    u64 t[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) t[j] = 0;
+    u64 aa = a->rows[0][tid];
+    fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+    fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
+    fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
+    fp_sqr_segment<NL, 3 * Q, NL>(t, aa, a, tid, av, P);
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const u64 s = t[j] + c;
+      r.v[j] = (u32)s & LIMB_MASK;
+      c = s >> LIMB_BITS;
+    }
+  }
+}
+
+// r = a^2 with a in VGPRs: stages a through the scratch LDS slot.
+template <int NL>
+__device__ __forceinline__ void fp_sqrv(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P,
+                                        LFp<NL>* stage) {
+  l_store<NL>(stage, a);
+  fp_sqr<NL>(r, stage, a, P);
+}
+
 // r = a*b with both operands in VGPRs: stages a through the scratch LDS slot.
 template <int NL>
 __device__ __forceinline__ void fp_mulv(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b,
@@ -323,7 +417,7 @@ __device__ __forceinline__ void fp_pow_uniform(Fp<NL>& r, const LFp<NL>* a_rows,
 #pragma unroll 1
   for (int i = e_bits - 1; i >= 0; --i) {
     l_store<NL>(stage, acc);
-    fp_mul<NL>(acc, stage, acc, P);
+    fp_sqr<NL>(acc, stage, acc, P);
     const u32 bit = (e_limbs[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u;
     if (bit) fp_mul<NL>(acc, a_rows, acc, P);
   }

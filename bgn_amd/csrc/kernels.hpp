@@ -110,8 +110,10 @@ struct KernelTable {
   //   mode 0: ea = eb = e.
   //   mode 1: B is one broadcast point (b.stride == 1): ea = e, eb = 0.
   //   mode 2: poly product: e = (q*d1 + i)*d2 + k ; ea = q*d1 + i ; eb = q*d2 + k.
+  //   run > 1: each lane owns `run` pairings and shares one F_p inversion among them; ws = workspace of
+  //   3*NL*sw u32 (sw >= count).  run == 1 / ws == null: one pairing per lane.
   void (*pairing)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                  size_t count, int mode, size_t d1, size_t d2);
+                  size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw);
   // plain canonical SoA -> canonical Montgomery SoA, in place (to chain kernels on the device)
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);

@@ -52,21 +52,7 @@ k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32*
 }
 
 // ---- pairing ----------------------------------------------------------------
-template <int NL>
-__global__ void __launch_bounds__(FP_BLOCK)
-k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
-          size_t count, int mode, size_t d1, size_t d2) {
-  __shared__ LFp<NL> L[4];
-  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
-  const bool live = e < count;
-  if (!live) e = count - 1;   // keep the wave's control flow uniform; results are discarded
-  PairOperands op;
-  op.ax = a.c0;
-  op.ay = a.c1;
-  op.sa = a.stride;
-  op.bx = b.c0;
-  op.by = b.c1;
-  op.sb = b.stride;
+__device__ __forceinline__ void pair_index(PairOperands& op, size_t e, int mode, size_t d1, size_t d2) {
   if (mode == 0) {
     op.ea = e;
     op.eb = e;
@@ -80,17 +66,115 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     op.ea = qi;
     op.eb = q * d2 + k;
   }
-  const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
-  Fp<NL> re, im;
-  pairing_lane<NL>(re, im, L, op, C, P);
-  if (ident) {               // e(O, .) = e(., O) = 1   (pbc pairing_apply)
-    fp_zero(re);
-    fp_zero(im);
-    re.v[0] = 1;
+}
+
+// Each lane owns `run` pairings e = j*T + t (T = lanes in the grid): pass 1 runs the Miller loops and
+// parks f and the prefix product of the norms in the workspace; one Fermat inversion per lane; pass 2
+// peels 1/N(f_j) off and finishes the exponentiation.  ws: 3 F_p per element (F0, F1, prefix).
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
+          size_t count, int mode, size_t d1, size_t d2, int run, u32* __restrict__ ws, size_t sw) {
+  __shared__ LFp<NL> L[4];
+  const size_t T = (size_t)gridDim.x * FP_BLOCK;
+  const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  PairOperands op;
+  op.ax = a.c0;
+  op.ay = a.c1;
+  op.sa = a.stride;
+  op.bx = b.c0;
+  op.by = b.c1;
+  op.sb = b.stride;
+  u32* wF0 = ws;
+  u32* wF1 = ws + (size_t)NL * sw;
+  u32* wPf = ws + (size_t)2 * NL * sw;
+  Miller<NL> S;
+  Fp<NL> acc;
+  fp_set(acc, P->one);
+#pragma unroll 1
+  for (int j = 0; j < run; ++j) {
+    size_t e = (size_t)j * T + t;
+    const bool live = e < count;
+    if (!__ballot(live)) break;
+    if (!live) e = count - 1;             // keep the wave's control flow uniform; results are discarded
+    pair_index(op, e, mode, d1, d2);
+    miller_loop<NL>(S, L, op, C, P);
+    if (run == 1) {
+      const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
+      Fp<NL> N, ninv, g0, g1, re, im;
+      miller_norm<NL>(N, S, L, P);
+      l_store(L + 1, N);
+      fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);
+      final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
+      fp_from_mont<NL>(im, g1, P, L);
+      fp_from_mont<NL>(re, g0, P, L);
+      if (ident) {             // e(O, .) = e(., O) = 1   (pbc pairing_apply)
+        fp_zero(re);
+        fp_zero(im);
+        re.v[0] = 1;
+      }
+      if (live) {
+        g_store<NL>(out.c0, out.stride, e, re);
+        g_store<NL>(out.c1, out.stride, e, im);
+      }
+      return;
+    }
+    Fp<NL> N, r;
+    miller_norm<NL>(N, S, L, P);          // <4, never 0 for a valid pair (f != 0)
+    {
+      // an identity operand runs the loop on placeholder coordinates: keep its norm out of the product
+      const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
+      fp_set(r, P->one);
+      fp_select(N, ident, r, N);
+    }
+    if (live) {
+      a_load(r, S.F0);
+      g_store<NL>(wF0, sw, e, r);
+      a_load(r, S.F1);
+      g_store<NL>(wF1, sw, e, r);
+      g_store<NL>(wPf, sw, e, acc);
+    }
+    l_store(L, acc);
+    fp_mul(r, L, N, P);                    // <2  (8)
+    fp_select(acc, live, r, acc);
   }
-  if (live) {
-    g_store<NL>(out.c0, out.stride, e, re);
-    g_store<NL>(out.c1, out.stride, e, im);
+  Fp<NL> inv;
+  l_store(L + 1, acc);
+  fp_pow_uniform<NL>(inv, L + 1, C->pm2, C->pm2_bits, P, L);     // 1 / prod N_j  <2
+#pragma unroll 1
+  for (int j = run - 1; j >= 0; --j) {
+    size_t e = (size_t)j * T + t;
+    const bool live = e < count;
+    if (!__ballot(live)) continue;
+    if (!live) e = count - 1;
+    pair_index(op, e, mode, d1, d2);
+    Fp<NL> r, N, ninv;
+    g_load<NL>(r, wF0, sw, e);
+    a_store(S.F0, r);
+    g_load<NL>(r, wF1, sw, e);
+    a_store(S.F1, r);
+    miller_norm<NL>(N, S, L, P);
+    const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
+    fp_set(r, P->one);
+    fp_select(N, ident, r, N);
+    g_load<NL>(r, wPf, sw, e);
+    l_store(L, inv);
+    fp_mul(ninv, L, r, P);                 // 1/N_j <2
+    fp_mul(r, L, N, P);                    // inverse of the shorter prefix <2  (8)
+    fp_select(inv, live, r, inv);
+    Fp<NL> g0, g1, re, im;
+    final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
+    fp_from_mont<NL>(im, g1, P, L);
+    fp_from_mont<NL>(re, g0, P, L);
+    if (ident) {
+      fp_zero(re);
+      fp_zero(im);
+      re.v[0] = 1;
+    }
+    if (live) {
+      g_store<NL>(out.c0, out.stride, e, re);
+      g_store<NL>(out.c1, out.stride, e, im);
+    }
   }
 }
 
@@ -237,10 +321,12 @@ static void launch_encode(hipStream_t s, const uint8_t* inf, const uint32_t* c0,
 }
 
 static void launch_pairing(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                           size_t count, int mode, size_t d1, size_t d2) {
+                           size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw) {
   if (!count) return;
-  hipLaunchKernelGGL(k_pairing<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
-                     consts, a, b, out, count, mode, d1, d2);
+  if (run < 1 || !ws) run = 1;
+  const size_t lanes = (count + run - 1) / run;
+  hipLaunchKernelGGL(k_pairing<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     consts, a, b, out, count, mode, d1, d2, run, ws, sw);
 }
 
 static void launch_to_mont(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride,

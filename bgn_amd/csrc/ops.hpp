@@ -225,7 +225,7 @@ __device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L
       Fp<NL> num;
       {
         Fp<NL> xx, t3;
-        fp_mulv(xx, x1, x1, P, L + 1);      // <2
+        fp_sqrv(xx, x1, P, L + 1);      // <2
         fp_dbl(t3, xx);
         fp_add(t3, t3, xx);                 // <6
         Fp<NL> one;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L
       Fp<NL> lam;
       fp_mul(lam, L + 1, num, P);           // lambda <2   (14)
       Fp<NL> x3, y3;
-      fp_mulv(x3, lam, lam, P, L + 1);      // <2 ; L1 = lambda
+      fp_sqrv(x3, lam, P, L + 1);      // <2 ; L1 = lambda
       fp_sub<1>(x3, x3, x1, P);             // <3
       fp_sub<1>(x3, x3, x2, P);             // <4
       fp_sub<4>(y3, x1, x3, P);             // <5
@@ -282,16 +282,16 @@ __device__ __forceinline__ void jac_double(JacAcc<NL>& S, LFp<NL>* L, const FpPa
   LFp<NL>* L1 = L + 1;
   Fp<NL> r, u, w;
   a_load(r, S.Z);
-  fp_mulv(r, r, r, P, S0);                 // ZZ <2
-  fp_mulv(w, r, r, P, S0);                 // ZZ^2 <2
+  fp_sqrv(r, r, P, S0);                 // ZZ <2
+  fp_sqrv(w, r, P, S0);                 // ZZ^2 <2
   a_load(r, S.X);
-  fp_mulv(u, r, r, P, S0);                 // XX <2
+  fp_sqrv(u, r, P, S0);                 // XX <2
   fp_dbl(r, u);
   fp_add(r, r, u);
   fp_add(r, r, w);                         // M <8
   l_store(L1, r);                          // L1 = M
   a_load(r, S.Y);
-  fp_mulv(u, r, r, P, S0);                 // YY <2
+  fp_sqrv(u, r, P, S0);                 // YY <2
   a_store(S.U, u);                         // U = YY
   a_load(r, S.X);
   fp_mulv(r, r, u, P, S0);                 // X*YY <2
@@ -304,7 +304,7 @@ __device__ __forceinline__ void jac_double(JacAcc<NL>& S, LFp<NL>* L, const FpPa
   fp_dbl(r, r);                            // Z3 <4
   a_store(S.Z, r);
   l_load(r, L1);
-  fp_mul(u, L1, r, P);                     // M^2 <2
+  fp_sqr(u, L1, r, P);                     // M^2 <2
   a_load(r, S.T);                          // S
   fp_dbl(w, r);                            // <16
   fp_sub<16>(u, u, w, P);                  // X3 <18
@@ -312,7 +312,7 @@ __device__ __forceinline__ void jac_double(JacAcc<NL>& S, LFp<NL>* L, const FpPa
   fp_sub<18>(r, r, u, P);                  // S - X3 <26
   fp_mul(r, L1, r, P);                     // M*(S-X3) <2   (208)
   a_load(u, S.U);
-  fp_mulv(u, u, u, P, S0);                 // YY^2 <2
+  fp_sqrv(u, u, P, S0);                 // YY^2 <2
   fp_dbl(u, u);
   fp_dbl(u, u);
   fp_dbl(u, u);                            // <16
@@ -331,7 +331,7 @@ __device__ __forceinline__ void jac_add_affine(JacAcc<NL>& S, bool& acc_inf, boo
   LFp<NL>* LY = L + 3;
   Fp<NL> r, u, w;
   a_load(r, S.Z);                          // <4
-  fp_mulv(u, r, r, P, S0);                 // ZZ <2
+  fp_sqrv(u, r, P, S0);                 // ZZ <2
   l_store(L1, u);                          // L1 = ZZ
   fp_mul(r, L1, r, P);                     // Z^3 <2
   fp_mul(r, LY, r, P);                     // yB*Z^3 <2
@@ -355,12 +355,12 @@ __device__ __forceinline__ void jac_add_affine(JacAcc<NL>& S, bool& acc_inf, boo
   a_load(r, S.Z);
   fp_mul(r, L1, r, P);                     // Z3 = Z*H <2   (80)
   a_store(S.U, r);                         // U = Z3 (committed below)
-  fp_mul(w, L1, u, P);                     // HH <2  (400)
+  fp_sqr(w, L1, u, P);                     // HH <2  (400)
   fp_mul(u, L1, w, P);                     // HHH <2
   a_load(r, S.X);
   fp_mulv(r, r, w, P, S0);                 // XHH <2
   a_load(w, S.T);
-  fp_mulv(w, w, w, P, S0);                 // rr^2 <2
+  fp_sqrv(w, w, P, S0);                 // rr^2 <2
   fp_sub<2>(w, w, u, P);                   // <4
   {
     Fp<NL> d;
@@ -405,26 +405,26 @@ __device__ __forceinline__ void jac_add_affine(JacAcc<NL>& S, bool& acc_inf, boo
     // M = 3x^2 + 1, S = 4x*y^2, X3 = M^2 - 2S, Y3 = M(S - X3) - 8y^4, Z3 = 2y.
     Fp<NL> one;
     l_load(r, LX);
-    fp_mulv(u, r, r, P, S0);               // xx <2
+    fp_sqrv(u, r, P, S0);               // xx <2
     fp_dbl(w, u);
     fp_add(w, w, u);
     fp_set(one, P->one);
     fp_add(w, w, one);                     // M <7
     l_store(L1, w);                        // L1 = M
     l_load(r, LY);
-    fp_mulv(u, r, r, P, S0);               // yy <2
+    fp_sqrv(u, r, P, S0);               // yy <2
     l_load(r, LX);
     fp_mulv(r, r, u, P, S0);               // x*yy <2
     fp_dbl(r, r);
     fp_dbl(r, r);                          // S <8
     a_store(S.T, r);
-    fp_mulv(u, u, u, P, S0);               // yy^2 <2
+    fp_sqrv(u, u, P, S0);               // yy^2 <2
     fp_dbl(u, u);
     fp_dbl(u, u);
     fp_dbl(u, u);                          // <16
     a_store(S.U, u);
     l_load(r, L1);
-    fp_mul(u, L1, r, P);                   // M^2 <2  (49)
+    fp_sqr(u, L1, r, P);                   // M^2 <2  (49)
     a_load(r, S.T);
     fp_dbl(w, r);                          // <16
     fp_sub<16>(u, u, w, P);                // X3 <18
@@ -463,7 +463,7 @@ __device__ __forceinline__ void jac_store_affine(JacAcc<NL>& S, bool is_inf, u32
   fp_reduce8(r, r, P);                      // <1 (Z <4)
   fp_inv<NL>(zi, r, L, C, P);               // <2   (uses L0, L1)
   l_store(L + 1, zi);
-  fp_mul(u, L + 1, zi, P);                  // zi^2 <2
+  fp_sqr(u, L + 1, zi, P);                  // zi^2 <2
   a_load(r, S.X);
   fp_mulv(r, r, u, P, L);                   // x <2   (36)
   fp_mul(u, L + 1, u, P);                   // zi^3 <2

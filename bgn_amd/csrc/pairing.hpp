@@ -55,17 +55,17 @@ __device__ __forceinline__ void miller_double(Miller<NL>& S, LFp<NL>* L, const P
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
   a_load(r, S.Z);
-  fp_mulv(r, r, r, P, S0);                 // ZZ <2            (Z <4: 16)
+  fp_sqrv(r, r, P, S0);                 // ZZ <2            (Z <4: 16)
   l_store(L1, r);                          // L1 = ZZ
-  fp_mul(w, L1, r, P);                     // w = ZZ^2 <2
+  fp_sqr(w, L1, r, P);                     // w = ZZ^2 <2
   a_load(r, S.X);
-  fp_mulv(u, r, r, P, S0);                 // u = XX <2        (324)
+  fp_sqrv(u, r, P, S0);                 // u = XX <2        (324)
   fp_dbl(r, u);
   fp_add(r, r, u);
   fp_add(r, r, w);                         // M = 3XX + ZZ^2 <8   (curve a = 1)
   a_store(S.T, r);                         // T = M
   a_load(r, S.Y);
-  fp_mulv(u, r, r, P, S0);                 // u = YY <2
+  fp_sqrv(u, r, P, S0);                 // u = YY <2
   l_store(L2, u);                          // L2 = YY
   a_load(r, S.X);
   fp_mulv(r, r, u, P, S0);                 // X*YY <2           (36)
@@ -94,7 +94,7 @@ __device__ __forceinline__ void miller_double(Miller<NL>& S, LFp<NL>* L, const P
   a_store(S.Y, u);                         // Y slot = cre  (Y dead)
   // X3 = M^2 - 2S
   a_load(r, S.T);
-  fp_mulv(u, r, r, P, S0);                 // M^2 <2            (64)
+  fp_sqrv(u, r, P, S0);                 // M^2 <2            (64)
   l_load(r, L3);                           // S <8
   fp_dbl(w, r);                            // 2S <16
   fp_sub<16>(u, u, w, P);                  // X3 <18
@@ -104,7 +104,7 @@ __device__ __forceinline__ void miller_double(Miller<NL>& S, LFp<NL>* L, const P
   a_load(u, S.T);
   fp_mulv(r, r, u, P, S0);                 // <2                (208)
   l_load(u, L2);
-  fp_mulv(u, u, u, P, S0);                 // YY^2 <2
+  fp_sqrv(u, u, P, S0);                 // YY^2 <2
   fp_dbl(u, u);
   fp_dbl(u, u);
   fp_dbl(u, u);                            // <16
@@ -155,7 +155,7 @@ __device__ __forceinline__ void miller_add(Miller<NL>& S, LFp<NL>* L, const Pair
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
   a_load(r, S.Z);                          // <4
-  fp_mulv(u, r, r, P, S0);                 // ZZ <2             (16)
+  fp_sqrv(u, r, P, S0);                 // ZZ <2             (16)
   l_store(L1, u);                          // L1 = ZZ
   fp_mul(r, L1, r, P);                     // Z^3 <2            (8)
   g_load(u, op.ay, op.sa, op.ea);       // yA <1
@@ -173,12 +173,12 @@ __device__ __forceinline__ void miller_add(Miller<NL>& S, LFp<NL>* L, const Pair
   a_load(r, S.Z);
   fp_mul(r, L1, r, P);                     // Z3 = Z*H <2       (80)
   a_store(S.Z, r);
-  fp_mul(w, L1, u, P);                     // HH <2             (400)
+  fp_sqr(w, L1, u, P);                     // HH <2             (400)
   fp_mul(u, L1, w, P);                     // HHH <2            (40)
   a_load(r, S.X);
   fp_mulv(r, r, w, P, S0);                 // XHH <2            (36)
   a_load(w, S.T);
-  fp_mulv(w, w, w, P, S0);                 // rr^2 <2           (400)
+  fp_sqrv(w, w, P, S0);                 // rr^2 <2           (400)
   fp_sub<2>(w, w, u, P);                   // <4
   {
     Fp<NL> d;
@@ -271,37 +271,48 @@ __device__ __forceinline__ void fp2_sqr_v(Fp<NL>& r0, Fp<NL>& r1, const Fp<NL>& 
   fp_dbl(r1, d);                           // <4
 }
 
-// g = f^((p-1)*l) : conj(f)/f = conj(f)^2 / N(f), then ^l.  f in (F0 <4, F1 <6).
-// Result in VGPRs, lazy (<4, <6).
+// ---- final exponentiation, split so the F_p inversion can be batched ----------------------
+// f^((p-1)*l): f^(p-1) = conj(f)/f = conj(f)^2 / N(f) with N(f) = F0^2 + F1^2 in F_p, then ^l.
+// The only inversion is 1/N.  A lane that owns a run of pairings multiplies the norms together,
+// inverts the product once (Fermat, ~1.5 k products) and peels the individual inverses off
+// (Montgomery's trick), so the inversion costs ~3 products per pairing instead of ~1.5 k.
+
+// N = F0^2 + F1^2 <4 from the state's F0 <4, F1 <6.
 template <int NL>
-__device__ __forceinline__ void final_exp(Fp<NL>& g0, Fp<NL>& g1, Miller<NL>& S, LFp<NL>* L,
-                                          const PairingConsts* __restrict__ C,
-                                          const FpParams<NL>* __restrict__ P) {
+__device__ __forceinline__ void miller_norm(Fp<NL>& N, Miller<NL>& S, LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
+  Fp<NL> r, u;
+  a_load(r, S.F0);
+  fp_sqrv(r, r, P, L);                  // F0^2 <2
+  a_load(u, S.F1);
+  fp_sqrv(u, u, P, L);                  // F1^2 <2
+  fp_add(N, r, u);                         // <4
+}
+
+// g = (conj(f)^2 * ninv)^l with ninv = 1/N(f) <2 given.  Result lazy (<4, <6).
+template <int NL>
+__device__ __forceinline__ void final_exp_with_inverse(Fp<NL>& g0, Fp<NL>& g1, Miller<NL>& S, const Fp<NL>& ninv,
+                                                       LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                                       const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
   LFp<NL>* L1 = L + 1;
   LFp<NL>* L2 = L + 2;
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
+  l_store(L3, ninv);                       // L3 = 1/N
   a_load(r, S.F0);
   a_load(u, S.F1);
   fp_mulv(w, r, u, P, S0);                 // F0*F1 <2          (24)
   fp_dbl(w, w);                            // <4
   fp_neg<4>(w, w, P);                      // im(conj(f)^2) = -2*F0*F1  <=4
-  a_store(S.T, w);
-  fp_mulv(r, r, r, P, S0);                 // F0^2 <2
-  fp_mulv(u, u, u, P, S0);                 // F1^2 <2
-  fp_add(w, r, u);                         // N = F0^2 + F1^2 <4
+  fp_mul(w, L3, w, P);                     // h1 <2             (8)
+  l_store(L2, w);                          // L2 = h1
+  fp_sqrv(r, r, P, S0);                 // F0^2 <2
+  fp_sqrv(u, u, P, S0);                 // F1^2 <2
   fp_sub<2>(r, r, u, P);                   // re(conj(f)^2) <4
-  a_store(S.X, r);
-  l_store(L1, w);                          // L1 = N
-  fp_pow_uniform<NL>(w, L1, C->pm2, C->pm2_bits, P, S0);   // 1/N <2
-  a_load(r, S.X);
-  fp_mulv(r, r, w, P, S0);                 // h0 <2             (8)
-  a_load(u, S.T);
-  fp_mulv(u, u, w, P, S0);                 // h1 <2             (8)
+  fp_mul(r, L3, r, P);                     // h0 <2             (8)
+  l_store(L1, r);                          // L1 = h0
+  l_load(u, L2);
   // g = h^l, l wave-uniform, square-and-multiply; h parked in L1/L2.
-  l_store(L1, r);
-  l_store(L2, u);
   LFp2<NL> h{L1, L2};
 #pragma unroll 1
   for (int i = C->l_bits - 2; i >= 0; --i) {
@@ -318,13 +329,11 @@ __device__ __forceinline__ void final_exp(Fp<NL>& g0, Fp<NL>& g1, Miller<NL>& S,
   g1 = u;
 }
 
-// Whole pairing for one lane.  A, B affine, canonical Montgomery form in HBM.
-// Result: canonical (non-Montgomery) re/im in [0, p).
+// Miller loop for one pairing: leaves f in S.F0 / S.F1.
 template <int NL>
-__device__ __forceinline__ void pairing_lane(Fp<NL>& out_re, Fp<NL>& out_im, LFp<NL>* L, const PairOperands& op,
-                                             const PairingConsts* __restrict__ C,
-                                             const FpParams<NL>* __restrict__ P) {
-  Miller<NL> S;
+__device__ __forceinline__ void miller_loop(Miller<NL>& S, LFp<NL>* L, const PairOperands& op,
+                                            const PairingConsts* __restrict__ C,
+                                            const FpParams<NL>* __restrict__ P) {
   {
     Fp<NL> r;
     g_load(r, op.ax, op.sa, op.ea);
@@ -344,8 +353,21 @@ __device__ __forceinline__ void pairing_lane(Fp<NL>& out_re, Fp<NL>& out_im, LFp
     const int d = C->naf[i];
     if (d != 0 && i != 0) miller_add<NL>(S, L, op, d, P);
   }
-  Fp<NL> g0, g1;
-  final_exp<NL>(g0, g1, S, L, C, P);
+}
+
+// Whole pairing for one lane (run of one).  A, B affine, canonical Montgomery form in HBM.
+// Result: canonical (non-Montgomery) re/im in [0, p).
+template <int NL>
+__device__ __forceinline__ void pairing_lane(Fp<NL>& out_re, Fp<NL>& out_im, LFp<NL>* L, const PairOperands& op,
+                                             const PairingConsts* __restrict__ C,
+                                             const FpParams<NL>* __restrict__ P) {
+  Miller<NL> S;
+  miller_loop<NL>(S, L, op, C, P);
+  Fp<NL> N, ninv, g0, g1;
+  miller_norm<NL>(N, S, L, P);
+  l_store(L + 1, N);
+  fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);   // 1/N <2
+  final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
   fp_from_mont<NL>(out_im, g1, P, L);
   fp_from_mont<NL>(out_re, g0, P, L);
 }

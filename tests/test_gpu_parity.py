@@ -302,3 +302,24 @@ def test_repeated_setup_keeps_key_tables_alive():
         pk.SetupDecryption(sk)
         c = pk.EncryptWithRandomness(7, 123456789)
         assert sk.Decrypt(c, pk) == 7
+
+
+def test_mult_runs_with_shared_inversion():
+    """count > 2*65536 makes every lane own a run of pairings that share one F_p inversion
+    (Montgomery's trick in the final exponentiation); ragged tail; identities inside the runs."""
+    fx = load_fixture("toy64")
+    opk, _ = oracle_key(fx)
+    pk, _ = engine_key(fx)
+    rng = random.Random(99)
+    pool = [R.pt_mul(opk.P, rng.randrange(1, opk.n), opk.p) for _ in range(6)] + [None]
+    wires = [R.elem_to_bytes(x, opk.p) for x in pool]
+    count = 3 * 65536 + 77           # run = 3, ragged last run
+    ia = np.array([rng.randrange(len(pool)) for _ in range(count)])
+    ib = np.array([rng.randrange(len(pool)) for _ in range(count)])
+    tab = np.frombuffer(b"".join(wires), dtype=np.uint8).reshape(len(pool), -1)
+    out = pk.engine.mult(tab[ia].tobytes(), tab[ib].tobytes())
+    exp = np.zeros((len(pool), len(pool), out.shape[1]), dtype=np.uint8)
+    for i in range(len(pool)):
+        for k in range(len(pool)):
+            exp[i, k] = np.frombuffer(R.elem_to_bytes(opk.e(pool[i], pool[k]), opk.p), dtype=np.uint8)
+    assert (out == exp[ia, ib]).all()

@@ -83,6 +83,33 @@ def secondary_metrics(pk, fx, dev, dec_log2):
     out["encrypt"] = {"value": n_enc / dt, "unit": "encrypts/s", "batch": n_enc,
                       "workload": "configs[1]: P^m * Q^r, 40-bit m, 1022-bit r, fused fixed-base kernel (8-bit window tables of P and Q in HBM)",
                       "algorithmic_bytes_per_unit": 5 + 128 + EB}
+    # --- EAdd (level 1): pairs of those ciphertexts
+    n_add = n_enc // 2
+    a1, b1 = cts[: n_add * EB], cts[n_add * EB: 2 * n_add * EB]
+    o1 = torch.empty(n_add * EB, dtype=torch.uint8, device=dev)
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.add_dev(1, a1, b1, o1, n_add)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out["eadd_l1"] = {"value": n_add / dt, "unit": "adds/s", "batch": n_add,
+                      "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion)",
+                      "algorithmic_bytes_per_unit": 3 * EB, "achieved_GBps": 3 * EB * n_add / dt / 1e9}
+    # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^(dec_log2-4) polynomials = 2^(dec_log2+4) pairs
+    npoly, d1, d2 = 1 << max(dec_log2 - 4, 0), 16, 16
+    pa = cts[: npoly * d1 * EB]
+    pb = cts[npoly * d1 * EB: npoly * (d1 + d2) * EB]
+    po = torch.empty(npoly * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.poly_mult_dev(npoly, d1, d2, pa, pb, po)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out["multpoly"] = {"value": npoly * d1 * d2 / dt, "unit": "coefficient pairs/s", "polys": npoly, "d1": d1, "d2": d2,
+                       "workload": "configs[4] shape on one GPU: MultPoly of 16x16-coefficient ciphertext polynomials "
+                                   "(d1*d2 pairings + segmented GT accumulation), sharded by polynomial across GPUs"}
     # --- Decrypt: first 2^dec_log2 of those ciphertexts, every 16th negated
     n_dec = 1 << dec_log2
     t0 = time.perf_counter()
@@ -216,6 +243,12 @@ def main():
         alg_bytes = 3 * EB                               # two G1 operands in, one GT element out
         achieved = alg_bytes * count / (k_ms * 1e-3) / 1e9
         mads = bgn_amd.synthetic.algorithmic_mads_per_pairing(fx)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and args.batch_log2 == 20 and args.key == "k1024":
+            with open(pmc) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"]     # separate rocprofv3 --pmc passes of this command
+            traffic_src = "profiles/r01_pmc_summary.json (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)"
         line = {
             "metric": "EMult pairings/sec at 1024-bit, batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,7 +261,7 @@ def main():
                        "parallelism": "batch-sharded x%d + RCCL all-gather of results" % world if world > 1 else "single GPU",
                        },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_pairing": alg_bytes},
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads,

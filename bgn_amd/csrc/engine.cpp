@@ -69,6 +69,8 @@ struct bgn_ctx {
   uint32_t* d_tabP = nullptr;
   uint32_t* d_tabQ = nullptr;
   int fixed_windows = 0;
+  uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
+  size_t miller_steps = 0;
   BsgsParams bsgs{};
   bool have_tables = false;
 
@@ -185,6 +187,7 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_sk) (void)hipFree(c->d_sk);
   if (c->d_gt) (void)hipFree(c->d_gt);
   if (c->d_table) (void)hipFree(c->d_table);
+  if (c->d_fixedpair) (void)hipFree(c->d_fixedpair);
   if (c->d_tabP) (void)hipFree(c->d_tabP);
   if (c->d_tabQ) (void)hipFree(c->d_tabQ);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -274,9 +277,18 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     // e(Q,Q) (blinding base of level-2 ops, bgn.go:306,469) and the GT identity
     {
       SoA2 o{c->d_keypts + 4 * c->nl, c->d_keypts + 5 * c->nl, nullptr, 1};
-      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0);
+      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0, nullptr);
       kt->to_mont(nullptr, c->d_params, o.c0, o.c1, 1, 1);
       HIP_BRK(hipMemcpy(c->d_keypts + 6 * c->nl, img.data() + c->nl, (size_t)c->nl * 4, hipMemcpyHostToDevice));  // one
+    }
+    // line table of e(P, .) for makeL2 and the level-1 decryption lift (one lane, ~0.2 s per key)
+    {
+      size_t steps = naf.size() - 1;
+      for (size_t i = 1; i + 1 < naf.size(); ++i)
+        if (naf[i] != 0) steps++;
+      c->miller_steps = steps;
+      HIP_BRK(hipMalloc((void**)&c->d_fixedpair, steps * 3 * (size_t)c->nl * 4));
+      kt->fixedpair_build(nullptr, c->d_params, c->d_consts, c->d_keypts, c->d_keypts + c->nl, c->d_fixedpair);
     }
     HIP_BRK(hipGetLastError());
     HIP_BRK(hipDeviceSynchronize());
@@ -353,7 +365,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   const int nl = c->nl;
   SoA2 g{c->d_gt, c->d_gt + nl, nullptr, 1}, gi{c->d_gt + 2 * nl, c->d_gt + 3 * nl, nullptr, 1};
   // g = e(P,P)^sk  (bgn.go:198-199)
-  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0);
+  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0, nullptr);
   kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
   gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
   kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
@@ -434,7 +446,8 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so);
+  kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
+              (mode == 1) ? c->d_fixedpair : nullptr);
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;
@@ -991,7 +1004,8 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   SoA2 base = A;
   if (level == 1) {
     // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp)
-    kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pairing_run(count), pws, st);
+    kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pairing_run(count), pws, st,
+                c->d_fixedpair);
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
@@ -1060,7 +1074,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   kt->decode(s, c->d_params, a, c->L, na, A);
   kt->decode(s, c->d_params, b, c->L, nb, Bv);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2, pairing_run(np), pws, sp);                 // pk.Mult(coeff1, coeff2), poly.go:146
+  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2, pairing_run(np), pws, sp, nullptr);                 // pk.Mult(coeff1, coeff2), poly.go:146
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;

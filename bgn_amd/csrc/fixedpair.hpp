@@ -1,0 +1,267 @@
+// fixedpair.hpp — pairing with a key-constant first argument: e(P, C).
+//
+// makeL2 (bgn.go:316-321) and the level-1 decryption lift pair every ciphertext with the same
+// point, pk.P.  The reduced Tate pairing of this curve is symmetric (distortion map), so
+// e(C, P) = e(P, C) and the Miller loop can run over P: all point arithmetic becomes a per-key
+// constant and only the line evaluations at phi(C) remain per ciphertext.
+//
+// Per Miller step s the line through the running point V = k_s*P, scaled by F_p factors, is
+//     l_s(phi(C)) = (a_s * xC + b_s) + i * (c_s * yC)
+// with (Jacobian formulas of pairing.hpp, B := C)
+//     doubling: a = M*ZZ,  b = M*X - 2YY,            c = Z3*ZZ
+//     addition: a = rr,    b = rr*xP - Z3*ysP,       c = Z3          (ysP = +-yP for the NAF digit)
+// The table (a_s, b_s, c_s), s over the 1024 doublings and 332 additions of the NAF of n, is built
+// once per key by one lane (k_fixedpair_build); a ciphertext then costs 7 products per doubling
+// step and 5 per addition step instead of 18 and 17.
+#pragma once
+#include "pairing.hpp"
+
+namespace bgn {
+
+// ---- table build: one lane, the point part of miller_double / miller_add plus the coefficients ----
+template <int NL>
+struct FixedBuild {
+  AFp<NL> X, Y, Z, T, U;
+};
+
+template <int NL>
+__device__ __forceinline__ void fixed_store3(u32* __restrict__ tab, size_t s, const Fp<NL>& a, const Fp<NL>& b,
+                                             const Fp<NL>& c, const FpParams<NL>* __restrict__ P, LFp<NL>* L) {
+  Fp<NL> t;
+  fp_canon<NL>(t, a, P, L);
+  g_store<NL>(tab + (3 * s + 0) * NL, 1, 0, t);
+  fp_canon<NL>(t, b, P, L);
+  g_store<NL>(tab + (3 * s + 1) * NL, 1, 0, t);
+  fp_canon<NL>(t, c, P, L);
+  g_store<NL>(tab + (3 * s + 2) * NL, 1, 0, t);
+}
+
+// V <- 2V and the tangent's coefficients
+template <int NL>
+__device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, u32* tab, size_t s, LFp<NL>* L,
+                                                   const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  LFp<NL>* L2 = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  a_load(r, S.Z);
+  fp_mulv(r, r, r, P, S0);                 // ZZ <2
+  l_store(L1, r);                          // L1 = ZZ
+  fp_mul(w, L1, r, P);                     // ZZ^2 <2
+  a_load(r, S.X);
+  fp_mulv(u, r, r, P, S0);                 // XX <2
+  fp_dbl(r, u);
+  fp_add(r, r, u);
+  fp_add(r, r, w);                         // M <8
+  l_store(L2, r);                          // L2 = M
+  a_load(r, S.Y);
+  fp_mulv(u, r, r, P, S0);                 // YY <2
+  a_store(S.U, u);                         // U = YY
+  a_load(r, S.X);
+  fp_mulv(r, r, u, P, S0);                 // X*YY <2
+  fp_dbl(r, r);
+  fp_dbl(r, r);                            // S <8
+  a_store(S.T, r);                         // T = S
+  // coefficients need the OLD X and the new Z3
+  a_load(r, S.Y);
+  a_load(u, S.Z);
+  fp_mulv(r, r, u, P, S0);                 // YZ <2
+  fp_dbl(r, r);                            // Z3 <4
+  a_store(S.Z, r);
+  {
+    Fp<NL> ca, cb, cc;
+    l_load(u, L1);                         // ZZ
+    fp_mul(ca, L2, u, P);                  // a = M*ZZ <2
+    fp_mul(cc, L1, r, P);                  // c = Z3*ZZ <2
+    a_load(u, S.X);
+    fp_mul(cb, L2, u, P);                  // M*X <2   (8*18)
+    a_load(u, S.U);
+    fp_dbl(u, u);                          // 2YY <4
+    fp_sub<4>(cb, cb, u, P);               // b <6
+    l_store(L3, cb);
+    fixed_store3<NL>(tab, s, ca, cb, cc, P, S0);
+  }
+  l_load(r, L2);
+  fp_mul(u, L2, r, P);                     // M^2 <2
+  a_load(r, S.T);                          // S
+  fp_dbl(w, r);
+  fp_sub<16>(u, u, w, P);                  // X3 <18
+  a_store(S.X, u);
+  fp_sub<18>(r, r, u, P);                  // S - X3 <26
+  fp_mul(r, L2, r, P);                     // <2
+  a_load(u, S.U);
+  fp_mulv(u, u, u, P, S0);                 // YY^2
+  fp_dbl(u, u);
+  fp_dbl(u, u);
+  fp_dbl(u, u);                            // <16
+  fp_sub<16>(r, r, u, P);                  // Y3 <18
+  a_store(S.Y, r);
+}
+
+// V <- V + sP and the chord's coefficients (px, py: P canonical Montgomery, stride 1)
+template <int NL>
+__device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, u32* tab, size_t s, const u32* px, const u32* py,
+                                                int sign, LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  LFp<NL>* L2 = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  a_load(r, S.Z);
+  fp_mulv(u, r, r, P, S0);                 // ZZ <2
+  l_store(L1, u);
+  fp_mul(r, L1, r, P);                     // Z^3 <2
+  g_load(u, py, 1, 0);
+  if (sign < 0) fp_neg<1>(u, u, P);        // ysP
+  l_store(L2, u);                          // L2 = ysP
+  fp_mul(r, L2, r, P);                     // ysP*Z^3 <2
+  a_load(u, S.Y);
+  fp_sub<18>(r, r, u, P);                  // rr <20
+  a_store(S.T, r);                         // T = rr
+  g_load(u, px, 1, 0);
+  fp_mul(u, L1, u, P);                     // xP*ZZ <2
+  a_load(w, S.X);
+  fp_sub<18>(u, u, w, P);                  // H <20
+  l_store(L1, u);                          // L1 = H
+  a_load(r, S.Z);
+  fp_mul(r, L1, r, P);                     // Z3 <2
+  a_store(S.Z, r);
+  {
+    Fp<NL> ca, cb, cc;
+    a_load(ca, S.T);                       // a = rr <20
+    cc = r;                                // c = Z3 <2
+    fp_mul(w, L2, r, P);                   // Z3*ysP <2
+    g_load(r, px, 1, 0);
+    l_store(L3, ca);
+    fp_mul(cb, L3, r, P);                  // rr*xP <2   (20)
+    fp_sub<2>(cb, cb, w, P);               // b <4
+    l_load(r, L1);                         // keep H across the store (it clobbers S0 only)
+    fixed_store3<NL>(tab, s, ca, cb, cc, P, S0);
+    u = r;
+  }
+  fp_mul(w, L1, u, P);                     // HH <2
+  fp_mul(u, L1, w, P);                     // HHH <2
+  a_load(r, S.X);
+  fp_mulv(r, r, w, P, S0);                 // XHH <2
+  a_load(w, S.T);
+  fp_mulv(w, w, w, P, S0);                 // rr^2 <2
+  fp_sub<2>(w, w, u, P);                   // <4
+  {
+    Fp<NL> d;
+    fp_dbl(d, r);
+    fp_sub<4>(w, w, d, P);                 // X3 <8
+  }
+  a_store(S.X, w);
+  fp_sub<8>(r, r, w, P);                   // XHH - X3 <10
+  a_load(w, S.T);
+  fp_mulv(r, r, w, P, S0);                 // <2
+  a_load(w, S.Y);
+  fp_mulv(w, w, u, P, S0);                 // Y*HHH <2
+  fp_sub<2>(r, r, w, P);                   // Y3 <4
+  a_store(S.Y, r);
+}
+
+// Builds the whole table (3 F_p per step) on lane 0 of the launch.
+template <int NL>
+__device__ __forceinline__ void fixed_build_lane(u32* tab, const u32* px, const u32* py, LFp<NL>* L,
+                                                 const PairingConsts* __restrict__ C,
+                                                 const FpParams<NL>* __restrict__ P) {
+  FixedBuild<NL> S;
+  {
+    Fp<NL> r;
+    g_load(r, px, 1, 0);
+    a_store(S.X, r);
+    g_load(r, py, 1, 0);
+    a_store(S.Y, r);
+    fp_set(r, P->one);
+    a_store(S.Z, r);
+    a_store(S.T, r);
+    a_store(S.U, r);
+  }
+  size_t s = 0;
+#pragma unroll 1
+  for (int i = C->naf_len - 2; i >= 0; --i) {
+    fixed_build_double<NL>(S, tab, s++, L, P);
+    const int d = C->naf[i];
+    if (d != 0 && i != 0) fixed_build_add<NL>(S, tab, s++, px, py, d, L, P);
+  }
+}
+
+// ---- per-ciphertext Miller loop over the table -----------------------------------------------
+// f in S.F0 / S.F1 on return; xC, yC (canonical Montgomery) are read from `op.ax/ay`.
+template <int NL>
+__device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, const PairOperands& op,
+                                                  const u32* __restrict__ tab, const PairingConsts* __restrict__ C,
+                                                  const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* LX = L + 1;
+  LFp<NL>* LY = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  g_load(r, op.ax, op.sa, op.ea);
+  l_store(LX, r);                          // LX = xC
+  g_load(r, op.ay, op.sa, op.ea);
+  l_store(LY, r);                          // LY = yC
+  fp_set(r, P->one);
+  a_store(S.F0, r);
+  fp_zero(r);
+  a_store(S.F1, r);
+  size_t s = 0;
+#pragma unroll 1
+  for (int i = C->naf_len - 2; i >= 0; --i) {
+    const int d = C->naf[i];
+    const int nsteps = (d != 0 && i != 0) ? 2 : 1;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k, ++s) {
+      const u32* e = tab + 3 * s * NL;
+      // line value
+      g_load(r, e, 1, 0);                  // a_s
+      fp_mul(r, LX, r, P);                 // a*xC <2
+      g_load(u, e + NL, 1, 0);             // b_s <1
+      fp_add(r, r, u);                     // cre <3
+      a_store(S.X, r);                     // X slot = cre
+      g_load(u, e + 2 * NL, 1, 0);         // c_s
+      fp_mul(u, LY, u, P);                 // cim <2
+      fp_add(r, r, u);                     // cre + cim <5
+      a_store(S.T, r);
+      a_store(S.Y, u);                     // Y slot = cim
+      // g = f^2 for a doubling step, g = f for an addition step
+      a_load(r, S.F0);                     // <4
+      a_load(u, S.F1);                     // <6
+      if (k == 0) {
+        fp_add(w, r, u);                   // <10
+        l_store(S0, w);
+        fp_sub<6>(w, r, u, P);             // <10
+        fp_mul(w, S0, w, P);               // g0 <2
+        fp_mulv(r, r, u, P, S0);           // F0*F1 <2
+        fp_dbl(r, r);                      // g1 <4
+      } else {
+        w = r;                             // g0 <4
+        r = u;                             // g1 <6
+      }
+      fp_add(u, w, r);                     // g0+g1 <10
+      l_store(L3, u);
+      // f = g * (cre + i*cim)
+      {
+        Fp<NL> c;
+        a_load(c, S.X);
+        fp_mulv(w, w, c, P, S0);           // v0 = g0*cre <2   (12)
+        a_load(c, S.Y);
+        fp_mulv(r, r, c, P, S0);           // v1 = g1*cim <2   (12)
+      }
+      a_load(u, S.T);
+      fp_mul(u, L3, u, P);                 // (g0+g1)(cre+cim) <2   (50)
+      {
+        Fp<NL> dd;
+        fp_sub<2>(dd, w, r, P);            // F0 <4
+        a_store(S.F0, dd);
+        fp_add(dd, w, r);                  // <4
+        fp_sub<4>(u, u, dd, P);            // F1 <6
+        a_store(S.F1, u);
+      }
+    }
+  }
+}
+
+}  // namespace bgn

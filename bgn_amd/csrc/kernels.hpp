@@ -112,8 +112,14 @@ struct KernelTable {
   //   mode 2: poly product: e = (q*d1 + i)*d2 + k ; ea = q*d1 + i ; eb = q*d2 + k.
   //   run > 1: each lane owns `run` pairings and shares one F_p inversion among them; ws = workspace of
   //   3*NL*sw u32 (sw >= count).  run == 1 / ws == null: one pairing per lane.
+  //   fixed_tab != null (mode 1 only): the second operand is the key's P and the Miller loop runs over the
+  //   precomputed line table (fixedpair.hpp); b is ignored.
   void (*pairing)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                  size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw);
+                  size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
+                  const uint32_t* fixed_tab);
+  // builds the line table of e(P, .) : 3*NL u32 per Miller step (px, py canonical Montgomery, stride 1)
+  void (*fixedpair_build)(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
+                          const uint32_t* py, uint32_t* tab);
   // plain canonical SoA -> canonical Montgomery SoA, in place (to chain kernels on the device)
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);

@@ -5,6 +5,7 @@
 #include "ops.hpp"
 #include "codec.hpp"
 #include "bsgs.hpp"
+#include "fixedpair.hpp"
 
 namespace bgn {
 
@@ -71,10 +72,11 @@ __device__ __forceinline__ void pair_index(PairOperands& op, size_t e, int mode,
 // Each lane owns `run` pairings e = j*T + t (T = lanes in the grid): pass 1 runs the Miller loops and
 // parks f and the prefix product of the norms in the workspace; one Fermat inversion per lane; pass 2
 // peels 1/N(f_j) off and finishes the exponentiation.  ws: 3 F_p per element (F0, F1, prefix).
-template <int NL>
+template <int NL, bool FIXED>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
-          size_t count, int mode, size_t d1, size_t d2, int run, u32* __restrict__ ws, size_t sw) {
+          size_t count, int mode, size_t d1, size_t d2, int run, u32* __restrict__ ws, size_t sw,
+          const u32* __restrict__ fixed_tab) {
   __shared__ LFp<NL> L[4];
   const size_t T = (size_t)gridDim.x * FP_BLOCK;
   const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
@@ -98,7 +100,10 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     if (!__ballot(live)) break;
     if (!live) e = count - 1;             // keep the wave's control flow uniform; results are discarded
     pair_index(op, e, mode, d1, d2);
-    miller_loop<NL>(S, L, op, C, P);
+    if (FIXED)
+      miller_loop_fixed<NL>(S, L, op, fixed_tab, C, P);
+    else
+      miller_loop<NL>(S, L, op, C, P);
     if (run == 1) {
       const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
       Fp<NL> N, ninv, g0, g1, re, im;
@@ -321,12 +326,30 @@ static void launch_encode(hipStream_t s, const uint8_t* inf, const uint32_t* c0,
 }
 
 static void launch_pairing(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                           size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw) {
+                           size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
+                           const uint32_t* fixed_tab) {
   if (!count) return;
   if (run < 1 || !ws) run = 1;
   const size_t lanes = (count + run - 1) / run;
-  hipLaunchKernelGGL(k_pairing<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
-                     consts, a, b, out, count, mode, d1, d2, run, ws, sw);
+  if (fixed_tab && mode == 1)
+    hipLaunchKernelGGL((k_pairing<NL_, true>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
+                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab);
+  else
+    hipLaunchKernelGGL((k_pairing<NL_, false>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
+                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_fixedpair_build(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, const u32* px, const u32* py,
+                  u32* tab) {
+  __shared__ LFp<NL> L[4];
+  fixed_build_lane<NL>(tab, px, py, L, C, P);     // every lane computes and stores the same values
+}
+
+static void launch_fixedpair_build(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
+                                   const uint32_t* py, uint32_t* tab) {
+  hipLaunchKernelGGL(k_fixedpair_build<NL_>, dim3(1), dim3(64), 0, s, (const FpParams<NL_>*)params, consts, px, py, tab);
 }
 
 static void launch_to_mont(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride,
@@ -401,10 +424,11 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {
       NL_,
       sizeof(FpParams<NL_>),
-      "k_pairing<" BGN_STR(BGN_NL) ">",
+      "k_pairing<" BGN_STR(BGN_NL) ", false>",
       launch_decode,
       launch_encode,
       launch_pairing,
+      launch_fixedpair_build,
       launch_to_mont,
       launch_g1_add,
       launch_g1_mul,

@@ -18,7 +18,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "kernels.hpp")]
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "kernels.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), os.path.join(_HERE, "emu.cpp"),
@@ -96,6 +96,22 @@ class Emu:
         assert self.lib.emu_pairing(self.nl, self.params, self.consts, A, B, out) == 0
         if ia or ib:
             return (1).to_bytes(self.L, "big") + bytes(self.L)
+        return self.encode(out)
+
+    def fixed_table(self, P_wire: bytes):
+        d = naf(self.n)
+        steps = (len(d) - 1) + sum(1 for i in range(1, len(d) - 1) if d[i])
+        Pm, _ = self.decode(P_wire)
+        tab = (C.c_uint32 * (3 * self.nl * steps))()
+        assert self.lib.emu_fixed_build(self.nl, self.params, self.consts, Pm, tab) == 0
+        return tab
+
+    def pairing_fixed(self, tab, c_wire: bytes) -> bytes:
+        Cm, inf = self.decode(c_wire)
+        if inf:
+            return (1).to_bytes(self.L, "big") + bytes(self.L)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_pairing_fixed(self.nl, self.params, self.consts, tab, Cm, out) == 0
         return self.encode(out)
 
     def g1_mul(self, base: bytes, k: int, klen: int = None) -> bytes:

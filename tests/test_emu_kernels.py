@@ -133,3 +133,12 @@ def test_emu_fixed_base_encrypt():
         assert E.g1_fixed(tP, tQ, W, x, W, r, W) == o.encrypt([x], [r]), (x, r)
     assert E.g1_fixed(tP, tQ, W, 77, 2, None, 0) == o.encrypt([77], None)
     assert E.g1_fixed(tP, tQ, W, 0, 1, None, 0) == zero
+
+
+def test_emu_fixed_argument_pairing(ctx):
+    """e(P, C) over the precomputed line table == makeL2 golden vectors (= e(C, P): the pairing is symmetric)."""
+    fx, E = ctx
+    tab = E.fixed_table(bytes.fromhex(fx["P"]))
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    for v in fx["make_l2"]:
+        assert E.pairing_fixed(tab, cts[v["a"]]).hex() == v["out"]

@@ -41,6 +41,7 @@
 
 #include "consts.hpp"
 #include "agpr.hpp"
+#include "gmem.hpp"
 
 namespace bgn {
 
@@ -105,26 +106,31 @@ __device__ __forceinline__ void l_load(Fp<NL>& r, const LFp<NL>* s) {
 
 // Limb-major structure-of-arrays storage in HBM: limb j of element e lives at
 // base[j * stride + e]; consecutive lanes touch consecutive dwords.
-// The limb row base + j*stride is wave-uniform (scalar address) and the element index is a 32-bit lane
-// offset, so the accesses use the SGPR-base addressing mode instead of 38 per-lane 64-bit addresses.
+// Limb-major SoA element <-> VGPRs (see gmem.hpp).  `base` and `stride` must be wave-uniform; the element
+// index is per lane and below 2^29.
 template <int NL>
 __device__ __forceinline__ void g_load(Fp<NL>& r, const u32* __restrict__ base, size_t stride, size_t e) {
-  const unsigned e32 = (unsigned)e;
+  const u32 off = (u32)e * 4u;
+  // recompute the row descriptors here (a few scalar adds) instead of letting them be hoisted out of the
+  // enclosing loops, where 38 descriptors per operand would be spilled to VGPR lanes
+  const unsigned long long st = gmem_pin_uniform(stride);
 #pragma unroll
-  for (int j = 0; j < NL; ++j) {
-    const u32* __restrict__ row = base + (size_t)j * stride;
-    r.v[j] = row[e32];
-  }
+  for (int j = 0; j < NL; ++j) r.v[j] = gmem_load_u32(base + (size_t)j * st, off);
 }
 
 template <int NL>
 __device__ __forceinline__ void g_store(u32* __restrict__ base, size_t stride, size_t e, const Fp<NL>& a) {
-  const unsigned e32 = (unsigned)e;
+  const u32 off = (u32)e * 4u;
+  const unsigned long long st = gmem_pin_uniform(stride);
 #pragma unroll
-  for (int j = 0; j < NL; ++j) {
-    u32* __restrict__ row = base + (size_t)j * stride;
-    row[e32] = a.v[j];
-  }
+  for (int j = 0; j < NL; ++j) gmem_store_u32(base + (size_t)j * st, off, a.v[j]);
+}
+
+// NL consecutive dwords at a per-lane pointer (table gathers).
+template <int NL>
+__device__ __forceinline__ void v_load(Fp<NL>& r, const u32* __restrict__ lane_ptr) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) r.v[j] = lane_ptr[j];
 }
 
 template <int NL>

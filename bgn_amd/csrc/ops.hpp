@@ -546,9 +546,9 @@ __device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, size_t e, bo
       if (__ballot(d != 0)) {
         const u32* ent = tab + ((size_t)w * 256 + d) * (size_t)(2 * NL);
         Fp<NL> t;
-        g_load(t, ent, 1, 0);
+        v_load(t, ent);                      // per-lane table entry: plain gather
         l_store(L + 2, t);
-        g_load(t, ent + NL, 1, 0);
+        v_load(t, ent + NL);
         l_store(L + 3, t);
         jac_add_affine<NL>(S, acc_inf, d != 0, L, P);
       }

@@ -21,7 +21,8 @@ def build() -> str:
                                                 ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "kernels.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
-                               "-include", os.path.join(_HERE, "agpr.hpp"), os.path.join(_HERE, "emu.cpp"),
+                               "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"),
+                               os.path.join(_HERE, "emu.cpp"),
                                "-o", _SO])
     return _SO
 

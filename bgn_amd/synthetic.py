@@ -39,15 +39,17 @@ def miller_schedule(n: int):
     return dbl, add
 
 
-def algorithmic_mads_per_pairing(fx) -> int:
+def algorithmic_mads_per_pairing(fx, run: int = 16) -> int:
     """32x32->64 multiply-adds one pairing needs in this formulation:
-    (#field products) * 2*NL^2 (schoolbook product + Montgomery reduction rows)."""
+    (#field products) * 2*NL^2 (schoolbook product + Montgomery reduction rows).
+    The F_p inversion of the final exponentiation is shared by `run` pairings per lane."""
     p, n, l = int(fx["p"], 16), int(fx["n"], 16), int(fx["l"])
     nl = 38 if p.bit_length() > 600 else (19 if p.bit_length() > 300 else (10 if p.bit_length() > 100 else 3))
     dbl, add = miller_schedule(n)
     e = p - 2
-    inv = (e.bit_length()) + bin(e).count("1")          # square-and-multiply 1/N
+    inv = (e.bit_length()) + bin(e).count("1")          # square-and-multiply 1/N, once per run
     lb = l.bit_length()
     lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l
-    products = dbl * 18 + add * 17 + 5 + inv + lpow
-    return products * 2 * nl * nl
+    per_pairing = dbl * 18 + add * 17 + 2 * 2 + 3 + 5 + lpow + 2   # Miller + norms (both passes) + peel + conj(f)^2/N + ^l + from_mont
+    products = per_pairing + inv / run
+    return int(products * 2 * nl * nl)

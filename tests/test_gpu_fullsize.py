@@ -1,0 +1,131 @@
+"""GPU: BASELINE.json's full sizes, checked through size-independent properties
+(the oracles cannot reach 2^20 elements in seconds): homomorphic round trips whose
+expected plaintexts are computed with plain integer arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import engine_key, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _scalars(vals: torch.Tensor, nbytes: int) -> torch.Tensor:
+    """int64 tensor -> big-endian fixed-length byte rows (uint8, on the same device)."""
+    out = torch.empty((vals.numel(), nbytes), dtype=torch.uint8, device=vals.device)
+    v = vals.clone()
+    for j in range(nbytes - 1, -1, -1):
+        out[:, j] = (v & 0xFF).to(torch.uint8)
+        v >>= 8
+    return out.contiguous()
+
+
+def _rand_r(count, gen, dev):
+    r = torch.randint(0, 256, (count, 128), dtype=torch.uint8, generator=gen)
+    r[:, 0] &= 0x3F
+    return r.to(dev)
+
+
+def test_config2_config3_encrypt_mult_decrypt_2pow20():
+    """configs[1]+[2]+[3] at batch 2^20, 1024-bit: Dec(Mult(Enc(a), Enc(b))) == a*b for 2^20 independent pairs
+    (20-bit a, b so that a*b < T = 2^40), plus Dec(Enc(a)) == a on level 1."""
+    fx = load_fixture("k1024")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng, dev = pk.engine, torch.device("cuda")
+    n = 1 << 20
+    g = torch.Generator().manual_seed(20)
+    a = torch.randint(0, 1 << 20, (n,), generator=g, dtype=torch.int64)
+    b = torch.randint(0, 1 << 20, (n,), generator=g, dtype=torch.int64)
+    EB = eng.elem_bytes
+    ca = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+    cb = torch.empty_like(ca)
+    eng.encrypt_dev(_scalars(a.to(dev), 3), 3, _rand_r(n, g, dev), 128, ca, n)
+    eng.encrypt_dev(_scalars(b.to(dev), 3), 3, _rand_r(n, g, dev), 128, cb, n)
+    prod = torch.empty_like(ca)
+    eng.mult_dev(ca, cb, prod, n)
+    m = torch.empty(n, dtype=torch.int64, device=dev)
+    st = torch.empty(n, dtype=torch.uint8, device=dev)
+    eng.decrypt_dev(2, prod, m, st, n)
+    torch.cuda.synchronize()
+    assert not bool(st.any().item())
+    assert bool((m.cpu() == a * b).all().item())
+    # level-1 round trip on a 2^16 slice (configs[3] batch)
+    k = 1 << 16
+    eng.decrypt_dev(1, ca[: k * EB], m[:k], st[:k], k)
+    torch.cuda.synchronize()
+    assert not bool(st[:k].any().item()) and bool((m[:k].cpu() == a[:k]).all().item())
+
+
+def test_add_is_homomorphic_at_2pow20():
+    """EAdd over 2^20 pairs: Dec(Add(Enc(a), Enc(b))) == a + b, incl. Sub giving negatives on a slice."""
+    fx = load_fixture("k1024")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng, dev = pk.engine, torch.device("cuda")
+    n = 1 << 20
+    g = torch.Generator().manual_seed(21)
+    a = torch.randint(0, 1 << 30, (n,), generator=g, dtype=torch.int64)
+    b = torch.randint(0, 1 << 30, (n,), generator=g, dtype=torch.int64)
+    EB = eng.elem_bytes
+    ca = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+    cb = torch.empty_like(ca)
+    eng.encrypt_dev(_scalars(a.to(dev), 4), 4, _rand_r(n, g, dev), 128, ca, n)
+    eng.encrypt_dev(_scalars(b.to(dev), 4), 4, _rand_r(n, g, dev), 128, cb, n)
+    s = torch.empty_like(ca)
+    eng.add_dev(1, ca, cb, s, n)
+    k = 1 << 17
+    m = torch.empty(k, dtype=torch.int64, device=dev)
+    st = torch.empty(k, dtype=torch.uint8, device=dev)
+    eng.decrypt_dev(1, s[: k * EB], m, st, k)
+    torch.cuda.synchronize()
+    assert not bool(st.any().item()) and bool((m.cpu() == (a + b)[:k]).all().item())
+    from bgn_amd._lib import check
+    d = torch.empty(k * EB, dtype=torch.uint8, device=dev)
+    check(eng._lib.bgn_sub_batch_dev(eng._h, k, 1, ca.data_ptr(), cb.data_ptr(), None, 0, d.data_ptr(), eng._stream()),
+          "bgn_sub_batch_dev")
+    eng.decrypt_dev(1, d, m, st, k)
+    torch.cuda.synchronize()
+    assert not bool(st.any().item()) and bool((m.cpu() == (a - b)[:k]).all().item())
+
+
+def test_config5_multpoly_shape_decrypts_to_convolution():
+    """configs[4] shape on one GPU: 2^12 polynomial pairs of 16x16 base-3 digits in {-1,0,1} (2^20 pairings);
+    DecryptPoly of every product equals the integer convolution (poly_test.go:172-189)."""
+    fx = load_fixture("k1024")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng, dev = pk.engine, torch.device("cuda")
+    npoly, d = 1 << 12, 16
+    g = torch.Generator().manual_seed(22)
+    ca = torch.randint(-1, 2, (npoly, d), generator=g, dtype=torch.int64)
+    cb = torch.randint(-1, 2, (npoly, d), generator=g, dtype=torch.int64)
+    EB = eng.elem_bytes
+    n = npoly * d
+
+    def enc(c):
+        # EncryptPoly (poly.go:11-29): a negative digit is Sub(zero, Enc(|c|)) == Neg(Enc(|c|))
+        mag = c.abs().reshape(-1)
+        ct = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+        eng.encrypt_dev(_scalars(mag.to(dev), 1), 1, _rand_r(n, g, dev), 128, ct, n)
+        neg = torch.empty_like(ct)
+        from bgn_amd._lib import check
+        check(eng._lib.bgn_neg_batch_dev(eng._h, n, 1, ct.data_ptr(), neg.data_ptr(), eng._stream()), "neg")
+        sel = (c.reshape(-1) < 0).to(dev)
+        out = ct.view(n, EB).clone()
+        out[sel] = neg.view(n, EB)[sel]
+        return out.reshape(-1).contiguous()
+
+    ea, eb = enc(ca), enc(cb)
+    out = torch.empty(npoly * 2 * d * EB, dtype=torch.uint8, device=dev)
+    eng.poly_mult_dev(npoly, d, d, ea, eb, out)
+    m = torch.empty(npoly * 2 * d, dtype=torch.int64, device=dev)
+    st = torch.empty(npoly * 2 * d, dtype=torch.uint8, device=dev)
+    eng.decrypt_dev(2, out, m, st, npoly * 2 * d)
+    torch.cuda.synchronize()
+    assert not bool(st.any().item())
+    conv = torch.zeros((npoly, 2 * d), dtype=torch.int64)
+    for i in range(d):
+        for k in range(d):
+            conv[:, i + k] += ca[:, i] * cb[:, k]
+    assert bool((m.cpu().view(npoly, 2 * d) == conv).all().item())

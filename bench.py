@@ -140,8 +140,8 @@ def secondary_metrics(pk, fx, dev, dec_log2):
     ok = bool((m.cpu() == want).all().item()) and not bool(st.any().item())
     out["decrypt"] = {"value": n_dec / dt, "unit": "decrypts/s", "batch": n_dec, "level": 1,
                       "workload": "configs[3]: T=2^40 BSGS Decrypt, batch=2^%d, m uniform in [0,2^40), 1/16 negative; "
-                                  "lift e(C,P) + C^sk + giant steps on an HBM-resident baby table (2^%s entries)"
-                                  % (dec_log2, os.environ.get("BGN_BSGS_MAX_LOG2", "28")),
+                                  "lift e(C,P) + C^sk + giant steps on an HBM-resident baby table (%d entries)"
+                                  % (dec_log2, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))),
                       "search_kernel_ms": k_ms, "kernel": eng.last_kernel_name(), "table_setup_s": t_setup,
                       "plaintexts_recovered_exactly": ok, "algorithmic_bytes_per_unit": EB + 16}
     return out

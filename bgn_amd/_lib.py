@@ -50,6 +50,7 @@ PROTOTYPES = {
     "bgn_poly_mult_batch_dev": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p, C.c_void_p]),
     "bgn_last_kernel_ms": (C.c_double, [_ctx]),
     "bgn_last_kernel_name": (C.c_char_p, [_ctx]),
+    "bgn_ctx_bsgs_baby_steps": (C.c_uint64, [_ctx]),
 }
 
 _lib = None

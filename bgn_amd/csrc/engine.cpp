@@ -341,8 +341,16 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if ((double)B < sq) B++;
   const uint64_t Mmax = B * B + B + 2;
   uint64_t S = 2;
-  // baby-step cap: 2^28 entries = 8.6 GB of HBM by default; BGN_BSGS_MAX_LOG2 overrides (16..30)
-  int cap_log2 = 28;
+  // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Take up to a
+  // quarter of the free HBM, at most 2^30 steps (34 GB; the slot's value field holds 31 bits);
+  // BGN_BSGS_MAX_LOG2 overrides (4..30).  Measured at T = 2^40, batch 2^16: 2^28 -> 2.9e5, 2^29 -> 4.1e5,
+  // 2^30 -> 5.1e5 decrypts/s; the build takes 0.3 - 0.65 s.
+  int cap_log2 = 30;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > free_b / 4) cap_log2--;
+  }
   if (const char* ev = getenv("BGN_BSGS_MAX_LOG2")) {
     const int v = atoi(ev);
     if (v >= 4 && v <= 30) cap_log2 = v;
@@ -1115,5 +1123,7 @@ double bgn_last_kernel_ms(bgn_ctx* c) {
 }
 
 const char* bgn_last_kernel_name(bgn_ctx* c) { return c ? c->last_kernel : ""; }
+
+uint64_t bgn_ctx_bsgs_baby_steps(const bgn_ctx* c) { return (c && c->have_tables) ? c->bsgs.S : 0; }
 
 }  // extern "C"

@@ -153,6 +153,8 @@ int bgn_poly_mult_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d1, size_t d2, co
 double bgn_last_kernel_ms(bgn_ctx* ctx);
 /* Name of that kernel (for matching against rocprofv3 --kernel-trace output). */
 const char* bgn_last_kernel_name(bgn_ctx* ctx);
+/* Number of baby steps of the discrete-log table built by bgn_ctx_setup_decryption (0 = none). */
+uint64_t bgn_ctx_bsgs_baby_steps(const bgn_ctx* ctx);
 
 #ifdef __cplusplus
 }

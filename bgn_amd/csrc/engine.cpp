@@ -277,7 +277,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     // e(Q,Q) (blinding base of level-2 ops, bgn.go:306,469) and the GT identity
     {
       SoA2 o{c->d_keypts + 4 * c->nl, c->d_keypts + 5 * c->nl, nullptr, 1};
-      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0, nullptr);
+      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0, nullptr, 0);
       kt->to_mont(nullptr, c->d_params, o.c0, o.c1, 1, 1);
       HIP_BRK(hipMemcpy(c->d_keypts + 6 * c->nl, img.data() + c->nl, (size_t)c->nl * 4, hipMemcpyHostToDevice));  // one
     }
@@ -373,7 +373,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   const int nl = c->nl;
   SoA2 g{c->d_gt, c->d_gt + nl, nullptr, 1}, gi{c->d_gt + 2 * nl, c->d_gt + 3 * nl, nullptr, 1};
   // g = e(P,P)^sk  (bgn.go:198-199)
-  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0, nullptr);
+  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0, nullptr, 0);
   kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
   gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
   kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
@@ -422,6 +422,12 @@ static int pairing_run(size_t count) {
   return (int)r;
 }
 
+// 0: inlined step programs; 1: compact-code interpreter (BGN_PAIRING_VM=1 selects it)
+static int pairing_variant() {
+  const char* ev = getenv("BGN_PAIRING_VM");
+  return (ev && ev[0] == '1') ? 1 : 0;
+}
+
 static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                           size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be = nullptr,
                           size_t r_len = 0) {
@@ -455,7 +461,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
   kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
-              (mode == 1) ? c->d_fixedpair : nullptr);
+              (mode == 1) ? c->d_fixedpair : nullptr, pairing_variant());
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;
@@ -1013,7 +1019,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   if (level == 1) {
     // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp)
     kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pairing_run(count), pws, st,
-                c->d_fixedpair);
+                c->d_fixedpair, 0);
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
@@ -1082,7 +1088,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   kt->decode(s, c->d_params, a, c->L, na, A);
   kt->decode(s, c->d_params, b, c->L, nb, Bv);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2, pairing_run(np), pws, sp, nullptr);                 // pk.Mult(coeff1, coeff2), poly.go:146
+  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2, pairing_run(np), pws, sp, nullptr, pairing_variant());                 // pk.Mult(coeff1, coeff2), poly.go:146
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;

@@ -330,14 +330,16 @@ __device__ __forceinline__ void fp_sqr_segment(u64 (&t)[NL], u64& aa, const LFp<
 // segmented square takes 6.6 us against 8.0 us for fp_mul, but inside k_pairing it made the kernel 3 %
 // SLOWER: the step bodies are straight-line code far larger than the 64 KB instruction cache, and the four
 // short loops (4-5 trips each) pay their cold first trip every time, where the product's single loop
-// amortises it over 19 trips.  Kept for the compact-code kernel planned next; disabled until then.
+// amortises it over 19 trips.  The compact-code interpreter (vm.hpp) uses it (fp_sqr_seg); the inlined
+// programs do not.
 constexpr bool kSegmentedSquare = false;
 
-// r = a^2/R mod p, lazy (< 2p); `a` both as LDS rows (streamed multiplier) and in VGPRs.  r may alias av.
+// r = a^2/R mod p by the segmented square, lazy (< 2p); `a` both as LDS rows (streamed multiplier) and in
+// VGPRs.  r may alias av.
 template <int NL>
-__device__ __forceinline__ void fp_sqr(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& av,
-                                       const FpParams<NL>* __restrict__ P) {
-  if constexpr (NL < 8 || !kSegmentedSquare) {
+__device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& av,
+                                           const FpParams<NL>* __restrict__ P) {
+  if constexpr (NL < 8) {
     fp_mul<NL>(r, a, av, P);
   } else {
     constexpr int Q = ((NL / 4 + 1) / 2) * 2;   // even segment length: 10 at NL = 38, 4 at NL = 19
@@ -358,6 +360,16 @@ __device__ __forceinline__ void fp_sqr(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>
       c = s >> LIMB_BITS;
     }
   }
+}
+
+// The squaring used by the hand-scheduled (inlined) step programs.
+template <int NL>
+__device__ __forceinline__ void fp_sqr(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& av,
+                                       const FpParams<NL>* __restrict__ P) {
+  if constexpr (kSegmentedSquare)
+    fp_sqr_seg<NL>(r, a, av, P);
+  else
+    fp_mul<NL>(r, a, av, P);
 }
 
 // r = a^2 with a in VGPRs: stages a through the scratch LDS slot.

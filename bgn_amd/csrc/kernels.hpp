@@ -116,7 +116,7 @@ struct KernelTable {
   //   precomputed line table (fixedpair.hpp); b is ignored.
   void (*pairing)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                   size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
-                  const uint32_t* fixed_tab);
+                  const uint32_t* fixed_tab, int variant /* 0: inlined step programs, 1: interpreter (vm.hpp) */);
   // builds the line table of e(P, .) : 3*NL u32 per Miller step (px, py canonical Montgomery, stride 1)
   void (*fixedpair_build)(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
                           const uint32_t* py, uint32_t* tab);

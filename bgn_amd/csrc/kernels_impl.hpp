@@ -6,6 +6,7 @@
 #include "codec.hpp"
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
+#include "vm.hpp"
 
 namespace bgn {
 
@@ -72,7 +73,9 @@ __device__ __forceinline__ void pair_index(PairOperands& op, size_t e, int mode,
 // Each lane owns `run` pairings e = j*T + t (T = lanes in the grid): pass 1 runs the Miller loops and
 // parks f and the prefix product of the norms in the workspace; one Fermat inversion per lane; pass 2
 // peels 1/N(f_j) off and finishes the exponentiation.  ws: 3 F_p per element (F0, F1, prefix).
-template <int NL, bool FIXED>
+// VARIANT 0: inlined step programs (pairing.hpp); 1: key-constant first argument (fixedpair.hpp);
+// 2: compact-code interpreter (vm.hpp)
+template <int NL, int VARIANT>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
           size_t count, int mode, size_t d1, size_t d2, int run, u32* __restrict__ ws, size_t sw,
@@ -100,8 +103,10 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     if (!__ballot(live)) break;
     if (!live) e = count - 1;             // keep the wave's control flow uniform; results are discarded
     pair_index(op, e, mode, d1, d2);
-    if (FIXED)
+    if (VARIANT == 1)
       miller_loop_fixed<NL>(S, L, op, fixed_tab, C, P);
+    else if (VARIANT == 2)
+      miller_loop_vm<NL>(S, L, op, C, P);
     else
       miller_loop<NL>(S, L, op, C, P);
     if (run == 1) {
@@ -327,15 +332,18 @@ static void launch_encode(hipStream_t s, const uint8_t* inf, const uint32_t* c0,
 
 static void launch_pairing(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                            size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
-                           const uint32_t* fixed_tab) {
+                           const uint32_t* fixed_tab, int variant) {
   if (!count) return;
   if (run < 1 || !ws) run = 1;
   const size_t lanes = (count + run - 1) / run;
   if (fixed_tab && mode == 1)
-    hipLaunchKernelGGL((k_pairing<NL_, true>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
+    hipLaunchKernelGGL((k_pairing<NL_, 1>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab);
+  else if (variant == 1)
+    hipLaunchKernelGGL((k_pairing<NL_, 2>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
+                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr);
   else
-    hipLaunchKernelGGL((k_pairing<NL_, false>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
+    hipLaunchKernelGGL((k_pairing<NL_, 0>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr);
 }
 
@@ -424,7 +432,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {
       NL_,
       sizeof(FpParams<NL_>),
-      "k_pairing<" BGN_STR(BGN_NL) ", false>",
+      "k_pairing<" BGN_STR(BGN_NL) ", 0>",
       launch_decode,
       launch_encode,
       launch_pairing,

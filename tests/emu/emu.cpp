@@ -13,6 +13,7 @@ thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 
 #include "codec.hpp"
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
+#include "vm.hpp"
 
 using namespace bgn;
 
@@ -63,6 +64,22 @@ struct Emu {
     PairOperands op{c, c + NL, 1, 0, nullptr, nullptr, 1, 0};
     Miller<NL> S;
     miller_loop_fixed<NL>(S, L, op, tab, C, P);
+    Fp<NL> N, ninv, g0, g1, re, im;
+    miller_norm<NL>(N, S, L, P);
+    l_store(L + 1, N);
+    fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);
+    final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
+    fp_from_mont<NL>(im, g1, P, L);
+    fp_from_mont<NL>(re, g0, P, L);
+    memcpy(out, re.v, 4 * NL);
+    memcpy(out + NL, im.v, 4 * NL);
+  }
+  static void pairing_vm(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    LFp<NL>* L = lds();
+    PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};
+    Miller<NL> S;
+    miller_loop_vm<NL>(S, L, op, C, P);
     Fp<NL> N, ninv, g0, g1, re, im;
     miller_norm<NL>(N, S, L, P);
     l_store(L + 1, N);
@@ -234,5 +251,6 @@ int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* o
 int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int windows, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, windows, x, xlen, r, rlen, out, oinf)) }
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, c, out)) }
+int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }
 size_t emu_consts_size() { return sizeof(PairingConsts); }
 }

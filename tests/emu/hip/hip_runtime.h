@@ -9,6 +9,7 @@
 #define __global__
 #define __forceinline__ inline
 #define __shared__ static
+#define __constant__
 #define __launch_bounds__(...)
 #define __restrict__
 struct EmuDim3 { unsigned x, y, z; };

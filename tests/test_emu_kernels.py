@@ -142,3 +142,11 @@ def test_emu_fixed_argument_pairing(ctx):
     cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
     for v in fx["make_l2"]:
         assert E.pairing_fixed(tab, cts[v["a"]]).hex() == v["out"]
+
+
+def test_emu_interpreter_miller_loop(ctx):
+    """The compact-code interpreter (vm.hpp) runs the same step programs as data: same pairing values."""
+    fx, E = ctx
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    for v in fx["mult"][:4]:
+        assert E.pairing_vm(cts[v["a"]], cts[v["b"]]).hex() == v["out"]

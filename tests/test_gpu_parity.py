@@ -323,3 +323,17 @@ def test_mult_runs_with_shared_inversion():
         for k in range(len(pool)):
             exp[i, k] = np.frombuffer(R.elem_to_bytes(opk.e(pool[i], pool[k]), opk.p), dtype=np.uint8)
     assert (out == exp[ia, ib]).all()
+
+
+def test_interpreter_variant_matches(monkeypatch):
+    """BGN_PAIRING_VM=1 routes Mult through the compact-code interpreter (vm.hpp): same bytes."""
+    fx = load_fixture("k512")
+    pk, _ = engine_key(fx)
+    cts = [e["ct"] for e in fx["encrypt"]]
+    a = H([cts[v["a"]] for v in fx["mult"]])
+    b = H([cts[v["b"]] for v in fx["mult"]])
+    monkeypatch.setenv("BGN_PAIRING_VM", "1")
+    out = pk.engine.mult(a, b)
+    assert pk.engine.last_kernel_name().startswith("k_pairing")
+    for row, v in zip(out, fx["mult"]):
+        assert bytes(row).hex() == v["out"]

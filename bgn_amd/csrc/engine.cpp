@@ -830,9 +830,11 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
     if (rc) return rc;
   }
   if ((int)x_len <= c->fixed_windows && (!r_be || (int)r_len <= c->fixed_windows)) {
+    uint32_t* fws = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
       Ws w(c, pass ? c->arena : nullptr);
       G = w.g1(st);
+      fws = (uint32_t*)w.cv.take((size_t)4 * c->nl * st * 4);
       if (!pass) {
         int rc = ensure_arena(c, w.cv.off);
         if (rc) return rc;
@@ -844,7 +846,7 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
     a.ox = G.c0; a.oy = G.c1; a.oinf = G.inf; a.so = G.stride;
     a.count = count;
     HIP_TRY(hipEventRecord(c->ev0, s));
-    kt->g1_fixed(s, c->d_params, c->d_consts, a);                              // bgn.go:344-350 fused
+    kt->g1_fixed(s, c->d_params, c->d_consts, a, pairing_run(count), fws, st);  // bgn.go:344-350 fused
     HIP_TRY(hipEventRecord(c->ev1, s));
     c->ev_valid = true;
     c->last_kernel = "k_g1_fixed";

@@ -124,7 +124,9 @@ struct KernelTable {
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);
   void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
-  void (*g1_fixed)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a);
+  // run > 1: each lane owns `run` elements and shares one inversion; ws = 4*NL*sw u32 of workspace (sw >= count)
+  void (*g1_fixed)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a, int run,
+                   uint32_t* ws, size_t sw);
   // SoA (stride) -> table entries [e][x limbs | y limbs]
   void (*soa_to_entries)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
                          uint32_t* entries);

@@ -223,12 +223,10 @@ k_g1_mul(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
-k_g1_fixed(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1FixedArgs A) {
+k_g1_fixed(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1FixedArgs A, int run,
+           u32* __restrict__ ws, size_t sw) {
   __shared__ LFp<NL> L[4];
-  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
-  const bool live = e < A.count;
-  if (!live) e = A.count - 1;
-  g1_fixed_lane<NL>(A, e, live, L, C, P);
+  g1_fixed_lane<NL>(A, run, ws, sw, L, C, P);
 }
 
 template <int NL>
@@ -379,10 +377,13 @@ static void launch_g1_mul(hipStream_t s, const void* params, const PairingConsts
                      a);
 }
 
-static void launch_g1_fixed(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a) {
+static void launch_g1_fixed(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a, int run,
+                            uint32_t* ws, size_t sw) {
   if (!a.count) return;
-  hipLaunchKernelGGL(k_g1_fixed<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
-                     consts, a);
+  if (run < 1 || !ws) run = 1;
+  const size_t lanes = (a.count + run - 1) / run;
+  hipLaunchKernelGGL(k_g1_fixed<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     consts, a, run, ws, sw);
 }
 
 static void launch_soa_to_entries(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,

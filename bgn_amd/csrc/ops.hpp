@@ -515,13 +515,12 @@ __device__ __forceinline__ void g1_scalarmul_lane(const G1MulArgs& A, size_t e, 
   jac_store_affine<NL>(S, acc_inf || binf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
 }
 
-// out = sum over windows of tabP[w][x_w] + tabQ[w][r_w]: EncryptWithRandomness (bgn.go:340-353) with both
-// PowBig calls and the final Mul fused; P and Q are fixed per key, so no doublings are needed at all.
+// acc = sum over windows of tabP[w][x_w] + tabQ[w][r_w] (Jacobian): EncryptWithRandomness
+// (bgn.go:340-353) with both PowBig calls and the final Mul fused; P and Q are fixed per key, so no
+// doublings are needed at all.
 template <int NL>
-__device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, size_t e, bool live, LFp<NL>* L,
-                                              const PairingConsts* __restrict__ C,
-                                              const FpParams<NL>* __restrict__ P) {
-  JacAcc<NL> S;
+__device__ __forceinline__ void g1_fixed_accumulate(JacAcc<NL>& S, bool& acc_inf, const G1FixedArgs& A, size_t e,
+                                                    LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
   {
     Fp<NL> t;
     fp_set(t, P->one);
@@ -532,7 +531,7 @@ __device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, size_t e, bo
     fp_zero(t);
     a_store(S.Z, t);
   }
-  bool acc_inf = true;
+  acc_inf = true;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     const uint8_t* k = pass ? A.r : A.x;
@@ -554,7 +553,91 @@ __device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, size_t e, bo
       }
     }
   }
-  jac_store_affine<NL>(S, acc_inf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
+}
+
+// Each lane owns `run` encryptions e = j*T + t and shares one F_p inversion among them (Montgomery's
+// trick on the Jacobian Z coordinates).  ws: 4 F_p per element (X, Y, Z, prefix), stride sw.
+template <int NL>
+__device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, int run, u32* __restrict__ ws, size_t sw,
+                                              LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                              const FpParams<NL>* __restrict__ P) {
+  const size_t T = (size_t)gridDim.x * FP_BLOCK;
+  const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  JacAcc<NL> S;
+  if (run <= 1 || !ws) {
+    size_t e = t;
+    const bool live = e < A.count;
+    if (!live) e = A.count - 1;
+    bool acc_inf;
+    g1_fixed_accumulate<NL>(S, acc_inf, A, e, L, P);
+    jac_store_affine<NL>(S, acc_inf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
+    return;
+  }
+  u32* wX = ws;
+  u32* wY = ws + (size_t)NL * sw;
+  u32* wZ = ws + (size_t)2 * NL * sw;
+  u32* wP = ws + (size_t)3 * NL * sw;
+  Fp<NL> acc;
+  fp_set(acc, P->one);
+#pragma unroll 1
+  for (int j = 0; j < run; ++j) {
+    size_t e = (size_t)j * T + t;
+    const bool live = e < A.count;
+    if (!__ballot(live)) break;
+    if (!live) e = A.count - 1;
+    bool acc_inf;
+    g1_fixed_accumulate<NL>(S, acc_inf, A, e, L, P);
+    Fp<NL> z, r;
+    a_load(z, S.Z);
+    fp_set(r, P->one);
+    fp_select(z, acc_inf, r, z);            // O: keep the product invertible
+    fp_reduce8(z, z, P);                    // <1
+    if (live) {
+      a_load(r, S.X);
+      g_store<NL>(wX, sw, e, r);
+      a_load(r, S.Y);
+      g_store<NL>(wY, sw, e, r);
+      g_store<NL>(wZ, sw, e, z);
+      g_store<NL>(wP, sw, e, acc);
+      A.oinf[e] = acc_inf ? 1 : 0;
+    }
+    l_store(L, acc);
+    fp_mul(r, L, z, P);                     // <2
+    fp_select(acc, live, r, acc);
+  }
+  Fp<NL> inv;
+  fp_inv<NL>(inv, acc, L, C, P);            // 1 / prod Z_j  <2
+#pragma unroll 1
+  for (int j = run - 1; j >= 0; --j) {
+    size_t e = (size_t)j * T + t;
+    const bool live = e < A.count;
+    if (!__ballot(live)) continue;
+    if (!live) e = A.count - 1;
+    Fp<NL> z, pf, zi, u, r;
+    g_load<NL>(z, wZ, sw, e);
+    g_load<NL>(pf, wP, sw, e);
+    l_store(L, inv);
+    fp_mul(zi, L, pf, P);                   // 1/Z_j <2
+    fp_mul(r, L, z, P);                     // inverse of the shorter prefix <2
+    fp_select(inv, live, r, inv);
+    l_store(L + 1, zi);
+    fp_sqr(u, L + 1, zi, P);                // zi^2 <2
+    g_load<NL>(r, wX, sw, e);
+    fp_mulv(r, r, u, P, L);                 // x <2   (18*2)
+    fp_mul(u, L + 1, u, P);                 // zi^3 <2
+    {
+      Fp<NL> o;
+      fp_from_mont<NL>(o, r, P, L);
+      if (live) g_store(A.ox, A.so, e, o);
+    }
+    g_load<NL>(r, wY, sw, e);
+    fp_mulv(r, r, u, P, L);                 // y <2
+    {
+      Fp<NL> o;
+      fp_from_mont<NL>(o, r, P, L);
+      if (live) g_store(A.oy, A.so, e, o);
+    }
+  }
 }
 
 }  // namespace bgn

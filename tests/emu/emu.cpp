@@ -147,7 +147,8 @@ struct Emu {
     A.x = x; A.xlen = xlen; A.r = r; A.rlen = rlen;
     A.ox = out; A.oy = out + NL; A.oinf = oinf; A.so = 1;
     A.count = 1;
-    g1_fixed_lane<NL>(A, 0, true, lds(), C, P);
+    blockIdx.x = 0; threadIdx.x = 0;
+    g1_fixed_lane<NL>(A, 1, nullptr, 0, lds(), C, P);
   }
   static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;

@@ -337,3 +337,20 @@ def test_interpreter_variant_matches(monkeypatch):
     assert pk.engine.last_kernel_name().startswith("k_pairing")
     for row, v in zip(out, fx["mult"]):
         assert bytes(row).hex() == v["out"]
+
+
+def test_encrypt_runs_with_shared_inversion():
+    """count > 2*65536: every lane owns a run of encryptions sharing one Jacobian->affine inversion; zero
+    plaintext/randomness (identity results) inside the runs; ragged tail."""
+    import oracle_c
+    fx = load_fixture("toy64")
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    rng = random.Random(17)
+    n = int(fx["n"], 16)
+    count = 2 * 65536 + 77
+    xs = [rng.randrange(1 << 20) for _ in range(count)]
+    rs = [rng.randrange(n) for _ in range(count)]
+    for i in range(0, count, 1000):
+        xs[i], rs[i] = 0, 0                       # identity
+    assert pk.engine.encrypt(xs, rs).tobytes() == o.encrypt(xs, rs)

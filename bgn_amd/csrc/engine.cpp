@@ -655,7 +655,16 @@ void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t k
 // Blind a level-1 result R (plain) with Q^r (bgn.go:488-495): R <- R + Q^r.  T1/T2 scratch G1 arrays.
 void blind_l1(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, uint32_t* prefix,
               size_t count) {
-  g1_mul_launch(c, s, c->key_Q(), r_be, r_len, r_len, T1, count);          // h1 = Q^r
+  if (c->d_tabQ && (int)r_len <= c->fixed_windows) {                        // h1 = Q^r from the window table
+    G1FixedArgs a;
+    a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.windows = c->fixed_windows;
+    a.x = nullptr; a.xlen = 0; a.r = r_be; a.rlen = r_len;
+    a.ox = T1.c0; a.oy = T1.c1; a.oinf = T1.inf; a.so = T1.stride;
+    a.count = count;
+    c->kt->g1_fixed(s, c->d_params, c->d_consts, a, 1, nullptr, 0);
+  } else {
+    g1_mul_launch(c, s, c->key_Q(), r_be, r_len, r_len, T1, count);        // generic ladder for over-long r
+  }
   c->kt->to_mont(s, c->d_params, T1.c0, T1.c1, T1.stride, count);
   c->kt->to_mont(s, c->d_params, R.c0, R.c1, R.stride, count);
   g1_add_launch(c, s, R, T1, T2, prefix, count, false);
@@ -683,6 +692,10 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   if (!count) return BGN_OK;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  if (r_be && level == 1) {            // blinding base tables (uses the arena: before any carving)
+    int rc = ensure_fixed_tables(c);
+    if (rc) return rc;
+  }
   const size_t st = round_up(count, 64);
   SoA2 A, B, O, T1, T2;
   uint32_t* prefix = nullptr;
@@ -772,6 +785,10 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  if (r_be && level == 1) {
+    int rc = ensure_fixed_tables(c);
+    if (rc) return rc;
+  }
   const size_t st = round_up(count, 64);
   SoA2 A, O, T1, T2;
   uint32_t* prefix = nullptr;

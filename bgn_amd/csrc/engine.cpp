@@ -41,6 +41,9 @@ int fail(int code, const char* fmt, ...) {
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// lane offsets inside a limb row are 32-bit byte offsets (gmem.hpp): at most 2^28 elements per call
+constexpr size_t kMaxBatch = (size_t)1 << 28;
+
 }  // namespace
 
 struct bgn_ctx {
@@ -432,6 +435,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
                           size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be = nullptr,
                           size_t r_len = 0) {
   if (!count) return BGN_OK;
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   const KernelTable* kt = c->kt;
@@ -690,6 +694,7 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
   if (r_be && !r_len) return fail(BGN_E_ARG, "r_len == 0");
   if (!count) return BGN_OK;
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   if (r_be && level == 1) {            // blinding base tables (uses the arena: before any carving)
@@ -744,6 +749,7 @@ int bgn_neg_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, uin
   if (!c || (count && (!a || !out))) return fail(BGN_E_ARG, "null argument");
   if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
   if (!count) return BGN_OK;
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -782,6 +788,7 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
   if (!k_len || (r_be && !r_len)) return fail(BGN_E_ARG, "zero scalar length");
   if (!count) return BGN_OK;
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -826,6 +833,7 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
   if (!c || (count && (!x_be || !out))) return fail(BGN_E_ARG, "null argument");
   if (!x_len || (r_be && !r_len)) return fail(BGN_E_ARG, "zero scalar length");
   if (!count) return BGN_OK;
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -1010,7 +1018,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   if (!c->have_secret) return fail(BGN_E_STATE, "secret key not set");
   if (!c->have_tables) return fail(BGN_E_STATE, "DL tables not computed!");          // gsbs.go:56-58 (panic)
   if (!count) return BGN_OK;
-  if (count > 0xffffffffull) return fail(BGN_E_ARG, "batch too large");
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
@@ -1087,6 +1095,8 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   if (!c || (npoly && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
   if (!npoly) return BGN_OK;
   if (!d1 || !d2) return fail(BGN_E_ARG, "polynomial degrees must be positive");
+  if (npoly > kMaxBatch || d1 > 4096 || d2 > 4096 || npoly * d1 * d2 > kMaxBatch)
+    return fail(BGN_E_ARG, "batch too large (max 2^28 coefficient pairs per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));

@@ -29,6 +29,10 @@
  *     (cgo pointer rules).  A context is immutable after setup and may be used
  *     from many threads; concurrent calls on one context serialise on its
  *     internal workspace (the reference serialises on pk.mu, bgn.go:40).
+ *   - `_dev` calls use the context's workspace: issue them for one context on
+ *     one stream (or order them yourself); the workspace grows with hipMalloc
+ *     on first use of a larger batch, so warm a context up before capturing
+ *     its calls into a hipGraph.  At most 2^28 elements per call.
  *   - There is no CPU fallback: without a HIP device every compute call fails
  *     with BGN_E_HIP.
  */

@@ -354,3 +354,29 @@ def test_encrypt_runs_with_shared_inversion():
     for i in range(0, count, 1000):
         xs[i], rs[i] = 0, 0                       # identity
     assert pk.engine.encrypt(xs, rs).tobytes() == o.encrypt(xs, rs)
+
+
+def test_argument_errors_are_reported_not_fatal():
+    import ctypes
+    from bgn_amd import _lib
+    fx = load_fixture("toy64")
+    pk, _ = engine_key(fx)
+    lib, h = pk.engine._lib, pk.engine._h
+    buf = ctypes.create_string_buffer(4 * pk.engine.elem_bytes)
+    assert lib.bgn_add_batch(h, 2, 3, buf, buf, None, 0, buf) == _lib.BGN_E_ARG          # bad level
+    assert b"level" in lib.bgn_last_error()
+    assert lib.bgn_mult_batch(h, 2, None, buf, None, 0, buf) == _lib.BGN_E_ARG           # null operand
+    assert lib.bgn_mult_batch_dev(h, (1 << 28) + 1, buf, buf, None, 0, buf, None) == _lib.BGN_E_ARG
+    assert b"too large" in lib.bgn_last_error()
+    fresh = load_fixture("k256")
+    import bgn_amd
+    pk2 = bgn_amd.PublicKey(int(fresh["p"], 16), int(fresh["n"], 16), fresh["l"], bytes.fromhex(fresh["P"]),
+                            bytes.fromhex(fresh["Q"]), fresh["msg_space"])
+    m = (ctypes.c_int64 * 1)()
+    st = (ctypes.c_uint8 * 1)()
+    rc = pk2.engine._lib.bgn_decrypt_batch(pk2.engine._h, 1, 1, buf, m, st)              # no secret key yet
+    assert rc == _lib.BGN_E_STATE
+    pk2.engine.set_secret(int(fresh["q1"], 16))
+    rc = pk2.engine._lib.bgn_decrypt_batch(pk2.engine._h, 1, 1, buf, m, st)              # gsbs.go:56-58
+    assert rc == _lib.BGN_E_STATE and b"DL tables not computed!" in lib.bgn_last_error()
+    pk2.engine.close()

@@ -171,8 +171,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("BGN_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -198,18 +200,19 @@ def main():
     # Synthetic level-1 ciphertexts, resident in HBM before the timed region.
     a, b = bgn_amd.synthetic.l1_ciphertext_pairs(pk, fx, count, seed=1000 + rank, device=dev)
     out = torch.empty(count * EB, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(total * EB, dtype=torch.uint8, device=dev) if world > 1 else None
+    use_dist = world > 1 or force_dist
+    gathered = torch.empty(total * EB, dtype=torch.uint8, device=dev) if use_dist else None
 
     def step():
         eng.mult_dev(a, b, out, count)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out)
 
     kernel_ms = []
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -217,15 +220,16 @@ def main():
         step()
         kernel_ms.append(eng.last_kernel_ms())          # HIP events on the kernel's own stream
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kernel_name = eng.last_kernel_name()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        assert bool((gathered[rank * count * EB:(rank + 1) * count * EB] == out).all().item()), "gather mismatch"
 
     # prefix of this rank's batch for the CPU leg (not timed)
     nchk = min(count, 4096)
@@ -274,7 +278,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -21,9 +21,14 @@ template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, SoA2 out) {
   __shared__ LFp<NL> stage;
-  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
-  if (e >= count) return;
-  const uint8_t* src = wire + e * (size_t)(2 * L);
+  __shared__ WireStage<NL> ws;
+  const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
+  const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+  const size_t EB = (size_t)(2 * L);
+  const u32 mis = wire_stage_in<NL>(&ws, wire + e0 * EB, nel * EB);
+  if (threadIdx.x >= nel) return;
+  const size_t e = e0 + threadIdx.x;
+  const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
   Fp<NL> x, y;
   wire_to_limbs<NL>(x, src, L);
   wire_to_limbs<NL>(y, src + L, L);
@@ -39,18 +44,25 @@ template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32* __restrict__ c1, size_t stride, int L,
          size_t count, uint8_t* __restrict__ wire) {
-  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
-  if (e >= count) return;
-  uint8_t* dst = wire + e * (size_t)(2 * L);
-  Fp<NL> x, y;
-  g_load<NL>(x, c0, stride, e);
-  g_load<NL>(y, c1, stride, e);
-  if (inf && inf[e]) {
-    fp_zero(x);
-    fp_zero(y);
+  __shared__ WireStage<NL> ws;
+  const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
+  const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+  const size_t EB = (size_t)(2 * L);
+  uint8_t* g = wire + e0 * EB;
+  if (threadIdx.x < nel) {
+    const size_t e = e0 + threadIdx.x;
+    uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
+    Fp<NL> x, y;
+    g_load<NL>(x, c0, stride, e);
+    g_load<NL>(y, c1, stride, e);
+    if (inf && inf[e]) {
+      fp_zero(x);
+      fp_zero(y);
+    }
+    limbs_to_wire<NL>(dst, L, x);
+    limbs_to_wire<NL>(dst + L, L, y);
   }
-  limbs_to_wire<NL>(dst, L, x);
-  limbs_to_wire<NL>(dst + L, L, y);
+  wire_stage_out<NL>(&ws, g, nel * EB);
 }
 
 // ---- pairing ----------------------------------------------------------------
@@ -113,8 +125,7 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
       const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
       Fp<NL> N, ninv, g0, g1, re, im;
       miller_norm<NL>(N, S, L, P);
-      l_store(L + 1, N);
-      fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);
+      fp_inv_mont<NL>(ninv, N, C->pm2_bits + 1, P, L);
       final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
       fp_from_mont<NL>(im, g1, P, L);
       fp_from_mont<NL>(re, g0, P, L);
@@ -149,8 +160,7 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     fp_select(acc, live, r, acc);
   }
   Fp<NL> inv;
-  l_store(L + 1, acc);
-  fp_pow_uniform<NL>(inv, L + 1, C->pm2, C->pm2_bits, P, L);     // 1 / prod N_j  <2
+  fp_inv_mont<NL>(inv, acc, C->pm2_bits + 1, P, L);              // 1 / prod N_j  <1
 #pragma unroll 1
   for (int j = run - 1; j >= 0; --j) {
     size_t e = (size_t)j * T + t;

@@ -13,12 +13,12 @@ __device__ __forceinline__ u32 scalar_bit(const uint8_t* __restrict__ k, size_t 
   return (k[len - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u;
 }
 
-// r = a^(p-2) = 1/a ; a <4 in VGPRs ; result <2.  Uses L[0] (stage) and L[1].
+// r = 1/a ; a <4 in VGPRs ; result <1 (0 for a = 0).  Uses L[0] (stage).  Division steps (fpinv.hpp), not
+// Fermat: ~30 products' worth of work instead of ~1.5 * bits(p).
 template <int NL>
 __device__ __forceinline__ void fp_inv(Fp<NL>& r, const Fp<NL>& a, LFp<NL>* L, const PairingConsts* __restrict__ C,
                                        const FpParams<NL>* __restrict__ P) {
-  l_store(L + 1, a);
-  fp_pow_uniform<NL>(r, L + 1, C->pm2, C->pm2_bits, P, L);
+  fp_inv_mont<NL>(r, a, C->pm2_bits + 1, P, L);
 }
 
 // Canonical Montgomery representative in [0,p) of a value < 8p by conditional

@@ -22,6 +22,7 @@
 // Bounds: "<k" means value < k*p.  Every product has bound-product <= 400 < 2^9.
 #pragma once
 #include "fp28.hpp"
+#include "fpinv.hpp"
 
 namespace bgn {
 
@@ -365,8 +366,7 @@ __device__ __forceinline__ void pairing_lane(Fp<NL>& out_re, Fp<NL>& out_im, LFp
   miller_loop<NL>(S, L, op, C, P);
   Fp<NL> N, ninv, g0, g1;
   miller_norm<NL>(N, S, L, P);
-  l_store(L + 1, N);
-  fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);   // 1/N <2
+  fp_inv_mont<NL>(ninv, N, C->pm2_bits + 1, P, L);              // 1/N <1
   final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
   fp_from_mont<NL>(out_im, g1, P, L);
   fp_from_mont<NL>(out_re, g0, P, L);

@@ -14,6 +14,7 @@ thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
 #include "vm.hpp"
+#include "fpinv.hpp"
 
 using namespace bgn;
 
@@ -45,6 +46,14 @@ struct Emu {
     }
     limbs_to_wire<NL>(wire, Lb, x);
     limbs_to_wire<NL>(wire + Lb, Lb, y);
+  }
+  // Montgomery-form inverse of a Montgomery-form value (limbs in, limbs out)
+  static void fp_inv(const u32* params, int p_bits, const u32* a, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    Fp<NL> x, r;
+    memcpy(x.v, a, 4 * NL);
+    fp_inv_mont<NL>(r, x, p_bits, P, lds());
+    memcpy(out, r.v, 4 * NL);
   }
   static void pairing(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
@@ -253,5 +262,6 @@ int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, cons
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, c, out)) }
 int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }
+int emu_fp_inv(int nl, const u32* params, int p_bits, const u32* a, u32* out) { DISPATCH(nl, fp_inv(params, p_bits, a, out)) }
 size_t emu_consts_size() { return sizeof(PairingConsts); }
 }

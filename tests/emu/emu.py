@@ -18,7 +18,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "vm.hpp", "kernels.hpp")]
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "vm.hpp", "kernels.hpp", "fpinv.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"),
@@ -89,6 +89,13 @@ class Emu:
         w = C.create_string_buffer(2 * self.L)
         assert self.lib.emu_encode(self.nl, plain, self.L, inf, w) == 0
         return w.raw
+
+    def fp_inv(self, a_mont: int) -> int:
+        """Montgomery-form inverse of a Montgomery-form residue (may be lazy, < 4p)."""
+        A = (C.c_uint32 * self.nl)(*limbs(a_mont, self.nl))
+        out = (C.c_uint32 * self.nl)()
+        assert self.lib.emu_fp_inv(self.nl, self.params, self.p.bit_length(), A, out) == 0
+        return sum(int(v) << (28 * j) for j, v in enumerate(out))
 
     def pairing(self, a: bytes, b: bytes) -> bytes:
         A, ia = self.decode(a)

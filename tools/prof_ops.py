@@ -14,10 +14,26 @@ EB = eng.elem_bytes
 g = torch.Generator().manual_seed(1)
 xs = torch.randint(0, 256, (2 * n, 5), dtype=torch.uint8, generator=g).to(dev)
 rs = torch.randint(0, 256, (2 * n, 128), dtype=torch.uint8, generator=g); rs[:, 0] &= 0x3F; rs = rs.to(dev)
+import time
 cts = torch.empty(2 * n * EB, dtype=torch.uint8, device=dev)
-eng.encrypt_dev(xs, 5, rs, 128, cts, 2 * n)
+
+
+def timed(label, units, fn, reps=2):
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print("%-22s n=%d  %.2f ms  %.3e /s  (%s %.2f ms)" % (label, units, dt * 1e3, units / dt, eng.last_kernel_name(),
+                                                       eng.last_kernel_ms()), flush=True)
+
+
+timed("encrypt", 2 * n, lambda: eng.encrypt_dev(xs, 5, rs, 128, cts, 2 * n))
 out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
-for _ in range(2):
-    eng.add_dev(1, cts[: n * EB], cts[n * EB:], out, n)
-torch.cuda.synchronize()
+timed("add L1", n, lambda: eng.add_dev(1, cts[: n * EB], cts[n * EB:], out, n))
+small = 1 << 10
+timed("add L1 small", small, lambda: eng.add_dev(1, cts[: small * EB], cts[n * EB: (n + small) * EB], out, small))
+m = min(n, 1 << 16)
+timed("mult", m, lambda: eng.mult_dev(cts[: m * EB], cts[n * EB: (n + m) * EB], out, m))
 print("done", n)

@@ -72,6 +72,7 @@ struct bgn_ctx {
   uint32_t* d_tabP = nullptr;
   uint32_t* d_tabQ = nullptr;
   int fixed_windows = 0;
+  int fixed_wbits = 8;
   uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
   size_t miller_steps = 0;
   BsgsParams bsgs{};
@@ -587,52 +588,138 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
   c->kt->g1_mul(s, c->d_params, c->d_consts, a);
 }
 
-// Window tables of the key's fixed bases: tab[w][d] = d * 256^w * B, w < windows, d < 256, built with the
-// generic ladder kernel (once per key).  Must be called with c->mu held; uses the arena.
+// Window tables of the key's fixed bases P and Q: tab[w][d] = d * 2^(wbits*w) * B for w < windows, d < 2^wbits,
+// so that B^k is a sum of one entry per window and needs no doublings (EncryptWithRandomness, bgn.go:344-350;
+// the blinding terms Q^r, bgn.go:492).  wbits = 16 by default: 2^16 entries per window, 1.3 GB per base at a
+// 1024-bit key -- HBM is what this GPU has plenty of, and it halves the additions of the 8-bit layout.
+// Built once per key: the entries 2^i * B by the ladder kernel (both bases in one launch), then round k fills
+// d = 2^k + j as tab[w][j] + tab[w][2^k] for all windows at once (affine additions with batched inversion).
+// Must be called with c->mu held; uses the arena.
+int fixed_window_bits(bgn_ctx* c) {
+  int wbits = 16;
+  if (const char* e = getenv("BGN_FIXED_WINDOW_BITS")) {
+    const int v = atoi(e);
+    if (v == 8 || v == 16) wbits = v;
+  }
+  if (wbits == 16) {   // fall back to the small layout when the device is short of memory
+    size_t fr = 0, tot = 0;
+    const size_t W = (size_t)(c->n.bits() + 15) / 16 + 1;
+    const size_t need = 2 * (W << 16) * 2 * (size_t)c->nl * 4;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 4 * need) wbits = 8;
+  }
+  return wbits;
+}
+
 int ensure_fixed_tables(bgn_ctx* c) {
   if (c->d_tabP) return BGN_OK;
   const KernelTable* kt = c->kt;
-  const int W = (c->n.bits() + 7) / 8 + 1;
-  const size_t ne = (size_t)W * 256;
-  const size_t st = round_up(ne, 64), sw = round_up((size_t)W, 64);
-  SoA2 base, ent;
-  uint8_t *k1 = nullptr, *k2 = nullptr;
+  const int wbits = fixed_window_bits(c);
+  const int W = (c->n.bits() + wbits - 1) / wbits + 1;
+  const size_t ne = (size_t)W << wbits;                       // entries per table
+  const size_t np = (size_t)W * wbits;                        // entries that are 2^i * B
+  const size_t klen = (np + 7) / 8;
+  const size_t maxc = (size_t)W * (((size_t)1 << (wbits - 1)) - 1);
+  const size_t sp = round_up(2 * np, 64), sr = round_up(maxc, 64);
+  SoA2 base, pw;
+  uint8_t* k1 = nullptr;
+  uint32_t* prefix = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
-    base = w.g1(sw);
-    ent = w.g1(st);
-    k1 = (uint8_t*)w.cv.take((size_t)W * W);
-    k2 = (uint8_t*)w.cv.take(ne);
+    base = w.g1(64);
+    pw = w.g1(sp);
+    prefix = w.fp(sr);
+    k1 = (uint8_t*)w.cv.take(2 * np * klen);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
     }
   }
-  std::vector<uint8_t> h1((size_t)W * W, 0), h2(ne);
-  for (int w = 0; w < W; ++w) h1[(size_t)w * W + (W - 1 - w)] = 1;          // 256^w, big-endian in W bytes
-  for (size_t i = 0; i < ne; ++i) h2[i] = (uint8_t)(i & 255);
+  std::vector<uint8_t> h1(2 * np * klen, 0);
+  for (size_t b = 0; b < 2; ++b)
+    for (size_t i = 0; i < np; ++i) h1[(b * np + i) * klen + (klen - 1 - i / 8)] = (uint8_t)(1u << (i % 8));   // 2^i
   HIP_TRY(hipMemcpy(k1, h1.data(), h1.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(k2, h2.data(), h2.size(), hipMemcpyHostToDevice));
-  uint32_t* tabs[2] = {nullptr, nullptr};
+  // base = [P, Q] as a two-element SoA
+  HIP_TRY(hipMemset(base.inf, 0, base.stride));
   for (int b = 0; b < 2; ++b) {
-    HIP_TRY(hipMalloc((void**)&tabs[b], ne * 2 * (size_t)c->nl * 4));
-    g1_mul_launch(c, nullptr, b ? c->key_Q() : c->key_P(), k1, (size_t)W, (size_t)W, base, (size_t)W);
-    kt->to_mont(nullptr, c->d_params, base.c0, base.c1, base.stride, (size_t)W);
+    const SoA2 key = b ? c->key_Q() : c->key_P();
+    HIP_TRY(hipMemcpy2D(base.c0 + b, base.stride * 4, key.c0, 4, 4, (size_t)c->nl, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy2D(base.c1 + b, base.stride * 4, key.c1, 4, 4, (size_t)c->nl, hipMemcpyDeviceToDevice));
+  }
+  uint32_t* tabs[2] = {nullptr, nullptr};
+  const size_t tab_bytes = ne * 2 * (size_t)c->nl * 4;
+  for (int b = 0; b < 2; ++b) {
+    if (hipMalloc((void**)&tabs[b], tab_bytes) != hipSuccess) {
+      if (tabs[0]) (void)hipFree(tabs[0]);
+      return fail(BGN_E_NOMEM, "fixed-base window tables");
+    }
+    HIP_TRY(hipMemset(tabs[b], 0, tab_bytes));
+  }
+  {
     G1MulArgs a;
     a.bx = base.c0; a.by = base.c1; a.binf = base.inf; a.sb = base.stride;
-    a.bdiv = 256;
-    a.k = k2; a.kstride = 1; a.klen = 1;
-    a.ox = ent.c0; a.oy = ent.c1; a.oinf = ent.inf; a.so = ent.stride;
-    a.count = ne;
+    a.bdiv = np;
+    a.k = k1; a.kstride = klen; a.klen = klen;
+    a.ox = pw.c0; a.oy = pw.c1; a.oinf = pw.inf; a.so = pw.stride;
+    a.count = 2 * np;
     kt->g1_mul(nullptr, c->d_params, c->d_consts, a);
-    kt->to_mont(nullptr, c->d_params, ent.c0, ent.c1, ent.stride, ne);
-    kt->soa_to_entries(nullptr, ent.c0, ent.c1, ent.stride, ne, tabs[b]);
+    kt->to_mont(nullptr, c->d_params, pw.c0, pw.c1, pw.stride, 2 * np);
+  }
+  for (int b = 0; b < 2; ++b) {
+    kt->tab_scatter_pow(nullptr, pw.c0 + b * np, pw.c1 + b * np, pw.stride, np, wbits, tabs[b]);
+    for (int k = 1; k < wbits; ++k) {
+      G1TabRoundArgs a;
+      a.tab = tabs[b]; a.wbits = wbits; a.windows = W; a.k = k;
+      a.prefix = prefix; a.sp = sr;
+      a.count = (size_t)W * (((size_t)1 << k) - 1);
+      a.run = run_for(a.count);
+      kt->g1_tab_round(nullptr, c->d_params, c->d_consts, a);
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   c->d_tabP = tabs[0];
   c->d_tabQ = tabs[1];
   c->fixed_windows = W;
+  c->fixed_wbits = wbits;
+  return BGN_OK;
+}
+
+// Does a big-endian scalar of `len` bytes fit the window tables?
+bool fixed_fits(const bgn_ctx* c, size_t len) {
+  return (len * 8 + c->fixed_wbits - 1) / c->fixed_wbits <= (size_t)c->fixed_windows;
+}
+
+// S <- P^x * Q^r (x_be or r_be may be null) by one table entry per window: one k_g1_fixed_step launch per
+// window over the whole batch, the running sums S kept in place (canonical Montgomery); the last launch writes
+// plain coordinates.  timed: record the context's events around one representative launch.
+int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, const uint8_t* x_be, size_t x_len,
+                       const uint8_t* r_be, size_t r_len, size_t count, bool timed) {
+  const int wbits = c->fixed_wbits;
+  const int wx = x_be ? (int)((x_len * 8 + wbits - 1) / wbits) : 0;
+  const int wr = r_be ? (int)((r_len * 8 + wbits - 1) / wbits) : 0;
+  const int steps = wx + wr;
+  HIP_TRY(hipMemsetAsync(S.c0, 0, (size_t)c->nl * S.stride * 4, s));
+  HIP_TRY(hipMemsetAsync(S.c1, 0, (size_t)c->nl * S.stride * 4, s));
+  HIP_TRY(hipMemsetAsync(S.inf, 1, S.stride, s));              // identity
+  const int probe = steps > 1 ? steps - 2 : 0;
+  for (int i = 0; i < steps; ++i) {
+    const bool isx = i < wx;
+    G1FixedStepArgs a;
+    a.sx = S.c0; a.sy = S.c1; a.sinf = S.inf; a.ss = S.stride;
+    a.tab = isx ? c->d_tabP : c->d_tabQ; a.wbits = wbits; a.window = isx ? i : i - wx;
+    a.k = isx ? x_be : r_be; a.klen = isx ? x_len : r_len;
+    a.prefix = prefix; a.sp = S.stride;
+    a.count = count;
+    a.run = run_for(count);
+    a.plain_out = (i == steps - 1) ? 1 : 0;
+    if (timed && i == probe) HIP_TRY(hipEventRecord(c->ev0, s));
+    c->kt->g1_fixed_step(s, c->d_params, c->d_consts, a);
+    if (timed && i == probe) HIP_TRY(hipEventRecord(c->ev1, s));
+  }
+  if (timed) {
+    c->ev_valid = true;
+    c->last_kernel = "k_g1_fixed_step";
+  }
   return BGN_OK;
 }
 
@@ -659,13 +746,8 @@ void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t k
 // Blind a level-1 result R (plain) with Q^r (bgn.go:488-495): R <- R + Q^r.  T1/T2 scratch G1 arrays.
 void blind_l1(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, uint32_t* prefix,
               size_t count) {
-  if (c->d_tabQ && (int)r_len <= c->fixed_windows) {                        // h1 = Q^r from the window table
-    G1FixedArgs a;
-    a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.windows = c->fixed_windows;
-    a.x = nullptr; a.xlen = 0; a.r = r_be; a.rlen = r_len;
-    a.ox = T1.c0; a.oy = T1.c1; a.oinf = T1.inf; a.so = T1.stride;
-    a.count = count;
-    c->kt->g1_fixed(s, c->d_params, c->d_consts, a, 1, nullptr, 0);
+  if (c->d_tabQ && fixed_fits(c, r_len)) {                                  // h1 = Q^r from the window table
+    (void)fixed_base_product(c, s, T1, prefix, nullptr, 0, r_be, r_len, count, false);
   } else {
     g1_mul_launch(c, s, c->key_Q(), r_be, r_len, r_len, T1, count);        // generic ladder for over-long r
   }
@@ -721,15 +803,21 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   const KernelTable* kt = c->kt;
   kt->decode(s, c->d_params, a, c->L, count, A);
   kt->decode(s, c->d_params, b, c->L, count, B);
+  HIP_TRY(hipEventRecord(c->ev0, s));
   if (level == 1) {
     g1_add_launch(c, s, A, B, O, prefix, count, subtract);
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->last_kernel = "k_g1_add";
     if (r_be) blind_l1(c, s, O, r_be, r_len, T1, T2, prefix, count);
     kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
   } else {
     gt_mul_launch(c, s, A, B, O, count, subtract);
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->last_kernel = "k_gt_mul";
     if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);
     kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
   }
+  c->ev_valid = true;
   HIP_TRY(hipGetLastError());
   return BGN_OK;
 }
@@ -854,27 +942,18 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
     int rc = ensure_fixed_tables(c);      // may re-carve the arena: G/H/O are re-derived below
     if (rc) return rc;
   }
-  if ((int)x_len <= c->fixed_windows && (!r_be || (int)r_len <= c->fixed_windows)) {
-    uint32_t* fws = nullptr;
+  if (fixed_fits(c, x_len) && (!r_be || fixed_fits(c, r_len))) {
     for (int pass = 0; pass < 2; ++pass) {
       Ws w(c, pass ? c->arena : nullptr);
       G = w.g1(st);
-      fws = (uint32_t*)w.cv.take((size_t)4 * c->nl * st * 4);
+      prefix = w.fp(st);
       if (!pass) {
         int rc = ensure_arena(c, w.cv.off);
         if (rc) return rc;
       }
     }
-    G1FixedArgs a;
-    a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.windows = c->fixed_windows;
-    a.x = x_be; a.xlen = x_len; a.r = r_be; a.rlen = r_len;
-    a.ox = G.c0; a.oy = G.c1; a.oinf = G.inf; a.so = G.stride;
-    a.count = count;
-    HIP_TRY(hipEventRecord(c->ev0, s));
-    kt->g1_fixed(s, c->d_params, c->d_consts, a, pairing_run(count), fws, st);  // bgn.go:344-350 fused
-    HIP_TRY(hipEventRecord(c->ev1, s));
-    c->ev_valid = true;
-    c->last_kernel = "k_g1_fixed";
+    int rc = fixed_base_product(c, s, G, prefix, x_be, x_len, r_be, r_len, count, true);   // bgn.go:344-350 fused
+    if (rc) return rc;
     kt->encode(s, G.inf, G.c0, G.c1, G.stride, c->L, count, out);
     HIP_TRY(hipGetLastError());
     return BGN_OK;

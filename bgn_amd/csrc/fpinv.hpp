@@ -19,6 +19,7 @@
 // cap from the proven bound of the division-step count, so it cannot spin.
 #pragma once
 #include "fp28.hpp"
+#include "imad.hpp"
 
 namespace bgn {
 
@@ -61,18 +62,18 @@ typedef long long i64;
 // (f, g) <- t * (f, g) / 2^28   (exact)
 template <int NL>
 __device__ __forceinline__ void divmat_apply_fg(i32 (&f)[NL], i32 (&g)[NL], const DivMat& t) {
-  i64 cf = (i64)t.u * f[0] + (i64)t.v * g[0];
-  i64 cg = (i64)t.q * f[0] + (i64)t.r * g[0];
-  cf >>= LIMB_BITS;
-  cg >>= LIMB_BITS;
+  i64 cf = imad(t.u, f[0], imad(t.v, g[0], 0));
+  i64 cg = imad(t.q, f[0], imad(t.r, g[0], 0));
+  cf = sar28(cf);
+  cg = sar28(cg);
 #pragma unroll
   for (int j = 1; j < NL; ++j) {
-    cf += (i64)t.u * f[j] + (i64)t.v * g[j];
-    cg += (i64)t.q * f[j] + (i64)t.r * g[j];
+    cf = imad(t.u, f[j], imad(t.v, g[j], cf));
+    cg = imad(t.q, f[j], imad(t.r, g[j], cg));
     f[j - 1] = (i32)((u32)cf & LIMB_MASK);
     g[j - 1] = (i32)((u32)cg & LIMB_MASK);
-    cf >>= LIMB_BITS;
-    cg >>= LIMB_BITS;
+    cf = sar28(cf);
+    cg = sar28(cg);
   }
   f[NL - 1] = (i32)cf;
   g[NL - 1] = (i32)cg;
@@ -85,25 +86,25 @@ __device__ __forceinline__ void divmat_apply_de(i32 (&d)[NL], i32 (&e)[NL], cons
   const i32 sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
   i32 md = (t.u & sd) + (t.v & se);
   i32 me = (t.q & sd) + (t.r & se);
-  i64 cd = (i64)t.u * d[0] + (i64)t.v * e[0];
-  i64 ce = (i64)t.q * d[0] + (i64)t.r * e[0];
+  i64 cd = imad(t.u, d[0], imad(t.v, e[0], 0));
+  i64 ce = imad(t.q, d[0], imad(t.r, e[0], 0));
   // P->pinv = -p^{-1} mod 2^28: the new md is == pinv * cd, so cd + p * md == 0 (mod 2^28)
   md -= (i32)(((u32)md - P->pinv * (u32)cd) & LIMB_MASK);
   me -= (i32)(((u32)me - P->pinv * (u32)ce) & LIMB_MASK);
-  cd += (i64)(i32)P->p[0] * md;
-  ce += (i64)(i32)P->p[0] * me;
-  cd >>= LIMB_BITS;
-  ce >>= LIMB_BITS;
+  cd = imad_s(md, (i32)P->p[0], cd);
+  ce = imad_s(me, (i32)P->p[0], ce);
+  cd = sar28(cd);
+  ce = sar28(ce);
 #pragma unroll
   for (int j = 1; j < NL; ++j) {
-    cd += (i64)t.u * d[j] + (i64)t.v * e[j];
-    ce += (i64)t.q * d[j] + (i64)t.r * e[j];
-    cd += (i64)(i32)P->p[j] * md;
-    ce += (i64)(i32)P->p[j] * me;
+    cd = imad(t.u, d[j], imad(t.v, e[j], cd));
+    ce = imad(t.q, d[j], imad(t.r, e[j], ce));
+    cd = imad_s(md, (i32)P->p[j], cd);
+    ce = imad_s(me, (i32)P->p[j], ce);
     d[j - 1] = (i32)((u32)cd & LIMB_MASK);
     e[j - 1] = (i32)((u32)ce & LIMB_MASK);
-    cd >>= LIMB_BITS;
-    ce >>= LIMB_BITS;
+    cd = sar28(cd);
+    ce = sar28(ce);
   }
   d[NL - 1] = (i32)cd;
   e[NL - 1] = (i32)ce;

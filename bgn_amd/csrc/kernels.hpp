@@ -30,21 +30,32 @@ struct G1AddArgs {
   int negate_b;                                                             // subtraction
 };
 
+// One window step of the fixed-base products (ops.hpp): state[e] += tab[window][digit_window(k[e])].
+// Table layout: entry (w, d) at tab + ((w << wbits) + d) * 2*NL : x limbs then y limbs, canonical
+// Montgomery; an all-zero entry is the identity (d = 0 is never read as a point).
+struct G1FixedStepArgs {
+  uint32_t* sx; uint32_t* sy; uint8_t* sinf; size_t ss;                     // state, canonical Montgomery (in place)
+  const uint32_t* tab; int wbits; int window;
+  const uint8_t* k; size_t klen;                                            // big-endian scalars, klen bytes each
+  uint32_t* prefix; size_t sp;
+  size_t count;
+  int run;
+  int plain_out;                                                            // write plain canonical (last step)
+};
+
+// Round k of the table construction: tab[w][2^k + j] = tab[w][j] + tab[w][2^k] for j in [1, 2^k), w < windows.
+struct G1TabRoundArgs {
+  uint32_t* tab; int wbits; int windows; int k;
+  uint32_t* prefix; size_t sp;
+  size_t count;                                                             // windows * (2^k - 1)
+  int run;
+};
+
 // G1 scalar multiplication (ops.hpp).
 struct G1MulArgs {
   const uint32_t* bx; const uint32_t* by; const uint8_t* binf; size_t sb;   // bases (sb == 1: broadcast), canonical Montgomery
   size_t bdiv;                                                              // > 1: element e uses base e / bdiv
   const uint8_t* k; size_t kstride; size_t klen;                            // big-endian scalars (kstride 0: one for all)
-  uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical affine out
-  size_t count;
-};
-
-// Fixed-base double scalar multiplication out = P^x * Q^r from per-key window tables (ops.hpp).
-// Table layout: entry (w, d), w = window (byte index from the least significant byte), d = 0..255, at
-// tab + (w*256 + d) * 2*NL : x limbs then y limbs, canonical Montgomery (d = 0 unused).
-struct G1FixedArgs {
-  const uint32_t* tabP; const uint32_t* tabQ; int windows;
-  const uint8_t* x; size_t xlen; const uint8_t* r; size_t rlen;             // r may be null
   uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical affine out
   size_t count;
 };
@@ -124,9 +135,11 @@ struct KernelTable {
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);
   void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
-  // run > 1: each lane owns `run` elements and shares one inversion; ws = 4*NL*sw u32 of workspace (sw >= count)
-  void (*g1_fixed)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a, int run,
-                   uint32_t* ws, size_t sw);
+  void (*g1_fixed_step)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedStepArgs a);
+  void (*g1_tab_round)(hipStream_t s, const void* params, const PairingConsts* consts, G1TabRoundArgs a);
+  // SoA element w*wbits + k (canonical Montgomery) -> table entry (w, 2^k)
+  void (*tab_scatter_pow)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count, int wbits,
+                          uint32_t* tab);
   // SoA (stride) -> table entries [e][x limbs | y limbs]
   void (*soa_to_entries)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
                          uint32_t* entries);

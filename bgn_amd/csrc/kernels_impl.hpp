@@ -233,10 +233,35 @@ k_g1_mul(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
-k_g1_fixed(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1FixedArgs A, int run,
-           u32* __restrict__ ws, size_t sw) {
-  __shared__ LFp<NL> L[4];
-  g1_fixed_lane<NL>(A, run, ws, sw, L, C, P);
+k_g1_fixed_step(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1FixedStepArgs A) {
+  __shared__ LFp<NL> L[2];
+  g1_add_run<NL>(G1IoFixedStep<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_g1_tab_round(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1TabRoundArgs A) {
+  __shared__ LFp<NL> L[2];
+  g1_add_run<NL>(G1IoTabRound<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
+}
+
+// SoA element i = w*wbits + k (the point 2^(w*wbits + k) * B) -> table entry (w, 2^k)
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_tab_scatter_pow(const u32* __restrict__ c0, const u32* __restrict__ c1, size_t stride, size_t count, int wbits,
+                  u32* __restrict__ tab) {
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  if (e >= count) return;
+  Fp<NL> x, y;
+  g_load<NL>(x, c0, stride, e);
+  g_load<NL>(y, c1, stride, e);
+  const size_t w = e / (size_t)wbits, k = e % (size_t)wbits;
+  u32* dst = tab + ((w << wbits) + ((size_t)1 << k)) * (size_t)(2 * NL);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    dst[j] = x.v[j];
+    dst[NL + j] = y.v[j];
+  }
 }
 
 template <int NL>
@@ -387,13 +412,25 @@ static void launch_g1_mul(hipStream_t s, const void* params, const PairingConsts
                      a);
 }
 
-static void launch_g1_fixed(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedArgs a, int run,
-                            uint32_t* ws, size_t sw) {
+static void launch_g1_fixed_step(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedStepArgs a) {
   if (!a.count) return;
-  if (run < 1 || !ws) run = 1;
-  const size_t lanes = (a.count + run - 1) / run;
-  hipLaunchKernelGGL(k_g1_fixed<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
-                     consts, a, run, ws, sw);
+  const size_t lanes = (a.count + a.run - 1) / a.run;
+  hipLaunchKernelGGL(k_g1_fixed_step<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     consts, a);
+}
+
+static void launch_g1_tab_round(hipStream_t s, const void* params, const PairingConsts* consts, G1TabRoundArgs a) {
+  if (!a.count) return;
+  const size_t lanes = (a.count + a.run - 1) / a.run;
+  hipLaunchKernelGGL(k_g1_tab_round<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     consts, a);
+}
+
+static void launch_tab_scatter_pow(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
+                                   int wbits, uint32_t* tab) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_tab_scatter_pow<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, c0, c1, stride, count, wbits,
+                     tab);
 }
 
 static void launch_soa_to_entries(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
@@ -451,7 +488,9 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_to_mont,
       launch_g1_add,
       launch_g1_mul,
-      launch_g1_fixed,
+      launch_g1_fixed_step,
+      launch_g1_tab_round,
+      launch_tab_scatter_pow,
       launch_soa_to_entries,
       launch_gt_mul,
       launch_gt_pow,

@@ -167,78 +167,187 @@ __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp
   return cs;
 }
 
+// Where the operands of an addition run come from and where the sums go.  An IO policy provides
+//   loadA / loadB (e, x, y, inf): canonical Montgomery coordinates (<1) and the identity flag;
+//   store (e, x3 <4, y3 <3, inf): lazy Montgomery sum.
+// (a) SoA operands -> plain SoA sum for the encoder: EAdd / ESub (bgn.go:482, :419, :350).
 template <int NL>
-__device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L, const PairingConsts* __restrict__ C,
-                                                  const FpParams<NL>* __restrict__ P) {
+struct G1IoSoA {
+  const G1AddArgs& A;
+  __device__ __forceinline__ void loadA(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    g_load(x, A.ax, A.sa, e);
+    g_load(y, A.ay, A.sa, e);
+    inf = A.ainf && A.ainf[e];
+  }
+  __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    const size_t eb = (A.sb == 1) ? 0 : e;
+    g_load(x, A.bx, A.sb, eb);
+    g_load(y, A.by, A.sb, eb);
+    if (A.negate_b) {
+      fp_neg<1>(y, y, P);
+      fp_reduce8(y, y, P);                  // p - 0 = p -> 0
+    }
+    inf = A.binf && A.binf[eb];
+  }
+  __device__ __forceinline__ void store(size_t e, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>* L,
+                                        const FpParams<NL>* __restrict__ P) const {
+    Fp<NL> o;
+    fp_from_mont<NL>(o, x3, P, L + 1);
+    g_store(A.ox, A.so, e, o);
+    fp_from_mont<NL>(o, y3, P, L + 1);
+    g_store(A.oy, A.so, e, o);
+    A.oinf[e] = inf ? 1 : 0;
+  }
+};
+
+// Digit `window` (wbits = 8 or 16 bits wide, counted from the least significant end) of a big-endian scalar.
+__device__ __forceinline__ u32 scalar_window(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
+  if (wbits == 8) return k[klen - 1 - (size_t)window];
+  const size_t lo = 2 * (size_t)window;
+  u32 d = k[klen - 1 - lo];
+  if (lo + 1 < klen) d |= (u32)k[klen - 2 - lo] << 8;
+  return d;
+}
+
+// Table entry -> coordinates; an all-zero entry stands for the identity (never a subgroup point).
+template <int NL>
+__device__ __forceinline__ void tab_load(Fp<NL>& x, Fp<NL>& y, bool& inf, const u32* __restrict__ ent) {
+  v_load(x, ent);
+  v_load(y, ent + NL);
+  inf = fp_is_zero_limbs(x) && fp_is_zero_limbs(y);
+}
+
+// (b) One window step of the fixed-base products P^x, Q^r (bgn.go:344-346): state += tab[window][digit],
+// in place, state in canonical Montgomery SoA; the last step writes plain coordinates for the encoder.
+template <int NL>
+struct G1IoFixedStep {
+  const G1FixedStepArgs& A;
+  __device__ __forceinline__ void loadA(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    g_load(x, A.sx, A.ss, e);
+    g_load(y, A.sy, A.ss, e);
+    inf = A.sinf[e] != 0;
+  }
+  __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    const u32 d = scalar_window(A.k + e * A.klen, A.klen, A.wbits, A.window);
+    tab_load<NL>(x, y, inf, A.tab + ((((size_t)A.window) << A.wbits) + d) * (size_t)(2 * NL));
+    inf = inf || d == 0;
+  }
+  __device__ __forceinline__ void store(size_t e, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>* L,
+                                        const FpParams<NL>* __restrict__ P) const {
+    Fp<NL> o;
+    if (A.plain_out) {
+      fp_from_mont<NL>(o, x3, P, L + 1);
+      g_store(A.sx, A.ss, e, o);
+      fp_from_mont<NL>(o, y3, P, L + 1);
+      g_store(A.sy, A.ss, e, o);
+    } else {
+      fp_reduce8(o, x3, P);
+      g_store(A.sx, A.ss, e, o);
+      fp_reduce8(o, y3, P);
+      g_store(A.sy, A.ss, e, o);
+    }
+    A.sinf[e] = inf ? 1 : 0;
+  }
+};
+
+// (c) Round k of the window-table construction: tab[w][2^k + j] = tab[w][j] + tab[w][2^k], j in [1, 2^k);
+// element e = w * (2^k - 1) + (j - 1).
+template <int NL>
+struct G1IoTabRound {
+  const G1TabRoundArgs& A;
+  __device__ __forceinline__ void split(size_t e, size_t& w, size_t& j) const {
+    const size_t per = ((size_t)1 << A.k) - 1;
+    w = e / per;
+    j = e - w * per + 1;
+  }
+  __device__ __forceinline__ void loadA(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    size_t w, j;
+    split(e, w, j);
+    tab_load<NL>(x, y, inf, A.tab + ((w << A.wbits) + j) * (size_t)(2 * NL));
+  }
+  __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    size_t w, j;
+    split(e, w, j);
+    tab_load<NL>(x, y, inf, A.tab + ((w << A.wbits) + ((size_t)1 << A.k)) * (size_t)(2 * NL));
+  }
+  __device__ __forceinline__ void store(size_t e, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>*,
+                                        const FpParams<NL>* __restrict__ P) const {
+    size_t w, j;
+    split(e, w, j);
+    u32* ent = A.tab + ((w << A.wbits) + ((size_t)1 << A.k) + j) * (size_t)(2 * NL);
+    Fp<NL> o;
+    fp_reduce8(o, x3, P);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ent[l] = inf ? 0u : o.v[l];
+    fp_reduce8(o, y3, P);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ent[NL + l] = inf ? 0u : o.v[l];
+  }
+};
+
+// The run itself: `run` additions per lane (element j*T + t), one inversion per lane.
+// prefix: workspace of one F_p per element, SoA with stride sp.
+template <int NL, class IO>
+__device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, u32* __restrict__ prefix, size_t sp,
+                                           LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                           const FpParams<NL>* __restrict__ P) {
   const size_t T = (size_t)gridDim.x * FP_BLOCK;
   const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
   Fp<NL> acc;
   fp_set(acc, P->one);
   // pass 1: prefix products of the denominators
 #pragma unroll 1
-  for (int j = 0; j < A.run; ++j) {
+  for (int j = 0; j < run; ++j) {
     const size_t e = (size_t)j * T + t;
-    if (e < A.count) {
-      const size_t eb = (A.sb == 1) ? 0 : e;
+    if (e < count) {
       Fp<NL> x1, y1, x2, y2, d;
-      g_load(x1, A.ax, A.sa, e);
-      g_load(y1, A.ay, A.sa, e);
-      g_load(x2, A.bx, A.sb, eb);
-      g_load(y2, A.by, A.sb, eb);
-      if (A.negate_b) {
-        fp_neg<1>(y2, y2, P);
-        fp_reduce8(y2, y2, P);              // p - 0 = p -> 0
-      }
-      g1_classify<NL>(d, x1, y1, A.ainf && A.ainf[e], x2, y2, A.binf && A.binf[eb], P);
-      g_store(A.prefix, A.sp, e, acc);
+      bool i1, i2;
+      io.loadA(e, x1, y1, i1, P);
+      io.loadB(e, x2, y2, i2, P);
+      g1_classify<NL>(d, x1, y1, i1, x2, y2, i2, P);
+      g_store(prefix, sp, e, acc);
       l_store(L, acc);
       fp_mul(acc, L, d, P);                 // <2
     }
   }
   Fp<NL> inv;
-  fp_inv<NL>(inv, acc, L, C, P);            // <2
+  fp_inv<NL>(inv, acc, L, C, P);            // <1
   // pass 2: walk back, peel one inverse per element
 #pragma unroll 1
-  for (int j = A.run - 1; j >= 0; --j) {
+  for (int j = run - 1; j >= 0; --j) {
     const size_t e = (size_t)j * T + t;
-    if (e < A.count) {
-      const size_t eb = (A.sb == 1) ? 0 : e;
+    if (e < count) {
       Fp<NL> x1, y1, x2, y2, d;
-      g_load(x1, A.ax, A.sa, e);
-      g_load(y1, A.ay, A.sa, e);
-      g_load(x2, A.bx, A.sb, eb);
-      g_load(y2, A.by, A.sb, eb);
-      if (A.negate_b) {
-        fp_neg<1>(y2, y2, P);
-        fp_reduce8(y2, y2, P);
-      }
-      const int cs = g1_classify<NL>(d, x1, y1, A.ainf && A.ainf[e], x2, y2, A.binf && A.binf[eb], P);
+      bool i1, i2;
+      io.loadA(e, x1, y1, i1, P);
+      io.loadB(e, x2, y2, i2, P);
+      const int cs = g1_classify<NL>(d, x1, y1, i1, x2, y2, i2, P);
       Fp<NL> dinv;
       {
         Fp<NL> pf;
-        g_load(pf, A.prefix, A.sp, e);
+        g_load(pf, prefix, sp, e);
         l_store(L, inv);                    // L0 = running inverse
         fp_mul(dinv, L, pf, P);             // 1/d <2
         fp_mul(inv, L, d, P);               // inverse of the shorter prefix <2
       }
-      // numerator: y2 - y1, or 3*x1^2 + 1 for a doubling
+      // numerator: y2 - y1, or 3*x1^2 + 1 for a doubling (rare: computed only when some lane doubles)
       Fp<NL> num;
-      {
+      fp_sub<1>(num, y2, y1, P);            // <2
+      if (__ballot(cs == G1C_DBL)) {
         Fp<NL> xx, t3;
-        fp_sqrv(xx, x1, P, L + 1);      // <2
+        fp_sqrv(xx, x1, P, L + 1);          // <2
         fp_dbl(t3, xx);
         fp_add(t3, t3, xx);                 // <6
         Fp<NL> one;
         fp_set(one, P->one);
         fp_add(t3, t3, one);                // <7
-        fp_sub<1>(num, y2, y1, P);          // <2
         fp_select(num, cs == G1C_DBL, t3, num);
       }
       l_store(L + 1, dinv);
       Fp<NL> lam;
       fp_mul(lam, L + 1, num, P);           // lambda <2   (14)
       Fp<NL> x3, y3;
-      fp_sqrv(x3, lam, P, L + 1);      // <2 ; L1 = lambda
+      fp_sqrv(x3, lam, P, L + 1);           // <2 ; L1 = lambda
       fp_sub<1>(x3, x3, x1, P);             // <3
       fp_sub<1>(x3, x3, x2, P);             // <4
       fp_sub<4>(y3, x1, x3, P);             // <5
@@ -250,14 +359,15 @@ __device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L
       fp_select(y3, isA, y1, y3);
       fp_select(x3, isB, x2, x3);
       fp_select(y3, isB, y2, y3);
-      Fp<NL> o;
-      fp_from_mont<NL>(o, x3, P, L + 1);
-      g_store(A.ox, A.so, e, o);
-      fp_from_mont<NL>(o, y3, P, L + 1);
-      g_store(A.oy, A.so, e, o);
-      A.oinf[e] = (cs == G1C_INF) ? 1 : 0;
+      io.store(e, x3, y3, cs == G1C_INF, L, P);
     }
   }
+}
+
+template <int NL>
+__device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L, const PairingConsts* __restrict__ C,
+                                                  const FpParams<NL>* __restrict__ P) {
+  g1_add_run<NL>(G1IoSoA<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
 }
 
 // ===========================================================================
@@ -513,131 +623,6 @@ __device__ __forceinline__ void g1_scalarmul_lane(const G1MulArgs& A, size_t e, 
   }
   const bool binf = A.binf && A.binf[eb];
   jac_store_affine<NL>(S, acc_inf || binf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
-}
-
-// acc = sum over windows of tabP[w][x_w] + tabQ[w][r_w] (Jacobian): EncryptWithRandomness
-// (bgn.go:340-353) with both PowBig calls and the final Mul fused; P and Q are fixed per key, so no
-// doublings are needed at all.
-template <int NL>
-__device__ __forceinline__ void g1_fixed_accumulate(JacAcc<NL>& S, bool& acc_inf, const G1FixedArgs& A, size_t e,
-                                                    LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
-  {
-    Fp<NL> t;
-    fp_set(t, P->one);
-    a_store(S.X, t);
-    a_store(S.Y, t);
-    a_store(S.T, t);
-    a_store(S.U, t);
-    fp_zero(t);
-    a_store(S.Z, t);
-  }
-  acc_inf = true;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const uint8_t* k = pass ? A.r : A.x;
-    const size_t klen = pass ? A.rlen : A.xlen;
-    const u32* tab = pass ? A.tabQ : A.tabP;
-    if (!k) continue;
-    k += e * klen;
-#pragma unroll 1
-    for (size_t w = 0; w < klen; ++w) {
-      const u32 d = k[klen - 1 - w];
-      if (__ballot(d != 0)) {
-        const u32* ent = tab + ((size_t)w * 256 + d) * (size_t)(2 * NL);
-        Fp<NL> t;
-        v_load(t, ent);                      // per-lane table entry: plain gather
-        l_store(L + 2, t);
-        v_load(t, ent + NL);
-        l_store(L + 3, t);
-        jac_add_affine<NL>(S, acc_inf, d != 0, L, P);
-      }
-    }
-  }
-}
-
-// Each lane owns `run` encryptions e = j*T + t and shares one F_p inversion among them (Montgomery's
-// trick on the Jacobian Z coordinates).  ws: 4 F_p per element (X, Y, Z, prefix), stride sw.
-template <int NL>
-__device__ __forceinline__ void g1_fixed_lane(const G1FixedArgs& A, int run, u32* __restrict__ ws, size_t sw,
-                                              LFp<NL>* L, const PairingConsts* __restrict__ C,
-                                              const FpParams<NL>* __restrict__ P) {
-  const size_t T = (size_t)gridDim.x * FP_BLOCK;
-  const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
-  JacAcc<NL> S;
-  if (run <= 1 || !ws) {
-    size_t e = t;
-    const bool live = e < A.count;
-    if (!live) e = A.count - 1;
-    bool acc_inf;
-    g1_fixed_accumulate<NL>(S, acc_inf, A, e, L, P);
-    jac_store_affine<NL>(S, acc_inf, A.ox, A.oy, A.oinf, A.so, e, live, L, C, P);
-    return;
-  }
-  u32* wX = ws;
-  u32* wY = ws + (size_t)NL * sw;
-  u32* wZ = ws + (size_t)2 * NL * sw;
-  u32* wP = ws + (size_t)3 * NL * sw;
-  Fp<NL> acc;
-  fp_set(acc, P->one);
-#pragma unroll 1
-  for (int j = 0; j < run; ++j) {
-    size_t e = (size_t)j * T + t;
-    const bool live = e < A.count;
-    if (!__ballot(live)) break;
-    if (!live) e = A.count - 1;
-    bool acc_inf;
-    g1_fixed_accumulate<NL>(S, acc_inf, A, e, L, P);
-    Fp<NL> z, r;
-    a_load(z, S.Z);
-    fp_set(r, P->one);
-    fp_select(z, acc_inf, r, z);            // O: keep the product invertible
-    fp_reduce8(z, z, P);                    // <1
-    if (live) {
-      a_load(r, S.X);
-      g_store<NL>(wX, sw, e, r);
-      a_load(r, S.Y);
-      g_store<NL>(wY, sw, e, r);
-      g_store<NL>(wZ, sw, e, z);
-      g_store<NL>(wP, sw, e, acc);
-      A.oinf[e] = acc_inf ? 1 : 0;
-    }
-    l_store(L, acc);
-    fp_mul(r, L, z, P);                     // <2
-    fp_select(acc, live, r, acc);
-  }
-  Fp<NL> inv;
-  fp_inv<NL>(inv, acc, L, C, P);            // 1 / prod Z_j  <2
-#pragma unroll 1
-  for (int j = run - 1; j >= 0; --j) {
-    size_t e = (size_t)j * T + t;
-    const bool live = e < A.count;
-    if (!__ballot(live)) continue;
-    if (!live) e = A.count - 1;
-    Fp<NL> z, pf, zi, u, r;
-    g_load<NL>(z, wZ, sw, e);
-    g_load<NL>(pf, wP, sw, e);
-    l_store(L, inv);
-    fp_mul(zi, L, pf, P);                   // 1/Z_j <2
-    fp_mul(r, L, z, P);                     // inverse of the shorter prefix <2
-    fp_select(inv, live, r, inv);
-    l_store(L + 1, zi);
-    fp_sqr(u, L + 1, zi, P);                // zi^2 <2
-    g_load<NL>(r, wX, sw, e);
-    fp_mulv(r, r, u, P, L);                 // x <2   (18*2)
-    fp_mul(u, L + 1, u, P);                 // zi^3 <2
-    {
-      Fp<NL> o;
-      fp_from_mont<NL>(o, r, P, L);
-      if (live) g_store(A.ox, A.so, e, o);
-    }
-    g_load<NL>(r, wY, sw, e);
-    fp_mulv(r, r, u, P, L);                 // y <2
-    {
-      Fp<NL> o;
-      fp_from_mont<NL>(o, r, P, L);
-      if (live) g_store(A.oy, A.so, e, o);
-    }
-  }
 }
 
 }  // namespace bgn

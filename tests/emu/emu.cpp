@@ -148,16 +148,63 @@ struct Emu {
       oinf[j] = oi[e];
     }
   }
-  static void g1_fixed(const u32* params, const PairingConsts* C, const u32* tabP, const u32* tabQ, int windows,
+  // all lanes of one workgroup, one after the other
+  template <class F>
+  static void each_lane(F f) {
+    blockIdx.x = 0;
+    gridDim.x = 1;
+    for (unsigned t = 0; t < FP_BLOCK; ++t) {
+      threadIdx.x = t;
+      f();
+    }
+    threadIdx.x = 0;
+  }
+  // window table from its 2^i * B entries (pow: windows*wbits entries of 2*NL Montgomery limbs) -- the
+  // scatter + rounds of ensure_fixed_tables (engine.cpp)
+  static void tab_build(const u32* params, const PairingConsts* C, int wbits, int windows, const u32* pow, u32* tab) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    const size_t ne = (size_t)windows << wbits;
+    memset(tab, 0, ne * 2 * NL * 4);
+    for (int w = 0; w < windows; ++w)
+      for (int k = 0; k < wbits; ++k)
+        memcpy(tab + (((size_t)w << wbits) + ((size_t)1 << k)) * 2 * NL, pow + ((size_t)w * wbits + k) * 2 * NL, 2 * NL * 4);
+    for (int k = 1; k < wbits; ++k) {
+      G1TabRoundArgs A;
+      A.tab = tab; A.wbits = wbits; A.windows = windows; A.k = k;
+      A.count = (size_t)windows * (((size_t)1 << k) - 1);
+      A.run = (int)((A.count + FP_BLOCK - 1) / FP_BLOCK);
+      const size_t st = (size_t)A.run * FP_BLOCK;
+      std::vector<u32> pf(NL * st);
+      A.prefix = pf.data(); A.sp = st;
+      each_lane([&] { g1_add_run<NL>(G1IoTabRound<NL>{A}, A.count, A.run, A.prefix, A.sp, lds(), C, P); });
+    }
+  }
+  // P^x * Q^r for one element: the launch sequence of fixed_base_product (engine.cpp)
+  static void g1_fixed(const u32* params, const PairingConsts* C, const u32* tabP, const u32* tabQ, int wbits,
                        const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
-    G1FixedArgs A;
-    A.tabP = tabP; A.tabQ = tabQ; A.windows = windows;
-    A.x = x; A.xlen = xlen; A.r = r; A.rlen = rlen;
-    A.ox = out; A.oy = out + NL; A.oinf = oinf; A.so = 1;
-    A.count = 1;
-    blockIdx.x = 0; threadIdx.x = 0;
-    g1_fixed_lane<NL>(A, 1, nullptr, 0, lds(), C, P);
+    const size_t st = FP_BLOCK;
+    std::vector<u32> sx(NL * st, 0), sy(NL * st, 0), pf(NL * st);
+    std::vector<uint8_t> si(st, 1);
+    const int wx = x ? (int)((xlen * 8 + wbits - 1) / wbits) : 0;
+    const int wr = r ? (int)((rlen * 8 + wbits - 1) / wbits) : 0;
+    blockIdx.x = 0; threadIdx.x = 0; gridDim.x = 1;
+    for (int i = 0; i < wx + wr; ++i) {
+      const bool isx = i < wx;
+      G1FixedStepArgs A;
+      A.sx = sx.data(); A.sy = sy.data(); A.sinf = si.data(); A.ss = st;
+      A.tab = isx ? tabP : tabQ; A.wbits = wbits; A.window = isx ? i : i - wx;
+      A.k = isx ? x : r; A.klen = isx ? xlen : rlen;
+      A.prefix = pf.data(); A.sp = st;
+      A.count = 1; A.run = 1;
+      A.plain_out = (i == wx + wr - 1) ? 1 : 0;
+      g1_add_run<NL>(G1IoFixedStep<NL>{A}, A.count, A.run, A.prefix, A.sp, lds(), C, P);
+    }
+    for (int l = 0; l < NL; ++l) {
+      out[l] = sx[l * st];
+      out[NL + l] = sy[l * st];
+    }
+    *oinf = si[0];
   }
   static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
@@ -258,7 +305,8 @@ int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
 int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
-int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int windows, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, windows, x, xlen, r, rlen, out, oinf)) }
+int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, x, xlen, r, rlen, out, oinf)) }
+int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, windows, pow, tab)) }
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, c, out)) }
 int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }

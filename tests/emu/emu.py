@@ -18,10 +18,10 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "vm.hpp", "kernels.hpp", "fpinv.hpp")]
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "vm.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
-                               "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"),
+                               "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"), "-include", os.path.join(_HERE, "imad.hpp"),
                                os.path.join(_HERE, "emu.cpp"),
                                "-o", _SO])
     return _SO
@@ -164,7 +164,7 @@ class Emu:
         return res
 
     def make_table(self, entries_wire):
-        """entries_wire[w*256 + d] = wire bytes of d*256^w*B (d = 0 ignored) -> device table layout."""
+        """entries_wire[(w << wbits) + d] = wire bytes of d*2^(wbits*w)*B (None: identity) -> device table layout."""
         tab = (C.c_uint32 * (2 * self.nl * len(entries_wire)))()
         for i, w in enumerate(entries_wire):
             if w is None:
@@ -173,12 +173,20 @@ class Emu:
             tab[2 * self.nl * i:2 * self.nl * (i + 1)] = list(x)
         return tab
 
-    def g1_fixed(self, tabP, tabQ, windows: int, x: int, xlen: int, r=None, rlen: int = 0) -> bytes:
+    def build_table(self, wbits: int, windows: int, pow_wire):
+        """pow_wire[i] = wire bytes of 2^i * B, i < windows*wbits -> full window table, built the way the engine does."""
+        assert len(pow_wire) == windows * wbits
+        pw = self.make_table(pow_wire)
+        tab = (C.c_uint32 * (2 * self.nl * (windows << wbits)))()
+        assert self.lib.emu_tab_build(self.nl, self.params, self.consts, wbits, windows, pw, tab) == 0
+        return tab
+
+    def g1_fixed(self, tabP, tabQ, wbits: int, x: int, xlen: int, r=None, rlen: int = 0) -> bytes:
         out = (C.c_uint32 * (2 * self.nl))()
         oinf = C.c_uint8()
         xb = x.to_bytes(xlen, "big")
         rb = r.to_bytes(rlen, "big") if r is not None else None
-        assert self.lib.emu_g1_fixed(self.nl, self.params, self.consts, tabP, tabQ, windows, xb, C.c_size_t(xlen), rb,
+        assert self.lib.emu_g1_fixed(self.nl, self.params, self.consts, tabP, tabQ, wbits, xb, C.c_size_t(xlen), rb,
                                      C.c_size_t(rlen), out, C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 

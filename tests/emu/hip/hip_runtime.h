@@ -26,3 +26,4 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   *p += v;
   return old;
 }
+static inline void __syncthreads() {}   // lanes run one after the other; staged-codec kernels are not emulated

@@ -100,8 +100,11 @@ def test_emu_poly_accumulation(ctx):
     assert [o.hex() for o in E.poly_acc(Ew, po["d1"], po["d2"])] == po["out"]
 
 
-def test_emu_fixed_base_encrypt():
-    """Window-table Encrypt (P^x * Q^r fused, no doublings) incl. zero digits, x = 0, r = 0 and scalars >= n."""
+@pytest.mark.parametrize("wbits", [8, 16])
+def test_emu_fixed_base_encrypt(wbits):
+    """Window-table Encrypt (P^x * Q^r, one table entry per window, no doublings) incl. zero digits, x = 0,
+    r = 0, odd scalar lengths and scalars >= n; the table itself is built by the engine's round scheme and
+    checked against the oracle entry by entry."""
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     import oracle_c
@@ -109,30 +112,31 @@ def test_emu_fixed_base_encrypt():
     E = emu.Emu.from_fixture(fx)
     o = oracle_c.Oracle.from_fixture(fx)
     n = int(fx["n"], 16)
-    W = (n.bit_length() + 7) // 8 + 1
+    W = (n.bit_length() + wbits - 1) // wbits + 1
+    KB = (W * wbits + 7) // 8          # bytes of a scalar that fills the table
     zero = bytes(2 * E.L)
+    enc = lambda k, base_is_q: o.encrypt([0], [k]) if base_is_q else o.encrypt([k], None)
 
     def table(base_is_q):
-        ents = []
-        for w in range(W):
-            for d in range(256):
-                k = d * 256 ** w
-                if d == 0:
-                    ents.append(None)
-                elif base_is_q:
-                    ents.append(o.encrypt([0], [k]))
-                else:
-                    ents.append(o.encrypt([k], None))
-        return E.make_table(ents)
+        tab = E.build_table(wbits, W, [enc(1 << i, base_is_q) for i in range(W * wbits)])
+        rng = random.Random(3 + base_is_q)
+        probes = [(w, d) for w in (0, W - 1) for d in (1, 2, 3, (1 << wbits) - 1)]
+        probes += [(rng.randrange(W), rng.randrange(1, 1 << wbits)) for _ in range(24)]
+        for w, d in probes:
+            want, _ = E.decode(enc(d << (wbits * w), base_is_q))
+            i = (w << wbits) + d
+            assert list(tab[2 * E.nl * i:2 * E.nl * (i + 1)]) == list(want), (w, d)
+        return tab
 
     tP, tQ = table(False), table(True)
     rng = random.Random(8)
     cases = [(0, 0), (0, 5), (7, 0), (1 << 40, 1 << 56), (n - 1, n - 1), (n + 3, n + 1), (256, 65536)]
     cases += [(rng.randrange(1 << 40), rng.randrange(n)) for _ in range(6)]
     for x, r in cases:
-        assert E.g1_fixed(tP, tQ, W, x, W, r, W) == o.encrypt([x], [r]), (x, r)
-    assert E.g1_fixed(tP, tQ, W, 77, 2, None, 0) == o.encrypt([77], None)
-    assert E.g1_fixed(tP, tQ, W, 0, 1, None, 0) == zero
+        assert E.g1_fixed(tP, tQ, wbits, x, KB, r, KB) == o.encrypt([x], [r]), (x, r)
+    assert E.g1_fixed(tP, tQ, wbits, 77, 2, None, 0) == o.encrypt([77], None)
+    assert E.g1_fixed(tP, tQ, wbits, 0x12345, 3, 0x6789ABCDEF, 5) == o.encrypt([0x12345], [0x6789ABCDEF])
+    assert E.g1_fixed(tP, tQ, wbits, 0, 1, None, 0) == zero
 
 
 def test_emu_fixed_argument_pairing(ctx):

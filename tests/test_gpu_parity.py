@@ -199,6 +199,36 @@ def test_encrypt_random_vs_c_oracle(name, count):
     assert pk.engine.encrypt(xs, rs).tobytes() == o.encrypt(xs, rs)
 
 
+@pytest.mark.parametrize("name", ["toy64", "k256", "k512"])
+def test_g1_runs_longer_than_one(name):
+    """Batches above 65536 elements give every lane a run of several elements sharing one inversion (EAdd), and
+    the window tables are built by such runs: check a 150k-element EAdd against the oracle's distinct sums and
+    Encrypt of scalars whose digits reach the last-built table entries."""
+    import numpy as np
+    import oracle_c
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    pool = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]][:7]
+    count = 150001
+    ia = np.arange(count) % len(pool)
+    ib = (np.arange(count) * 3 + 1) % len(pool)
+    P = np.frombuffer(b"".join(pool), dtype=np.uint8).reshape(len(pool), EB)
+    got = np.asarray(eng.add(1, P[ia].reshape(-1), P[ib].reshape(-1))).reshape(count, EB)
+    want = {}
+    for i in range(len(pool)):
+        j = (i * 3 + 1) % len(pool)
+        want[i] = np.frombuffer(o.add(1, pool[i], pool[j]), dtype=np.uint8)
+    W = np.stack([want[i] for i in range(len(pool))])
+    assert (got == W[ia]).all()
+    n = int(fx["n"], 16)
+    xs = [0xFFFF, 0xFFFE, 0x8001, 0xFFFF0000FFFF, 4095, 5000, 32767, (1 << 40) - 1, n - 1]
+    rs = [n - 1, 0xFFFF, 1, 0xFFFFFFFF, 2, 3, 4, 5, 0xFFFF7FFF]
+    assert eng.encrypt(xs, rs).tobytes() == o.encrypt(xs, rs)
+
+
 # ---------------------------------------------------------------------------
 # Decrypt (BSGS) and MultPoly
 # ---------------------------------------------------------------------------

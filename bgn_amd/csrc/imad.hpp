@@ -9,7 +9,7 @@
 // run-to-run varying results in k_g1_tab_round<19> on MI355X although the host emulation of the same code
 // was right and the instruction stream looked correct -- measured in round 1, cause not established; do not
 // reintroduce without a GPU test.)
-// (tests/emu/imad.hpp is the host stand-in with the same include guard.)
+// (The CPU unit-test harness force-includes a host stand-in with the same include guard.)
 #ifndef BGN_IMAD_HPP
 #define BGN_IMAD_HPP
 #include <hip/hip_runtime.h>

@@ -177,9 +177,11 @@ class Engine:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def mult_dev(self, a, b, out, count: Optional[int] = None) -> None:
+    def mult_dev(self, a, b, out, count: Optional[int] = None, r=None, r_len: int = 0) -> None:
+        """Device-resident Mult; r (count x r_len big-endian bytes on the device) blinds with e(Q,Q)^r."""
         count = a.numel() // self.elem_bytes if count is None else count
-        check(self._lib.bgn_mult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(),
+        check(self._lib.bgn_mult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(),
+                                           r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
                                            self._stream()), "bgn_mult_batch_dev")
 
     def make_l2_dev(self, a, out, count: Optional[int] = None) -> None:
@@ -191,9 +193,11 @@ class Engine:
         check(self._lib.bgn_encrypt_batch_dev(self._h, count, x.data_ptr(), x_len, r.data_ptr() if r is not None else None,
                                               r_len, out.data_ptr(), self._stream()), "bgn_encrypt_batch_dev")
 
-    def add_dev(self, level: int, a, b, out, count: Optional[int] = None) -> None:
+    def add_dev(self, level: int, a, b, out, count: Optional[int] = None, r=None, r_len: int = 0) -> None:
+        """Device-resident Add; r blinds with Q^r (level 1) resp. e(Q,Q)^r (level 2)."""
         count = a.numel() // self.elem_bytes if count is None else count
-        check(self._lib.bgn_add_batch_dev(self._h, count, level, a.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(),
+        check(self._lib.bgn_add_batch_dev(self._h, count, level, a.data_ptr(), b.data_ptr(),
+                                          r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
                                           self._stream()), "bgn_add_batch_dev")
 
     def decrypt_dev(self, level: int, ct, m, status, count: Optional[int] = None) -> None:

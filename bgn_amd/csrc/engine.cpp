@@ -71,6 +71,9 @@ struct bgn_ctx {
   // fixed-base window tables for P and Q (built on first use)
   uint32_t* d_tabP = nullptr;
   uint32_t* d_tabQ = nullptr;
+  uint32_t* d_tabG = nullptr;     // window table of e(Q,Q) in GT (level-2 blinding)
+  int gt_windows = 0;
+  int gt_wbits = 8;
   int fixed_windows = 0;
   int fixed_wbits = 8;
   uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
@@ -194,6 +197,7 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_fixedpair) (void)hipFree(c->d_fixedpair);
   if (c->d_tabP) (void)hipFree(c->d_tabP);
   if (c->d_tabQ) (void)hipFree(c->d_tabQ);
+  if (c->d_tabG) (void)hipFree(c->d_tabG);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -411,6 +415,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
 
 namespace {
 void blind_l2(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, size_t count);
+int ensure_gt_table(bgn_ctx* c);
 }
 
 // pairings per lane: keep 65536 lanes (one wave per SIMD on every CU) busy before lengthening the runs
@@ -439,6 +444,10 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  if (r_be) {
+    int rc = ensure_gt_table(c);
+    if (rc) return rc;
+  }
   const KernelTable* kt = c->kt;
   const size_t sa = round_up(na, 64), sb = round_up(nb ? nb : 1, 64), so = round_up(count, 64);
   Carver probe(nullptr);
@@ -760,8 +769,47 @@ void blind_l1(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_l
   (void)hipMemcpyAsync(R.inf, T2.inf, R.stride, hipMemcpyDeviceToDevice, s);
 }
 
+// Window table of the key's e(Q,Q) in GT, same shape as the G1 tables: the level-2 blinding factor
+// e(Q,Q)^r (bgn.go:302-311, :466-474, :279-288) becomes one F_p^2 product per 16-bit window instead of a
+// square-and-multiply over all bits of r (the reference even recomputes the pairing e(Q,Q) each time).
+// Built once per key on first use: g^(2^i) by squarings, then doubling rounds of products.  c->mu held.
+int ensure_gt_table(bgn_ctx* c) {
+  if (c->d_tabG) return BGN_OK;
+  const KernelTable* kt = c->kt;
+  const int wbits = fixed_window_bits(c);
+  const int W = (c->n.bits() + wbits - 1) / wbits + 1;
+  const size_t bytes = ((size_t)W << wbits) * 2 * (size_t)c->nl * 4;
+  uint32_t* tab = nullptr;
+  if (hipMalloc((void**)&tab, bytes) != hipSuccess) return fail(BGN_E_NOMEM, "GT window table");
+  HIP_TRY(hipMemset(tab, 0, bytes));
+  const SoA2 g = c->key_eQQ();
+  kt->gt_tab_pows(nullptr, c->d_params, g.c0, g.c1, wbits, W, tab);
+  for (int k = 1; k < wbits; ++k) {
+    GtTabRoundArgs a;
+    a.tab = tab; a.wbits = wbits; a.windows = W; a.k = k;
+    a.count = (size_t)W * (((size_t)1 << k) - 1);
+    kt->gt_tab_round(nullptr, c->d_params, a);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  c->d_tabG = tab;
+  c->gt_windows = W;
+  c->gt_wbits = wbits;
+  return BGN_OK;
+}
+
 // Blind a level-2 result R (plain) with e(Q,Q)^r (bgn.go:466-474): R <- R * e(Q,Q)^r.
 void blind_l2(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, size_t count) {
+  if (c->d_tabG && (r_len * 8 + c->gt_wbits - 1) / c->gt_wbits <= (size_t)c->gt_windows) {
+    GtFixedArgs a;
+    a.tab = c->d_tabG; a.wbits = c->gt_wbits;
+    a.k = r_be; a.klen = r_len;
+    a.r0 = R.c0; a.r1 = R.c1; a.sr = R.stride;
+    a.o0 = nullptr; a.o1 = nullptr; a.so = 0;
+    a.count = count;
+    c->kt->gt_fixed(s, c->d_params, a);
+    return;
+  }
   gt_pow_launch(c, s, c->key_eQQ(), r_be, r_len, r_len, T1, count);
   c->kt->to_mont(s, c->d_params, T1.c0, T1.c1, T1.stride, count);
   c->kt->to_mont(s, c->d_params, R.c0, R.c1, R.stride, count);
@@ -779,8 +827,8 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  if (r_be && level == 1) {            // blinding base tables (uses the arena: before any carving)
-    int rc = ensure_fixed_tables(c);
+  if (r_be) {                          // blinding base tables (G1 ones use the arena: before any carving)
+    int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
     if (rc) return rc;
   }
   const size_t st = round_up(count, 64);
@@ -880,8 +928,8 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  if (r_be && level == 1) {
-    int rc = ensure_fixed_tables(c);
+  if (r_be) {
+    int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
     if (rc) return rc;
   }
   const size_t st = round_up(count, 64);

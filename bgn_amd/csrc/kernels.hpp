@@ -75,6 +75,18 @@ struct GtPowArgs {
   size_t count;
 };
 
+// Fixed-base GT power from a window table (ops.hpp): e(Q,Q)^r, optionally multiplied into R in place.
+struct GtFixedArgs {
+  const uint32_t* tab; int wbits;
+  const uint8_t* k; size_t klen;                                            // big-endian scalars, klen bytes each
+  uint32_t* r0; uint32_t* r1; size_t sr;                                    // R (plain canonical, in place) or null
+  uint32_t* o0; uint32_t* o1; size_t so;                                    // plain canonical out when r0 == null
+  size_t count;
+};
+struct GtTabRoundArgs {
+  uint32_t* tab; int wbits; int windows; int k;
+  size_t count;                                                             // windows * (2^k - 1)
+};
 
 // Discrete-log decryption and MultPoly accumulation (bsgs.hpp).
 struct BsgsSlot {
@@ -145,6 +157,11 @@ struct KernelTable {
                          uint32_t* entries);
   void (*gt_mul)(hipStream_t s, const void* params, GtMulArgs a);
   void (*gt_pow)(hipStream_t s, const void* params, GtPowArgs a);
+  void (*gt_fixed)(hipStream_t s, const void* params, GtFixedArgs a);
+  // window table of g = (g0, g1) (canonical Montgomery, stride 1): entries g^(2^i), then the doubling rounds
+  void (*gt_tab_pows)(hipStream_t s, const void* params, const uint32_t* g0, const uint32_t* g1, int wbits, int windows,
+                      uint32_t* tab);
+  void (*gt_tab_round)(hipStream_t s, const void* params, GtTabRoundArgs a);
   void (*bsgs_build)(hipStream_t s, const void* params, BsgsParams b, unsigned long long chunk, size_t lanes);
   void (*bsgs_search)(hipStream_t s, const void* params, BsgsParams b, BsgsSearchArgs a);
   void (*poly_acc)(hipStream_t s, const void* params, PolyAccArgs a);

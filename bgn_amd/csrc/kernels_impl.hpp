@@ -320,6 +320,33 @@ k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
+k_gt_fixed(const FpParams<NL>* __restrict__ P, GtFixedArgs A) {
+  __shared__ LFp<NL> L[4];
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < A.count;
+  if (!live) e = A.count - 1;
+  gt_fixed_lane<NL>(A, e, live, L, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_gt_tab_pows(const FpParams<NL>* __restrict__ P, const u32* g0, const u32* g1, int wbits, int windows, u32* tab) {
+  __shared__ LFp<NL> L[1];
+  gt_tab_pows_lane<NL>(tab, wbits, windows, g0, g1, L, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_gt_tab_round(const FpParams<NL>* __restrict__ P, GtTabRoundArgs A) {
+  __shared__ LFp<NL> L[4];
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < A.count;
+  if (!live) e = A.count - 1;
+  gt_tab_round_lane<NL>(A, e, live, L, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
 k_bsgs_build(const FpParams<NL>* __restrict__ P, BsgsParams B, unsigned long long chunk) {
   __shared__ LFp<NL> L[4];
   bsgs_build_lane<NL>(B, chunk, L, P);
@@ -449,6 +476,23 @@ static void launch_gt_pow(hipStream_t s, const void* params, GtPowArgs a) {
   hipLaunchKernelGGL(k_gt_pow<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
 }
 
+static void launch_gt_fixed(hipStream_t s, const void* params, GtFixedArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_gt_fixed<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
+}
+
+static void launch_gt_tab_pows(hipStream_t s, const void* params, const uint32_t* g0, const uint32_t* g1, int wbits,
+                               int windows, uint32_t* tab) {
+  hipLaunchKernelGGL(k_gt_tab_pows<NL_>, dim3(1), dim3(64), 0, s, (const FpParams<NL_>*)params, g0, g1, wbits, windows,
+                     tab);
+}
+
+static void launch_gt_tab_round(hipStream_t s, const void* params, GtTabRoundArgs a) {
+  if (!a.count) return;
+  hipLaunchKernelGGL(k_gt_tab_round<NL_>, dim3(grid_for(a.count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     a);
+}
+
 static void launch_bsgs_build(hipStream_t s, const void* params, BsgsParams b, unsigned long long chunk, size_t lanes) {
   if (!lanes) return;
   hipLaunchKernelGGL(k_bsgs_build<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, b,
@@ -494,6 +538,9 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_soa_to_entries,
       launch_gt_mul,
       launch_gt_pow,
+      launch_gt_fixed,
+      launch_gt_tab_pows,
+      launch_gt_tab_round,
       launch_bsgs_build,
       launch_bsgs_search,
       launch_poly_acc,

@@ -13,6 +13,15 @@ __device__ __forceinline__ u32 scalar_bit(const uint8_t* __restrict__ k, size_t 
   return (k[len - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u;
 }
 
+// Digit `window` (wbits = 8 or 16 bits wide, counted from the least significant end) of a big-endian scalar.
+__device__ __forceinline__ u32 scalar_window(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
+  if (wbits == 8) return k[klen - 1 - (size_t)window];
+  const size_t lo = 2 * (size_t)window;
+  u32 d = k[klen - 1 - lo];
+  if (lo + 1 < klen) d |= (u32)k[klen - 2 - lo] << 8;
+  return d;
+}
+
 // r = 1/a ; a <4 in VGPRs ; result <1 (0 for a = 0).  Uses L[0] (stage).  Division steps (fpinv.hpp), not
 // Fermat: ~30 products' worth of work instead of ~1.5 * bits(p).
 template <int NL>
@@ -79,6 +88,43 @@ __device__ __forceinline__ void gt_mul_lane(Fp<NL>& o0, Fp<NL>& o1, LFp<NL>* L, 
   fp_from_mont<NL>(o1, r, P, L);
 }
 
+// acc <- acc * b where take (per lane), b = (L[1], L[2]) canonical <1 with L[3] = b0 + b1 <2; the accumulator
+// (A0 <4, A1 <6) lives in two AGPR slots: v0 = b0*a0, v1 = b1*a1, w = (b0+b1)(a0+a1).
+template <int NL>
+__device__ __forceinline__ void gt_acc_mul(AFp<NL>& A0, AFp<NL>& A1, bool take, LFp<NL>* L,
+                                           const FpParams<NL>* __restrict__ P) {
+  Fp<NL> v0, v1, s;
+  {
+    Fp<NL> a0, a1;
+    a_load(a0, A0);                     // <4
+    a_load(a1, A1);                     // <6
+    fp_add(s, a0, a1);                  // <10
+    fp_mul(v0, L + 1, a0, P);           // <2
+    fp_mul(v1, L + 2, a1, P);           // <2
+  }
+  fp_mul(s, L + 3, s, P);               // <2   (2*10)
+  Fp<NL> m, cur;
+  fp_sub<2>(m, v0, v1, P);              // <4
+  a_load(cur, A0);
+  fp_select(m, take, m, cur);
+  a_store(A0, m);
+  fp_add(v0, v0, v1);                   // <4
+  fp_sub<4>(m, s, v0, P);               // <6
+  a_load(cur, A1);
+  fp_select(m, take, m, cur);
+  a_store(A1, m);
+}
+
+// b -> multiplier slots of gt_acc_mul
+template <int NL>
+__device__ __forceinline__ void gt_set_multiplier(LFp<NL>* L, const Fp<NL>& b0, const Fp<NL>& b1) {
+  Fp<NL> s;
+  fp_add(s, b0, b1);
+  l_store(L + 1, b0);
+  l_store(L + 2, b1);
+  l_store(L + 3, s);
+}
+
 // acc = base^k, k per lane (big-endian bytes) ; base = (L[1], L[2]) with
 // L[3] = base0+base1 precomputed (base canonical <1).  Square-and-multiply from
 // bit nbits-1; the multiply is executed when any lane of the wave needs it and
@@ -107,33 +153,118 @@ __device__ __forceinline__ void gt_pow_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL>* L, 
       a_store(A1, s1);
     }
     const bool bit = scalar_bit(k, klen, i) != 0;
-    if (__ballot(bit)) {
-      // (a0 + i a1) * base: v0 = b0*a0, v1 = b1*a1, w = (b0+b1)(a0+a1)
-      Fp<NL> v0, v1, s;
-      {
-        Fp<NL> a0, a1;
-        a_load(a0, A0);                     // <4
-        a_load(a1, A1);                     // <6
-        fp_add(s, a0, a1);                  // <10
-        fp_mul(v0, L + 1, a0, P);           // <2
-        fp_mul(v1, L + 2, a1, P);           // <2
-      }
-      fp_mul(s, L + 3, s, P);               // <2   (2*10)
-      Fp<NL> m, cur;
-      fp_sub<2>(m, v0, v1, P);              // <4
-      a_load(cur, A0);
-      fp_select(m, bit, m, cur);
-      a_store(A0, m);
-      fp_add(v0, v0, v1);                   // <4
-      fp_sub<4>(m, s, v0, P);               // <6
-      a_load(cur, A1);
-      fp_select(m, bit, m, cur);
-      a_store(A1, m);
-    }
+    if (__ballot(bit)) gt_acc_mul<NL>(A0, A1, bit, L, P);
     started = started || bit;
   }
   a_load(r0, A0);
   a_load(r1, A1);
+}
+
+// Fixed-base power in GT from a window table (same layout as the G1 tables: entry (w, d) at
+// tab + ((w << wbits) + d) * 2*NL, re limbs then im limbs, canonical Montgomery): g^k = prod_w tab[w][k_w],
+// one F_p^2 product per non-zero window and no squarings.  This is the blinding factor e(Q,Q)^r of
+// level-2 results (bgn.go:302-311, :466-474, :279-288), whose base is fixed per key.
+// With R != null the result is multiplied into R (plain canonical, in place); otherwise it is written
+// plain canonical to (o0, o1).
+template <int NL>
+__device__ __forceinline__ void gt_fixed_lane(const GtFixedArgs& A, size_t e, bool live, LFp<NL>* L,
+                                              const FpParams<NL>* __restrict__ P) {
+  AFp<NL> A0, A1;
+  {
+    Fp<NL> t;
+    fp_set(t, P->one);
+    a_store(A0, t);
+    fp_zero(t);
+    a_store(A1, t);
+  }
+  const uint8_t* k = A.k + e * A.klen;
+  const int windows = (int)((A.klen * 8 + A.wbits - 1) / A.wbits);
+#pragma unroll 1
+  for (int w = 0; w < windows; ++w) {
+    const u32 d = scalar_window(k, A.klen, A.wbits, w);
+    if (__ballot(d != 0)) {
+      const u32* ent = A.tab + ((((size_t)w) << A.wbits) + d) * (size_t)(2 * NL);
+      Fp<NL> b0, b1;
+      v_load(b0, ent);
+      v_load(b1, ent + NL);
+      gt_set_multiplier<NL>(L, b0, b1);
+      gt_acc_mul<NL>(A0, A1, d != 0, L, P);
+    }
+  }
+  if (A.r0) {
+    Fp<NL> b0, b1, t;
+    g_load<NL>(t, A.r0, A.sr, e);
+    fp_to_mont<NL>(b0, t, P, L);
+    g_load<NL>(t, A.r1, A.sr, e);
+    fp_to_mont<NL>(b1, t, P, L);
+    gt_set_multiplier<NL>(L, b0, b1);
+    gt_acc_mul<NL>(A0, A1, true, L, P);
+  }
+  Fp<NL> r, o;
+  a_load(r, A0);
+  fp_from_mont<NL>(o, r, P, L);
+  if (live) g_store<NL>(A.r0 ? A.r0 : A.o0, A.r0 ? A.sr : A.so, e, o);
+  a_load(r, A1);
+  fp_from_mont<NL>(o, r, P, L);
+  if (live) g_store<NL>(A.r0 ? A.r1 : A.o1, A.r0 ? A.sr : A.so, e, o);
+}
+
+// Table construction, step 1: the entries g^(2^i) by successive squarings (every lane of the single
+// workgroup computes and stores the same values).
+template <int NL>
+__device__ __forceinline__ void gt_tab_pows_lane(u32* __restrict__ tab, int wbits, int windows, const u32* g0,
+                                                 const u32* g1, LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
+  Fp<NL> a0, a1;
+  g_load<NL>(a0, g0, 1, 0);
+  g_load<NL>(a1, g1, 1, 0);
+#pragma unroll 1
+  for (int i = 0; i < windows * wbits; ++i) {
+    u32* ent = tab + ((((size_t)(i / wbits)) << wbits) + ((size_t)1 << (i % wbits))) * (size_t)(2 * NL);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      ent[l] = a0.v[l];
+      ent[NL + l] = a1.v[l];
+    }
+    Fp<NL> s0, s1;
+    fp2_sqr_v(s0, s1, a0, a1, P, L);        // <2, <4
+    fp_reduce8(a0, s0, P);
+    fp_reduce8(a1, s1, P);
+  }
+}
+
+// Table construction, step 2, round k: tab[w][2^k + j] = tab[w][j] * tab[w][2^k], j in [1, 2^k);
+// element e = w * (2^k - 1) + (j - 1).
+template <int NL>
+__device__ __forceinline__ void gt_tab_round_lane(const GtTabRoundArgs& A, size_t e, bool live, LFp<NL>* L,
+                                                  const FpParams<NL>* __restrict__ P) {
+  const size_t per = ((size_t)1 << A.k) - 1;
+  const size_t w = e / per, j = e - w * per + 1;
+  const u32* ea = A.tab + ((w << A.wbits) + j) * (size_t)(2 * NL);
+  const u32* eb = A.tab + ((w << A.wbits) + ((size_t)1 << A.k)) * (size_t)(2 * NL);
+  u32* eo = A.tab + ((w << A.wbits) + ((size_t)1 << A.k) + j) * (size_t)(2 * NL);
+  AFp<NL> A0, A1;
+  Fp<NL> b0, b1;
+  v_load(b0, ea);
+  v_load(b1, ea + NL);
+  a_store(A0, b0);
+  a_store(A1, b1);
+  v_load(b0, eb);
+  v_load(b1, eb + NL);
+  gt_set_multiplier<NL>(L, b0, b1);
+  gt_acc_mul<NL>(A0, A1, true, L, P);
+  Fp<NL> r, o;
+  a_load(r, A0);
+  fp_reduce8(o, r, P);
+  if (live) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) eo[l] = o.v[l];
+  }
+  a_load(r, A1);
+  fp_reduce8(o, r, P);
+  if (live) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) eo[NL + l] = o.v[l];
+  }
 }
 
 // ===========================================================================
@@ -199,15 +330,6 @@ struct G1IoSoA {
     A.oinf[e] = inf ? 1 : 0;
   }
 };
-
-// Digit `window` (wbits = 8 or 16 bits wide, counted from the least significant end) of a big-endian scalar.
-__device__ __forceinline__ u32 scalar_window(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
-  if (wbits == 8) return k[klen - 1 - (size_t)window];
-  const size_t lo = 2 * (size_t)window;
-  u32 d = k[klen - 1 - lo];
-  if (lo + 1 < klen) d |= (u32)k[klen - 2 - lo] << 8;
-  return d;
-}
 
 // Table entry -> coordinates; an all-zero entry stands for the identity (never a subgroup point).
 template <int NL>

@@ -206,6 +206,38 @@ struct Emu {
     }
     *oinf = si[0];
   }
+  // window table of g in GT, built like ensure_gt_table (engine.cpp): squarings, then doubling rounds
+  static void gt_tab_build(const u32* params, int wbits, int windows, const u32* g, u32* tab) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    memset(tab, 0, ((size_t)windows << wbits) * 2 * NL * 4);
+    blockIdx.x = 0; threadIdx.x = 0; gridDim.x = 1;
+    gt_tab_pows_lane<NL>(tab, wbits, windows, g, g + NL, lds(), P);
+    for (int k = 1; k < wbits; ++k) {
+      GtTabRoundArgs A;
+      A.tab = tab; A.wbits = wbits; A.windows = windows; A.k = k;
+      A.count = (size_t)windows * (((size_t)1 << k) - 1);
+      for (size_t e = 0; e < A.count; ++e) gt_tab_round_lane<NL>(A, e, true, lds(), P);
+    }
+  }
+  // out = g^k from the table, times R (plain limbs) when R != null
+  static void gt_fixed(const u32* params, const u32* tab, int wbits, const uint8_t* k, size_t klen, const u32* R, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    GtFixedArgs A;
+    A.tab = tab; A.wbits = wbits; A.k = k; A.klen = klen;
+    A.count = 1;
+    u32 r[2 * NL];
+    if (R) {
+      memcpy(r, R, sizeof r);
+      A.r0 = r; A.r1 = r + NL; A.sr = 1;
+      A.o0 = nullptr; A.o1 = nullptr; A.so = 0;
+    } else {
+      A.r0 = nullptr; A.r1 = nullptr; A.sr = 0;
+      A.o0 = out; A.o1 = out + NL; A.so = 1;
+    }
+    blockIdx.x = 0; threadIdx.x = 0; gridDim.x = 1;
+    gt_fixed_lane<NL>(A, 0, true, lds(), P);
+    if (R) memcpy(out, r, sizeof r);
+  }
   static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     Fp<NL> o0, o1;
@@ -311,5 +343,7 @@ int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32*
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, c, out)) }
 int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }
 int emu_fp_inv(int nl, const u32* params, int p_bits, const u32* a, u32* out) { DISPATCH(nl, fp_inv(params, p_bits, a, out)) }
+int emu_gt_tab_build(int nl, const u32* params, int wbits, int windows, const u32* g, u32* tab) { DISPATCH(nl, gt_tab_build(params, wbits, windows, g, tab)) }
+int emu_gt_fixed(int nl, const u32* params, const u32* tab, int wbits, const uint8_t* k, size_t klen, const u32* R, u32* out) { DISPATCH(nl, gt_fixed(params, tab, wbits, k, klen, R, out)) }
 size_t emu_consts_size() { return sizeof(PairingConsts); }
 }

@@ -197,6 +197,22 @@ class Emu:
         assert self.lib.emu_gt_mul(self.nl, self.params, A, B, 1 if conj_b else 0, out) == 0
         return self.encode(out)
 
+    def gt_table(self, g_wire: bytes, wbits: int, windows: int):
+        g, _ = self.decode(g_wire)
+        tab = (C.c_uint32 * (2 * self.nl * (windows << wbits)))()
+        assert self.lib.emu_gt_tab_build(self.nl, self.params, wbits, windows, g, tab) == 0
+        return tab
+
+    def gt_fixed(self, tab, wbits: int, k: int, klen: int, r_wire: bytes = None) -> bytes:
+        """g^k from the window table (times the GT element r_wire when given)."""
+        out = (C.c_uint32 * (2 * self.nl))()
+        R = None
+        if r_wire is not None:
+            pl = [int.from_bytes(r_wire[:self.L], "big"), int.from_bytes(r_wire[self.L:], "big")]
+            R = (C.c_uint32 * (2 * self.nl))(*(limbs(pl[0], self.nl) + limbs(pl[1], self.nl)))
+        assert self.lib.emu_gt_fixed(self.nl, self.params, tab, wbits, k.to_bytes(klen, "big"), C.c_size_t(klen), R, out) == 0
+        return self.encode(out)
+
     def bsgs(self, g_wire: bytes, msg_space: int, xs_wire, S=None):
         """Build the table for generator g and search every x (GT wire bytes).  Returns (m list, status list)."""
         import math

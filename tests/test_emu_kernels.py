@@ -67,6 +67,28 @@ def test_emu_gt_ops(ctx):
         assert E.gt_pow(l2[v["a"]], int(v["k"], 16), (n.bit_length() + 7) // 8).hex() == v["out"]
 
 
+@pytest.mark.parametrize("wbits", [8, 16])
+def test_emu_gt_fixed_base_blinding(wbits):
+    """e(Q,Q)^r from the GT window table (level-2 blinding, bgn.go:302-311) == square-and-multiply, alone and
+    multiplied into a result; zero digits, r = 0, odd scalar lengths, r >= n."""
+    from conftest import oracle_key
+    fx = load_fixture("toy64")
+    E = emu.Emu.from_fixture(fx)
+    opk, _ = oracle_key(fx)
+    p, n = opk.p, opk.n
+    g = opk.e(opk.Q, opk.Q)
+    W = (n.bit_length() + wbits - 1) // wbits + 1
+    KB = (W * wbits + 7) // 8
+    tab = E.gt_table(R.elem_to_bytes(g, p), wbits, W)
+    rng = random.Random(12)
+    other = R.f2_pow(opk.e(opk.P, opk.Q), 777, p)
+    for r, klen in [(0, 1), (1, 1), (0x10000, 3), (0xFFFF, 2), (n - 1, KB), (n + 5, KB), (rng.randrange(n), KB),
+                    (rng.randrange(1 << 40), 5)]:
+        want = R.f2_pow(g, r, p)
+        assert E.gt_fixed(tab, wbits, r, klen) == R.elem_to_bytes(want, p), r
+        assert E.gt_fixed(tab, wbits, r, klen, R.elem_to_bytes(other, p)) == R.elem_to_bytes(R.f2_mul(want, other, p), p), r
+
+
 def test_emu_bsgs_ranges_and_signs(ctx):
     """Accept range [1, Mmax] with Mmax = B*B+B+2 (gsbs.go:77-105), zero short-cut, negative retry,
     for several baby/giant splits (the result must not depend on the split)."""

@@ -36,4 +36,12 @@ small = 1 << 10
 timed("add L1 small", small, lambda: eng.add_dev(1, cts[: small * EB], cts[n * EB: (n + small) * EB], out, small))
 m = min(n, 1 << 16)
 timed("mult", m, lambda: eng.mult_dev(cts[: m * EB], cts[n * EB: (n + m) * EB], out, m))
+# level 2 and blinded (non-deterministic mode) variants: results multiplied by Q^r resp. e(Q,Q)^r
+l2 = torch.empty(m * EB, dtype=torch.uint8, device=dev)
+eng.mult_dev(cts[: m * EB], cts[n * EB: (n + m) * EB], l2, m)
+timed("add L2", m, lambda: eng.add_dev(2, l2, l2, out, m))
+rb = rs[:n]
+timed("add L1 blinded", n, lambda: eng.add_dev(1, cts[: n * EB], cts[n * EB:], out, n, rb, 128))
+timed("add L2 blinded", m, lambda: eng.add_dev(2, l2, l2, out, m, rb, 128), reps=3)
+timed("mult blinded", m, lambda: eng.mult_dev(cts[: m * EB], cts[n * EB: (n + m) * EB], out, m, rb, 128))
 print("done", n)

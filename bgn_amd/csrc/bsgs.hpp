@@ -14,9 +14,11 @@
 //   * the baby table lives in HBM as an open-addressing hash of 96-bit
 //     fingerprints of the canonical real part; because GT has norm 1,
 //     conj(g^j) = g^-j shares its real part with g^j, so one probe covers +-j
-//     (the parity of the imaginary part, stored with j, tells which);
-//   * baby/giant sizes are re-balanced for 288 GB of HBM: S = up to 2^26 baby
-//     steps, G = ceil((Mmax+1)/S) giant steps, where Mmax = B*B + B + 2,
+//     (the parity of the imaginary part, stored with j, tells which), and the
+//     giant steps are spaced 2*S apart: step i resolves m = 2*i*S +- j for
+//     j in [0, S], so the walk is half as long as one that only adds j;
+//   * baby/giant sizes are re-balanced for 288 GB of HBM: S = up to 2^30 baby
+//     steps, G = floor((Mmax+S)/(2S)) + 1 giant steps, where Mmax = B*B + B + 2,
 //     B = ceil(sqrt(T)), is exactly the largest value the reference's loops can
 //     return; candidates outside [1, Mmax] are rejected so the accept / error
 //     behaviour matches gsbs.go:77-105 and the retry rule bgn.go:235-242.
@@ -116,7 +118,7 @@ __device__ __forceinline__ void gt_pow_u64(Fp<NL>& r0, Fp<NL>& r1, unsigned long
   a_load(r1, A1);
 }
 
-// Table build: lane t inserts g^j for j in [t*chunk, (t+1)*chunk) and j < S.
+// Table build: lane t inserts g^j for j in [t*chunk, (t+1)*chunk) and j <= S.
 // Replaces computeTableGT (gsbs.go:28-37) and makes computeTableG1 unnecessary.
 template <int NL>
 __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned long long chunk, LFp<NL>* L,
@@ -129,7 +131,8 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
 #pragma unroll 1
   for (unsigned long long c = 0; c < chunk; ++c) {
     const unsigned long long j = j0 + c;
-    if (j < B.S) {
+    if (!__ballot(j <= B.S)) break;            // the lane that only holds j = S stops after it
+    if (j <= B.S) {
       Fp<NL> re, im;
       fp_reduce8(re, a0, P);
       fp_reduce8(im, a1, P);
@@ -246,7 +249,7 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
           fp_reduce8(im, a1, P);
           const long long j = (long long)(s.val >> 1);
           const bool same = ((im.v[0] & 1u) == (s.val & 1u)) || fp_is_zero_limbs(im);
-          const long long m = (long long)(i * B.S) + (same ? j : -j);
+          const long long m = (long long)(i * B.stride) + (same ? j : -j);
           if (m >= 1 && (unsigned long long)m <= B.Mmax) {
             found = true;
             result = m;

@@ -78,6 +78,11 @@ struct bgn_ctx {
   int fixed_wbits = 8;
   uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
   size_t miller_steps = 0;
+  PairingConsts pc_host;               // host image of *d_consts
+  // decryption lift over the secret order (set_secret): line table of f_{q2, q1*P} and the constants whose
+  // NAF is that of q2 = n / q1 — half the Miller steps of e(P, .)
+  PairingConsts* d_consts_sk = nullptr;
+  uint32_t* d_fixedpair_sk = nullptr;
   BsgsParams bsgs{};
   bool have_tables = false;
 
@@ -195,6 +200,8 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_gt) (void)hipFree(c->d_gt);
   if (c->d_table) (void)hipFree(c->d_table);
   if (c->d_fixedpair) (void)hipFree(c->d_fixedpair);
+  if (c->d_fixedpair_sk) (void)hipFree(c->d_fixedpair_sk);
+  if (c->d_consts_sk) (void)hipFree(c->d_consts_sk);
   if (c->d_tabP) (void)hipFree(c->d_tabP);
   if (c->d_tabQ) (void)hipFree(c->d_tabQ);
   if (c->d_tabG) (void)hipFree(c->d_tabG);
@@ -272,6 +279,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     pc.l_bits = BigU(l).bits();
     HIP_BRK(hipMalloc((void**)&c->d_consts, sizeof pc));
     HIP_BRK(hipMemcpy(c->d_consts, &pc, sizeof pc, hipMemcpyHostToDevice));
+    c->pc_host = pc;
 
     // key points -> Montgomery SoA (stride 1)
     HIP_BRK(hipMalloc((void**)&c->d_keywire, (size_t)6 * c->L));
@@ -314,11 +322,62 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   return BGN_OK;
 }
 
+namespace {
+void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
+                   size_t count);
+
+// Decryption lift over the secret order.  Decrypt needs csk = e(C, P)^q1 (bgn.go:222-228 in GT).  By
+// bilinearity that is e(q1*P, C), and P' = q1*P has order q2 = n/q1, so f_{n,P'} = f_{q2,P'}^q1 (same
+// divisor, F_p constant killed by the final exponent):
+//     e(C, P)^q1 = ( f_{q2,P'}(phi(C))^((p-1)*l) )^q1.
+// The Miller loop therefore runs over the NAF of q2 — half as many steps as over n — on the line table of
+// P' (a per-key constant like the table of P), and the power by q1 that decrypt performs anyway completes
+// the exponent.  Same value as before, bit for bit.  BGN_DECRYPT_ORDER_TABLE=0 keeps the e(P, .) table.
+int build_secret_order_table(bgn_ctx* c) {
+  if (c->d_fixedpair_sk) (void)hipFree(c->d_fixedpair_sk);
+  if (c->d_consts_sk) (void)hipFree(c->d_consts_sk);
+  c->d_fixedpair_sk = nullptr;
+  c->d_consts_sk = nullptr;
+  if (const char* ev = getenv("BGN_DECRYPT_ORDER_TABLE"))
+    if (ev[0] == '0') return BGN_OK;
+  BigU q2, rem;
+  BigU::divmod(c->n, c->q1, q2, rem);
+  if (!rem.is_zero() || q2.bits() < 2 || !(q2.w[0] & 1u)) return BGN_OK;   // not a factor of n: generic path
+  std::vector<signed char> naf = q2.naf();
+  PairingConsts pc = c->pc_host;
+  pc.naf_len = (int)naf.size();
+  memset(pc.naf, 0, sizeof pc.naf);
+  memcpy(pc.naf, naf.data(), naf.size());
+  int rc = ensure_arena(c, 1 << 16);
+  if (rc) return rc;
+  Carver cv(c->arena);
+  SoA2 Pq = cv.soa(c->nl, 1, true);
+  HIP_TRY(hipMemset(Pq.inf, 0, 1));
+  g1_mul_launch(c, nullptr, c->key_P(), c->d_sk, 0, c->sk_len, Pq, 1);             // P' = q1 * P
+  c->kt->to_mont(nullptr, c->d_params, Pq.c0, Pq.c1, 1, 1);
+  uint8_t inf = 0;
+  HIP_TRY(hipMemcpy(&inf, Pq.inf, 1, hipMemcpyDeviceToHost));
+  if (inf) return BGN_OK;                                                          // P has order dividing q1
+  size_t steps = naf.size() - 1;
+  for (size_t i = 1; i + 1 < naf.size(); ++i)
+    if (naf[i] != 0) steps++;
+  HIP_TRY(hipMalloc((void**)&c->d_consts_sk, sizeof pc));
+  HIP_TRY(hipMemcpy(c->d_consts_sk, &pc, sizeof pc, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&c->d_fixedpair_sk, steps * 3 * (size_t)c->nl * 4));
+  c->kt->fixedpair_build(nullptr, c->d_params, c->d_consts_sk, Pq.c0, Pq.c1, c->d_fixedpair_sk);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return BGN_OK;
+}
+}  // namespace
+
 int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   if (!c || !q1_be || !q1_len) return fail(BGN_E_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   c->q1 = BigU::from_be(q1_be, q1_len);
   if (c->q1.is_zero()) return fail(BGN_E_ARG, "secret key is zero");
+  HIP_TRY(hipDeviceSynchronize());
   if (c->d_sk) (void)hipFree(c->d_sk);
   c->d_sk = nullptr;
   HIP_TRY(hipMalloc((void**)&c->d_sk, q1_len));
@@ -326,7 +385,7 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   c->sk_len = q1_len;
   c->have_secret = true;
   c->have_tables = false;
-  return BGN_OK;
+  return build_secret_order_table(c);
 }
 
 // forward declarations of launch helpers defined further down
@@ -364,7 +423,9 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
     if (v >= 4 && v <= 30) cap_log2 = v;
   }
   while (S < Mmax + 1 && S < ((uint64_t)1 << cap_log2)) S <<= 1;
-  const uint64_t G = (Mmax + S) / S + 1;
+  // a probe resolves m = i*2S +- j with j in [0, S] (bsgs.hpp): giant steps are 2S apart, the last one
+  // must reach Mmax from above: i <= (Mmax + S) / 2S
+  const uint64_t G = (Mmax + S) / (2 * S) + 1;
   const uint64_t slots = (2 * S < 64) ? 64 : 2 * S;
 
   if (c->d_table) (void)hipFree(c->d_table);
@@ -385,9 +446,9 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
   gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
   kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
-  // gamma^-1 = conj(g^S)
+  // gamma^-1 = conj(g^(2S))
   uint8_t sbe[8];
-  for (int i = 0; i < 8; ++i) sbe[i] = (uint8_t)(S >> (8 * (7 - i)));
+  for (int i = 0; i < 8; ++i) sbe[i] = (uint8_t)((2 * S) >> (8 * (7 - i)));
   HIP_TRY(hipMemcpy(d_scalar, sbe, 8, hipMemcpyHostToDevice));
   gt_pow_launch(c, nullptr, g, d_scalar, 0, 8, t2, 1);
   kt->to_mont(nullptr, c->d_params, t2.c0, t2.c1, 1, 1);
@@ -397,13 +458,14 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   bp.table = c->d_table;
   bp.mask = slots - 1;
   bp.S = S;
+  bp.stride = 2 * S;
   bp.G = G;
   bp.Mmax = Mmax;
   bp.g0 = g.c0; bp.g1 = g.c1; bp.gi0 = gi.c0; bp.gi1 = gi.c1;
   c->bsgs = bp;
   uint64_t chunk = S / 65536;
   if (chunk < 1) chunk = 1;
-  const size_t lanes = (size_t)((S + chunk - 1) / chunk);
+  const size_t lanes = (size_t)((S + 1 + chunk - 1) / chunk);      // j in [0, S]
   kt->bsgs_build(nullptr, c->d_params, bp, chunk, lanes);     // computeTableGT, gsbs.go:28-37
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
@@ -1171,9 +1233,11 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   kt->decode(s, c->d_params, ct, c->L, count, A);
   SoA2 base = A;
   if (level == 1) {
-    // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp)
-    kt->pairing(s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pairing_run(count), pws, st,
-                c->d_fixedpair, 0);
+    // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp).  With the secret-order table the
+    // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
+    const bool sk_tab = c->d_fixedpair_sk != nullptr;
+    kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
+                pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 0);
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }

@@ -122,6 +122,25 @@ struct BigU {
     r.trim();
     return r;
   }
+  // q = a / b, r = a mod b by shift-and-subtract (setup only: a few thousand word passes); b != 0
+  static void divmod(const BigU& a, const BigU& b, BigU& q, BigU& r) {
+    q = BigU();
+    r = BigU();
+    const int nb = a.bits();
+    q.w.assign((size_t)(nb + 31) / 32, 0);
+    for (int i = nb - 1; i >= 0; --i) {
+      r.shl1();
+      if (a.bit(i)) {
+        if (r.w.empty()) r.w.push_back(0);
+        r.w[0] |= 1u;
+      }
+      if (cmp(r, b) >= 0) {
+        r.sub(b);
+        q.w[(size_t)i / 32] |= 1u << (i % 32);
+      }
+    }
+    q.trim();
+  }
   // 28-bit limbs, little-endian, zero padded to nl
   void to_limbs28(uint32_t* out, int nl) const {
     for (int j = 0; j < nl; ++j) {

@@ -98,11 +98,12 @@ struct BsgsSlot {
 struct BsgsParams {
   BsgsSlot* table;
   unsigned long long mask;          // slots - 1 (power of two)
-  unsigned long long S;             // baby steps
+  unsigned long long S;             // baby steps: the table holds g^j for j in [0, S]
+  unsigned long long stride;        // giant-step spacing 2*S: one probe resolves m = i*stride +- j
   unsigned long long G;             // giant steps
   unsigned long long Mmax;          // largest accepted |m|
   const uint32_t* g0; const uint32_t* g1;     // g = e(P,P)^sk, canonical Montgomery, stride 1
-  const uint32_t* gi0; const uint32_t* gi1;   // gamma^-1 = conj(g^S), canonical Montgomery, stride 1
+  const uint32_t* gi0; const uint32_t* gi1;   // gamma^-1 = conj(g^stride), canonical Montgomery, stride 1
 };
 
 struct BsgsSearchArgs {

@@ -269,10 +269,10 @@ struct Emu {
     std::vector<BsgsSlot> table(slots);
     memset(table.data(), 0, slots * sizeof(BsgsSlot));
     BsgsParams B;
-    B.table = table.data(); B.mask = slots - 1; B.S = S; B.G = G; B.Mmax = Mmax;
+    B.table = table.data(); B.mask = slots - 1; B.S = S; B.stride = 2 * S; B.G = G; B.Mmax = Mmax;
     B.g0 = g; B.g1 = g + NL; B.gi0 = gi; B.gi1 = gi + NL;
     blockIdx.x = 0;
-    bsgs_build_lane<NL>(B, S, lds(), P);
+    bsgs_build_lane<NL>(B, S + 1, lds(), P);     // j in [0, S]
     std::vector<u32> todo(count + 1);
     u32 todo_count = 0;
     for (int i = 0; i < count; ++i) { m[i] = 0; status[i] = 1; }

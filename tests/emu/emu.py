@@ -222,9 +222,9 @@ class Emu:
             S = 2
             while S < Mmax + 1 and S < (1 << 26):
                 S <<= 1
-        G = (Mmax + S) // S + 1
+        G = (Mmax + S) // (2 * S) + 1
         g, _ = self.decode(g_wire)
-        gS = self.gt_pow(g_wire, S, 8)
+        gS = self.gt_pow(g_wire, 2 * S, 8)            # giant steps are 2S apart (bsgs.hpp)
         L = self.L
         conj = gS[:L] + ((self.p - int.from_bytes(gS[L:], "big")) % self.p).to_bytes(L, "big")
         gi, _ = self.decode(conj)

@@ -293,7 +293,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     // e(Q,Q) (blinding base of level-2 ops, bgn.go:306,469) and the GT identity
     {
       SoA2 o{c->d_keypts + 4 * c->nl, c->d_keypts + 5 * c->nl, nullptr, 1};
-      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0, nullptr, 0);
+      kt->pairing(nullptr, c->d_params, c->d_consts, c->key_Q(), c->key_Q(), o, 1, 0, 0, 0, 1, nullptr, 0, nullptr, 0, 0);
       kt->to_mont(nullptr, c->d_params, o.c0, o.c1, 1, 1);
       HIP_BRK(hipMemcpy(c->d_keypts + 6 * c->nl, img.data() + c->nl, (size_t)c->nl * 4, hipMemcpyHostToDevice));  // one
     }
@@ -442,7 +442,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   const int nl = c->nl;
   SoA2 g{c->d_gt, c->d_gt + nl, nullptr, 1}, gi{c->d_gt + 2 * nl, c->d_gt + 3 * nl, nullptr, 1};
   // g = e(P,P)^sk  (bgn.go:198-199)
-  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0, nullptr, 0);
+  kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 0, 0, 0, 1, nullptr, 0, nullptr, 0, 0);
   kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
   gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
   kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
@@ -537,7 +537,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
   kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
-              (mode == 1) ? c->d_fixedpair : nullptr, pairing_variant());
+              (mode == 1) ? c->d_fixedpair : nullptr, 1, pairing_variant());
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;
@@ -1237,7 +1237,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
     const bool sk_tab = c->d_fixedpair_sk != nullptr;
     kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
-                pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 0);
+                pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, 0);
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
@@ -1281,6 +1281,34 @@ int bgn_decrypt_batch(bgn_ctx* c, size_t count, int level, const uint8_t* ct, in
 }
 
 // ---- MultPoly --------------------------------------------------------------------------------
+// The d1*d2 pairings of one product share each coefficient of one operand among all coefficients of the
+// other.  With tables: a line table per coefficient of the operand with fewer coefficients
+// (fixedpair.hpp, ~11.5 products per Miller step, once), then every pair costs 7 / 5 products per
+// doubling / addition step instead of 18 / 17.  The tables are 3*NL*4 bytes per step and coefficient
+// (618 KB at a 1024-bit key: 40 GB for 2^16 coefficients), so the polynomials are processed in chunks
+// sized to a third of the free HBM.  Results are identical (the reduced pairing is symmetric and its
+// value canonical).  BGN_POLY_TABLES=0 selects the direct d1*d2 full pairings;
+// BGN_POLY_TABLE_MAX_MB caps the table size (tests use it to force several chunks).
+namespace {
+size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
+  if (const char* ev = getenv("BGN_POLY_TABLES"))
+    if (ev[0] == '0') return 0;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+  size_t budget = fr / 3;
+  if (const char* ev = getenv("BGN_POLY_TABLE_MAX_MB")) {
+    const long v = atol(ev);
+    if (v > 0 && ((size_t)v << 20) < budget) budget = (size_t)v << 20;
+  }
+  const size_t per_coeff = c->miller_steps * 3 * (size_t)c->nl * 4;
+  // table columns are padded to a multiple of 64 coefficients
+  size_t polys = budget / per_coeff / dt;
+  if (polys > npoly) polys = npoly;
+  while (polys && round_up(polys * dt, 64) * per_coeff > budget) polys--;
+  return polys;
+}
+}  // namespace
+
 int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
                             uint8_t* out, void* stream) {
   if (!c || (npoly && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
@@ -1291,8 +1319,14 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  const size_t na = npoly * d1, nb = npoly * d2, np = npoly * d1 * d2, no = npoly * (d1 + d2);
-  const size_t sa = round_up(na, 64), sb = round_up(nb, 64), sp = round_up(np, 64), so = round_up(no, 64);
+  const size_t na = npoly * d1, nb = npoly * d2, no = npoly * (d1 + d2);
+  const size_t sa = round_up(na, 64), sb = round_up(nb, 64), so = round_up(no, 64);
+  // tables on the operand with fewer coefficients (each table is then shared by more pairs)
+  const bool tab_on_a = d1 <= d2;
+  const size_t dt = tab_on_a ? d1 : d2;
+  const size_t chunk = (d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
+  const size_t cp = chunk ? chunk : npoly;
+  const size_t np = cp * d1 * d2, sp = round_up(np, 64);
   SoA2 A, Bv, E, O;
   uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
@@ -1304,21 +1338,50 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
       if (rc) return rc;
     }
   }
+  uint32_t* tab = nullptr;
+  const size_t ts = round_up(cp * dt, 64);
+  if (chunk) {
+    if (hipMalloc((void**)&tab, c->miller_steps * 3 * (size_t)c->nl * 4 * ts) != hipSuccess)
+      return fail(BGN_E_NOMEM, "MultPoly line tables (%zu MB)", (c->miller_steps * 3 * (size_t)c->nl * 4 * ts) >> 20);
+  }
   const KernelTable* kt = c->kt;
   kt->decode(s, c->d_params, a, c->L, na, A);
   kt->decode(s, c->d_params, b, c->L, nb, Bv);
+  auto view = [](SoA2 v, size_t off) {
+    v.c0 += off;
+    v.c1 += off;
+    if (v.inf) v.inf += off;
+    return v;
+  };
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, Bv, E, np, 2, d1, d2, pairing_run(np), pws, sp, nullptr, pairing_variant());                 // pk.Mult(coeff1, coeff2), poly.go:146
+  for (size_t q0 = 0; q0 < npoly; q0 += cp) {
+    const size_t nq = (npoly - q0 < cp) ? npoly - q0 : cp;
+    const size_t pairs = nq * d1 * d2;
+    const SoA2 Aq = view(A, q0 * d1), Bq = view(Bv, q0 * d2);
+    if (chunk) {
+      const SoA2 T = tab_on_a ? Aq : Bq, V = tab_on_a ? Bq : Aq;
+      kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);
+      kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(pairs), pws, sp,
+                  tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
+    } else {
+      kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(pairs), pws, sp, nullptr, 0,
+                  pairing_variant());
+    }
+    kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, pairs);
+    PolyAccArgs pa;
+    pa.e0 = E.c0; pa.e1 = E.c1; pa.se = E.stride;
+    pa.o0 = O.c0 + q0 * (d1 + d2); pa.o1 = O.c1 + q0 * (d1 + d2); pa.so = O.stride;
+    pa.npoly = nq; pa.d1 = d1; pa.d2 = d2;
+    kt->poly_acc(s, c->d_params, pa);                                              // result[i+k] = Add(result[i+k], coeff), poly.go:148
+  }
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
-  c->last_kernel = kt->pairing_kernel_name;
-  kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, np);
-  PolyAccArgs pa;
-  pa.e0 = E.c0; pa.e1 = E.c1; pa.se = E.stride;
-  pa.o0 = O.c0; pa.o1 = O.c1; pa.so = O.stride;
-  pa.npoly = npoly; pa.d1 = d1; pa.d2 = d2;
-  kt->poly_acc(s, c->d_params, pa);                                                  // result[i+k] = Add(result[i+k], coeff), poly.go:148
+  c->last_kernel = chunk ? "k_fixedpair_build_batch + k_pairing<.,1>" : kt->pairing_kernel_name;
   kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, no, out);
+  if (tab) {
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipFree(tab));
+  }
   HIP_TRY(hipGetLastError());
   return BGN_OK;
 }

@@ -13,6 +13,13 @@
 // The table (a_s, b_s, c_s), s over the 1024 doublings and 332 additions of the NAF of n, is built
 // once per key by one lane (k_fixedpair_build); a ciphertext then costs 7 products per doubling
 // step and 5 per addition step instead of 18 and 17.
+//
+// The same split serves MultPoly (poly.go:123-156): the d1*d2 pairings e(a_i, b_k) of one polynomial
+// product share their first argument d2 times, so a table is built per coefficient a_i (one lane each,
+// k_fixedpair_build_batch) and every pair runs the 7/5-product loop over its coefficient's table.  Such
+// tables are limb-major across coefficients — value v of step s, limb j, coefficient I at
+// tab[((3*s + v)*NL + j)*ts + I] — so the lanes of a wave read neighbouring dwords; the key's own table
+// is the special case ts = 1, I = 0.
 #pragma once
 #include "pairing.hpp"
 
@@ -25,20 +32,28 @@ struct FixedBuild {
 };
 
 template <int NL>
-__device__ __forceinline__ void fixed_store3(u32* __restrict__ tab, size_t s, const Fp<NL>& a, const Fp<NL>& b,
-                                             const Fp<NL>& c, const FpParams<NL>* __restrict__ P, LFp<NL>* L) {
+__device__ __forceinline__ void fixed_store3(u32* __restrict__ tab, size_t ts, size_t te, bool live, size_t s,
+                                             const Fp<NL>& a, const Fp<NL>& b, const Fp<NL>& c,
+                                             const FpParams<NL>* __restrict__ P, LFp<NL>* L) {
   Fp<NL> t;
   fp_canon<NL>(t, a, P, L);
-  g_store<NL>(tab + (3 * s + 0) * NL, 1, 0, t);
+  if (live) g_store<NL>(tab + (3 * s + 0) * NL * ts, ts, te, t);
   fp_canon<NL>(t, b, P, L);
-  g_store<NL>(tab + (3 * s + 1) * NL, 1, 0, t);
+  if (live) g_store<NL>(tab + (3 * s + 1) * NL * ts, ts, te, t);
   fp_canon<NL>(t, c, P, L);
-  g_store<NL>(tab + (3 * s + 2) * NL, 1, 0, t);
+  if (live) g_store<NL>(tab + (3 * s + 2) * NL * ts, ts, te, t);
 }
+
+// Where a lane's table lives (ts = limb stride in u32, te = the lane's column) and whether it stores.
+struct FixedTabRef {
+  u32* tab;
+  size_t ts, te;
+  bool live;
+};
 
 // V <- 2V and the tangent's coefficients
 template <int NL>
-__device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, u32* tab, size_t s, LFp<NL>* L,
+__device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, const FixedTabRef& tr, size_t s, LFp<NL>* L,
                                                    const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
   LFp<NL>* L1 = L + 1;
@@ -80,7 +95,7 @@ __device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, u32* tab, 
     fp_dbl(u, u);                          // 2YY <4
     fp_sub<4>(cb, cb, u, P);               // b <6
     l_store(L3, cb);
-    fixed_store3<NL>(tab, s, ca, cb, cc, P, S0);
+    fixed_store3<NL>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P, S0);
   }
   l_load(r, L2);
   fp_mul(u, L2, r, P);                     // M^2 <2
@@ -99,10 +114,11 @@ __device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, u32* tab, 
   a_store(S.Y, r);
 }
 
-// V <- V + sP and the chord's coefficients (px, py: P canonical Montgomery, stride 1)
+// V <- V + sP and the chord's coefficients (px, py: P canonical Montgomery, limb stride sp, element ep)
 template <int NL>
-__device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, u32* tab, size_t s, const u32* px, const u32* py,
-                                                int sign, LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
+__device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, const FixedTabRef& tr, size_t s, const u32* px,
+                                                const u32* py, size_t sp, size_t ep, int sign, LFp<NL>* L,
+                                                const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
   LFp<NL>* L1 = L + 1;
   LFp<NL>* L2 = L + 2;
@@ -112,14 +128,14 @@ __device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, u32* tab, siz
   fp_mulv(u, r, r, P, S0);                 // ZZ <2
   l_store(L1, u);
   fp_mul(r, L1, r, P);                     // Z^3 <2
-  g_load(u, py, 1, 0);
+  g_load(u, py, sp, ep);
   if (sign < 0) fp_neg<1>(u, u, P);        // ysP
   l_store(L2, u);                          // L2 = ysP
   fp_mul(r, L2, r, P);                     // ysP*Z^3 <2
   a_load(u, S.Y);
   fp_sub<18>(r, r, u, P);                  // rr <20
   a_store(S.T, r);                         // T = rr
-  g_load(u, px, 1, 0);
+  g_load(u, px, sp, ep);
   fp_mul(u, L1, u, P);                     // xP*ZZ <2
   a_load(w, S.X);
   fp_sub<18>(u, u, w, P);                  // H <20
@@ -132,12 +148,12 @@ __device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, u32* tab, siz
     a_load(ca, S.T);                       // a = rr <20
     cc = r;                                // c = Z3 <2
     fp_mul(w, L2, r, P);                   // Z3*ysP <2
-    g_load(r, px, 1, 0);
+    g_load(r, px, sp, ep);
     l_store(L3, ca);
     fp_mul(cb, L3, r, P);                  // rr*xP <2   (20)
     fp_sub<2>(cb, cb, w, P);               // b <4
     l_load(r, L1);                         // keep H across the store (it clobbers S0 only)
-    fixed_store3<NL>(tab, s, ca, cb, cc, P, S0);
+    fixed_store3<NL>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P, S0);
     u = r;
   }
   fp_mul(w, L1, u, P);                     // HH <2
@@ -162,17 +178,17 @@ __device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, u32* tab, siz
   a_store(S.Y, r);
 }
 
-// Builds the whole table (3 F_p per step) on lane 0 of the launch.
+// Builds this lane's whole table (3 F_p per step) for the point (px, py)[ep].
 template <int NL>
-__device__ __forceinline__ void fixed_build_lane(u32* tab, const u32* px, const u32* py, LFp<NL>* L,
-                                                 const PairingConsts* __restrict__ C,
+__device__ __forceinline__ void fixed_build_lane(const FixedTabRef& tr, const u32* px, const u32* py, size_t sp,
+                                                 size_t ep, LFp<NL>* L, const PairingConsts* __restrict__ C,
                                                  const FpParams<NL>* __restrict__ P) {
   FixedBuild<NL> S;
   {
     Fp<NL> r;
-    g_load(r, px, 1, 0);
+    g_load(r, px, sp, ep);
     a_store(S.X, r);
-    g_load(r, py, 1, 0);
+    g_load(r, py, sp, ep);
     a_store(S.Y, r);
     fp_set(r, P->one);
     a_store(S.Z, r);
@@ -182,17 +198,19 @@ __device__ __forceinline__ void fixed_build_lane(u32* tab, const u32* px, const 
   size_t s = 0;
 #pragma unroll 1
   for (int i = C->naf_len - 2; i >= 0; --i) {
-    fixed_build_double<NL>(S, tab, s++, L, P);
+    fixed_build_double<NL>(S, tr, s++, L, P);
     const int d = C->naf[i];
-    if (d != 0 && i != 0) fixed_build_add<NL>(S, tab, s++, px, py, d, L, P);
+    if (d != 0 && i != 0) fixed_build_add<NL>(S, tr, s++, px, py, sp, ep, d, L, P);
   }
 }
 
 // ---- per-ciphertext Miller loop over the table -----------------------------------------------
-// f in S.F0 / S.F1 on return; xC, yC (canonical Montgomery) are read from `op.ax/ay`.
+// f in S.F0 / S.F1 on return; xC, yC (canonical Montgomery) are read from `op.ax/ay`; the lane's table
+// is column `te` of a table with limb stride `ts` (the key's table: ts = 1, te = 0).
 template <int NL>
 __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, const PairOperands& op,
-                                                  const u32* __restrict__ tab, const PairingConsts* __restrict__ C,
+                                                  const u32* __restrict__ tab, size_t ts, size_t te,
+                                                  const PairingConsts* __restrict__ C,
                                                   const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
   LFp<NL>* LX = L + 1;
@@ -214,14 +232,14 @@ __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, con
     const int nsteps = (d != 0 && i != 0) ? 2 : 1;
 #pragma unroll 1
     for (int k = 0; k < nsteps; ++k, ++s) {
-      const u32* e = tab + 3 * s * NL;
+      const u32* e = tab + 3 * s * NL * ts;
       // line value
-      g_load(r, e, 1, 0);                  // a_s
+      g_load(r, e, ts, te);                // a_s
       fp_mul(r, LX, r, P);                 // a*xC <2
-      g_load(u, e + NL, 1, 0);             // b_s <1
+      g_load(u, e + NL * ts, ts, te);      // b_s <1
       fp_add(r, r, u);                     // cre <3
       a_store(S.X, r);                     // X slot = cre
-      g_load(u, e + 2 * NL, 1, 0);         // c_s
+      g_load(u, e + 2 * NL * ts, ts, te);  // c_s
       fp_mul(u, LY, u, P);                 // cim <2
       fp_add(r, r, u);                     // cre + cim <5
       a_store(S.T, r);

@@ -136,14 +136,22 @@ struct KernelTable {
   //   mode 2: poly product: e = (q*d1 + i)*d2 + k ; ea = q*d1 + i ; eb = q*d2 + k.
   //   run > 1: each lane owns `run` pairings and shares one F_p inversion among them; ws = workspace of
   //   3*NL*sw u32 (sw >= count).  run == 1 / ws == null: one pairing per lane.
-  //   fixed_tab != null (mode 1 only): the second operand is the key's P and the Miller loop runs over the
+  //   fixed_tab != null, mode 1: the second operand is the key's P and the Miller loop runs over the
   //   precomputed line table (fixedpair.hpp); b is ignored.
+  //   fixed_tab != null, mode 3 / 4: poly product (e as in mode 2) over per-coefficient line tables with limb
+  //   stride tab_stride (fixedpair_build_batch).  mode 3: tables of the first polynomial, a = second polynomial's
+  //   points, b = first polynomial (identity flags only); mode 4: tables of the second polynomial, a = first
+  //   polynomial's points, b = second polynomial (identity flags only).
   void (*pairing)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                   size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
-                  const uint32_t* fixed_tab, int variant /* 0: inlined step programs, 1: interpreter (vm.hpp) */);
+                  const uint32_t* fixed_tab, size_t tab_stride,
+                  int variant /* 0: inlined step programs, 1: interpreter (vm.hpp) */);
   // builds the line table of e(P, .) : 3*NL u32 per Miller step (px, py canonical Montgomery, stride 1)
   void (*fixedpair_build)(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
                           const uint32_t* py, uint32_t* tab);
+  // one line table per point of a[0..count): value v of step s, limb j, point I at tab[((3*s+v)*NL + j)*ts + I]
+  void (*fixedpair_build_batch)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, size_t count,
+                                uint32_t* tab, size_t ts);
   // plain canonical SoA -> canonical Montgomery SoA, in place (to chain kernels on the device)
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);

@@ -66,7 +66,21 @@ k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32*
 }
 
 // ---- pairing ----------------------------------------------------------------
-__device__ __forceinline__ void pair_index(PairOperands& op, size_t e, int mode, size_t d1, size_t d2) {
+// Returns the lane's column in a per-coefficient line table (modes 3 and 4), 0 otherwise.
+__device__ __forceinline__ size_t pair_index(PairOperands& op, size_t e, int mode, size_t d1, size_t d2) {
+  if (mode >= 3) {
+    // poly product over per-coefficient line tables: e = (q*d1 + i)*d2 + k as in mode 2.  `a` holds the
+    // evaluated points, `b` the table side (only its identity flags are read):
+    //   mode 3: tables of the first polynomial's coefficients,  a = second polynomial
+    //   mode 4: tables of the second polynomial's coefficients, a = first polynomial
+    const size_t k = e % d2;
+    const size_t qi = e / d2;
+    const size_t q = qi / d1;
+    const size_t qk = q * d2 + k;
+    op.ea = (mode == 3) ? qk : qi;
+    op.eb = (mode == 3) ? qi : qk;
+    return op.eb;
+  }
   if (mode == 0) {
     op.ea = e;
     op.eb = e;
@@ -80,6 +94,7 @@ __device__ __forceinline__ void pair_index(PairOperands& op, size_t e, int mode,
     op.ea = qi;
     op.eb = q * d2 + k;
   }
+  return 0;
 }
 
 // Each lane owns `run` pairings e = j*T + t (T = lanes in the grid): pass 1 runs the Miller loops and
@@ -91,7 +106,7 @@ template <int NL, int VARIANT>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
           size_t count, int mode, size_t d1, size_t d2, int run, u32* __restrict__ ws, size_t sw,
-          const u32* __restrict__ fixed_tab) {
+          const u32* __restrict__ fixed_tab, size_t tab_stride) {
   __shared__ LFp<NL> L[4];
   const size_t T = (size_t)gridDim.x * FP_BLOCK;
   const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
@@ -114,9 +129,9 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     const bool live = e < count;
     if (!__ballot(live)) break;
     if (!live) e = count - 1;             // keep the wave's control flow uniform; results are discarded
-    pair_index(op, e, mode, d1, d2);
+    const size_t te = pair_index(op, e, mode, d1, d2);
     if (VARIANT == 1)
-      miller_loop_fixed<NL>(S, L, op, fixed_tab, C, P);
+      miller_loop_fixed<NL>(S, L, op, fixed_tab, tab_stride, te, C, P);
     else if (VARIANT == 2)
       miller_loop_vm<NL>(S, L, op, C, P);
     else
@@ -392,19 +407,22 @@ static void launch_encode(hipStream_t s, const uint8_t* inf, const uint32_t* c0,
 
 static void launch_pairing(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                            size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
-                           const uint32_t* fixed_tab, int variant) {
+                           const uint32_t* fixed_tab, size_t tab_stride, int variant) {
   if (!count) return;
   if (run < 1 || !ws) run = 1;
   const size_t lanes = (count + run - 1) / run;
-  if (fixed_tab && mode == 1)
+  if (fixed_tab && (mode == 1 || mode >= 3))
     hipLaunchKernelGGL((k_pairing<NL_, 1>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
-                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab);
+                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab,
+                       mode == 1 ? (size_t)1 : tab_stride);
   else if (variant == 1)
     hipLaunchKernelGGL((k_pairing<NL_, 2>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
-                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr);
+                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
+                       (size_t)0);
   else
     hipLaunchKernelGGL((k_pairing<NL_, 0>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
-                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr);
+                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
+                       (size_t)0);
 }
 
 template <int NL>
@@ -412,7 +430,30 @@ __global__ void __launch_bounds__(64)
 k_fixedpair_build(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, const u32* px, const u32* py,
                   u32* tab) {
   __shared__ LFp<NL> L[4];
-  fixed_build_lane<NL>(tab, px, py, L, C, P);     // every lane computes and stores the same values
+  // every lane computes the same values, lane 0 stores them
+  fixed_build_lane<NL>(FixedTabRef{tab, 1, 0, threadIdx.x == 0}, px, py, 1, 0, L, C, P);
+}
+
+// One table per point of `a` (lane I -> column I of a table with limb stride ts): MultPoly's shared
+// first arguments.  An identity point builds a table of placeholder values; the pairing kernel overrides
+// every result that involves it.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_fixedpair_build_batch(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, size_t count,
+                        u32* tab, size_t ts) {
+  __shared__ LFp<NL> L[4];
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < count;
+  if (!__ballot(live)) return;
+  if (!live) e = count - 1;
+  fixed_build_lane<NL>(FixedTabRef{tab, ts, e, live}, a.c0, a.c1, a.stride, e, L, C, P);
+}
+
+static void launch_fixedpair_build_batch(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a,
+                                         size_t count, uint32_t* tab, size_t ts) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_fixedpair_build_batch<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s,
+                     (const FpParams<NL_>*)params, consts, a, count, tab, ts);
 }
 
 static void launch_fixedpair_build(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
@@ -529,6 +570,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_encode,
       launch_pairing,
       launch_fixedpair_build,
+      launch_fixedpair_build_batch,
       launch_to_mont,
       launch_g1_add,
       launch_g1_mul,

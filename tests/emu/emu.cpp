@@ -64,15 +64,17 @@ struct Emu {
     memcpy(out + NL, im.v, 4 * NL);
   }
   // e(P, c) through the precomputed line table: build (one lane) + per-ciphertext loop + final exponentiation
-  static void fixed_build(const u32* params, const PairingConsts* C, const u32* p, u32* tab) {
-    fixed_build_lane<NL>(tab, p, p + NL, lds(), C, (const FpParams<NL>*)params);
+  // table column te of a table with limb stride ts (ts = 1, te = 0: the key's own table)
+  static void fixed_build(const u32* params, const PairingConsts* C, const u32* p, u32* tab, size_t ts, size_t te) {
+    fixed_build_lane<NL>(FixedTabRef{tab, ts, te, true}, p, p + NL, 1, 0, lds(), C, (const FpParams<NL>*)params);
   }
-  static void pairing_fixed(const u32* params, const PairingConsts* C, const u32* tab, const u32* c, u32* out) {
+  static void pairing_fixed(const u32* params, const PairingConsts* C, const u32* tab, size_t ts, size_t te,
+                            const u32* c, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
     PairOperands op{c, c + NL, 1, 0, nullptr, nullptr, 1, 0};
     Miller<NL> S;
-    miller_loop_fixed<NL>(S, L, op, tab, C, P);
+    miller_loop_fixed<NL>(S, L, op, tab, ts, te, C, P);
     Fp<NL> N, ninv, g0, g1, re, im;
     miller_norm<NL>(N, S, L, P);
     l_store(L + 1, N);
@@ -339,8 +341,8 @@ int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned lo
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
 int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, x, xlen, r, rlen, out, oinf)) }
 int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, windows, pow, tab)) }
-int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab)) }
-int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, c, out)) }
+int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab, size_t ts, size_t te) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab, ts, te)) }
+int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, c, out)) }
 int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }
 int emu_fp_inv(int nl, const u32* params, int p_bits, const u32* a, u32* out) { DISPATCH(nl, fp_inv(params, p_bits, a, out)) }
 int emu_gt_tab_build(int nl, const u32* params, int wbits, int windows, const u32* g, u32* tab) { DISPATCH(nl, gt_tab_build(params, wbits, windows, g, tab)) }

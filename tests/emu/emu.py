@@ -115,20 +115,23 @@ class Emu:
             return (1).to_bytes(self.L, "big") + bytes(self.L)
         return self.encode(out)
 
-    def fixed_table(self, P_wire: bytes):
+    def fixed_table(self, P_wire: bytes, ts: int = 1, te: int = 0, tab=None):
+        """Line table of e(P, .) in column `te` of a table with limb stride `ts` (fixedpair.hpp); several
+        points can share one table (MultPoly's per-coefficient tables) by passing `tab` back in."""
         d = naf(self.n)
         steps = (len(d) - 1) + sum(1 for i in range(1, len(d) - 1) if d[i])
         Pm, _ = self.decode(P_wire)
-        tab = (C.c_uint32 * (3 * self.nl * steps))()
-        assert self.lib.emu_fixed_build(self.nl, self.params, self.consts, Pm, tab) == 0
+        if tab is None:
+            tab = (C.c_uint32 * (3 * self.nl * steps * ts))()
+        assert self.lib.emu_fixed_build(self.nl, self.params, self.consts, Pm, tab, C.c_size_t(ts), C.c_size_t(te)) == 0
         return tab
 
-    def pairing_fixed(self, tab, c_wire: bytes) -> bytes:
+    def pairing_fixed(self, tab, c_wire: bytes, ts: int = 1, te: int = 0) -> bytes:
         Cm, inf = self.decode(c_wire)
         if inf:
             return (1).to_bytes(self.L, "big") + bytes(self.L)
         out = (C.c_uint32 * (2 * self.nl))()
-        assert self.lib.emu_pairing_fixed(self.nl, self.params, self.consts, tab, Cm, out) == 0
+        assert self.lib.emu_pairing_fixed(self.nl, self.params, self.consts, tab, C.c_size_t(ts), C.c_size_t(te), Cm, out) == 0
         return self.encode(out)
 
     def g1_mul(self, base: bytes, k: int, klen: int = None) -> bytes:

@@ -170,6 +170,23 @@ def test_emu_fixed_argument_pairing(ctx):
         assert E.pairing_fixed(tab, cts[v["a"]]).hex() == v["out"]
 
 
+def test_emu_per_coefficient_line_tables(ctx):
+    """MultPoly's shared first arguments: tables of several ciphertexts as columns of one limb-major table
+    (fixedpair.hpp) give the Mult golden vectors, in either argument order (the pairing is symmetric)."""
+    fx, E = ctx
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    # identity operands are overridden by the kernel around the loop, not by the table
+    rows = [v for v in fx["mult"] if any(cts[v["a"]]) and any(cts[v["b"]])][:3]
+    ts, tab = 5, None
+    for col, v in enumerate(rows):
+        tab = E.fixed_table(cts[v["a"]], ts, col + 1, tab)           # columns 1..3 of 5
+    for col, v in enumerate(rows):
+        assert E.pairing_fixed(tab, cts[v["b"]], ts, col + 1).hex() == v["out"]
+    v = rows[0]
+    tb = E.fixed_table(cts[v["b"]], 2, 1)
+    assert E.pairing_fixed(tb, cts[v["a"]], 2, 1).hex() == v["out"]
+
+
 def test_emu_interpreter_miller_loop(ctx):
     """The compact-code interpreter (vm.hpp) runs the same step programs as data: same pairing values."""
     fx, E = ctx

@@ -305,6 +305,35 @@ def test_poly_mult_many_vs_c_oracle_and_decrypt():
         assert [int(v) for v in m[q * (d1 + d2):(q + 1) * (d1 + d2)]] == conv
 
 
+@pytest.mark.parametrize("d1,d2,env", [
+    (4, 3, {}),                                  # tables on the second polynomial (fewer coefficients)
+    (2, 5, {}),                                  # tables on the first
+    (3, 3, {"BGN_POLY_TABLE_MAX_MB": "3"}),      # table budget of 3 MB = 64 columns: 21 polynomials per chunk
+    (4, 3, {"BGN_POLY_TABLES": "0"}),            # direct d1*d2 full pairings
+    (1, 4, {}), (4, 1, {}), (1, 1, {}),          # degenerate shapes
+])
+def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
+    """MultPoly over per-coefficient line tables (fixedpair.hpp) == the oracle's d1*d2 full pairings +
+    accumulation, for either table side, chunked tables, identity coefficients (Enc(0) deterministic) and
+    the direct path."""
+    import oracle_c
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fx = load_fixture("k256")
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    rng = random.Random(100 * d1 + d2)
+    n = int(fx["n"], 16)
+    npoly = 70 if env.get("BGN_POLY_TABLE_MAX_MB") else 9
+    xa = [rng.choice([0, 1, 2, n - 1]) for _ in range(npoly * d1)]
+    xb = [rng.choice([0, 1, 2, n - 1]) for _ in range(npoly * d2)]
+    # r = 0 with x = 0 is the identity of G1 (encryptZero in deterministic mode, bgn.go:562-564)
+    ea = o.encrypt(xa, [rng.choice([0, rng.randrange(n)]) for _ in xa])
+    eb = o.encrypt(xb, [rng.choice([0, rng.randrange(n)]) for _ in xb])
+    out = pk.engine.poly_mult(npoly, d1, d2, ea, eb)
+    assert out.tobytes() == o.poly_mult(npoly, d1, d2, ea, eb)
+
+
 def test_decrypt_large_message_space_1024():
     """T = 2^40 (BASELINE configs[3]): uniform messages incl. negatives, through Encrypt -> Decrypt on the engine;
     exercises the re-balanced 2^26-entry HBM table."""

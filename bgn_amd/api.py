@@ -171,6 +171,30 @@ class Engine:
               "bgn_poly_mult_batch")
         return out
 
+    def poly_multconst(self, npoly: int, d: int, level: int, ct: BytesLike, coeffs, shared: bool = True) -> np.ndarray:
+        """MultConstPoly of `npoly` ciphertext polynomials (d coefficients each) by encoded plaintext
+        constants: `coeffs` is one list of dp digits (shared) or npoly lists.  Returns npoly*(d+dp) rows."""
+        rows = [list(coeffs)] if shared else [list(r) for r in coeffs]
+        dp = len(rows[0])
+        if any(len(r) != dp for r in rows) or (not shared and len(rows) != npoly):
+            raise ValueError("plaintext polynomials must have one common degree")
+        k = _scalars([v for r in rows for v in r])
+        a = _as_u8(ct, self.elem_bytes)
+        if len(a) != npoly * d:
+            raise ValueError("coefficient count mismatch")
+        out = self._out(npoly * (d + dp))
+        check(self._lib.bgn_poly_multconst_batch(self._h, npoly, d, dp, level, _ptr(a), _ptr(k), k.shape[1],
+                                                 0 if shared else 1, _ptr(out)), "bgn_poly_multconst_batch")
+        return out
+
+    def poly_eval(self, npoly: int, d: int, level: int, ct: BytesLike, base: int) -> np.ndarray:
+        a = _as_u8(ct, self.elem_bytes)
+        if len(a) != npoly * d:
+            raise ValueError("coefficient count mismatch")
+        out = self._out(npoly)
+        check(self._lib.bgn_poly_eval_batch(self._h, npoly, d, level, _ptr(a), base, _ptr(out)), "bgn_poly_eval_batch")
+        return out
+
     # ---- device-buffer batch ops (torch uint8 CUDA tensors; asynchronous) ---------
     @staticmethod
     def _stream():
@@ -208,6 +232,15 @@ class Engine:
     def poly_mult_dev(self, npoly: int, d1: int, d2: int, a, b, out) -> None:
         check(self._lib.bgn_poly_mult_batch_dev(self._h, npoly, d1, d2, a.data_ptr(), b.data_ptr(), out.data_ptr(),
                                                 self._stream()), "bgn_poly_mult_batch_dev")
+
+    def poly_multconst_dev(self, npoly: int, d: int, dp: int, level: int, ct, p, k_len: int, per_poly: bool, out) -> None:
+        check(self._lib.bgn_poly_multconst_batch_dev(self._h, npoly, d, dp, level, ct.data_ptr(), p.data_ptr(), k_len,
+                                                     1 if per_poly else 0, out.data_ptr(), self._stream()),
+              "bgn_poly_multconst_batch_dev")
+
+    def poly_eval_dev(self, npoly: int, d: int, level: int, ct, base: int, out) -> None:
+        check(self._lib.bgn_poly_eval_batch_dev(self._h, npoly, d, level, ct.data_ptr(), base, out.data_ptr(),
+                                                self._stream()), "bgn_poly_eval_batch_dev")
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.bgn_last_kernel_ms(self._h))
@@ -247,8 +280,9 @@ class PublicKey:
     on the CPU side of the boundary, north_star)."""
 
     def __init__(self, p: int, n: int, l: int, P: bytes, Q: bytes, MsgSpace: int, Deterministic: bool = True,
-                 PolyBase: int = 3, device: int = 0):
+                 PolyBase: int = 3, device: int = 0, FPScaleBase: int = 3, FPPrecision: float = 0.0001):
         self.N = int(n)
+        self.FPScaleBase, self.FPPrecision = int(FPScaleBase), float(FPPrecision)     # PolyEncodingParams, bgn.go:43-48
         self.P, self.Q = bytes(P), bytes(Q)
         self.MsgSpace = int(MsgSpace)
         self.Deterministic = bool(Deterministic)
@@ -360,30 +394,134 @@ class PublicKey:
         res = [self.Sub(self.encryptZero(), c) for c in ct.Coefficients]        # poly.go:45-55
         return PolyCiphertext(res, ct.Degree, ct.ScaleFactor, ct.L2)
 
+    def MultConstPoly(self, ct: PolyCiphertext, constant) -> PolyCiphertext:
+        """poly.go:71-120.  `constant` is a number (encoded here with the unbalanced base-b expansion of
+        plaintext.go:34-63, CPU side) or an already encoded (digits, scale) pair.  One engine call computes
+        the whole convolution result[i+k] += MultConst(ct[i], p[k])."""
+        negative = False
+        if isinstance(constant, tuple):
+            digits, scale = list(constant[0]), int(constant[1])
+        else:
+            negative = constant < 0                                          # poly.go:73-76
+            digits, scale = self.NewUnbalancedPlaintext(-constant if negative else constant)
+        if not self.Deterministic:
+            raise NotImplementedError("MultConstPoly on a non-deterministic key blinds every step with fresh "
+                                      "randomness (bgn.go:260-269): run the deterministic form and blind the result")
+        out = self.engine.poly_multconst(1, ct.Degree, 2 if ct.L2 else 1, b"".join(c.C for c in ct.Coefficients), digits)
+        prod = PolyCiphertext([Ciphertext(bytes(r), ct.L2) for r in out], ct.Degree + len(digits),
+                              ct.ScaleFactor + scale, ct.L2)
+        return self.NegPoly(prod) if negative else prod                      # poly.go:115-119
+
+    def MakePolyL2(self, ct: PolyCiphertext) -> PolyCiphertext:
+        """poly.go:159-163: MultPoly(EncryptPoly(1), ct).  The encoding of 1 is the single digit [1]."""
+        one = PolyCiphertext([self.Encrypt(1)], 1, 0, False)                 # EncryptPoly -> pk.Encrypt, poly.go:24
+        return self.MultPoly(one, ct)
+
+    def alignPolyCiphertexts(self, ct1: PolyCiphertext, ct2: PolyCiphertext):
+        """poly.go:209-226: bring both operands to the larger scale factor by MultConstPoly with
+        FPScaleBase^diff.  Returns the pair in the reference's order (larger scale first)."""
+        if ct1.ScaleFactor > ct2.ScaleFactor:
+            diff = ct1.ScaleFactor - ct2.ScaleFactor
+            ct2 = self.MultConstPoly(ct2, self.FPScaleBase ** diff)
+            ct2.ScaleFactor = ct1.ScaleFactor
+        elif ct2.ScaleFactor > ct1.ScaleFactor:
+            return self.alignPolyCiphertexts(ct2, ct1)
+        return ct1, ct2
+
+    def SubPoly(self, ct1: PolyCiphertext, ct2: PolyCiphertext) -> PolyCiphertext:
+        return self.AddPoly(ct1, self.NegPoly(ct2))                          # poly.go:166-168
+
     def AddPoly(self, p1: PolyCiphertext, p2: PolyCiphertext) -> PolyCiphertext:
-        """poly.go:171-207 for operands of equal scale factor (alignment via
-        MultConstPoly is host control flow over the same kernels)."""
-        if p1.ScaleFactor != p2.ScaleFactor:
-            raise NotImplementedError("scale alignment (poly.go:209-226) stays host-side; align before calling")
-        if p1.L2 != p2.L2:
-            raise NotImplementedError("mixed-level AddPoly: lift with MakePolyL2 first (poly.go:173-182)")
-        deg = max(p1.Degree, p2.Degree)
-        res = []
-        for i in range(deg):
-            if i >= p2.Degree:
-                res.append(p1.Coefficients[i])
-            elif i >= p1.Degree:
-                res.append(p2.Coefficients[i])
-            else:
-                res.append(self.Add(p1.Coefficients[i], p2.Coefficients[i]))
+        """poly.go:171-207: lift to a common level, align the scale factors, add coefficient-wise (one batch
+        call for the common prefix)."""
+        if p1.L2 or p2.L2:
+            if not p1.L2:
+                return self.AddPoly(self.MakePolyL2(p1), p2)                 # poly.go:175-177
+            if not p2.L2:
+                return self.AddPoly(p1, self.MakePolyL2(p2))                 # poly.go:179-181
+        p1, p2 = self.alignPolyCiphertexts(p1, p2)
+        deg, common = max(p1.Degree, p2.Degree), min(p1.Degree, p2.Degree)
+        res = self.AddBatch(p1.Coefficients[:common], p2.Coefficients[:common])
+        res += (p1 if p1.Degree > p2.Degree else p2).Coefficients[common:deg]
         return PolyCiphertext(res, deg, p1.ScaleFactor, p1.L2)
 
     def EvalPoly(self, ct: PolyCiphertext) -> Ciphertext:
-        acc = self.EncryptDeterministic(0)                                   # poly.go:58-68
-        for c in reversed(ct.Coefficients):
-            acc = self.MultConst(acc, self.PolyBase)
-            acc = self.Add(acc, c)
-        return acc
+        """poly.go:58-68 (Horner over MultConst/Add) as one multi-scalar sum on the device."""
+        if not self.Deterministic:
+            acc = self.EncryptDeterministic(0)
+            for c in reversed(ct.Coefficients):
+                acc = self.MultConst(acc, self.PolyBase)
+                acc = self.Add(acc, c)
+            return acc
+        out = self.engine.poly_eval(1, ct.Degree, 2 if ct.L2 else 1, b"".join(c.C for c in ct.Coefficients), self.PolyBase)
+        return Ciphertext(bytes(out[0]), ct.L2)
+
+    # -- plaintext encoding (plaintext.go; CPU side of the boundary) --
+    def NewUnbalancedPlaintext(self, m):
+        """plaintext.go:34-63: digits of the unbalanced base-b expansion of m >= 0 and its scale factor.
+        Integers only need the expansion; a fractional m goes through `rationalize` first."""
+        from fractions import Fraction
+        scale = 0
+        if isinstance(m, float) and m != int(m):
+            import math
+            num, scale = rationalize(m - math.floor(m), self.FPScaleBase, self.FPPrecision)
+            m = int(math.floor(m)) * self.FPScaleBase ** scale + num         # plaintext.go:49-52
+        m = int(m)
+        if m < 0:
+            raise ValueError("Negative encoding not supported")             # plaintext.go:175-177
+        return unbalanced_encode(m, self.PolyBase), scale
+
+
+def unbalanced_encode(target: int, base: int) -> List[int]:
+    """unbalancedEncode (plaintext.go:164-212): greedy from the top power, digit 2 when 2*b^i still fits, else 1;
+    for base 3 this is the ordinary ternary expansion.  Like the reference, the result carries one zero
+    coefficient above the top digit (`coefficients[:bound+1]` with bound = top index + 1).  Zero encodes as [0]."""
+    if target == 0:
+        return [0]
+    digits: List[int] = []
+    top = None
+    while True:
+        i = 0
+        while base ** (i + 1) <= target:                                   # degree(): largest i with b^i <= target
+            i += 1
+        if top is None:
+            top = i
+            digits = [0] * (top + 2)
+        v = base ** i
+        if 2 * v <= target:
+            v, digits[i] = 2 * v, 2
+        else:
+            digits[i] = 1
+        if v == target:
+            return digits
+        target -= v
+
+
+def rationalize(x: float, base: int, precision: float):
+    """rationalize (plaintext.go:271-317), float for float: smallest power of the base whose multiple
+    approximates frac(x) within `precision`.  Returns (numerator, scale)."""
+    import math
+    factor = math.floor(x)
+    x = 1.0 + math.remainder(x, 1.0)
+    if abs(x) > 1.0:
+        x += 1.0
+    if x >= 0.0:
+        x -= float(int(x))
+    num, pw = 1.0, 1.0
+    qmin, qmax = x - precision, x + precision
+    while True:
+        denom = float(base) ** pw
+        rat = num / denom
+        if qmin <= rat <= qmax:
+            while int(num) % base == 0:
+                num /= base
+                pw -= 1
+            denom = float(base) ** pw
+            return int(factor * denom + num), int(pw)
+        if num + 1 >= denom:
+            num = 1.0
+            pw += 1
+        num += 1
 
 
 class SecretKey:

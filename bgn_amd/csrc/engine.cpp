@@ -1403,6 +1403,114 @@ int bgn_poly_mult_batch(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, const ui
   return S.down(out, dout, npoly * (d1 + d2) * E);
 }
 
+// ---- MultConstPoly / EvalPoly ---------------------------------------------------------------------
+namespace {
+int poly_lin_common(bgn_ctx* c, size_t npoly, size_t d, size_t dp, int level, const uint8_t* ct, const uint8_t* k_dev,
+                    const std::vector<uint8_t>* k_host, size_t k_len, size_t kq, uint8_t* out, hipStream_t s) {
+  const size_t nin = npoly * d, nout = npoly * (dp ? d + dp : 1);
+  if (nin > kMaxBatch || nout > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t si = round_up(nin, 64), so = round_up(nout, 64);
+  SoA2 A, O;
+  uint8_t* kbuf = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    if (level == 1) { A = w.g1(si); O = w.g1(so); } else { A = w.gt(si); O = w.gt(so); }
+    if (k_host) kbuf = (uint8_t*)w.cv.take(k_host->size());
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  if (k_host) {
+    HIP_TRY(hipMemcpyAsync(kbuf, k_host->data(), k_host->size(), hipMemcpyHostToDevice, s));
+    k_dev = kbuf;
+  }
+  const KernelTable* kt = c->kt;
+  kt->decode(s, c->d_params, ct, c->L, nin, A);
+  PolyLinArgs a;
+  a.cx = A.c0; a.cy = A.c1; a.cinf = A.inf; a.sc = A.stride;
+  a.k = k_dev; a.klen = k_len; a.kq = kq;
+  a.ox = O.c0; a.oy = O.c1; a.oinf = O.inf; a.so = O.stride;
+  a.npoly = npoly; a.d = d; a.dp = dp;
+  a.nbits = (int)(k_len * 8);
+  HIP_TRY(hipEventRecord(c->ev0, s));
+  kt->poly_lin(s, c->d_params, c->d_consts, level, a);
+  HIP_TRY(hipEventRecord(c->ev1, s));
+  c->ev_valid = true;
+  c->last_kernel = "k_poly_lin";
+  kt->encode(s, level == 1 ? O.inf : nullptr, O.c0, O.c1, O.stride, c->L, nout, out);
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+}  // namespace
+
+int bgn_poly_multconst_batch_dev(bgn_ctx* c, size_t npoly, size_t d, size_t dp, int level, const uint8_t* ct,
+                                 const uint8_t* p_be, size_t k_len, int k_per_poly, uint8_t* out, void* stream) {
+  if (!c || (npoly && (!ct || !p_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!npoly) return BGN_OK;
+  if (!d || !dp || d > 4096 || dp > 4096) return fail(BGN_E_ARG, "polynomial degrees must be in [1, 4096]");
+  if (!k_len || k_len > 4096) return fail(BGN_E_ARG, "scalar length out of range");
+  // result[i+k] = Add(result[i+k], MultConst(ct[i], p[k])), poly.go:97-113
+  return poly_lin_common(c, npoly, d, dp, level, ct, p_be, nullptr, k_len, k_per_poly ? dp : 0, out, (hipStream_t)stream);
+}
+
+int bgn_poly_eval_batch_dev(bgn_ctx* c, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
+                            uint8_t* out, void* stream) {
+  if (!c || (npoly && (!ct || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!npoly) return BGN_OK;
+  if (!d || d > 4096) return fail(BGN_E_ARG, "polynomial degree must be in [1, 4096]");
+  // acc = MultConst(acc, base); acc = Add(acc, ct[i]) from the top coefficient down (poly.go:62-65)
+  // = sum_i base^i * ct[i]: the scalars base^i, big-endian, one fixed length
+  std::vector<BigU> pw(d);
+  pw[0] = BigU((uint64_t)1);
+  for (size_t i = 1; i < d; ++i) pw[i] = BigU::mul_u64(pw[i - 1], base);
+  size_t k_len = ((size_t)pw[d - 1].bits() + 7) / 8;
+  if (!k_len) k_len = 1;
+  std::vector<uint8_t> kb(d * k_len, 0);
+  for (size_t i = 0; i < d; ++i)
+    for (size_t j = 0; j < k_len; ++j) {
+      const size_t word = j / 4;
+      if (word < pw[i].w.size()) kb[i * k_len + (k_len - 1 - j)] = (uint8_t)(pw[i].w[word] >> (8 * (j % 4)));
+    }
+  return poly_lin_common(c, npoly, d, 0, level, ct, nullptr, &kb, k_len, 0, out, (hipStream_t)stream);
+}
+
+int bgn_poly_multconst_batch(bgn_ctx* c, size_t npoly, size_t d, size_t dp, int level, const uint8_t* ct,
+                             const uint8_t* p_be, size_t k_len, int k_per_poly, uint8_t* out) {
+  if (!c || (npoly && (!ct || !p_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!npoly) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t E = 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(3);
+  uint8_t *dct = nullptr, *dk = nullptr, *dout = nullptr;
+  UP(ct, npoly * d * E, dct);
+  UP(p_be, (k_per_poly ? npoly : 1) * dp * k_len, dk);
+  UP(nullptr, npoly * (d + dp) * E, dout);
+  int rc = bgn_poly_multconst_batch_dev(c, npoly, d, dp, level, dct, dk, k_len, k_per_poly, dout, nullptr);
+  if (rc) return rc;
+  return S.down(out, dout, npoly * (d + dp) * E);
+}
+
+int bgn_poly_eval_batch(bgn_ctx* c, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base, uint8_t* out) {
+  if (!c || (npoly && (!ct || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!npoly) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t E = 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(2);
+  uint8_t *dct = nullptr, *dout = nullptr;
+  UP(ct, npoly * d * E, dct);
+  UP(nullptr, npoly * E, dout);
+  int rc = bgn_poly_eval_batch_dev(c, npoly, d, level, dct, base, dout, nullptr);
+  if (rc) return rc;
+  return S.down(out, dout, npoly * E);
+}
+
 double bgn_last_kernel_ms(bgn_ctx* c) {
   if (!c || !c->ev_valid) return -1.0;
   if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;

@@ -120,6 +120,18 @@ struct PolyAccArgs {
   size_t npoly, d1, d2;
 };
 
+// Multi-scalar sums over the coefficients of ciphertext polynomials (polyops.hpp):
+//   dp > 0 (MultConstPoly, poly.go:71-120): out[q*(d+dp) + s] = sum_{i+k=s} K[q][k] * c[q*d + i], s < d + dp
+//   dp = 0 (EvalPoly, poly.go:58-68):       out[q]            = sum_i K[q][i] * c[q*d + i]
+// G1 sums for level 1, products of powers in GT for level 2.
+struct PolyLinArgs {
+  const uint32_t* cx; const uint32_t* cy; const uint8_t* cinf; size_t sc;   // coefficients, canonical Montgomery
+  const uint8_t* k; size_t klen; size_t kq;                                 // big-endian scalars; kq = scalars per polynomial (0: one set for all)
+  uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical out
+  size_t npoly, d, dp;
+  int nbits;                                                                // scalar bits to scan (<= 8*klen)
+};
+
 struct KernelTable {
   int nl;
   size_t params_bytes;   // sizeof(FpParams<NL>)
@@ -174,6 +186,7 @@ struct KernelTable {
   void (*bsgs_build)(hipStream_t s, const void* params, BsgsParams b, unsigned long long chunk, size_t lanes);
   void (*bsgs_search)(hipStream_t s, const void* params, BsgsParams b, BsgsSearchArgs a);
   void (*poly_acc)(hipStream_t s, const void* params, PolyAccArgs a);
+  void (*poly_lin)(hipStream_t s, const void* params, const PairingConsts* consts, int level, PolyLinArgs a);
   const char* bsgs_kernel_name;
 };
 

@@ -6,6 +6,7 @@
 #include "codec.hpp"
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
+#include "polyops.hpp"
 #include "vm.hpp"
 
 namespace bgn {
@@ -554,6 +555,32 @@ static void launch_bsgs_search(hipStream_t s, const void* params, BsgsParams b, 
   hipLaunchKernelGGL(k_bsgs_search<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, b, a);
 }
 
+template <int NL, int LEVEL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_poly_lin(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, PolyLinArgs A) {
+  __shared__ LFp<NL> L[4];
+  const size_t total = A.npoly * (A.dp ? A.d + A.dp : 1);
+  size_t lane = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = lane < total;
+  if (!__ballot(live)) return;
+  if (!live) lane = total - 1;               // keep every index in range; nothing is taken or stored
+  if (LEVEL == 1)
+    poly_lin_g1_lane<NL>(A, lane, live, L, C, P);
+  else
+    poly_lin_gt_lane<NL>(A, lane, live, L, P);
+}
+
+static void launch_poly_lin(hipStream_t s, const void* params, const PairingConsts* consts, int level, PolyLinArgs a) {
+  const size_t total = a.npoly * (a.dp ? a.d + a.dp : 1);
+  if (!total) return;
+  if (level == 1)
+    hipLaunchKernelGGL((k_poly_lin<NL_, 1>), dim3(grid_for(total)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                       consts, a);
+  else
+    hipLaunchKernelGGL((k_poly_lin<NL_, 2>), dim3(grid_for(total)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                       consts, a);
+}
+
 static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
   const size_t total = a.npoly * (a.d1 + a.d2);
   if (!total) return;
@@ -586,6 +613,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_bsgs_build,
       launch_bsgs_search,
       launch_poly_acc,
+      launch_poly_lin,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
   };
   return &t;

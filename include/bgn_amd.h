@@ -132,6 +132,24 @@ int bgn_decrypt_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* ct, 
 int bgn_poly_mult_batch(bgn_ctx* ctx, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
                         uint8_t* out);
 
+/* MultConstPoly over `npoly` ciphertext polynomials of d coefficients (level 1 or 2) and encoded plaintext
+ * constants of dp coefficients: out[q][s] = sum_{i+k=s} p[q][k] * ct[q][i] for s < d+dp (slot d+dp-1 is the
+ * identity, as in the reference).  p: unsigned big-endian scalars of k_len bytes each — dp of them when
+ * k_per_poly == 0 (one constant for every polynomial), npoly*dp otherwise.  Deterministic form (a key with
+ * Deterministic == false blinds every MultConst/Add of the loop with fresh randomness: blind the result with
+ * bgn_add_batch and explicit r instead).  The plaintext encoding (NewUnbalancedPlaintext, plaintext.go:34-63)
+ * and the sign rule (NegPoly of the product, poly.go:115-119) stay on the host.
+ * Replaces MultConstPoly (poly.go:71-120); alignPolyCiphertexts (poly.go:209-226) is this call with the
+ * encoded power of the scale base. */
+int bgn_poly_multconst_batch(bgn_ctx* ctx, size_t npoly, size_t d, size_t dp, int level, const uint8_t* ct,
+                             const uint8_t* p_be, size_t k_len, int k_per_poly, uint8_t* out);
+
+/* EvalPoly over `npoly` ciphertext polynomials of d coefficients: out[q] = sum_i base^i * ct[q][i]
+ * (Horner in the reference: acc = MultConst(acc, base); acc = Add(acc, ct[i]) from the top coefficient down).
+ * Replaces EvalPoly (poly.go:58-68). */
+int bgn_poly_eval_batch(bgn_ctx* ctx, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
+                        uint8_t* out);
+
 /* ---- batch operations, device buffers (same semantics; asynchronous) -------- */
 int bgn_encrypt_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be,
                           size_t r_len, uint8_t* out, void* stream);
@@ -148,6 +166,11 @@ int bgn_multconst_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t
 int bgn_decrypt_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status,
                           void* stream);
 int bgn_poly_mult_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                            uint8_t* out, void* stream);
+
+int bgn_poly_multconst_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d, size_t dp, int level, const uint8_t* ct,
+                                 const uint8_t* p_be, size_t k_len, int k_per_poly, uint8_t* out, void* stream);
+int bgn_poly_eval_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
                             uint8_t* out, void* stream);
 
 /* ---- measurement hooks (used by bench.py; not part of the drop-in surface) --- */

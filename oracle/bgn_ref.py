@@ -441,6 +441,25 @@ class PublicKey:
             acc = self.Add(acc, c)
         return acc
 
+    def NegPoly(self, coeffs: Sequence[Ciphertext]) -> List[Ciphertext]:
+        """poly.go:45-55"""
+        return [self.Sub(self.encryptZero(), c) for c in coeffs]
+
+    def MultConstPoly(self, coeffs: Sequence[Ciphertext], l2: bool, digits: Sequence[int]) -> List[Ciphertext]:
+        """poly.go:71-120 after the sign split and NewUnbalancedPlaintext (`digits` = poly.Coefficients):
+        result[i+k] = Add(result[i+k], MultConst(ct[i], poly[k])), every slot starting from zero
+        (makeL2(zero) for a level-2 operand, poly.go:85-93).  Deterministic mode only."""
+        degree = len(coeffs) + len(digits)
+        zero = self.encryptZero()
+        if l2:
+            zero = self.makeL2(zero)
+        result = [zero for _ in range(degree)]
+        for i in range(len(coeffs) - 1, -1, -1):
+            for k in range(len(digits) - 1, -1, -1):
+                coeff = self.MultConst(coeffs[i], digits[k])              # poly.go:106
+                result[i + k] = self.Add(result[i + k], coeff)            # poly.go:107
+        return result
+
     def EncryptPolyCoeffs(self, coeffs: Sequence[int], rs: Sequence[int]) -> List[Ciphertext]:
         """poly.go:11-29: negative digits become Sub(zero, Enc(|c|))."""
         out = []
@@ -450,6 +469,141 @@ class PublicKey:
             else:
                 out.append(self.EncryptWithRandomness(c, r))
         return out
+
+
+# --------------------------------------------------------------------------
+# plaintext encoding (plaintext.go) — CPU side of the boundary; restated so the
+# poly-layer tests can drive MultConstPoly / alignPolyCiphertexts like poly_test.go
+# --------------------------------------------------------------------------
+DEGREE_BOUND = 128                                   # plaintext.go:11
+
+
+def _degree_tables(base: int):
+    """computeEncodingTable, plaintext.go:104-124"""
+    deg = [base ** i for i in range(DEGREE_BOUND)]
+    sums, acc = [], 0
+    for v in deg:
+        acc += v
+        sums.append(acc)
+    return deg, sums
+
+
+def _degree(target: int, deg, sums, bound: int, balanced: bool) -> int:
+    """degree, plaintext.go:127-151"""
+    if target == 1:
+        return 0
+    if balanced:
+        for i in range(1, bound + 1):
+            if sums[i] >= target:
+                return i
+    else:
+        for i in range(1, bound + 1):
+            if deg[i] > target:
+                return i - 1
+    return -1
+
+
+def unbalancedEncode(target: int, base: int) -> List[int]:
+    """plaintext.go:164-212.  Returns Coefficients (len = Degree)."""
+    deg, sums = _degree_tables(base)
+    if target == 0:
+        return [0]
+    if target < 0:
+        raise ValueError("Negative encoding not supported")
+    coefficients = [0] * DEGREE_BOUND
+    bound = len(sums)
+    last = DEGREE_BOUND
+    while True:
+        index = _degree(target, deg, sums, last - 1 if last == DEGREE_BOUND else last, False)
+        last = index + 1
+        if bound == len(sums):
+            bound = index + 1
+        value = deg[index]
+        if 2 * value <= target:
+            value = 2 * value
+            coefficients[index] = 2
+        else:
+            coefficients[index] = 1
+        if value == target:
+            return coefficients[:bound + 1]
+        target -= value
+
+
+def balancedEncode(target: int, base: int) -> List[int]:
+    """plaintext.go:214-268"""
+    deg, sums = _degree_tables(base)
+    if target == 0:
+        return [0]
+    negative = target < 0
+    if negative:
+        target = -target
+    coefficients = [0] * DEGREE_BOUND
+    bound = len(sums)
+    last = DEGREE_BOUND - 1
+    next_negative = False
+    while True:
+        index = _degree(target, deg, sums, last, True)
+        last = index
+        if bound == len(sums):
+            bound = index
+        coefficients[index] = -1 if next_negative else 1
+        if deg[index] == target:
+            if negative:
+                for i in range(bound + 1):
+                    coefficients[i] *= -1
+            return coefficients[:bound + 1]
+        if deg[index] > target:
+            next_negative = not next_negative
+            target = deg[index] - target
+        else:
+            target -= deg[index]
+
+
+def rationalize(x: float, base: int, precision: float) -> Tuple[int, int]:
+    """plaintext.go:271-317, float64 for float64."""
+    factor = math.floor(x)
+    x = 1.0 + math.remainder(x, 1.0)
+    if abs(x) > 1.0:
+        x += 1.0
+    if x >= 0.0:
+        x -= float(int(x))
+    elif x <= -0.0:
+        x += float(int(x))
+    num = 1.0
+    pw = 1.0
+    qmin, qmax = x - precision, x + precision
+    while True:
+        denom = math.pow(float(base), pw)
+        rat = num / denom
+        if qmin <= rat <= qmax:
+            while int(num) % base == 0:
+                num = num / float(base)
+                pw -= 1
+            denom = math.pow(float(base), pw)
+            return int(factor * denom + num), int(pw)
+        if num + 1 >= denom:
+            num = 1.0
+            pw += 1
+        num += 1
+
+
+def NewUnbalancedPlaintext(m, base: int, fp_scale_base: int, fp_precision: float) -> Tuple[List[int], int]:
+    """plaintext.go:34-63 -> (Coefficients, ScaleFactor)"""
+    mf = float(m)
+    if math.remainder(mf, 1.0) != 0.0:
+        numerator, scale = rationalize(mf - math.floor(mf), fp_scale_base, fp_precision)
+        m_int = int(mf)                                  # big.Float.Int truncates toward zero
+        m_int = m_int * int(math.pow(float(fp_scale_base), float(scale))) + numerator
+        return unbalancedEncode(m_int, base), scale
+    return unbalancedEncode(int(mf), base), 0
+
+
+def poly_eval_plain(coeffs: Sequence[int], base: int) -> int:
+    """PolyEval (plaintext.go:320-339) on integer coefficients, without the scale division."""
+    acc = 0
+    for c in reversed(coeffs):
+        acc = acc * base + c
+    return acc
 
 
 @dataclass

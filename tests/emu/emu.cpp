@@ -13,6 +13,7 @@ thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 
 #include "codec.hpp"
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
+#include "polyops.hpp"
 #include "vm.hpp"
 #include "fpinv.hpp"
 
@@ -317,6 +318,27 @@ struct Emu {
     for (size_t s = 0; s < deg; ++s)
       for (int l = 0; l < NL; ++l) { out[s * 2 * NL + l] = o0[l * deg + s]; out[s * 2 * NL + NL + l] = o1[l * deg + s]; }
   }
+  // one polynomial: c = d elements (2*NL Montgomery limbs each) with identity flags, scalars k (klen bytes each);
+  // dp > 0: convolution with dp scalars, d + dp outputs; dp == 0: dot product with d scalars, one output
+  static void poly_lin(const u32* params, const PairingConsts* C, int level, const u32* c, const uint8_t* cinf, int d,
+                       int dp, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    const size_t n = (size_t)d, nout = dp ? (size_t)(d + dp) : 1;
+    std::vector<u32> cx(NL * n), cy(NL * n), ox(NL * nout), oy(NL * nout);
+    for (size_t i = 0; i < n; ++i)
+      for (int l = 0; l < NL; ++l) { cx[l * n + i] = c[i * 2 * NL + l]; cy[l * n + i] = c[i * 2 * NL + NL + l]; }
+    PolyLinArgs A;
+    A.cx = cx.data(); A.cy = cy.data(); A.cinf = level == 1 ? cinf : nullptr; A.sc = n;
+    A.k = k; A.klen = klen; A.kq = 0;
+    A.ox = ox.data(); A.oy = oy.data(); A.oinf = oinf; A.so = nout;
+    A.npoly = 1; A.d = d; A.dp = dp; A.nbits = (int)(klen * 8);
+    for (size_t s = 0; s < nout; ++s) {
+      if (level == 1) poly_lin_g1_lane<NL>(A, s, true, lds(), C, P);
+      else { poly_lin_gt_lane<NL>(A, s, true, lds(), P); oinf[s] = 0; }
+    }
+    for (size_t s = 0; s < nout; ++s)
+      for (int l = 0; l < NL; ++l) { out[s * 2 * NL + l] = ox[l * nout + s]; out[s * 2 * NL + NL + l] = oy[l * nout + s]; }
+  }
 };
 
 #define DISPATCH(nl, call)            \
@@ -341,6 +363,7 @@ int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned lo
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
 int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, x, xlen, r, rlen, out, oinf)) }
 int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, windows, pow, tab)) }
+int emu_poly_lin(int nl, const u32* params, const void* C, int level, const u32* c, const uint8_t* cinf, int d, int dp, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, poly_lin(params, (const PairingConsts*)C, level, c, cinf, d, dp, k, klen, out, oinf)) }
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab, size_t ts, size_t te) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab, ts, te)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, c, out)) }
 int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }

@@ -18,7 +18,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "vm.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "vm.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"), "-include", os.path.join(_HERE, "imad.hpp"),
@@ -241,6 +241,29 @@ class Emu:
         assert self.lib.emu_bsgs(self.nl, self.params, g, gi, C.c_ulonglong(S), C.c_ulonglong(G), C.c_ulonglong(Mmax),
                                  xs, n, m, st) == 0
         return list(m), list(st)
+
+    def poly_lin(self, level: int, c_wire, scalars, dp: int):
+        """polyops.hpp on one polynomial: dp > 0 convolution with the dp scalars (d + dp outputs), dp == 0 dot
+        product with d scalars (one output).  Returns wire bytes per output."""
+        d = len(c_wire)
+        cm = (C.c_uint32 * (2 * self.nl * d))()
+        cinf = (C.c_uint8 * d)()
+        for j, w in enumerate(c_wire):
+            x, inf = self.decode(w)
+            cm[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
+            cinf[j] = inf if level == 1 else 0
+        klen = max(1, max((int(v).bit_length() + 7) // 8 for v in scalars))
+        kb = b"".join(int(v).to_bytes(klen, "big") for v in scalars)
+        nout = d + dp if dp else 1
+        out = (C.c_uint32 * (2 * self.nl * nout))()
+        oinf = (C.c_uint8 * nout)()
+        assert self.lib.emu_poly_lin(self.nl, self.params, self.consts, level, cm, cinf, d, dp, kb, C.c_size_t(klen),
+                                     out, oinf) == 0
+        res = []
+        for s in range(nout):
+            pl = (C.c_uint32 * (2 * self.nl))(*out[2 * self.nl * s:2 * self.nl * (s + 1)])
+            res.append(self.encode(pl, oinf[s]) if level == 1 else self.encode(pl))
+        return res
 
     def poly_acc(self, E_wire, d1: int, d2: int):
         n = d1 * d2

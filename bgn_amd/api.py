@@ -18,7 +18,7 @@ from typing import Iterable, List, Optional, Sequence, Union
 
 import numpy as np
 
-from . import _lib
+from . import _lib, gob
 from ._lib import check
 
 BytesLike = Union[bytes, bytearray, memoryview, np.ndarray]
@@ -263,7 +263,8 @@ class Ciphertext:
         return Ciphertext(self.C, self.L2)
 
     def Bytes(self) -> bytes:
-        return self.C
+        """ciphertext.go:76-92: the gob envelope of {CBytes, L2}."""
+        return gob.marshal_ciphertext(self.C, self.L2)
 
 
 @dataclass
@@ -273,6 +274,13 @@ class PolyCiphertext:
     Degree: int
     ScaleFactor: int
     L2: bool
+
+    def Copy(self) -> "PolyCiphertext":
+        return PolyCiphertext(self.Coefficients, self.Degree, self.ScaleFactor, self.L2)   # ciphertext.go:41-43
+
+    def Bytes(self) -> bytes:
+        """ciphertext.go:94-116"""
+        return gob.marshal_poly_ciphertext([c.C for c in self.Coefficients], self.Degree, self.ScaleFactor, self.L2)
 
 
 class PublicKey:
@@ -299,6 +307,22 @@ class PublicKey:
 
     def _lvl(self, ct: Ciphertext) -> int:
         return 2 if ct.L2 else 1
+
+    # -- wire envelopes: bgn.go:501-560 --
+    def _elem(self, b: bytes) -> bytes:
+        if len(b) == 0:
+            return self._zero                        # gob drops empty slices; the identity is all zero
+        if len(b) != self.engine.elem_bytes:
+            raise ValueError(f"element of {len(b)} bytes, expected {self.engine.elem_bytes}")
+        return bytes(b)
+
+    def NewCiphertextFromBytes(self, data: bytes) -> Ciphertext:
+        c, l2 = gob.unmarshal_ciphertext(data)       # raises "no data provided" on empty input (bgn.go:503-505)
+        return Ciphertext(self._elem(c), l2)
+
+    def NewPolyCiphertextFromBytes(self, data: bytes) -> PolyCiphertext:
+        coeffs, degree, scale, l2 = gob.unmarshal_poly_ciphertext(data)
+        return PolyCiphertext([Ciphertext(self._elem(c), l2) for c in coeffs], degree, scale, l2)
 
     # -- encryption: bgn.go:325-353 --
     def EncryptBatch(self, xs: Sequence[int], rs: Optional[Sequence[int]] = None) -> List[Ciphertext]:

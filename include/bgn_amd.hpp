@@ -43,6 +43,29 @@ struct Ciphertext {
   Ciphertext Copy() const { return *this; }
 };
 
+// ciphertext.go:26-31
+struct PolyCiphertext {
+  std::vector<Ciphertext> Coefficients;
+  int Degree = 0;
+  int ScaleFactor = 0;
+  bool L2 = false;
+  PolyCiphertext Copy() const { return *this; }
+};
+
+// unbalancedEncode (plaintext.go:164-212) for a machine integer: greedy base-b digits, least significant
+// first, with the reference's one zero coefficient above the top digit; 0 encodes as [0].  Plaintext
+// encoding stays on the CPU side of the boundary.
+inline std::vector<uint64_t> UnbalancedEncode(uint64_t m, uint64_t base) {
+  std::vector<uint64_t> d;
+  if (m == 0) return {0};
+  while (m) {
+    d.push_back(m % base);
+    m /= base;
+  }
+  d.push_back(0);
+  return d;
+}
+
 class SecretKey;
 
 // bgn.go:28-41 (hot-path members)
@@ -51,6 +74,8 @@ class PublicKey {
   Bytes N;
   uint64_t MsgSpace;
   bool Deterministic;
+  uint64_t PolyBase = 3;      // PolyEncodingParams, bgn.go:19-25
+  uint64_t FPScaleBase = 3;
 
   PublicKey(const Bytes& p, const Bytes& n, uint64_t l, const Bytes& P, const Bytes& Q, uint64_t msgSpace,
             bool deterministic = true, int device = 0)
@@ -140,6 +165,83 @@ class PublicKey {
   // ---- bgn.go:195-201 ----
   void SetupDecryption(const SecretKey& sk) const;
 
+  // ---- poly.go (coefficient vectors; digits are already-encoded plaintext coefficients) ----
+  // EncryptPoly, poly.go:11-29: a negative digit is Sub(zero, Enc(|c|)); r[i] is the randomness of digit i.
+  PolyCiphertext EncryptPoly(const std::vector<int64_t>& digits, const std::vector<Scalar>& r, int scale = 0) const {
+    PolyCiphertext out;
+    for (size_t i = 0; i < digits.size(); ++i) {
+      const int64_t c = digits[i];
+      Ciphertext e = EncryptWithRandomness(scalar_u64((uint64_t)(c < 0 ? -c : c)), r[i]);
+      out.Coefficients.push_back(c < 0 ? Sub(encryptZero(), e) : e);
+    }
+    out.Degree = (int)digits.size();
+    out.ScaleFactor = scale;
+    return out;
+  }
+  // MultPoly, poly.go:123-156: one engine call for the d1*d2 pairings and the accumulation.
+  PolyCiphertext MultPoly(const PolyCiphertext& a, const PolyCiphertext& b) const {
+    Bytes A = join(a.Coefficients), B = join(b.Coefficients), out((size_t)(a.Degree + b.Degree) * E_);
+    check(bgn_poly_mult_batch(h_, 1, (size_t)a.Degree, (size_t)b.Degree, A.data(), B.data(), out.data()),
+          "bgn_poly_mult_batch");
+    return PolyCiphertext{split(out, true), a.Degree + b.Degree, a.ScaleFactor + b.ScaleFactor, true};
+  }
+  // NegPoly, poly.go:45-55
+  PolyCiphertext NegPoly(const PolyCiphertext& ct) const {
+    PolyCiphertext out = ct;
+    for (auto& c : out.Coefficients) c = Sub(ct.L2 ? makeL2(encryptZero()) : encryptZero(), c);
+    return out;
+  }
+  // MultConstPoly, poly.go:71-120, on the encoded constant (digits, scale, sign): one engine call.
+  PolyCiphertext MultConstPoly(const PolyCiphertext& ct, const std::vector<uint64_t>& digits, int scale = 0,
+                               bool negative = false) const {
+    std::vector<Scalar> ks;
+    for (uint64_t d : digits) ks.push_back(scalar_u64(d));
+    size_t kl = 0;
+    Bytes A = join(ct.Coefficients), kb = pack(ks, kl), out((size_t)(ct.Degree + (int)digits.size()) * E_);
+    check(bgn_poly_multconst_batch(h_, 1, (size_t)ct.Degree, digits.size(), ct.L2 ? 2 : 1, A.data(), kb.data(), kl, 0,
+                                   out.data()),
+          "bgn_poly_multconst_batch");
+    PolyCiphertext prod{split(out, ct.L2), ct.Degree + (int)digits.size(), ct.ScaleFactor + scale, ct.L2};
+    return negative ? NegPoly(prod) : prod;                                          // poly.go:115-119
+  }
+  PolyCiphertext MultConstPoly(const PolyCiphertext& ct, int64_t constant) const {
+    return MultConstPoly(ct, UnbalancedEncode((uint64_t)(constant < 0 ? -constant : constant), PolyBase), 0,
+                         constant < 0);
+  }
+  // MakePolyL2, poly.go:159-163: MultPoly(EncryptPoly(1), ct); r blinds the encryption of 1.
+  PolyCiphertext MakePolyL2(const PolyCiphertext& ct, const Scalar& r) const {
+    return MultPoly(EncryptPoly({1}, {r}), ct);
+  }
+  // AddPoly, poly.go:171-207 with alignPolyCiphertexts, poly.go:209-226.  r is used if a level-1 operand has
+  // to be lifted (MakePolyL2).
+  PolyCiphertext AddPoly(PolyCiphertext a, PolyCiphertext b, const Scalar& r = scalar_u64(1)) const {
+    if (a.L2 && !b.L2) b = MakePolyL2(b, r);
+    if (!a.L2 && b.L2) a = MakePolyL2(a, r);
+    if (a.ScaleFactor < b.ScaleFactor) std::swap(a, b);
+    if (a.ScaleFactor > b.ScaleFactor) {
+      uint64_t f = 1;
+      for (int i = 0; i < a.ScaleFactor - b.ScaleFactor; ++i) f *= FPScaleBase;
+      b = MultConstPoly(b, UnbalancedEncode(f, PolyBase));
+      b.ScaleFactor = a.ScaleFactor;
+    }
+    const int deg = a.Degree > b.Degree ? a.Degree : b.Degree, common = a.Degree < b.Degree ? a.Degree : b.Degree;
+    std::vector<Ciphertext> ca(a.Coefficients.begin(), a.Coefficients.begin() + common),
+        cb(b.Coefficients.begin(), b.Coefficients.begin() + common);
+    PolyCiphertext out{AddBatch(ca, cb), deg, a.ScaleFactor, a.L2};
+    const PolyCiphertext& longer = a.Degree > b.Degree ? a : b;
+    out.Coefficients.insert(out.Coefficients.end(), longer.Coefficients.begin() + common, longer.Coefficients.end());
+    return out;
+  }
+  PolyCiphertext SubPoly(const PolyCiphertext& a, const PolyCiphertext& b) const { return AddPoly(a, NegPoly(b)); }
+  // EvalPoly, poly.go:58-68
+  Ciphertext EvalPoly(const PolyCiphertext& ct) const {
+    Bytes A = join(ct.Coefficients);
+    Ciphertext out{Bytes(E_), ct.L2};
+    check(bgn_poly_eval_batch(h_, 1, (size_t)ct.Degree, ct.L2 ? 2 : 1, A.data(), PolyBase, out.C.data()),
+          "bgn_poly_eval_batch");
+    return out;
+  }
+
  private:
   friend class SecretKey;
   bgn_ctx* h_ = nullptr;
@@ -204,6 +306,10 @@ class SecretKey {
   int64_t DecryptFailSafe(const Ciphertext& ct, const PublicKey& pk) const {          // bgn.go:210-216
     auto r = DecryptBatch({ct}, pk);
     return r.second[0] == BGN_DL_OK ? r.first[0] : 0;
+  }
+  // DecryptPoly, poly.go:32-42 (per-coefficient errors are ignored there: a miss decrypts to 0)
+  std::vector<int64_t> DecryptPoly(const PolyCiphertext& ct, const PublicKey& pk) const {
+    return DecryptBatch(ct.Coefficients, pk).first;
   }
 };
 

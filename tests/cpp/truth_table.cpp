@@ -44,6 +44,27 @@ int main(int argc, char** argv) {
     expect("(-1) * (-1)", D(pk.Mult(pk.Neg(one), pk.Neg(one))), 1);
     expect("1*1 + 1 (mixed level)", D(pk.Add(pk.Mult(one, one), one)), 2);
     expect("3 * Enc(1) via MultConst", D(pk.MultConst(one, scalar_u64(3))), 3);
+    // poly layer (poly_test.go:92-189): digits of 9 and -4 in balanced base 3
+    auto ev = [&](const PolyCiphertext& c) {
+      int64_t acc = 0;
+      std::vector<int64_t> d = sk.DecryptPoly(c, pk);
+      for (size_t i = d.size(); i-- > 0;) acc = acc * 3 + d[i];
+      return acc;
+    };
+    std::vector<Scalar> rs{scalar_u64(11), scalar_u64(22), scalar_u64(33)};
+    PolyCiphertext a = pk.EncryptPoly({0, 0, 1}, rs), b = pk.EncryptPoly({-1, -1}, rs);
+    expect("poly 9 + (-4)", ev(pk.AddPoly(a, b)), 5);
+    expect("poly 9 - (-4)", ev(pk.SubPoly(a, b)), 13);
+    expect("poly 9 * (-4)", ev(pk.MultPoly(a, b)), -36);
+    expect("poly 9 * const 6", ev(pk.MultConstPoly(a, 6)), 54);
+    expect("poly (-4) * const -5", ev(pk.MultConstPoly(b, -5)), 20);
+    expect("poly (9 * -4) * const 2 (level 2)", ev(pk.MultConstPoly(pk.MultPoly(a, b), 2)), -72);
+    expect("poly 9*(-4) + 9 (mixed level)", ev(pk.AddPoly(pk.MultPoly(a, b), a, scalar_u64(44))), -27);
+    expect("EvalPoly(9)", D(pk.EvalPoly(a)), 9);
+    PolyCiphertext b2 = pk.EncryptPoly({-1, -1}, rs, 2);
+    PolyCiphertext s2 = pk.AddPoly(a, b2);
+    expect("poly 9 + (-4 / 3^2) at scale 2", ev(s2), 77);
+    expect("scale factor after alignment", s2.ScaleFactor, 2);
     bool threw = false;
     try {
       sk.Decrypt(pk.EncryptWithRandomness(scalar_u64(5000), scalar_u64(1)), pk);

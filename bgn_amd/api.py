@@ -283,6 +283,25 @@ class PolyCiphertext:
         return gob.marshal_poly_ciphertext([c.C for c in self.Coefficients], self.Degree, self.ScaleFactor, self.L2)
 
 
+@dataclass
+class ProofOfPlaintextKnowledge:
+    """gadgets.go:10-14"""
+    Ct: Ciphertext
+    Nonce: Ciphertext
+    DL: int
+
+
+@dataclass
+class DecryptionProof:
+    """gadgets.go:18-21"""
+    Value: int
+    Randomness: int
+
+
+def NewDecryptionProof(v: int, r: int) -> DecryptionProof:
+    return DecryptionProof(int(v), int(r))                                    # gadgets.go:24-28
+
+
 class PublicKey:
     """bgn.go:28-41 — hot-path methods only (keygen and plaintext encoding stay
     on the CPU side of the boundary, north_star)."""
@@ -479,6 +498,53 @@ class PublicKey:
             return acc
         out = self.engine.poly_eval(1, ct.Degree, 2 if ct.L2 else 1, b"".join(c.C for c in ct.Coefficients), self.PolyBase)
         return Ciphertext(bytes(out[0]), ct.L2)
+
+    # -- proofs: gadgets.go --
+    def _hash(self, ct_bytes: bytes, nonce_bytes: bytes) -> int:
+        import hashlib
+        return int.from_bytes(hashlib.sha256(bytes(ct_bytes) + bytes(nonce_bytes)).digest(), "big")   # gadgets.go:80-96
+
+    def NewProofOfPlaintextKnowledge(self, sk: "SecretKey", v: int, z: int, nonce1: Optional[int] = None):
+        """gadgets.go:32-54 (`nonce1` may be supplied to make the proof reproducible)."""
+        if nonce1 is None:
+            nonce1 = secrets.randbelow(self.N)
+        ct, nonce = self.EncryptBatch([v, nonce1], [z, 0])
+        nonce2 = self._hash(ct.C, nonce.C)
+        DL = (nonce1 + nonce2 * v + sk.R * z * nonce2 * (self.N // sk.Key)) % self.N
+        return ProofOfPlaintextKnowledge(ct, nonce, DL)
+
+    def CheckDecryptionProofBatch(self, cts: Sequence[Ciphertext], proofs: Sequence["DecryptionProof"]) -> List[bool]:
+        if not cts:
+            return []
+        v = _scalars([pr.Value for pr in proofs])
+        r = _scalars([pr.Randomness for pr in proofs])
+        a = _as_u8(b"".join(c.C for c in cts), self.engine.elem_bytes)
+        ok = np.zeros(len(cts), dtype=np.uint8)
+        check(self.engine._lib.bgn_check_decryption_proof_batch(self.engine._h, len(cts), _ptr(a), _ptr(v), v.shape[1],
+                                                                _ptr(r), r.shape[1], _ptr(ok)),
+              "bgn_check_decryption_proof_batch")
+        return [bool(x) for x in ok]
+
+    def CheckDecryptionProof(self, ct: Ciphertext, proof: "DecryptionProof") -> bool:
+        return self.CheckDecryptionProofBatch([ct], [proof])[0]                # gadgets.go:57-61
+
+    def CheckProofOfPlaintextKnoewledgeBatch(self, cts: Sequence[Ciphertext],
+                                             proofs: Sequence["ProofOfPlaintextKnowledge"]) -> List[bool]:
+        if not cts:
+            return []
+        E = self.engine.elem_bytes
+        c = _scalars([self._hash(pr.Ct.C, pr.Nonce.C) for pr in proofs], 32)   # nonce2 := hash(proof), gadgets.go:67
+        dl = _scalars([pr.DL for pr in proofs])
+        a = _as_u8(b"".join(x.C for x in cts), E)
+        nn = _as_u8(b"".join(pr.Nonce.C for pr in proofs), E)
+        ok = np.zeros(len(cts), dtype=np.uint8)
+        check(self.engine._lib.bgn_check_plaintext_knowledge_batch(self.engine._h, len(cts), _ptr(a), _ptr(nn), _ptr(c), 32,
+                                                                   _ptr(dl), dl.shape[1], _ptr(ok)),
+              "bgn_check_plaintext_knowledge_batch")
+        return [bool(x) for x in ok]
+
+    def CheckProofOfPlaintextKnoewledge(self, ct: Ciphertext, proof: "ProofOfPlaintextKnowledge") -> bool:
+        return self.CheckProofOfPlaintextKnoewledgeBatch([ct], [proof])[0]     # gadgets.go:65-77 (name as in the reference)
 
     # -- plaintext encoding (plaintext.go; CPU side of the boundary) --
     def NewUnbalancedPlaintext(self, m):

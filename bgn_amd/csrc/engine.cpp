@@ -1511,6 +1511,103 @@ int bgn_poly_eval_batch(bgn_ctx* c, size_t npoly, size_t d, int level, const uin
   return S.down(out, dout, npoly * E);
 }
 
+// ---- proof verification (gadgets.go) --------------------------------------------------------------
+// Both checks are a few group operations per proof over the kernels above, followed by an element
+// comparison; the comparison is on canonical wire bytes (Element.Equals on affine coordinates).
+namespace {
+__global__ void k_wire_equal(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t eb, size_t count,
+                             uint8_t* __restrict__ ok) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const uint8_t* x = a + e * eb;
+  const uint8_t* y = b + e * eb;
+  uint8_t diff = 0;
+  for (size_t i = 0; i < eb; ++i) diff |= (uint8_t)(x[i] ^ y[i]);
+  ok[e] = diff == 0 ? 1 : 0;
+}
+
+int wire_equal(bgn_ctx* c, hipStream_t s, const uint8_t* a, const uint8_t* b, size_t count, uint8_t* ok) {
+  hipLaunchKernelGGL(k_wire_equal, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, a, b, (size_t)2 * c->L, count,
+                     ok);
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+}  // namespace
+
+int bgn_check_decryption_proof_batch_dev(bgn_ctx* c, size_t count, const uint8_t* ct, const uint8_t* v_be, size_t v_len,
+                                         const uint8_t* r_be, size_t r_len, uint8_t* ok, void* stream) {
+  if (!c || (count && (!ct || !v_be || !r_be || !ok))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  DevBuf res;
+  int rc = res.alloc(count * 2 * (size_t)c->L);
+  if (rc) return rc;
+  // res := pk.EncryptWithRandomness(proof.Value, proof.Randomness); ct.C.Equals(res.C)   (gadgets.go:57-61)
+  if ((rc = bgn_encrypt_batch_dev(c, count, v_be, v_len, r_be, r_len, (uint8_t*)res.p, stream))) return rc;
+  if ((rc = wire_equal(c, (hipStream_t)stream, ct, (const uint8_t*)res.p, count, ok))) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));       // the scratch buffer is freed on return
+  return BGN_OK;
+}
+
+int bgn_check_plaintext_knowledge_batch_dev(bgn_ctx* c, size_t count, const uint8_t* ct, const uint8_t* nonce,
+                                            const uint8_t* c_be, size_t c_len, const uint8_t* dl_be, size_t dl_len,
+                                            uint8_t* ok, void* stream) {
+  if (!c || (count && (!ct || !nonce || !c_be || !dl_be || !ok))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t eb = count * 2 * (size_t)c->L;
+  DevBuf t1, t2;
+  int rc;
+  if ((rc = t1.alloc(eb)) || (rc = t2.alloc(eb))) return rc;
+  uint8_t* a = (uint8_t*)t1.p;
+  uint8_t* b = (uint8_t*)t2.p;
+  // res.PowBig(ct.C, nonce2); res.Mul(res, proof.Nonce.C)      (gadgets.go:69-71) — never blinded
+  if ((rc = bgn_multconst_batch_dev(c, count, 1, ct, c_be, c_len, nullptr, 0, a, stream))) return rc;
+  if ((rc = bgn_add_batch_dev(c, count, 1, a, nonce, nullptr, 0, b, stream))) return rc;
+  // G.PowBig(pk.P, proof.DL); G.Equals(res)                      (gadgets.go:73-76)
+  if ((rc = bgn_encrypt_batch_dev(c, count, dl_be, dl_len, nullptr, 0, a, stream))) return rc;
+  if ((rc = wire_equal(c, (hipStream_t)stream, a, b, count, ok))) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return BGN_OK;
+}
+
+int bgn_check_decryption_proof_batch(bgn_ctx* c, size_t count, const uint8_t* ct, const uint8_t* v_be, size_t v_len,
+                                     const uint8_t* r_be, size_t r_len, uint8_t* ok) {
+  if (!c || (count && (!ct || !v_be || !r_be || !ok))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  Staged S;
+  S.bufs.reserve(4);
+  uint8_t *dct = nullptr, *dv = nullptr, *dr = nullptr, *dok = nullptr;
+  UP(ct, count * 2 * (size_t)c->L, dct);
+  UP(v_be, count * v_len, dv);
+  UP(r_be, count * r_len, dr);
+  UP(nullptr, count, dok);
+  int rc = bgn_check_decryption_proof_batch_dev(c, count, dct, dv, v_len, dr, r_len, dok, nullptr);
+  if (rc) return rc;
+  return S.down(ok, dok, count);
+}
+
+int bgn_check_plaintext_knowledge_batch(bgn_ctx* c, size_t count, const uint8_t* ct, const uint8_t* nonce,
+                                        const uint8_t* c_be, size_t c_len, const uint8_t* dl_be, size_t dl_len,
+                                        uint8_t* ok) {
+  if (!c || (count && (!ct || !nonce || !c_be || !dl_be || !ok))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t eb = count * 2 * (size_t)c->L;
+  Staged S;
+  S.bufs.reserve(5);
+  uint8_t *dct = nullptr, *dn = nullptr, *dc = nullptr, *dd = nullptr, *dok = nullptr;
+  UP(ct, eb, dct);
+  UP(nonce, eb, dn);
+  UP(c_be, count * c_len, dc);
+  UP(dl_be, count * dl_len, dd);
+  UP(nullptr, count, dok);
+  int rc = bgn_check_plaintext_knowledge_batch_dev(c, count, dct, dn, dc, c_len, dd, dl_len, dok, nullptr);
+  if (rc) return rc;
+  return S.down(ok, dok, count);
+}
+
 double bgn_last_kernel_ms(bgn_ctx* c) {
   if (!c || !c->ev_valid) return -1.0;
   if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;

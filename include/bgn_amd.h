@@ -150,6 +150,21 @@ int bgn_poly_multconst_batch(bgn_ctx* ctx, size_t npoly, size_t d, size_t dp, in
 int bgn_poly_eval_batch(bgn_ctx* ctx, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
                         uint8_t* out);
 
+/* ok[i] = 1 iff ct[i] == P^v[i] * Q^r[i] (Element.Equals on the affine point).  v, r: any non-negative
+ * integers (sums of plaintexts / randomness exceed n, gadgets_test.go:37-39).
+ * Replaces CheckDecryptionProof (gadgets.go:57-61). */
+int bgn_check_decryption_proof_batch(bgn_ctx* ctx, size_t count, const uint8_t* ct, const uint8_t* v_be, size_t v_len,
+                                     const uint8_t* r_be, size_t r_len, uint8_t* ok);
+
+/* ok[i] = 1 iff ct[i]^c[i] * nonce[i] == P^dl[i], with c[i] the caller-computed challenge
+ * sha256(proof.Ct.C.Bytes() || proof.Nonce.C.Bytes()) as a big-endian integer (hash(), gadgets.go:80-96,
+ * stays on the host) and dl[i] = proof.DL.  Note the reference hashes the proof's own Ct but raises the
+ * ciphertext under test to the challenge (gadgets.go:67-70): pass that one as ct.
+ * Replaces CheckProofOfPlaintextKnoewledge (gadgets.go:65-77). */
+int bgn_check_plaintext_knowledge_batch(bgn_ctx* ctx, size_t count, const uint8_t* ct, const uint8_t* nonce,
+                                        const uint8_t* c_be, size_t c_len, const uint8_t* dl_be, size_t dl_len,
+                                        uint8_t* ok);
+
 /* ---- batch operations, device buffers (same semantics; asynchronous) -------- */
 int bgn_encrypt_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be,
                           size_t r_len, uint8_t* out, void* stream);
@@ -172,6 +187,13 @@ int bgn_poly_multconst_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d, size_t dp
                                  const uint8_t* p_be, size_t k_len, int k_per_poly, uint8_t* out, void* stream);
 int bgn_poly_eval_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
                             uint8_t* out, void* stream);
+
+/* The two proof checks synchronise the stream before returning (they own scratch buffers). */
+int bgn_check_decryption_proof_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* ct, const uint8_t* v_be,
+                                         size_t v_len, const uint8_t* r_be, size_t r_len, uint8_t* ok, void* stream);
+int bgn_check_plaintext_knowledge_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* ct, const uint8_t* nonce,
+                                            const uint8_t* c_be, size_t c_len, const uint8_t* dl_be, size_t dl_len,
+                                            uint8_t* ok, void* stream);
 
 /* ---- measurement hooks (used by bench.py; not part of the drop-in surface) --- */
 /* Milliseconds spent in the dominant kernel of the most recent *_dev call on

@@ -472,6 +472,54 @@ class PublicKey:
 
 
 # --------------------------------------------------------------------------
+# proofs (gadgets.go)
+# --------------------------------------------------------------------------
+@dataclass
+class ProofOfPlaintextKnowledge:
+    """gadgets.go:10-14"""
+    Ct: Ciphertext
+    Nonce: Ciphertext
+    DL: Optional[int]
+
+
+@dataclass
+class DecryptionProof:
+    """gadgets.go:18-21"""
+    Value: int
+    Randomness: int
+
+
+def proof_hash(proof: ProofOfPlaintextKnowledge, p: int) -> int:
+    """hash, gadgets.go:80-96: sha256 over Ct.C.Bytes() || Nonce.C.Bytes(), as a big-endian integer."""
+    import hashlib
+    return int.from_bytes(hashlib.sha256(elem_to_bytes(proof.Ct.C, p) + elem_to_bytes(proof.Nonce.C, p)).digest(), "big")
+
+
+def NewProofOfPlaintextKnowledge(pk: "PublicKey", sk: "SecretKey", v: int, z: int, nonce1: int) -> ProofOfPlaintextKnowledge:
+    """gadgets.go:32-54 with the nonce as an argument (the reference draws it, :33)."""
+    ct = pk.EncryptWithRandomness(v, z)
+    nonce = pk.EncryptWithRandomness(nonce1, 0)
+    proof = ProofOfPlaintextKnowledge(ct, nonce, None)
+    nonce2 = proof_hash(proof, pk.p)
+    DL = nonce1 + nonce2 * v
+    DL += sk.R * z * nonce2 * (pk.n // sk.Key)
+    proof.DL = DL % pk.n
+    return proof
+
+
+def CheckDecryptionProof(pk: "PublicKey", ct: Ciphertext, proof: DecryptionProof) -> bool:
+    """gadgets.go:57-61"""
+    return ct.C == pk.EncryptWithRandomness(proof.Value, proof.Randomness).C
+
+
+def CheckProofOfPlaintextKnoewledge(pk: "PublicKey", ct: Ciphertext, proof: ProofOfPlaintextKnowledge) -> bool:
+    """gadgets.go:65-77"""
+    nonce2 = proof_hash(proof, pk.p)
+    res = pt_add(pt_mul(ct.C, nonce2, pk.p), proof.Nonce.C, pk.p)
+    return pt_mul(pk.P, proof.DL, pk.p) == res
+
+
+# --------------------------------------------------------------------------
 # plaintext encoding (plaintext.go) — CPU side of the boundary; restated so the
 # poly-layer tests can drive MultConstPoly / alignPolyCiphertexts like poly_test.go
 # --------------------------------------------------------------------------

@@ -11,7 +11,7 @@
 //     e(C, P) (the makeL2 kernel), since e(C^sk, P) = (e(P,P)^sk)^m has the same
 //     m and a GT giant step costs 3 field products against ~20 for an affine
 //     G1 step;
-//   * the baby table lives in HBM as an open-addressing hash of 96-bit
+//   * the baby table lives in HBM as an open-addressing hash of 94-bit
 //     fingerprints of the canonical real part; because GT has norm 1,
 //     conj(g^j) = g^-j shares its real part with g^j, so one probe covers +-j
 //     (the parity of the imaginary part, stored with j, tells which), and the
@@ -139,7 +139,8 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
       unsigned long long key;
       u32 check;
       bsgs_fingerprint<NL>(key, check, re);
-      const u32 val = ((u32)j << 1) | (im.v[0] & 1u);
+      const u32 val = (u32)j;                                  // j <= S <= 2^31
+      check = (check & 0x7fffffffu) | ((im.v[0] & 1u) << 31);   // parity of the imaginary part rides in the check word
       unsigned long long h = bsgs_mix(key) & B.mask;
       for (;;) {
         const unsigned long long old = atomicCAS(&B.table[h].key, 0ull, key);
@@ -244,11 +245,11 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       for (;;) {
         const BsgsSlot s = B.table[h];
         if (s.key == 0ull) break;
-        if (s.key == key && s.check == check) {
+        if (s.key == key && ((s.check ^ check) & 0x7fffffffu) == 0u) {
           Fp<NL> im;
           fp_reduce8(im, a1, P);
-          const long long j = (long long)(s.val >> 1);
-          const bool same = ((im.v[0] & 1u) == (s.val & 1u)) || fp_is_zero_limbs(im);
+          const long long j = (long long)s.val;
+          const bool same = ((im.v[0] & 1u) == (s.check >> 31)) || fp_is_zero_limbs(im);
           const long long m = (long long)(i * B.stride) + (same ? j : -j);
           if (m >= 1 && (unsigned long long)m <= B.Mmax) {
             found = true;

@@ -409,18 +409,18 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   const uint64_t Mmax = B * B + B + 2;
   uint64_t S = 2;
   // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Take up to a
-  // quarter of the free HBM, at most 2^30 steps (34 GB; the slot's value field holds 31 bits);
-  // BGN_BSGS_MAX_LOG2 overrides (4..30).  Measured at T = 2^40, batch 2^16: 2^28 -> 2.9e5, 2^29 -> 4.1e5,
-  // 2^30 -> 5.1e5 decrypts/s; the build takes 0.3 - 0.65 s.
-  int cap_log2 = 30;
+  // third of the free HBM, at most 2^31 steps (69 GB; the slot's value field holds j <= 2^31);
+  // BGN_BSGS_MAX_LOG2 overrides (4..31).  Measured at T = 2^40, batch 2^16 (giant steps 2S apart):
+  // 2^30 -> 8.9e5 decrypts/s; the build takes 0.6 s at 2^30, twice that at 2^31.
+  int cap_log2 = 31;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > free_b / 4) cap_log2--;
+      while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > free_b / 3) cap_log2--;
   }
   if (const char* ev = getenv("BGN_BSGS_MAX_LOG2")) {
     const int v = atoi(ev);
-    if (v >= 4 && v <= 30) cap_log2 = v;
+    if (v >= 4 && v <= 31) cap_log2 = v;
   }
   while (S < Mmax + 1 && S < ((uint64_t)1 << cap_log2)) S <<= 1;
   // a probe resolves m = i*2S +- j with j in [0, S] (bsgs.hpp): giant steps are 2S apart, the last one

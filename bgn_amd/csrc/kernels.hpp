@@ -91,8 +91,8 @@ struct GtTabRoundArgs {
 // Discrete-log decryption and MultPoly accumulation (bsgs.hpp).
 struct BsgsSlot {
   unsigned long long key;   // 0 = empty; bit 63 forced to 1
-  uint32_t check;
-  uint32_t val;                  // (j << 1) | parity(im)
+  uint32_t check;                // 31 more fingerprint bits; bit 31 = parity(im)
+  uint32_t val;                  // j
 };
 
 struct BsgsParams {

@@ -26,6 +26,10 @@ struct PairingConsts {
   int pad;
   signed char naf[MAX_NAF];    // little-endian signed digits of n
   u32 pm2[MAX_EXP_LIMBS];      // p-2 as 28-bit limbs (little-endian)
+  // width-3 NAF of n (digits 0, +-1, +-3) for the windowed Miller loop of pairing.hpp; 0 digits = not used
+  int wnaf_len;
+  int pad2;
+  signed char wnaf[MAX_NAF];
 };
 
 }  // namespace bgn

@@ -277,6 +277,15 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     pm2.to_limbs28(pc.pm2, MAX_EXP_LIMBS);
     pc.l = l;
     pc.l_bits = BigU(l).bits();
+    {
+      // width-3 NAF for the windowed Miller loop (BGN_MILLER_WINDOW=0 keeps the plain NAF)
+      const char* ev = getenv("BGN_MILLER_WINDOW");
+      std::vector<signed char> wn = n.wnaf(3);
+      if (!(ev && ev[0] == '0') && (int)wn.size() <= MAX_NAF && wn.size() >= 4) {
+        pc.wnaf_len = (int)wn.size();
+        memcpy(pc.wnaf, wn.data(), wn.size());
+      }
+    }
     HIP_BRK(hipMalloc((void**)&c->d_consts, sizeof pc));
     HIP_BRK(hipMemcpy(c->d_consts, &pc, sizeof pc, hipMemcpyHostToDevice));
     c->pc_host = pc;
@@ -340,6 +349,7 @@ int build_secret_order_table(bgn_ctx* c) {
   if (!rem.is_zero() || q2.bits() < 2 || !(q2.w[0] & 1u)) return BGN_OK;   // not a factor of n: generic path
   std::vector<signed char> naf = q2.naf();
   PairingConsts pc = c->pc_host;
+  pc.wnaf_len = 0;                       // the table loops run over the plain NAF
   pc.naf_len = (int)naf.size();
   memset(pc.naf, 0, sizeof pc.naf);
   memcpy(pc.naf, naf.data(), naf.size());
@@ -514,7 +524,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
-  probe.take((size_t)3 * c->nl * so * 4);
+  probe.take((size_t)(mode == 1 ? 3 : 7) * c->nl * so * 4);
   if (r_be) {
     probe.soa(c->nl, so, false);
     probe.soa(c->nl, so, false);
@@ -525,7 +535,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   SoA2 A = cv.soa(c->nl, sa, true);
   SoA2 B = nb ? cv.soa(c->nl, sb, true) : c->key_P();
   SoA2 O = cv.soa(c->nl, so, false);
-  uint32_t* ws = (uint32_t*)cv.take((size_t)3 * c->nl * so * 4);
+  uint32_t* ws = (uint32_t*)cv.take((size_t)(mode == 1 ? 3 : 7) * c->nl * so * 4);   // 7: room for the windowed loop's (3A, f_3)
   SoA2 T1{}, T2{};
   if (r_be) {
     T1 = cv.soa(c->nl, so, false);
@@ -1334,17 +1344,19 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     A = w.g1(sa); Bv = w.g1(sb); E = w.gt(sp); O = w.gt(so);
-    pws = (uint32_t*)w.cv.take((size_t)3 * c->nl * sp * 4);
+    pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : 7) * c->nl * sp * 4);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
     }
   }
+  DevBuf tabbuf;                       // freed on every return path
   uint32_t* tab = nullptr;
   const size_t ts = round_up(cp * dt, 64);
   if (chunk) {
-    if (hipMalloc((void**)&tab, c->miller_steps * 3 * (size_t)c->nl * 4 * ts) != hipSuccess)
+    if (hipMalloc(&tabbuf.p, c->miller_steps * 3 * (size_t)c->nl * 4 * ts) != hipSuccess)
       return fail(BGN_E_NOMEM, "MultPoly line tables (%zu MB)", (c->miller_steps * 3 * (size_t)c->nl * 4 * ts) >> 20);
+    tab = (uint32_t*)tabbuf.p;
   }
   const KernelTable* kt = c->kt;
   kt->decode(s, c->d_params, a, c->L, na, A);
@@ -1380,11 +1392,8 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   c->ev_valid = true;
   c->last_kernel = chunk ? "k_fixedpair_build_batch + k_pairing<.,1>" : kt->pairing_kernel_name;
   kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, no, out);
-  if (tab) {
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipFree(tab));
-  }
   HIP_TRY(hipGetLastError());
+  if (tab) HIP_TRY(hipStreamSynchronize(s));   // the tables are released on return
   return BGN_OK;
 }
 

@@ -150,6 +150,27 @@ struct BigU {
       out[j] = v;
     }
   }
+  // Width-w non-adjacent form (w = 3: digits 0, +-1, +-3), little-endian; the top digit is positive.
+  std::vector<signed char> wnaf(int w) const {
+    std::vector<signed char> d;
+    BigU n = *this;
+    const int full = 1 << w, half = 1 << (w - 1);
+    while (!n.is_zero()) {
+      if (n.w[0] & 1u) {
+        int z = (int)(n.w[0] & (uint32_t)(full - 1));
+        if (z >= half) z -= full;
+        d.push_back((signed char)z);
+        if (z > 0)
+          n.sub(BigU((uint64_t)z));
+        else
+          n.add_small((uint32_t)(-z));
+      } else {
+        d.push_back(0);
+      }
+      n.shr1();
+    }
+    return d;
+  }
   // Non-adjacent form, little-endian digits in {-1,0,1}
   std::vector<signed char> naf() const {
     std::vector<signed char> d;

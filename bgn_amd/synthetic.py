@@ -23,33 +23,46 @@ def l1_ciphertext_pairs(pk, fx, count: int, seed: int, device):
     return a, b
 
 
-def miller_schedule(n: int):
-    """(#doubling steps, #addition steps) of the NAF Miller loop in pairing.hpp."""
-    d = []
+def _signed_digits(n: int, w: int):
+    d, full, half = [], 1 << w, 1 << (w - 1)
     while n:
         if n & 1:
-            z = 2 - (n & 3)
+            z = n & (full - 1)
+            if z >= half:
+                z -= full
             d.append(z)
             n -= z
         else:
             d.append(0)
         n >>= 1
+    return d
+
+
+def miller_schedule(n: int, window: int = 3):
+    """(#doubling steps, #addition steps, #extra F_p^2 products by f_3, #precomputation products) of the
+    Miller loop in pairing.hpp: width-3 NAF by default (miller_loop_w3), plain NAF with window = 2."""
+    d = _signed_digits(n, window)
     dbl = len(d) - 1
     add = sum(1 for i, x in enumerate(d[:-1]) if x and i != 0)
-    return dbl, add
+    threes = sum(1 for x in d[:-1] if abs(x) == 3)
+    pre = (18 + 17 + INVERSION_PRODUCTS + 8) if window > 2 else 0     # (3A, f_3): one doubling, one addition step, 1/Z, 4 + 4 products
+    return dbl, add, threes, pre
 
 
-def algorithmic_mads_per_pairing(fx, run: int = 16) -> int:
+# One F_p inversion by division steps (fpinv.hpp) costs about as much as 55 field products (measured, DESIGN.md 5).
+INVERSION_PRODUCTS = 55
+
+
+def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 3) -> int:
     """32x32->64 multiply-adds one pairing needs in this formulation:
     (#field products) * 2*NL^2 (schoolbook product + Montgomery reduction rows).
     The F_p inversion of the final exponentiation is shared by `run` pairings per lane."""
     p, n, l = int(fx["p"], 16), int(fx["n"], 16), int(fx["l"])
     nl = 38 if p.bit_length() > 600 else (19 if p.bit_length() > 300 else (10 if p.bit_length() > 100 else 3))
-    dbl, add = miller_schedule(n)
-    e = p - 2
-    inv = (e.bit_length()) + bin(e).count("1")          # square-and-multiply 1/N, once per run
+    dbl, add, threes, pre = miller_schedule(n, window)
     lb = l.bit_length()
     lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l
-    per_pairing = dbl * 18 + add * 17 + 2 * 2 + 3 + 5 + lpow + 2   # Miller + norms (both passes) + peel + conj(f)^2/N + ^l + from_mont
-    products = per_pairing + inv / run
+    # Miller + norms (both passes) + peel + conj(f)^2/N + ^l + from_mont
+    per_pairing = pre + dbl * 18 + add * 17 + threes * 3 + 2 * 2 + 3 + 5 + lpow + 2
+    products = per_pairing + INVERSION_PRODUCTS / run
     return int(products * 2 * nl * nl)

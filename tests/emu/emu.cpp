@@ -86,6 +86,24 @@ struct Emu {
     memcpy(out, re.v, 4 * NL);
     memcpy(out + NL, im.v, 4 * NL);
   }
+  static void pairing_w3(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    LFp<NL>* L = lds();
+    PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};
+    u32 win[4 * NL];
+    Win3 W{win, win + NL, win + 2 * NL, win + 3 * NL, 1, 0};
+    Miller<NL> S;
+    miller_loop_w3<NL>(S, L, op, W, C, P);
+    Fp<NL> N, ninv, g0, g1, re, im;
+    miller_norm<NL>(N, S, L, P);
+    l_store(L + 1, N);
+    fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);
+    final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
+    fp_from_mont<NL>(im, g1, P, L);
+    fp_from_mont<NL>(re, g0, P, L);
+    memcpy(out, re.v, 4 * NL);
+    memcpy(out + NL, im.v, 4 * NL);
+  }
   static void pairing_vm(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
@@ -355,6 +373,7 @@ extern "C" {
 int emu_decode(int nl, const u32* params, const uint8_t* wire, int Lb, u32* out, uint8_t* inf) { DISPATCH(nl, decode(params, wire, Lb, out, inf)) }
 int emu_encode(int nl, const u32* plain, int Lb, uint8_t inf, uint8_t* wire) { DISPATCH(nl, encode(plain, Lb, inf, wire)) }
 int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing(params, (const PairingConsts*)C, a, b, out)) }
+int emu_pairing_w3(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_w3(params, (const PairingConsts*)C, a, b, out)) }
 int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, out, oinf)) }
 int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, out, oinf)) }
 int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, out)) }

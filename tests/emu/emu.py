@@ -39,6 +39,22 @@ def nl_for(p: int) -> int:
     raise ValueError("field too large")
 
 
+def wnaf(n: int, w: int = 3):
+    """Width-w NAF, little-endian digits (hostbig.hpp BigU::wnaf)."""
+    d, full, half = [], 1 << w, 1 << (w - 1)
+    while n:
+        if n & 1:
+            z = n & (full - 1)
+            if z >= half:
+                z -= full
+            d.append(z)
+            n -= z
+        else:
+            d.append(0)
+        n >>= 1
+    return d
+
+
 def naf(n: int):
     d = []
     while n:
@@ -69,6 +85,8 @@ class Emu:
         buf = struct.pack("<iiQii", len(d), pm2.bit_length(), l, l.bit_length(), 0)
         buf += bytes((x & 0xFF) for x in d) + bytes(MAX_NAF - len(d))
         buf += struct.pack("<%dI" % MAX_EXP_LIMBS, *limbs(pm2, MAX_EXP_LIMBS))
+        wd = wnaf(n, 3)
+        buf += struct.pack("<ii", len(wd), 0) + bytes((x & 0xFF) for x in wd) + bytes(MAX_NAF - len(wd))
         assert len(buf) == self.lib.emu_consts_size() or True
         self.lib.emu_consts_size.restype = C.c_size_t
         assert len(buf) == self.lib.emu_consts_size(), (len(buf), self.lib.emu_consts_size())
@@ -104,6 +122,14 @@ class Emu:
         assert self.lib.emu_pairing(self.nl, self.params, self.consts, A, B, out) == 0
         if ia or ib:
             return (1).to_bytes(self.L, "big") + bytes(self.L)
+        return self.encode(out)
+
+    def pairing_w3(self, a: bytes, b: bytes) -> bytes:
+        """The width-3 windowed Miller loop (pairing.hpp miller_loop_w3) + final exponentiation."""
+        A, _ = self.decode(a)
+        B, _ = self.decode(b)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_pairing_w3(self.nl, self.params, self.consts, A, B, out) == 0
         return self.encode(out)
 
     def pairing_vm(self, a: bytes, b: bytes) -> bytes:

@@ -31,6 +31,18 @@ def test_emu_pairing(ctx):
         assert E.pairing(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
 
 
+def test_emu_windowed_miller_loop(ctx):
+    """The width-3 windowed Miller loop (digits 0, +-1, +-3 of n; 3A and f_3 precomputed per pairing) gives the
+    Mult golden vectors, for group orders whose top window digit is 1 and 3 alike."""
+    fx, E = ctx
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    digits = emu.wnaf(int(fx["n"], 16), 3)
+    assert set(digits) <= {0, 1, -1, 3, -3} and digits[-1] in (1, 3)
+    rows = [v for v in fx["mult"] if any(cts[v["a"]]) and any(cts[v["b"]])]
+    for v in rows[:4]:
+        assert E.pairing_w3(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+
+
 def test_emu_scalar_mult_exceptional_cases(ctx):
     """acc == +-base inside the ladder: k = n, n+-1, n+2 for P; multiples of q1 (+-1, +2) for Q of order q1."""
     fx, E = ctx

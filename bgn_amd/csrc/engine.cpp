@@ -86,6 +86,10 @@ struct bgn_ctx {
   BsgsParams bsgs{};
   bool have_tables = false;
 
+  // scratch of the fixed-base products' accumulation chains (grown on demand, like the arena)
+  uint8_t* chain_ws = nullptr;
+  size_t chain_ws_bytes = 0;
+
   // workspace arena (device)
   std::mutex mu;
   uint8_t* arena = nullptr;
@@ -192,6 +196,7 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   if (c->arena) (void)hipFree(c->arena);
+  if (c->chain_ws) (void)hipFree(c->chain_ws);
   if (c->d_params) (void)hipFree(c->d_params);
   if (c->d_consts) (void)hipFree(c->d_consts);
   if (c->d_keypts) (void)hipFree(c->d_keypts);
@@ -653,6 +658,7 @@ void g1_add_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, uint32_t* 
   a.count = count;
   a.run = run_for(count);
   a.negate_b = negate_b ? 1 : 0;
+  a.mont_out = 0;
   c->kt->g1_add(s, c->d_params, c->d_consts, a);
 }
 
@@ -771,12 +777,82 @@ bool fixed_fits(const bgn_ctx* c, size_t len) {
 // S <- P^x * Q^r (x_be or r_be may be null) by one table entry per window: one k_g1_fixed_step launch per
 // window over the whole batch, the running sums S kept in place (canonical Montgomery); the last launch writes
 // plain coordinates.  timed: record the context's events around one representative launch.
+// S (plain canonical, with identity flags) = P^x * Q^r from the window tables (x_be or r_be may be null).
+// The wx + wr windows are split over kFixedChains accumulation chains per element, all advanced by one
+// launch per step (G1FixedChainArgs): 17 launches of 4 additions per element instead of 67 of one, with the
+// lane's shared inversion amortised over four times as many additions; two addition passes sum the chains.
+// BGN_FIXED_CHAINS=1 selects the single-chain walk (one launch per window, running sums in place).
+constexpr int kFixedChains = 4;
+
 int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, const uint8_t* x_be, size_t x_len,
                        const uint8_t* r_be, size_t r_len, size_t count, bool timed) {
   const int wbits = c->fixed_wbits;
   const int wx = x_be ? (int)((x_len * 8 + wbits - 1) / wbits) : 0;
   const int wr = r_be ? (int)((r_len * 8 + wbits - 1) / wbits) : 0;
   const int steps = wx + wr;
+  bool chains = steps >= 2 * kFixedChains;
+  if (const char* ev = getenv("BGN_FIXED_CHAINS"))
+    if (ev[0] == '1') chains = false;
+  if (chains) {
+    const size_t pitch = round_up(count, 64);
+    const size_t slots = (size_t)kFixedChains * pitch;
+    const size_t fp_bytes = (size_t)c->nl * 4;
+    // X (chains*pitch points + flags), Y (2*pitch points + flags), prefix (chains*pitch F_p)
+    const size_t need = round_up(slots * 2 * fp_bytes, 256) + round_up(slots, 256) + round_up(2 * pitch * 2 * fp_bytes, 256) +
+                        round_up(2 * pitch, 256) + round_up(slots * fp_bytes, 256) + 4096;
+    if (need > c->chain_ws_bytes) {
+      if (c->chain_ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(c->chain_ws));
+        c->chain_ws = nullptr;
+        c->chain_ws_bytes = 0;
+      }
+      const size_t want = round_up(need + need / 8, 1 << 20);
+      if (hipMalloc((void**)&c->chain_ws, want) != hipSuccess) return fail(BGN_E_NOMEM, "fixed-base chain workspace");
+      c->chain_ws_bytes = want;
+    }
+    Carver cv(c->chain_ws);
+    SoA2 X = cv.soa(c->nl, slots, true);
+    SoA2 Y = cv.soa(c->nl, 2 * pitch, true);
+    uint32_t* pf = (uint32_t*)cv.take(slots * fp_bytes);
+    HIP_TRY(hipMemsetAsync(X.inf, 1, slots, s));                 // every chain starts from the identity
+    const int csteps = (steps + kFixedChains - 1) / kFixedChains;
+    const int probe = csteps > 1 ? csteps - 2 : 0;
+    for (int i = 0; i < csteps; ++i) {
+      G1FixedChainArgs a;
+      a.sx = X.c0; a.sy = X.c1; a.sinf = X.inf; a.ss = X.stride;
+      a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.wbits = wbits;
+      a.x = x_be; a.xlen = x_len; a.wx = wx;
+      a.r = r_be; a.rlen = r_len; a.wr = wr;
+      a.step = i; a.steps = csteps; a.chains = kFixedChains;
+      a.pitch = pitch; a.count = count;
+      a.prefix = pf; a.sp = slots;
+      a.run = run_for(slots);
+      if (timed && i == probe) HIP_TRY(hipEventRecord(c->ev0, s));
+      c->kt->g1_fixed_chain(s, c->d_params, c->d_consts, a);
+      if (timed && i == probe) HIP_TRY(hipEventRecord(c->ev1, s));
+    }
+    // chains 0,1 + chains 2,3 -> Y (Montgomery), then Y[0] + Y[1] -> S (plain)
+    auto add = [&](SoA2 A, size_t offa, SoA2 B, size_t offb, SoA2 O, size_t n, bool mont) {
+      G1AddArgs g;
+      g.ax = A.c0 + offa; g.ay = A.c1 + offa; g.ainf = A.inf + offa; g.sa = A.stride;
+      g.bx = B.c0 + offb; g.by = B.c1 + offb; g.binf = B.inf + offb; g.sb = B.stride;
+      g.ox = O.c0; g.oy = O.c1; g.oinf = O.inf; g.so = O.stride;
+      g.prefix = pf; g.sp = slots;
+      g.count = n;
+      g.run = run_for(n);
+      g.negate_b = 0;
+      g.mont_out = mont ? 1 : 0;
+      c->kt->g1_add(s, c->d_params, c->d_consts, g);
+    };
+    add(X, 0, X, 2 * pitch, Y, 2 * pitch, true);
+    add(Y, 0, Y, pitch, S, count, false);
+    if (timed) {
+      c->ev_valid = true;
+      c->last_kernel = "k_g1_fixed_chain";
+    }
+    return BGN_OK;
+  }
   HIP_TRY(hipMemsetAsync(S.c0, 0, (size_t)c->nl * S.stride * 4, s));
   HIP_TRY(hipMemsetAsync(S.c1, 0, (size_t)c->nl * S.stride * 4, s));
   HIP_TRY(hipMemsetAsync(S.inf, 1, S.stride, s));              // identity

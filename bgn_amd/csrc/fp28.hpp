@@ -133,6 +133,40 @@ __device__ __forceinline__ void v_load(Fp<NL>& r, const u32* __restrict__ lane_p
   for (int j = 0; j < NL; ++j) r.v[j] = lane_ptr[j];
 }
 
+// Two elements stored back to back at a per-lane pointer (a window-table entry: x limbs then y limbs, 8*NL
+// bytes, so every entry is 8-byte aligned and 16-byte aligned when NL is even): read with the widest vector
+// loads the alignment allows.  A lane's entry is its own run of cache lines; dword loads would touch each of
+// those lines 16 times per wave instruction stream, and 64 lanes * 304 B exceed the 16 KB L1 of a CU.
+struct alignas(16) GVec4 { u32 v[4]; };
+struct alignas(8) GVec2 { u32 v[2]; };
+
+template <int NL>
+__device__ __forceinline__ void v_load2(Fp<NL>& a, Fp<NL>& b, const u32* __restrict__ lane_ptr) {
+  u32 w[2 * NL];
+  if constexpr (NL % 2 == 0) {
+    const GVec4* q = reinterpret_cast<const GVec4*>(lane_ptr);
+#pragma unroll
+    for (int k = 0; k < NL / 2; ++k) {
+      const GVec4 t = q[k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[4 * k + i] = t.v[i];
+    }
+  } else {
+    const GVec2* q = reinterpret_cast<const GVec2*>(lane_ptr);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const GVec2 t = q[k];
+      w[2 * k] = t.v[0];
+      w[2 * k + 1] = t.v[1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    a.v[j] = w[j];
+    b.v[j] = w[NL + j];
+  }
+}
+
 template <int NL>
 __device__ __forceinline__ void fp_set(Fp<NL>& r, const u32* __restrict__ c) {
 #pragma unroll

@@ -28,6 +28,7 @@ struct G1AddArgs {
   size_t count;
   int run;                                                                  // elements per lane
   int negate_b;                                                             // subtraction
+  int mont_out;                                                             // write canonical Montgomery instead of plain
 };
 
 // One window step of the fixed-base products (ops.hpp): state[e] += tab[window][digit_window(k[e])].
@@ -41,6 +42,22 @@ struct G1FixedStepArgs {
   size_t count;
   int run;
   int plain_out;                                                            // write plain canonical (last step)
+};
+
+// Fixed-base product P^x * Q^r over `chains` independent accumulation chains per element (ops.hpp): the
+// windows of x (table P) and r (table Q) are numbered 0 .. wx+wr-1, chain c takes windows c*steps .. c*steps +
+// steps-1, and one launch adds window c*steps + step into state[c*pitch + e] for every chain at once.  A lane's
+// run then spans chains as well as elements, so the shared inversion is amortised over `chains` times more
+// additions than with one chain; the chain sums are added up afterwards.
+struct G1FixedChainArgs {
+  uint32_t* sx; uint32_t* sy; uint8_t* sinf; size_t ss;                     // state, canonical Montgomery, chains*pitch slots
+  const uint32_t* tabP; const uint32_t* tabQ; int wbits;
+  const uint8_t* x; size_t xlen; int wx;                                    // x == null: wx = 0
+  const uint8_t* r; size_t rlen; int wr;                                    // r == null: wr = 0
+  int step; int steps; int chains;
+  size_t pitch; size_t count;                                               // count <= pitch, pitch a multiple of 64
+  uint32_t* prefix; size_t sp;
+  int run;
 };
 
 // Round k of the table construction: tab[w][2^k + j] = tab[w][j] + tab[w][2^k] for j in [1, 2^k), w < windows.
@@ -170,6 +187,7 @@ struct KernelTable {
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);
   void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
   void (*g1_fixed_step)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedStepArgs a);
+  void (*g1_fixed_chain)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedChainArgs a);
   void (*g1_tab_round)(hipStream_t s, const void* params, const PairingConsts* consts, G1TabRoundArgs a);
   // SoA element w*wbits + k (canonical Montgomery) -> table entry (w, 2^k)
   void (*tab_scatter_pow)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count, int wbits,

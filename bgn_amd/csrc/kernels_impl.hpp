@@ -261,6 +261,13 @@ k_g1_fixed_step(const FpParams<NL>* __restrict__ P, const PairingConsts* __restr
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
+k_g1_fixed_chain(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1FixedChainArgs A) {
+  __shared__ LFp<NL> L[2];
+  g1_add_run<NL>(G1IoFixedChain<NL>{A}, (size_t)A.chains * A.pitch, A.run, A.prefix, A.sp, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
 k_g1_tab_round(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1TabRoundArgs A) {
   __shared__ LFp<NL> L[2];
   g1_add_run<NL>(G1IoTabRound<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
@@ -493,6 +500,14 @@ static void launch_g1_fixed_step(hipStream_t s, const void* params, const Pairin
                      consts, a);
 }
 
+static void launch_g1_fixed_chain(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedChainArgs a) {
+  const size_t total = (size_t)a.chains * a.pitch;
+  if (!a.count || !total) return;
+  const size_t lanes = (total + a.run - 1) / a.run;
+  hipLaunchKernelGGL(k_g1_fixed_chain<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     consts, a);
+}
+
 static void launch_g1_tab_round(hipStream_t s, const void* params, const PairingConsts* consts, G1TabRoundArgs a) {
   if (!a.count) return;
   const size_t lanes = (a.count + a.run - 1) / a.run;
@@ -607,6 +622,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_g1_add,
       launch_g1_mul,
       launch_g1_fixed_step,
+      launch_g1_fixed_chain,
       launch_g1_tab_round,
       launch_tab_scatter_pow,
       launch_soa_to_entries,

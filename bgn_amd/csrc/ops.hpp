@@ -185,8 +185,7 @@ __device__ __forceinline__ void gt_fixed_lane(const GtFixedArgs& A, size_t e, bo
     if (__ballot(d != 0)) {
       const u32* ent = A.tab + ((((size_t)w) << A.wbits) + d) * (size_t)(2 * NL);
       Fp<NL> b0, b1;
-      v_load(b0, ent);
-      v_load(b1, ent + NL);
+      v_load2(b0, b1, ent);
       gt_set_multiplier<NL>(L, b0, b1);
       gt_acc_mul<NL>(A0, A1, d != 0, L, P);
     }
@@ -244,12 +243,10 @@ __device__ __forceinline__ void gt_tab_round_lane(const GtTabRoundArgs& A, size_
   u32* eo = A.tab + ((w << A.wbits) + ((size_t)1 << A.k) + j) * (size_t)(2 * NL);
   AFp<NL> A0, A1;
   Fp<NL> b0, b1;
-  v_load(b0, ea);
-  v_load(b1, ea + NL);
+  v_load2(b0, b1, ea);
   a_store(A0, b0);
   a_store(A1, b1);
-  v_load(b0, eb);
-  v_load(b1, eb + NL);
+  v_load2(b0, b1, eb);
   gt_set_multiplier<NL>(L, b0, b1);
   gt_acc_mul<NL>(A0, A1, true, L, P);
   Fp<NL> r, o;
@@ -323,10 +320,17 @@ struct G1IoSoA {
   __device__ __forceinline__ void store(size_t e, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>* L,
                                         const FpParams<NL>* __restrict__ P) const {
     Fp<NL> o;
-    fp_from_mont<NL>(o, x3, P, L + 1);
-    g_store(A.ox, A.so, e, o);
-    fp_from_mont<NL>(o, y3, P, L + 1);
-    g_store(A.oy, A.so, e, o);
+    if (A.mont_out) {
+      fp_reduce8(o, x3, P);
+      g_store(A.ox, A.so, e, o);
+      fp_reduce8(o, y3, P);
+      g_store(A.oy, A.so, e, o);
+    } else {
+      fp_from_mont<NL>(o, x3, P, L + 1);
+      g_store(A.ox, A.so, e, o);
+      fp_from_mont<NL>(o, y3, P, L + 1);
+      g_store(A.oy, A.so, e, o);
+    }
     A.oinf[e] = inf ? 1 : 0;
   }
 };
@@ -334,8 +338,7 @@ struct G1IoSoA {
 // Table entry -> coordinates; an all-zero entry stands for the identity (never a subgroup point).
 template <int NL>
 __device__ __forceinline__ void tab_load(Fp<NL>& x, Fp<NL>& y, bool& inf, const u32* __restrict__ ent) {
-  v_load(x, ent);
-  v_load(y, ent + NL);
+  v_load2(x, y, ent);
   inf = fp_is_zero_limbs(x) && fp_is_zero_limbs(y);
 }
 
@@ -369,6 +372,40 @@ struct G1IoFixedStep {
       g_store(A.sy, A.ss, e, o);
     }
     A.sinf[e] = inf ? 1 : 0;
+  }
+};
+
+// (b') The same over several accumulation chains per element (G1FixedChainArgs): virtual element
+// v = c*pitch + e adds window c*steps + step of element e into state[v].
+template <int NL>
+struct G1IoFixedChain {
+  const G1FixedChainArgs& A;
+  __device__ __forceinline__ void loadA(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    g_load(x, A.sx, A.ss, v);
+    g_load(y, A.sy, A.ss, v);
+    inf = A.sinf[v] != 0;
+  }
+  __device__ __forceinline__ void loadB(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__) const {
+    const size_t c = v / A.pitch, e = v - c * A.pitch;
+    const int gw = (int)c * A.steps + A.step;
+    const bool live = e < A.count && gw < A.wx + A.wr;
+    const bool isx = gw < A.wx;
+    const int lw = isx ? gw : gw - A.wx;
+    u32 d = 0;
+    if (live) d = isx ? scalar_window(A.x + e * A.xlen, A.xlen, A.wbits, lw) : scalar_window(A.r + e * A.rlen, A.rlen, A.wbits, lw);
+    // entry (lw, 0) is all zero and always mapped: dead lanes and zero digits read it and add the identity
+    const u32* tab = isx ? A.tabP : A.tabQ;
+    tab_load<NL>(x, y, inf, tab + ((((size_t)(live ? lw : 0)) << A.wbits) + d) * (size_t)(2 * NL));
+    inf = inf || d == 0;
+  }
+  __device__ __forceinline__ void store(size_t v, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>*,
+                                        const FpParams<NL>* __restrict__ P) const {
+    Fp<NL> o;
+    fp_reduce8(o, x3, P);
+    g_store(A.sx, A.ss, v, o);
+    fp_reduce8(o, y3, P);
+    g_store(A.sy, A.ss, v, o);
+    A.sinf[v] = inf ? 1 : 0;
   }
 };
 

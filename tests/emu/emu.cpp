@@ -159,6 +159,7 @@ struct Emu {
     A.count = st - (T - 1);       // elements j*T for j < count are in range; others have no lane here
     A.run = count;
     A.negate_b = negate_b;
+    A.mont_out = 0;
     g1_add_batch_lane<NL>(A, lds(), C, P);
     for (int j = 0; j < count; ++j) {
       const size_t e = (size_t)j * T;

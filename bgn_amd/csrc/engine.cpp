@@ -649,7 +649,8 @@ struct Ws {   // workspace planner: two passes (size, then carve)
 };
 
 // out (plain, with inf) = A (+/-) B on G1, both canonical Montgomery
-void g1_add_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, uint32_t* prefix, size_t count, bool negate_b) {
+void g1_add_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, uint32_t* prefix, size_t count, bool negate_b,
+                   bool plain = false) {
   G1AddArgs a;
   a.ax = A.c0; a.ay = A.c1; a.ainf = A.inf; a.sa = A.stride;
   a.bx = B.c0; a.by = B.c1; a.binf = B.inf; a.sb = B.stride;
@@ -659,6 +660,7 @@ void g1_add_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, uint32_t* 
   a.run = run_for(count);
   a.negate_b = negate_b ? 1 : 0;
   a.mont_out = 0;
+  a.plain_io = plain ? 1 : 0;
   c->kt->g1_add(s, c->d_params, c->d_consts, a);
 }
 
@@ -843,6 +845,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
       g.run = run_for(n);
       g.negate_b = 0;
       g.mont_out = mont ? 1 : 0;
+      g.plain_io = 0;
       c->kt->g1_add(s, c->d_params, c->d_consts, g);
     };
     add(X, 0, X, 2 * pitch, Y, 2 * pitch, true);
@@ -999,11 +1002,17 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
     }
   }
   const KernelTable* kt = c->kt;
-  kt->decode(s, c->d_params, a, c->L, count, A);
-  kt->decode(s, c->d_params, b, c->L, count, B);
+  if (level == 1) {
+    // wire-to-wire G1 addition runs on plain residues: no Montgomery conversion of operands or sum (ops.hpp)
+    kt->decode_plain(s, c->d_params, a, c->L, count, A);
+    kt->decode_plain(s, c->d_params, b, c->L, count, B);
+  } else {
+    kt->decode(s, c->d_params, a, c->L, count, A);
+    kt->decode(s, c->d_params, b, c->L, count, B);
+  }
   HIP_TRY(hipEventRecord(c->ev0, s));
   if (level == 1) {
-    g1_add_launch(c, s, A, B, O, prefix, count, subtract);
+    g1_add_launch(c, s, A, B, O, prefix, count, subtract, true);
     HIP_TRY(hipEventRecord(c->ev1, s));
     c->last_kernel = "k_g1_add";
     if (r_be) blind_l1(c, s, O, r_be, r_len, T1, T2, prefix, count);

@@ -29,6 +29,7 @@ struct G1AddArgs {
   int run;                                                                  // elements per lane
   int negate_b;                                                             // subtraction
   int mont_out;                                                             // write canonical Montgomery instead of plain
+  int plain_io;                                                             // operands and sum are plain residues (decode_plain)
 };
 
 // One window step of the fixed-base products (ops.hpp): state[e] += tab[window][digit_window(k[e])].
@@ -156,6 +157,8 @@ struct KernelTable {
 
   // wire bytes (2L per element, big-endian) -> SoA, canonical Montgomery form.
   void (*decode)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out);
+  // wire bytes -> SoA, canonical plain residues (no Montgomery conversion): operands of a plain_io addition.
+  void (*decode_plain)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out);
   // SoA canonical *plain* (non-Montgomery) -> wire bytes; inf != null writes zeros for identity.
   void (*encode)(hipStream_t s, const uint8_t* inf, const uint32_t* c0, const uint32_t* c1, size_t stride, int L,
                  size_t count, uint8_t* wire);

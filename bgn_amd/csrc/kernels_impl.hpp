@@ -20,7 +20,7 @@ constexpr int NL_ = BGN_NL;
 
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
-k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, SoA2 out) {
+k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, SoA2 out, int plain) {
   __shared__ LFp<NL> stage;
   __shared__ WireStage<NL> ws;
   const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
@@ -34,6 +34,11 @@ k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, i
   wire_to_limbs<NL>(x, src, L);
   wire_to_limbs<NL>(y, src + L, L);
   if (out.inf) out.inf[e] = (fp_is_zero_limbs(x) && fp_is_zero_limbs(y)) ? 1 : 0;
+  if (plain) {                              // wave-uniform
+    g_store<NL>(out.c0, out.stride, e, x);
+    g_store<NL>(out.c1, out.stride, e, y);
+    return;
+  }
   Fp<NL> m;
   fp_to_mont<NL>(m, x, P, &stage);
   g_store<NL>(out.c0, out.stride, e, m);
@@ -409,7 +414,13 @@ static inline unsigned grid_for(size_t count) { return (unsigned)((count + FP_BL
 static void launch_decode(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out) {
   if (!count) return;
   hipLaunchKernelGGL(k_decode<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire,
-                     L, count, out);
+                     L, count, out, 0);
+}
+
+static void launch_decode_plain(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_decode<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire,
+                     L, count, out, 1);
 }
 
 static void launch_encode(hipStream_t s, const uint8_t* inf, const uint32_t* c0, const uint32_t* c1, size_t stride,
@@ -614,6 +625,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       sizeof(FpParams<NL_>),
       "k_pairing<" BGN_STR(BGN_NL) ", 0>",
       launch_decode,
+      launch_decode_plain,
       launch_encode,
       launch_pairing,
       launch_fixedpair_build,

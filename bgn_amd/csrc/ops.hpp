@@ -273,8 +273,9 @@ __device__ __forceinline__ void gt_tab_round_lane(const GtTabRoundArgs& A, size_
 // case codes
 constexpr int G1C_ADD = 0, G1C_DBL = 1, G1C_INF = 2, G1C_A = 3, G1C_B = 4;
 
-// Classify and return the denominator (canonical inputs <1).  d <2 (never 0 mod p).
-template <int NL>
+// Classify and return the denominator (canonical inputs <1).  d <2 (never 0 mod p).  The neutral
+// denominator of the special cases is the multiplicative identity of the inputs' representation.
+template <int NL, bool PLAIN = false>
 __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp<NL>& y1, bool inf1,
                                            const Fp<NL>& x2, const Fp<NL>& y2, bool inf2,
                                            const FpParams<NL>* __restrict__ P) {
@@ -289,7 +290,12 @@ __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp
   fp_dbl(dd, y1);                           // <2
   fp_sub<1>(da, x2, x1, P);                 // <2, != 0 when x1 != x2
   Fp<NL> one;
-  fp_set(one, P->one);
+  if constexpr (PLAIN) {
+    fp_zero(one);
+    one.v[0] = 1;
+  } else {
+    fp_set(one, P->one);
+  }
   fp_select(d, cs == G1C_ADD, da, one);
   fp_select(d, cs == G1C_DBL, dd, d);
   return cs;
@@ -320,7 +326,7 @@ struct G1IoSoA {
   __device__ __forceinline__ void store(size_t e, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>* L,
                                         const FpParams<NL>* __restrict__ P) const {
     Fp<NL> o;
-    if (A.mont_out) {
+    if (A.mont_out || A.plain_io) {       // same representation out as in: reduce only
       fp_reduce8(o, x3, P);
       g_store(A.ox, A.so, e, o);
       fp_reduce8(o, y3, P);
@@ -446,7 +452,16 @@ struct G1IoTabRound {
 
 // The run itself: `run` additions per lane (element j*T + t), one inversion per lane.
 // prefix: workspace of one F_p per element, SoA with stride sp.
-template <int NL, class IO>
+//
+// PLAIN: the coordinates are plain residues, not Montgomery forms, in and out.  The Montgomery product
+// mm(a, b) = a*b/R of a plain value with a Montgomery form is the plain product, so with d, num plain:
+//   prefix products acc_k = prod d_i * R^(1-k) (from acc_0 = R), inv = R^2/acc, peeled 1/d_k comes out as
+//   R^2/d_k, lambda*R = mm(R^2/d, num), lambda = mm(lambda*R, 1), x3 = mm(lambda*R, lambda) - x1 - x2,
+//   y3 = mm(lambda*R, x1 - x3) - y1
+// which is the same seven products as in Montgomery form (one extra mm by 1, one squaring less... the square
+// becomes a product) but needs no conversion of the four input coordinates and the two output coordinates:
+// six products fewer per addition for wire-to-wire EAdd / ESub.
+template <int NL, class IO, bool PLAIN = false>
 __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, u32* __restrict__ prefix, size_t sp,
                                            LFp<NL>* L, const PairingConsts* __restrict__ C,
                                            const FpParams<NL>* __restrict__ P) {
@@ -463,7 +478,7 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
       bool i1, i2;
       io.loadA(e, x1, y1, i1, P);
       io.loadB(e, x2, y2, i2, P);
-      g1_classify<NL>(d, x1, y1, i1, x2, y2, i2, P);
+      g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P);
       g_store(prefix, sp, e, acc);
       l_store(L, acc);
       fp_mul(acc, L, d, P);                 // <2
@@ -480,7 +495,7 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
       bool i1, i2;
       io.loadA(e, x1, y1, i1, P);
       io.loadB(e, x2, y2, i2, P);
-      const int cs = g1_classify<NL>(d, x1, y1, i1, x2, y2, i2, P);
+      const int cs = g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P);
       Fp<NL> dinv;
       {
         Fp<NL> pf;
@@ -494,25 +509,41 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
       fp_sub<1>(num, y2, y1, P);            // <2
       if (__ballot(cs == G1C_DBL)) {
         Fp<NL> xx, t3;
-        fp_sqrv(xx, x1, P, L + 1);          // <2
+        if constexpr (PLAIN) {
+          fp_to_mont<NL>(t3, x1, P, L + 1);   // x1*R
+          fp_mulv(xx, t3, x1, P, L + 1);      // x1^2, plain <2
+        } else {
+          fp_sqrv(xx, x1, P, L + 1);        // <2
+        }
         fp_dbl(t3, xx);
         fp_add(t3, t3, xx);                 // <6
         Fp<NL> one;
-        fp_set(one, P->one);
+        if constexpr (PLAIN) {
+          fp_zero(one);
+          one.v[0] = 1;
+        } else {
+          fp_set(one, P->one);
+        }
         fp_add(t3, t3, one);                // <7
         fp_select(num, cs == G1C_DBL, t3, num);
       }
       l_store(L + 1, dinv);
       Fp<NL> lam;
-      fp_mul(lam, L + 1, num, P);           // lambda <2   (14)
+      fp_mul(lam, L + 1, num, P);           // lambda (Montgomery form) <2   (14)
       Fp<NL> x3, y3;
-      fp_sqrv(x3, lam, P, L + 1);           // <2 ; L1 = lambda
+      if constexpr (PLAIN) {
+        Fp<NL> lp;
+        fp_from_mont<NL>(lp, lam, P, L + 1);  // lambda, plain <1 ; L1 = lambda*R
+        fp_mul(x3, L + 1, lp, P);             // lambda^2, plain <2
+      } else {
+        fp_sqrv(x3, lam, P, L + 1);         // <2 ; L1 = lambda
+      }
       fp_sub<1>(x3, x3, x1, P);             // <3
       fp_sub<1>(x3, x3, x2, P);             // <4
       fp_sub<4>(y3, x1, x3, P);             // <5
       fp_mul(y3, L + 1, y3, P);             // <2   (10)
       fp_sub<1>(y3, y3, y1, P);             // <3
-      // select special cases (all in Montgomery form)
+      // select special cases (same representation as the inputs)
       const bool isA = cs == G1C_A, isB = cs == G1C_B;
       fp_select(x3, isA, x1, x3);
       fp_select(y3, isA, y1, y3);
@@ -526,7 +557,10 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
 template <int NL>
 __device__ __forceinline__ void g1_add_batch_lane(const G1AddArgs& A, LFp<NL>* L, const PairingConsts* __restrict__ C,
                                                   const FpParams<NL>* __restrict__ P) {
-  g1_add_run<NL>(G1IoSoA<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
+  if (A.plain_io)
+    g1_add_run<NL, G1IoSoA<NL>, true>(G1IoSoA<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
+  else
+    g1_add_run<NL, G1IoSoA<NL>, false>(G1IoSoA<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
 }
 
 // ===========================================================================

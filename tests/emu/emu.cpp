@@ -132,7 +132,7 @@ struct Emu {
   }
   // count elements processed by ONE lane as a run (exercises the batched inversion)
   static void g1_add(const u32* params, const PairingConsts* C, const u32* a, const uint8_t* ainf, const u32* b,
-                     const uint8_t* binf, int count, int negate_b, u32* out, uint8_t* oinf) {
+                     const uint8_t* binf, int count, int negate_b, int plain, u32* out, uint8_t* oinf) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     // SoA with stride = count ; with one thread the kernel's element index is j*T + t, T = gridDim*256 = 256:
     // emulate by giving each run element its own "row" of 256 (only column 0 used)
@@ -160,6 +160,7 @@ struct Emu {
     A.run = count;
     A.negate_b = negate_b;
     A.mont_out = 0;
+    A.plain_io = plain;
     g1_add_batch_lane<NL>(A, lds(), C, P);
     for (int j = 0; j < count; ++j) {
       const size_t e = (size_t)j * T;
@@ -376,7 +377,7 @@ int emu_encode(int nl, const u32* plain, int Lb, uint8_t inf, uint8_t* wire) { D
 int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing(params, (const PairingConsts*)C, a, b, out)) }
 int emu_pairing_w3(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_w3(params, (const PairingConsts*)C, a, b, out)) }
 int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, out, oinf)) }
-int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, out, oinf)) }
+int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, int plain, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, plain, out, oinf)) }
 int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, out)) }
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
 int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }

@@ -169,23 +169,31 @@ class Emu:
         assert self.lib.emu_g1_mul(self.nl, self.params, self.consts, B, ib, kb, C.c_size_t(klen), out, C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 
-    def g1_add(self, a_list, b_list, subtract=False):
-        """One lane processing the whole list as a single batched-inversion run."""
+    def decode_plain(self, wire: bytes):
+        """wire -> plain limbs (k_decode with plain = 1): no Montgomery conversion."""
+        x, y = int.from_bytes(wire[:self.L], "big"), int.from_bytes(wire[self.L:], "big")
+        return limbs(x, self.nl) + limbs(y, self.nl), int(x == 0 and y == 0)
+
+    def g1_add(self, a_list, b_list, subtract=False, plain=False):
+        """One lane processing the whole list as a single batched-inversion run; plain = the representation
+        EAdd / ESub use (plain residues in and out, ops.hpp g1_add_run<PLAIN>)."""
         n = len(a_list)
+        dec = self.decode_plain if plain else self.decode
         A = (C.c_uint32 * (2 * self.nl * n))()
         B = (C.c_uint32 * (2 * self.nl * n))()
         ai = (C.c_uint8 * n)()
         bi = (C.c_uint8 * n)()
         for j in range(n):
-            x, i = self.decode(a_list[j])
+            x, i = dec(a_list[j])
             A[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
             ai[j] = i
-            x, i = self.decode(b_list[j])
+            x, i = dec(b_list[j])
             B[2 * self.nl * j:2 * self.nl * (j + 1)] = list(x)
             bi[j] = i
         out = (C.c_uint32 * (2 * self.nl * n))()
         oi = (C.c_uint8 * n)()
-        assert self.lib.emu_g1_add(self.nl, self.params, self.consts, A, ai, B, bi, n, 1 if subtract else 0, out, oi) == 0
+        assert self.lib.emu_g1_add(self.nl, self.params, self.consts, A, ai, B, bi, n, 1 if subtract else 0,
+                                   1 if plain else 0, out, oi) == 0
         res = []
         for j in range(n):
             pl = (C.c_uint32 * (2 * self.nl))(*out[2 * self.nl * j:2 * self.nl * (j + 1)])

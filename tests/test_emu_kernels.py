@@ -66,6 +66,9 @@ def test_emu_g1_add_run(ctx):
     b = [cts[v["b"]] for v in fx["l1"]]
     assert [x.hex() for x in E.g1_add(a, b)] == [v["add"] for v in fx["l1"]]
     assert [x.hex() for x in E.g1_add(a, b, True)] == [v["sub"] for v in fx["l1"]]
+    # the representation EAdd / ESub run in: plain residues in and out, no Montgomery conversions
+    assert [x.hex() for x in E.g1_add(a, b, plain=True)] == [v["add"] for v in fx["l1"]]
+    assert [x.hex() for x in E.g1_add(a, b, True, plain=True)] == [v["sub"] for v in fx["l1"]]
 
 
 def test_emu_gt_ops(ctx):

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "bgn_poly_mult_batch": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p]),
     "bgn_poly_multconst_batch": (C.c_int, [_ctx, _sz, _sz, _sz, C.c_int, _u8p, _u8p, _sz, C.c_int, _u8p]),
     "bgn_poly_eval_batch": (C.c_int, [_ctx, _sz, _sz, C.c_int, _u8p, C.c_uint64, _u8p]),
+    "bgn_validate_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p]),
+    "bgn_validate_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, C.c_void_p]),
     "bgn_check_decryption_proof_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p, _sz, _u8p, _sz, _u8p]),
     "bgn_check_plaintext_knowledge_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, _sz, _u8p, _sz, _u8p]),
     "bgn_encrypt_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _sz, _u8p, _sz, _u8p, C.c_void_p]),

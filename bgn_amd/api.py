@@ -171,6 +171,13 @@ class Engine:
               "bgn_poly_mult_batch")
         return out
 
+    def validate(self, level: int, a: BytesLike) -> np.ndarray:
+        """1 per element that is a valid encoding (range; on the curve / norm 1), 0 otherwise."""
+        A = _as_u8(a, self.elem_bytes)
+        ok = np.zeros(len(A), dtype=np.uint8)
+        check(self._lib.bgn_validate_batch(self._h, len(A), level, _ptr(A), _ptr(ok)), "bgn_validate_batch")
+        return ok
+
     def poly_multconst(self, npoly: int, d: int, level: int, ct: BytesLike, coeffs, shared: bool = True) -> np.ndarray:
         """MultConstPoly of `npoly` ciphertext polynomials (d coefficients each) by encoded plaintext
         constants: `coeffs` is one list of dp digits (shared) or npoly lists.  Returns npoly*(d+dp) rows."""

@@ -400,7 +400,7 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
 
 // forward declarations of launch helpers defined further down
 namespace {
-void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b);
+void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b, bool plain_a = false);
 void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
                    size_t count);
 }
@@ -881,13 +881,14 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
   return BGN_OK;
 }
 
-void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b) {
+void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b, bool plain_a) {
   GtMulArgs a;
   a.a0 = A.c0; a.a1 = A.c1; a.sa = A.stride;
   a.b0 = B.c0; a.b1 = B.c1; a.sb = B.stride;
   a.o0 = O.c0; a.o1 = O.c1; a.so = O.stride;
   a.count = count;
   a.conj_b = conj_b ? 1 : 0;
+  a.plain_a = plain_a ? 1 : 0;
   c->kt->gt_mul(s, c->d_params, a);
 }
 
@@ -1007,7 +1008,8 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
     kt->decode_plain(s, c->d_params, a, c->L, count, A);
     kt->decode_plain(s, c->d_params, b, c->L, count, B);
   } else {
-    kt->decode(s, c->d_params, a, c->L, count, A);
+    // wire-to-wire GT product: a stays plain, only b goes to Montgomery form (ops.hpp gt_mul_lane)
+    kt->decode_plain(s, c->d_params, a, c->L, count, A);
     kt->decode(s, c->d_params, b, c->L, count, B);
   }
   HIP_TRY(hipEventRecord(c->ev0, s));
@@ -1018,7 +1020,7 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
     if (r_be) blind_l1(c, s, O, r_be, r_len, T1, T2, prefix, count);
     kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
   } else {
-    gt_mul_launch(c, s, A, B, O, count, subtract);
+    gt_mul_launch(c, s, A, B, O, count, subtract, true);
     HIP_TRY(hipEventRecord(c->ev1, s));
     c->last_kernel = "k_gt_mul";
     if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);
@@ -1605,6 +1607,32 @@ int bgn_poly_eval_batch(bgn_ctx* c, size_t npoly, size_t d, int level, const uin
   int rc = bgn_poly_eval_batch_dev(c, npoly, d, level, dct, base, dout, nullptr);
   if (rc) return rc;
   return S.down(out, dout, npoly * E);
+}
+
+// ---- input validation ---------------------------------------------------------------------------
+int bgn_validate_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* in, uint8_t* ok, void* stream) {
+  if (!c || (count && (!in || !ok))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!count) return BGN_OK;
+  if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
+  HIP_TRY(hipSetDevice(c->device));
+  c->kt->validate((hipStream_t)stream, c->d_params, in, c->L, count, level, ok);
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
+}
+
+int bgn_validate_batch(bgn_ctx* c, size_t count, int level, const uint8_t* in, uint8_t* ok) {
+  if (!c || (count && (!in || !ok))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  Staged S;
+  S.bufs.reserve(2);
+  uint8_t *din = nullptr, *dok = nullptr;
+  UP(in, count * 2 * (size_t)c->L, din);
+  UP(nullptr, count, dok);
+  int rc = bgn_validate_batch_dev(c, count, level, din, dok, nullptr);
+  if (rc) return rc;
+  return S.down(ok, dok, count);
 }
 
 // ---- proof verification (gadgets.go) --------------------------------------------------------------

@@ -85,6 +85,7 @@ struct GtMulArgs {
   uint32_t* o0; uint32_t* o1; size_t so;                                    // plain canonical out
   size_t count;
   int conj_b;
+  int plain_a;                                                              // a holds plain residues (decode_plain)
 };
 struct GtPowArgs {
   const uint32_t* a0; const uint32_t* a1; size_t sa;                        // sa == 1: broadcast base
@@ -159,6 +160,8 @@ struct KernelTable {
   void (*decode)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out);
   // wire bytes -> SoA, canonical plain residues (no Montgomery conversion): operands of a plain_io addition.
   void (*decode_plain)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out);
+  // ok[e] = 1 iff wire element e is a valid encoding for the level (range; on the curve / norm 1).
+  void (*validate)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int level, uint8_t* ok);
   // SoA canonical *plain* (non-Montgomery) -> wire bytes; inf != null writes zeros for identity.
   void (*encode)(hipStream_t s, const uint8_t* inf, const uint32_t* c0, const uint32_t* c1, size_t stride, int L,
                  size_t count, uint8_t* wire);

@@ -46,6 +46,58 @@ k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, i
   g_store<NL>(out.c1, out.stride, e, m);
 }
 
+// ok[e] = 1 iff element e of `wire` is a valid encoding: components below p and, level 1, on the curve
+// y^2 = x^3 + x (or the all-zero identity encoding); level 2, of norm 1 (re^2 + im^2 = 1: the subgroup of
+// order p + 1 that contains GT).
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_validate(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, int level,
+           uint8_t* __restrict__ ok) {
+  __shared__ LFp<NL> stage;
+  __shared__ WireStage<NL> ws;
+  const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
+  const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+  const size_t EB = (size_t)(2 * L);
+  const u32 mis = wire_stage_in<NL>(&ws, wire + e0 * EB, nel * EB);
+  if (threadIdx.x >= nel) return;
+  const size_t e = e0 + threadIdx.x;
+  const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
+  Fp<NL> x, y;
+  wire_to_limbs<NL>(x, src, L);
+  wire_to_limbs<NL>(y, src + L, L);
+  // range: v < p  <=>  v - p borrows
+  bool in_range = true;
+  {
+    i32 cx = 0, cy = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      cx = ((i32)x.v[j] - (i32)P->p[j] + cx) >> LIMB_BITS;
+      cy = ((i32)y.v[j] - (i32)P->p[j] + cy) >> LIMB_BITS;
+    }
+    in_range = (cx != 0) && (cy != 0);
+  }
+  const bool zero = fp_is_zero_limbs(x) && fp_is_zero_limbs(y);
+  Fp<NL> xm, ym, t, u;
+  fp_to_mont<NL>(xm, x, P, &stage);          // <1
+  fp_to_mont<NL>(ym, y, P, &stage);
+  fp_sqrv(u, ym, P, &stage);                 // y^2 (im^2) <2
+  fp_sqrv(t, xm, P, &stage);                 // x^2 (re^2) <2
+  if (level == 1) {
+    fp_mulv(t, t, xm, P, &stage);            // x^3 <2
+    fp_add(t, t, xm);                        // x^3 + x <3
+    fp_sub<2>(t, t, u, P);                   // x^3 + x - y^2 <5
+  } else {
+    Fp<NL> one;
+    fp_set(one, P->one);
+    fp_add(t, t, u);                         // re^2 + im^2 <4
+    fp_sub<1>(t, t, one, P);                 // - 1 <5
+  }
+  Fp<NL> c;
+  fp_from_mont<NL>(c, t, P, &stage);         // canonical: zero iff the relation holds
+  const bool rel = fp_is_zero_limbs(c);
+  ok[e] = (in_range && (rel || (level == 1 && zero))) ? 1 : 0;
+}
+
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32* __restrict__ c1, size_t stride, int L,
@@ -321,7 +373,7 @@ k_gt_mul(const FpParams<NL>* __restrict__ P, GtMulArgs A) {
   if (e >= A.count) return;
   Fp<NL> o0, o1;
   gt_mul_lane<NL>(o0, o1, L, A.a0, A.a1, A.sa, (A.sa == 1) ? 0 : e, A.b0, A.b1, A.sb, (A.sb == 1) ? 0 : e,
-                  A.conj_b != 0, P);
+                  A.conj_b != 0, P, A.plain_a != 0);
   g_store<NL>(A.o0, A.so, e, o0);
   g_store<NL>(A.o1, A.so, e, o1);
 }
@@ -421,6 +473,13 @@ static void launch_decode_plain(hipStream_t s, const void* params, const uint8_t
   if (!count) return;
   hipLaunchKernelGGL(k_decode<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire,
                      L, count, out, 1);
+}
+
+static void launch_validate(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int level,
+                            uint8_t* ok) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_validate<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire,
+                     L, count, level, ok);
 }
 
 static void launch_encode(hipStream_t s, const uint8_t* inf, const uint32_t* c0, const uint32_t* c1, size_t stride,
@@ -626,6 +685,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       "k_pairing<" BGN_STR(BGN_NL) ", 0>",
       launch_decode,
       launch_decode_plain,
+      launch_validate,
       launch_encode,
       launch_pairing,
       launch_fixedpair_build,

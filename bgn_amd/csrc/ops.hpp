@@ -59,11 +59,13 @@ __device__ __forceinline__ void fp_reduce8(Fp<NL>& r, const Fp<NL>& a, const FpP
 
 // out = a * b  (conj_b: a * conj(b) = a / b on the norm-1 subgroup GT; this is
 // result.Div on level-2 ciphertexts, bgn.go:397).  Replaces result.Mul,
-// bgn.go:460.  Inputs canonical Montgomery; output plain canonical.
+// bgn.go:460.  Inputs canonical Montgomery; output plain canonical.  plain_a: a is given as plain
+// residues (the Montgomery product of a plain value and a Montgomery form is the plain product), which
+// saves a's conversion on the way in and the result's on the way out for wire-to-wire products.
 template <int NL>
 __device__ __forceinline__ void gt_mul_lane(Fp<NL>& o0, Fp<NL>& o1, LFp<NL>* L, const u32* a0, const u32* a1,
                                             size_t sa, size_t ea, const u32* b0, const u32* b1, size_t sb, size_t eb,
-                                            bool conj_b, const FpParams<NL>* __restrict__ P) {
+                                            bool conj_b, const FpParams<NL>* __restrict__ P, bool plain_a = false) {
   Fp<NL> r, u, w;
   g_load(r, a0, sa, ea);
   g_load(u, a1, sa, ea);
@@ -83,6 +85,11 @@ __device__ __forceinline__ void gt_mul_lane(Fp<NL>& o0, Fp<NL>& o1, LFp<NL>* L, 
     fp_sub<2>(d, w, u, P);                 // re <4
     fp_add(w, w, u);                       // <4
     fp_sub<4>(r, r, w, P);                 // im <6
+    if (plain_a) {                         // wave-uniform
+      fp_reduce8(o0, d, P);
+      fp_reduce8(o1, r, P);
+      return;
+    }
     fp_from_mont<NL>(o0, d, P, L);
   }
   fp_from_mont<NL>(o1, r, P, L);

@@ -51,7 +51,7 @@ extern "C" {
 #define BGN_E_PARAM (-2)    /* unsupported or inconsistent pairing parameters     */
 #define BGN_E_HIP (-3)      /* HIP runtime failure / no device                    */
 #define BGN_E_STATE (-4)    /* missing secret key or decryption tables            */
-#define BGN_E_POINT (-5)    /* an input is not a valid encoding                   */
+#define BGN_E_POINT (-5)    /* an input is not a valid encoding (reserved for callers of bgn_validate_batch) */
 #define BGN_E_NOMEM (-6)
 
 /* per-element status written by bgn_decrypt_batch */
@@ -150,6 +150,15 @@ int bgn_poly_multconst_batch(bgn_ctx* ctx, size_t npoly, size_t d, size_t dp, in
 int bgn_poly_eval_batch(bgn_ctx* ctx, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
                         uint8_t* out);
 
+/* ok[i] = 1 iff in[i] is a valid element encoding for `level`: both F_p components below p and
+ *   level 1: y^2 = x^3 + x, or the all-zero identity encoding;
+ *   level 2: re^2 + im^2 = 1 (the subgroup of order p + 1 that contains GT; the order-n test x^n = 1 is a
+ *            full exponentiation, bgn_multconst_batch with k = n, and left to callers that need it).
+ * The reference accepts any bytes (Element.SetBytes, ciphertext.go:100 / bgn.go:518-521; PBC maps an invalid
+ * point to the identity without telling).  The batch operations of this library do not validate their inputs:
+ * ciphertexts from an untrusted source go through this call first. */
+int bgn_validate_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* in, uint8_t* ok);
+
 /* ok[i] = 1 iff ct[i] == P^v[i] * Q^r[i] (Element.Equals on the affine point).  v, r: any non-negative
  * integers (sums of plaintexts / randomness exceed n, gadgets_test.go:37-39).
  * Replaces CheckDecryptionProof (gadgets.go:57-61). */
@@ -188,6 +197,7 @@ int bgn_poly_multconst_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d, size_t dp
 int bgn_poly_eval_batch_dev(bgn_ctx* ctx, size_t npoly, size_t d, int level, const uint8_t* ct, uint64_t base,
                             uint8_t* out, void* stream);
 
+int bgn_validate_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* in, uint8_t* ok, void* stream);
 /* The two proof checks synchronise the stream before returning (they own scratch buffers). */
 int bgn_check_decryption_proof_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* ct, const uint8_t* v_be,
                                          size_t v_len, const uint8_t* r_be, size_t r_len, uint8_t* ok, void* stream);

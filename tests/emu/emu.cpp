@@ -261,10 +261,10 @@ struct Emu {
     gt_fixed_lane<NL>(A, 0, true, lds(), P);
     if (R) memcpy(out, r, sizeof r);
   }
-  static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, u32* out) {
+  static void gt_mul(const u32* params, const u32* a, const u32* b, int conj_b, int plain_a, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     Fp<NL> o0, o1;
-    gt_mul_lane<NL>(o0, o1, lds(), a, a + NL, 1, 0, b, b + NL, 1, 0, conj_b != 0, P);
+    gt_mul_lane<NL>(o0, o1, lds(), a, a + NL, 1, 0, b, b + NL, 1, 0, conj_b != 0, P, plain_a != 0);
     memcpy(out, o0.v, 4 * NL);
     memcpy(out + NL, o1.v, 4 * NL);
   }
@@ -378,7 +378,7 @@ int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u3
 int emu_pairing_w3(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_w3(params, (const PairingConsts*)C, a, b, out)) }
 int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, out, oinf)) }
 int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, int plain, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, plain, out, oinf)) }
-int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, out)) }
+int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, int plain_a, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, plain_a, out)) }
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
 int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }

@@ -227,11 +227,15 @@ class Emu:
                                      C.c_size_t(rlen), out, C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 
-    def gt_mul(self, a: bytes, b: bytes, conj_b=False) -> bytes:
-        A, _ = self.decode(a)
+    def gt_mul(self, a: bytes, b: bytes, conj_b=False, plain_a=False) -> bytes:
+        if plain_a:
+            pl, _ = self.decode_plain(a)
+            A = (C.c_uint32 * (2 * self.nl))(*pl)
+        else:
+            A, _ = self.decode(a)
         B, _ = self.decode(b)
         out = (C.c_uint32 * (2 * self.nl))()
-        assert self.lib.emu_gt_mul(self.nl, self.params, A, B, 1 if conj_b else 0, out) == 0
+        assert self.lib.emu_gt_mul(self.nl, self.params, A, B, 1 if conj_b else 0, 1 if plain_a else 0, out) == 0
         return self.encode(out)
 
     def gt_table(self, g_wire: bytes, wbits: int, windows: int):

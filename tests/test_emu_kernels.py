@@ -78,6 +78,8 @@ def test_emu_gt_ops(ctx):
     for v in fx["l2"]:
         assert E.gt_mul(l2[v["a"]], l2[v["b"]]).hex() == v["add"]
         assert E.gt_mul(l2[v["a"]], l2[v["b"]], True).hex() == v["sub"]
+        assert E.gt_mul(l2[v["a"]], l2[v["b"]], plain_a=True).hex() == v["add"]          # wire-to-wire form
+        assert E.gt_mul(l2[v["a"]], l2[v["b"]], True, plain_a=True).hex() == v["sub"]
     for v in fx["multconst_l2"]:
         assert E.gt_pow(l2[v["a"]], int(v["k"], 16), (n.bit_length() + 7) // 8).hex() == v["out"]
 

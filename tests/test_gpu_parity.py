@@ -439,3 +439,31 @@ def test_argument_errors_are_reported_not_fatal():
     rc = pk2.engine._lib.bgn_decrypt_batch(pk2.engine._h, 1, 1, buf, m, st)              # gsbs.go:56-58
     assert rc == _lib.BGN_E_STATE and b"DL tables not computed!" in lib.bgn_last_error()
     pk2.engine.close()
+
+
+@pytest.mark.parametrize("name", ["k256", "k1024"])
+def test_validate_batch(name):
+    """bgn_validate_batch: range and curve / norm-1 membership of untrusted encodings (the reference accepts any
+    bytes, ciphertext.go:100; PBC maps an invalid point to O silently)."""
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    p = int(fx["p"], 16)
+    L = fx["fp_bytes"]
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    good = [c for c in cts if any(c)][:4]
+    ident = bytes(2 * L)
+    off_curve = bytearray(good[0]); off_curve[-1] ^= 1
+    x = int.from_bytes(good[1][:L], "big")
+    y = int.from_bytes(good[1][L:], "big")
+    too_big = None
+    if x + p < 1 << (8 * L):                              # a non-canonical representative of a valid point
+        too_big = (x + p).to_bytes(L, "big") + good[1][L:]
+    neg = good[1][:L] + (p - y).to_bytes(L, "big")        # -A is on the curve
+    rows = good + [ident, bytes(off_curve), neg] + ([too_big] if too_big else [])
+    want = [1] * len(good) + [1, 0, 1] + ([0] if too_big else [])
+    assert [int(v) for v in pk.engine.validate(1, b"".join(rows))] == want
+    l2 = pk.engine.mult(good[0] + good[1], good[2] + good[3])
+    one = (1).to_bytes(L, "big") + bytes(L)
+    bad = bytearray(bytes(l2[0])); bad[3] ^= 0x40
+    rows = [bytes(l2[0]), bytes(l2[1]), one, bytes(bad), ident]
+    assert [int(v) for v in pk.engine.validate(2, b"".join(rows))] == [1, 1, 1, 0, 0]

@@ -16,7 +16,9 @@
 //     conj(g^j) = g^-j shares its real part with g^j, so one probe covers +-j
 //     (the parity of the imaginary part, stored with j, tells which), and the
 //     giant steps are spaced 2*S apart: step i resolves m = 2*i*S +- j for
-//     j in [0, S], so the walk is half as long as one that only adds j;
+//     j in [0, S], so the walk is half as long as one that only adds j; the walk
+//     itself advances the real part alone by the two-term recurrence of the norm-1
+//     group, one field product per giant step;
 //   * baby/giant sizes are re-balanced for 288 GB of HBM: S = up to 2^30 baby
 //     steps, G = floor((Mmax+S)/(2S)) + 1 giant steps, where Mmax = B*B + B + 2,
 //     B = ceil(sqrt(T)), is exactly the largest value the reference's loops can
@@ -220,6 +222,10 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       fp_reduce8(a1, a1, P);
     }
   }
+  // Walk.  Only the real part of y_i = x * gamma^-i is needed to probe, and on the norm-1 group it obeys
+  //     Re(y_(i+1)) = 2*Re(gamma) * Re(y_i) - Re(y_(i-1))          (y_(i+1) + y_(i-1) = y_i * (gamma^-1 + gamma))
+  // so a giant step costs ONE field product instead of the three of an F_p^2 product.  The imaginary part,
+  // whose parity decides between +j and -j, is recomputed from x for the one step that hits.
   bool done = !live;
   bool found = false;
   long long result = 0;
@@ -231,40 +237,75 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       done = true;
     }
   }
+  Fp<NL> rc, rp;                                 // Re(y_i), Re(y_(i-1)), canonical
+  fp_reduce8(rc, a0, P);
+  {
+    // y_(i0-1) = y_i0 * gamma = y_i0 * conj(gamma^-1):  Re = a0*K0 + a1*K1
+    Fp<NL> v0, v1;
+    fp_mul(v0, L + 1, a0, P);                   // <2
+    fp_mul(v1, L + 2, a1, P);                   // <2
+    fp_add(v0, v0, v1);                         // <4
+    fp_reduce8(rp, v0, P);
+    Fp<NL> k0;
+    g_load<NL>(k0, B.gi0, 1, 0);
+    fp_dbl(k0, k0);                             // T = 2*Re(gamma^-1) = 2*Re(gamma) <2
+    l_store(L, k0);                             // L[0] = T for the whole walk
+  }
+  bool hit = false;
+  unsigned long long hit_i = 0;
+  u32 hit_j = 0, hit_par = 0;
 #pragma unroll 1
   for (unsigned long long i = i0; i < i0 + steps; ++i) {
     if (!__ballot(!done)) break;
     if (i >= i1) done = true;
-    Fp<NL> re;
-    fp_reduce8(re, a0, P);
     unsigned long long key;
     u32 check;
-    bsgs_fingerprint<NL>(key, check, re);
+    bsgs_fingerprint<NL>(key, check, rc);
     if (!done) {
       unsigned long long h = bsgs_mix(key) & B.mask;
       for (;;) {
         const BsgsSlot s = B.table[h];
         if (s.key == 0ull) break;
         if (s.key == key && ((s.check ^ check) & 0x7fffffffu) == 0u) {
-          Fp<NL> im;
-          fp_reduce8(im, a1, P);
-          const long long j = (long long)s.val;
-          const bool same = ((im.v[0] & 1u) == (s.check >> 31)) || fp_is_zero_limbs(im);
-          const long long m = (long long)(i * B.stride) + (same ? j : -j);
-          if (m >= 1 && (unsigned long long)m <= B.Mmax) {
-            found = true;
-            result = m;
-          }
-          done = true;       // m is unique: a hit outside [1, Mmax] means this attempt fails
+          hit = true;        // m is unique: whatever this hit decodes to decides the attempt
+          hit_i = i;
+          hit_j = s.val;
+          hit_par = s.check >> 31;
+          done = true;
           break;
         }
         h = (h + 1) & B.mask;
       }
     }
-    Fp<NL> m0, m1;
-    fp2_mul_const(m0, m1, a0, a1, L, P);       // aux.Div(aux, gamma), gsbs.go:102
-    a0 = m0;
-    a1 = m1;
+    Fp<NL> nx;
+    fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
+    fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
+    rp = rc;
+    fp_reduce8(rc, nx, P);
+  }
+  if (__ballot(hit)) {
+    // Im(y_hit) for the lanes that hit: y_hit = x * (gamma^-1)^hit_i
+    Fp<NL> g0, g1;
+    gt_pow_u64<NL>(g0, g1, hit ? hit_i : 0ull, L, P);      // <4, <6 ; uses L[0] as scratch, L[1..3] = gamma^-1
+    Fp<NL> x0, x1;
+    g_load<NL>(x0, A.x0, A.sx, e);
+    g_load<NL>(x1, A.x1, A.sx, e);
+    if (A.mode == 1) {
+      fp_neg<1>(x1, x1, P);
+      fp_reduce8(x1, x1, P);
+    }
+    Fp<NL> im, t;
+    fp_mulv(im, x0, g1, P, L);                   // x0*g1 <2   (6)
+    fp_mulv(t, x1, g0, P, L);                    // x1*g0 <2   (4)
+    fp_add(im, im, t);                           // <4
+    fp_reduce8(im, im, P);
+    const long long j = (long long)hit_j;
+    const bool same = ((im.v[0] & 1u) == hit_par) || fp_is_zero_limbs(im);
+    const long long m = (long long)(hit_i * B.stride) + (same ? j : -j);
+    if (hit && m >= 1 && (unsigned long long)m <= B.Mmax) {
+      found = true;
+      result = m;
+    }
   }
   if (live && found) {                         // status / m are pre-set to "not found" by the caller
     A.m[e] = (A.mode == 1) ? -result : result;

@@ -899,6 +899,21 @@ void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t k
   a.k = k; a.kstride = kstride; a.klen = klen;
   a.o0 = O.c0; a.o1 = O.c1; a.so = O.stride;
   a.count = count;
+  a.norm1 = 0;
+  a.p_bits = c->p_bits;
+  c->kt->gt_pow(s, c->d_params, a);
+}
+
+// O (canonical Montgomery) = A^k for bases of norm 1 (GT elements): the Lucas-type ladder of ops.hpp
+void gt_pow_norm1_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
+                         size_t count) {
+  GtPowArgs a;
+  a.a0 = A.c0; a.a1 = A.c1; a.sa = A.stride;
+  a.k = k; a.kstride = kstride; a.klen = klen;
+  a.o0 = O.c0; a.o1 = O.c1; a.so = O.stride;
+  a.count = count;
+  a.norm1 = 1;
+  a.p_bits = c->p_bits + 1;          // the division-step cap fp_inv_mont's other callers use (bits(p-2) + 1)
   c->kt->gt_pow(s, c->d_params, a);
 }
 
@@ -1340,8 +1355,17 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
-  gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);                        // csk.PowBig(ct.C, sk.Key), bgn.go:223
-  kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
+  // csk.PowBig(ct.C, sk.Key), bgn.go:223.  Level-2 ciphertexts and the lift both have norm 1: the power runs
+  // on the real part (two products per bit).  BGN_DECRYPT_LUCAS=0 selects square-and-multiply in F_p^2.
+  {
+    const char* ev = getenv("BGN_DECRYPT_LUCAS");
+    if (ev && ev[0] == '0') {
+      gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);
+      kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
+    } else {
+      gt_pow_norm1_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);
+    }
+  }
   HIP_TRY(hipMemsetAsync(todo_count, 0, 4, s));
   HIP_TRY(hipMemsetAsync(status, 1, count, s));          // "cannot find discrete log" until a lane finds it
   HIP_TRY(hipMemsetAsync(m, 0, count * 8, s));

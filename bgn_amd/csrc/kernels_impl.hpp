@@ -386,6 +386,17 @@ k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
   const bool live = e < A.count;
   if (!live) e = A.count - 1;
   const size_t ea = (A.sa == 1) ? 0 : e;
+  if (A.norm1) {                                   // wave-uniform
+    Fp<NL> b0, b1, r0, r1, o;
+    g_load<NL>(b0, A.a0, A.sa, ea);
+    g_load<NL>(b1, A.a1, A.sa, ea);
+    gt_pow_norm1_lane<NL>(r0, r1, L, b0, b1, A.k + e * A.kstride, A.klen, (int)(A.klen * 8), A.p_bits, P);
+    fp_reduce8(o, r0, P);
+    if (live) g_store<NL>(A.o0, A.so, e, o);
+    fp_reduce8(o, r1, P);
+    if (live) g_store<NL>(A.o1, A.so, e, o);
+    return;
+  }
   {
     Fp<NL> b0, b1, s;
     g_load<NL>(b0, A.a0, A.sa, ea);

@@ -167,6 +167,59 @@ __device__ __forceinline__ void gt_pow_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL>* L, 
   a_load(r1, A1);
 }
 
+// base^k for a base of norm 1 (every element of GT, every output of the final exponentiation) by the
+// Lucas-type ladder on the real part: with A_j = Re(base^j),
+//     A_(2j) = 2*A_j^2 - 1,   A_(2j+1) = 2*A_j*A_(j+1) - A_1,   A_(2j+2) = 2*A_(j+1)^2 - 1,
+// the pair (A_j, A_(j+1)) advances by one exponent bit with one product and one squaring, whatever the bit
+// — two field products per bit against two plus three per set bit for square-and-multiply in F_p^2.  The
+// imaginary part follows at the end from base^(k+1) = base^k * base:
+//     Im(base^k) = (A_k*A_1 - A_(k+1)) / Im(base)                      (one inversion; 0 if Im(base) = 0)
+// This is the power by the secret key of Decrypt (csk.PowBig(ct.C, sk.Key), bgn.go:223).
+// x0, x1: the base, canonical Montgomery.  Result (r0 <5, r1 <2), Montgomery form.
+template <int NL>
+__device__ __forceinline__ void gt_pow_norm1_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL>* L, const Fp<NL>& x0, const Fp<NL>& x1,
+                                                  const uint8_t* __restrict__ k, size_t klen, int nbits, int p_bits,
+                                                  const FpParams<NL>* __restrict__ P) {
+  AFp<NL> SA, SB, SX, SY;
+  {
+    Fp<NL> t;
+    fp_set(t, P->one);
+    a_store(SA, t);                          // A_0 = 1
+    a_store(SB, x0);                         // A_1
+    a_store(SX, x0);
+    a_store(SY, x1);
+  }
+#pragma unroll 1
+  for (int i = nbits - 1; i >= 0; --i) {
+    const bool bit = scalar_bit(k, klen, i) != 0;
+    Fp<NL> a, b, t, u;
+    a_load(a, SA);                           // <5
+    a_load(b, SB);                           // <5
+    fp_select(u, bit, b, a);                 // the one to square
+    fp_mulv(t, a, b, P, L);                  // A_j*A_(j+1) <2   (25)
+    fp_sqrv(u, u, P, L);                     // <2
+    a_load(a, SX);                           // A_1 <1
+    fp_dbl(t, t);                            // <4
+    fp_sub<1>(t, t, a, P);                   // A_(2j+1) <5
+    fp_set(a, P->one);
+    fp_dbl(u, u);                            // <4
+    fp_sub<1>(u, u, a, P);                   // A_(2j) or A_(2j+2) <5
+    fp_select(a, bit, t, u);
+    fp_select(b, bit, u, t);
+    a_store(SA, a);
+    a_store(SB, b);
+  }
+  Fp<NL> inv, w, t;
+  a_load(t, SY);
+  fp_inv_mont<NL>(inv, t, p_bits, P, L);     // 1/Im(base) <1
+  a_load(r0, SA);                            // A_k <5
+  a_load(t, SX);
+  fp_mulv(w, r0, t, P, L);                   // A_k*A_1 <2   (5)
+  a_load(t, SB);                             // A_(k+1) <5
+  fp_sub<5>(w, w, t, P);                     // <7
+  fp_mulv(r1, w, inv, P, L);                 // Im(base^k) <2   (7)
+}
+
 // Fixed-base power in GT from a window table (same layout as the G1 tables: entry (w, d) at
 // tab + ((w << wbits) + d) * 2*NL, re limbs then im limbs, canonical Montgomery): g^k = prod_w tab[w][k_w],
 // one F_p^2 product per non-zero window and no squarings.  This is the blinding factor e(Q,Q)^r of

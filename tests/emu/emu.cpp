@@ -268,6 +268,19 @@ struct Emu {
     memcpy(out, o0.v, 4 * NL);
     memcpy(out + NL, o1.v, 4 * NL);
   }
+  // Lucas-type ladder for a base of norm 1; out = plain canonical like gt_pow
+  static void gt_pow_norm1(const u32* params, int p_bits, const u32* a, const uint8_t* k, size_t klen, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    LFp<NL>* L = lds();
+    Fp<NL> b0, b1, r0, r1, o;
+    memcpy(b0.v, a, 4 * NL);
+    memcpy(b1.v, a + NL, 4 * NL);
+    gt_pow_norm1_lane<NL>(r0, r1, L, b0, b1, k, klen, (int)(klen * 8), p_bits, P);
+    fp_from_mont<NL>(o, r0, P, L);
+    memcpy(out, o.v, 4 * NL);
+    fp_from_mont<NL>(o, r1, P, L);
+    memcpy(out + NL, o.v, 4 * NL);
+  }
   static void gt_pow(const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
@@ -380,6 +393,7 @@ int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_
 int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, int plain, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, plain, out, oinf)) }
 int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, int plain_a, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, plain_a, out)) }
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }
+int emu_gt_pow_norm1(int nl, const u32* params, int p_bits, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow_norm1(params, p_bits, a, k, klen, out)) }
 int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
 int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, x, xlen, r, rlen, out, oinf)) }

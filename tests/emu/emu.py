@@ -317,6 +317,15 @@ class Emu:
             res.append(self.encode(pl))
         return res
 
+    def gt_pow_norm1(self, a: bytes, k: int, klen: int = None) -> bytes:
+        """a^k for a of norm 1 by the Lucas-type ladder (ops.hpp gt_pow_norm1_lane)."""
+        A, _ = self.decode(a)
+        klen = klen or max(1, (k.bit_length() + 7) // 8)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_gt_pow_norm1(self.nl, self.params, self.p.bit_length() + 1, A, k.to_bytes(klen, "big"),
+                                         C.c_size_t(klen), out) == 0
+        return self.encode(out)
+
     def gt_pow(self, a: bytes, k: int, klen: int = None) -> bytes:
         A, _ = self.decode(a)
         klen = klen or max(1, (k.bit_length() + 7) // 8)

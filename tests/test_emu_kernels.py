@@ -106,6 +106,22 @@ def test_emu_gt_fixed_base_blinding(wbits):
         assert E.gt_fixed(tab, wbits, r, klen, R.elem_to_bytes(other, p)) == R.elem_to_bytes(R.f2_mul(want, other, p), p), r
 
 
+def test_emu_norm1_power_ladder(ctx):
+    """x^k on the norm-1 group by the real-part ladder == the F_p^2 power, including k = 0, 1, the secret key, k >= n,
+    and the bases 1 and -1 whose imaginary part is zero."""
+    from conftest import oracle_key
+    fx, E = ctx
+    opk, osk = oracle_key(fx)
+    p, n = opk.p, opk.n
+    cts = [R.elem_from_bytes(bytes.fromhex(e["ct"]), p) for e in fx["encrypt"] if int(e["ct"], 16)]
+    xs = [opk.e(cts[0], cts[1]), opk.e(cts[2], opk.P), (1, 0), (p - 1, 0)]
+    rng = random.Random(9)
+    for x in xs:
+        assert (x[0] * x[0] + x[1] * x[1]) % p == 1
+        for k in [0, 1, 2, 3, osk.Key, n - 1, n + 7, rng.randrange(n)]:
+            assert E.gt_pow_norm1(R.elem_to_bytes(x, p), k) == R.elem_to_bytes(R.f2_pow(x, k, p), p), (x, k)
+
+
 def test_emu_bsgs_ranges_and_signs(ctx):
     """Accept range [1, Mmax] with Mmax = B*B+B+2 (gsbs.go:77-105), zero short-cut, negative retry,
     for several baby/giant splits (the result must not depend on the split)."""

@@ -130,19 +130,41 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
   load_const_rows<NL>(L, B.g0, B.g1);
   Fp<NL> a0, a1;
   gt_pow_u64<NL>(a0, a1, j0, L, P);
+  // g^(j+1) = T*g^j - g^(j-1) with T = 2*Re(g) on the norm-1 group, component by component: two field
+  // products per entry instead of the three of an F_p^2 product.  (c0, c1) = g^j, (p0, p1) = g^(j-1), canonical.
+  Fp<NL> c0, c1;
+  AFp<NL> AP0, AP1;                            // g^(j-1) parked in AGPR slots: the product needs the VGPRs
+  fp_reduce8(c0, a0, P);
+  fp_reduce8(c1, a1, P);
+  {
+    Fp<NL> p0, p1;
+    // g^(j0-1) = g^j0 * conj(g):  Re = a0*G0 + a1*G1,  Im = a1*G0 - a0*G1
+    Fp<NL> v0, v1;
+    fp_mul(v0, L + 1, c0, P);                  // G0*a0 <2
+    fp_mul(v1, L + 2, c1, P);                  // G1*a1 <2
+    fp_add(v0, v0, v1);                        // <4
+    fp_reduce8(p0, v0, P);
+    fp_mul(v0, L + 1, c1, P);                  // G0*a1 <2
+    fp_mul(v1, L + 2, c0, P);                  // G1*a0 <2
+    fp_sub<2>(v0, v0, v1, P);                  // <4
+    fp_reduce8(p1, v0, P);
+    a_store(AP0, p0);
+    a_store(AP1, p1);
+    Fp<NL> t;
+    g_load<NL>(t, B.g0, 1, 0);
+    fp_dbl(t, t);                              // T <2
+    l_store(L, t);                             // L[0] = T
+  }
 #pragma unroll 1
   for (unsigned long long c = 0; c < chunk; ++c) {
     const unsigned long long j = j0 + c;
     if (!__ballot(j <= B.S)) break;            // the lane that only holds j = S stops after it
     if (j <= B.S) {
-      Fp<NL> re, im;
-      fp_reduce8(re, a0, P);
-      fp_reduce8(im, a1, P);
       unsigned long long key;
       u32 check;
-      bsgs_fingerprint<NL>(key, check, re);
+      bsgs_fingerprint<NL>(key, check, c0);
       const u32 val = (u32)j;                                  // j <= S <= 2^31
-      check = (check & 0x7fffffffu) | ((im.v[0] & 1u) << 31);   // parity of the imaginary part rides in the check word
+      check = (check & 0x7fffffffu) | ((c1.v[0] & 1u) << 31);   // parity of the imaginary part rides in the check word
       unsigned long long h = bsgs_mix(key) & B.mask;
       for (;;) {
         const unsigned long long old = atomicCAS(&B.table[h].key, 0ull, key);
@@ -154,10 +176,17 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
         h = (h + 1) & B.mask;
       }
     }
-    Fp<NL> m0, m1;
-    fp2_mul_const(m0, m1, a0, a1, L, P);
-    a0 = m0;
-    a1 = m1;
+    Fp<NL> n, t;
+    fp_mul(n, L, c0, P);                       // T*Re <2
+    a_load(t, AP0);
+    fp_sub<1>(n, n, t, P);                     // <3
+    a_store(AP0, c0);
+    fp_reduce8(c0, n, P);
+    fp_mul(n, L, c1, P);                       // T*Im <2
+    a_load(t, AP1);
+    fp_sub<1>(n, n, t, P);                     // <3
+    a_store(AP1, c1);
+    fp_reduce8(c1, n, P);
   }
 }
 

@@ -6,6 +6,7 @@
 // helpers for 64-bit values; randomness is always supplied by the caller.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -36,11 +37,302 @@ inline void check(int rc, const char* where) {
   if (rc != BGN_OK) throw Error(rc, where);
 }
 
+// ---- Go encoding/gob streams of the two ciphertext envelopes (ciphertext.go:17-20, :33-38) --------------
+// Format notes and the reader's rules (type ids and field order come from the definitions in the stream) are
+// in bgn_amd/gob.py; this is the same codec for compiled callers.
+namespace gob {
+struct Error : std::runtime_error {
+  explicit Error(const std::string& m) : std::runtime_error(m) {}
+};
+inline void put_uint(Bytes& o, uint64_t v) {
+  if (v < 128) {
+    o.push_back((uint8_t)v);
+    return;
+  }
+  int n = 0;
+  for (uint64_t t = v; t; t >>= 8) ++n;
+  o.push_back((uint8_t)(256 - n));
+  for (int i = n - 1; i >= 0; --i) o.push_back((uint8_t)(v >> (8 * i)));
+}
+inline void put_int(Bytes& o, int64_t v) { put_uint(o, v < 0 ? (((uint64_t)~v) << 1) | 1 : ((uint64_t)v) << 1); }
+inline void put_bytes(Bytes& o, const uint8_t* p, size_t n) {
+  put_uint(o, n);
+  o.insert(o.end(), p, p + n);
+}
+inline void put_str(Bytes& o, const char* s) { put_bytes(o, (const uint8_t*)s, strlen(s)); }
+inline void put_message(Bytes& o, const Bytes& body) {
+  put_uint(o, body.size());
+  o.insert(o.end(), body.begin(), body.end());
+}
+// wireType{StructT: &structType{CommonType{name, id}, fields}} / wireType{SliceT: &sliceType{CommonType, elem}}
+inline Bytes struct_def(int64_t id, const char* name, const std::vector<std::pair<const char*, int64_t>>& fields) {
+  Bytes b;
+  put_int(b, -id);
+  b.push_back(3); b.push_back(1);
+  b.push_back(1); put_str(b, name); b.push_back(1); put_int(b, id); b.push_back(0);
+  if (!fields.empty()) {
+    b.push_back(1);
+    put_uint(b, fields.size());
+    for (auto& f : fields) {
+      b.push_back(1); put_str(b, f.first); b.push_back(1); put_int(b, f.second); b.push_back(0);
+    }
+  }
+  b.push_back(0); b.push_back(0);
+  return b;
+}
+inline Bytes slice_def(int64_t id, const char* name, int64_t elem) {
+  Bytes b;
+  put_int(b, -id);
+  b.push_back(2); b.push_back(1);
+  b.push_back(1); put_str(b, name); b.push_back(1); put_int(b, id); b.push_back(0);
+  b.push_back(1); put_int(b, elem);
+  b.push_back(0); b.push_back(0);
+  return b;
+}
+
+struct Reader {
+  const uint8_t* p;
+  const uint8_t* e;
+  const uint8_t* take(size_t n) {
+    if ((size_t)(e - p) < n) throw Error("truncated gob stream");
+    const uint8_t* r = p;
+    p += n;
+    return r;
+  }
+  uint64_t uint_() {
+    uint8_t b = *take(1);
+    if (b < 128) return b;
+    size_t n = 256 - b;
+    if (n > 8) throw Error("unsigned integer wider than 64 bits");
+    const uint8_t* q = take(n);
+    uint64_t v = 0;
+    for (size_t i = 0; i < n; ++i) v = (v << 8) | q[i];
+    return v;
+  }
+  int64_t int_() {
+    uint64_t u = uint_();
+    return (u & 1) ? (int64_t)~(u >> 1) : (int64_t)(u >> 1);
+  }
+  Bytes bytes_() {
+    size_t n = (size_t)uint_();
+    const uint8_t* q = take(n);
+    return Bytes(q, q + n);
+  }
+  bool done() const { return p >= e; }
+};
+// A user type read from the stream: a struct (field names and type ids) or a slice (element type id).
+struct Type {
+  bool is_struct = false;
+  std::string name;
+  std::vector<std::pair<std::string, int64_t>> fields;
+  int64_t elem = 0;
+};
+inline std::pair<std::string, int64_t> read_common(Reader& r) {   // CommonType and fieldType: {Name string; Id typeId}
+  std::string name;
+  int64_t id = 0;
+  int field = -1;
+  for (;;) {
+    uint64_t d = r.uint_();
+    if (!d) return {name, id};
+    field += (int)d;
+    if (field == 0) {
+      Bytes b = r.bytes_();
+      name.assign(b.begin(), b.end());
+    } else if (field == 1) {
+      id = r.int_();
+    } else {
+      throw Error("unknown CommonType field");
+    }
+  }
+}
+inline Type read_wire_type(Reader& r) {
+  Type t;
+  bool have = false;
+  int field = -1;
+  for (;;) {
+    uint64_t d = r.uint_();
+    if (!d) break;
+    field += (int)d;
+    if (field != 1 && field != 2) throw Error("gob type kind not used by the ciphertext envelopes");
+    t.is_struct = field == 2;
+    have = true;
+    int f = -1;
+    for (;;) {
+      uint64_t dd = r.uint_();
+      if (!dd) break;
+      f += (int)dd;
+      if (f == 0) {
+        t.name = read_common(r).first;
+      } else if (f == 1 && t.is_struct) {
+        uint64_t n = r.uint_();
+        for (uint64_t i = 0; i < n; ++i) t.fields.push_back(read_common(r));
+      } else if (f == 1) {
+        t.elem = r.int_();
+      } else {
+        throw Error("unknown type field");
+      }
+    }
+  }
+  if (!have) throw Error("empty type definition");
+  return t;
+}
+// Decoded top-level struct of the envelopes: whichever of these fields the stream carries.
+struct Envelope {
+  Bytes CBytes;
+  std::vector<Bytes> CoeffBytes;
+  int64_t Degree = 0, ScaleFactor = 0;
+  bool L2 = false;
+};
+inline Envelope decode(const Bytes& data) {
+  if (data.empty()) throw Error("no data provided");   // bgn.go:503-505
+  Reader r{data.data(), data.data() + data.size()};
+  std::vector<std::pair<int64_t, Type>> types;
+  auto find = [&](int64_t id) -> const Type* {
+    for (auto& t : types)
+      if (t.first == id) return &t.second;
+    return nullptr;
+  };
+  while (!r.done()) {
+    size_t n = (size_t)r.uint_();
+    const uint8_t* q = r.take(n);
+    Reader m{q, q + n};
+    int64_t id = m.int_();
+    if (id < 0) {
+      types.push_back({-id, read_wire_type(m)});
+      continue;
+    }
+    const Type* t = find(id);
+    if (!t || !t->is_struct) throw Error("top-level value is not a struct");
+    Envelope out;
+    int field = -1;
+    for (;;) {
+      uint64_t d = m.uint_();
+      if (!d) return out;
+      field += (int)d;
+      if (field >= (int)t->fields.size()) throw Error("field number out of range");
+      const std::string& fn = t->fields[field].first;
+      const int64_t ft = t->fields[field].second;
+      if (ft == 1) {
+        bool v = m.uint_() != 0;
+        if (fn == "L2") out.L2 = v;
+      } else if (ft == 2) {
+        int64_t v = m.int_();
+        if (fn == "Degree") out.Degree = v;
+        if (fn == "ScaleFactor") out.ScaleFactor = v;
+      } else if (ft == 3) {
+        (void)m.uint_();
+      } else if (ft == 5 || ft == 6) {
+        Bytes v = m.bytes_();
+        if (fn == "CBytes") out.CBytes = v;
+      } else {
+        const Type* st = find(ft);
+        if (!st || st->is_struct || st->elem != 5) throw Error("unsupported field type");
+        uint64_t cnt = m.uint_();
+        std::vector<Bytes> v;
+        for (uint64_t i = 0; i < cnt; ++i) v.push_back(m.bytes_());
+        if (fn == "CoeffBytes") out.CoeffBytes = v;
+      }
+    }
+  }
+  throw Error("gob stream holds no value");
+}
+// Ciphertext.Bytes(), ciphertext.go:76-92
+inline Bytes marshal_ciphertext(const Bytes& c, bool l2) {
+  Bytes out;
+  put_message(out, struct_def(65, "ciphertextWrapper", {{"CBytes", 5}, {"L2", 1}}));
+  Bytes v;
+  put_int(v, 65);
+  if (!c.empty()) { v.push_back(1); put_bytes(v, c.data(), c.size()); }
+  if (l2) { v.push_back(c.empty() ? 2 : 1); v.push_back(1); }
+  v.push_back(0);
+  put_message(out, v);
+  return out;
+}
+// PolyCiphertext.Bytes(), ciphertext.go:94-116
+inline Bytes marshal_poly_ciphertext(const std::vector<Bytes>& coeffs, int64_t degree, int64_t scale, bool l2) {
+  Bytes out;
+  put_message(out, struct_def(65, "polyCiphertextWrapper", {{"CoeffBytes", 66}, {"Degree", 2}, {"ScaleFactor", 2}, {"L2", 1}}));
+  put_message(out, slice_def(66, "[][]uint8", 5));
+  Bytes v;
+  put_int(v, 65);
+  int last = -1;
+  auto delta = [&](int field) {
+    put_uint(v, (uint64_t)(field - last));
+    last = field;
+  };
+  if (!coeffs.empty()) {
+    delta(0);
+    put_uint(v, coeffs.size());
+    for (auto& c : coeffs) put_bytes(v, c.data(), c.size());
+  }
+  if (degree) { delta(1); put_int(v, degree); }
+  if (scale) { delta(2); put_int(v, scale); }
+  if (l2) { delta(3); v.push_back(1); }
+  v.push_back(0);
+  put_message(out, v);
+  return out;
+}
+}  // namespace gob
+
+// sha256 (FIPS 180-4) for the challenge of gadgets.go:80-96
+namespace sha256 {
+inline Bytes digest(const Bytes& msg) {
+  static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  Bytes m = msg;
+  const uint64_t bits = (uint64_t)msg.size() * 8;
+  m.push_back(0x80);
+  while (m.size() % 64 != 56) m.push_back(0);
+  for (int i = 7; i >= 0; --i) m.push_back((uint8_t)(bits >> (8 * i)));
+  auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+  for (size_t off = 0; off < m.size(); off += 64) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i)
+      w[i] = ((uint32_t)m[off + 4 * i] << 24) | ((uint32_t)m[off + 4 * i + 1] << 16) | ((uint32_t)m[off + 4 * i + 2] << 8) | m[off + 4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+      const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+      const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+      const uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  Bytes out(32);
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 4; ++j) out[4 * i + j] = (uint8_t)(h[i] >> (24 - 8 * j));
+  return out;
+}
+}  // namespace sha256
+
 // ciphertext.go:12-15 — C holds Element.Bytes(); the G1 identity is 2L zero bytes.
 struct Ciphertext {
   Bytes C;
   bool L2 = false;
   Ciphertext Copy() const { return *this; }
+  Bytes Bytes_() const { return gob::marshal_ciphertext(C, L2); }   // Ciphertext.Bytes(), ciphertext.go:76-92
+};
+
+// gadgets.go:10-21
+struct ProofOfPlaintextKnowledge {
+  Ciphertext Ct, Nonce;
+  Scalar DL;
+};
+struct DecryptionProof {
+  Scalar Value, Randomness;
 };
 
 // ciphertext.go:26-31
@@ -50,6 +342,11 @@ struct PolyCiphertext {
   int ScaleFactor = 0;
   bool L2 = false;
   PolyCiphertext Copy() const { return *this; }
+  Bytes Bytes_() const {                                              // PolyCiphertext.Bytes(), ciphertext.go:94-116
+    std::vector<Bytes> cb;
+    for (auto& c : Coefficients) cb.push_back(c.C);
+    return gob::marshal_poly_ciphertext(cb, Degree, ScaleFactor, L2);
+  }
 };
 
 // unbalancedEncode (plaintext.go:164-212) for a machine integer: greedy base-b digits, least significant
@@ -165,6 +462,76 @@ class PublicKey {
   // ---- bgn.go:195-201 ----
   void SetupDecryption(const SecretKey& sk) const;
 
+  // ---- wire envelopes: bgn.go:501-560 ----
+  Ciphertext NewCiphertextFromBytes(const Bytes& data) const {
+    gob::Envelope w = gob::decode(data);
+    return Ciphertext{element(w.CBytes), w.L2};
+  }
+  PolyCiphertext NewPolyCiphertextFromBytes(const Bytes& data) const {
+    gob::Envelope w = gob::decode(data);
+    PolyCiphertext out;
+    for (auto& b : w.CoeffBytes) out.Coefficients.push_back(Ciphertext{element(b), w.L2});
+    out.Degree = (int)w.Degree;
+    out.ScaleFactor = (int)w.ScaleFactor;
+    out.L2 = w.L2;
+    return out;
+  }
+
+  // ---- untrusted inputs: 1 per element that is a valid encoding (bgn_validate_batch) ----
+  std::vector<uint8_t> Validate(const std::vector<Ciphertext>& cts) const {
+    std::vector<uint8_t> ok(cts.size());
+    if (cts.empty()) return ok;
+    Bytes A = join(cts);
+    check(bgn_validate_batch(h_, cts.size(), cts[0].L2 ? 2 : 1, A.data(), ok.data()), "bgn_validate_batch");
+    return ok;
+  }
+
+  // ---- gadgets.go:57-77 (verification; proof generation needs big-integer arithmetic and stays with the caller) ----
+  std::vector<uint8_t> CheckDecryptionProofBatch(const std::vector<Ciphertext>& cts,
+                                                 const std::vector<DecryptionProof>& proofs) const {
+    std::vector<uint8_t> ok(cts.size());
+    if (cts.empty()) return ok;
+    std::vector<Scalar> v, r;
+    for (auto& pr : proofs) {
+      v.push_back(pr.Value);
+      r.push_back(pr.Randomness);
+    }
+    size_t vl = 0, rl = 0;
+    Bytes A = join(cts), vb = pack(v, vl), rb = pack(r, rl);
+    check(bgn_check_decryption_proof_batch(h_, cts.size(), A.data(), vb.data(), vl, rb.data(), rl, ok.data()),
+          "bgn_check_decryption_proof_batch");
+    return ok;
+  }
+  bool CheckDecryptionProof(const Ciphertext& ct, const DecryptionProof& proof) const {
+    return CheckDecryptionProofBatch({ct}, {proof})[0] != 0;
+  }
+  // hash(), gadgets.go:80-96
+  static Scalar ProofHash(const ProofOfPlaintextKnowledge& proof) {
+    Bytes m = proof.Ct.C;
+    m.insert(m.end(), proof.Nonce.C.begin(), proof.Nonce.C.end());
+    return sha256::digest(m);
+  }
+  std::vector<uint8_t> CheckProofOfPlaintextKnoewledgeBatch(const std::vector<Ciphertext>& cts,
+                                                            const std::vector<ProofOfPlaintextKnowledge>& proofs) const {
+    std::vector<uint8_t> ok(cts.size());
+    if (cts.empty()) return ok;
+    std::vector<Scalar> c, dl;
+    std::vector<Ciphertext> nonces;
+    for (auto& pr : proofs) {
+      c.push_back(ProofHash(pr));
+      dl.push_back(pr.DL);
+      nonces.push_back(pr.Nonce);
+    }
+    size_t cl = 0, dll = 0;
+    Bytes A = join(cts), N = join(nonces), cb = pack(c, cl), db = pack(dl, dll);
+    check(bgn_check_plaintext_knowledge_batch(h_, cts.size(), A.data(), N.data(), cb.data(), cl, db.data(), dll, ok.data()),
+          "bgn_check_plaintext_knowledge_batch");
+    return ok;
+  }
+  bool CheckProofOfPlaintextKnoewledge(const Ciphertext& ct, const ProofOfPlaintextKnowledge& proof) const {
+    return CheckProofOfPlaintextKnoewledgeBatch({ct}, {proof})[0] != 0;       // name as in the reference
+  }
+
   // ---- poly.go (coefficient vectors; digits are already-encoded plaintext coefficients) ----
   // EncryptPoly, poly.go:11-29: a negative digit is Sub(zero, Enc(|c|)); r[i] is the randomness of digit i.
   PolyCiphertext EncryptPoly(const std::vector<int64_t>& digits, const std::vector<Scalar>& r, int scale = 0) const {
@@ -247,6 +614,11 @@ class PublicKey {
   bgn_ctx* h_ = nullptr;
   size_t E_ = 0;
 
+  Bytes element(const Bytes& b) const {          // gob drops empty slices: the all-zero identity
+    if (b.empty()) return Bytes(E_, 0);
+    if (b.size() != E_) throw gob::Error("element of unexpected length");
+    return b;
+  }
   void align(Ciphertext& a, Ciphertext& b) const {                                  // bgn.go:447-453
     if (a.L2 && !b.L2) b = makeL2(b);
     if (!a.L2 && b.L2) a = makeL2(a);

@@ -3,6 +3,7 @@
 // Exit code 0 = all checks passed, 3 = no GPU (context creation failed with BGN_E_HIP), 1 = mismatch.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "bgn_amd.hpp"
@@ -16,8 +17,52 @@ static Bytes unhex(const std::string& s) {
   return b;
 }
 
+// Host-side format code, checked before any GPU is touched: the gob streams must equal the ones of
+// bgn_amd/gob.py byte for byte (both follow encoding/gob's documented layout), and decode back.
+static int host_checks() {
+  int bad = 0;
+  const uint8_t ct_stream[] = {0x31, 0xff, 0x81, 0x03, 0x01, 0x01, 0x11, 0x63, 0x69, 0x70, 0x68, 0x65, 0x72, 0x74, 0x65, 0x78, 0x74, 0x57, 0x72, 0x61, 0x70, 0x70, 0x65, 0x72, 0x01, 0xff, 0x82, 0x00, 0x01, 0x02, 0x01, 0x06, 0x43, 0x42, 0x79, 0x74, 0x65, 0x73, 0x01, 0x0a, 0x00, 0x01, 0x02, 0x4c, 0x32, 0x01, 0x02, 0x00, 0x00, 0x00, 0x0a, 0xff, 0x82, 0x01, 0x03, 0x01, 0x02, 0x03, 0x01, 0x01, 0x00};
+  const uint8_t poly_stream[] = {0x55, 0xff, 0x81, 0x03, 0x01, 0x01, 0x15, 0x70, 0x6f, 0x6c, 0x79, 0x43, 0x69, 0x70, 0x68, 0x65, 0x72, 0x74, 0x65, 0x78, 0x74, 0x57, 0x72, 0x61, 0x70, 0x70, 0x65, 0x72, 0x01, 0xff, 0x82, 0x00, 0x01, 0x04, 0x01, 0x0a, 0x43, 0x6f, 0x65, 0x66, 0x66, 0x42, 0x79, 0x74, 0x65, 0x73, 0x01, 0xff, 0x84, 0x00, 0x01, 0x06, 0x44, 0x65, 0x67, 0x72, 0x65, 0x65, 0x01, 0x04, 0x00, 0x01, 0x0b, 0x53, 0x63, 0x61, 0x6c, 0x65, 0x46, 0x61, 0x63, 0x74, 0x6f, 0x72, 0x01, 0x04, 0x00, 0x01, 0x02, 0x4c, 0x32, 0x01, 0x02, 0x00, 0x00, 0x00, 0x17, 0xff, 0x83, 0x02, 0x01, 0x01, 0x09, 0x5b, 0x5d, 0x5b, 0x5d, 0x75, 0x69, 0x6e, 0x74, 0x38, 0x01, 0xff, 0x84, 0x00, 0x01, 0x0a, 0x00, 0x00, 0x0e, 0xff, 0x82, 0x01, 0x02, 0x02, 0x01, 0x02, 0x01, 0x03, 0x01, 0x04, 0x01, 0x02, 0x00};
+  const uint8_t zero_stream[] = {0x31, 0xff, 0x81, 0x03, 0x01, 0x01, 0x11, 0x63, 0x69, 0x70, 0x68, 0x65, 0x72, 0x74, 0x65, 0x78, 0x74, 0x57, 0x72, 0x61, 0x70, 0x70, 0x65, 0x72, 0x01, 0xff, 0x82, 0x00, 0x01, 0x02, 0x01, 0x06, 0x43, 0x42, 0x79, 0x74, 0x65, 0x73, 0x01, 0x0a, 0x00, 0x01, 0x02, 0x4c, 0x32, 0x01, 0x02, 0x00, 0x00, 0x00, 0x03, 0xff, 0x82, 0x00};
+  Bytes a = gob::marshal_ciphertext(Bytes{1, 2, 3}, true);
+  if (a != Bytes(ct_stream, ct_stream + sizeof ct_stream)) { printf("MISMATCH gob ciphertext stream\n"); bad++; }
+  Bytes b = gob::marshal_poly_ciphertext({Bytes{1, 2}, Bytes{3}}, 2, 1, false);
+  if (b != Bytes(poly_stream, poly_stream + sizeof poly_stream)) { printf("MISMATCH gob poly stream\n"); bad++; }
+  Bytes z = gob::marshal_ciphertext(Bytes{}, false);
+  if (z != Bytes(zero_stream, zero_stream + sizeof zero_stream)) { printf("MISMATCH gob zero-value stream\n"); bad++; }
+  gob::Envelope e = gob::decode(a);
+  if (e.CBytes != Bytes{1, 2, 3} || !e.L2) { printf("MISMATCH gob decode\n"); bad++; }
+  e = gob::decode(b);
+  if (e.CoeffBytes.size() != 2 || e.CoeffBytes[1] != Bytes{3} || e.Degree != 2 || e.ScaleFactor != 1 || e.L2) {
+    printf("MISMATCH gob poly decode\n");
+    bad++;
+  }
+  bool threw = false;
+  try {
+    gob::decode(Bytes{});
+  } catch (const gob::Error&) {
+    threw = true;
+  }
+  if (!threw) { printf("MISMATCH empty gob input accepted\n"); bad++; }
+  // the documented integer encodings of encoding/gob
+  Bytes t;
+  gob::put_uint(t, 256);
+  gob::put_int(t, -129);
+  const uint8_t want[] = {0xfe, 0x01, 0x00, 0xfe, 0x01, 0x01};
+  if (t.size() != 6 || memcmp(t.data(), want, 6) != 0) { printf("MISMATCH gob integer encodings\n"); bad++; }
+  // sha256("abc"), FIPS 180-4 appendix B.1
+  const uint8_t abc[] = {0xba, 0x78, 0x16, 0xbf, 0x8f, 0x01, 0xcf, 0xea, 0x41, 0x41, 0x40, 0xde, 0x5d, 0xae, 0x22, 0x23,
+                         0xb0, 0x03, 0x61, 0xa3, 0x96, 0x17, 0x7a, 0x9c, 0xb4, 0x10, 0xff, 0x61, 0xf2, 0x00, 0x15, 0xad};
+  Bytes dg = sha256::digest(Bytes{'a', 'b', 'c'});
+  if (memcmp(dg.data(), abc, 32) != 0) { printf("MISMATCH sha256\n"); bad++; }
+  std::vector<uint64_t> d100 = UnbalancedEncode(100, 3);
+  if (d100 != std::vector<uint64_t>{1, 0, 2, 0, 1, 0}) { printf("MISMATCH UnbalancedEncode\n"); bad++; }
+  return bad;
+}
+
 int main(int argc, char** argv) {
   if (argc != 8) return 2;
+  if (host_checks()) return 1;
   try {
     PublicKey pk(unhex(argv[1]), unhex(argv[2]), strtoull(argv[3], nullptr, 10), unhex(argv[4]), unhex(argv[5]),
                  strtoull(argv[7], nullptr, 10), true, 0);
@@ -65,6 +110,37 @@ int main(int argc, char** argv) {
     PolyCiphertext s2 = pk.AddPoly(a, b2);
     expect("poly 9 + (-4 / 3^2) at scale 2", ev(s2), 77);
     expect("scale factor after alignment", s2.ScaleFactor, 2);
+    // wire envelopes (bgn_test.go:37-85): Bytes() -> New...FromBytes preserves the element
+    {
+      Ciphertext back = pk.NewCiphertextFromBytes(one.Bytes_());
+      if (back.C != one.C || back.L2) { printf("MISMATCH gob round trip (L1)\n"); bad++; }
+      Ciphertext l2 = pk.Mult(one, one);
+      back = pk.NewCiphertextFromBytes(l2.Bytes_());
+      if (back.C != l2.C || !back.L2) { printf("MISMATCH gob round trip (L2)\n"); bad++; }
+      PolyCiphertext pb = pk.NewPolyCiphertextFromBytes(b2.Bytes_());
+      if (pb.Degree != b2.Degree || pb.ScaleFactor != 2 || pb.L2 || pb.Coefficients.size() != b2.Coefficients.size() ||
+          pb.Coefficients[1].C != b2.Coefficients[1].C) { printf("MISMATCH gob poly round trip\n"); bad++; }
+    }
+    // proofs (gadgets_test.go:9-71): decryption proofs incl. the aggregate whose exponents add up
+    {
+      Ciphertext c1 = pk.EncryptWithRandomness(scalar_u64(1000003), scalar_u64(777)),
+                 c2 = pk.EncryptWithRandomness(scalar_u64(2000003), scalar_u64(999));
+      expect("decryption proof valid", pk.CheckDecryptionProof(c1, {scalar_u64(1000003), scalar_u64(777)}), 1);
+      expect("decryption proof wrong randomness", pk.CheckDecryptionProof(c1, {scalar_u64(1000003), scalar_u64(778)}), 0);
+      expect("decryption proof wrong value", pk.CheckDecryptionProof(c1, {scalar_u64(1000004), scalar_u64(777)}), 0);
+      expect("decryption proof aggregate", pk.CheckDecryptionProof(pk.Add(c1, c2), {scalar_u64(3000006), scalar_u64(1776)}), 1);
+      // proof of plaintext knowledge with v = 0, z = 0: Ct = O, DL = nonce1 whatever the challenge
+      ProofOfPlaintextKnowledge pr{pk.EncryptDeterministic(scalar_u64(0)), pk.EncryptDeterministic(scalar_u64(424242)),
+                                   scalar_u64(424242)};
+      expect("plaintext-knowledge proof valid", pk.CheckProofOfPlaintextKnoewledge(pr.Ct, pr), 1);
+      pr.DL = scalar_u64(424243);
+      expect("plaintext-knowledge proof wrong DL", pk.CheckProofOfPlaintextKnoewledge(pr.Ct, pr), 0);
+      std::vector<uint8_t> ok = pk.Validate({c1, c2, zero});
+      Ciphertext broken = c1;
+      broken.C.back() ^= 1;
+      expect("validate good", ok[0] + ok[1] + ok[2], 3);
+      expect("validate off-curve", pk.Validate({broken})[0], 0);
+    }
     bool threw = false;
     try {
       sk.Decrypt(pk.EncryptWithRandomness(scalar_u64(5000), scalar_u64(1)), pk);

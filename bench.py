@@ -56,6 +56,51 @@ def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0):
                       f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
 
 
+def config0_metrics(no_cpu: bool):
+    """BASELINE configs[0]: 512-bit params, 128 ciphertexts, pk.Add and pk.Mult over 128 independent pairs — the
+    shape of BenchmarkAdd / BenchmarkMult (bgn_test.go:97-140), which the reference runs on one goroutine.  Host
+    buffers in and out (the size at which the boundary copies matter), next to the single-threaded C oracle on the
+    same 128 pairs."""
+    import numpy as np
+    from conftest import load_fixture
+    import bgn_amd
+    fx = load_fixture("k512")
+    pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                           fx["msg_space"], True, fx["poly_base"])
+    eng = pk.engine
+    rng = np.random.default_rng(7)
+    n, nn = 128, int(fx["n"], 16)
+    xs = [int(v) for v in rng.integers(0, 1021, 2 * n)]
+    rs = [int.from_bytes(rng.bytes(60), "big") % nn for _ in range(2 * n)]
+    cts = eng.encrypt(xs, rs)
+    a, b = cts[:n].tobytes(), cts[n:].tobytes()
+    out = {}
+    for name, fn in (("eadd", lambda: eng.add(1, a, b)), ("emult", lambda: eng.mult(a, b))):
+        fn()
+        t0 = time.perf_counter()
+        res = fn()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": n / dt, "unit": "ops/s", "wall_ms_for_128": dt * 1e3, "result": res.tobytes()}
+    if not no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        try:
+            import oracle_c
+            if oracle_c.available():
+                orc = oracle_c.Oracle.from_fixture(fx)
+                for name, fn in (("eadd", lambda: orc.add(1, a, b)), ("emult", lambda: orc.mult(a, b))):
+                    t0 = time.perf_counter()
+                    ref = fn()
+                    dt = time.perf_counter() - t0
+                    out[name]["cpu_single_thread_ops_per_s"] = n / dt
+                    out[name]["matches_cpu_bit_exact"] = bool(ref == out[name]["result"])
+        except (ImportError, AttributeError):
+            pass
+    for name in out:
+        del out[name]["result"]
+    out["workload"] = "configs[0]: 512-bit params, 128-ciphertext EAdd + EMult, host buffers through the C ABI"
+    return out
+
+
 def secondary_metrics(pk, fx, dev, dec_log2s):
     """BASELINE configs[1] (Encrypt) and configs[3] (BSGS Decrypt, T = 2^40, batch 2^16), reported next to the
     headline value.  Inputs resident in HBM; one warm-up pass then one timed pass each."""
@@ -240,6 +285,8 @@ def main():
     extra = None
     if not args.no_extra and world == 1 and args.key == "k1024":
         extra = secondary_metrics(pk, fx, dev, [min(k, 20) for k in args.decrypt_log2])
+        if rank == 0:
+            extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

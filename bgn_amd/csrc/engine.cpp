@@ -1545,7 +1545,8 @@ int poly_lin_common(bgn_ctx* c, size_t npoly, size_t d, size_t dp, int level, co
     }
   }
   if (k_host) {
-    HIP_TRY(hipMemcpyAsync(kbuf, k_host->data(), k_host->size(), hipMemcpyHostToDevice, s));
+    // blocking copy: the scalars live in a caller's local vector
+    HIP_TRY(hipMemcpy(kbuf, k_host->data(), k_host->size(), hipMemcpyHostToDevice));
     k_dev = kbuf;
   }
   const KernelTable* kt = c->kt;

@@ -74,8 +74,10 @@ struct bgn_ctx {
   uint32_t* d_tabG = nullptr;     // window table of e(Q,Q) in GT (level-2 blinding)
   int gt_windows = 0;
   int gt_wbits = 8;
-  int fixed_windows = 0;
+  int fixed_windows = 0;               // table of P
   int fixed_wbits = 8;
+  int fixed_windows_q = 0;             // table of Q: wider windows (20 bits, 17 GB at a 1024-bit key) — Q's exponents
+  int fixed_wbits_q = 8;               // are the full-length random ones
   uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
   size_t miller_steps = 0;
   PairingConsts pc_host;               // host image of *d_consts
@@ -696,16 +698,42 @@ int fixed_window_bits(bgn_ctx* c) {
   return wbits;
 }
 
+// Window width of Q's table.  Q carries the blinding exponents — uniformly random below n — so every window
+// of it is used by every encryption: 20-bit windows (52 additions instead of 64 at a 1024-bit key) for 17 GB
+// of HBM.  BGN_FIXED_WINDOW_BITS_Q overrides (8..22); never narrower than P's table.
+int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
+  int wbits = wbits_p == 16 ? 20 : wbits_p;
+  if (const char* e = getenv("BGN_FIXED_WINDOW_BITS_Q")) {
+    const int v = atoi(e);
+    if (v >= 8 && v <= 22) wbits = v;
+  }
+  if (wbits < wbits_p) wbits = wbits_p;
+  while (wbits > wbits_p) {
+    size_t fr = 0, tot = 0;
+    const size_t W = (size_t)(c->n.bits() + wbits - 1) / wbits + 1;
+    const size_t need = (W << wbits) * 2 * (size_t)c->nl * 4;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= 4 * need) break;
+    wbits--;
+  }
+  return wbits;
+}
+
 int ensure_fixed_tables(bgn_ctx* c) {
   if (c->d_tabP) return BGN_OK;
   const KernelTable* kt = c->kt;
-  const int wbits = fixed_window_bits(c);
-  const int W = (c->n.bits() + wbits - 1) / wbits + 1;
-  const size_t ne = (size_t)W << wbits;                       // entries per table
-  const size_t np = (size_t)W * wbits;                        // entries that are 2^i * B
-  const size_t klen = (np + 7) / 8;
-  const size_t maxc = (size_t)W * (((size_t)1 << (wbits - 1)) - 1);
-  const size_t sp = round_up(2 * np, 64), sr = round_up(maxc, 64);
+  int wb[2], W[2];
+  size_t np[2], maxc = 0;
+  wb[0] = fixed_window_bits(c);
+  wb[1] = fixed_window_bits_q(c, wb[0]);
+  for (int b = 0; b < 2; ++b) {
+    W[b] = (c->n.bits() + wb[b] - 1) / wb[b] + 1;
+    np[b] = (size_t)W[b] * wb[b];                            // entries that are 2^i * B
+    const size_t mc = (size_t)W[b] * (((size_t)1 << (wb[b] - 1)) - 1);
+    if (mc > maxc) maxc = mc;
+  }
+  const size_t npt = np[0] + np[1];
+  const size_t klen = ((np[0] > np[1] ? np[0] : np[1]) + 7) / 8;
+  const size_t sp = round_up(npt, 64), sr = round_up(maxc, 64);
   SoA2 base, pw;
   uint8_t* k1 = nullptr;
   uint32_t* prefix = nullptr;
@@ -714,49 +742,44 @@ int ensure_fixed_tables(bgn_ctx* c) {
     base = w.g1(64);
     pw = w.g1(sp);
     prefix = w.fp(sr);
-    k1 = (uint8_t*)w.cv.take(2 * np * klen);
+    k1 = (uint8_t*)w.cv.take(npt * klen);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
     }
   }
-  std::vector<uint8_t> h1(2 * np * klen, 0);
-  for (size_t b = 0; b < 2; ++b)
-    for (size_t i = 0; i < np; ++i) h1[(b * np + i) * klen + (klen - 1 - i / 8)] = (uint8_t)(1u << (i % 8));   // 2^i
+  std::vector<uint8_t> h1(npt * klen, 0);
+  for (size_t b = 0, o = 0; b < 2; o += np[b], ++b)
+    for (size_t i = 0; i < np[b]; ++i) h1[(o + i) * klen + (klen - 1 - i / 8)] = (uint8_t)(1u << (i % 8));   // 2^i
   HIP_TRY(hipMemcpy(k1, h1.data(), h1.size(), hipMemcpyHostToDevice));
-  // base = [P, Q] as a two-element SoA
-  HIP_TRY(hipMemset(base.inf, 0, base.stride));
-  for (int b = 0; b < 2; ++b) {
-    const SoA2 key = b ? c->key_Q() : c->key_P();
-    HIP_TRY(hipMemcpy2D(base.c0 + b, base.stride * 4, key.c0, 4, 4, (size_t)c->nl, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy2D(base.c1 + b, base.stride * 4, key.c1, 4, 4, (size_t)c->nl, hipMemcpyDeviceToDevice));
-  }
   uint32_t* tabs[2] = {nullptr, nullptr};
-  const size_t tab_bytes = ne * 2 * (size_t)c->nl * 4;
   for (int b = 0; b < 2; ++b) {
+    const size_t tab_bytes = ((size_t)W[b] << wb[b]) * 2 * (size_t)c->nl * 4;
     if (hipMalloc((void**)&tabs[b], tab_bytes) != hipSuccess) {
       if (tabs[0]) (void)hipFree(tabs[0]);
       return fail(BGN_E_NOMEM, "fixed-base window tables");
     }
     HIP_TRY(hipMemset(tabs[b], 0, tab_bytes));
   }
-  {
+  // the entries 2^i * B of both tables by the ladder kernel, one launch per base (the base is a broadcast point)
+  for (size_t b = 0, o = 0; b < 2; o += np[b], ++b) {
+    const SoA2 key = b ? c->key_Q() : c->key_P();
     G1MulArgs a;
-    a.bx = base.c0; a.by = base.c1; a.binf = base.inf; a.sb = base.stride;
-    a.bdiv = np;
-    a.k = k1; a.kstride = klen; a.klen = klen;
-    a.ox = pw.c0; a.oy = pw.c1; a.oinf = pw.inf; a.so = pw.stride;
-    a.count = 2 * np;
+    a.bx = key.c0; a.by = key.c1; a.binf = nullptr; a.sb = 1;
+    a.bdiv = 0;
+    a.k = k1 + o * klen; a.kstride = klen; a.klen = klen;
+    a.ox = pw.c0 + o; a.oy = pw.c1 + o; a.oinf = pw.inf + o; a.so = pw.stride;
+    a.count = np[b];
     kt->g1_mul(nullptr, c->d_params, c->d_consts, a);
-    kt->to_mont(nullptr, c->d_params, pw.c0, pw.c1, pw.stride, 2 * np);
   }
-  for (int b = 0; b < 2; ++b) {
-    kt->tab_scatter_pow(nullptr, pw.c0 + b * np, pw.c1 + b * np, pw.stride, np, wbits, tabs[b]);
-    for (int k = 1; k < wbits; ++k) {
+  kt->to_mont(nullptr, c->d_params, pw.c0, pw.c1, pw.stride, npt);
+  for (size_t b = 0, o = 0; b < 2; o += np[b], ++b) {
+    kt->tab_scatter_pow(nullptr, pw.c0 + o, pw.c1 + o, pw.stride, np[b], wb[b], tabs[b]);
+    for (int k = 1; k < wb[b]; ++k) {
       G1TabRoundArgs a;
-      a.tab = tabs[b]; a.wbits = wbits; a.windows = W; a.k = k;
+      a.tab = tabs[b]; a.wbits = wb[b]; a.windows = W[b]; a.k = k;
       a.prefix = prefix; a.sp = sr;
-      a.count = (size_t)W * (((size_t)1 << k) - 1);
+      a.count = (size_t)W[b] * (((size_t)1 << k) - 1);
       a.run = run_for(a.count);
       kt->g1_tab_round(nullptr, c->d_params, c->d_consts, a);
     }
@@ -765,14 +788,18 @@ int ensure_fixed_tables(bgn_ctx* c) {
   HIP_TRY(hipDeviceSynchronize());
   c->d_tabP = tabs[0];
   c->d_tabQ = tabs[1];
-  c->fixed_windows = W;
-  c->fixed_wbits = wbits;
+  c->fixed_windows = W[0];
+  c->fixed_wbits = wb[0];
+  c->fixed_windows_q = W[1];
+  c->fixed_wbits_q = wb[1];
+  (void)base;
   return BGN_OK;
 }
 
-// Does a big-endian scalar of `len` bytes fit the window tables?
-bool fixed_fits(const bgn_ctx* c, size_t len) {
-  return (len * 8 + c->fixed_wbits - 1) / c->fixed_wbits <= (size_t)c->fixed_windows;
+// Does a big-endian scalar of `len` bytes fit the window table of P (of Q)?
+bool fixed_fits(const bgn_ctx* c, size_t len, bool q = false) {
+  const int wbits = q ? c->fixed_wbits_q : c->fixed_wbits;
+  return (len * 8 + wbits - 1) / wbits <= (size_t)(q ? c->fixed_windows_q : c->fixed_windows);
 }
 
 // S <- P^x * Q^r (x_be or r_be may be null) by one table entry per window: one k_g1_fixed_step launch per
@@ -787,9 +814,9 @@ constexpr int kFixedChains = 4;
 
 int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, const uint8_t* x_be, size_t x_len,
                        const uint8_t* r_be, size_t r_len, size_t count, bool timed) {
-  const int wbits = c->fixed_wbits;
-  const int wx = x_be ? (int)((x_len * 8 + wbits - 1) / wbits) : 0;
-  const int wr = r_be ? (int)((r_len * 8 + wbits - 1) / wbits) : 0;
+  const int wbp = c->fixed_wbits, wbq = c->fixed_wbits_q;
+  const int wx = x_be ? (int)((x_len * 8 + wbp - 1) / wbp) : 0;
+  const int wr = r_be ? (int)((r_len * 8 + wbq - 1) / wbq) : 0;
   const int steps = wx + wr;
   bool chains = steps >= 2 * kFixedChains;
   if (const char* ev = getenv("BGN_FIXED_CHAINS"))
@@ -822,7 +849,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
     for (int i = 0; i < csteps; ++i) {
       G1FixedChainArgs a;
       a.sx = X.c0; a.sy = X.c1; a.sinf = X.inf; a.ss = X.stride;
-      a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.wbits = wbits;
+      a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.wbits_p = wbp; a.wbits_q = wbq;
       a.x = x_be; a.xlen = x_len; a.wx = wx;
       a.r = r_be; a.rlen = r_len; a.wr = wr;
       a.step = i; a.steps = csteps; a.chains = kFixedChains;
@@ -863,7 +890,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
     const bool isx = i < wx;
     G1FixedStepArgs a;
     a.sx = S.c0; a.sy = S.c1; a.sinf = S.inf; a.ss = S.stride;
-    a.tab = isx ? c->d_tabP : c->d_tabQ; a.wbits = wbits; a.window = isx ? i : i - wx;
+    a.tab = isx ? c->d_tabP : c->d_tabQ; a.wbits = isx ? wbp : wbq; a.window = isx ? i : i - wx;
     a.k = isx ? x_be : r_be; a.klen = isx ? x_len : r_len;
     a.prefix = prefix; a.sp = S.stride;
     a.count = count;
@@ -919,7 +946,7 @@ void gt_pow_norm1_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, si
 // Blind a level-1 result R (plain) with Q^r (bgn.go:488-495): R <- R + Q^r.  T1/T2 scratch G1 arrays.
 void blind_l1(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_len, SoA2 T1, SoA2 T2, uint32_t* prefix,
               size_t count) {
-  if (c->d_tabQ && fixed_fits(c, r_len)) {                                  // h1 = Q^r from the window table
+  if (c->d_tabQ && fixed_fits(c, r_len, true)) {                            // h1 = Q^r from the window table
     (void)fixed_base_product(c, s, T1, prefix, nullptr, 0, r_be, r_len, count, false);
   } else {
     g1_mul_launch(c, s, c->key_Q(), r_be, r_len, r_len, T1, count);        // generic ladder for over-long r
@@ -1165,7 +1192,7 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
     int rc = ensure_fixed_tables(c);      // may re-carve the arena: G/H/O are re-derived below
     if (rc) return rc;
   }
-  if (fixed_fits(c, x_len) && (!r_be || fixed_fits(c, r_len))) {
+  if (fixed_fits(c, x_len) && (!r_be || fixed_fits(c, r_len, true))) {
     for (int pass = 0; pass < 2; ++pass) {
       Ws w(c, pass ? c->arena : nullptr);
       G = w.g1(st);

@@ -52,7 +52,7 @@ struct G1FixedStepArgs {
 // additions than with one chain; the chain sums are added up afterwards.
 struct G1FixedChainArgs {
   uint32_t* sx; uint32_t* sy; uint8_t* sinf; size_t ss;                     // state, canonical Montgomery, chains*pitch slots
-  const uint32_t* tabP; const uint32_t* tabQ; int wbits;
+  const uint32_t* tabP; const uint32_t* tabQ; int wbits_p; int wbits_q;       // window widths of the two tables
   const uint8_t* x; size_t xlen; int wx;                                    // x == null: wx = 0
   const uint8_t* r; size_t rlen; int wr;                                    // r == null: wr = 0
   int step; int steps; int chains;

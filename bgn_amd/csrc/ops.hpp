@@ -13,13 +13,22 @@ __device__ __forceinline__ u32 scalar_bit(const uint8_t* __restrict__ k, size_t 
   return (k[len - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u;
 }
 
-// Digit `window` (wbits = 8 or 16 bits wide, counted from the least significant end) of a big-endian scalar.
+// Digit `window` (wbits <= 24 bits wide, counted from the least significant end) of a big-endian scalar.
 __device__ __forceinline__ u32 scalar_window(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
   if (wbits == 8) return k[klen - 1 - (size_t)window];
-  const size_t lo = 2 * (size_t)window;
-  u32 d = k[klen - 1 - lo];
-  if (lo + 1 < klen) d |= (u32)k[klen - 2 - lo] << 8;
-  return d;
+  if (wbits == 16) {
+    const size_t lo = 2 * (size_t)window;
+    u32 d = k[klen - 1 - lo];
+    if (lo + 1 < klen) d |= (u32)k[klen - 2 - lo] << 8;
+    return d;
+  }
+  const size_t bit0 = (size_t)window * (size_t)wbits;
+  const size_t byte = bit0 >> 3;
+  u32 v = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (byte + i < klen) v |= (u32)k[klen - 1 - (byte + i)] << (8 * i);
+  return (v >> (bit0 & 7)) & ((1u << wbits) - 1u);      // wbits + 7 <= 31 bits of the 32 fetched
 }
 
 // r = 1/a ; a <4 in VGPRs ; result <1 (0 for a = 0).  Uses L[0] (stage).  Division steps (fpinv.hpp), not
@@ -458,10 +467,11 @@ struct G1IoFixedChain {
     const bool isx = gw < A.wx;
     const int lw = isx ? gw : gw - A.wx;
     u32 d = 0;
-    if (live) d = isx ? scalar_window(A.x + e * A.xlen, A.xlen, A.wbits, lw) : scalar_window(A.r + e * A.rlen, A.rlen, A.wbits, lw);
+    const int wb = isx ? A.wbits_p : A.wbits_q;
+    if (live) d = isx ? scalar_window(A.x + e * A.xlen, A.xlen, wb, lw) : scalar_window(A.r + e * A.rlen, A.rlen, wb, lw);
     // entry (lw, 0) is all zero and always mapped: dead lanes and zero digits read it and add the identity
     const u32* tab = isx ? A.tabP : A.tabQ;
-    tab_load<NL>(x, y, inf, tab + ((((size_t)(live ? lw : 0)) << A.wbits) + d) * (size_t)(2 * NL));
+    tab_load<NL>(x, y, inf, tab + ((((size_t)(live ? lw : 0)) << wb) + d) * (size_t)(2 * NL));
     inf = inf || d == 0;
   }
   __device__ __forceinline__ void store(size_t v, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>*,

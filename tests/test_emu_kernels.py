@@ -155,7 +155,7 @@ def test_emu_poly_accumulation(ctx):
     assert [o.hex() for o in E.poly_acc(Ew, po["d1"], po["d2"])] == po["out"]
 
 
-@pytest.mark.parametrize("wbits", [8, 16])
+@pytest.mark.parametrize("wbits", [8, 11, 16])
 def test_emu_fixed_base_encrypt(wbits):
     """Window-table Encrypt (P^x * Q^r, one table entry per window, no doublings) incl. zero digits, x = 0,
     r = 0, odd scalar lengths and scalars >= n; the table itself is built by the engine's round scheme and

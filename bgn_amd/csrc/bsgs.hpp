@@ -380,9 +380,9 @@ __device__ __forceinline__ void poly_acc_lane(const PolyAccArgs& A, size_t lane,
     }
   }
   Fp<NL> o;
-  fp_from_mont<NL>(o, a0, P, L);
+  if (A.mont_out) fp_reduce8(o, a0, P); else fp_from_mont<NL>(o, a0, P, L);
   if (live) g_store<NL>(A.o0, A.so, lane, o);
-  fp_from_mont<NL>(o, a1, P, L);
+  if (A.mont_out) fp_reduce8(o, a1, P); else fp_from_mont<NL>(o, a1, P, L);
   if (live) g_store<NL>(A.o1, A.so, lane, o);
 }
 

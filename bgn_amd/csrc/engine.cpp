@@ -88,6 +88,11 @@ struct bgn_ctx {
   BsgsParams bsgs{};
   bool have_tables = false;
 
+  // MultPoly's per-coefficient line tables: kept between calls (a 40 GB hipMalloc / hipFree per call costs
+  // seconds now and then), released before the other large per-key tables are sized
+  uint32_t* poly_tab = nullptr;
+  size_t poly_tab_bytes = 0;
+
   // scratch of the fixed-base products' accumulation chains (grown on demand, like the arena)
   uint8_t* chain_ws = nullptr;
   size_t chain_ws_bytes = 0;
@@ -109,6 +114,15 @@ struct bgn_ctx {
 };
 
 namespace {
+
+// Give MultPoly's cached line tables back (before sizing another large table against the free memory).
+void release_poly_tables(bgn_ctx* c) {
+  if (!c->poly_tab) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->poly_tab);
+  c->poly_tab = nullptr;
+  c->poly_tab_bytes = 0;
+}
 
 int ensure_arena(bgn_ctx* c, size_t bytes) {
   if (bytes <= c->arena_bytes) return BGN_OK;
@@ -199,6 +213,7 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   (void)hipDeviceSynchronize();
   if (c->arena) (void)hipFree(c->arena);
   if (c->chain_ws) (void)hipFree(c->chain_ws);
+  if (c->poly_tab) (void)hipFree(c->poly_tab);
   if (c->d_params) (void)hipFree(c->d_params);
   if (c->d_consts) (void)hipFree(c->d_consts);
   if (c->d_keypts) (void)hipFree(c->d_keypts);
@@ -413,6 +428,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if (msg_space < 1 || msg_space > ((uint64_t)1 << 60)) return fail(BGN_E_ARG, "message space out of range");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  release_poly_tables(c);
   const KernelTable* kt = c->kt;
   // gsbs.go:60: bound = ceil(sqrt(T)); getDL returns i*bound + v + 1 <= bound*bound + bound + 2
   double sq = __builtin_sqrt((double)msg_space);
@@ -494,10 +510,11 @@ void blind_l2(bgn_ctx* c, hipStream_t s, SoA2 R, const uint8_t* r_be, size_t r_l
 int ensure_gt_table(bgn_ctx* c);
 }
 
-// pairings per lane: keep 65536 lanes (one wave per SIMD on every CU) busy before lengthening the runs
+// pairings per lane: one wave per SIMD on every CU first (65536 lanes), then lengthen the runs (measured best
+// at 16).  A lane runs for the whole kernel, so the lanes must fit ONE round of 65536: the run is the ceiling
+// of count / 65536 (a floor leaves a second, nearly empty round that doubles the kernel time).
 static int pairing_run(size_t count) {
-  // one wave per SIMD on every CU first (65536 lanes), then lengthen the runs (measured best at 16)
-  size_t r = count / 65536;
+  size_t r = (count + 65535) / 65536;
   if (r < 1) r = 1;
   if (r > 16) r = 16;
   if (const char* ev = getenv("BGN_PAIRING_RUN")) {     // tuning knob for experiments
@@ -720,6 +737,7 @@ int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
 
 int ensure_fixed_tables(bgn_ctx* c) {
   if (c->d_tabP) return BGN_OK;
+  release_poly_tables(c);
   const KernelTable* kt = c->kt;
   int wb[2], W[2];
   size_t np[2], maxc = 0;
@@ -1444,7 +1462,7 @@ size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
     if (ev[0] == '0') return 0;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-  size_t budget = fr / 3;
+  size_t budget = (fr + c->poly_tab_bytes) / 3;          // the cached tables count as free
   if (const char* ev = getenv("BGN_POLY_TABLE_MAX_MB")) {
     const long v = atol(ev);
     if (v > 0 && ((size_t)v << 20) < budget) budget = (size_t)v << 20;
@@ -1454,57 +1472,54 @@ size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
   size_t polys = budget / per_coeff / dt;
   if (polys > npoly) polys = npoly;
   while (polys && round_up(polys * dt, 64) * per_coeff > budget) polys--;
+  // one lane builds one table and runs for the whole kernel: whole rounds of 65536 lanes per chunk
+  const size_t round_polys = 65536 / dt;
+  if (polys < npoly && round_polys && polys > round_polys) polys -= polys % round_polys;
   return polys;
 }
 }  // namespace
 
-int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
-                            uint8_t* out, void* stream) {
-  if (!c || (npoly && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
-  if (!npoly) return BGN_OK;
-  if (!d1 || !d2) return fail(BGN_E_ARG, "polynomial degrees must be positive");
-  if (npoly > kMaxBatch || d1 > 4096 || d2 > 4096 || npoly * d1 * d2 > kMaxBatch)
-    return fail(BGN_E_ARG, "batch too large (max 2^28 coefficient pairs per call)");
-  hipStream_t s = (hipStream_t)stream;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t na = npoly * d1, nb = npoly * d2, no = npoly * (d1 + d2);
-  const size_t sa = round_up(na, 64), sb = round_up(nb, 64), so = round_up(no, 64);
+namespace {
+// The convolution itself on device arrays: A (npoly*d1) and Bv (npoly*d2) level-1 coefficients, canonical
+// Montgomery with identity flags; O (npoly*(d1+d2) GT elements) plain canonical, or canonical Montgomery when
+// the result feeds a Karatsuba combination.  Uses the arena for the pairing values; c->mu held.
+int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2, SoA2 A, SoA2 Bv, SoA2 O, bool mont_out,
+                   bool* used_tables) {
   // tables on the operand with fewer coefficients (each table is then shared by more pairs)
   const bool tab_on_a = d1 <= d2;
   const size_t dt = tab_on_a ? d1 : d2;
   const size_t chunk = (d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
-  SoA2 A, Bv, E, O;
+  SoA2 E;
   uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
-    A = w.g1(sa); Bv = w.g1(sb); E = w.gt(sp); O = w.gt(so);
+    E = w.gt(sp);
     pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : 7) * c->nl * sp * 4);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
     }
   }
-  DevBuf tabbuf;                       // freed on every return path
   uint32_t* tab = nullptr;
   const size_t ts = round_up(cp * dt, 64);
   if (chunk) {
-    if (hipMalloc(&tabbuf.p, c->miller_steps * 3 * (size_t)c->nl * 4 * ts) != hipSuccess)
-      return fail(BGN_E_NOMEM, "MultPoly line tables (%zu MB)", (c->miller_steps * 3 * (size_t)c->nl * 4 * ts) >> 20);
-    tab = (uint32_t*)tabbuf.p;
+    const size_t need = c->miller_steps * 3 * (size_t)c->nl * 4 * ts;
+    if (need > c->poly_tab_bytes) {
+      release_poly_tables(c);
+      if (hipMalloc((void**)&c->poly_tab, need) != hipSuccess) return fail(BGN_E_NOMEM, "MultPoly line tables (%zu MB)", need >> 20);
+      c->poly_tab_bytes = need;
+    }
+    tab = c->poly_tab;
   }
   const KernelTable* kt = c->kt;
-  kt->decode(s, c->d_params, a, c->L, na, A);
-  kt->decode(s, c->d_params, b, c->L, nb, Bv);
   auto view = [](SoA2 v, size_t off) {
     v.c0 += off;
     v.c1 += off;
     if (v.inf) v.inf += off;
     return v;
   };
-  HIP_TRY(hipEventRecord(c->ev0, s));
   for (size_t q0 = 0; q0 < npoly; q0 += cp) {
     const size_t nq = (npoly - q0 < cp) ? npoly - q0 : cp;
     const size_t pairs = nq * d1 * d2;
@@ -1523,14 +1538,99 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
     pa.e0 = E.c0; pa.e1 = E.c1; pa.se = E.stride;
     pa.o0 = O.c0 + q0 * (d1 + d2); pa.o1 = O.c1 + q0 * (d1 + d2); pa.so = O.stride;
     pa.npoly = nq; pa.d1 = d1; pa.d2 = d2;
+    pa.mont_out = mont_out ? 1 : 0;
     kt->poly_acc(s, c->d_params, pa);                                              // result[i+k] = Add(result[i+k], coeff), poly.go:148
+  }
+  HIP_TRY(hipGetLastError());
+  if (used_tables) *used_tables = chunk != 0;
+  return BGN_OK;
+}
+}  // namespace
+
+// Square products of even length run as Karatsuba over the bilinear pairing (polyops.hpp): L levels turn npoly
+// products of d x d coefficients into 3^L * npoly products of d/2^L x d/2^L, which go through the table path
+// above; 16 x 16 becomes 27 products of 2 x 2 = 108 table evaluations + 54 tables instead of 256 + 16.
+// BGN_POLY_KARATSUBA=0 multiplies directly.
+int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                            uint8_t* out, void* stream) {
+  if (!c || (npoly && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!npoly) return BGN_OK;
+  if (!d1 || !d2) return fail(BGN_E_ARG, "polynomial degrees must be positive");
+  if (npoly > kMaxBatch || d1 > 4096 || d2 > 4096 || npoly * d1 * d2 > kMaxBatch)
+    return fail(BGN_E_ARG, "batch too large (max 2^28 coefficient pairs per call)");
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  int levels = 0;
+  {
+    const char* ev = getenv("BGN_POLY_KARATSUBA");
+    if (d1 == d2 && !(ev && ev[0] == '0'))
+      for (size_t dk = d1; dk % 2 == 0 && dk >= 4; dk /= 2) levels++;
+  }
+  // level k holds n[k] = 3^k * npoly polynomials of dk[k] = d / 2^k coefficients
+  std::vector<size_t> n(levels + 1), dk(levels + 1);
+  n[0] = npoly;
+  dk[0] = d1;
+  for (int k = 1; k <= levels; ++k) {
+    n[k] = 3 * n[k - 1];
+    dk[k] = dk[k - 1] / 2;
+  }
+  // scratch outside the arena (the core carves the arena): operands of every level, results of every level
+  const KernelTable* kt = c->kt;
+  std::vector<SoA2> A(levels + 1), B(levels + 1), R(levels + 1);
+  uint32_t* prefix = nullptr;
+  DevBuf scratch;
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver cv((uint8_t*)scratch.p);
+    size_t maxsplit = 64;
+    for (int k = 0; k <= levels; ++k) {
+      const size_t da = (k == 0) ? d1 : dk[k], db = (k == 0) ? d2 : dk[k];
+      A[k] = cv.soa(c->nl, round_up(n[k] * da, 64), true);
+      B[k] = cv.soa(c->nl, round_up(n[k] * db, 64), true);
+      R[k] = cv.soa(c->nl, round_up(n[k] * (da + db), 64), false);
+      if (k && n[k] * dk[k] > maxsplit) maxsplit = n[k] * dk[k];
+    }
+    prefix = (uint32_t*)cv.take(round_up(maxsplit, 64) * (size_t)c->nl * 4);
+    if (!pass) {
+      int rc = scratch.alloc(cv.off);
+      if (rc) return rc;
+    }
+  }
+  kt->decode(s, c->d_params, a, c->L, npoly * d1, A[0]);
+  kt->decode(s, c->d_params, b, c->L, npoly * d2, B[0]);
+  HIP_TRY(hipEventRecord(c->ev0, s));
+  for (int k = 0; k < levels; ++k) {
+    for (int side = 0; side < 2; ++side) {
+      const SoA2 src = side ? B[k] : A[k], dst = side ? B[k + 1] : A[k + 1];
+      PolySplitArgs ps;
+      ps.sx = src.c0; ps.sy = src.c1; ps.sinf = src.inf; ps.ss = src.stride;
+      ps.dx = dst.c0; ps.dy = dst.c1; ps.dinf = dst.inf; ps.sd = dst.stride;
+      ps.n = n[k]; ps.h = dk[k + 1];
+      ps.prefix = prefix; ps.sp = round_up(n[k + 1] * dk[k + 1], 64);
+      ps.run = run_for(n[k + 1] * dk[k + 1]);
+      kt->poly_split(s, c->d_params, c->d_consts, ps);
+    }
+  }
+  bool used_tables = false;
+  {
+    const size_t da = levels ? dk[levels] : d1, db = levels ? dk[levels] : d2;
+    int rc = poly_mult_core(c, s, n[levels], da, db, A[levels], B[levels], R[levels], levels != 0, &used_tables);
+    if (rc) return rc;
+  }
+  for (int k = levels - 1; k >= 0; --k) {
+    PolyCombineArgs pc;
+    pc.p0 = R[k + 1].c0; pc.p1 = R[k + 1].c1; pc.sp = R[k + 1].stride;
+    pc.o0 = R[k].c0; pc.o1 = R[k].c1; pc.so = R[k].stride;
+    pc.n = n[k]; pc.h = dk[k + 1];
+    pc.plain_out = (k == 0) ? 1 : 0;
+    kt->poly_combine(s, c->d_params, pc);
   }
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
-  c->last_kernel = chunk ? "k_fixedpair_build_batch + k_pairing<.,1>" : kt->pairing_kernel_name;
-  kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, no, out);
+  c->last_kernel = used_tables ? "k_fixedpair_build_batch + k_pairing<.,1>" : kt->pairing_kernel_name;
+  kt->encode(s, nullptr, R[0].c0, R[0].c1, R[0].stride, c->L, npoly * (d1 + d2), out);
   HIP_TRY(hipGetLastError());
-  if (tab) HIP_TRY(hipStreamSynchronize(s));   // the tables are released on return
+  HIP_TRY(hipStreamSynchronize(s));            // the scratch arrays are released on return
   return BGN_OK;
 }
 

@@ -139,6 +139,24 @@ struct PolyAccArgs {
   const uint32_t* e0; const uint32_t* e1; size_t se;   // pairings, canonical Montgomery, index (q*d1 + i)*d2 + k
   uint32_t* o0; uint32_t* o1; size_t so;               // plain canonical, index q*(d1+d2) + s
   size_t npoly, d1, d2;
+  int mont_out;                                        // canonical Montgomery out (an inner product of the Karatsuba scheme)
+};
+
+// One Karatsuba level of the ciphertext-polynomial product (polyops.hpp).  Split: n polynomials of d = 2h
+// level-1 coefficients -> 3n polynomials of h coefficients: [low half | low + high | high half] (polynomial
+// t*n + q is part t of polynomial q).  Combine: the 3n products (2h GT coefficients each) -> n products of 4h.
+struct PolySplitArgs {
+  const uint32_t* sx; const uint32_t* sy; const uint8_t* sinf; size_t ss;   // source, canonical Montgomery, index q*d + i
+  uint32_t* dx; uint32_t* dy; uint8_t* dinf; size_t sd;                     // destination, canonical Montgomery, index q'*h + i
+  size_t n, h;
+  uint32_t* prefix; size_t sp;
+  int run;
+};
+struct PolyCombineArgs {
+  const uint32_t* p0; const uint32_t* p1; size_t sp;                        // sub-products, canonical Montgomery, index (t*n + q)*2h + u
+  uint32_t* o0; uint32_t* o1; size_t so;                                    // index q*4h + s
+  size_t n, h;
+  int plain_out;                                                            // last level: plain canonical for the encoder
 };
 
 // Multi-scalar sums over the coefficients of ciphertext polynomials (polyops.hpp):
@@ -214,6 +232,8 @@ struct KernelTable {
   void (*bsgs_search)(hipStream_t s, const void* params, BsgsParams b, BsgsSearchArgs a);
   void (*poly_acc)(hipStream_t s, const void* params, PolyAccArgs a);
   void (*poly_lin)(hipStream_t s, const void* params, const PairingConsts* consts, int level, PolyLinArgs a);
+  void (*poly_split)(hipStream_t s, const void* params, const PairingConsts* consts, PolySplitArgs a);
+  void (*poly_combine)(hipStream_t s, const void* params, PolyCombineArgs a);
   const char* bsgs_kernel_name;
 };
 

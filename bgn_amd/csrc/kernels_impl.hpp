@@ -682,6 +682,39 @@ static void launch_poly_lin(hipStream_t s, const void* params, const PairingCons
                        consts, a);
 }
 
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_poly_split(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, PolySplitArgs A) {
+  __shared__ LFp<NL> L[2];
+  g1_add_run<NL>(G1IoPolySplit<NL>{A}, 3 * A.n * A.h, A.run, A.prefix, A.sp, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_poly_combine(const FpParams<NL>* __restrict__ P, PolyCombineArgs A) {
+  __shared__ LFp<NL> L[4];
+  const size_t total = A.n * 4 * A.h;
+  size_t lane = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = lane < total;
+  if (!__ballot(live)) return;
+  if (!live) lane = total - 1;
+  poly_combine_lane<NL>(A, lane, live, L, P);
+}
+
+static void launch_poly_split(hipStream_t s, const void* params, const PairingConsts* consts, PolySplitArgs a) {
+  const size_t total = 3 * a.n * a.h;
+  if (!total) return;
+  const size_t lanes = (total + a.run - 1) / a.run;
+  hipLaunchKernelGGL(k_poly_split<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts,
+                     a);
+}
+
+static void launch_poly_combine(hipStream_t s, const void* params, PolyCombineArgs a) {
+  const size_t total = a.n * 4 * a.h;
+  if (!total) return;
+  hipLaunchKernelGGL(k_poly_combine<NL_>, dim3(grid_for(total)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, a);
+}
+
 static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
   const size_t total = a.npoly * (a.d1 + a.d2);
   if (!total) return;
@@ -718,6 +751,8 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_bsgs_search,
       launch_poly_acc,
       launch_poly_lin,
+      launch_poly_split,
+      launch_poly_combine,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
   };
   return &t;

@@ -346,7 +346,7 @@ struct Emu {
       for (int l = 0; l < NL; ++l) { e0[l * n + i] = E[i * 2 * NL + l]; e1[l * n + i] = E[i * 2 * NL + NL + l]; }
     PolyAccArgs A;
     A.e0 = e0.data(); A.e1 = e1.data(); A.se = n; A.o0 = o0.data(); A.o1 = o1.data(); A.so = deg;
-    A.npoly = 1; A.d1 = d1; A.d2 = d2;
+    A.npoly = 1; A.d1 = d1; A.d2 = d2; A.mont_out = 0;
     for (size_t s = 0; s < deg; ++s) poly_acc_lane<NL>(A, s, true, lds(), P);
     for (size_t s = 0; s < deg; ++s)
       for (int l = 0; l < NL; ++l) { out[s * 2 * NL + l] = o0[l * deg + s]; out[s * 2 * NL + NL + l] = o1[l * deg + s]; }

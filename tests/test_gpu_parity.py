@@ -311,6 +311,11 @@ def test_poly_mult_many_vs_c_oracle_and_decrypt():
     (3, 3, {"BGN_POLY_TABLE_MAX_MB": "3"}),      # table budget of 3 MB = 64 columns: 21 polynomials per chunk
     (4, 3, {"BGN_POLY_TABLES": "0"}),            # direct d1*d2 full pairings
     (1, 4, {}), (4, 1, {}), (1, 1, {}),          # degenerate shapes
+    (2, 2, {}),                                  # square, below the Karatsuba threshold
+    (4, 4, {}), (8, 8, {}),                      # Karatsuba: one and two levels down to 2 x 2
+    (6, 6, {}),                                  # one level, odd leaves 3 x 3
+    (8, 8, {"BGN_POLY_KARATSUBA": "0"}),         # the same product without it
+    (4, 4, {"BGN_POLY_TABLES": "0"}),            # Karatsuba over direct pairings at the leaves
 ])
 def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
     """MultPoly over per-coefficient line tables (fixedpair.hpp) == the oracle's d1*d2 full pairings +

@@ -472,3 +472,22 @@ def test_validate_batch(name):
     bad = bytearray(bytes(l2[0])); bad[3] ^= 0x40
     rows = [bytes(l2[0]), bytes(l2[1]), one, bytes(bad), ident]
     assert [int(v) for v in pk.engine.validate(2, b"".join(rows))] == [1, 1, 1, 0, 0]
+
+
+def test_decrypt_with_unusual_secrets_does_not_misbehave():
+    """bgn_ctx_set_secret builds the secret-order line table only when the secret divides n; any other value
+    falls back to the table of P.  A wrong secret must simply fail to find discrete logs (or find the trivial
+    one), never crash; the right one must still decrypt afterwards."""
+    import bgn_amd
+    fx = load_fixture("k256")
+    pk, sk = engine_key(fx)
+    n, q1 = int(fx["n"], 16), int(fx["q1"], 16)
+    cts = pk.EncryptBatch([5, 0, 9], [11, 0, 13])
+    wire = b"".join(c.C for c in cts)
+    for wrong in (n // q1, q1 + 2, 1):             # the other prime factor; not a factor; trivial
+        pk.SetupDecryption(bgn_amd.SecretKey(wrong))
+        m, st = pk.engine.decrypt(1, wire)
+        assert len(m) == 3 and int(st[1]) == 0 and int(m[1]) == 0      # the identity decrypts to 0 under any key
+    pk.SetupDecryption(sk)
+    m, st = pk.engine.decrypt(1, wire)
+    assert not st.any() and [int(v) for v in m] == [5, 0, 9]

@@ -361,12 +361,16 @@ __device__ __forceinline__ void fp_sqr_segment(u64 (&t)[NL], u64& aa, const LFp<
 }
 
 // Measured on MI355X (round 1, tools/ubench/fp_rates.hip and same-box A/B of bench.py): in isolation the
-// segmented square takes 6.6 us against 8.0 us for fp_mul, but inside k_pairing it made the kernel 3 %
-// SLOWER: the step bodies are straight-line code far larger than the 64 KB instruction cache, and the four
-// short loops (4-5 trips each) pay their cold first trip every time, where the product's single loop
-// amortises it over 19 trips.  The compact-code interpreter (vm.hpp) uses it (fp_sqr_seg); the inlined
-// programs do not.
-constexpr bool kSegmentedSquare = false;
+// segmented square takes 6.6 us against 8.0 us for fp_mul.  Inside k_pairing its effect depends on what the
+// compiler makes of the surrounding step program: the first kernel of the round got 3 % SLOWER with it
+// (four short loops per square in 120 KB of straight-line code), the kernel at the end of the round —
+// buffer-descriptor loads, windowed loop — gains 2.6 % with four segments and 3.3 % with five (2920 -> 2845 ms
+// per 2^20 pairings), while THREE segments lose 11 % (3237 ms).  -DBGN_SQUARE_SEGMENTS=1 selects fp_mul.
+#ifndef BGN_SQUARE_SEGMENTS
+#define BGN_SQUARE_SEGMENTS 5
+#endif
+constexpr bool kSegmentedSquare = BGN_SQUARE_SEGMENTS > 1;
+constexpr int kSquareSegments = BGN_SQUARE_SEGMENTS > 1 ? BGN_SQUARE_SEGMENTS : 4;
 
 // r = a^2/R mod p by the segmented square, lazy (< 2p); `a` both as LDS rows (streamed multiplier) and in
 // VGPRs.  r may alias av.
@@ -376,16 +380,33 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
   if constexpr (NL < 8) {
     fp_mul<NL>(r, a, av, P);
   } else {
-    constexpr int Q = ((NL / 4 + 1) / 2) * 2;   // even segment length: 10 at NL = 38, 4 at NL = 19
+    // even segment length: 10 at NL = 38 with four segments
+    constexpr int Q = ((NL / kSquareSegments + 1) / 2) * 2;
+    static_assert((kSquareSegments - 1) * Q < NL, "segment layout");
     const int tid = threadIdx.x;
     u64 t[NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) t[j] = 0;
     u64 aa = a->rows[0][tid];
-    fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
-    fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
-    fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
-    fp_sqr_segment<NL, 3 * Q, NL>(t, aa, a, tid, av, P);
+    if constexpr (kSquareSegments == 2) {
+      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, Q, NL>(t, aa, a, tid, av, P);
+    } else if constexpr (kSquareSegments == 3) {
+      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 2 * Q, NL>(t, aa, a, tid, av, P);
+    } else if constexpr (kSquareSegments == 4) {
+      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 3 * Q, NL>(t, aa, a, tid, av, P);
+    } else {
+      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 4 * Q, NL>(t, aa, a, tid, av, P);
+    }
     u64 c = 0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {

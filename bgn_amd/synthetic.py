@@ -53,16 +53,30 @@ def miller_schedule(n: int, window: int = 3):
 INVERSION_PRODUCTS = 55
 
 
-def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 3) -> int:
-    """32x32->64 multiply-adds one pairing needs in this formulation:
-    (#field products) * 2*NL^2 (schoolbook product + Montgomery reduction rows).
+def square_mads(nl: int, segments: int = 5) -> int:
+    """Multiply-adds of one Montgomery squaring by the segmented square of fp28.hpp: row i of segment
+    [lo, hi) multiplies a_i by the limbs j >= lo (doubled beyond hi), plus the nl reduction MADs per row."""
+    if nl < 8 or segments <= 1:
+        return 2 * nl * nl
+    q = ((nl // segments + 1) // 2) * 2
+    bounds = [k * q for k in range(segments)] + [nl]
+    prod = sum((hi - lo) * (nl - lo) for lo, hi in zip(bounds[:-1], bounds[1:]))
+    return prod + nl * nl
+
+
+def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 3, segments: int = 5) -> int:
+    """32x32->64 multiply-adds one pairing executes in this formulation: general field products at 2*NL^2
+    (schoolbook product + Montgomery reduction rows), squarings at the segmented square's count.
     The F_p inversion of the final exponentiation is shared by `run` pairings per lane."""
     p, n, l = int(fx["p"], 16), int(fx["n"], 16), int(fx["l"])
     nl = 38 if p.bit_length() > 600 else (19 if p.bit_length() > 300 else (10 if p.bit_length() > 100 else 3))
     dbl, add, threes, pre = miller_schedule(n, window)
     lb = l.bit_length()
-    lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l
+    lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l (no field squarings)
     # Miller + norms (both passes) + peel + conj(f)^2/N + ^l + from_mont
     per_pairing = pre + dbl * 18 + add * 17 + threes * 3 + 2 * 2 + 3 + 5 + lpow + 2
+    # of which field squarings: 6 per doubling step, 3 per addition step (pairing.hpp), 9 in the set-up of the
+    # windowed loop, 4 + 2 in the norms / conj(f)^2
+    squares = dbl * 6 + add * 3 + (9 if window > 2 else 0) + 6
     products = per_pairing + INVERSION_PRODUCTS / run
-    return int(products * 2 * nl * nl)
+    return int((products - squares) * 2 * nl * nl + squares * square_mads(nl, segments))

@@ -400,12 +400,20 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
       fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 3 * Q, NL>(t, aa, a, tid, av, P);
-    } else {
+    } else if constexpr (kSquareSegments == 5) {
       fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 4 * Q, NL>(t, aa, a, tid, av, P);
+    } else {
+      static_assert(kSquareSegments == 6, "2 to 6 segments");
+      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 4 * Q, 5 * Q>(t, aa, a, tid, av, P);
+      fp_sqr_segment<NL, 5 * Q, NL>(t, aa, a, tid, av, P);
     }
     u64 c = 0;
 #pragma unroll

@@ -14,7 +14,7 @@ import ctypes as C
 import math
 import secrets
 from dataclasses import dataclass
-from typing import Iterable, List, Optional, Sequence, Union
+from typing import List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -557,7 +557,6 @@ class PublicKey:
     def NewUnbalancedPlaintext(self, m):
         """plaintext.go:34-63: digits of the unbalanced base-b expansion of m >= 0 and its scale factor.
         Integers only need the expansion; a fractional m goes through `rationalize` first."""
-        from fractions import Fraction
         scale = 0
         if isinstance(m, float) and m != int(m):
             import math

@@ -290,10 +290,22 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
     unsigned long long key;
     u32 check;
     bsgs_fingerprint<NL>(key, check, rc);
+    // the first slot of the probe sequence is fetched before the next step's product and examined after it:
+    // at one wave per SIMD nothing else hides the ~2 us of a random HBM access
+    unsigned long long h = bsgs_mix(key) & B.mask;
+    BsgsSlot s0;
+    s0.key = 0ull;
+    s0.check = 0;
+    s0.val = 0;
+    if (!done) s0 = B.table[h];
+    Fp<NL> nx;
+    fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
+    fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
+    rp = rc;
+    fp_reduce8(rc, nx, P);
     if (!done) {
-      unsigned long long h = bsgs_mix(key) & B.mask;
+      BsgsSlot s = s0;
       for (;;) {
-        const BsgsSlot s = B.table[h];
         if (s.key == 0ull) break;
         if (s.key == key && ((s.check ^ check) & 0x7fffffffu) == 0u) {
           hit = true;        // m is unique: whatever this hit decodes to decides the attempt
@@ -304,13 +316,9 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
           break;
         }
         h = (h + 1) & B.mask;
+        s = B.table[h];
       }
     }
-    Fp<NL> nx;
-    fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
-    fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
-    rp = rc;
-    fp_reduce8(rc, nx, P);
   }
   if (__ballot(hit)) {
     // Im(y_hit) for the lanes that hit: y_hit = x * (gamma^-1)^hit_i

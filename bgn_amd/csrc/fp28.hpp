@@ -371,6 +371,7 @@ __device__ __forceinline__ void fp_sqr_segment(u64 (&t)[NL], u64& aa, const LFp<
 #endif
 constexpr bool kSegmentedSquare = BGN_SQUARE_SEGMENTS > 1;
 constexpr int kSquareSegments = BGN_SQUARE_SEGMENTS > 1 ? BGN_SQUARE_SEGMENTS : 4;
+static_assert(kSquareSegments >= 2 && kSquareSegments <= 6, "2 to 6 segments");
 
 // r = a^2/R mod p by the segmented square, lazy (< 2p); `a` both as LDS rows (streamed multiplier) and in
 // VGPRs.  r may alias av.
@@ -407,7 +408,6 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
       fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 4 * Q, NL>(t, aa, a, tid, av, P);
     } else {
-      static_assert(kSquareSegments == 6, "2 to 6 segments");
       fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);

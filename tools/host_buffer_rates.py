@@ -1,0 +1,36 @@
+"""Host-buffer (PCIe-inclusive) rates of the no-suffix entry points at the 1024-bit key: what a cgo caller with
+Go-owned slices sees."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from conftest import load_fixture, engine_key
+import bgn_amd
+fx = load_fixture("k1024")
+pk, sk = engine_key(fx)
+eng = pk.engine
+n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
+rng = np.random.default_rng(1)
+xs = rng.integers(0, 256, (n, 5), dtype=np.uint8)
+rs = rng.integers(0, 256, (n, 128), dtype=np.uint8); rs[:, 0] &= 0x3F
+import ctypes as C
+from bgn_amd._lib import check
+out = np.zeros((n, eng.elem_bytes), dtype=np.uint8)
+P = lambda a: a.ctypes.data_as(C.c_void_p)
+
+
+def timed(label, fn, units, reps=2):
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+    print("%-14s n=%d  %.1f ms  %.3e /s" % (label, units, dt * 1e3, units / dt), flush=True)
+
+
+timed("encrypt", lambda: check(eng._lib.bgn_encrypt_batch(eng._h, n, P(xs), 5, P(rs), 128, P(out)), "enc"), n)
+a, b = out[: n // 2].copy(), out[n // 2:].copy()
+o2 = np.zeros_like(a)
+timed("add L1", lambda: check(eng._lib.bgn_add_batch(eng._h, n // 2, 1, P(a), P(b), None, 0, P(o2)), "add"), n // 2)
+m = min(n // 2, 1 << 16)
+timed("mult", lambda: check(eng._lib.bgn_mult_batch(eng._h, m, P(a), P(b), None, 0, P(o2)), "mult"), m)
+pk.SetupDecryption(sk)
+mm = np.zeros(m, dtype=np.int64); st = np.zeros(m, dtype=np.uint8)
+timed("decrypt L1", lambda: check(eng._lib.bgn_decrypt_batch(eng._h, m, 1, P(out), P(mm), P(st)), "dec"), m)

@@ -44,8 +44,23 @@ def _worker(rank, world, port, total, q):
 
     got = sharded_apply(op, total, E, E, [ta, tb], world, rank, dist)
     full = o.mult(a, b)
+    ok = got.numpy().tobytes() == full
+    # MultPoly shards by polynomial (BASELINE configs[4]): the unit is one polynomial of d coefficients in and
+    # 2d GT coefficients out, so every product's accumulation stays on one rank
+    d = 2
+    npoly = total // d
+    if npoly:
+        pa, pb = ta[: npoly * d * E], tb[: npoly * d * E]
+
+        def pop(sa, sb):
+            n_here = sa.numel() // (d * E)
+            return torch.frombuffer(bytearray(o.poly_mult(n_here, d, d, sa.numpy().tobytes(), sb.numpy().tobytes())),
+                                    dtype=torch.uint8)
+
+        gotp = sharded_apply(pop, npoly, d * E, 2 * d * E, [pa, pb], world, rank, dist)
+        ok = ok and gotp.numpy().tobytes() == o.poly_mult(npoly, d, d, pa.numpy().tobytes(), pb.numpy().tobytes())
     lo, hi = shard_range(total, world, rank)
-    q.put((rank, got.numpy().tobytes() == full, (lo, hi)))
+    q.put((rank, ok, (lo, hi)))
     dist.destroy_process_group()
 
 

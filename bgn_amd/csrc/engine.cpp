@@ -85,6 +85,7 @@ struct bgn_ctx {
   // NAF is that of q2 = n / q1 — half the Miller steps of e(P, .)
   PairingConsts* d_consts_sk = nullptr;
   uint32_t* d_fixedpair_sk = nullptr;
+  bool fixed_normalized = false;       // the key tables hold a/c, b/c (fixedpair.hpp): pairing variant 2
   BsgsParams bsgs{};
   bool have_tables = false;
 
@@ -122,6 +123,22 @@ void release_poly_tables(bgn_ctx* c) {
   (void)hipFree(c->poly_tab);
   c->poly_tab = nullptr;
   c->poly_tab_bytes = 0;
+}
+
+// Divide every line of a per-key table by its c (fixedpair.hpp fixed_normalize_lane): one product less per
+// Miller step for every ciphertext paired with the key.  BGN_FIXED_NORMALIZE=0 keeps (a, b, c).
+bool fixed_normalize_enabled() {
+  const char* ev = getenv("BGN_FIXED_NORMALIZE");
+  return !(ev && ev[0] == '0');
+}
+int normalize_key_table(bgn_ctx* c, uint32_t* tab, size_t steps) {
+  uint32_t* pfx = nullptr;
+  if (hipMalloc((void**)&pfx, steps * (size_t)c->nl * 4) != hipSuccess) return fail(BGN_E_NOMEM, "line-table scratch");
+  c->kt->fixedpair_normalize(nullptr, c->d_params, tab, steps, pfx, c->p_bits + 1);
+  hipError_t e = hipDeviceSynchronize();
+  (void)hipFree(pfx);
+  if (e != hipSuccess) return fail(BGN_E_HIP, "fixedpair_normalize: %s", hipGetErrorString(e));
+  return BGN_OK;
 }
 
 int ensure_arena(bgn_ctx* c, size_t bytes) {
@@ -331,6 +348,8 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
       c->miller_steps = steps;
       HIP_BRK(hipMalloc((void**)&c->d_fixedpair, steps * 3 * (size_t)c->nl * 4));
       kt->fixedpair_build(nullptr, c->d_params, c->d_consts, c->d_keypts, c->d_keypts + c->nl, c->d_fixedpair);
+      c->fixed_normalized = fixed_normalize_enabled();
+      if (c->fixed_normalized && (rc = normalize_key_table(c, c->d_fixedpair, steps)) != BGN_OK) break;
     }
     HIP_BRK(hipGetLastError());
     HIP_BRK(hipDeviceSynchronize());
@@ -392,6 +411,10 @@ int build_secret_order_table(bgn_ctx* c) {
   HIP_TRY(hipMemcpy(c->d_consts_sk, &pc, sizeof pc, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&c->d_fixedpair_sk, steps * 3 * (size_t)c->nl * 4));
   c->kt->fixedpair_build(nullptr, c->d_params, c->d_consts_sk, Pq.c0, Pq.c1, c->d_fixedpair_sk);
+  if (c->fixed_normalized) {
+    int rcn = normalize_key_table(c, c->d_fixedpair_sk, steps);
+    if (rcn) return rcn;
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return BGN_OK;
@@ -472,7 +495,7 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   // (over P's line table: the batch kernel k_pairing<., 0> is then launched by Mult alone, which keeps its
   // rocprofv3 average the per-batch figure bench.py reports)
   kt->pairing(nullptr, c->d_params, c->d_consts, c->key_P(), c->key_P(), t1, 1, 1, 0, 0, 1, nullptr, 0, c->d_fixedpair, 1,
-              0);
+              c->fixed_normalized ? 2 : 0);
   kt->to_mont(nullptr, c->d_params, t1.c0, t1.c1, 1, 1);
   gt_pow_launch(c, nullptr, t1, c->d_sk, 0, c->sk_len, g, 1);
   kt->to_mont(nullptr, c->d_params, g.c0, g.c1, 1, 1);
@@ -568,7 +591,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
   kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
-              (mode == 1) ? c->d_fixedpair : nullptr, 1, pairing_variant());
+              (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : pairing_variant());
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
   c->last_kernel = kt->pairing_kernel_name;
@@ -1395,7 +1418,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
     const bool sk_tab = c->d_fixedpair_sk != nullptr;
     kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
-                pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, 0);
+                pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }

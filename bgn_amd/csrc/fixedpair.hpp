@@ -207,12 +207,58 @@ __device__ __forceinline__ void fixed_build_lane(const FixedTabRef& tr, const u3
   }
 }
 
+// ---- per-key tables: divide every line by its c_s ----------------------------------------------
+// A line may be scaled by any element of F_p^* (the final exponent kills it), so (a_s, b_s, c_s) can be
+// replaced by (a_s/c_s, b_s/c_s, 1): the imaginary part of the line value is then y_C itself and a Miller step
+// needs 6 / 4 products instead of 7 / 5.  The inverses come from one inversion for the whole table
+// (Montgomery's trick over the steps: 5 products per step), worth it for a table that serves every
+// ciphertext of a key; MultPoly's per-coefficient tables, each used by a handful of pairs, stay as they are.
+// One lane; `pfx` = scratch of `steps` F_p values; the table has limb stride 1 (column 0).
+template <int NL>
+__device__ __forceinline__ void fixed_normalize_lane(u32* tab, size_t steps, u32* pfx, int p_bits, LFp<NL>* L,
+                                                     const FpParams<NL>* __restrict__ P) {
+  const bool live = threadIdx.x == 0;
+  Fp<NL> acc, c, t;
+  fp_set(acc, P->one);
+#pragma unroll 1
+  for (size_t s = 0; s < steps; ++s) {
+    g_load<NL>(c, tab + (3 * s + 2) * NL, 1, 0);
+    if (live) g_store<NL>(pfx + s * NL, 1, 0, acc);
+    l_store(L, acc);
+    fp_mul(t, L, c, P);                     // <2
+    fp_cond_sub_p<NL>(acc, t, P);           // canonical
+  }
+  Fp<NL> inv;
+  fp_inv_mont<NL>(inv, acc, p_bits, P, L);  // 1 / prod c_s
+#pragma unroll 1
+  for (size_t s = steps; s-- > 0;) {
+    Fp<NL> pf, ci;
+    g_load<NL>(c, tab + (3 * s + 2) * NL, 1, 0);
+    g_load<NL>(pf, pfx + s * NL, 1, 0);
+    l_store(L, inv);
+    fp_mul(ci, L, pf, P);                   // 1/c_s <2
+    fp_mul(t, L, c, P);                     // inverse of the shorter prefix <2
+    fp_cond_sub_p<NL>(inv, t, P);
+    l_store(L + 1, ci);
+    g_load<NL>(c, tab + (3 * s + 0) * NL, 1, 0);
+    fp_mul(t, L + 1, c, P);                 // a_s/c_s <2
+    fp_cond_sub_p<NL>(t, t, P);
+    if (live) g_store<NL>(tab + (3 * s + 0) * NL, 1, 0, t);
+    g_load<NL>(c, tab + (3 * s + 1) * NL, 1, 0);
+    fp_mul(t, L + 1, c, P);                 // b_s/c_s <2
+    fp_cond_sub_p<NL>(t, t, P);
+    if (live) g_store<NL>(tab + (3 * s + 1) * NL, 1, 0, t);
+  }
+}
+
 // ---- per-ciphertext Miller loop over the table -----------------------------------------------
 // f in S.F0 / S.F1 on return; xC, yC (canonical Montgomery) are read from `op.ax/ay`; the lane's table
 // is column `te` of a table with limb stride `ts` (the key's table: ts = 1, te = 0).
+// normalized (wave-uniform): the table holds a_s/c_s and b_s/c_s (fixed_normalize_lane), the line is
+// (a'*xC + b') + i*yC and a step costs one product less.
 template <int NL>
 __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, const PairOperands& op,
-                                                  const u32* __restrict__ tab, size_t ts, size_t te,
+                                                  const u32* __restrict__ tab, size_t ts, size_t te, bool normalized,
                                                   const PairingConsts* __restrict__ C,
                                                   const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
@@ -242,8 +288,12 @@ __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, con
       g_load(u, e + NL * ts, ts, te);      // b_s <1
       fp_add(r, r, u);                     // cre <3
       a_store(S.X, r);                     // X slot = cre
-      g_load(u, e + 2 * NL * ts, ts, te);  // c_s
-      fp_mul(u, LY, u, P);                 // cim <2
+      if (normalized) {
+        l_load(u, LY);                     // cim = yC <1: the line was divided by c_s when the table was built
+      } else {
+        g_load(u, e + 2 * NL * ts, ts, te);  // c_s
+        fp_mul(u, LY, u, P);               // cim <2
+      }
       fp_add(r, r, u);                     // cre + cim <5
       a_store(S.T, r);
       a_store(S.Y, u);                     // Y slot = cim

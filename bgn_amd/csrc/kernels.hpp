@@ -205,6 +205,9 @@ struct KernelTable {
   // builds the line table of e(P, .) : 3*NL u32 per Miller step (px, py canonical Montgomery, stride 1)
   void (*fixedpair_build)(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
                           const uint32_t* py, uint32_t* tab);
+  // divides every line of a key table (limb stride 1) by its c: (a, b, c) -> (a/c, b/c, c); pfx = scratch of
+  // steps*NL u32.  A normalised table is used by passing variant = 2 to `pairing` (mode 1).
+  void (*fixedpair_normalize)(hipStream_t s, const void* params, uint32_t* tab, size_t steps, uint32_t* pfx, int p_bits);
   // one line table per point of a[0..count): value v of step s, limb j, point I at tab[((3*s+v)*NL + j)*ts + I]
   void (*fixedpair_build_batch)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, size_t count,
                                 uint32_t* tab, size_t ts);

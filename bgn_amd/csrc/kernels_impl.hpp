@@ -165,7 +165,7 @@ template <int NL, int VARIANT>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
           size_t count, int mode, size_t d1, size_t d2, int run, u32* __restrict__ ws, size_t sw,
-          const u32* __restrict__ fixed_tab, size_t tab_stride) {
+          const u32* __restrict__ fixed_tab, size_t tab_stride, int tab_normalized) {
   __shared__ LFp<NL> L[4];
   const size_t T = (size_t)gridDim.x * FP_BLOCK;
   const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
@@ -190,7 +190,7 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     if (!live) e = count - 1;             // keep the wave's control flow uniform; results are discarded
     const size_t te = pair_index(op, e, mode, d1, d2);
     if (VARIANT == 1)
-      miller_loop_fixed<NL>(S, L, op, fixed_tab, tab_stride, te, C, P);
+      miller_loop_fixed<NL>(S, L, op, fixed_tab, tab_stride, te, tab_normalized != 0, C, P);
     else if (VARIANT == 2)
       miller_loop_vm<NL>(S, L, op, C, P);
     else if (ws && C->wnaf_len > 0) {
@@ -505,18 +505,19 @@ static void launch_pairing(hipStream_t s, const void* params, const PairingConst
   if (!count) return;
   if (run < 1 || !ws) run = 1;
   const size_t lanes = (count + run - 1) / run;
+  // variant bit 1 (value 2) with a key table: the table is normalised (fixed_normalize_lane)
   if (fixed_tab && (mode == 1 || mode >= 3))
     hipLaunchKernelGGL((k_pairing<NL_, 1>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab,
-                       mode == 1 ? (size_t)1 : tab_stride);
+                       mode == 1 ? (size_t)1 : tab_stride, (mode == 1 && (variant & 2)) ? 1 : 0);
   else if (variant == 1)
     hipLaunchKernelGGL((k_pairing<NL_, 2>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
-                       (size_t)0);
+                       (size_t)0, 0);
   else
     hipLaunchKernelGGL((k_pairing<NL_, 0>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
-                       (size_t)0);
+                       (size_t)0, 0);
 }
 
 template <int NL>
@@ -541,6 +542,19 @@ k_fixedpair_build_batch(const FpParams<NL>* __restrict__ P, const PairingConsts*
   if (!__ballot(live)) return;
   if (!live) e = count - 1;
   fixed_build_lane<NL>(FixedTabRef{tab, ts, e, live}, a.c0, a.c1, a.stride, e, L, C, P);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64)
+k_fixedpair_normalize(const FpParams<NL>* __restrict__ P, u32* tab, size_t steps, u32* pfx, int p_bits) {
+  __shared__ LFp<NL> L[4];
+  fixed_normalize_lane<NL>(tab, steps, pfx, p_bits, L, P);
+}
+
+static void launch_fixedpair_normalize(hipStream_t s, const void* params, uint32_t* tab, size_t steps, uint32_t* pfx,
+                                       int p_bits) {
+  hipLaunchKernelGGL(k_fixedpair_normalize<NL_>, dim3(1), dim3(64), 0, s, (const FpParams<NL_>*)params, tab, steps, pfx,
+                     p_bits);
 }
 
 static void launch_fixedpair_build_batch(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a,
@@ -733,6 +747,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_encode,
       launch_pairing,
       launch_fixedpair_build,
+      launch_fixedpair_normalize,
       launch_fixedpair_build_batch,
       launch_to_mont,
       launch_g1_add,

@@ -69,13 +69,17 @@ struct Emu {
   static void fixed_build(const u32* params, const PairingConsts* C, const u32* p, u32* tab, size_t ts, size_t te) {
     fixed_build_lane<NL>(FixedTabRef{tab, ts, te, true}, p, p + NL, 1, 0, lds(), C, (const FpParams<NL>*)params);
   }
+  static void fixed_normalize(const u32* params, const PairingConsts* C, u32* tab, size_t steps) {
+    std::vector<u32> pfx(steps * NL);
+    fixed_normalize_lane<NL>(tab, steps, pfx.data(), C->pm2_bits + 1, lds(), (const FpParams<NL>*)params);
+  }
   static void pairing_fixed(const u32* params, const PairingConsts* C, const u32* tab, size_t ts, size_t te,
-                            const u32* c, u32* out) {
+                            int normalized, const u32* c, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
     PairOperands op{c, c + NL, 1, 0, nullptr, nullptr, 1, 0};
     Miller<NL> S;
-    miller_loop_fixed<NL>(S, L, op, tab, ts, te, C, P);
+    miller_loop_fixed<NL>(S, L, op, tab, ts, te, normalized != 0, C, P);
     Fp<NL> N, ninv, g0, g1, re, im;
     miller_norm<NL>(N, S, L, P);
     l_store(L + 1, N);
@@ -400,7 +404,8 @@ int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, cons
 int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, windows, pow, tab)) }
 int emu_poly_lin(int nl, const u32* params, const void* C, int level, const u32* c, const uint8_t* cinf, int d, int dp, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, poly_lin(params, (const PairingConsts*)C, level, c, cinf, d, dp, k, klen, out, oinf)) }
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab, size_t ts, size_t te) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab, ts, te)) }
-int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, c, out)) }
+int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, int normalized, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, normalized, c, out)) }
+int emu_fixed_normalize(int nl, const u32* params, const void* C, u32* tab, size_t steps) { DISPATCH(nl, fixed_normalize(params, (const PairingConsts*)C, tab, steps)) }
 int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }
 int emu_fp_inv(int nl, const u32* params, int p_bits, const u32* a, u32* out) { DISPATCH(nl, fp_inv(params, p_bits, a, out)) }
 int emu_gt_tab_build(int nl, const u32* params, int wbits, int windows, const u32* g, u32* tab) { DISPATCH(nl, gt_tab_build(params, wbits, windows, g, tab)) }

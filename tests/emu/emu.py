@@ -152,12 +152,20 @@ class Emu:
         assert self.lib.emu_fixed_build(self.nl, self.params, self.consts, Pm, tab, C.c_size_t(ts), C.c_size_t(te)) == 0
         return tab
 
-    def pairing_fixed(self, tab, c_wire: bytes, ts: int = 1, te: int = 0) -> bytes:
+    def fixed_normalize(self, tab):
+        """Divide every line of a key table (ts = 1) by its c, in place (fixedpair.hpp fixed_normalize_lane)."""
+        d = naf(self.n)
+        steps = (len(d) - 1) + sum(1 for i in range(1, len(d) - 1) if d[i])
+        assert self.lib.emu_fixed_normalize(self.nl, self.params, self.consts, tab, C.c_size_t(steps)) == 0
+        return tab
+
+    def pairing_fixed(self, tab, c_wire: bytes, ts: int = 1, te: int = 0, normalized: bool = False) -> bytes:
         Cm, inf = self.decode(c_wire)
         if inf:
             return (1).to_bytes(self.L, "big") + bytes(self.L)
         out = (C.c_uint32 * (2 * self.nl))()
-        assert self.lib.emu_pairing_fixed(self.nl, self.params, self.consts, tab, C.c_size_t(ts), C.c_size_t(te), Cm, out) == 0
+        assert self.lib.emu_pairing_fixed(self.nl, self.params, self.consts, tab, C.c_size_t(ts), C.c_size_t(te),
+                                          1 if normalized else 0, Cm, out) == 0
         return self.encode(out)
 
     def g1_mul(self, base: bytes, k: int, klen: int = None) -> bytes:

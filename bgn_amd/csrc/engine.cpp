@@ -1133,30 +1133,21 @@ int bgn_neg_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, uin
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   const size_t st = round_up(count, 64);
-  SoA2 A, Z, O;
-  uint32_t* prefix = nullptr;
+  SoA2 A;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
-    if (level == 1) { A = w.g1(st); Z = w.g1(st); O = w.g1(st); prefix = w.fp(st); }
-    else { A = w.gt(st); O = w.gt(st); }
+    A = (level == 1) ? w.g1(st) : w.gt(st);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
     }
   }
   const KernelTable* kt = c->kt;
-  kt->decode(s, c->d_params, a, c->L, count, A);
-  if (level == 1) {
-    // Neg(c) = Sub(encryptZero(), c), bgn.go:436-438: identity minus c
-    HIP_TRY(hipMemsetAsync(Z.c0, 0, (size_t)c->nl * st * 4, s));
-    HIP_TRY(hipMemsetAsync(Z.c1, 0, (size_t)c->nl * st * 4, s));
-    HIP_TRY(hipMemsetAsync(Z.inf, 1, st, s));
-    g1_add_launch(c, s, Z, A, O, prefix, count, true);
-    kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
-  } else {
-    gt_mul_launch(c, s, c->gt_one(), A, O, count, true);   // 1 * conj(a) = a^-1 on GT (Sub of the GT identity, bgn.go:397)
-    kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
-  }
+  // Neg(c) = Sub(encryptZero(), c), bgn.go:436-438.  Level 1: (x, y) -> (x, p - y); level 2: 1 / c = conj(c) on
+  // GT (norm 1), (re, im) -> (re, p - im).  No field product at all: plain residues in, one coordinate negated.
+  kt->decode_plain(s, c->d_params, a, c->L, count, A);
+  kt->g1_neg(s, c->d_params, A.c1, A.stride, A.inf, count);
+  kt->encode(s, A.inf, A.c0, A.c1, A.stride, c->L, count, out);
   HIP_TRY(hipGetLastError());
   return BGN_OK;
 }

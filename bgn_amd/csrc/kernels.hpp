@@ -214,6 +214,8 @@ struct KernelTable {
   // plain canonical SoA -> canonical Montgomery SoA, in place (to chain kernels on the device)
   void (*to_mont)(hipStream_t s, const void* params, uint32_t* c0, uint32_t* c1, size_t stride, size_t count);
   void (*g1_add)(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a);
+  // y <- p - y in place on plain residues (identity flags respected): Neg on level 1
+  void (*g1_neg)(hipStream_t s, const void* params, uint32_t* y, size_t stride, const uint8_t* inf, size_t count);
   void (*g1_mul)(hipStream_t s, const void* params, const PairingConsts* consts, G1MulArgs a);
   void (*g1_fixed_step)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedStepArgs a);
   void (*g1_fixed_chain)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedChainArgs a);

@@ -292,6 +292,22 @@ k_to_mont(const FpParams<NL>* __restrict__ P, u32* c0, u32* c1, size_t stride, s
   g_store<NL>(c1, stride, e, m);
 }
 
+// Neg on level 1 (bgn.go:436-438: Sub(encryptZero(), c)): (x, y) -> (x, p - y) on plain residues; the
+// identity stays the identity, a point with y = 0 (never a ciphertext) is its own negative.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_g1_neg(const FpParams<NL>* __restrict__ P, u32* __restrict__ y, size_t stride, const uint8_t* __restrict__ inf,
+         size_t count) {
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  if (e >= count) return;
+  if (inf && inf[e]) return;
+  Fp<NL> v, r;
+  g_load<NL>(v, y, stride, e);
+  fp_neg<1>(r, v, P);                  // p - y, in [1, p]
+  fp_cond_sub_p<NL>(r, r, P);          // y = 0 -> 0
+  g_store<NL>(y, stride, e, r);
+}
+
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_g1_add(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1AddArgs A) {
@@ -576,6 +592,12 @@ static void launch_to_mont(hipStream_t s, const void* params, uint32_t* c0, uint
                      stride, count);
 }
 
+static void launch_g1_neg(hipStream_t s, const void* params, uint32_t* y, size_t stride, const uint8_t* inf, size_t count) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_g1_neg<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, y, stride,
+                     inf, count);
+}
+
 static void launch_g1_add(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a) {
   if (!a.count) return;
   const size_t lanes = (a.count + a.run - 1) / a.run;
@@ -751,6 +773,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_fixedpair_build_batch,
       launch_to_mont,
       launch_g1_add,
+      launch_g1_neg,
       launch_g1_mul,
       launch_g1_fixed_step,
       launch_g1_fixed_chain,

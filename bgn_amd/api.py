@@ -437,6 +437,12 @@ class PublicKey:
         d1, d2 = ct1.Degree, ct2.Degree
         out = self.engine.poly_mult(1, d1, d2, b"".join(c.C for c in ct1.Coefficients),
                                     b"".join(c.C for c in ct2.Coefficients))
+        if not self.Deterministic:
+            # the reference blinds every Mult and every Add of the loop (bgn.go:302-311, :466-474): each output
+            # coefficient ends up multiplied by e(Q,Q)^(sum of fresh r's), i.e. by one uniformly random power
+            L = self.engine.elem_bytes // 2
+            one = ((1).to_bytes(L, "big") + bytes(L)) * (d1 + d2)
+            out = self.engine.add(2, out.tobytes(), one, self._r(d1 + d2))
         coeffs = [Ciphertext(bytes(row), True) for row in out]
         return PolyCiphertext(coeffs, d1 + d2, ct1.ScaleFactor + ct2.ScaleFactor, True)
 

@@ -546,10 +546,21 @@ class PublicKey {
     return out;
   }
   // MultPoly, poly.go:123-156: one engine call for the d1*d2 pairings and the accumulation.
-  PolyCiphertext MultPoly(const PolyCiphertext& a, const PolyCiphertext& b) const {
-    Bytes A = join(a.Coefficients), B = join(b.Coefficients), out((size_t)(a.Degree + b.Degree) * E_);
+  // r (one value per output coefficient, a.Degree + b.Degree of them) blinds the result for keys with
+  // Deterministic == false: the reference's per-step blinding (bgn.go:302-311, :466-474) multiplies every output
+  // coefficient by e(Q,Q) to a sum of fresh random exponents, i.e. by one uniformly random power.
+  PolyCiphertext MultPoly(const PolyCiphertext& a, const PolyCiphertext& b, const std::vector<Scalar>* r = nullptr) const {
+    const size_t deg = (size_t)(a.Degree + b.Degree);
+    Bytes A = join(a.Coefficients), B = join(b.Coefficients), out(deg * E_);
     check(bgn_poly_mult_batch(h_, 1, (size_t)a.Degree, (size_t)b.Degree, A.data(), B.data(), out.data()),
           "bgn_poly_mult_batch");
+    if (r) {
+      size_t rl = 0;
+      Bytes rb = pack(*r, rl), one(deg * E_, 0), blinded(deg * E_);
+      for (size_t i = 0; i < deg; ++i) one[i * E_ + E_ / 2 - 1] = 1;           // the GT identity: re = 1, im = 0
+      check(bgn_add_batch(h_, deg, 2, out.data(), one.data(), rb.data(), rl, blinded.data()), "bgn_add_batch");
+      out = blinded;
+    }
     return PolyCiphertext{split(out, true), a.Degree + b.Degree, a.ScaleFactor + b.ScaleFactor, true};
   }
   // NegPoly, poly.go:45-55

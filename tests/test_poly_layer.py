@@ -156,3 +156,25 @@ def test_gpu_poly_layer_mirror_end_to_end():
     assert not st.any() and int(m[0]) == 9
     m, st = pk.engine.decrypt(2, pk.EvalPoly(pk.MultPoly(a, b)).C)
     assert not st.any() and int(m[0]) == -36
+
+
+@pytest.mark.gpu
+def test_gpu_nondeterministic_key_blinds_poly_products():
+    """A key with Deterministic == false (the reference's production mode, bgn.go:37): MultPoly's coefficients are
+    blinded with fresh randomness — different bytes on every call, the same plaintext product."""
+    import bgn_amd
+    fx = load_fixture("k256")
+    det, sk = engine_key(fx)
+    pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                           fx["msg_space"], False, fx["poly_base"])
+    pk.SetupDecryption(sk)
+    ev = lambda pct: R.poly_eval_plain(sk.DecryptPoly(pct, pk), pk.PolyBase)
+    a = pk.EncryptPoly(R.balancedEncode(7, 3))
+    b = pk.EncryptPoly(R.balancedEncode(-5, 3))
+    p1, p2 = pk.MultPoly(a, b), pk.MultPoly(a, b)
+    assert ev(p1) == -35 and ev(p2) == -35
+    assert [c.C for c in p1.Coefficients] != [c.C for c in p2.Coefficients]
+    # the deterministic product of the same operands is the unblinded value: equal plaintext, different bytes
+    p0 = det.MultPoly(a, b)
+    assert ev(p0) == -35 and [c.C for c in p0.Coefficients] != [c.C for c in p1.Coefficients]
+    assert ev(pk.AddPoly(p1, a)) == -28 and ev(pk.SubPoly(a, b)) == 12

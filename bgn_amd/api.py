@@ -331,6 +331,17 @@ class PublicKey:
             return None
         return [secrets.randbelow(self.N) for _ in range(count)]     # newCryptoRandom, bgn.go:567-574
 
+    def _blind(self, rows: np.ndarray, l2: bool) -> np.ndarray:
+        """Results of a fused loop on a key with Deterministic == false: the reference blinds every Mult / MultConst /
+        Add of the loop with fresh randomness (bgn.go:260-269, :302-311, :466-474, :488-495), so each result ends up
+        multiplied by Q (resp. e(Q,Q)) to a sum of fresh exponents — one uniformly random power, applied here by
+        adding the identity with blinding."""
+        if self.Deterministic or len(rows) == 0:
+            return rows
+        E = self.engine.elem_bytes
+        ident = ((1).to_bytes(E // 2, "big") + bytes(E // 2)) if l2 else bytes(E)
+        return self.engine.add(2 if l2 else 1, rows.tobytes(), ident * len(rows), self._r(len(rows)))
+
     def _lvl(self, ct: Ciphertext) -> int:
         return 2 if ct.L2 else 1
 
@@ -437,12 +448,7 @@ class PublicKey:
         d1, d2 = ct1.Degree, ct2.Degree
         out = self.engine.poly_mult(1, d1, d2, b"".join(c.C for c in ct1.Coefficients),
                                     b"".join(c.C for c in ct2.Coefficients))
-        if not self.Deterministic:
-            # the reference blinds every Mult and every Add of the loop (bgn.go:302-311, :466-474): each output
-            # coefficient ends up multiplied by e(Q,Q)^(sum of fresh r's), i.e. by one uniformly random power
-            L = self.engine.elem_bytes // 2
-            one = ((1).to_bytes(L, "big") + bytes(L)) * (d1 + d2)
-            out = self.engine.add(2, out.tobytes(), one, self._r(d1 + d2))
+        out = self._blind(out, True)
         coeffs = [Ciphertext(bytes(row), True) for row in out]
         return PolyCiphertext(coeffs, d1 + d2, ct1.ScaleFactor + ct2.ScaleFactor, True)
 
@@ -460,10 +466,8 @@ class PublicKey:
         else:
             negative = constant < 0                                          # poly.go:73-76
             digits, scale = self.NewUnbalancedPlaintext(-constant if negative else constant)
-        if not self.Deterministic:
-            raise NotImplementedError("MultConstPoly on a non-deterministic key blinds every step with fresh "
-                                      "randomness (bgn.go:260-269): run the deterministic form and blind the result")
         out = self.engine.poly_multconst(1, ct.Degree, 2 if ct.L2 else 1, b"".join(c.C for c in ct.Coefficients), digits)
+        out = self._blind(out, ct.L2)                                        # bgn.go:260-269 on every step of the loop
         prod = PolyCiphertext([Ciphertext(bytes(r), ct.L2) for r in out], ct.Degree + len(digits),
                               ct.ScaleFactor + scale, ct.L2)
         return self.NegPoly(prod) if negative else prod                      # poly.go:115-119
@@ -503,14 +507,8 @@ class PublicKey:
 
     def EvalPoly(self, ct: PolyCiphertext) -> Ciphertext:
         """poly.go:58-68 (Horner over MultConst/Add) as one multi-scalar sum on the device."""
-        if not self.Deterministic:
-            acc = self.EncryptDeterministic(0)
-            for c in reversed(ct.Coefficients):
-                acc = self.MultConst(acc, self.PolyBase)
-                acc = self.Add(acc, c)
-            return acc
         out = self.engine.poly_eval(1, ct.Degree, 2 if ct.L2 else 1, b"".join(c.C for c in ct.Coefficients), self.PolyBase)
-        return Ciphertext(bytes(out[0]), ct.L2)
+        return Ciphertext(bytes(self._blind(out, ct.L2)[0]), ct.L2)
 
     # -- proofs: gadgets.go --
     def _hash(self, ct_bytes: bytes, nonce_bytes: bytes) -> int:

@@ -178,3 +178,8 @@ def test_gpu_nondeterministic_key_blinds_poly_products():
     p0 = det.MultPoly(a, b)
     assert ev(p0) == -35 and [c.C for c in p0.Coefficients] != [c.C for c in p1.Coefficients]
     assert ev(pk.AddPoly(p1, a)) == -28 and ev(pk.SubPoly(a, b)) == 12
+    # MultConstPoly and EvalPoly are blinded the same way
+    c1, c2 = pk.MultConstPoly(a, 4), pk.MultConstPoly(a, 4)
+    assert ev(c1) == 28 and [c.C for c in c1.Coefficients] != [c.C for c in c2.Coefficients]
+    e1, e2 = pk.EvalPoly(a), pk.EvalPoly(a)
+    assert e1.C != e2.C and sk.Decrypt(e1, pk) == 7 and sk.Decrypt(e2, pk) == 7

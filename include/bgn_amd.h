@@ -127,7 +127,10 @@ int bgn_decrypt_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* ct, 
 
 /* MultPoly over `npoly` independent pairs of L1 coefficient vectors:
  * a: npoly*d1 elements, b: npoly*d2 elements, out: npoly*(d1+d2) GT elements,
- * out[q][i+k] = prod e(a[q][i], b[q][k]); slot d1+d2-1 is the GT identity.
+ * out[q][i+k] = prod e(a[q][i], b[q][k]); slot d1+d2-1 is the GT identity.  Deterministic form: a key with
+ * Deterministic == false blinds every Mult and Add of the loop, which multiplies each output coefficient by
+ * e(Q,Q) to a sum of fresh exponents — blind the result with bgn_add_batch(level 2, out, identities, r) instead
+ * (the host mirrors do).
  * Replaces MultPoly (poly.go:123-156). */
 int bgn_poly_mult_batch(bgn_ctx* ctx, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
                         uint8_t* out);

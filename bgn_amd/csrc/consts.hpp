@@ -26,9 +26,10 @@ struct PairingConsts {
   int pad;
   signed char naf[MAX_NAF];    // little-endian signed digits of n
   u32 pm2[MAX_EXP_LIMBS];      // p-2 as 28-bit limbs (little-endian)
-  // width-3 NAF of n (digits 0, +-1, +-3) for the windowed Miller loop of pairing.hpp; 0 digits = not used
+  // width-w NAF of n (w = 3: digits 0, +-1, +-3; w = 4: up to +-7) for the windowed Miller loop of
+  // pairing.hpp; wnaf_len = 0: not used
   int wnaf_len;
-  int pad2;
+  int wnaf_w;
   signed char wnaf[MAX_NAF];
 };
 

@@ -317,11 +317,13 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     pc.l = l;
     pc.l_bits = BigU(l).bits();
     {
-      // width-3 NAF for the windowed Miller loop (BGN_MILLER_WINDOW=0 keeps the plain NAF)
+      // width-4 NAF for the windowed Miller loop (BGN_MILLER_WINDOW=3: width 3; =0: the plain NAF)
       const char* ev = getenv("BGN_MILLER_WINDOW");
-      std::vector<signed char> wn = n.wnaf(3);
+      const int w = (ev && ev[0] == '3') ? 3 : 4;
+      std::vector<signed char> wn = n.wnaf(w);
       if (!(ev && ev[0] == '0') && (int)wn.size() <= MAX_NAF && wn.size() >= 4) {
         pc.wnaf_len = (int)wn.size();
+        pc.wnaf_w = w;
         memcpy(pc.wnaf, wn.data(), wn.size());
       }
     }
@@ -570,7 +572,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
-  probe.take((size_t)(mode == 1 ? 3 : 7) * c->nl * so * 4);
+  probe.take((size_t)(mode == 1 ? 3 : 22) * c->nl * so * 4);
   if (r_be) {
     probe.soa(c->nl, so, false);
     probe.soa(c->nl, so, false);
@@ -581,7 +583,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   SoA2 A = cv.soa(c->nl, sa, true);
   SoA2 B = nb ? cv.soa(c->nl, sb, true) : c->key_P();
   SoA2 O = cv.soa(c->nl, so, false);
-  uint32_t* ws = (uint32_t*)cv.take((size_t)(mode == 1 ? 3 : 7) * c->nl * so * 4);   // 7: room for the windowed loop's (3A, f_3)
+  uint32_t* ws = (uint32_t*)cv.take((size_t)(mode == 1 ? 3 : 22) * c->nl * so * 4);   // 22: room for the windowed loop's (dA, f_d)
   SoA2 T1{}, T2{};
   if (r_be) {
     T1 = cv.soa(c->nl, so, false);
@@ -1510,7 +1512,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
-    pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : 7) * c->nl * sp * 4);
+    pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : 22) * c->nl * sp * 4);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;

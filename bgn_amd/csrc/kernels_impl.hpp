@@ -158,7 +158,7 @@ __device__ __forceinline__ size_t pair_index(PairOperands& op, size_t e, int mod
 // Each lane owns `run` pairings e = j*T + t (T = lanes in the grid): pass 1 runs the Miller loops and
 // parks f and the prefix product of the norms in the workspace; one Fermat inversion per lane; pass 2
 // peels 1/N(f_j) off and finishes the exponentiation.  ws: 3 F_p per element (F0, F1, prefix), plus 4 more
-// (3A, f_3) for the windowed Miller loop of VARIANT 0: 7 * NL * sw u32 in all.
+// WIN_SLOTS = 19 for the windowed Miller loop of VARIANT 0: 22 * NL * sw u32 in all.
 // VARIANT 0: inlined step programs (pairing.hpp); 1: key-constant first argument (fixedpair.hpp);
 // 2: compact-code interpreter (vm.hpp)
 template <int NL, int VARIANT>
@@ -194,9 +194,9 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     else if (VARIANT == 2)
       miller_loop_vm<NL>(S, L, op, C, P);
     else if (ws && C->wnaf_len > 0) {
-      // width-3 windowed loop; its per-pairing table (3A, f_3) lives behind the three run arrays of ws
-      Win3 W{ws + (size_t)3 * NL * sw, ws + (size_t)4 * NL * sw, ws + (size_t)5 * NL * sw, ws + (size_t)6 * NL * sw, sw, e};
-      miller_loop_w3<NL>(S, L, op, W, C, P);
+      // windowed loop; its per-pairing table (dA, f_d) lives behind the three run arrays of ws
+      WinTab W{ws + (size_t)3 * NL * sw, sw, e};
+      miller_loop_w<NL>(S, L, op, W, C, P);
     } else
       miller_loop<NL>(S, L, op, C, P);
     if (run == 1) {

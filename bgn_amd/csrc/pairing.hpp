@@ -356,32 +356,37 @@ __device__ __forceinline__ void miller_loop(Miller<NL>& S, LFp<NL>* L, const Pai
   }
 }
 
-// ---- windowed Miller loop (width-3 NAF of n: digits 0, +-1, +-3) ------------------------------
-// A digit +-3 adds +-3A in one step: f <- f * f_{3,A}^(+-1) * l_{V,+-3A},  V <- V +- 3A, with
-// f_{-3,A} = conj(f_{3,A}) up to F_p factors (the norm) and vertical lines, both killed by the final
-// exponent like every other scaling in this file.  3A (affine) and f_3 = f_{3,A}(phi(B)) are computed
-// per pairing by one doubling step and one addition step from (A, 1) and parked in HBM: four F_p per
-// pairing (`Win3`).  n has 341 non-zero NAF digits at 1024 bits and 256 non-zero width-3 digits, half
-// of them +-3, each costing one extra F_p^2 product (3) over the 17 of an addition step: about 4 %
-// fewer field products per pairing, the ~95 of the precomputation included.
-struct Win3 {
-  u32* x3;  // 3A, canonical Montgomery
-  u32* y3;
-  u32* f0;  // f_{3,A}(phi(B)), canonical Montgomery
-  u32* f1;
-  size_t s;  // limb stride
-  size_t e;  // element
+// ---- windowed Miller loop (width-w NAF of n, w = 3 or 4: digits 0, +-1, +-3 [, +-5, +-7]) -------
+// A digit +-d adds +-dA in one step: f <- f * f_{d,A}^(+-1) * l_{V,+-dA},  V <- V +- dA, with
+// f_{-d,A} = conj(f_{d,A}) up to F_p factors (the norm) and vertical lines, both killed by the final
+// exponent like every other scaling in this file.  dA (affine) and f_d = f_{d,A}(phi(B)) are computed per
+// pairing and parked in HBM (`WinTab`):
+//     2A, f_2 by one doubling step from (A, 1), 2A made affine;
+//     3A = 2A + A, 5A = 3A + 2A, 7A = 5A + 2A by addition steps, f_3 = f_2*l, f_5 = f_3*l*f_2, f_7 = f_5*l*f_2;
+//     one shared inversion makes 3A, 5A, 7A affine.
+// n has 341 non-zero NAF digits at 1024 bits, 256 width-3 digits and 205 width-4 digits; a digit other than
+// +-1 costs one extra F_p^2 product (3) over the 17 of an addition step.  Width 3: ~100 products of set-up,
+// 3.9 % fewer products per pairing than the NAF; width 4: ~210 of set-up, 6.7 % fewer.
+struct WinTab {
+  u32* base;   // slot k of pairing e: limb j at base[(k*NL + j)*s + e]
+  size_t s;    // limb stride
+  size_t e;    // element
 };
+constexpr int WIN_SLOTS = 19;   // 2A (2), f_2 (2), then x,y,f0,f1 of 3A, 5A, 7A (12), Z of 3A, 5A, 7A (3)
+
+template <int NL>
+__device__ __forceinline__ u32* win_slot(const WinTab& W, int k) { return W.base + (size_t)k * NL * W.s; }
+__device__ __forceinline__ int win_point_slot(int d) { return 4 + 4 * ((d - 3) / 2); }   // x; y = +1, f0 = +2, f1 = +3
 
 // f <- f * (c0 + i*c1) with c canonical (<1) in HBM; conj negates c1.
 template <int NL>
-__device__ __forceinline__ void miller_mul_f3(Miller<NL>& S, LFp<NL>* L, const Win3& W, bool conj,
-                                              const FpParams<NL>* __restrict__ P) {
+__device__ __forceinline__ void miller_mul_f(Miller<NL>& S, LFp<NL>* L, const u32* c0p, const u32* c1p, size_t cs,
+                                             size_t ce, bool conj, const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
-  g_load(r, W.f0, W.s, W.e);               // c0 <1
-  g_load(w, W.f1, W.s, W.e);               // c1 <1
+  g_load(r, c0p, cs, ce);                  // c0 <1
+  g_load(w, c1p, cs, ce);                  // c1 <1
   if (conj) fp_neg<1>(w, w, P);            // <=1
   fp_add(u, r, w);                         // c0+c1 <2
   l_store(L3, u);
@@ -404,12 +409,47 @@ __device__ __forceinline__ void miller_mul_f3(Miller<NL>& S, LFp<NL>* L, const W
   }
 }
 
-// Miller loop over the width-3 digits C->wnaf; leaves f in S.F0 / S.F1.
+// f (canonical) -> two slots
 template <int NL>
-__device__ __forceinline__ void miller_loop_w3(Miller<NL>& S, LFp<NL>* L, const PairOperands& op, const Win3& W,
-                                               const PairingConsts* __restrict__ C,
-                                               const FpParams<NL>* __restrict__ P) {
-  // precomputation: (V, f) = (3A, f_3) by one doubling and one addition step
+__device__ __forceinline__ void win_store_f(Miller<NL>& S, const WinTab& W, int k, LFp<NL>* S0,
+                                            const FpParams<NL>* __restrict__ P) {
+  Fp<NL> r, u;
+  a_load(r, S.F0);
+  fp_canon<NL>(u, r, P, S0);
+  g_store(win_slot<NL>(W, k), W.s, W.e, u);
+  a_load(r, S.F1);
+  fp_canon<NL>(u, r, P, S0);
+  g_store(win_slot<NL>(W, k + 1), W.s, W.e, u);
+}
+
+// (X, Y) * (zi^2, zi^3) -> canonical affine coordinates in slots k, k+1; zi <2 in VGPRs, X <8, Y <4 in slots kx, ky
+template <int NL>
+__device__ __forceinline__ void win_make_affine(const WinTab& W, int k, const u32* xs, const u32* ys, const Fp<NL>& zi,
+                                                LFp<NL>* L, const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* L1 = L + 1;
+  Fp<NL> r, u;
+  l_store(L1, zi);
+  fp_sqr(u, L1, zi, P);                    // zi^2 <2
+  g_load(r, xs, W.s, W.e);                 // X <8
+  fp_mulv(r, r, u, P, S0);                 // x <2   (16)
+  fp_cond_sub_p<NL>(r, r, P);              // <1
+  fp_mul(u, L1, u, P);                     // zi^3 <2
+  g_store(win_slot<NL>(W, k), W.s, W.e, r);
+  g_load(r, ys, W.s, W.e);                 // Y <4
+  fp_mulv(r, r, u, P, S0);                 // y <2   (8)
+  fp_cond_sub_p<NL>(r, r, P);
+  g_store(win_slot<NL>(W, k + 1), W.s, W.e, r);
+}
+
+// Miller loop over the width-w digits C->wnaf; leaves f in S.F0 / S.F1.
+template <int NL>
+__device__ __forceinline__ void miller_loop_w(Miller<NL>& S, LFp<NL>* L, const PairOperands& op, const WinTab& W,
+                                              const PairingConsts* __restrict__ C,
+                                              const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  const int maxd = (C->wnaf_w >= 4) ? 7 : 3;
+  // ---- set-up: (2A, f_2), then 3A [, 5A, 7A] with their f_d ----
   {
     Fp<NL> r;
     g_load(r, op.ax, op.sa, op.ea);
@@ -423,67 +463,122 @@ __device__ __forceinline__ void miller_loop_w3(Miller<NL>& S, LFp<NL>* L, const 
     fp_zero(r);
     a_store(S.F1, r);
   }
-  miller_double<NL>(S, L, op, P);
-  miller_add<NL>(S, L, op, 1, P);
-  {
-    LFp<NL>* S0 = L;
-    LFp<NL>* L1 = L + 1;
-    Fp<NL> r, u, zi;
-    a_load(r, S.Z);                          // <2
-    fp_inv_mont<NL>(zi, r, C->pm2_bits + 1, P, S0);   // 1/Z <1 (0 for a degenerate operand: results are overridden)
-    l_store(L1, zi);
-    fp_sqr(u, L1, zi, P);                    // zi^2 <2
-    a_load(r, S.X);                          // <8
-    fp_mulv(r, r, u, P, S0);                 // x3 <2   (16)
-    fp_cond_sub_p<NL>(r, r, P);              // <1
-    g_store(W.x3, W.s, W.e, r);
-    fp_mul(u, L1, u, P);                     // zi^3 <2
-    a_load(r, S.Y);                          // <4
-    fp_mulv(r, r, u, P, S0);                 // y3 <2   (8)
-    fp_cond_sub_p<NL>(r, r, P);
-    g_store(W.y3, W.s, W.e, r);
-    a_load(r, S.F0);
-    fp_canon<NL>(u, r, P, S0);
-    g_store(W.f0, W.s, W.e, u);
-    a_load(r, S.F1);
-    fp_canon<NL>(u, r, P, S0);
-    g_store(W.f1, W.s, W.e, u);
+  miller_double<NL>(S, L, op, P);                          // V = 2A (Z <4), f = f_2
+  PairOperands op2 = op;                                   // addend 2A
+  if (maxd > 3) {
+    win_store_f<NL>(S, W, 2, S0, P);
+    Fp<NL> r, zi;
+    a_load(r, S.X);
+    g_store(win_slot<NL>(W, 4), W.s, W.e, r);              // park X, Y of 2A (slots of 3A, overwritten below)
+    a_load(r, S.Y);
+    g_store(win_slot<NL>(W, 5), W.s, W.e, r);
+    a_load(r, S.Z);
+    fp_inv_mont<NL>(zi, r, C->pm2_bits + 1, P, S0);        // 1/Z <1 (0 for a degenerate operand: results are overridden)
+    // X <18, Y <18 here (not <8 / <4): the products below stay within the bound (18 * 2)
+    win_make_affine<NL>(W, 0, win_slot<NL>(W, 4), win_slot<NL>(W, 5), zi, L, P);
+    g_load(r, win_slot<NL>(W, 0), W.s, W.e);
+    a_store(S.X, r);
+    g_load(r, win_slot<NL>(W, 1), W.s, W.e);
+    a_store(S.Y, r);
+    fp_set(r, P->one);
+    a_store(S.Z, r);
+    op2.ax = win_slot<NL>(W, 0);
+    op2.ay = win_slot<NL>(W, 1);
+    op2.sa = W.s;
+    op2.ea = W.e;
   }
-  PairOperands op3 = op;
-  op3.ax = W.x3;
-  op3.ay = W.y3;
-  op3.sa = W.s;
-  op3.ea = W.e;
-  const int top = C->wnaf[C->wnaf_len - 1];      // 1 or 3, wave-uniform
-  if (top == 3) {
-    // start from (3A, f_3): the state already holds f_3; V restarts from the affine copy
+#pragma unroll 1
+  for (int d = 3; d <= maxd; d += 2) {
+    miller_add<NL>(S, L, d == 3 ? op : op2, 1, P);         // 3A = 2A + A, 5A = 3A + 2A, 7A = 5A + 2A
+    if (d > 3) miller_mul_f<NL>(S, L, win_slot<NL>(W, 2), win_slot<NL>(W, 3), W.s, W.e, false, P);   // * f_2
+    const int k = win_point_slot(d);
+    win_store_f<NL>(S, W, k + 2, S0, P);
     Fp<NL> r;
-    g_load(r, W.x3, W.s, W.e);
+    a_load(r, S.X);                                        // <8
+    g_store(win_slot<NL>(W, k), W.s, W.e, r);
+    a_load(r, S.Y);                                        // <4
+    g_store(win_slot<NL>(W, k + 1), W.s, W.e, r);
+    a_load(r, S.Z);                                        // <2
+    g_store(win_slot<NL>(W, 16 + (d - 3) / 2), W.s, W.e, r);
+  }
+  {
+    // one inversion for Z3 [, Z5, Z7] (Montgomery's trick), then the affine coordinates
+    LFp<NL>* L1 = L + 1;
+    LFp<NL>* L2 = L + 2;
+    Fp<NL> r, u, inv;
+    if (maxd > 3) {
+      g_load(r, win_slot<NL>(W, 16), W.s, W.e);            // Z3 <2
+      l_store(L1, r);
+      g_load(u, win_slot<NL>(W, 17), W.s, W.e);            // Z5
+      fp_mul(r, L1, u, P);                                 // Z3*Z5 <2
+      l_store(L2, r);                                      // L2 = Z3*Z5
+      g_load(u, win_slot<NL>(W, 18), W.s, W.e);            // Z7
+      fp_mul(r, L2, u, P);                                 // Z3*Z5*Z7 <2
+      fp_inv_mont<NL>(inv, r, C->pm2_bits + 1, P, S0);     // <1
+      l_load(r, L2);
+      l_store(L1, inv);
+      fp_mul(r, L1, r, P);                                 // 1/Z7 <2
+      win_make_affine<NL>(W, win_point_slot(7), win_slot<NL>(W, win_point_slot(7)), win_slot<NL>(W, win_point_slot(7) + 1),
+                          r, L, P);
+      g_load(u, win_slot<NL>(W, 18), W.s, W.e);            // Z7
+      l_store(L1, inv);
+      fp_mul(inv, L1, u, P);                               // 1/(Z3*Z5) <2
+      g_load(u, win_slot<NL>(W, 16), W.s, W.e);            // Z3
+      l_store(L1, inv);
+      fp_mul(r, L1, u, P);                                 // 1/Z5 <2
+      win_make_affine<NL>(W, win_point_slot(5), win_slot<NL>(W, win_point_slot(5)), win_slot<NL>(W, win_point_slot(5) + 1),
+                          r, L, P);
+      g_load(u, win_slot<NL>(W, 17), W.s, W.e);            // Z5
+      l_store(L1, inv);
+      fp_mul(r, L1, u, P);                                 // 1/Z3 <2
+    } else {
+      g_load(u, win_slot<NL>(W, 16), W.s, W.e);            // Z3 <2
+      fp_inv_mont<NL>(r, u, C->pm2_bits + 1, P, S0);       // 1/Z3 <1
+    }
+    win_make_affine<NL>(W, win_point_slot(3), win_slot<NL>(W, win_point_slot(3)), win_slot<NL>(W, win_point_slot(3) + 1),
+                        r, L, P);
+  }
+  // ---- start from the top digit ----
+  const int top = C->wnaf[C->wnaf_len - 1];                // 1, 3, 5 or 7, wave-uniform
+  {
+    Fp<NL> r;
+    const u32* sx = top == 1 ? op.ax : win_slot<NL>(W, win_point_slot(top));
+    const u32* sy = top == 1 ? op.ay : win_slot<NL>(W, win_point_slot(top) + 1);
+    const size_t ss = top == 1 ? op.sa : W.s, se = top == 1 ? op.ea : W.e;
+    g_load(r, sx, ss, se);
     a_store(S.X, r);
-    g_load(r, W.y3, W.s, W.e);
+    g_load(r, sy, ss, se);
     a_store(S.Y, r);
     fp_set(r, P->one);
     a_store(S.Z, r);
-  } else {
-    Fp<NL> r;
-    g_load(r, op.ax, op.sa, op.ea);
-    a_store(S.X, r);
-    g_load(r, op.ay, op.sa, op.ea);
-    a_store(S.Y, r);
-    fp_set(r, P->one);
-    a_store(S.Z, r);
-    a_store(S.F0, r);
-    fp_zero(r);
-    a_store(S.F1, r);
+    if (top == 1) {
+      a_store(S.F0, r);
+      fp_zero(r);
+      a_store(S.F1, r);
+    } else {
+      g_load(r, win_slot<NL>(W, win_point_slot(top) + 2), W.s, W.e);
+      a_store(S.F0, r);
+      g_load(r, win_slot<NL>(W, win_point_slot(top) + 3), W.s, W.e);
+      a_store(S.F1, r);
+    }
   }
 #pragma unroll 1
   for (int i = C->wnaf_len - 2; i >= 0; --i) {
     miller_double<NL>(S, L, op, P);
     const int d = C->wnaf[i];
     if (d == 0) continue;
-    const bool three = (d == 3 || d == -3);
-    if (i != 0) miller_add<NL>(S, L, three ? op3 : op, d, P);   // the last addition (V = -+dA, vertical) is skipped
-    if (three) miller_mul_f3<NL>(S, L, W, d < 0, P);
+    const int ad = d < 0 ? -d : d;
+    PairOperands opd = op;
+    if (ad > 1) {
+      opd.ax = win_slot<NL>(W, win_point_slot(ad));
+      opd.ay = win_slot<NL>(W, win_point_slot(ad) + 1);
+      opd.sa = W.s;
+      opd.ea = W.e;
+    }
+    if (i != 0) miller_add<NL>(S, L, opd, d, P);           // the last addition (V = -+dA, vertical) is skipped
+    if (ad > 1)
+      miller_mul_f<NL>(S, L, win_slot<NL>(W, win_point_slot(ad) + 2), win_slot<NL>(W, win_point_slot(ad) + 3), W.s, W.e,
+                       d < 0, P);
   }
 }
 

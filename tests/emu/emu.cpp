@@ -94,10 +94,10 @@ struct Emu {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
     PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};
-    u32 win[4 * NL];
-    Win3 W{win, win + NL, win + 2 * NL, win + 3 * NL, 1, 0};
+    u32 win[WIN_SLOTS * NL];
+    WinTab W{win, 1, 0};
     Miller<NL> S;
-    miller_loop_w3<NL>(S, L, op, W, C, P);
+    miller_loop_w<NL>(S, L, op, W, C, P);
     Fp<NL> N, ninv, g0, g1, re, im;
     miller_norm<NL>(N, S, L, P);
     l_store(L + 1, N);

@@ -85,8 +85,14 @@ class Emu:
         buf = struct.pack("<iiQii", len(d), pm2.bit_length(), l, l.bit_length(), 0)
         buf += bytes((x & 0xFF) for x in d) + bytes(MAX_NAF - len(d))
         buf += struct.pack("<%dI" % MAX_EXP_LIMBS, *limbs(pm2, MAX_EXP_LIMBS))
-        wd = wnaf(n, 3)
-        buf += struct.pack("<ii", len(wd), 0) + bytes((x & 0xFF) for x in wd) + bytes(MAX_NAF - len(wd))
+        self._base = buf
+        self.consts = None
+        self.set_window(4)
+
+    def set_window(self, w: int):
+        """Install the width-w NAF of n for the windowed Miller loop (pairing.hpp miller_loop_w)."""
+        wd = wnaf(self.n, w)
+        buf = self._base + struct.pack("<ii", len(wd), w) + bytes((x & 0xFF) for x in wd) + bytes(MAX_NAF - len(wd))
         assert len(buf) == self.lib.emu_consts_size() or True
         self.lib.emu_consts_size.restype = C.c_size_t
         assert len(buf) == self.lib.emu_consts_size(), (len(buf), self.lib.emu_consts_size())
@@ -125,7 +131,7 @@ class Emu:
         return self.encode(out)
 
     def pairing_w3(self, a: bytes, b: bytes) -> bytes:
-        """The width-3 windowed Miller loop (pairing.hpp miller_loop_w3) + final exponentiation."""
+        """The windowed Miller loop (pairing.hpp miller_loop_w, width set by set_window) + final exponentiation."""
         A, _ = self.decode(a)
         B, _ = self.decode(b)
         out = (C.c_uint32 * (2 * self.nl))()

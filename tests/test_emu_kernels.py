@@ -31,16 +31,19 @@ def test_emu_pairing(ctx):
         assert E.pairing(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
 
 
-def test_emu_windowed_miller_loop(ctx):
-    """The width-3 windowed Miller loop (digits 0, +-1, +-3 of n; 3A and f_3 precomputed per pairing) gives the
-    Mult golden vectors, for group orders whose top window digit is 1 and 3 alike."""
+@pytest.mark.parametrize("w", [3, 4])
+def test_emu_windowed_miller_loop(ctx, w):
+    """The windowed Miller loop (digits 0, +-1, +-3 [, +-5, +-7] of n; dA and f_d precomputed per pairing) gives
+    the Mult golden vectors, whatever the top window digit of the group order."""
     fx, E = ctx
     cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
-    digits = emu.wnaf(int(fx["n"], 16), 3)
-    assert set(digits) <= {0, 1, -1, 3, -3} and digits[-1] in (1, 3)
+    digits = emu.wnaf(int(fx["n"], 16), w)
+    assert set(abs(d) for d in digits) <= ({0, 1, 3} if w == 3 else {0, 1, 3, 5, 7}) and digits[-1] > 0
+    E.set_window(w)
     rows = [v for v in fx["mult"] if any(cts[v["a"]]) and any(cts[v["b"]])]
     for v in rows[:4]:
         assert E.pairing_w3(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+    E.set_window(4)
 
 
 def test_emu_scalar_mult_exceptional_cases(ctx):

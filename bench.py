@@ -319,7 +319,7 @@ def main():
         alg_bytes = 3 * EB                               # two G1 operands in, one GT element out
         achieved = alg_bytes * count / (k_ms * 1e-3) / 1e9
         mads = bgn_amd.synthetic.algorithmic_mads_per_pairing(
-            fx, run=max(1, min(16, count // 65536)), window={"0": 2, "3": 3}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 4))
+            fx, run=max(1, min(16, count // 65536)), window={"0": 2, "3": 3, "4": 4}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 5))
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")
         if os.path.exists(pmc) and args.batch_log2 == 20 and args.key == "k1024":

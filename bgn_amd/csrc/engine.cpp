@@ -81,6 +81,7 @@ struct bgn_ctx {
   uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
   size_t miller_steps = 0;
   PairingConsts pc_host;               // host image of *d_consts
+  int pair_ws_slots = 3;               // F_p values of pairing workspace per pairing: 3 + the windowed loop's table
   // decryption lift over the secret order (set_secret): line table of f_{q2, q1*P} and the constants whose
   // NAF is that of q2 = n / q1 — half the Miller steps of e(P, .)
   PairingConsts* d_consts_sk = nullptr;
@@ -317,14 +318,16 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     pc.l = l;
     pc.l_bits = BigU(l).bits();
     {
-      // width-4 NAF for the windowed Miller loop (BGN_MILLER_WINDOW=3: width 3; =0: the plain NAF)
+      // width-w NAF for the windowed Miller loop: BGN_MILLER_WINDOW = 3, 4, 5 (default 5), 0 = the plain NAF
       const char* ev = getenv("BGN_MILLER_WINDOW");
-      const int w = (ev && ev[0] == '3') ? 3 : 4;
+      int w = 5;
+      if (ev && ev[0] >= '3' && ev[0] <= '5') w = ev[0] - '0';
       std::vector<signed char> wn = n.wnaf(w);
       if (!(ev && ev[0] == '0') && (int)wn.size() <= MAX_NAF && wn.size() >= 4) {
         pc.wnaf_len = (int)wn.size();
         pc.wnaf_w = w;
         memcpy(pc.wnaf, wn.data(), wn.size());
+        c->pair_ws_slots = 3 + 4 + 6 * (((1 << (w - 1)) - 2) / 2);
       }
     }
     HIP_BRK(hipMalloc((void**)&c->d_consts, sizeof pc));
@@ -572,7 +575,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
-  probe.take((size_t)(mode == 1 ? 3 : 22) * c->nl * so * 4);
+  probe.take((size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4);
   if (r_be) {
     probe.soa(c->nl, so, false);
     probe.soa(c->nl, so, false);
@@ -583,7 +586,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   SoA2 A = cv.soa(c->nl, sa, true);
   SoA2 B = nb ? cv.soa(c->nl, sb, true) : c->key_P();
   SoA2 O = cv.soa(c->nl, so, false);
-  uint32_t* ws = (uint32_t*)cv.take((size_t)(mode == 1 ? 3 : 22) * c->nl * so * 4);   // 22: room for the windowed loop's (dA, f_d)
+  uint32_t* ws = (uint32_t*)cv.take((size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4);   // room for the windowed loop's (dA, f_d)
   SoA2 T1{}, T2{};
   if (r_be) {
     T1 = cv.soa(c->nl, so, false);
@@ -1512,7 +1515,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
-    pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : 22) * c->nl * sp * 4);
+    pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;

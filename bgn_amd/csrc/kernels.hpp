@@ -190,7 +190,7 @@ struct KernelTable {
   //   mode 1: B is one broadcast point (b.stride == 1): ea = e, eb = 0.
   //   mode 2: poly product: e = (q*d1 + i)*d2 + k ; ea = q*d1 + i ; eb = q*d2 + k.
   //   run > 1: each lane owns `run` pairings and shares one F_p inversion among them; ws = workspace of
-  //   22*NL*sw u32 (sw >= count; 3*NL*sw suffice with fixed_tab).  run == 1 / ws == null: one pairing per lane.
+  //   (3 + 4 + 6*npts)*NL*sw u32 with npts = 2^(w-2) - 1 window multiples (sw >= count; 3*NL*sw suffice with fixed_tab).  run == 1 / ws == null: one pairing per lane.
   //   With ws != null and consts->wnaf_len > 0 the general Miller loop is the windowed one (width consts->wnaf_w).
   //   fixed_tab != null, mode 1: the second operand is the key's P and the Miller loop runs over the
   //   precomputed line table (fixedpair.hpp); b is ignored.

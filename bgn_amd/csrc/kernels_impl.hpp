@@ -158,7 +158,7 @@ __device__ __forceinline__ size_t pair_index(PairOperands& op, size_t e, int mod
 // Each lane owns `run` pairings e = j*T + t (T = lanes in the grid): pass 1 runs the Miller loops and
 // parks f and the prefix product of the norms in the workspace; one Fermat inversion per lane; pass 2
 // peels 1/N(f_j) off and finishes the exponentiation.  ws: 3 F_p per element (F0, F1, prefix), plus 4 more
-// WIN_SLOTS = 19 for the windowed Miller loop of VARIANT 0: 22 * NL * sw u32 in all.
+// win_slots(w) for the windowed Miller loop of VARIANT 0: (3 + win_slots(w)) * NL * sw u32 in all.
 // VARIANT 0: inlined step programs (pairing.hpp); 1: key-constant first argument (fixedpair.hpp);
 // 2: compact-code interpreter (vm.hpp)
 template <int NL, int VARIANT>

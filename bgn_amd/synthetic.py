@@ -38,17 +38,19 @@ def _signed_digits(n: int, w: int):
     return d
 
 
-def miller_schedule(n: int, window: int = 4):
+def miller_schedule(n: int, window: int = 5):
     """(#doubling steps, #addition steps, #extra F_p^2 products by f_d, #set-up products) of the Miller loop in
-    pairing.hpp: width-4 NAF by default (miller_loop_w), width 3, or the plain NAF with window = 2."""
+    pairing.hpp: width-5 NAF by default (miller_loop_w), width 3 / 4, or the plain NAF with window = 2."""
     d = _signed_digits(n, window)
     dbl = len(d) - 1
     add = sum(1 for i, x in enumerate(d[:-1]) if x and i != 0)
     big = sum(1 for x in d[:-1] if abs(x) > 1)
-    if window == 3:      # (3A, f_3): one doubling, one addition step, 1/Z, 4 + 4 products
-        pre = 18 + 17 + INVERSION_PRODUCTS + 8
-    elif window >= 4:    # 2A affine, three addition steps, two products by f_2, one shared inversion, coordinates, canonical f_d
-        pre = 18 + (INVERSION_PRODUCTS + 4) + 3 * 17 + 2 * 3 + (INVERSION_PRODUCTS + 6 + 12) + 16
+    if window >= 3:
+        npts = (1 << (window - 2)) - 1                       # odd multiples 3A .. (2^(w-1) - 1) A
+        pre = 18 + npts * 17 + (npts - 1) * 3                # doubling step, addition steps, products by f_2
+        pre += INVERSION_PRODUCTS + 7 * npts + 4 * npts      # shared inversion, peel + coordinates, canonical f_d
+        if window >= 4:
+            pre += INVERSION_PRODUCTS + 4 + 4                # 2A made affine, canonical f_2
     else:
         pre = 0
     return dbl, add, big, pre
@@ -69,7 +71,7 @@ def square_mads(nl: int, segments: int = 5) -> int:
     return prod + nl * nl
 
 
-def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 4, segments: int = 5) -> int:
+def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: int = 5) -> int:
     """32x32->64 multiply-adds one pairing executes in this formulation: general field products at 2*NL^2
     (schoolbook product + Montgomery reduction rows), squarings at the segmented square's count.
     The F_p inversion of the final exponentiation is shared by `run` pairings per lane."""
@@ -82,6 +84,6 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 4, segments: i
     per_pairing = pre + dbl * 18 + add * 17 + threes * 3 + 2 * 2 + 3 + 5 + lpow + 2
     # of which field squarings: 6 per doubling step, 3 per addition step (pairing.hpp), 9 in the set-up of the
     # windowed loop, 4 + 2 in the norms / conj(f)^2
-    squares = dbl * 6 + add * 3 + (9 if window == 3 else (21 if window >= 4 else 0)) + 6
+    squares = dbl * 6 + add * 3 + ((6 + 3 * ((1 << (window - 2)) - 1) + 3) if window >= 3 else 0) + 6
     products = per_pairing + INVERSION_PRODUCTS / run
     return int((products - squares) * 2 * nl * nl + squares * square_mads(nl, segments))

@@ -87,7 +87,7 @@ class Emu:
         buf += struct.pack("<%dI" % MAX_EXP_LIMBS, *limbs(pm2, MAX_EXP_LIMBS))
         self._base = buf
         self.consts = None
-        self.set_window(4)
+        self.set_window(5)
 
     def set_window(self, w: int):
         """Install the width-w NAF of n for the windowed Miller loop (pairing.hpp miller_loop_w)."""

@@ -321,11 +321,11 @@ def main():
         mads = bgn_amd.synthetic.algorithmic_mads_per_pairing(
             fx, run=max(1, min(16, count // 65536)), window={"0": 2, "3": 3, "4": 4}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 5))
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", "r01e_pmc_summary.json")
         if os.path.exists(pmc) and args.batch_log2 == 20 and args.key == "k1024":
             with open(pmc) as f:
                 traffic = json.load(f)["hbm_bytes_per_launch"]     # separate rocprofv3 --pmc passes of this command
-            traffic_src = "profiles/r01d_pmc_summary.json (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)"
+            traffic_src = "profiles/r01e_pmc_summary.json (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)"
         line = {
             "metric": "EMult pairings/sec at 1024-bit, batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -558,11 +558,30 @@ static int pairing_variant() {
   return (ev && ev[0] == '1') ? 1 : 0;
 }
 
+static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
+                         size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len);
+
+// Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with
+// the width-5 loop) stays at 31 GB however long the arrays are.
 static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                           size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be = nullptr,
                           size_t r_len = 0) {
   if (!count) return BGN_OK;
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
+  const size_t piece = (size_t)1 << 22, eb = (size_t)2 * c->L;
+  for (size_t off = 0; off < count; off += piece) {
+    const size_t n = count - off < piece ? count - off : piece;
+    int rc = pairing_chunk(c, n, a + off * eb, n, b ? b + off * eb : nullptr, b ? n : 0, mode, d1, d2, out + off * eb, s,
+                           r_be ? r_be + off * r_len : nullptr, r_len);
+    if (rc) return rc;
+  }
+  (void)na;
+  (void)nb;
+  return BGN_OK;
+}
+
+static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
+                         size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   if (r_be) {

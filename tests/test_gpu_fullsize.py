@@ -129,3 +129,27 @@ def test_config5_multpoly_shape_decrypts_to_convolution():
         for k in range(d):
             conv[:, i + k] += ca[:, i] * cb[:, k]
     assert bool((m.cpu().view(npoly, 2 * d) == conv).all().item())
+
+
+def test_mult_longer_than_one_piece():
+    """Mult processes its arrays in pieces of 2^22 pairs (bounded workspace): a batch that spans two pieces, with
+    inputs cycling through a small pool, reproduces the pool's pairings at every position."""
+    import oracle_c
+    fx = load_fixture("toy64")
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    pool = 7
+    pa = b"".join(cts[i % len(cts)] for i in range(pool))
+    pb = b"".join(cts[(3 * i + 1) % len(cts)] for i in range(pool))
+    want = torch.frombuffer(bytearray(o.mult(pa, pb)), dtype=torch.uint8).view(pool, EB).cuda()
+    count = (1 << 22) + 77
+    idx = torch.arange(count, device="cuda") % pool
+    a = torch.frombuffer(bytearray(pa), dtype=torch.uint8).view(pool, EB).cuda()[idx].reshape(-1).contiguous()
+    b = torch.frombuffer(bytearray(pb), dtype=torch.uint8).view(pool, EB).cuda()[idx].reshape(-1).contiguous()
+    out = torch.empty(count * EB, dtype=torch.uint8, device="cuda")
+    eng.mult_dev(a, b, out, count)
+    torch.cuda.synchronize()
+    assert bool((out.view(count, EB) == want[idx]).all().item())

@@ -321,6 +321,10 @@ k_g1_mul(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C
   __shared__ LFp<NL> L[4];
   size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
   const bool live = e < A.count;
+  // a wave without live lanes leaves: the windowed variant writes a per-element table, and a whole wave of
+  // stand-ins for the last element would race with the wave that owns it (lanes of ONE wave run in lockstep
+  // and write identical values, which is harmless)
+  if (!__ballot(live)) return;
   if (!live) e = A.count - 1;
   g1_scalarmul_lane<NL>(A, e, live, L, C, P);
 }

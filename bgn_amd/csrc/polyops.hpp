@@ -47,7 +47,7 @@ __device__ __forceinline__ void poly_lin_g1_lane(const PolyLinArgs& A, size_t la
   bool acc_inf = true;
 #pragma unroll 1
   for (int b = A.nbits - 1; b >= 0; --b) {
-    if (__ballot(!acc_inf)) jac_double<NL>(S, L, P);
+    jac_double_checked<NL>(S, acc_inf, L, P);
 #pragma unroll 1
     for (size_t i = 0; i < A.d; ++i) {
       const long long ki = poly_lin_scalar_index(A, s, i);

@@ -125,13 +125,21 @@ struct Emu {
     memcpy(out + NL, im.v, 4 * NL);
   }
   static void g1_mul(const u32* params, const PairingConsts* C, const u32* base, uint8_t binf, const uint8_t* k,
-                     size_t klen, u32* out, uint8_t* oinf) {
+                     size_t klen, int window, u32* out, uint8_t* oinf) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     G1MulArgs A;
     A.bx = base; A.by = base + NL; A.binf = &binf; A.sb = 1;
     A.k = k; A.kstride = 0; A.klen = klen;
     A.ox = out; A.oy = out + NL; A.oinf = oinf; A.so = 1;
     A.count = 1;
+    std::vector<u32> wtab;
+    std::vector<uint8_t> winf;
+    A.wtab = nullptr; A.winf = nullptr; A.wcap = 0;
+    if (window) {                                   // the 4-bit windowed variant with its per-element table
+      wtab.assign((size_t)5 * NL * 16, 0);
+      winf.assign(16, 0);
+      A.wtab = wtab.data(); A.winf = winf.data(); A.wcap = 1;
+    }
     g1_scalarmul_lane<NL>(A, 0, true, lds(), C, P);
   }
   // count elements processed by ONE lane as a run (exercises the batched inversion)
@@ -393,7 +401,7 @@ int emu_decode(int nl, const u32* params, const uint8_t* wire, int Lb, u32* out,
 int emu_encode(int nl, const u32* plain, int Lb, uint8_t inf, uint8_t* wire) { DISPATCH(nl, encode(plain, Lb, inf, wire)) }
 int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing(params, (const PairingConsts*)C, a, b, out)) }
 int emu_pairing_w3(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_w3(params, (const PairingConsts*)C, a, b, out)) }
-int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, out, oinf)) }
+int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, int window, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, window, out, oinf)) }
 int emu_g1_add(int nl, const u32* params, const void* C, const u32* a, const uint8_t* ainf, const u32* b, const uint8_t* binf, int count, int negate_b, int plain, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_add(params, (const PairingConsts*)C, a, ainf, b, binf, count, negate_b, plain, out, oinf)) }
 int emu_gt_mul(int nl, const u32* params, const u32* a, const u32* b, int conj_b, int plain_a, u32* out) { DISPATCH(nl, gt_mul(params, a, b, conj_b, plain_a, out)) }
 int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow(params, a, k, klen, out)) }

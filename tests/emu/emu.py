@@ -174,13 +174,14 @@ class Emu:
                                           1 if normalized else 0, Cm, out) == 0
         return self.encode(out)
 
-    def g1_mul(self, base: bytes, k: int, klen: int = None) -> bytes:
+    def g1_mul(self, base: bytes, k: int, klen: int = None, window: bool = False) -> bytes:
         B, ib = self.decode(base)
         klen = klen or max(1, (k.bit_length() + 7) // 8)
         kb = k.to_bytes(klen, "big")
         out = (C.c_uint32 * (2 * self.nl))()
         oinf = C.c_uint8()
-        assert self.lib.emu_g1_mul(self.nl, self.params, self.consts, B, ib, kb, C.c_size_t(klen), out, C.byref(oinf)) == 0
+        assert self.lib.emu_g1_mul(self.nl, self.params, self.consts, B, ib, kb, C.c_size_t(klen), 1 if window else 0, out,
+                                   C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 
     def decode_plain(self, wire: bytes):

@@ -46,19 +46,37 @@ def test_emu_windowed_miller_loop(ctx, w):
     E.set_window(5)
 
 
-def test_emu_scalar_mult_exceptional_cases(ctx):
-    """acc == +-base inside the ladder: k = n, n+-1, n+2 for P; multiples of q1 (+-1, +2) for Q of order q1."""
+@pytest.mark.parametrize("window", [False, True])
+def test_emu_scalar_mult_exceptional_cases(ctx, window):
+    """acc == +-base inside the ladder: k = n, n+-1, n+2 for P; multiples of q1 (+-1, +2) for Q of order q1; a base
+    of order 2 and of order 4 (points of the curve outside the ciphertext subgroup), the identity — for the binary
+    ladder and for the 4-bit windows over a per-element table of multiples."""
     fx, E = ctx
     p, n, q1 = int(fx["p"], 16), int(fx["n"], 16), int(fx["q1"], 16)
     Pw, Qw = bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"])
     Pp, Qp = R.elem_from_bytes(Pw, p), R.elem_from_bytes(Qw, p)
     rng = random.Random(1)
     L = (n.bit_length() + 7) // 8 + 1
-    for k in [0, 1, 2, 3, 4, 5, 7, n - 1, n, n + 1, n + 2, 2 * n + 5, rng.randrange(n)]:
-        assert E.g1_mul(Pw, k, L) == R.elem_to_bytes(R.pt_mul(Pp, k, p), p), k
+    for k in [0, 1, 2, 3, 4, 5, 7, 15, 16, 17, 0xF0F0, n - 1, n, n + 1, n + 2, 2 * n + 5, 16 * n + 3, rng.randrange(n)]:
+        assert E.g1_mul(Pw, k, L, window) == R.elem_to_bytes(R.pt_mul(Pp, k, p), p), k
     for k in [q1 - 1, q1, q1 + 1, q1 + 2, 2 * q1, 2 * q1 + 2, 3 * q1 + 2]:
-        assert E.g1_mul(Qw, k, L) == R.elem_to_bytes(R.pt_mul(Qp, k, p), p), k
-    assert E.g1_mul(bytes(2 * E.L), 5, 2) == bytes(2 * E.L)      # identity base
+        assert E.g1_mul(Qw, k, L, window) == R.elem_to_bytes(R.pt_mul(Qp, k, p), p), k
+    assert E.g1_mul(bytes(2 * E.L), 5, 2, window) == bytes(2 * E.L)      # identity base
+    # (0, 0) is the identity's encoding; a point of order 4 exists when l = (p+1)/n is a multiple of 4 (it is, by
+    # construction): x = 1 gives y^2 = 2 — take any point T of order n*l and multiply up instead
+    T = None
+    for x in range(2, 200):
+        rhs = (x * x * x + x) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs:
+            T = R.pt_mul((x, y), n * (fx["l"] // 4), p)       # order divides 4
+            if T is not None and R.pt_mul(T, 2, p) is not None:
+                break
+            T = None
+    if T is not None:
+        Tw = R.elem_to_bytes(T, p)
+        for k in [1, 2, 3, 4, 5, 6, 7, 8, 0x1234, 0x4444]:
+            assert E.g1_mul(Tw, k, 2, window) == R.elem_to_bytes(R.pt_mul(T, k, p), p), ("order-4 base", k)
 
 
 def test_emu_g1_add_run(ctx):

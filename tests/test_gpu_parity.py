@@ -491,3 +491,24 @@ def test_decrypt_with_unusual_secrets_does_not_misbehave():
     pk.SetupDecryption(sk)
     m, st = pk.engine.decrypt(1, wire)
     assert not st.any() and [int(v) for v in m] == [5, 0, 9]
+
+
+@pytest.mark.parametrize("name,count", [("toy64", 300), ("k256", 65), ("k512", 5)])
+def test_multconst_windowed_vs_oracle(name, count):
+    """MultConst on level 1 with scalars of 128 bits and more runs over a per-element table of multiples (4-bit
+    windows); ragged counts (the last element has stand-in lanes), scalars >= n, an identity operand."""
+    import oracle_c
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    rng = random.Random(23)
+    n = int(fx["n"], 16)
+    xs = [rng.randrange(1, 1000) for _ in range(count)]
+    rs = [rng.randrange(n) for _ in range(count)]
+    xs[1 % count], rs[1 % count] = 0, 0                      # identity
+    cts = o.encrypt(xs, rs)
+    klen = max(16, (n.bit_length() + 7) // 8 + 1)
+    ks = [rng.randrange(1 << (8 * klen)) for _ in range(count)]
+    ks[0] = n
+    ks[-1] = n + 1
+    assert pk.engine.multconst(1, cts, ks).tobytes() == o.multconst(1, cts, ks)

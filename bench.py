@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — EMult (Type-A1 Tate pairing) throughput on MI355X.
+"""bench.py — EMult (Type-A1 Tate pairing) and BSGS Decrypt throughput on MI355X.
 
-Metric (BASELINE.json): EMult pairings/sec at 1024-bit params, batch = 2^20 per
-GPU.  One "step" = one pass of pk.Mult over a batch of 2^20 pairs of level-1
-ciphertexts: PBC wire bytes resident in HBM -> wire bytes resident in HBM
-(decode, Miller loop + final exponentiation, encode), then — when more than
-one GPU takes part — the RCCL all-gather of the result arrays named by the
-north star.  Batches shard by contiguous ranges, one process per GPU, no
-collective on the data path other than that gather (scaling: weak, 2^20 per GPU).
+Metric (BASELINE.json): EMult pairings/sec + BSGS decrypts/sec at 1024-bit, batch = 2^20 per GPU.
+One "step" = one pass of pk.Mult over a batch of 2^20 pairs of level-1 ciphertexts — SURVEY.md 8(d) Config 3:
+the outputs of Config 2 (Encrypt of 2^20 random 40-bit messages with full-length randomness, produced on the GPU
+before the timed region) paired with a fixed permutation of themselves — PBC wire bytes resident in HBM -> wire
+bytes resident in HBM (decode, Miller loop + final exponentiation, encode), then — when more than one GPU takes
+part — the RCCL all-gather of the result arrays named by the north star.  Batches shard by contiguous ranges, one
+process per GPU, no collective on the data path other than that gather (scaling: weak, 2^20 per GPU).
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-log2 B]
-For N > 1 launch through torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE).
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--workload emult|multpoly] [--batch-log2 B]
+  --gpus N with WORLD_SIZE unset: this process spawns N fresh rank processes of itself (before anything touches
+  the GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU, RCCL over xGMI between them.
+  Under an external launcher (python -m torch.distributed.run ... bench.py --gpus N) the ranks come from the
+  environment and --gpus must agree with WORLD_SIZE.
+  --workload multpoly: BASELINE configs[4] — 2^14 MultPoly instances of 16x16 coefficient polynomials (2^22
+  coefficient pairs) per job plus one AddPoly, sharded by polynomial across the GPUs (strong scaling).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,44 +29,75 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# profiles/ubench_valu_rates_r01.txt: v_mad_u64_u32, 4 waves/SIMD: 454.75 G wave-instr/s
-VALU_MAD_PEAK = 454.75e9 * 64  # lane-MADs per second, whole chip
+# profiles/ubench_valu_rates_r01.txt: v_mad_u64_u32 wave-instructions per second, whole chip
+VALU_MAD_PEAK_4W = 454.75e9 * 64   # lane-MADs/s at 4 waves per SIMD (the chip's ceiling)
+VALU_MAD_PEAK_1W = 378.08e9 * 64   # at 1 wave per SIMD — the occupancy these 512-register kernels run at
+# profiles/ubench_fp_rates_r01.txt: field products per second of the whole chip at NL = 38, one wave per SIMD
+PRODUCT_CEILING = {38: 8.15e9}
+
+
+def cpu_budget():
+    """What the box lets this process use: affinity, and the cgroup CPU quota (cpu.max) when there is one."""
+    info = {"nproc": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    info["cgroup_cpus"] = float(txt[0]) / float(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    info["cgroup_cpus"] = q / p
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
 
 
 def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0):
-    """The oracle timed on this box's host cores on a bounded sample of the same
-    workload: the first pairs of the very batch the GPU just processed.  Its
-    outputs are compared byte for byte with the GPU's.  Test-infrastructure code
-    used as the reported baseline and checker only; never on the product path."""
+    """The oracle timed on this box's host cores on a bounded sample of the same workload: the first pairs of the
+    very batch the GPU just processed.  Its outputs are compared byte for byte with the GPU's.
+    Test-infrastructure code used as the reported baseline and checker only; never on the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    res = None
     try:
         import oracle_c
         if oracle_c.available():
-            return oracle_c.bench_pairings(fx, a_host, b_host, gpu_out_host, seconds)
+            res = oracle_c.bench_pairings(fx, a_host, b_host, gpu_out_host, seconds)
     except ImportError:
         pass
-    import bgn_ref as R
-    from conftest import oracle_key
-    opk, _ = oracle_key(fx)
-    EB = 2 * R.fp_len(opk.p)
-    npairs = len(a_host) // EB
-    n, ok, t0 = 0, True, time.time()
-    while time.time() - t0 < seconds and n < npairs:
-        A = R.elem_from_bytes(a_host[n * EB:(n + 1) * EB], opk.p)
-        B = R.elem_from_bytes(b_host[n * EB:(n + 1) * EB], opk.p)
-        ok &= R.elem_to_bytes(opk.e(A, B), opk.p) == gpu_out_host[n * EB:(n + 1) * EB]
-        n += 1
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "pairings/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} pairs of the GPU batch, pure-Python big-int oracle (oracle/bgn_ref.py), "
-                      f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
+    if res is None:
+        import bgn_ref as R
+        from conftest import oracle_key
+        opk, _ = oracle_key(fx)
+        EB = 2 * R.fp_len(opk.p)
+        npairs = len(a_host) // EB
+        n, ok, t0 = 0, True, time.time()
+        while time.time() - t0 < seconds and n < npairs:
+            A = R.elem_from_bytes(a_host[n * EB:(n + 1) * EB], opk.p)
+            B = R.elem_from_bytes(b_host[n * EB:(n + 1) * EB], opk.p)
+            ok &= R.elem_to_bytes(opk.e(A, B), opk.p) == gpu_out_host[n * EB:(n + 1) * EB]
+            n += 1
+        dt = time.time() - t0
+        res = {"value": n / dt, "unit": "pairings/s", "cores": 1, "kind": "port",
+               "sample": f"first {n} pairs of the GPU batch, pure-Python big-int oracle (oracle/bgn_ref.py), "
+                         f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
+    res["host_cpu"] = cpu_budget()      # `cores` = threads started; the cgroup quota says what they could get
+    return res
 
 
 def config0_metrics(no_cpu: bool):
     """BASELINE configs[0]: 512-bit params, 128 ciphertexts, pk.Add and pk.Mult over 128 independent pairs — the
     shape of BenchmarkAdd / BenchmarkMult (bgn_test.go:97-140), which the reference runs on one goroutine.  Host
     buffers in and out (the size at which the boundary copies matter), next to the single-threaded C oracle on the
-    same 128 pairs."""
+    same 128 pairs; and the latency of ONE Mult (count = 1), 512- and 1024-bit."""
     import numpy as np
     from conftest import load_fixture
     import bgn_amd
@@ -77,10 +114,19 @@ def config0_metrics(no_cpu: bool):
     out = {}
     for name, fn in (("eadd", lambda: eng.add(1, a, b)), ("emult", lambda: eng.mult(a, b))):
         fn()
-        t0 = time.perf_counter()
-        res = fn()
-        dt = time.perf_counter() - t0
-        out[name] = {"value": n / dt, "unit": "ops/s", "wall_ms_for_128": dt * 1e3, "result": res.tobytes()}
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        out[name] = {"value": n / best, "unit": "ops/s", "wall_ms_for_128": best * 1e3, "result": res.tobytes()}
+    E = eng.elem_bytes
+    eng.mult(a[:E], b[:E])
+    t0 = time.perf_counter()
+    one = eng.mult(a[:E], b[:E])
+    out["emult_count1_latency_ms"] = (time.perf_counter() - t0) * 1e3
+    assert one.tobytes() == out["emult"]["result"][:E]
     if not no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         try:
@@ -95,129 +141,169 @@ def config0_metrics(no_cpu: bool):
                     out[name]["matches_cpu_bit_exact"] = bool(ref == out[name]["result"])
         except (ImportError, AttributeError):
             pass
-    for name in out:
+    for name in ("eadd", "emult"):
         del out[name]["result"]
     out["workload"] = "configs[0]: 512-bit params, 128-ciphertext EAdd + EMult, host buffers through the C ABI"
     return out
 
 
-def secondary_metrics(pk, fx, dev, dec_log2s):
-    """BASELINE configs[1] (Encrypt) and configs[3] (BSGS Decrypt, T = 2^40, batch 2^16), reported next to the
-    headline value.  Inputs resident in HBM; one warm-up pass then one timed pass each."""
+def _timed(fn, sync, reps=2):
+    dt = None
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        dt = time.perf_counter() - t0
+    return dt
+
+
+def op_rooflines(entry, products_per_unit, nl):
+    """Every secondary entry carries the two bounds: field products against the measured product ceiling of the
+    chip (the VALU bound that applies) and algorithmic bytes against the HBM peak."""
+    ceil = PRODUCT_CEILING.get(nl)
+    entry["products_per_unit"] = products_per_unit
+    if ceil:
+        entry["frac_of_product_ceiling"] = entry["value"] * products_per_unit / ceil
+        entry["product_ceiling_per_s"] = ceil
+    if "algorithmic_bytes_per_unit" in entry:
+        gbs = entry["value"] * entry["algorithmic_bytes_per_unit"] / 1e9
+        entry["hbm"] = {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+    return entry
+
+
+def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
+    """BASELINE configs[1] (Encrypt), EAdd, configs[4]'s shape on one GPU and configs[3] (BSGS Decrypt, T = 2^40),
+    on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used.  Inputs resident in HBM; one warm-up pass
+    then one timed pass each."""
     import numpy as np
     import torch
     import bgn_amd
+    import bgn_amd.synthetic as syn
     eng = pk.engine
     EB = eng.elem_bytes
+    nl = 38
+    sync = torch.cuda.synchronize
     out = {}
-    # --- Encrypt: configs[1]: 2^20 messages m uniform in [0, 2^40), r uniform below 2^1022
-    n_enc = 1 << 20
-    g = torch.Generator(device="cpu")
-    g.manual_seed(4242)
-    xs = torch.randint(0, 256, (n_enc, 5), dtype=torch.uint8, generator=g).to(dev)          # 40-bit plaintexts
-    rs = torch.randint(0, 256, (n_enc, 128), dtype=torch.uint8, generator=g)
-    rs[:, 0] &= 0x3F                                                                          # r < 2^1022 < n
-    rs = rs.to(dev)
-    cts = torch.empty(n_enc * EB, dtype=torch.uint8, device=dev)
-    for it in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.encrypt_dev(xs, 5, rs, 128, cts, n_enc)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    out["encrypt"] = {"value": n_enc / dt, "unit": "encrypts/s", "batch": n_enc,
-                      "workload": "configs[1]: batch=2^20 Encrypt P^m * Q^r, 40-bit m, 1022-bit r, fixed-base: one entry of the "
-                                  "16-bit window tables of P and Q (HBM, 1.3 GB each) per window, affine additions over four "
-                                  "accumulation chains per element (one launch adds four windows), one inversion per run of 64",
-                      "kernel": eng.last_kernel_name(), "kernel_ms_per_step": eng.last_kernel_ms(),
-                      "algorithmic_bytes_per_unit": 5 + 128 + EB}
+    n_enc = xs.shape[0]
+    tmp = torch.empty_like(cts)
+    dt = _timed(lambda: eng.encrypt_dev(xs, xs.shape[1], rs, rs.shape[1], tmp, n_enc), sync)
+    assert bool((tmp == cts).all().item())
+    del tmp
+    out["encrypt"] = op_rooflines(
+        {"value": n_enc / dt, "unit": "encrypts/s", "batch": n_enc,
+         "workload": "configs[1]: batch=2^20 Encrypt P^m * Q^r, 40-bit m, 1022-bit r, fixed-base window tables of P "
+                     "(16-bit) and Q (20-bit) in HBM, affine additions over four accumulation chains per element, one "
+                     "inversion per run of 64",
+         "kernel": eng.last_kernel_name(), "kernel_ms_per_step": eng.last_kernel_ms(),
+         "algorithmic_bytes_per_unit": xs.shape[1] + rs.shape[1] + EB},
+        syn.encrypt_products(xs.shape[1] * 8, rs.shape[1] * 8), nl)
     # --- EAdd (level 1): pairs of those ciphertexts
     n_add = n_enc // 2
     a1, b1 = cts[: n_add * EB], cts[n_add * EB: 2 * n_add * EB]
     o1 = torch.empty(n_add * EB, dtype=torch.uint8, device=dev)
-    for it in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.add_dev(1, a1, b1, o1, n_add)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    out["eadd_l1"] = {"value": n_add / dt, "unit": "adds/s", "batch": n_add,
-                      "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion)",
-                      "algorithmic_bytes_per_unit": 3 * EB, "achieved_GBps": 3 * EB * n_add / dt / 1e9}
+    dt = _timed(lambda: eng.add_dev(1, a1, b1, o1, n_add), sync)
+    out["eadd_l1"] = op_rooflines(
+        {"value": n_add / dt, "unit": "adds/s", "batch": n_add,
+         "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion), wire bytes to wire bytes",
+         "kernel": eng.last_kernel_name(), "algorithmic_bytes_per_unit": 3 * EB},
+        syn.eadd_products(n_add), nl)
+    del o1
     # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
     npoly, d1, d2 = 1 << 12, 16, 16
     pa = cts[: npoly * d1 * EB]
     pb = cts[npoly * d1 * EB: npoly * (d1 + d2) * EB]
     po = torch.empty(npoly * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
-    for it in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.poly_mult_dev(npoly, d1, d2, pa, pb, po)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    out["multpoly"] = {"value": npoly * d1 * d2 / dt, "unit": "coefficient pairs/s", "polys": npoly, "d1": d1, "d2": d2,
-                       "workload": "configs[4] shape on one GPU: MultPoly of 16x16-coefficient ciphertext polynomials "
-                                   "(d1*d2 pairings + segmented GT accumulation), sharded by polynomial across GPUs"}
-    # --- Decrypt: the first 2^k of those ciphertexts, every 16th negated; k = configs[3]'s 2^16 and the metric's 2^20
+    dt = _timed(lambda: eng.poly_mult_dev(npoly, d1, d2, pa, pb, po), sync)
+    out["multpoly"] = op_rooflines(
+        {"value": npoly * d1 * d2 / dt, "unit": "coefficient pairs/s", "polys": npoly, "d1": d1, "d2": d2,
+         "workload": "configs[4] shape on one GPU: MultPoly of 16x16-coefficient ciphertext polynomials "
+                     "(Karatsuba over the bilinear pairing, per-coefficient line tables, segmented GT accumulation), "
+                     "sharded by polynomial across GPUs",
+         "algorithmic_bytes_per_unit": 3 * EB},
+        syn.multpoly_products_per_pair(fx, d1), nl)
+    del po
+    # --- Decrypt: the first 2^k of those ciphertexts, every 16th negated and every 4096th out of range
     t0 = time.perf_counter()
     pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
-    torch.cuda.synchronize()
+    sync()
     t_setup = time.perf_counter() - t0
-    neg = torch.empty_like(cts)
-    eng._lib.bgn_neg_batch_dev(eng._h, n_enc, 1, cts.data_ptr(), neg.data_ptr(), eng._stream())
-    mixed = cts.view(n_enc, EB).clone()
-    mixed[::16] = neg.view(n_enc, EB)[::16]
-    del neg
-    want_all = torch.zeros(n_enc, dtype=torch.int64)
-    xb = xs.cpu().numpy().astype(np.int64)
-    for j in range(5):
-        want_all = want_all * 256 + torch.from_numpy(xb[:, j])
-    want_all[::16] = -want_all[::16]
+    mixed, want, want_st = syn.decrypt_mix(pk, fx, cts, xs, dev)
+    dec = {}
     for k in sorted(set(dec_log2s)):
         n_dec = 1 << k
-        sel = mixed[:n_dec].reshape(-1).contiguous()
+        sel = mixed[: n_dec * EB]
         m = torch.empty(n_dec, dtype=torch.int64, device=dev)
         st = torch.empty(n_dec, dtype=torch.uint8, device=dev)
-        for it in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            eng.decrypt_dev(1, sel, m, st, n_dec)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        k_ms = eng.last_kernel_ms()
-        ok = bool((m.cpu() == want_all[:n_dec]).all().item()) and not bool(st.any().item())
-        out["decrypt" if k == 16 else "decrypt_2^%d" % k] = {
-            "value": n_dec / dt, "unit": "decrypts/s", "batch": n_dec, "level": 1,
-            "workload": "configs[3]: T=2^40 BSGS Decrypt, batch=2^%d, m uniform in [0,2^40), 1/16 negative; Miller loop "
-                        "over the secret order's line table + final exponentiation + ^sk, then giant steps 2S apart "
-                        "on an HBM-resident baby table (%d entries)" % (k, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))),
-            "search_kernel_ms": k_ms, "kernel": eng.last_kernel_name(), "table_setup_s": t_setup,
-            "plaintexts_recovered_exactly": ok, "algorithmic_bytes_per_unit": EB + 16}
+        dt = _timed(lambda: eng.decrypt_dev(1, sel, m, st, n_dec), sync)
+        lift_ms, walk_ms = eng.last_aux_kernel_ms(), eng.last_kernel_ms()
+        ok = bool((m.cpu() == want[:n_dec]).all().item()) and bool((st.cpu() == want_st[:n_dec]).all().item())
+        alg = EB + 16
+        e = op_rooflines(
+            {"value": n_dec / dt, "unit": "decrypts/s", "batch": n_dec, "level": 1,
+             "workload": "configs[3]: T=2^40 BSGS Decrypt, batch=2^%d, m uniform in [0,2^40), 1/16 negative, 1/4096 out "
+                         "of range (status NOT_FOUND); Miller loop over the secret order's line table + final "
+                         "exponentiation + ^sk, then giant steps 2S apart on an HBM-resident baby table (%d entries)"
+                         % (k, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))),
+             "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
+            syn.decrypt_products(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
+        # the dominant kernel of Decrypt is the lift (k_pairing<38, 1>), timed by HIP events on its stream
+        e["roofline"] = {"bound": "hbm", "achieved": alg * n_dec / (lift_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg * n_dec / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": eng.last_aux_kernel_name(), "kernel_ms": lift_ms,
+                         "walk_kernel": eng.last_kernel_name(), "walk_kernels_ms": walk_ms,
+                         "algorithmic_bytes_per_decrypt": alg}
+        dec[k] = e
     # --- Decrypt of level-2 ciphertexts (configs[3] asks for both levels): products of 20-bit messages
     n2 = 1 << 16
+    g = torch.Generator(device="cpu")
+    g.manual_seed(777)
     xs2 = torch.randint(0, 256, (2 * n2, 3), dtype=torch.uint8, generator=g)
     xs2[:, 0] &= 0x0F                                                                         # 20-bit plaintexts
     xs2 = xs2.to(dev)
     c2 = torch.empty(2 * n2 * EB, dtype=torch.uint8, device=dev)
-    eng.encrypt_dev(xs2, 3, rs[: 2 * n2], 128, c2, 2 * n2)
+    eng.encrypt_dev(xs2, 3, rs[: 2 * n2], rs.shape[1], c2, 2 * n2)
     l2 = torch.empty(n2 * EB, dtype=torch.uint8, device=dev)
     eng.mult_dev(c2[: n2 * EB], c2[n2 * EB:], l2, n2)
     m = torch.empty(n2, dtype=torch.int64, device=dev)
     st = torch.empty(n2, dtype=torch.uint8, device=dev)
-    for it in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.decrypt_dev(2, l2, m, st, n2)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+    dt = _timed(lambda: eng.decrypt_dev(2, l2, m, st, n2), sync)
     xv = xs2.cpu().numpy().astype(np.int64)
     val = (xv[:, 0] * 65536 + xv[:, 1] * 256 + xv[:, 2])
     ok = bool((m.cpu().numpy() == val[:n2] * val[n2:]).all()) and not bool(st.any().item())
-    out["decrypt_l2"] = {"value": n2 / dt, "unit": "decrypts/s", "batch": n2, "level": 2,
-                         "workload": "configs[3], level 2: Decrypt of 2^16 products of two 20-bit messages (outputs of Mult): "
-                                     "^sk by the norm-1 ladder, then the same giant-step walk",
-                         "plaintexts_recovered_exactly": ok}
-    return out
+    out["decrypt_l2"] = op_rooflines(
+        {"value": n2 / dt, "unit": "decrypts/s", "batch": n2, "level": 2,
+         "workload": "configs[3], level 2: Decrypt of 2^16 products of two 20-bit messages (outputs of Mult): "
+                     "^sk by the norm-1 ladder, then the same giant-step walk",
+         "plaintexts_recovered_exactly": ok, "algorithmic_bytes_per_unit": EB + 16},
+        syn.decrypt_products(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h)), level=2), nl)
+    return out, dec
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start N fresh rank processes of this script, one per GPU, before anything in
+    this process has touched the GPU (this parent never does), and return the worst exit code.  Rank 0 prints the
+    JSON line on the shared stdout."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:                                  # a failed rank leaves the others at a barrier: end them
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -225,23 +311,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--workload", choices=["emult", "multpoly"], default="emult")
+    ap.add_argument("--batch-log2", type=int, default=20, help="emult: pairs per GPU (log2)")
+    ap.add_argument("--polys-log2", type=int, default=14, help="multpoly: polynomials in the whole job (log2)")
     ap.add_argument("--key", default="k1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary Encrypt / Decrypt measurements")
     ap.add_argument("--decrypt-log2", type=int, nargs="+", default=[16, 20],
-                    help="batch sizes (log2, at most 20) of the secondary Decrypt measurement")
+                    help="batch sizes (log2, at most 20) of the Decrypt measurement")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and gather even with one rank")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != world:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    force_dist = os.environ.get("BGN_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path with one rank
-    if world > 1 or force_dist:
+    use_dist = world > 1 or args.force_dist or os.environ.get("BGN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -253,29 +350,36 @@ def main():
 
     from conftest import load_fixture
     import bgn_amd
-    import bgn_amd.synthetic
-    from bgn_amd.sharding import shard_range
+    import bgn_amd.synthetic as syn
+    from bgn_amd.sharding import gather_shards, shard_range
 
     fx = load_fixture(args.key)
     pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]),
                            bytes.fromhex(fx["Q"]), fx["msg_space"], True, fx["poly_base"], device=local_rank)
     eng = pk.engine
     EB = eng.elem_bytes
+    rccl_ranks = dist.get_world_size() if use_dist else 0
+
+    if args.workload == "multpoly":
+        return bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks)
+
     per_gpu = 1 << args.batch_log2
     total = per_gpu * world
     lo, hi = shard_range(total, world, rank)           # contiguous slice of the global batch
     count = hi - lo
 
-    # Synthetic level-1 ciphertexts, resident in HBM before the timed region.
-    a, b = bgn_amd.synthetic.l1_ciphertext_pairs(pk, fx, count, seed=1000 + rank, device=dev)
+    # Config 2 on the GPU (not timed): this rank's 2^20 ciphertexts; Config 3: paired with a fixed permutation.
+    xs, rs, cts = syn.config2_ciphertexts(pk, count, seed=1000 + rank, device=dev)
+    a = cts
+    b = syn.permuted_copy(cts, EB, seed=5)
     out = torch.empty(count * EB, dtype=torch.uint8, device=dev)
-    use_dist = world > 1 or force_dist
-    gathered = torch.empty(total * EB, dtype=torch.uint8, device=dev) if use_dist else None
+    gathered = None
 
     def step():
+        nonlocal gathered
         eng.mult_dev(a, b, out, count)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, out)
+            gathered = gather_shards(out, total, EB, world, rank, dist)
 
     kernel_ms = []
     for _ in range(args.warmup):
@@ -298,19 +402,19 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        assert bool((gathered[rank * count * EB:(rank + 1) * count * EB] == out).all().item()), "gather mismatch"
+        assert bool((gathered[lo * EB:hi * EB] == out).all().item()), "gather mismatch"
 
-    # prefix of this rank's batch for the CPU leg (not timed)
+    # prefix of this rank's batch for the CPU leg (not timed): 4096 distinct pairs
     nchk = min(count, 4096)
     a_h = a[: nchk * EB].cpu().numpy().tobytes()
     b_h = b[: nchk * EB].cpu().numpy().tobytes()
     o_h = out[: nchk * EB].cpu().numpy().tobytes()
+    distinct = len({a_h[i * EB:(i + 1) * EB] + b_h[i * EB:(i + 1) * EB] for i in range(nchk)})
 
-    extra = None
-    if not args.no_extra and world == 1 and args.key == "k1024":
-        extra = secondary_metrics(pk, fx, dev, [min(k, 20) for k in args.decrypt_log2])
-        if rank == 0:
-            extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
+    extra = dec = None
+    if not args.no_extra and world == 1 and args.key == "k1024" and args.batch_log2 == 20:
+        extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2])
+        extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -318,37 +422,126 @@ def main():
         k_ms = sum(kernel_ms) / len(kernel_ms)
         alg_bytes = 3 * EB                               # two G1 operands in, one GT element out
         achieved = alg_bytes * count / (k_ms * 1e-3) / 1e9
-        mads = bgn_amd.synthetic.algorithmic_mads_per_pairing(
-            fx, run=max(1, min(16, count // 65536)), window={"0": 2, "3": 3, "4": 4}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 5))
+        mads = syn.algorithmic_mads_per_pairing(
+            fx, run=max(1, min(16, -(-count // 65536))),
+            window={"0": 2, "3": 3, "4": 4}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 5))
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01e_pmc_summary.json")
-        if os.path.exists(pmc) and args.batch_log2 == 20 and args.key == "k1024":
-            with open(pmc) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"]     # separate rocprofv3 --pmc passes of this command
-            traffic_src = "profiles/r01e_pmc_summary.json (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)"
+        for name in ("r02_pmc_summary.json", "r01e_pmc_summary.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc) and args.batch_log2 == 20 and args.key == "k1024":
+                with open(pmc) as f:
+                    traffic = json.load(f)["hbm_bytes_per_launch"]     # separate rocprofv3 --pmc passes of this command
+                traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)" % name
+                break
+        mad_rate = mads * count / (k_ms * 1e-3)
         line = {
             "metric": "EMult pairings/sec at 1024-bit, batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (28-bit limbs, 64-bit accumulators)", "data": "synthetic",
             "config": {"workload": "configs[2]: 1024-bit params, batch=2^%d EMult (Tate pairing G1xG1->GT, "
-                                   "Miller+final-exp) per MI355X" % args.batch_log2,
+                                   "Miller+final-exp) per MI355X; operands = Config 2's Encrypt outputs (random 40-bit "
+                                   "m, full-length r) x a fixed permutation of them" % args.batch_log2,
                        "key": fx["name"], "fp_bits": int(fx["p"], 16).bit_length(), "limbs28": 38,
-                       "batch_per_gpu": per_gpu, "global_batch": total,
-                       "parallelism": "batch-sharded x%d + RCCL all-gather of results" % world if world > 1 else "single GPU",
-                       },
+                       "batch_per_gpu": per_gpu, "global_batch": total, "rccl_ranks": rccl_ranks,
+                       "distinct_pairs_in_checked_prefix": distinct,
+                       "parallelism": ("batch-sharded x%d, one process per GPU + RCCL all-gather of results" % world)
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_pairing": alg_bytes},
-            "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads,
-                              "achieved": mads * count / (k_ms * 1e-3), "peak": VALU_MAD_PEAK,
-                              "unit": "lane-MAD/s", "frac": mads * count / (k_ms * 1e-3) / VALU_MAD_PEAK},
+            "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads, "achieved": mad_rate,
+                              "unit": "lane-MAD/s",
+                              "peak": VALU_MAD_PEAK_4W, "frac": mad_rate / VALU_MAD_PEAK_4W,
+                              "peak_at_1_wave_per_simd": VALU_MAD_PEAK_1W,
+                              "frac_at_1_wave_per_simd": mad_rate / VALU_MAD_PEAK_1W},
         }
+        if dec:
+            # BASELINE's metric names "EMult pairings/sec + BSGS decrypts/sec": the second headline
+            top = dec.get(20) or dec[max(dec)]
+            line["decrypt"] = {"metric": "BSGS decrypts/sec at 1024-bit, T=2^40, batch=2^%d" % (20 if 20 in dec else max(dec)),
+                               **top}
+            for k, e in dec.items():
+                extra["decrypt" if k == 16 else "decrypt_2^%d" % k] = e
         if extra:
             line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
+    """BASELINE configs[4]: 2^14 MultPoly instances of 16x16 level-1 coefficient polynomials (2^22 coefficient
+    pairs: d1*d2 pairings and the GT accumulation into 31 coefficients each, poly.go:123-156) followed by one
+    AddPoly of the products with each other (poly.go:171-207: 32 GT products per pair of polynomials), sharded by
+    polynomial: rank g owns polynomials [g*N/G, (g+1)*N/G), results all-gathered (RCCL).  Strong scaling: the
+    job is 2^14 polynomials whatever N."""
+    import torch
+    import torch.distributed as dist
+    import bgn_amd.synthetic as syn
+    from bgn_amd.sharding import gather_shards, shard_range
+    eng = pk.engine
+    EB = eng.elem_bytes
+    d1 = d2 = 16
+    npoly = 1 << args.polys_log2
+    lo, hi = shard_range(npoly, world, rank)
+    mine = hi - lo
+    # coefficients: Encrypt of base-3 digits in {-1, 0, 1} (plaintext.go:209-266), on the GPU, not timed
+    _, _, ca = syn.config2_ciphertexts(pk, mine * d1, seed=2000 + rank, device=dev, digits=True)
+    _, _, cb = syn.config2_ciphertexts(pk, mine * d2, seed=3000 + rank, device=dev, digits=True)
+    prod = torch.empty(mine * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+    summ = torch.empty(((mine + 1) // 2) * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        eng.poly_mult_dev(mine, d1, d2, ca, cb, prod)
+        half = mine // 2                                  # AddPoly: product q + product q + half, coefficient-wise
+        if half:
+            n = half * (d1 + d2)
+            eng.add_dev(2, prod[: n * EB], prod[n * EB: 2 * n * EB], summ, n)
+        if use_dist:
+            gathered = gather_shards(prod, npoly, (d1 + d2) * EB, world, rank, dist)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        assert bool((gathered[lo * (d1 + d2) * EB: hi * (d1 + d2) * EB] == prod).all().item()), "gather mismatch"
+    if rank == 0:
+        pairs = npoly * d1 * d2
+        value = pairs * args.steps / dt
+        ppp = syn.multpoly_products_per_pair(fx, d1)
+        line = {"metric": "MultPoly coefficient pairs/sec at 1024-bit (configs[4])", "value": value,
+                "unit": "coefficient pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "u32 (28-bit limbs, 64-bit accumulators)", "data": "synthetic",
+                "config": {"workload": "configs[4]: 1024-bit poly.go MultPoly of 2^%d pairs of 16x16 coefficient "
+                                       "polynomials (2^%d coefficient pairs) + one AddPoly, sharded by polynomial over "
+                                       "%d GPU(s) + RCCL all-gather" % (args.polys_log2, args.polys_log2 + 8, world),
+                           "key": fx["name"], "polys": npoly, "polys_per_gpu": mine, "d1": d1, "d2": d2,
+                           "rccl_ranks": rccl_ranks},
+                "roofline": {"bound": "hbm", "achieved": value * 3 * EB / 1e9 / world, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": value * 3 * EB / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                             "algorithmic_bytes_per_pair": 3 * EB, "note": "per GPU, over the whole step (several kernels)"},
+                "roofline_valu": {"products_per_pair": ppp, "frac_of_product_ceiling": value / world * ppp / PRODUCT_CEILING[38]}}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

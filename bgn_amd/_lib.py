@@ -58,8 +58,29 @@ PROTOTYPES = {
     "bgn_poly_eval_batch_dev": (C.c_int, [_ctx, _sz, _sz, C.c_int, _u8p, C.c_uint64, _u8p, C.c_void_p]),
     "bgn_check_decryption_proof_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, _sz, _u8p, _sz, _u8p, C.c_void_p]),
     "bgn_check_plaintext_knowledge_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, _sz, _u8p, _sz, _u8p, C.c_void_p]),
+    "bgn_shard_range": (None, [_sz, C.c_int, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "bgn_mctx_create": (C.c_int, [C.POINTER(_ctx), _u8p, _sz, _u8p, _sz, C.c_uint64, _u8p, _u8p, C.c_int,
+                                  C.POINTER(C.c_int), C.c_int]),
+    "bgn_mctx_destroy": (None, [_ctx]),
+    "bgn_mctx_device_count": (C.c_int, [_ctx]),
+    "bgn_mctx_ctx": (_ctx, [_ctx, C.c_int]),
+    "bgn_mctx_set_secret": (C.c_int, [_ctx, _u8p, _sz]),
+    "bgn_mctx_setup_decryption": (C.c_int, [_ctx, C.c_uint64]),
+    "bgn_mencrypt_batch": (C.c_int, [_ctx, _sz, _u8p, _sz, _u8p, _sz, _u8p]),
+    "bgn_madd_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bgn_msub_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bgn_mmult_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, _sz, _u8p]),
+    "bgn_mmake_l2_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p]),
+    "bgn_mmultconst_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _sz, _u8p, _sz, _u8p]),
+    "bgn_mdecrypt_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p]),
+    "bgn_mpoly_mult_batch": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p]),
+    "bgn_mmult_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, C.c_int]),
+    "bgn_mdecrypt_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, C.c_int]),
+    "bgn_mpoly_mult_batch_dev": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p, C.c_int]),
     "bgn_last_kernel_ms": (C.c_double, [_ctx]),
     "bgn_last_kernel_name": (C.c_char_p, [_ctx]),
+    "bgn_last_aux_kernel_ms": (C.c_double, [_ctx]),
+    "bgn_last_aux_kernel_name": (C.c_char_p, [_ctx]),
     "bgn_ctx_bsgs_baby_steps": (C.c_uint64, [_ctx]),
 }
 

@@ -255,6 +255,140 @@ class Engine:
     def last_kernel_name(self) -> str:
         return self._lib.bgn_last_kernel_name(self._h).decode()
 
+    def last_aux_kernel_ms(self) -> float:
+        return float(self._lib.bgn_last_aux_kernel_ms(self._h))
+
+    def last_aux_kernel_name(self) -> str:
+        return self._lib.bgn_last_aux_kernel_name(self._h).decode()
+
+
+class MultiEngine:
+    """One bgn_mctx: a public key replicated on several GPUs of the node, driven from this process
+    (include/bgn_amd.h, "several GPUs of one node").  Batches split into contiguous shards (MultPoly by
+    polynomial, poly.go:139-153) and every shard runs on its own device; results land in one array."""
+
+    def __init__(self, p: int, n: int, l: int, P_wire: bytes, Q_wire: bytes, deterministic: bool = True,
+                 devices: Sequence[int] = (0,)):
+        self._lib = _lib.load()
+        self.p, self.n, self.l = int(p), int(n), int(l)
+        pb = _int_bytes(self.p, (self.p.bit_length() + 7) // 8)
+        nb = _int_bytes(self.n, (self.n.bit_length() + 7) // 8)
+        self.devices = [int(d) for d in devices]
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        self._keep = (pb, nb, bytes(P_wire), bytes(Q_wire))
+        check(self._lib.bgn_mctx_create(C.byref(self._h), pb, len(pb), nb, len(nb), self.l, self._keep[2],
+                                        self._keep[3], 1 if deterministic else 0, devs, len(self.devices)),
+              "bgn_mctx_create")
+        self.L = int(self._lib.bgn_fp_bytes(self._lib.bgn_mctx_ctx(self._h, 0)))
+        self.elem_bytes = 2 * self.L
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.bgn_mctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_ranges(self, total: int):
+        out = []
+        for r in range(len(self.devices)):
+            lo, hi = C.c_size_t(), C.c_size_t()
+            self._lib.bgn_shard_range(total, len(self.devices), r, C.byref(lo), C.byref(hi))
+            out.append((lo.value, hi.value))
+        return out
+
+    def set_secret(self, q1: int) -> None:
+        b = _int_bytes(q1, (int(q1).bit_length() + 7) // 8)
+        check(self._lib.bgn_mctx_set_secret(self._h, b, len(b)), "bgn_mctx_set_secret")
+
+    def setup_decryption(self, msg_space: int) -> None:
+        check(self._lib.bgn_mctx_setup_decryption(self._h, int(msg_space)), "bgn_mctx_setup_decryption")
+
+    def _out(self, count: int) -> np.ndarray:
+        return np.zeros((count, self.elem_bytes), dtype=np.uint8)
+
+    def encrypt(self, x: Sequence[int], r: Optional[Sequence[int]] = None) -> np.ndarray:
+        xs = _scalars(x)
+        rs = _scalars(r) if r is not None else None
+        out = self._out(len(xs))
+        check(self._lib.bgn_mencrypt_batch(self._h, len(xs), _ptr(xs), xs.shape[1], _ptr(rs),
+                                           rs.shape[1] if rs is not None else 0, _ptr(out)), "bgn_mencrypt_batch")
+        return out
+
+    def _binop(self, fn, name, level, a, b):
+        A, B = _as_u8(a, self.elem_bytes), _as_u8(b, self.elem_bytes)
+        if len(A) != len(B):
+            raise ValueError("operand counts differ")
+        out = self._out(len(A))
+        check(fn(self._h, len(A), level, _ptr(A), _ptr(B), None, 0, _ptr(out)), name)
+        return out
+
+    def add(self, level: int, a: BytesLike, b: BytesLike) -> np.ndarray:
+        return self._binop(self._lib.bgn_madd_batch, "bgn_madd_batch", level, a, b)
+
+    def sub(self, level: int, a: BytesLike, b: BytesLike) -> np.ndarray:
+        return self._binop(self._lib.bgn_msub_batch, "bgn_msub_batch", level, a, b)
+
+    def mult(self, a: BytesLike, b: BytesLike) -> np.ndarray:
+        A, B = _as_u8(a, self.elem_bytes), _as_u8(b, self.elem_bytes)
+        if len(A) != len(B):
+            raise ValueError("operand counts differ")
+        out = self._out(len(A))
+        check(self._lib.bgn_mmult_batch(self._h, len(A), _ptr(A), _ptr(B), None, 0, _ptr(out)), "bgn_mmult_batch")
+        return out
+
+    def make_l2(self, a: BytesLike) -> np.ndarray:
+        A = _as_u8(a, self.elem_bytes)
+        out = self._out(len(A))
+        check(self._lib.bgn_mmake_l2_batch(self._h, len(A), _ptr(A), _ptr(out)), "bgn_mmake_l2_batch")
+        return out
+
+    def multconst(self, level: int, a: BytesLike, k: Sequence[int]) -> np.ndarray:
+        A = _as_u8(a, self.elem_bytes)
+        ks = _scalars(k)
+        if len(ks) != len(A):
+            raise ValueError("operand counts differ")
+        out = self._out(len(A))
+        check(self._lib.bgn_mmultconst_batch(self._h, len(A), level, _ptr(A), _ptr(ks), ks.shape[1], None, 0,
+                                             _ptr(out)), "bgn_mmultconst_batch")
+        return out
+
+    def decrypt(self, level: int, ct: BytesLike):
+        A = _as_u8(ct, self.elem_bytes)
+        m = np.zeros(len(A), dtype=np.int64)
+        st = np.zeros(len(A), dtype=np.uint8)
+        check(self._lib.bgn_mdecrypt_batch(self._h, len(A), level, _ptr(A), _ptr(m), _ptr(st)), "bgn_mdecrypt_batch")
+        return m, st
+
+    def poly_mult(self, npoly: int, d1: int, d2: int, a: BytesLike, b: BytesLike) -> np.ndarray:
+        A, B = _as_u8(a, self.elem_bytes), _as_u8(b, self.elem_bytes)
+        if len(A) != npoly * d1 or len(B) != npoly * d2:
+            raise ValueError("coefficient array sizes do not match npoly*d1 / npoly*d2")
+        out = self._out(npoly * (d1 + d2))
+        check(self._lib.bgn_mpoly_mult_batch(self._h, npoly, d1, d2, _ptr(A), _ptr(B), _ptr(out)),
+              "bgn_mpoly_mult_batch")
+        return out
+
+    # device arrays (torch uint8 CUDA tensors) resident on device `root`; returns after the gather
+    def mult_dev(self, a, b, out, root: int, count: Optional[int] = None) -> None:
+        count = a.numel() // self.elem_bytes if count is None else count
+        check(self._lib.bgn_mmult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(), out.data_ptr(), root),
+              "bgn_mmult_batch_dev")
+
+    def decrypt_dev(self, level: int, ct, m, status, root: int, count: Optional[int] = None) -> None:
+        count = ct.numel() // self.elem_bytes if count is None else count
+        check(self._lib.bgn_mdecrypt_batch_dev(self._h, count, level, ct.data_ptr(), m.data_ptr(), status.data_ptr(),
+                                               root), "bgn_mdecrypt_batch_dev")
+
+    def poly_mult_dev(self, npoly: int, d1: int, d2: int, a, b, out, root: int) -> None:
+        check(self._lib.bgn_mpoly_mult_batch_dev(self._h, npoly, d1, d2, a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                                 root), "bgn_mpoly_mult_batch_dev")
+
 
 # ---------------------------------------------------------------------------
 # Reference-shaped objects

@@ -111,6 +111,15 @@ struct bgn_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   const char* last_kernel = "";
+  // the workspace is shared by every call on this context: a call issued on another stream than the previous
+  // one first waits (on the device) for that call's last kernel (StreamOrder below)
+  hipEvent_t ev_busy = nullptr;
+  hipStream_t busy_stream = nullptr;
+  bool busy_valid = false;
+  // second pair: the kernel in front of the walk in Decrypt (the lift e(C, .) on level 1, the power on level 2)
+  hipEvent_t ev2 = nullptr, ev3 = nullptr;
+  bool ev2_valid = false;
+  const char* aux_kernel = "";
 
   SoA2 key_P() const { return SoA2{d_keypts, d_keypts + nl, nullptr, 1}; }
   SoA2 key_Q() const { return SoA2{d_keypts + 2 * nl, d_keypts + 3 * nl, nullptr, 1}; }
@@ -158,6 +167,23 @@ int ensure_arena(bgn_ctx* c, size_t bytes) {
   c->arena_bytes = want;
   return BGN_OK;
 }
+
+// Orders the calls of one context across streams.  Every `_dev` call uses the context's workspace; issued on
+// the stream of the previous call it is ordered by the stream, issued on another one it is made to wait for the
+// previous call's work on the device (no host synchronisation).  Constructed under c->mu.
+struct StreamOrder {
+  bgn_ctx* c;
+  hipStream_t s;
+  StreamOrder(bgn_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+    if (c->busy_valid && c->busy_stream != s) (void)hipStreamWaitEvent(s, c->ev_busy, 0);
+  }
+  ~StreamOrder() {
+    if (c->ev_busy && hipEventRecord(c->ev_busy, s) == hipSuccess) {
+      c->busy_stream = s;
+      c->busy_valid = true;
+    }
+  }
+};
 
 // Carves SoA2 views out of the arena.
 struct Carver {
@@ -224,6 +250,8 @@ std::vector<uint32_t> build_params(const BigU& p, int nl) {
 extern "C" {
 
 const char* bgn_last_error(void) { return g_err.c_str(); }
+// multi.cpp reports a shard's failure (raised on that shard's thread) to the calling thread through this
+void bgn_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
 const char* bgn_version(void) { return "bgn_amd 0.1 (gfx950)"; }
 
 size_t bgn_fp_bytes(const bgn_ctx* ctx) { return ctx ? (size_t)ctx->L : 0; }
@@ -240,7 +268,11 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_consts) (void)hipFree(c->d_consts);
   if (c->d_keypts) (void)hipFree(c->d_keypts);
   if (c->d_keywire) (void)hipFree(c->d_keywire);
-  if (c->d_sk) (void)hipFree(c->d_sk);
+  if (c->d_sk) {
+    (void)hipMemset(c->d_sk, 0, c->sk_len);
+    (void)hipFree(c->d_sk);
+  }
+  c->q1.wipe();
   if (c->d_gt) (void)hipFree(c->d_gt);
   if (c->d_table) (void)hipFree(c->d_table);
   if (c->d_fixedpair) (void)hipFree(c->d_fixedpair);
@@ -251,6 +283,9 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->d_tabG) (void)hipFree(c->d_tabG);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_busy) (void)hipEventDestroy(c->ev_busy);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev3) (void)hipEventDestroy(c->ev3);
   delete c;
 }
 
@@ -364,6 +399,9 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     HIP_BRK(hipDeviceSynchronize());
     HIP_BRK(hipEventCreate(&c->ev0));
     HIP_BRK(hipEventCreate(&c->ev1));
+    HIP_BRK(hipEventCreateWithFlags(&c->ev_busy, hipEventDisableTiming));
+    HIP_BRK(hipEventCreate(&c->ev2));
+    HIP_BRK(hipEventCreate(&c->ev3));
 #undef HIP_BRK
   } while (0);
   if (rc != BGN_OK) {
@@ -434,11 +472,17 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   if (!c || !q1_be || !q1_len) return fail(BGN_E_ARG, "null argument");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  c->q1.wipe();
   c->q1 = BigU::from_be(q1_be, q1_len);
   if (c->q1.is_zero()) return fail(BGN_E_ARG, "secret key is zero");
   HIP_TRY(hipDeviceSynchronize());
-  if (c->d_sk) (void)hipFree(c->d_sk);
+  if (c->d_sk) {
+    (void)hipMemset(c->d_sk, 0, c->sk_len);
+    (void)hipFree(c->d_sk);
+  }
   c->d_sk = nullptr;
+  c->have_secret = false;
+  c->have_tables = false;
   HIP_TRY(hipMalloc((void**)&c->d_sk, q1_len));
   HIP_TRY(hipMemcpy(c->d_sk, q1_be, q1_len, hipMemcpyHostToDevice));
   c->sk_len = q1_len;
@@ -456,10 +500,13 @@ void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t k
 
 int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if (!c) return fail(BGN_E_ARG, "null context");
-  if (!c->have_secret) return fail(BGN_E_STATE, "secret key not set");
   if (msg_space < 1 || msg_space > ((uint64_t)1 << 60)) return fail(BGN_E_ARG, "message space out of range");
   std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_secret) return fail(BGN_E_STATE, "secret key not set");
   HIP_TRY(hipSetDevice(c->device));
+  // the old table is gone from here on: a failure below must not leave have_tables pointing at freed memory
+  c->have_tables = false;
+  c->bsgs = BsgsParams{};
   release_poly_tables(c);
   const KernelTable* kt = c->kt;
   // gsbs.go:60: bound = ceil(sqrt(T)); getDL returns i*bound + v + 1 <= bound*bound + bound + 2
@@ -487,7 +534,10 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   const uint64_t G = (Mmax + S) / (2 * S) + 1;
   const uint64_t slots = (2 * S < 64) ? 64 : 2 * S;
 
-  if (c->d_table) (void)hipFree(c->d_table);
+  if (c->d_table) {
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(c->d_table);
+  }
   c->d_table = nullptr;
   if (!c->d_gt) HIP_TRY(hipMalloc((void**)&c->d_gt, (size_t)4 * c->nl * 4));
   HIP_TRY(hipMalloc((void**)&c->d_table, slots * sizeof(BsgsSlot)));
@@ -587,6 +637,7 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
 static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                          size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len) {
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   if (r_be) {
     int rc = ensure_gt_table(c);
@@ -750,15 +801,22 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
   if (!(ev && ev[0] == '0') && B.stride != 1 && klen >= 16 && count * per <= ((size_t)24 << 30)) {
     const size_t cap = round_up(count, 64), need = cap * per + 4096;
     bool ok = true;
-    if (need > c->mul_ws_bytes) {
-      if (c->mul_ws) {
-        (void)hipDeviceSynchronize();
-        (void)hipFree(c->mul_ws);
-        c->mul_ws = nullptr;
-        c->mul_ws_bytes = 0;
+    if (need > c->mul_ws_bytes || getenv("BGN_TEST_FAIL_MUL_WS")) {
+      // allocate the larger table first and free the old one only then; a failed hipMalloc leaves its error as
+      // the thread's last error, which the callers' hipGetLastError() after the launches would report although
+      // the binary-ladder fallback ran: clear it.  BGN_TEST_FAIL_MUL_WS forces the failure (tests).
+      uint8_t* fresh = nullptr;
+      ok = !getenv("BGN_TEST_FAIL_MUL_WS") && hipMalloc((void**)&fresh, need) == hipSuccess;
+      if (ok) {
+        if (c->mul_ws) {
+          (void)hipDeviceSynchronize();
+          (void)hipFree(c->mul_ws);
+        }
+        c->mul_ws = fresh;
+        c->mul_ws_bytes = need;
+      } else {
+        (void)hipGetLastError();
       }
-      ok = hipMalloc((void**)&c->mul_ws, need) == hipSuccess;
-      if (ok) c->mul_ws_bytes = need;
     }
     if (ok) {
       a.wtab = (uint32_t*)c->mul_ws;
@@ -1116,6 +1174,7 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   if (!count) return BGN_OK;
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   if (r_be) {                          // blinding base tables (G1 ones use the arena: before any carving)
     int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
@@ -1185,6 +1244,7 @@ int bgn_neg_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, uin
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   const size_t st = round_up(count, 64);
   SoA2 A;
@@ -1215,6 +1275,7 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   if (r_be) {
     int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
@@ -1260,6 +1321,7 @@ int bgn_encrypt_batch_dev(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t 
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   const size_t st = round_up(count, 64);
   SoA2 G, H, O;
@@ -1436,6 +1498,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   const size_t st = round_up(count, 64);
   SoA2 A, X, Y;
@@ -1462,8 +1525,12 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp).  With the secret-order table the
     // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
     const bool sk_tab = c->d_fixedpair_sk != nullptr;
+    HIP_TRY(hipEventRecord(c->ev2, s));
     kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
                 pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
+    HIP_TRY(hipEventRecord(c->ev3, s));
+    c->ev2_valid = true;
+    c->aux_kernel = c->nl == 38 ? "k_pairing<38, 1>" : c->nl == 19 ? "k_pairing<19, 1>" : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
@@ -1628,6 +1695,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
     return fail(BGN_E_ARG, "batch too large (max 2^28 coefficient pairs per call)");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   int levels = 0;
   {
@@ -1726,6 +1794,7 @@ int poly_lin_common(bgn_ctx* c, size_t npoly, size_t d, size_t dp, int level, co
   const size_t nin = npoly * d, nout = npoly * (dp ? d + dp : 1);
   if (nin > kMaxBatch || nout > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   std::lock_guard<std::mutex> lk(c->mu);
+  StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   const size_t si = round_up(nin, 64), so = round_up(nout, 64);
   SoA2 A, O;
@@ -1950,6 +2019,15 @@ int bgn_check_plaintext_knowledge_batch(bgn_ctx* c, size_t count, const uint8_t*
   if (rc) return rc;
   return S.down(ok, dok, count);
 }
+
+double bgn_last_aux_kernel_ms(bgn_ctx* c) {
+  if (!c || !c->ev2_valid) return -1.0;
+  if (hipEventSynchronize(c->ev3) != hipSuccess) return -1.0;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev2, c->ev3) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+const char* bgn_last_aux_kernel_name(bgn_ctx* c) { return c ? c->aux_kernel : ""; }
 
 double bgn_last_kernel_ms(bgn_ctx* c) {
   if (!c || !c->ev_valid) return -1.0;

@@ -33,6 +33,12 @@ struct BigU {
     while (!w.empty() && w.back() == 0) w.pop_back();
   }
   bool is_zero() const { return w.empty(); }
+  // overwrite the words before releasing them (secret keys)
+  void wipe() {
+    volatile uint32_t* v = w.data();
+    for (size_t i = 0; i < w.size(); ++i) v[i] = 0;
+    w.clear();
+  }
   int bits() const {
     if (w.empty()) return 0;
     uint32_t t = w.back();

@@ -4,23 +4,89 @@ from __future__ import annotations
 import numpy as np
 
 
-def l1_ciphertext_pairs(pk, fx, count: int, seed: int, device):
-    """Two arrays of `count` level-1 ciphertexts (wire bytes, uint8 CUDA tensors).
+def _r_shape(n: int):
+    """Byte length of the blinding exponents and the mask of their top byte: r uniform below 2^(bits(n) - 2) < n
+    (keygen sets the top two bits of both prime factors, bgn.go:153,160)."""
+    nbits = n.bit_length()
+    r_len = (nbits + 7) // 8
+    top_bits = max(1, (nbits - 2) - 8 * (r_len - 1))
+    return r_len, (1 << min(top_bits, 8)) - 1
 
-    Until the engine's Encrypt kernel is used here, operands are drawn
-    (seeded, with replacement) from the key fixture's pool of valid
-    ciphertexts.  The pairing kernel's control flow and instruction stream do
-    not depend on operand values, so throughput is unaffected by the draw."""
+
+def config2_ciphertexts(pk, count: int, seed: int, device, digits: bool = False):
+    """SURVEY.md 8(d) Config 2 on the GPU: `count` level-1 ciphertexts P^m * Q^r of seeded random messages
+    (40-bit m; with digits=True base-3 digits in {-1, 0, 1} as EncryptPoly makes them, poly.go:11-29: a negative
+    digit is Sub(zero, Enc(|c|))) and full-length random r.  Returns (xs, rs, cts): the big-endian scalar arrays
+    and the wire bytes, all uint8 CUDA tensors."""
     import torch
-    pool = [bytes.fromhex(e["ct"]) for e in fx["encrypt"] if int(e["ct"], 16) != 0]
-    pool_t = torch.from_numpy(np.frombuffer(b"".join(pool), dtype=np.uint8).reshape(len(pool), -1).copy()).to(device)
+    eng = pk.engine
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
-    ia = torch.randint(0, len(pool), (count,), generator=g).to(device)
-    ib = torch.randint(0, len(pool), (count,), generator=g).to(device)
-    a = pool_t[ia].reshape(-1).contiguous()
-    b = pool_t[ib].reshape(-1).contiguous()
-    return a, b
+    r_len, top_mask = _r_shape(pk.N)
+    if digits:
+        d = torch.randint(-1, 2, (count,), generator=g)
+        xs = d.abs().to(torch.uint8).reshape(count, 1)
+    else:
+        xs = torch.randint(0, 256, (count, 5), dtype=torch.uint8, generator=g)          # 40-bit plaintexts
+    rs = torch.randint(0, 256, (count, r_len), dtype=torch.uint8, generator=g)
+    rs[:, 0] &= top_mask
+    xs, rs = xs.to(device), rs.to(device)
+    cts = torch.empty(count * eng.elem_bytes, dtype=torch.uint8, device=device)
+    eng.encrypt_dev(xs, xs.shape[1], rs, r_len, cts, count)
+    if digits:
+        neg = torch.empty_like(cts)
+        eng._lib.bgn_neg_batch_dev(eng._h, count, 1, cts.data_ptr(), neg.data_ptr(), eng._stream())
+        sel = (d < 0).to(device)
+        v = cts.view(count, eng.elem_bytes)
+        v[sel] = neg.view(count, eng.elem_bytes)[sel]
+    torch.cuda.synchronize()
+    return xs, rs, cts
+
+
+def permuted_copy(cts, elem_bytes: int, seed: int):
+    """Config 3's second operand: a fixed (seeded) permutation of the first."""
+    import torch
+    count = cts.numel() // elem_bytes
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    perm = torch.randperm(count, generator=g).to(cts.device)
+    return cts.view(count, elem_bytes)[perm].reshape(-1).contiguous()
+
+
+def decrypt_mix(pk, fx, cts, xs, device, neg_every: int = 16, oor_every: int = 4096):
+    """SURVEY.md 8(d) Config 4's inputs from Config 2's ciphertexts: every 16th negated (the retry of
+    bgn.go:235-242 finds it), every 4096th replaced by the encryption of a message beyond B*B + B + 2
+    (gsbs.go:105: no discrete log in either direction).  Returns (wire bytes, expected m, expected status)."""
+    import numpy as np
+    import torch
+    eng = pk.engine
+    EB = eng.elem_bytes
+    n = xs.shape[0]
+    neg = torch.empty_like(cts)
+    eng._lib.bgn_neg_batch_dev(eng._h, n, 1, cts.data_ptr(), neg.data_ptr(), eng._stream())
+    mixed = cts.view(n, EB).clone()
+    mixed[::neg_every] = neg.view(n, EB)[::neg_every]
+    del neg
+    want = torch.zeros(n, dtype=torch.int64)
+    xb = xs.cpu().numpy().astype(np.int64)
+    for j in range(xb.shape[1]):
+        want = want * 256 + torch.from_numpy(xb[:, j])
+    want[::neg_every] = -want[::neg_every]
+    status = torch.zeros(n, dtype=torch.uint8)
+    idx = torch.arange(7, n, oor_every)
+    if len(idx):
+        T = int(fx["msg_space"])
+        big = [2 * T + 12345 + 3 * int(i) for i in idx]                      # > B*B + B + 2 for every T >= 4
+        xl = (max(big).bit_length() + 7) // 8
+        xo = torch.from_numpy(np.frombuffer(b"".join(v.to_bytes(xl, "big") for v in big), dtype=np.uint8).copy())
+        xo = xo.reshape(len(big), xl).to(device)
+        co = torch.empty(len(big) * EB, dtype=torch.uint8, device=device)
+        eng.encrypt_dev(xo, xl, None, 0, co, len(big))
+        mixed[idx.to(device)] = co.view(len(big), EB)
+        want[idx] = 0
+        status[idx] = 1
+    torch.cuda.synchronize()
+    return mixed.reshape(-1).contiguous(), want, status
 
 
 def _signed_digits(n: int, w: int):
@@ -87,3 +153,63 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: i
     squares = dbl * 6 + add * 3 + ((6 + 3 * ((1 << (window - 2)) - 1) + 3) if window >= 3 else 0) + 6
     products = per_pairing + INVERSION_PRODUCTS / run
     return int((products - squares) * 2 * nl * nl + squares * square_mads(nl, segments))
+
+
+# ---- field products per unit of the other operations, for the product-ceiling fractions ----
+def _run_for(count: int) -> int:
+    """Elements per lane of the batched-inversion kernels (engine.cpp run_for)."""
+    return max(1, min(64, -(-count // 65536)))
+
+
+def eadd_products(count: int) -> float:
+    """Affine addition with Montgomery's trick over a lane's run: 7 products + one inversion per run."""
+    return 7 + INVERSION_PRODUCTS / _run_for(count)
+
+
+def encrypt_products(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20) -> float:
+    """Fixed-base product P^m * Q^r: one affine addition per window (four accumulation chains, runs of 64) and
+    three more to sum the chains."""
+    windows = -(-x_bits // wbits_p) + -(-r_bits // wbits_q)
+    return (windows + 3) * (7 + INVERSION_PRODUCTS / 64)
+
+
+def _naf_counts(n: int):
+    d = _signed_digits(n, 2)
+    return len(d) - 1, sum(1 for i, x in enumerate(d[:-1]) if x and i != 0)
+
+
+def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
+    """Decrypt (bgn.go:218-250): level 1 lifts with the Miller loop over the normalised line table of q1*P along
+    the NAF of q2 = n/q1 (6 / 4 products per doubling / addition step) and the final exponentiation; both levels
+    raise to q1 on the norm-1 ladder (2 per bit, one inversion for the imaginary part) and walk G giant steps at
+    1.1 products each (bsgs.hpp)."""
+    import math
+    n, q1, l, T = int(fx["n"], 16), int(fx["q1"], 16), int(fx["l"]), int(fx["msg_space"])
+    B = math.isqrt(T - 1) + 1 if T > 1 else 1
+    mmax = B * B + B + 2
+    S = max(1, int(baby_steps))
+    G = (mmax + S) // (2 * S) + 1
+    prods = 2 * q1.bit_length() + INVERSION_PRODUCTS + 1.1 * G + 40
+    if level == 1:
+        dbl, add = _naf_counts(n // q1)
+        lb = l.bit_length()
+        prods += dbl * 6 + add * 4 + 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
+    return prods
+
+
+def multpoly_products_per_pair(fx, d: int) -> float:
+    """MultPoly of two d-coefficient polynomials (d a power of two >= 2) per coefficient pair: Karatsuba levels
+    down to 2x2 products, each 4 evaluations over a per-coefficient line table (7 / 5 per step + final
+    exponentiation) and 2 table builds (11.5 per step)."""
+    n, l = int(fx["n"], 16), int(fx["l"])
+    dbl, add = _naf_counts(n)
+    lb = l.bit_length()
+    fe = 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
+    ev = dbl * 7 + add * 5 + fe
+    build = (dbl + add) * 11.5
+    leaves = 1
+    k = d
+    while k > 2:
+        leaves *= 3
+        k //= 2
+    return leaves * (4 * ev + 2 * build) / (d * d)

@@ -29,8 +29,10 @@
  *     (cgo pointer rules).  A context is immutable after setup and may be used
  *     from many threads; concurrent calls on one context serialise on its
  *     internal workspace (the reference serialises on pk.mu, bgn.go:40).
- *   - `_dev` calls use the context's workspace: issue them for one context on
- *     one stream (or order them yourself); the workspace grows with hipMalloc
+ *   - `_dev` calls use the context's workspace.  Calls on one context are
+ *     ordered by the engine: a call issued on another stream than the previous
+ *     one waits on the device for that call's work before touching the
+ *     workspace (no host synchronisation).  The workspace grows with hipMalloc
  *     on first use of a larger batch, so warm a context up before capturing
  *     its calls into a hipGraph.  At most 2^28 elements per call.
  *   - There is no CPU fallback: without a HIP device every compute call fails
@@ -212,6 +214,56 @@ int bgn_check_plaintext_knowledge_batch_dev(bgn_ctx* ctx, size_t count, const ui
  * memory, kept by the context between calls and given back when another per-key table is built (BGN_POLY_TABLES=0
  * disables the tables); it synchronises the stream before returning (it owns scratch arrays). */
 
+/* ---- several GPUs of one node from one process ------------------------------------------------------------
+ * Every batch element of this path is independent; the reference's only parallel unit is one goroutine per
+ * coefficient pair of MultPoly with the accumulation local to the polynomial (poly.go:139-153).  A bgn_mctx
+ * holds one bgn_ctx per listed device (the key context and its tables are replicated, a device may be listed
+ * more than once), splits a batch into contiguous shards — unit = element, for MultPoly = polynomial — and runs
+ * each shard on its device from its own host thread and stream.  No collective on the data path: host-buffer
+ * calls copy every shard in and out of the caller's arrays directly; `_dev` calls take arrays resident on device
+ * `root`, move the other devices' slices by peer DMA (xGMI) and gather the results into `out` on `root` the
+ * same way; they return after the gather has completed.  The multi-process form (one rank per GPU, RCCL
+ * all-gather of the result arrays) uses the same bgn_shard_range split with one bgn_ctx per rank. */
+typedef struct bgn_mctx bgn_mctx;
+
+/* [lo, hi) of `total` units owned by `rank` of `world`: contiguous, sizes differ by at most one. */
+void bgn_shard_range(size_t total, int world, int rank, size_t* lo, size_t* hi);
+
+/* As bgn_ctx_create, on each of devices[0..ndev). */
+int bgn_mctx_create(bgn_mctx** out, const uint8_t* p_be, size_t p_len, const uint8_t* n_be, size_t n_len, uint64_t l,
+                    const uint8_t* P_wire, const uint8_t* Q_wire, int deterministic, const int* devices, int ndev);
+void bgn_mctx_destroy(bgn_mctx* m);
+int bgn_mctx_device_count(const bgn_mctx* m);
+/* The context of shard i (owned by m), for the single-device calls this section does not repeat. */
+bgn_ctx* bgn_mctx_ctx(bgn_mctx* m, int i);
+/* bgn_ctx_set_secret / bgn_ctx_setup_decryption on every device (in parallel). */
+int bgn_mctx_set_secret(bgn_mctx* m, const uint8_t* q1_be, size_t q1_len);
+int bgn_mctx_setup_decryption(bgn_mctx* m, uint64_t msg_space);
+
+/* Host buffers; arguments as the single-device calls (Encrypt bgn.go:325-353, Add :442-497, Sub :375-433,
+ * Mult :294-314, makeL2 :316-321, MultConst :253-291, Decrypt :205-250, MultPoly poly.go:123-156). */
+int bgn_mencrypt_batch(bgn_mctx* m, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be, size_t r_len,
+                       uint8_t* out);
+int bgn_madd_batch(bgn_mctx* m, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                   size_t r_len, uint8_t* out);
+int bgn_msub_batch(bgn_mctx* m, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
+                   size_t r_len, uint8_t* out);
+int bgn_mmult_batch(bgn_mctx* m, size_t count, const uint8_t* a, const uint8_t* b, const uint8_t* r_be, size_t r_len,
+                    uint8_t* out);
+int bgn_mmake_l2_batch(bgn_mctx* m, size_t count, const uint8_t* a, uint8_t* out);
+int bgn_mmultconst_batch(bgn_mctx* m, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t k_len,
+                         const uint8_t* r_be, size_t r_len, uint8_t* out);
+int bgn_mdecrypt_batch(bgn_mctx* m, size_t count, int level, const uint8_t* ct, int64_t* msg, uint8_t* status);
+int bgn_mpoly_mult_batch(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                         uint8_t* out);
+
+/* Device buffers resident on HIP device `root` (one of the context's devices or any peer-accessible one). */
+int bgn_mmult_batch_dev(bgn_mctx* m, size_t count, const uint8_t* a, const uint8_t* b, uint8_t* out, int root);
+int bgn_mdecrypt_batch_dev(bgn_mctx* m, size_t count, int level, const uint8_t* ct, int64_t* msg, uint8_t* status,
+                           int root);
+int bgn_mpoly_mult_batch_dev(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
+                             uint8_t* out, int root);
+
 /* ---- measurement hooks (used by bench.py; not part of the drop-in surface) --- */
 /* Milliseconds spent in the dominant kernel of the most recent *_dev call on
  * this context, measured with HIP events on the stream it ran on; blocks until
@@ -219,6 +271,10 @@ int bgn_check_plaintext_knowledge_batch_dev(bgn_ctx* ctx, size_t count, const ui
 double bgn_last_kernel_ms(bgn_ctx* ctx);
 /* Name of that kernel (for matching against rocprofv3 --kernel-trace output). */
 const char* bgn_last_kernel_name(bgn_ctx* ctx);
+/* The same for the kernel in front of the discrete-log walk of the most recent bgn_decrypt_batch_dev on level 1:
+ * the lift e(C, .) over the key's line table, Decrypt's dominant kernel. */
+double bgn_last_aux_kernel_ms(bgn_ctx* ctx);
+const char* bgn_last_aux_kernel_name(bgn_ctx* ctx);
 /* Number of baby steps of the discrete-log table built by bgn_ctx_setup_decryption (0 = none). */
 uint64_t bgn_ctx_bsgs_baby_steps(const bgn_ctx* ctx);
 

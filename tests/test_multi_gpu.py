@@ -1,0 +1,143 @@
+"""GPU: the multi-GPU path on the HIP engine.
+
+* bgn_mctx_* (one process, several devices): device lists that name cuda:0 more than once give real
+  multi-context sharding on a one-GPU box — ragged shards, MultPoly by polynomial, the device-resident form
+  with and without the peer-staging path — compared with the single-context engine and the oracle.
+* ShardedOps (one process per rank): the code tests/test_sharding_gloo.py runs on CPU, here with the HIP engine
+  at world = 1 in-process and at world = 2 with two gloo ranks sharing cuda:0.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, engine_key, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool(fx, n, step=1, off=0):
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    return b"".join(cts[(step * i + off) % len(cts)] for i in range(n))
+
+
+@pytest.fixture(scope="module")
+def multi():
+    import bgn_amd
+    fx = load_fixture("k256")
+    me = bgn_amd.MultiEngine(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                             True, devices=[0, 0, 0])
+    me.set_secret(int(fx["q1"], 16))
+    me.setup_decryption(fx["msg_space"])
+    yield fx, me
+    me.close()
+
+
+@pytest.mark.parametrize("count", [1, 2, 7, 64])
+def test_mctx_host_buffers_match_single_context(multi, count):
+    fx, me = multi
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng = pk.engine
+    assert me.shard_ranges(count)[-1][1] == count
+    a, b = _pool(fx, count), _pool(fx, count, 3, 1)
+    assert me.mult(a, b).tobytes() == eng.mult(a, b).tobytes()
+    assert me.add(1, a, b).tobytes() == eng.add(1, a, b).tobytes()
+    assert me.sub(1, a, b).tobytes() == eng.sub(1, a, b).tobytes()
+    assert me.make_l2(a).tobytes() == eng.make_l2(a).tobytes()
+    xs = [(17 * i + 3) % fx["msg_space"] for i in range(count)]
+    rs = [(1234567 * i + 99) % int(fx["n"], 16) for i in range(count)]
+    assert me.encrypt(xs, rs).tobytes() == eng.encrypt(xs, rs).tobytes()
+    ks = [5 + i for i in range(count)]
+    assert me.multconst(1, a, ks).tobytes() == eng.multconst(1, a, ks).tobytes()
+    m1, s1 = me.decrypt(1, a)
+    m0, s0 = eng.decrypt(1, a)
+    assert m1.tolist() == m0.tolist() and s1.tolist() == s0.tolist()
+
+
+@pytest.mark.parametrize("npoly,d1,d2", [(1, 2, 2), (5, 3, 2), (8, 4, 4)])
+def test_mctx_multpoly_shards_by_polynomial(multi, npoly, d1, d2):
+    fx, me = multi
+    import oracle_c
+    o = oracle_c.Oracle.from_fixture(fx)
+    a, b = _pool(fx, npoly * d1), _pool(fx, npoly * d2, 5, 2)
+    assert me.poly_mult(npoly, d1, d2, a, b).tobytes() == o.poly_mult(npoly, d1, d2, a, b)
+
+
+@pytest.mark.parametrize("staging", ["0", "1"])
+def test_mctx_device_resident_forms(multi, staging, monkeypatch):
+    """Arrays resident on cuda:0, gathered into one output array on cuda:0; BGN_MCTX_FORCE_STAGING=1 sends every
+    shard through the peer-copy path (scratch on the shard's device, hipMemcpyPeerAsync in and out)."""
+    import torch
+    monkeypatch.setenv("BGN_MCTX_FORCE_STAGING", staging)
+    fx, me = multi
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    count, E = 11, eng.elem_bytes
+    a, b = _pool(fx, count), _pool(fx, count, 3, 1)
+    ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).cuda()
+    tb = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    out = torch.zeros(count * E, dtype=torch.uint8, device="cuda")
+    me.mult_dev(ta, tb, out, root=0)
+    assert out.cpu().numpy().tobytes() == eng.mult(a, b).tobytes()
+    m = torch.zeros(count, dtype=torch.int64, device="cuda")
+    st = torch.ones(count, dtype=torch.uint8, device="cuda")
+    me.decrypt_dev(1, ta, m, st, root=0)
+    m0, s0 = eng.decrypt(1, a)
+    assert m.cpu().tolist() == m0.tolist() and st.cpu().tolist() == s0.tolist()
+    npoly, d = 5, 2
+    po = torch.zeros(npoly * 2 * d * E, dtype=torch.uint8, device="cuda")
+    me.poly_mult_dev(npoly, d, d, ta[: npoly * d * E], tb[: npoly * d * E], po, root=0)
+    assert po.cpu().numpy().tobytes() == eng.poly_mult(npoly, d, d, a[: npoly * d * E], b[: npoly * d * E]).tobytes()
+
+
+def test_sharded_ops_world1_on_the_engine():
+    """The sharder of the multi-process form (bgn_amd/sharding.py) driving the HIP engine at world = 1."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sharding_gloo import sharded_checks
+    fx = load_fixture("toy64")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    assert sharded_checks(lambda: pk.engine, fx, 7, 1, 0, None)
+
+
+def _gpu_rank(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bgn_amd
+    from test_sharding_gloo import sharded_checks
+    fx = load_fixture("toy64")
+
+    def make():
+        pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]),
+                               bytes.fromhex(fx["Q"]), fx["msg_space"], True, fx["poly_base"], device=0)
+        pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+        return pk.engine
+
+    ok = sharded_checks(make, fx, total, world, rank, dist)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_ops_two_ranks_share_one_gpu():
+    """Two ranks (gloo rendezvous; both on cuda:0, the box has one GPU) each run their shard on their own HIP
+    engine; the gathered arrays equal the oracle's on the whole batch."""
+    import torch.multiprocessing as mp
+    from test_sharding_gloo import _free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_rank, args=(r, 2, port, 9, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -1,10 +1,12 @@
-"""CPU: the N > 1 path (contiguous batch sharding + gather of results) with two gloo
-processes.  The per-shard compute is stood in for by the oracle (tests may use it);
-what is under test is bgn_amd/sharding.py: slice arithmetic, ragged tails, gather order."""
+"""CPU: the N > 1 path with two gloo processes.  What is under test is the sharder the product uses
+(bgn_amd/sharding.py: ShardedOps — slice arithmetic, ragged tails, MultPoly sharded by polynomial, gather
+order, the packed Decrypt gather); the per-shard compute is stood in for by the oracle behind the Engine's
+method signatures (tests may use it; tests/test_multi_gpu.py runs the same code on the HIP engine)."""
 import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -21,6 +23,62 @@ def _free_port():
     return p
 
 
+class OracleEngine:
+    """The C oracle behind the host-buffer method signatures of bgn_amd.Engine."""
+
+    def __init__(self, fx):
+        import oracle_c
+        self.o = oracle_c.Oracle.from_fixture(fx)
+        self.o.setup_decryption(int(fx["q1"], 16), fx["msg_space"])
+        self.elem_bytes = self.o.E
+
+    def _np(self, b):
+        return np.frombuffer(b, dtype=np.uint8).reshape(-1, self.elem_bytes)
+
+    def mult(self, a, b):
+        return self._np(self.o.mult(a.tobytes(), b.tobytes()))
+
+    def add(self, level, a, b):
+        return self._np(self.o.add(level, a.tobytes(), b.tobytes()))
+
+    def poly_mult(self, npoly, d1, d2, a, b):
+        return self._np(self.o.poly_mult(npoly, d1, d2, a.tobytes(), b.tobytes()))
+
+    def decrypt(self, level, ct):
+        m, st = self.o.decrypt(level, ct.tobytes())
+        return np.array(m, dtype=np.int64), np.array(st, dtype=np.uint8)
+
+
+def sharded_checks(make_engine, fx, total, world, rank, dist_mod):
+    """Runs Mult, Add, MultPoly (by polynomial) and Decrypt through ShardedOps on this rank and compares the
+    gathered arrays with the oracle's results on the whole batch.  Shared with the GPU tests."""
+    import oracle_c
+    from bgn_amd.sharding import ShardedOps
+    o = oracle_c.Oracle.from_fixture(fx)
+    o.setup_decryption(int(fx["q1"], 16), fx["msg_space"])
+    E = o.E
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    a = b"".join(cts[i % len(cts)] for i in range(total))
+    b = b"".join(cts[(3 * i + 1) % len(cts)] for i in range(total))
+    ta = torch.frombuffer(bytearray(a), dtype=torch.uint8)
+    tb = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+    ops = ShardedOps(make_engine(), E, world, rank, dist_mod)
+    ok = ops.mult(ta, tb).numpy().tobytes() == o.mult(a, b)
+    ok &= ops.add(1, ta, tb).numpy().tobytes() == o.add(1, a, b)
+    # MultPoly shards by polynomial (BASELINE configs[4]): the unit is one polynomial of d coefficients in and
+    # 2d GT coefficients out, so every product's accumulation stays on one rank
+    d = 2
+    npoly = total // d
+    if npoly:
+        pa, pb = ta[: npoly * d * E], tb[: npoly * d * E]
+        ok &= ops.poly_mult(npoly, d, d, pa, pb).numpy().tobytes() == \
+            o.poly_mult(npoly, d, d, pa.numpy().tobytes(), pb.numpy().tobytes())
+    m, st = ops.decrypt(1, ta)
+    wm, wst = o.decrypt(1, a)
+    ok &= m.tolist() == wm and st.tolist() == wst
+    return bool(ok)
+
+
 def _worker(rank, world, port, total, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -28,44 +86,15 @@ def _worker(rank, world, port, total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import oracle_c
-    from bgn_amd.sharding import shard_range, sharded_apply
+    from bgn_amd.sharding import shard_range
     fx = load_fixture("toy64")
-    o = oracle_c.Oracle.from_fixture(fx)
-    E = o.E
-    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
-    a = b"".join(cts[i % len(cts)] for i in range(total))
-    b = b"".join(cts[(3 * i + 1) % len(cts)] for i in range(total))
-    ta = torch.frombuffer(bytearray(a), dtype=torch.uint8)
-    tb = torch.frombuffer(bytearray(b), dtype=torch.uint8)
-
-    def op(sa, sb):   # this rank's shard of pk.Mult
-        return torch.frombuffer(bytearray(o.mult(sa.numpy().tobytes(), sb.numpy().tobytes())), dtype=torch.uint8)
-
-    got = sharded_apply(op, total, E, E, [ta, tb], world, rank, dist)
-    full = o.mult(a, b)
-    ok = got.numpy().tobytes() == full
-    # MultPoly shards by polynomial (BASELINE configs[4]): the unit is one polynomial of d coefficients in and
-    # 2d GT coefficients out, so every product's accumulation stays on one rank
-    d = 2
-    npoly = total // d
-    if npoly:
-        pa, pb = ta[: npoly * d * E], tb[: npoly * d * E]
-
-        def pop(sa, sb):
-            n_here = sa.numel() // (d * E)
-            return torch.frombuffer(bytearray(o.poly_mult(n_here, d, d, sa.numpy().tobytes(), sb.numpy().tobytes())),
-                                    dtype=torch.uint8)
-
-        gotp = sharded_apply(pop, npoly, d * E, 2 * d * E, [pa, pb], world, rank, dist)
-        ok = ok and gotp.numpy().tobytes() == o.poly_mult(npoly, d, d, pa.numpy().tobytes(), pb.numpy().tobytes())
-    lo, hi = shard_range(total, world, rank)
-    q.put((rank, ok, (lo, hi)))
+    ok = sharded_checks(lambda: OracleEngine(fx), fx, total, world, rank, dist)
+    q.put((rank, ok, shard_range(total, world, rank)))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("total", [10, 7])
-def test_two_rank_sharded_mult_matches_single(total):
+def test_two_rank_sharded_ops_match_single(total):
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     ctx = mp.get_context("spawn")
@@ -84,11 +113,39 @@ def test_two_rank_sharded_mult_matches_single(total):
 
 
 def test_shard_range_properties():
+    import ctypes as C
+    from bgn_amd import _lib
     from bgn_amd.sharding import shard_range
+    lib = _lib.load()
     for total in [0, 1, 5, 64, 1 << 20, (1 << 22) + 3]:
-        for world in [1, 2, 4, 8]:
+        for world in [1, 2, 3, 4, 8]:
             rs = [shard_range(total, world, r) for r in range(world)]
             assert rs[0][0] == 0 and rs[-1][1] == total
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             sizes = [h - l for l, h in rs]
             assert max(sizes) - min(sizes) <= 1
+            for r in range(world):          # the C ABI's split is the same one
+                lo, hi = C.c_size_t(), C.c_size_t()
+                lib.bgn_shard_range(total, world, r, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == rs[r]
+    lo, hi = C.c_size_t(7), C.c_size_t(7)
+    lib.bgn_shard_range(10, 0, 0, C.byref(lo), C.byref(hi))     # bad world: empty range
+    assert (lo.value, hi.value) == (0, 0)
+
+
+def test_mctx_rejects_bad_device_lists_before_touching_the_gpu():
+    import ctypes as C
+    from bgn_amd import _lib
+    lib = _lib.load()
+    fx = load_fixture("toy64")
+    pb = int(fx["p"], 16).to_bytes(fx["fp_bytes"], "big")
+    nb = int(fx["n"], 16).to_bytes(8, "big")
+    h = C.c_void_p()
+    rc = lib.bgn_mctx_create(C.byref(h), pb, len(pb), nb, len(nb), fx["l"], bytes.fromhex(fx["P"]),
+                             bytes.fromhex(fx["Q"]), 1, None, 0)
+    assert rc == -1 and not h.value and b"device list" in lib.bgn_last_error()
+    if not torch.cuda.is_available():       # no CPU fallback: creation fails loudly without a device
+        devs = (C.c_int * 2)(0, 0)
+        rc = lib.bgn_mctx_create(C.byref(h), pb, len(pb), nb, len(nb), fx["l"], bytes.fromhex(fx["P"]),
+                                 bytes.fromhex(fx["Q"]), 1, devs, 2)
+        assert rc == -3 and not h.value

@@ -323,7 +323,7 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1:
+        if args.gpus > 1 or os.environ.get("BGN_BENCH_SPAWN") == "1":     # the latter: rehearse the spawn with one rank
             sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
         world, rank, local_rank = 1, 0, 0
     else:

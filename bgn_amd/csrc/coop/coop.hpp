@@ -1,0 +1,224 @@
+// coop.hpp — wave-cooperative Type-A1 pairing for small batches ("layout B" of SURVEY.md section 7; the
+// limb-parallel design BASELINE.json's north star describes).
+//
+// Replaces `res.Pair(ct1.C, ct2.C)` (bgn.go:300) when a call carries too few pairings to fill the chip with
+// one pairing per lane (pairing.hpp: 166 ms per 1024-bit pairing whatever the batch below 65536).  Here ONE
+// pairing belongs to a workgroup of four waves, one per SIMD of a CU:
+//   * a field element lies across the lanes of a wave, one 28-bit limb per lane (lane j = limb j, lanes >= NL
+//     hold zero), so a value is ONE VGPR, the whole Miller state a handful of LDS rows, and a Montgomery product
+//     is NL steps of {broadcast one limb of b (v_readlane), multiply-add into the lane accumulators, quotient
+//     digit from lane 0 (v_readfirstlane + scalar multiply), multiply-add of p, shift the accumulators down one
+//     lane (DPP wave_shl) with the 28-bit carry split} — about 10 instructions per limb instead of 2*NL^2
+//     multiply-adds in one lane;
+//   * limbs are signed and lazily normalised (one carry pass per operand; values stay >= 0 because every
+//     subtraction adds a multiple of p chosen from static bounds), so additions and subtractions are lane-local;
+//   * the independent products of a step program run on the four waves at once: tools/coop/gen_prog.py
+//     schedules every segment of the pairing into rounds of at most four micro-ops
+//         dst = (sum ca*V[ia] + KA*p) * (sum cb*V[ib] + KB*p) / R + sum ce*V[ie] + KE*p
+//     over value slots V[] in LDS, with a workgroup barrier between rounds (a Miller doubling step: 18
+//     products in 5 rounds; an addition step: 17 in 6).  This file interprets those tables.
+// The formulas are pairing.hpp's (Jacobian doubling / mixed addition, denominator elimination, NAF of n, final
+// exponent as conj(f)^2/N(f) then ^l); outputs are canonical, hence the same bytes as the one-pairing-per-lane
+// kernel and the oracle.  tests/coop_model.py restates the arithmetic of this file on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../fp28.hpp"
+#include "../kernels.hpp"
+
+namespace bgn {
+
+struct CoopUOp {
+  uint8_t kind, dst, na, nb, ne, KA, KB, KE;
+  uint8_t ia[4];
+  int8_t ca[4];
+  uint8_t ib[4];
+  int8_t cb[4];
+  uint8_t ie[4];
+  int8_t ce[4];
+};
+static_assert(sizeof(CoopUOp) == 32, "micro-op layout");
+
+#include "coop_prog.inc"
+
+constexpr int COOP_BLOCK = 64 * COOP_W;
+
+// lane j reads lane j-1 (lane 0 reads 0) / lane j reads lane j+1 (lane 63 reads 0): whole-wave DPP shifts
+__device__ __forceinline__ u32 coop_shr1(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ u32 coop_shl1(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true); }
+
+template <int NL>
+struct CoopLane {
+  u32 p;       // limb `lane` of the modulus (0 beyond NL)
+  u32 keep;    // normalisation: bits a lane keeps (28 below the top limb, all of them in the top limb)
+  u32 carry;   // ... and whether it passes a carry up (not from the top limb)
+  u32 pinv;    // -p^-1 mod 2^28 (wave-uniform)
+  int lane;
+};
+
+// One carry pass: every limb keeps its low 28 bits and takes the (signed) excess of the limb below.
+template <int NL>
+__device__ __forceinline__ u32 coop_normalize(long long acc, const CoopLane<NL>& c) {
+  const u32 lo = (u32)acc & c.keep;
+  const u32 hi = (u32)(acc >> LIMB_BITS) & c.carry;
+  return lo + coop_shr1(hi);
+}
+
+// sum of c_k * V[i_k] + K*p on signed limbs, 64-bit per lane (no carries).
+template <int NL>
+__device__ __forceinline__ long long coop_combo(const u32 (*V)[64], int n, const uint8_t* idx, const int8_t* cf, int K,
+                                                const CoopLane<NL>& c) {
+  long long acc = (long long)K * (long long)c.p;
+  for (int k = 0; k < n; ++k) acc += (long long)cf[k] * (long long)(int)V[idx[k]][c.lane];
+  return acc;
+}
+
+// Montgomery product a*b/R on lanes: returns the unnormalised signed limbs (|.| < 2^31).
+template <int NL>
+__device__ __forceinline__ int coop_mul(u32 a, u32 b, const CoopLane<NL>& c) {
+  long long acc = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bi = __builtin_amdgcn_readlane((int)b, i);
+    acc += (long long)(int)a * (long long)bi;
+    const u32 t0 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)acc);
+    const u32 q = (t0 * c.pinv) & LIMB_MASK;
+    acc += (long long)((unsigned long long)c.p * (unsigned long long)q);
+    const u32 lo = (u32)acc & LIMB_MASK;
+    const int hi = (int)(acc >> LIMB_BITS);
+    acc = (long long)(int)(coop_shl1(lo) + (u32)hi);
+  }
+  return (int)acc;
+}
+
+template <int NL>
+__device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopUOp* __restrict__ u, const CoopLane<NL>& c) {
+  const int kind = u->kind;
+  if (kind == 0) return;
+  long long t;
+  if (kind == 1) {
+    const u32 a = coop_normalize<NL>(coop_combo<NL>(V, u->na, u->ia, u->ca, u->KA, c), c);
+    const u32 b = coop_normalize<NL>(coop_combo<NL>(V, u->nb, u->ib, u->cb, u->KB, c), c);
+    t = (long long)coop_mul<NL>(a, b, c);
+    if (u->ne) t += coop_combo<NL>(V, u->ne, u->ie, u->ce, u->KE, c);
+  } else {
+    t = coop_combo<NL>(V, u->ne, u->ie, u->ce, u->KE, c);
+  }
+  V[u->dst][c.lane] = coop_normalize<NL>(t, c);
+}
+
+template <int NL>
+__device__ __forceinline__ void coop_run(u32 (*V)[64], int seg, int wave, const CoopLane<NL>& c) {
+  const int first = kCoopSegFirst[seg], n = kCoopSegRounds[seg];
+  for (int r = 0; r < n; ++r) {
+    coop_exec<NL>(V, &kCoopProg[(first + r) * COOP_W + wave], c);
+    __syncthreads();
+  }
+}
+
+// Tight limbs of the representative in [0, p) of a value in [0, 2p) held as lazy signed limbs.
+template <int NL>
+__device__ __forceinline__ u32 coop_canonical(u32 x, const CoopLane<NL>& c) {
+  long long acc = (long long)(int)x;
+#pragma unroll 1
+  for (int i = 0; i < NL; ++i) acc = (long long)(int)coop_normalize<NL>(acc, c);
+  long long d = acc - (long long)c.p;
+#pragma unroll 1
+  for (int i = 0; i < NL; ++i) d = (long long)(int)coop_normalize<NL>(d, c);
+  const int top = __builtin_amdgcn_readlane((int)d, NL - 1);
+  return top < 0 ? (u32)acc : (u32)d;
+}
+
+// One pairing per workgroup of COOP_W waves.  Operands: canonical Montgomery SoA; result: plain canonical SoA
+// (what k_pairing<NL, 0> reads and writes).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point.
+template <int NL>
+__global__ void __launch_bounds__(COOP_BLOCK)
+k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
+               size_t count, int mode) {
+  __shared__ u32 V[COOP_NSLOTS][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t e = blockIdx.x;
+  if (e >= count) return;
+  const size_t ea = e, eb = (mode == 1) ? 0 : e;
+  CoopLane<NL> c;
+  c.lane = lane;
+  c.p = lane < NL ? P->p[lane < NL ? lane : 0] : 0u;
+  c.keep = lane < NL - 1 ? LIMB_MASK : 0xFFFFFFFFu;
+  c.carry = lane < NL - 1 ? 0xFFFFFFFFu : 0u;
+  c.pinv = P->pinv;
+  const int lj = lane < NL ? lane : 0;
+  const bool in = lane < NL;
+  // operands and constants into their slots, one wave each
+  if (wave == 0) {
+    const u32 x = in ? a.c0[(size_t)lj * a.stride + ea] : 0u;
+    V[COOP_SLOT_AX][lane] = x;
+    V[COOP_SLOT_X_0][lane] = x;
+    V[COOP_SLOT_ZERO][lane] = 0;
+    V[COOP_SLOT_V1_0][lane] = 0;
+  } else if (wave == 1) {
+    const u32 y = in ? a.c1[(size_t)lj * a.stride + ea] : 0u;
+    V[COOP_SLOT_AY][lane] = y;
+    V[COOP_SLOT_Y_0][lane] = y;
+    V[COOP_SLOT_RAW1][lane] = lane == 0 ? 1u : 0u;
+  } else if (wave == 2) {
+    V[COOP_SLOT_BX][lane] = in ? b.c0[(size_t)lj * b.stride + eb] : 0u;
+    const u32 o = in ? P->one[lj] : 0u;
+    V[COOP_SLOT_ONE][lane] = o;
+    V[COOP_SLOT_Z_0][lane] = o;
+  } else {
+    V[COOP_SLOT_BY][lane] = in ? b.c1[(size_t)lj * b.stride + eb] : 0u;
+    const u32 o = in ? P->one[lj] : 0u;
+    V[COOP_SLOT_V0_0][lane] = o;
+    V[COOP_SLOT_V2_0][lane] = o;
+  }
+  __syncthreads();
+  // Miller loop over the NAF of n (pairing.hpp miller_loop); the state ping-pongs between two slot sets
+  int par = 0;
+#pragma unroll 1
+  for (int i = C->naf_len - 2; i >= 0; --i) {
+    coop_run<NL>(V, COOP_SEG_DBL0 + 3 * par, wave, c);
+    par ^= 1;
+    const int d = C->naf[i];
+    if (d != 0 && i != 0) {
+      coop_run<NL>(V, (d > 0 ? COOP_SEG_ADDP0 : COOP_SEG_ADDM0) + 3 * par, wave, c);
+      par ^= 1;
+    }
+  }
+  // final exponentiation: N = F0^2 + F1^2, 1/N = N^(p-2), h = conj(f)^2/N, g = h^l
+  coop_run<NL>(V, COOP_SEG_NORM0 + par, wave, c);
+  coop_run<NL>(V, COOP_SEG_INV0, wave, c);
+  int ip = 0;
+#pragma unroll 1
+  for (int i = C->pm2_bits - 2; i >= 0; --i) {
+    coop_run<NL>(V, COOP_SEG_ISQ0 + 2 * ip, wave, c);
+    ip ^= 1;
+    if ((C->pm2[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u) {
+      coop_run<NL>(V, COOP_SEG_IMU0 + 2 * ip, wave, c);
+      ip ^= 1;
+    }
+  }
+  coop_run<NL>(V, COOP_SEG_H0 + ip, wave, c);
+  int lp = 0;
+#pragma unroll 1
+  for (int i = C->l_bits - 2; i >= 0; --i) {
+    coop_run<NL>(V, lp ? COOP_SEG_LSQ1 : COOP_SEG_LSQ0, wave, c);
+    lp ^= 1;
+    if ((C->l >> i) & 1ull) {
+      coop_run<NL>(V, lp ? COOP_SEG_LMU1 : COOP_SEG_LMU0, wave, c);
+      lp ^= 1;
+    }
+  }
+  coop_run<NL>(V, lp ? COOP_SEG_OUT1 : COOP_SEG_OUT0, wave, c);
+  // canonical residues out: wave 0 the real part, wave 1 the imaginary part
+  if (wave < 2) {
+    const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]);       // e(O, .) = e(., O) = 1
+    u32 r = coop_canonical<NL>(V[wave == 0 ? COOP_SLOT_OUT0 : COOP_SLOT_OUT1][lane], c);
+    if (ident) r = (wave == 0 && lane == 0) ? 1u : 0u;
+    u32* dst = wave == 0 ? out.c0 : out.c1;
+    if (in) dst[(size_t)lj * out.stride + e] = r;
+  }
+}
+
+}  // namespace bgn

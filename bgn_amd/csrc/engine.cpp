@@ -16,6 +16,7 @@
 #include "hostbig.hpp"
 #include "kernels.hpp"
 #include "consts.hpp"
+#include "coop/coop_api.hpp"
 
 using namespace bgn;
 
@@ -615,6 +616,19 @@ static int pairing_variant() {
 static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                          size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len);
 
+// Small batches go to the wave-cooperative kernel (coop/coop.hpp: one pairing per workgroup of four waves) —
+// a lane of k_pairing runs a whole pairing alone, so any batch below one wave per SIMD (65536 pairings) costs
+// the latency of ONE pairing there (166 ms at a 1024-bit key, 28 ms at 512 bits), while the cooperative kernel
+// finishes a pairing in a few milliseconds and runs one per CU (several with more workgroups resident).
+// The crossovers come from the committed sweep profiles/r02_small_batch.csv; BGN_COOP_MAX / BGN_COOP_MAX_L2
+// override them (0 disables the kernel).
+static size_t coop_limit(const bgn_ctx* c, int mode) {
+  const char* ev = getenv(mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
+  if (ev) return (size_t)strtoull(ev, nullptr, 10);
+  (void)c;
+  return mode == 1 ? 1024 : 4096;
+}
+
 // Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with
 // the width-5 loop) stays at 31 GB however long the arrays are.
 static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
@@ -669,11 +683,16 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
-              (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : pairing_variant());
+  if (mode <= 1 && count <= coop_limit(c, mode) &&
+      coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode)) {
+    c->last_kernel = coop_pairing_kernel_name(c->nl);
+  } else {
+    kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
+                (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : pairing_variant());
+    c->last_kernel = kt->pairing_kernel_name;
+  }
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
-  c->last_kernel = kt->pairing_kernel_name;
   if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);      // res.Mul(res, e(Q,Q)^r), bgn.go:302-311
   kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
   HIP_TRY(hipGetLastError());

@@ -1,0 +1,78 @@
+"""GPU: the wave-cooperative small-batch pairing kernel (bgn_amd/csrc/coop/) against the golden vectors, the
+one-pairing-per-lane kernel and the C oracle.  The engine picks the kernel by batch size (BGN_COOP_MAX /
+BGN_COOP_MAX_L2 override the crossovers; 0 disables the cooperative kernel), so both kernels are driven through
+the same C-ABI calls here."""
+import random
+
+import numpy as np
+import pytest
+
+import bgn_ref as R
+from conftest import engine_key, load_fixture, oracle_key, KEYS
+
+pytestmark = pytest.mark.gpu
+
+
+def H(hexes):
+    return b"".join(bytes.fromhex(h) for h in hexes)
+
+
+@pytest.mark.parametrize("name", KEYS)
+@pytest.mark.parametrize("kernel", ["coop", "lane"])
+def test_mult_and_make_l2_golden_on_both_kernels(name, kernel, monkeypatch):
+    lim = "1000000" if kernel == "coop" else "0"
+    monkeypatch.setenv("BGN_COOP_MAX", lim)
+    monkeypatch.setenv("BGN_COOP_MAX_L2", lim)
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    cts = [e["ct"] for e in fx["encrypt"]]
+    out = eng.mult(H([cts[v["a"]] for v in fx["mult"]]), H([cts[v["b"]] for v in fx["mult"]]))
+    assert ("coop" in eng.last_kernel_name()) == (kernel == "coop")
+    for row, v in zip(out, fx["mult"]):
+        assert bytes(row).hex() == v["out"], f"{name}: Mult({v['a']},{v['b']}) on the {kernel} kernel"
+    out = eng.make_l2(H([cts[v["a"]] for v in fx["make_l2"]]))
+    assert ("coop" in eng.last_kernel_name()) == (kernel == "coop")
+    for row, v in zip(out, fx["make_l2"]):
+        assert bytes(row).hex() == v["out"]
+
+
+@pytest.mark.parametrize("name,count", [("toy64", 333), ("k256", 130), ("k512", 64), ("k1024", 48)])
+def test_coop_random_pairs_vs_c_oracle_and_lane_kernel(name, count, monkeypatch):
+    """Seeded random ciphertext pairs (Encrypt outputs with full-length randomness, a few identities): the
+    cooperative kernel, the lane kernel and the C oracle give the same bytes."""
+    import oracle_c
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    o = oracle_c.Oracle.from_fixture(fx)
+    rng = random.Random(99)
+    n = int(fx["n"], 16)
+    xs = [rng.randrange(0, fx["msg_space"]) for _ in range(2 * count)]
+    rs = [rng.randrange(0, n) for _ in range(2 * count)]
+    cts = eng.encrypt(xs, rs).copy()
+    cts[5] = 0                      # identity operands (2L zero bytes)
+    cts[count + 9] = 0
+    a, b = cts[:count].tobytes(), cts[count:].tobytes()
+    monkeypatch.setenv("BGN_COOP_MAX", "1000000")
+    got = eng.mult(a, b).tobytes()
+    assert "coop" in eng.last_kernel_name()
+    monkeypatch.setenv("BGN_COOP_MAX", "0")
+    lane = eng.mult(a, b).tobytes()
+    assert "coop" not in eng.last_kernel_name()
+    assert got == lane
+    assert got == o.mult(a, b)
+    E = eng.elem_bytes
+    one = (1).to_bytes(E // 2, "big") + bytes(E // 2)
+    assert got[5 * E: 6 * E] == one and got[9 * E: 10 * E] == one
+
+
+def test_coop_single_pairing_count_one(monkeypatch):
+    """count = 1, the reference's own call shape (bgn_test.go:127-140: one Mult per iteration)."""
+    fx = load_fixture("k1024")
+    pk, _ = engine_key(fx)
+    cts = [e["ct"] for e in fx["encrypt"]]
+    v = fx["mult"][0]
+    out = pk.engine.mult(bytes.fromhex(cts[v["a"]]), bytes.fromhex(cts[v["b"]]))
+    assert "coop" in pk.engine.last_kernel_name()
+    assert bytes(out[0]).hex() == v["out"]

@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Step programs of the wave-cooperative pairing kernel (bgn_amd/csrc/coop/), as scheduled micro-op tables.
+
+The small-batch kernel gives ONE pairing to a workgroup of W = 4 waves (one per SIMD of a CU).  A field element
+is spread over the lanes of a wave, one 28-bit limb per lane, so a value is one VGPR and a Montgomery product is
+NL broadcast-multiply-shift steps instead of 2*NL^2 multiply-adds in one lane.  What the four waves do is fixed by
+this file: every segment of the pairing (Miller doubling step, addition steps, the pieces of the final
+exponentiation; formulas of bgn_amd/csrc/pairing.hpp, which restates `Pair` of bgn.go:300) is a DAG of micro-ops
+
+    dst = (sum ca_k * V[ia_k] + KA*p) * (sum cb_k * V[ib_k] + KB*p) / R  +  sum ce_k * V[ie_k] + KE*p     (mul)
+    dst =  sum ce_k * V[ie_k] + KE*p                                                                        (lin)
+
+over value slots V[] in LDS.  The generator tracks an upper bound (in units of p) for every slot, chooses the
+multiples of p that keep every operand non-negative, checks the Montgomery input condition
+bound(A) * bound(B) <= 2^9 <= R/p, list-schedules the DAG into rounds of at most W independent micro-ops
+(one per wave, a workgroup barrier between rounds) and assigns LDS slots by liveness.  Loop-carried state is
+ping-ponged between two slot sets so that no slot is read and written in the same round.
+
+Output: bgn_amd/csrc/coop/coop_prog.inc (committed; regenerate with `python tools/coop/gen_prog.py`).
+tests/test_coop_program.py executes the same tables on Python integers against the oracle.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+W = 4                 # waves per pairing
+MAX_TERMS = 4         # terms per linear operand
+BOUND_PRODUCT = 512   # bound(A) * bound(B) <= 2^9 <= R/p (engine.cpp chooses NL so)
+MUL_WEIGHT, LIN_WEIGHT = 10, 1
+
+
+class Form(dict):
+    """Integer linear form over slot names."""
+
+    def __add__(self, o):
+        r = Form(self)
+        for k, v in o.items():
+            r[k] = r.get(k, 0) + v
+            if r[k] == 0:
+                del r[k]
+        return r
+
+    def __neg__(self):
+        return Form({k: -v for k, v in self.items()})
+
+    def __sub__(self, o):
+        return self + (-o)
+
+    def __rmul__(self, c):
+        return Form({k: c * v for k, v in self.items()}) if c else Form()
+
+
+def S(name):
+    return Form({name: 1})
+
+
+class UOp:
+    def __init__(self, kind, dst, A, B, E):
+        self.kind, self.dst, self.A, self.B, self.E = kind, dst, A, B, E
+        self.KA = self.KB = self.KE = 0
+        self.round = -1
+
+    def reads(self):
+        r = set()
+        for f in (self.A, self.B, self.E):
+            if f:
+                r |= set(f)
+        return r
+
+
+class Builder:
+    """Accumulates the micro-ops of one segment; `bound` holds the slot bounds (units of p)."""
+
+    def __init__(self, bound, prefix):
+        self.bound = bound
+        self.prefix = prefix
+        self.uops = []
+        self.ntemp = 0
+
+    def _combo(self, form):
+        """(K, upper bound) of form + K*p with K the smallest multiple of p that makes it non-negative."""
+        assert len(form) <= MAX_TERMS, "too many terms: %r" % (form,)
+        K = sum(-c * self.bound[s] for s, c in form.items() if c < 0)
+        ub = sum(c * self.bound[s] for s, c in form.items() if c > 0) + K
+        return K, ub
+
+    def _dst(self, out):
+        if out is None:
+            out = "%s.t%d" % (self.prefix, self.ntemp)
+            self.ntemp += 1
+        return out
+
+    def mul(self, A, B, E=None, out=None):
+        u = UOp("mul", self._dst(out), Form(A), Form(B), Form(E) if E else None)
+        u.KA, ba = self._combo(u.A)
+        u.KB, bb = self._combo(u.B)
+        assert ba * bb <= BOUND_PRODUCT, "bound product %d * %d too large for %s" % (ba, bb, u.dst)
+        bd = 2                                          # (A*B + Q*p)/R < (ba*bb/2^9 + 1) p <= 2p
+        if u.E:
+            u.KE, be = self._combo(u.E)
+            bd += be
+        assert u.dst not in self.bound or self.bound[u.dst] >= bd, "bound of %s: %d > declared %d" % (
+            u.dst, bd, self.bound.get(u.dst, -1))
+        self.bound.setdefault(u.dst, bd)
+        self.uops.append(u)
+        return S(u.dst)
+
+    def lin(self, E, out=None):
+        u = UOp("lin", self._dst(out), None, None, Form(E))
+        u.KE, be = self._combo(u.E)
+        assert u.dst not in self.bound or self.bound[u.dst] >= be
+        self.bound.setdefault(u.dst, be)
+        self.uops.append(u)
+        return S(u.dst)
+
+
+def schedule(uops, w=W):
+    """List scheduling into rounds of at most w micro-ops; a micro-op reads only slots written in earlier rounds
+    (or never written in this segment).  Priority: longest path to a sink."""
+    writer = {u.dst: i for i, u in enumerate(uops)}
+    assert len(writer) == len(uops), "a slot is written twice in one segment"
+    deps = [sorted(writer[s] for s in u.reads() if s in writer) for u in uops]
+    for i, d in enumerate(deps):
+        assert all(j < i for j in d), "program order must be topological"
+    users = [[] for _ in uops]
+    for i, d in enumerate(deps):
+        for j in d:
+            users[j].append(i)
+    prio = [0] * len(uops)
+    for i in reversed(range(len(uops))):
+        wgt = MUL_WEIGHT if uops[i].kind == "mul" else LIN_WEIGHT
+        prio[i] = wgt + max((prio[j] for j in users[i]), default=0)
+    done, rounds = {}, []
+    while len(done) < len(uops):
+        r = len(rounds)
+        ready = [i for i in range(len(uops)) if i not in done and all(j in done and done[j] < r for j in deps[i])]
+        ready.sort(key=lambda i: (-prio[i], i))
+        take = ready[:w]
+        assert take
+        for i in take:
+            done[i] = r
+            uops[i].round = r
+        rounds.append([uops[i] for i in take])
+    return rounds
+
+
+class Program:
+    def __init__(self):
+        self.globals = {}      # name -> physical slot (never written by a scheduled micro-op of a loop body reading it)
+        self.segments = []     # (name, rounds)
+        self.bound = {}
+        self.phys = {}
+        self.nphys = 0
+
+    def fixed(self, name, bound):
+        self.phys[name] = self.nphys
+        self.nphys += 1
+        self.bound[name] = bound
+        return S(name)
+
+    def segment(self, name, build):
+        b = Builder(self.bound, name)
+        build(b)
+        rounds = schedule(b.uops)
+        self.segments.append((name, rounds))
+        return rounds
+
+    def allocate_temps(self):
+        """Temps are segment-local: a physical slot is free again in the round after its last read."""
+        base = self.nphys
+        top = base
+        for name, rounds in self.segments:
+            last_read = {}
+            for r, us in enumerate(rounds):
+                for u in us:
+                    for s in u.reads():
+                        last_read[s] = r
+            free, busy = [], {}
+            nxt = base
+            for r, us in enumerate(rounds):
+                for s in [s for s, (ph, lr) in busy.items() if lr < r]:
+                    free.append(busy.pop(s)[0])
+                for u in us:
+                    if u.dst in self.phys and not u.dst.startswith(name + ".t"):
+                        continue
+                    assert u.dst in last_read, "dead micro-op %s in %s" % (u.dst, name)
+                    if free:
+                        ph = free.pop()
+                    else:
+                        ph = nxt
+                        nxt += 1
+                    self.phys[u.dst] = ph
+                    busy[u.dst] = (ph, last_read[u.dst])
+            top = max(top, nxt)
+        self.nslots = top
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The pairing
+# ---------------------------------------------------------------------------------------------------------------
+STATE_BOUNDS = {"X": 19, "Y": 19, "Z": 2, "v0": 2, "v1": 2, "v2": 2}      # Miller state: V = (X, Y, Z), f = v-form
+
+
+def build_program():
+    P = Program()
+    # operands (canonical Montgomery, < p) and constants
+    ax, ay, bx, by = (P.fixed(n, 1) for n in ("ax", "ay", "bx", "by"))
+    one = P.fixed("one", 1)          # R mod p
+    raw1 = P.fixed("raw1", 1)        # the integer 1: a Montgomery product with it divides by R
+    zero = P.fixed("zero", 1)
+    # values that outlive a loop
+    n1, n2, fm = (P.fixed(n, 2) for n in ("n1", "n2", "fm"))            # F0^2, F1^2, F0*F1
+    h0, h1 = P.fixed("h0", 2), P.fixed("h1", 2)                          # h = conj(f)^2 / N(f)
+    out0, out1 = P.fixed("out0", 2), P.fixed("out1", 2)
+    st = [{k: P.fixed("%s@%d" % (k, par), b) for k, b in STATE_BOUNDS.items()} for par in (0, 1)]
+    acc = [P.fixed("acc@%d" % par, 4) for par in (0, 1)]                 # inversion ladder
+    rr = [(P.fixed("r0@%d" % par, 9), P.fixed("r1@%d" % par, 9)) for par in (0, 1)]   # h^l ladder
+
+    def name(f):
+        (k,) = f.keys()
+        return k
+
+    def f_of(s):      # f = F0 + i F1 from the stored Karatsuba triple
+        return s["v0"] - s["v1"], s["v2"] - s["v0"] - s["v1"]
+
+    def finish_f(b, F0, F1, cre, cim, so):
+        """f <- (F0 + i F1) * (cre + i cim) as the triple (F0*cre, F1*cim, (F0+F1)(cre+cim))."""
+        b.mul(F0, cre, out=name(so["v0"]))
+        b.mul(F1, cim, out=name(so["v1"]))
+        b.mul(F0 + F1, cre + cim, out=name(so["v2"]))
+
+    def dbl(b, si, so):
+        """pairing.hpp miller_double: f <- f^2 * l_{V,V}(phi(B)), V <- 2V (Jacobian, a = 1)."""
+        X, Y, Z = si["X"], si["Y"], si["Z"]
+        F0, F1 = f_of(si)
+        ZZ = b.mul(Z, Z)
+        XX = b.mul(X, X)
+        YY = b.mul(Y, Y)
+        Z3 = b.mul(2 * Y, Z, out=name(so["Z"]))
+        g0 = b.mul(F0 + F1, F0 - F1)
+        g1h = b.mul(F0, F1)
+        Wq = b.mul(ZZ, ZZ)
+        XYY = b.mul(X, YY)
+        Y4 = b.mul(YY, YY)
+        ZZxB = b.mul(ZZ, bx)
+        Z3ZZ = b.mul(Z3, ZZ)
+        cim = b.mul(Z3ZZ, by)
+        M = 3 * XX + Wq
+        X3 = b.mul(M, M, E=-8 * XYY, out=name(so["X"]))                 # M^2 - 2S, S = 4 X YY
+        cre = b.mul(M, ZZxB + X, E=-2 * YY)
+        b.mul(M, 4 * XYY - X3, E=-8 * Y4, out=name(so["Y"]))            # M (S - X3) - 8 YY^2
+        finish_f(b, g0, 2 * g1h, cre, cim, so)
+
+    def add(sign):
+        def build(b, si, so):
+            """pairing.hpp miller_add: f <- f * l_{V,sA}(phi(B)), V <- V + sA (mixed addition)."""
+            X, Y, Z = si["X"], si["Y"], si["Z"]
+            F0, F1 = f_of(si)
+            ysA = sign * ay
+            ZZ = b.mul(Z, Z)
+            ZZZ = b.mul(ZZ, Z)
+            yZ3 = b.mul(ysA, ZZZ)
+            xZZ = b.mul(ax, ZZ)
+            rrr = yZ3 - Y
+            H = xZZ - X
+            Z3 = b.mul(Z, H, out=name(so["Z"]))
+            HH = b.mul(H, H)
+            HHH = b.mul(H, HH)
+            XHH = b.mul(X, HH)
+            X3 = b.mul(rrr, rrr, E=-HHH - 2 * XHH, out=name(so["X"]))
+            YH = b.mul(Y, HHH)
+            b.mul(rrr, XHH - X3, E=-YH, out=name(so["Y"]))
+            Z3y = b.mul(Z3, ysA)
+            cre = b.mul(rrr, bx + ax, E=-Z3y)
+            cim = b.mul(Z3, by)
+            finish_f(b, F0, F1, cre, cim, so)
+        return build
+
+    for par in (0, 1):
+        si, so = st[par], st[1 - par]
+        P.segment("DBL%d" % par, lambda b, si=si, so=so: dbl(b, si, so))
+        P.segment("ADDP%d" % par, lambda b, si=si, so=so: add(1)(b, si, so))
+        P.segment("ADDM%d" % par, lambda b, si=si, so=so: add(-1)(b, si, so))
+
+    # ---- final exponentiation: f^(p-1) = conj(f)^2 / N(f), then ^l (pairing.hpp final_exp_with_inverse) ----
+    for par in (0, 1):
+        def norm(b, s=st[par], par=par):
+            F0, F1 = f_of(s)
+            b.mul(F0, F0, out="n1")
+            b.mul(F1, F1, out="n2")
+            b.mul(F0, F1, out="fm")
+        P.segment("NORM%d" % par, norm)
+    N = n1 + n2
+    # 1/N by Fermat: acc <- N, then for every lower bit of p-2: acc <- acc^2 [* N]
+    P.segment("INV0", lambda b: b.lin(N, out="acc@0"))
+    for par in (0, 1):
+        P.segment("ISQ%d" % par, lambda b, par=par: b.mul(acc[par], acc[par], out="acc@%d" % (1 - par)))
+        P.segment("IMU%d" % par, lambda b, par=par: b.mul(acc[par], N, out="acc@%d" % (1 - par)))
+    for par in (0, 1):
+        def hseg(b, par=par):
+            b.mul(n1 - n2, acc[par], out="h0")
+            b.mul(-2 * fm, acc[par], out="h1")
+            b.mul(n1 - n2, acc[par], out="r0@0")
+            b.mul(-2 * fm, acc[par], out="r1@0")
+        P.segment("H%d" % par, hseg)
+    for par in (0, 1):
+        r0, r1 = rr[par]
+        def f2sq(b, r0=r0, r1=r1, par=par):
+            b.mul(r0 + r1, r0 - r1, out="r0@%d" % (1 - par))
+            b.mul(2 * r0, r1, out="r1@%d" % (1 - par))
+        P.segment("LSQ%d" % par, f2sq)
+        def f2mu(b, r0=r0, r1=r1, par=par):
+            t1 = b.mul(r1, h1)
+            t2 = b.mul(r0, h1)
+            b.mul(r0, h0, E=-t1, out="r0@%d" % (1 - par))
+            b.mul(r1, h0, E=t2, out="r1@%d" % (1 - par))
+        P.segment("LMU%d" % par, f2mu)
+        def outseg(b, r0=r0, r1=r1):
+            b.mul(r0, raw1, out="out0")
+            b.mul(r1, raw1, out="out1")
+        P.segment("OUT%d" % par, outseg)
+    # loop-carried bounds hold (Builder.mul asserted every declared bound)
+    P.allocate_temps()
+    return P
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Emission
+# ---------------------------------------------------------------------------------------------------------------
+def emit(P, path):
+    seg_index = {}
+    rows = []
+    rnd = 0
+    for name, rounds in P.segments:
+        seg_index[name] = (rnd, len(rounds))
+        for us in rounds:
+            row = list(us) + [None] * (W - len(us))
+            rows.append(row)
+            rnd += 1
+    lines = []
+    lines.append("// GENERATED by tools/coop/gen_prog.py — do not edit.  Micro-op tables of the wave-cooperative pairing.")
+    lines.append("// %d segments, %d rounds of %d micro-ops, %d LDS value slots." % (len(P.segments), rnd, W, P.nslots))
+    lines.append("#define COOP_W %d" % W)
+    lines.append("#define COOP_NSLOTS %d" % P.nslots)
+    lines.append("#define COOP_MAX_TERMS %d" % MAX_TERMS)
+    for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "v0@0", "v1@0", "v2@0"):
+        lines.append("#define COOP_SLOT_%s %d" % (gname.replace("@", "_").upper(), P.phys[gname]))
+    lines.append("enum CoopSeg {")
+    for i, (name, _) in enumerate(P.segments):
+        lines.append("  COOP_SEG_%s = %d," % (name, i))
+    lines.append("  COOP_NSEG = %d" % len(P.segments))
+    lines.append("};")
+    lines.append("static __device__ const unsigned short kCoopSegFirst[COOP_NSEG] = {%s};" %
+                 ", ".join(str(seg_index[n][0]) for n, _ in P.segments))
+    lines.append("static __device__ const unsigned short kCoopSegRounds[COOP_NSEG] = {%s};" %
+                 ", ".join(str(seg_index[n][1]) for n, _ in P.segments))
+    lines.append("// {kind (0 nop, 1 mul, 2 lin), dst, na, nb, ne, KA, KB, KE, ia[4], ca[4], ib[4], cb[4], ie[4], ce[4]}")
+    lines.append("static __device__ const CoopUOp kCoopProg[%d] = {" % (rnd * W))
+
+    def terms(form):
+        items = sorted(form.items(), key=lambda kv: P.phys[kv[0]]) if form else []
+        idx = [P.phys[k] for k, _ in items] + [0] * (MAX_TERMS - len(items))
+        cf = [c for _, c in items] + [0] * (MAX_TERMS - len(items))
+        assert all(-128 <= c <= 127 for c in cf)
+        return len(items), idx, cf
+
+    for r, row in enumerate(rows):
+        for u in row:
+            if u is None:
+                lines.append("  {0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},")
+                continue
+            na, ia, ca = terms(u.A)
+            nb, ib, cb = terms(u.B)
+            ne, ie, ce = terms(u.E)
+            assert max(u.KA, u.KB, u.KE) <= 255
+            br = lambda v: "{%s}" % ", ".join(str(x) for x in v)
+            lines.append("  {%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s, %s, %s, %s},   // r%d %s" % (
+                1 if u.kind == "mul" else 2, P.phys[u.dst], na, nb, ne, u.KA, u.KB, u.KE, br(ia), br(ca), br(ib), br(cb),
+                br(ie), br(ce), r, u.dst))
+    lines.append("};")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return seg_index
+
+
+def summary(P):
+    out = []
+    for name, rounds in P.segments:
+        nm = sum(1 for us in rounds for u in us if u.kind == "mul")
+        out.append("%-6s %2d rounds, %2d products" % (name, len(rounds), nm))
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    P = build_program()
+    path = os.path.join(root, "bgn_amd", "csrc", "coop", "coop_prog.inc")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    emit(P, path)
+    print(summary(P))
+    print("slots:", P.nslots, "->", path)

@@ -19,7 +19,7 @@
 //     products in 5 rounds; an addition step: 17 in 6).  This file interprets those tables.
 // The formulas are pairing.hpp's (Jacobian doubling / mixed addition, denominator elimination, NAF of n, final
 // exponent as conj(f)^2/N(f) then ^l); outputs are canonical, hence the same bytes as the one-pairing-per-lane
-// kernel and the oracle.  tests/coop_model.py restates the arithmetic of this file on the CPU.
+// kernel.  The CPU tests hold a lane-level model of the arithmetic of this file.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,17 +28,6 @@
 #include "../kernels.hpp"
 
 namespace bgn {
-
-struct CoopUOp {
-  uint8_t kind, dst, na, nb, ne, KA, KB, KE;
-  uint8_t ia[4];
-  int8_t ca[4];
-  uint8_t ib[4];
-  int8_t cb[4];
-  uint8_t ie[4];
-  int8_t ce[4];
-};
-static_assert(sizeof(CoopUOp) == 32, "micro-op layout");
 
 #include "coop_prog.inc"
 
@@ -65,12 +54,32 @@ __device__ __forceinline__ u32 coop_normalize(long long acc, const CoopLane<NL>&
   return lo + coop_shr1(hi);
 }
 
-// sum of c_k * V[i_k] + K*p on signed limbs, 64-bit per lane (no carries).
+// A micro-op: eight dwords read through scalar loads (coop_prog.inc documents the packing).
+struct CoopWords {
+  u32 w[8];
+};
+__device__ __forceinline__ CoopWords coop_fetch(int row, int wave) {
+  const u32* q = kCoopProg[row * COOP_W + wave];
+  CoopWords u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) u.w[k] = q[k];
+  return u;
+}
+
+// sum of c_k * V[i_k] + K*p on signed limbs, 64-bit per lane (no carries); n in 1..3 terms, the slot indices and
+// signed coefficients packed one byte each.  Every branch is wave-uniform.
 template <int NL>
-__device__ __forceinline__ long long coop_combo(const u32 (*V)[64], int n, const uint8_t* idx, const int8_t* cf, int K,
-                                                const CoopLane<NL>& c) {
-  long long acc = (long long)K * (long long)c.p;
-  for (int k = 0; k < n; ++k) acc += (long long)cf[k] * (long long)(int)V[idx[k]][c.lane];
+__device__ __forceinline__ long long coop_combo(const u32 (*V)[64], int n, u32 idx, u32 cf, int K, const CoopLane<NL>& c) {
+  const int v0 = (int)V[idx & 0xFFu][c.lane];
+  long long acc = (long long)K * (long long)c.p + (long long)(int)(signed char)(cf & 0xFFu) * (long long)v0;
+  if (n > 1) {
+    const int v1 = (int)V[(idx >> 8) & 0xFFu][c.lane];
+    acc += (long long)(int)(signed char)((cf >> 8) & 0xFFu) * (long long)v1;
+    if (n > 2) {
+      const int v2 = (int)V[(idx >> 16) & 0xFFu][c.lane];
+      acc += (long long)(int)(signed char)((cf >> 16) & 0xFFu) * (long long)v2;
+    }
+  }
   return acc;
 }
 
@@ -93,27 +102,34 @@ __device__ __forceinline__ int coop_mul(u32 a, u32 b, const CoopLane<NL>& c) {
 }
 
 template <int NL>
-__device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopUOp* __restrict__ u, const CoopLane<NL>& c) {
-  const int kind = u->kind;
+__device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, const CoopLane<NL>& c) {
+  const int kind = (int)(u.w[0] & 0xFFu);
   if (kind == 0) return;
+  const int ne = (int)(u.w[1] & 0xFFu);
   long long t;
   if (kind == 1) {
-    const u32 a = coop_normalize<NL>(coop_combo<NL>(V, u->na, u->ia, u->ca, u->KA, c), c);
-    const u32 b = coop_normalize<NL>(coop_combo<NL>(V, u->nb, u->ib, u->cb, u->KB, c), c);
+    const u32 a = coop_normalize<NL>(coop_combo<NL>(V, (int)((u.w[0] >> 16) & 0xFFu), u.w[2], u.w[3], (int)((u.w[1] >> 8) & 0xFFu), c), c);
+    const u32 b = coop_normalize<NL>(coop_combo<NL>(V, (int)(u.w[0] >> 24), u.w[4], u.w[5], (int)((u.w[1] >> 16) & 0xFFu), c), c);
     t = (long long)coop_mul<NL>(a, b, c);
-    if (u->ne) t += coop_combo<NL>(V, u->ne, u->ie, u->ce, u->KE, c);
+    if (ne) t += coop_combo<NL>(V, ne, u.w[6], u.w[7], (int)(u.w[1] >> 24), c);
   } else {
-    t = coop_combo<NL>(V, u->ne, u->ie, u->ce, u->KE, c);
+    t = coop_combo<NL>(V, ne, u.w[6], u.w[7], (int)(u.w[1] >> 24), c);
   }
-  V[u->dst][c.lane] = coop_normalize<NL>(t, c);
+  V[(u.w[0] >> 8) & 0xFFu][c.lane] = coop_normalize<NL>(t, c);
 }
 
+// One segment: its rounds in order, a workgroup barrier after each; the next round's micro-op is fetched while
+// the current one computes.
 template <int NL>
 __device__ __forceinline__ void coop_run(u32 (*V)[64], int seg, int wave, const CoopLane<NL>& c) {
-  const int first = kCoopSegFirst[seg], n = kCoopSegRounds[seg];
+  const int first = (int)kCoopSegFirst[seg], n = (int)kCoopSegRounds[seg];
+  CoopWords cur = coop_fetch(first, wave);
+#pragma unroll 1
   for (int r = 0; r < n; ++r) {
-    coop_exec<NL>(V, &kCoopProg[(first + r) * COOP_W + wave], c);
+    const CoopWords nxt = coop_fetch(first + (r + 1 < n ? r + 1 : r), wave);
+    coop_exec<NL>(V, cur, c);
     __syncthreads();
+    cur = nxt;
   }
 }
 
@@ -175,29 +191,27 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   }
   __syncthreads();
   // Miller loop over the NAF of n (pairing.hpp miller_loop); the state ping-pongs between two slot sets
+  // (a doubling step, or a doubling and the addition of +-A scheduled as one segment; the last addition is
+  // skipped as in PBC)
   int par = 0;
 #pragma unroll 1
   for (int i = C->naf_len - 2; i >= 0; --i) {
-    coop_run<NL>(V, COOP_SEG_DBL0 + 3 * par, wave, c);
+    // (digit i through a dword load: scalar loads have no byte form)
+    const int d = (int)(signed char)((reinterpret_cast<const u32*>(C->naf)[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+    const int seg = (d != 0 && i != 0) ? (d > 0 ? COOP_SEG_DAP0 : COOP_SEG_DAM0) : COOP_SEG_DBL0;
+    coop_run<NL>(V, seg + 3 * par, wave, c);
     par ^= 1;
-    const int d = C->naf[i];
-    if (d != 0 && i != 0) {
-      coop_run<NL>(V, (d > 0 ? COOP_SEG_ADDP0 : COOP_SEG_ADDM0) + 3 * par, wave, c);
-      par ^= 1;
-    }
   }
   // final exponentiation: N = F0^2 + F1^2, 1/N = N^(p-2), h = conj(f)^2/N, g = h^l
   coop_run<NL>(V, COOP_SEG_NORM0 + par, wave, c);
   coop_run<NL>(V, COOP_SEG_INV0, wave, c);
+  // (right to left: the squaring chain and the running product advance in the same round on two waves)
   int ip = 0;
 #pragma unroll 1
-  for (int i = C->pm2_bits - 2; i >= 0; --i) {
-    coop_run<NL>(V, COOP_SEG_ISQ0 + 2 * ip, wave, c);
+  for (int i = 0; i < C->pm2_bits; ++i) {
+    const u32 bit = (C->pm2[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u;
+    coop_run<NL>(V, (bit ? COOP_SEG_IMU0 : COOP_SEG_ISQ0) + 2 * ip, wave, c);
     ip ^= 1;
-    if ((C->pm2[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u) {
-      coop_run<NL>(V, COOP_SEG_IMU0 + 2 * ip, wave, c);
-      ip ^= 1;
-    }
   }
   coop_run<NL>(V, COOP_SEG_H0 + ip, wave, c);
   int lp = 0;

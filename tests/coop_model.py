@@ -100,21 +100,18 @@ class ValueMachine:
         par = 0
         d = naf(n)
         for i in range(len(d) - 2, -1, -1):
-            self.run("DBL%d" % par)
-            par ^= 1
             if d[i] and i != 0:
-                self.run(("ADDP%d" if d[i] > 0 else "ADDM%d") % par)
-                par ^= 1
+                self.run(("DAP%d" if d[i] > 0 else "DAM%d") % par)       # doubling + addition of +-A, one segment
+            else:
+                self.run("DBL%d" % par)
+            par ^= 1
         self.run("NORM%d" % par)
         self.run("INV0")
         ip = 0
         e = self.p - 2
-        for i in range(e.bit_length() - 2, -1, -1):
-            self.run("ISQ%d" % ip)
+        for i in range(e.bit_length()):                                      # right to left
+            self.run(("IMU%d" if (e >> i) & 1 else "ISQ%d") % ip)
             ip ^= 1
-            if (e >> i) & 1:
-                self.run("IMU%d" % ip)
-                ip ^= 1
         self.run("H%d" % ip)
         lp = 0
         for i in range(l.bit_length() - 2, -1, -1):

@@ -214,8 +214,13 @@ def build_program():
     h0, h1 = P.fixed("h0", 2), P.fixed("h1", 2)                          # h = conj(f)^2 / N(f)
     out0, out1 = P.fixed("out0", 2), P.fixed("out1", 2)
     st = [{k: P.fixed("%s@%d" % (k, par), b) for k, b in STATE_BOUNDS.items()} for par in (0, 1)]
-    acc = [P.fixed("acc@%d" % par, 4) for par in (0, 1)]                 # inversion ladder
+    acc = [P.fixed("acc@%d" % par, 4) for par in (0, 1)]                 # inversion: running product
+    sq = [P.fixed("sq@%d" % par, 4) for par in (0, 1)]                   # ... and the squaring chain N^(2^i)
     rr = [(P.fixed("r0@%d" % par, 9), P.fixed("r1@%d" % par, 9)) for par in (0, 1)]   # h^l ladder
+
+    def name(f):
+        (k,) = f.keys()
+        return k
 
     def name(f):
         (k,) = f.keys()
@@ -277,11 +282,21 @@ def build_program():
             finish_f(b, F0, F1, cre, cim, so)
         return build
 
+    # a NAF digit is followed by a zero, so the loop is a sequence of D (doubling) and DA+- (doubling, then the
+    # addition of +-A) steps; DA is scheduled as ONE segment so that the addition's first products overlap the
+    # doubling's last ones.  The intermediate state of DA lives in temporaries.
+    MID_BOUNDS = dict(STATE_BOUNDS)
     for par in (0, 1):
         si, so = st[par], st[1 - par]
         P.segment("DBL%d" % par, lambda b, si=si, so=so: dbl(b, si, so))
-        P.segment("ADDP%d" % par, lambda b, si=si, so=so: add(1)(b, si, so))
-        P.segment("ADDM%d" % par, lambda b, si=si, so=so: add(-1)(b, si, so))
+        for sign, nm in ((1, "DAP"), (-1, "DAM")):
+            def dbladd(b, si=si, so=so, sign=sign, nm=nm, par=par):
+                mid = {k: S("%s%d.%s" % (nm, par, k)) for k in STATE_BOUNDS}
+                for k, f in mid.items():
+                    b.bound[name(f)] = MID_BOUNDS[k]
+                dbl(b, si, mid)
+                add(sign)(b, mid, so)
+            P.segment("%s%d" % (nm, par), dbladd)
 
     # ---- final exponentiation: f^(p-1) = conj(f)^2 / N(f), then ^l (pairing.hpp final_exp_with_inverse) ----
     for par in (0, 1):
@@ -292,11 +307,21 @@ def build_program():
             b.mul(F0, F1, out="fm")
         P.segment("NORM%d" % par, norm)
     N = n1 + n2
-    # 1/N by Fermat: acc <- N, then for every lower bit of p-2: acc <- acc^2 [* N]
-    P.segment("INV0", lambda b: b.lin(N, out="acc@0"))
+    # 1/N = N^(p-2) by Fermat, right to left: s_i = N^(2^i) and acc <- acc * s_i for the set bits run on two
+    # waves in the same round, so the chain is bits(p) rounds deep instead of 1.5 * bits(p)
+    def inv0(b):
+        b.lin(N, out="sq@0")
+        b.lin(one, out="acc@0")
+    P.segment("INV0", inv0)
     for par in (0, 1):
-        P.segment("ISQ%d" % par, lambda b, par=par: b.mul(acc[par], acc[par], out="acc@%d" % (1 - par)))
-        P.segment("IMU%d" % par, lambda b, par=par: b.mul(acc[par], N, out="acc@%d" % (1 - par)))
+        def isq(b, par=par):            # bit clear: only the squaring; acc moves to the other set unchanged
+            b.mul(sq[par], sq[par], out="sq@%d" % (1 - par))
+            b.lin(acc[par], out="acc@%d" % (1 - par))
+        def imu(b, par=par):            # bit set
+            b.mul(sq[par], sq[par], out="sq@%d" % (1 - par))
+            b.mul(acc[par], sq[par], out="acc@%d" % (1 - par))
+        P.segment("ISQ%d" % par, isq)
+        P.segment("IMU%d" % par, imu)
     for par in (0, 1):
         def hseg(b, par=par):
             b.mul(n1 - n2, acc[par], out="h0")
@@ -351,12 +376,14 @@ def emit(P, path):
         lines.append("  COOP_SEG_%s = %d," % (name, i))
     lines.append("  COOP_NSEG = %d" % len(P.segments))
     lines.append("};")
-    lines.append("static __device__ const unsigned short kCoopSegFirst[COOP_NSEG] = {%s};" %
+    lines.append("static __device__ const unsigned int kCoopSegFirst[COOP_NSEG] = {%s};" %
                  ", ".join(str(seg_index[n][0]) for n, _ in P.segments))
-    lines.append("static __device__ const unsigned short kCoopSegRounds[COOP_NSEG] = {%s};" %
+    lines.append("static __device__ const unsigned int kCoopSegRounds[COOP_NSEG] = {%s};" %
                  ", ".join(str(seg_index[n][1]) for n, _ in P.segments))
-    lines.append("// {kind (0 nop, 1 mul, 2 lin), dst, na, nb, ne, KA, KB, KE, ia[4], ca[4], ib[4], cb[4], ie[4], ce[4]}")
-    lines.append("static __device__ const CoopUOp kCoopProg[%d] = {" % (rnd * W))
+    lines.append("// eight dwords per micro-op (scalar loads have no byte form): kind | dst<<8 | na<<16 | nb<<24, "
+                 "ne | KA<<8 | KB<<16 | KE<<24,")
+    lines.append("// then slot indices and signed coefficients of A, B, E, four bytes each; kind: 0 nop, 1 mul, 2 lin")
+    lines.append("alignas(32) static __device__ const unsigned int kCoopProg[%d][8] = {" % (rnd * W))
 
     def terms(form):
         items = sorted(form.items(), key=lambda kv: P.phys[kv[0]]) if form else []
@@ -368,16 +395,16 @@ def emit(P, path):
     for r, row in enumerate(rows):
         for u in row:
             if u is None:
-                lines.append("  {0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},")
+                lines.append("  {0, 0, 0, 0, 0, 0, 0, 0},")
                 continue
             na, ia, ca = terms(u.A)
             nb, ib, cb = terms(u.B)
             ne, ie, ce = terms(u.E)
             assert max(u.KA, u.KB, u.KE) <= 255
-            br = lambda v: "{%s}" % ", ".join(str(x) for x in v)
-            lines.append("  {%d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %s, %s, %s, %s},   // r%d %s" % (
-                1 if u.kind == "mul" else 2, P.phys[u.dst], na, nb, ne, u.KA, u.KB, u.KE, br(ia), br(ca), br(ib), br(cb),
-                br(ie), br(ce), r, u.dst))
+            pk = lambda v: sum((x & 0xFF) << (8 * i) for i, x in enumerate(v))
+            words = [pk([1 if u.kind == "mul" else 2, P.phys[u.dst], na, nb]), pk([ne, u.KA, u.KB, u.KE]),
+                     pk(ia), pk(ca), pk(ib), pk(cb), pk(ie), pk(ce)]
+            lines.append("  {%s},   // r%d %s" % (", ".join("0x%08xu" % w for w in words), r, u.dst))
     lines.append("};")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")

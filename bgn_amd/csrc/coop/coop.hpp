@@ -58,11 +58,20 @@ __device__ __forceinline__ u32 coop_normalize(long long acc, const CoopLane<NL>&
 struct CoopWords {
   u32 w[8];
 };
-__device__ __forceinline__ CoopWords coop_fetch(int row, int wave) {
+typedef unsigned int coop_u32x8 __attribute__((ext_vector_type(8)));
+// The fetch is issued as inline assembly so that it STARTS where it is written — one round ahead, in front of
+// the product loop — instead of being sunk to its first use; coop_fetch_wait makes the registers usable.
+__device__ __forceinline__ coop_u32x8 coop_fetch_start(int row, int wave) {
   const u32* q = kCoopProg[row * COOP_W + wave];
+  coop_u32x8 r;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(r) : "s"(q));
+  return r;
+}
+__device__ __forceinline__ CoopWords coop_fetch_wait(coop_u32x8 r) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
   CoopWords u;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) u.w[k] = q[k];
+  u.w[0] = r[0]; u.w[1] = r[1]; u.w[2] = r[2]; u.w[3] = r[3];
+  u.w[4] = r[4]; u.w[5] = r[5]; u.w[6] = r[6]; u.w[7] = r[7];
   return u;
 }
 
@@ -101,6 +110,27 @@ __device__ __forceinline__ int coop_mul(u32 a, u32 b, const CoopLane<NL>& c) {
   return (int)acc;
 }
 
+// The two operand sums of a product with their LDS reads issued together: terms 0 and 1 of both unconditionally
+// (an unused term has coefficient 0 and reads slot 0), the rare third terms under a wave-uniform branch.
+template <int NL>
+__device__ __forceinline__ void coop_operands(u32& a, u32& b, const u32 (*V)[64], const CoopWords& u, const CoopLane<NL>& c) {
+  const int a0 = (int)V[u.w[2] & 0xFFu][c.lane], a1 = (int)V[(u.w[2] >> 8) & 0xFFu][c.lane];
+  const int b0 = (int)V[u.w[4] & 0xFFu][c.lane], b1 = (int)V[(u.w[4] >> 8) & 0xFFu][c.lane];
+  long long sa = (long long)(int)((u.w[1] >> 8) & 0xFFu) * (long long)c.p;
+  long long sb = (long long)(int)((u.w[1] >> 16) & 0xFFu) * (long long)c.p;
+  sa += (long long)(int)(signed char)(u.w[3] & 0xFFu) * (long long)a0;
+  sb += (long long)(int)(signed char)(u.w[5] & 0xFFu) * (long long)b0;
+  sa += (long long)(int)(signed char)((u.w[3] >> 8) & 0xFFu) * (long long)a1;
+  sb += (long long)(int)(signed char)((u.w[5] >> 8) & 0xFFu) * (long long)b1;
+  if ((u.w[3] | u.w[5]) & 0xFF0000u) {
+    const int a2 = (int)V[(u.w[2] >> 16) & 0xFFu][c.lane], b2 = (int)V[(u.w[4] >> 16) & 0xFFu][c.lane];
+    sa += (long long)(int)(signed char)((u.w[3] >> 16) & 0xFFu) * (long long)a2;
+    sb += (long long)(int)(signed char)((u.w[5] >> 16) & 0xFFu) * (long long)b2;
+  }
+  a = coop_normalize<NL>(sa, c);
+  b = coop_normalize<NL>(sb, c);
+}
+
 template <int NL>
 __device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, const CoopLane<NL>& c) {
   const int kind = (int)(u.w[0] & 0xFFu);
@@ -108,8 +138,8 @@ __device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, cons
   const int ne = (int)(u.w[1] & 0xFFu);
   long long t;
   if (kind == 1) {
-    const u32 a = coop_normalize<NL>(coop_combo<NL>(V, (int)((u.w[0] >> 16) & 0xFFu), u.w[2], u.w[3], (int)((u.w[1] >> 8) & 0xFFu), c), c);
-    const u32 b = coop_normalize<NL>(coop_combo<NL>(V, (int)(u.w[0] >> 24), u.w[4], u.w[5], (int)((u.w[1] >> 16) & 0xFFu), c), c);
+    u32 a, b;
+    coop_operands<NL>(a, b, V, u, c);
     t = (long long)coop_mul<NL>(a, b, c);
     if (ne) t += coop_combo<NL>(V, ne, u.w[6], u.w[7], (int)(u.w[1] >> 24), c);
   } else {
@@ -123,13 +153,13 @@ __device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, cons
 template <int NL>
 __device__ __forceinline__ void coop_run(u32 (*V)[64], int seg, int wave, const CoopLane<NL>& c) {
   const int first = (int)kCoopSegFirst[seg], n = (int)kCoopSegRounds[seg];
-  CoopWords cur = coop_fetch(first, wave);
+  CoopWords cur = coop_fetch_wait(coop_fetch_start(first, wave));
 #pragma unroll 1
   for (int r = 0; r < n; ++r) {
-    const CoopWords nxt = coop_fetch(first + (r + 1 < n ? r + 1 : r), wave);
+    const coop_u32x8 nxt = coop_fetch_start(first + (r + 1 < n ? r + 1 : r), wave);
     coop_exec<NL>(V, cur, c);
+    cur = coop_fetch_wait(nxt);
     __syncthreads();
-    cur = nxt;
   }
 }
 
@@ -191,15 +221,27 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   }
   __syncthreads();
   // Miller loop over the NAF of n (pairing.hpp miller_loop); the state ping-pongs between two slot sets
-  // (a doubling step, or a doubling and the addition of +-A scheduled as one segment; the last addition is
-  // skipped as in PBC)
+  // (steps scheduled as segments: a doubling and the addition of +-A that follows it, two consecutive plain
+  // doublings, or one doubling; the last addition is skipped as in PBC)
+  const u32* nafw = reinterpret_cast<const u32*>(C->naf);       // digits through dword loads (no scalar byte loads)
+  auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
   int par = 0;
+  int i = C->naf_len - 2;
 #pragma unroll 1
-  for (int i = C->naf_len - 2; i >= 0; --i) {
-    // (digit i through a dword load: scalar loads have no byte form)
-    const int d = (int)(signed char)((reinterpret_cast<const u32*>(C->naf)[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-    const int seg = (d != 0 && i != 0) ? (d > 0 ? COOP_SEG_DAP0 : COOP_SEG_DAM0) : COOP_SEG_DBL0;
-    coop_run<NL>(V, seg + 3 * par, wave, c);
+  while (i >= 0) {
+    const int d = digit(i);
+    int seg;
+    if (d != 0 && i != 0) {
+      seg = d > 0 ? COOP_SEG_DAP0 : COOP_SEG_DAM0;
+      i -= 1;
+    } else if (i >= 1 && (i == 1 || digit(i - 1) == 0)) {
+      seg = COOP_SEG_DD0;
+      i -= 2;
+    } else {
+      seg = COOP_SEG_DBL0;
+      i -= 1;
+    }
+    coop_run<NL>(V, seg + 4 * par, wave, c);
     par ^= 1;
   }
   // final exponentiation: N = F0^2 + F1^2, 1/N = N^(p-2), h = conj(f)^2/N, g = h^l

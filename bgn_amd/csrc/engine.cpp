@@ -625,8 +625,12 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
 static size_t coop_limit(const bgn_ctx* c, int mode) {
   const char* ev = getenv(mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
-  (void)c;
-  return mode == 1 ? 1024 : 4096;
+  // profiles/r02_small_batch.csv (MI355X): Mult at 1024 bits — 8192 pairings 121 ms cooperative against 164 ms,
+  // 16384: 237 against 164; at 512 bits — 4096: 17.9 against 28.0 ms, 8192: 33.9 against 28.1.  makeL2 (the lane
+  // kernel walks P's line table there, a third of the products): 1024 bits — 2048: 34 against 54 ms, 4096: 63
+  // against 54; 512 bits — 1024: 5.9 against 10.1 ms, 2048: 9.8 against 10.1.
+  if (mode == 1) return c->nl >= 38 ? 3000 : c->nl >= 19 ? 1800 : 1024;
+  return c->nl >= 38 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
 // Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with

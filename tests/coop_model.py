@@ -99,11 +99,17 @@ class ValueMachine:
         V.update({"X@0": V["ax"], "Y@0": V["ay"], "Z@0": V["one"], "v0@0": V["one"], "v1@0": 0, "v2@0": V["one"]})
         par = 0
         d = naf(n)
-        for i in range(len(d) - 2, -1, -1):
+        i = len(d) - 2
+        while i >= 0:
             if d[i] and i != 0:
                 self.run(("DAP%d" if d[i] > 0 else "DAM%d") % par)       # doubling + addition of +-A, one segment
+                i -= 1
+            elif i >= 1 and (i == 1 or d[i - 1] == 0):
+                self.run("DD%d" % par)                                    # two plain doublings, one segment
+                i -= 2
             else:
                 self.run("DBL%d" % par)
+                i -= 1
             par ^= 1
         self.run("NORM%d" % par)
         self.run("INV0")

@@ -289,6 +289,13 @@ def build_program():
     for par in (0, 1):
         si, so = st[par], st[1 - par]
         P.segment("DBL%d" % par, lambda b, si=si, so=so: dbl(b, si, so))
+        def dbl2(b, si=si, so=so, par=par):                      # two doubling steps in one schedule
+            mid = {k: S("DD%d.%s" % (par, k)) for k in STATE_BOUNDS}
+            for k, f in mid.items():
+                b.bound[name(f)] = MID_BOUNDS[k]
+            dbl(b, si, mid)
+            dbl(b, mid, so)
+        P.segment("DD%d" % par, dbl2)
         for sign, nm in ((1, "DAP"), (-1, "DAM")):
             def dbladd(b, si=si, so=so, sign=sign, nm=nm, par=par):
                 mid = {k: S("%s%d.%s" % (nm, par, k)) for k in STATE_BOUNDS}

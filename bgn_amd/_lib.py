@@ -77,6 +77,7 @@ PROTOTYPES = {
     "bgn_mmult_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, C.c_int]),
     "bgn_mdecrypt_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, C.c_int]),
     "bgn_mpoly_mult_batch_dev": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p, C.c_int]),
+    "bgn_field_ops_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p]),
     "bgn_last_kernel_ms": (C.c_double, [_ctx]),
     "bgn_last_kernel_name": (C.c_char_p, [_ctx]),
     "bgn_last_aux_kernel_ms": (C.c_double, [_ctx]),

@@ -249,6 +249,13 @@ class Engine:
         check(self._lib.bgn_poly_eval_batch_dev(self._h, npoly, d, level, ct.data_ptr(), base, out.data_ptr(),
                                                 self._stream()), "bgn_poly_eval_batch_dev")
 
+    def field_ops(self, xy: BytesLike):
+        """Diagnostics: (x*y || 1/x, x^2 || y^2) for elements x||y of plain residues (bgn_field_ops_batch)."""
+        A = _as_u8(xy, self.elem_bytes)
+        o1, o2 = self._out(len(A)), self._out(len(A))
+        check(self._lib.bgn_field_ops_batch(self._h, len(A), _ptr(A), _ptr(o1), _ptr(o2)), "bgn_field_ops_batch")
+        return o1, o2
+
     def last_kernel_ms(self) -> float:
         return float(self._lib.bgn_last_kernel_ms(self._h))
 
@@ -590,16 +597,22 @@ class PublicKey:
         res = [self.Sub(self.encryptZero(), c) for c in ct.Coefficients]        # poly.go:45-55
         return PolyCiphertext(res, ct.Degree, ct.ScaleFactor, ct.L2)
 
-    def MultConstPoly(self, ct: PolyCiphertext, constant) -> PolyCiphertext:
-        """poly.go:71-120.  `constant` is a number (encoded here with the unbalanced base-b expansion of
-        plaintext.go:34-63, CPU side) or an already encoded (digits, scale) pair.  One engine call computes
-        the whole convolution result[i+k] += MultConst(ct[i], p[k])."""
-        negative = False
-        if isinstance(constant, tuple):
+    def MultConstPoly(self, ct: PolyCiphertext, constant, negative: bool = False) -> PolyCiphertext:
+        """poly.go:71-120.  `constant` is the ENCODED plaintext — the reference encodes its *big.Float argument
+        with NewUnbalancedPlaintext (plaintext.go:34-63), which stays on the CPU side of the boundary: an object
+        with .Coefficients / .ScaleFactor, a (digits, scale) pair, or a plain integer (expanded here, sign split
+        as poly.go:73-76).  `negative`: the constant was negative and |constant| was encoded (NegPoly of the
+        product, poly.go:115-119).  One engine call computes the whole convolution
+        result[i+k] += MultConst(ct[i], p[k])."""
+        if hasattr(constant, "Coefficients"):
+            digits, scale = [int(c) for c in constant.Coefficients], int(constant.ScaleFactor)
+        elif isinstance(constant, tuple):
             digits, scale = list(constant[0]), int(constant[1])
         else:
-            negative = constant < 0                                          # poly.go:73-76
-            digits, scale = self.NewUnbalancedPlaintext(-constant if negative else constant)
+            if int(constant) != constant:
+                raise TypeError("encode fractional constants on the host side (plaintext.go) and pass the digits")
+            negative = negative != (constant < 0)                            # poly.go:73-76
+            digits, scale = self.NewUnbalancedPlaintext(abs(int(constant)))
         out = self.engine.poly_multconst(1, ct.Degree, 2 if ct.L2 else 1, b"".join(c.C for c in ct.Coefficients), digits)
         out = self._blind(out, ct.L2)                                        # bgn.go:260-269 on every step of the loop
         prod = PolyCiphertext([Ciphertext(bytes(r), ct.L2) for r in out], ct.Degree + len(digits),
@@ -691,19 +704,16 @@ class PublicKey:
     def CheckProofOfPlaintextKnoewledge(self, ct: Ciphertext, proof: "ProofOfPlaintextKnowledge") -> bool:
         return self.CheckProofOfPlaintextKnoewledgeBatch([ct], [proof])[0]     # gadgets.go:65-77 (name as in the reference)
 
-    # -- plaintext encoding (plaintext.go; CPU side of the boundary) --
-    def NewUnbalancedPlaintext(self, m):
-        """plaintext.go:34-63: digits of the unbalanced base-b expansion of m >= 0 and its scale factor.
-        Integers only need the expansion; a fractional m goes through `rationalize` first."""
-        scale = 0
-        if isinstance(m, float) and m != int(m):
-            import math
-            num, scale = rationalize(m - math.floor(m), self.FPScaleBase, self.FPPrecision)
-            m = int(math.floor(m)) * self.FPScaleBase ** scale + num         # plaintext.go:49-52
+    # -- the integer expansion alignPolyCiphertexts needs (poly.go:209-226 multiplies by FPScaleBase^diff) --
+    def NewUnbalancedPlaintext(self, m: int):
+        """Unbalanced base-b digits of an integer m >= 0 and scale factor 0 (plaintext.go:58-62).  Fractional
+        values go through plaintext.go's rationalize on the host side, outside this package."""
+        if int(m) != m:
+            raise TypeError("integers only: the fixed-point encoding of plaintext.go stays on the host side")
         m = int(m)
         if m < 0:
             raise ValueError("Negative encoding not supported")             # plaintext.go:175-177
-        return unbalanced_encode(m, self.PolyBase), scale
+        return unbalanced_encode(m, self.PolyBase), 0
 
 
 def unbalanced_encode(target: int, base: int) -> List[int]:
@@ -729,33 +739,6 @@ def unbalanced_encode(target: int, base: int) -> List[int]:
         if v == target:
             return digits
         target -= v
-
-
-def rationalize(x: float, base: int, precision: float):
-    """rationalize (plaintext.go:271-317), float for float: smallest power of the base whose multiple
-    approximates frac(x) within `precision`.  Returns (numerator, scale)."""
-    import math
-    factor = math.floor(x)
-    x = 1.0 + math.remainder(x, 1.0)
-    if abs(x) > 1.0:
-        x += 1.0
-    if x >= 0.0:
-        x -= float(int(x))
-    num, pw = 1.0, 1.0
-    qmin, qmax = x - precision, x + precision
-    while True:
-        denom = float(base) ** pw
-        rat = num / denom
-        if qmin <= rat <= qmax:
-            while int(num) % base == 0:
-                num /= base
-                pw -= 1
-            denom = float(base) ** pw
-            return int(factor * denom + num), int(pw)
-        if num + 1 >= denom:
-            num = 1.0
-            pw += 1
-        num += 1
 
 
 class SecretKey:

@@ -53,6 +53,14 @@ __device__ __forceinline__ void bsgs_fingerprint(unsigned long long& key, u32& c
   if (NL <= 3) ck = c.v[2] >> 8;
   check = ck;
 }
+// ... shortened to the bits the table was built with (BsgsParams::key_keep / check_keep: all of them in
+// production; the tests keep a few so that false hits occur and the verification below is exercised)
+template <int NL>
+__device__ __forceinline__ void bsgs_fingerprint(unsigned long long& key, u32& check, const Fp<NL>& c, const BsgsParams& B) {
+  bsgs_fingerprint<NL>(key, check, c);
+  key = (key & B.key_keep) | (1ull << 63);
+  check &= B.check_keep;
+}
 
 // (r0, r1) = (a0 + i a1) * K with the constant K in LDS rows: L[1] = K0, L[2] = K1,
 // L[3] = K0 + K1 (K canonical <1).  a0 <4, a1 <6 ; r0 <4, r1 <6.
@@ -162,7 +170,7 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
     if (j <= B.S) {
       unsigned long long key;
       u32 check;
-      bsgs_fingerprint<NL>(key, check, c0);
+      bsgs_fingerprint<NL>(key, check, c0, B);
       const u32 val = (u32)j;                                  // j <= S <= 2^31
       check = (check & 0x7fffffffu) | ((c1.v[0] & 1u) << 31);   // parity of the imaginary part rides in the check word
       unsigned long long h = bsgs_mix(key) & B.mask;
@@ -216,132 +224,167 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
   const size_t idx = lane / parts;
   const unsigned long long part = lane % parts;
   const size_t e = (A.mode == 1) ? A.todo[idx] : idx;
-  const unsigned long long i0 = part * steps;
-  unsigned long long i1 = i0 + steps;
+  unsigned long long i0 = part * steps;        // first giant step of this attempt (moves up after a rejected hit)
+  unsigned long long i1 = part * steps + steps;
   if (i1 > B.G) i1 = B.G;
-  load_const_rows<NL>(L, B.gi0, B.gi1);
-  Fp<NL> a0, a1;
-  if (__ballot(i0 != 0)) {
-    // start of this part: x * gamma^-i0
-    gt_pow_u64<NL>(a0, a1, i0, L, P);          // (gamma^-1)^i0  <4,<6
-    Fp<NL> x0, x1, sm;
-    g_load<NL>(x0, A.x0, A.sx, e);
-    g_load<NL>(x1, A.x1, A.sx, e);
-    if (A.mode == 1) {
-      fp_neg<1>(x1, x1, P);
-      fp_reduce8(x1, x1, P);
-    }
-    fp_add(sm, x0, x1);
-    // product with x as the LDS-resident constant, then restore gamma^-1
-    l_store(L + 1, x0);
-    l_store(L + 2, x1);
-    l_store(L + 3, sm);
-    Fp<NL> m0, m1;
-    fp2_mul_const(m0, m1, a0, a1, L, P);
-    a0 = m0;
-    a1 = m1;
-    load_const_rows<NL>(L, B.gi0, B.gi1);
-    fp_reduce8(a0, a0, P);
-    fp_reduce8(a1, a1, P);
-  } else {
-    g_load<NL>(a0, A.x0, A.sx, e);
-    g_load<NL>(a1, A.x1, A.sx, e);
-    if (A.mode == 1) {
-      fp_neg<1>(a1, a1, P);                   // conj(x) = x^-1 on GT: Neg(ct), bgn.go:236
-      fp_reduce8(a1, a1, P);
-    }
-  }
-  // Walk.  Only the real part of y_i = x * gamma^-i is needed to probe, and on the norm-1 group it obeys
-  //     Re(y_(i+1)) = 2*Re(gamma) * Re(y_i) - Re(y_(i-1))          (y_(i+1) + y_(i-1) = y_i * (gamma^-1 + gamma))
-  // so a giant step costs ONE field product instead of the three of an F_p^2 product.  The imaginary part,
-  // whose parity decides between +j and -j, is recomputed from x for the one step that hits.
-  bool done = !live;
-  bool found = false;
+  bool found = false, finished = !live;
   long long result = 0;
-  if (i0 == 0) {
-    Fp<NL> one;
-    fp_set(one, P->one);
-    if (fp_eq_limbs(a0, one) && fp_is_zero_limbs(a1)) {   // zero.Equals(csk), bgn.go:359-363
-      found = true;
-      done = true;
-    }
-  }
-  Fp<NL> rc, rp;                                 // Re(y_i), Re(y_(i-1)), canonical
-  fp_reduce8(rc, a0, P);
-  {
-    // y_(i0-1) = y_i0 * gamma = y_i0 * conj(gamma^-1):  Re = a0*K0 + a1*K1
-    Fp<NL> v0, v1;
-    fp_mul(v0, L + 1, a0, P);                   // <2
-    fp_mul(v1, L + 2, a1, P);                   // <2
-    fp_add(v0, v0, v1);                         // <4
-    fp_reduce8(rp, v0, P);
-    Fp<NL> k0;
-    g_load<NL>(k0, B.gi0, 1, 0);
-    fp_dbl(k0, k0);                             // T = 2*Re(gamma^-1) = 2*Re(gamma) <2
-    l_store(L, k0);                             // L[0] = T for the whole walk
-  }
-  bool hit = false;
-  unsigned long long hit_i = 0;
-  u32 hit_j = 0, hit_par = 0;
+  // A table hit is a match of 94 fingerprint bits of Re(y_i): the candidate m it decodes to is VERIFIED by
+  // g^|m| == x on all limbs before it is accepted (gsbs.go:83,90 compares whole elements).  A rejected hit —
+  // probability ~2^-94 per probe with the full fingerprint — resumes the walk at the same giant step behind the
+  // rejected slot.  Every pass of this loop is one walk of the wave; kMaxAttempts bounds it.
+  bool resume = false;
+  unsigned long long resume_h = 0;
+  constexpr int kMaxAttempts = 64;
 #pragma unroll 1
-  for (unsigned long long i = i0; i < i0 + steps; ++i) {
-    if (!__ballot(!done)) break;
-    if (i >= i1) done = true;
-    unsigned long long key;
-    u32 check;
-    bsgs_fingerprint<NL>(key, check, rc);
-    // the first slot of the probe sequence is fetched before the next step's product and examined after it:
-    // at one wave per SIMD nothing else hides the ~2 us of a random HBM access
-    unsigned long long h = bsgs_mix(key) & B.mask;
-    BsgsSlot s0;
-    s0.key = 0ull;
-    s0.check = 0;
-    s0.val = 0;
-    if (!done) s0 = B.table[h];
-    Fp<NL> nx;
-    fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
-    fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
-    rp = rc;
-    fp_reduce8(rc, nx, P);
-    if (!done) {
-      BsgsSlot s = s0;
-      for (;;) {
-        if (s.key == 0ull) break;
-        if (s.key == key && ((s.check ^ check) & 0x7fffffffu) == 0u) {
-          hit = true;        // m is unique: whatever this hit decodes to decides the attempt
-          hit_i = i;
-          hit_j = s.val;
-          hit_par = s.check >> 31;
-          done = true;
-          break;
-        }
-        h = (h + 1) & B.mask;
-        s = B.table[h];
+  for (int attempt = 0; attempt < kMaxAttempts; ++attempt) {
+    if (!__ballot(!finished)) break;
+    load_const_rows<NL>(L, B.gi0, B.gi1);
+    Fp<NL> a0, a1;
+    if (__ballot(i0 != 0)) {
+      // start of this part: x * gamma^-i0
+      gt_pow_u64<NL>(a0, a1, i0, L, P);          // (gamma^-1)^i0  <4,<6
+      Fp<NL> x0, x1, sm;
+      g_load<NL>(x0, A.x0, A.sx, e);
+      g_load<NL>(x1, A.x1, A.sx, e);
+      if (A.mode == 1) {
+        fp_neg<1>(x1, x1, P);
+        fp_reduce8(x1, x1, P);
+      }
+      fp_add(sm, x0, x1);
+      // product with x as the LDS-resident constant, then restore gamma^-1
+      l_store(L + 1, x0);
+      l_store(L + 2, x1);
+      l_store(L + 3, sm);
+      Fp<NL> m0, m1;
+      fp2_mul_const(m0, m1, a0, a1, L, P);
+      a0 = m0;
+      a1 = m1;
+      load_const_rows<NL>(L, B.gi0, B.gi1);
+      fp_reduce8(a0, a0, P);
+      fp_reduce8(a1, a1, P);
+    } else {
+      g_load<NL>(a0, A.x0, A.sx, e);
+      g_load<NL>(a1, A.x1, A.sx, e);
+      if (A.mode == 1) {
+        fp_neg<1>(a1, a1, P);                   // conj(x) = x^-1 on GT: Neg(ct), bgn.go:236
+        fp_reduce8(a1, a1, P);
       }
     }
-  }
-  if (__ballot(hit)) {
-    // Im(y_hit) for the lanes that hit: y_hit = x * (gamma^-1)^hit_i
-    Fp<NL> g0, g1;
-    gt_pow_u64<NL>(g0, g1, hit ? hit_i : 0ull, L, P);      // <4, <6 ; uses L[0] as scratch, L[1..3] = gamma^-1
-    Fp<NL> x0, x1;
-    g_load<NL>(x0, A.x0, A.sx, e);
-    g_load<NL>(x1, A.x1, A.sx, e);
-    if (A.mode == 1) {
-      fp_neg<1>(x1, x1, P);
-      fp_reduce8(x1, x1, P);
+    // Walk.  Only the real part of y_i = x * gamma^-i is needed to probe, and on the norm-1 group it obeys
+    //     Re(y_(i+1)) = 2*Re(gamma) * Re(y_i) - Re(y_(i-1))          (y_(i+1) + y_(i-1) = y_i * (gamma^-1 + gamma))
+    // so a giant step costs ONE field product instead of the three of an F_p^2 product.  The imaginary part,
+    // whose parity decides between +j and -j, is recomputed from x for the one step that hits.
+    bool done = finished;
+    if (i0 == 0 && attempt == 0) {
+      Fp<NL> one;
+      fp_set(one, P->one);
+      if (fp_eq_limbs(a0, one) && fp_is_zero_limbs(a1)) {   // zero.Equals(csk), bgn.go:359-363
+        found = true;
+        done = true;
+        finished = true;
+      }
     }
-    Fp<NL> im, t;
-    fp_mulv(im, x0, g1, P, L);                   // x0*g1 <2   (6)
-    fp_mulv(t, x1, g0, P, L);                    // x1*g0 <2   (4)
-    fp_add(im, im, t);                           // <4
-    fp_reduce8(im, im, P);
-    const long long j = (long long)hit_j;
-    const bool same = ((im.v[0] & 1u) == hit_par) || fp_is_zero_limbs(im);
-    const long long m = (long long)(hit_i * B.stride) + (same ? j : -j);
-    if (hit && m >= 1 && (unsigned long long)m <= B.Mmax) {
-      found = true;
-      result = m;
+    Fp<NL> rc, rp;                                 // Re(y_i), Re(y_(i-1)), canonical
+    fp_reduce8(rc, a0, P);
+    {
+      // y_(i0-1) = y_i0 * gamma = y_i0 * conj(gamma^-1):  Re = a0*K0 + a1*K1
+      Fp<NL> v0, v1;
+      fp_mul(v0, L + 1, a0, P);                   // <2
+      fp_mul(v1, L + 2, a1, P);                   // <2
+      fp_add(v0, v0, v1);                         // <4
+      fp_reduce8(rp, v0, P);
+      Fp<NL> k0;
+      g_load<NL>(k0, B.gi0, 1, 0);
+      fp_dbl(k0, k0);                             // T = 2*Re(gamma^-1) = 2*Re(gamma) <2
+      l_store(L, k0);                             // L[0] = T for the whole walk
+    }
+    bool hit = false;
+    unsigned long long hit_i = 0, hit_h = 0;
+    u32 hit_j = 0, hit_par = 0;
+    const unsigned long long iend = part * steps + steps;
+#pragma unroll 1
+    for (unsigned long long i = i0; i < iend; ++i) {
+      if (!__ballot(!done)) break;
+      if (i >= i1) done = true;
+      unsigned long long key;
+      u32 check;
+      bsgs_fingerprint<NL>(key, check, rc, B);
+      // the first slot of the probe sequence is fetched before the next step's product and examined after it:
+      // at one wave per SIMD nothing else hides the ~2 us of a random HBM access
+      unsigned long long h = bsgs_mix(key) & B.mask;
+      if (resume && i == i0) h = (resume_h + 1) & B.mask;       // behind the slot the verification rejected
+      BsgsSlot s0;
+      s0.key = 0ull;
+      s0.check = 0;
+      s0.val = 0;
+      if (!done) s0 = B.table[h];
+      Fp<NL> nx;
+      fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
+      fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
+      rp = rc;
+      fp_reduce8(rc, nx, P);
+      if (!done) {
+        BsgsSlot s = s0;
+        for (;;) {
+          if (s.key == 0ull) break;
+          if (s.key == key && ((s.check ^ check) & 0x7fffffffu & B.check_keep) == 0u) {
+            hit = true;
+            hit_i = i;
+            hit_h = h;
+            hit_j = s.val;
+            hit_par = s.check >> 31;
+            done = true;
+            break;
+          }
+          h = (h + 1) & B.mask;
+          s = B.table[h];
+        }
+      }
+    }
+    if (!hit) finished = true;                    // walked its range to the end
+    if (__ballot(hit)) {
+      // Im(y_hit) for the lanes that hit: y_hit = x * (gamma^-1)^hit_i
+      Fp<NL> g0, g1;
+      gt_pow_u64<NL>(g0, g1, hit ? hit_i : 0ull, L, P);      // <4, <6 ; uses L[0] as scratch, L[1..3] = gamma^-1
+      Fp<NL> x0, x1;
+      g_load<NL>(x0, A.x0, A.sx, e);
+      g_load<NL>(x1, A.x1, A.sx, e);
+      if (A.mode == 1) {
+        fp_neg<1>(x1, x1, P);
+        fp_reduce8(x1, x1, P);
+      }
+      Fp<NL> im, t;
+      fp_mulv(im, x0, g1, P, L);                   // x0*g1 <2   (6)
+      fp_mulv(t, x1, g0, P, L);                    // x1*g0 <2   (4)
+      fp_add(im, im, t);                           // <4
+      fp_reduce8(im, im, P);
+      const long long j = (long long)hit_j;
+      const bool same = ((im.v[0] & 1u) == hit_par) || fp_is_zero_limbs(im);
+      const long long m = (long long)(hit_i * B.stride) + (same ? j : -j);
+      // full-width verification: g^|m| against x (conj(x) in the retry mode) on every limb of both components;
+      // a negative candidate stands for conj(g^|m|)
+      load_const_rows<NL>(L, B.g0, B.g1);
+      gt_pow_u64<NL>(g0, g1, hit ? (unsigned long long)(m < 0 ? -m : m) : 0ull, L, P);
+      fp_reduce8(g0, g0, P);
+      fp_reduce8(g1, g1, P);
+      if (m < 0) {
+        fp_neg<1>(g1, g1, P);
+        fp_reduce8(g1, g1, P);
+      }
+      const bool genuine = fp_eq_limbs(g0, x0) && fp_eq_limbs(g1, x1);
+      if (hit && genuine) {
+        // m is unique: whatever the genuine hit decodes to decides the attempt (out of [1, Mmax]: no log here)
+        if (m >= 1 && (unsigned long long)m <= B.Mmax) {
+          found = true;
+          result = m;
+        }
+        finished = true;
+      } else if (hit) {
+        resume = true;                              // a false hit: same giant step, behind the rejected slot
+        resume_h = hit_h;
+        i0 = hit_i;
+      }
     }
   }
   if (live && found) {                         // status / m are pre-set to "not found" by the caller

@@ -253,7 +253,11 @@ extern "C" {
 const char* bgn_last_error(void) { return g_err.c_str(); }
 // multi.cpp reports a shard's failure (raised on that shard's thread) to the calling thread through this
 void bgn_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
-const char* bgn_version(void) { return "bgn_amd 0.1 (gfx950)"; }
+#ifdef BGN_WITH_VM
+const char* bgn_version(void) { return "bgn_amd 0.2 (gfx950) +vm"; }
+#else
+const char* bgn_version(void) { return "bgn_amd 0.2 (gfx950)"; }
+#endif
 
 size_t bgn_fp_bytes(const bgn_ctx* ctx) { return ctx ? (size_t)ctx->L : 0; }
 
@@ -575,6 +579,15 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   bp.G = G;
   bp.Mmax = Mmax;
   bp.g0 = g.c0; bp.g1 = g.c1; bp.gi0 = gi.c0; bp.gi1 = gi.c1;
+  bp.key_keep = ~0ull;
+  bp.check_keep = ~0u;
+  if (const char* ev = getenv("BGN_TEST_BSGS_FP_BITS")) {        // tests: a fingerprint of only this many bits
+    const int v = atoi(ev);
+    if (v >= 1 && v < 63) {
+      bp.key_keep = (1ull << v) - 1;
+      bp.check_keep = 0u;
+    }
+  }
   c->bsgs = bp;
   uint64_t chunk = S / 65536;
   if (chunk < 1) chunk = 1;
@@ -1206,6 +1219,26 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   const size_t st = round_up(count, 64);
   SoA2 A, B, O, T1, T2;
   uint32_t* prefix = nullptr;
+  // level 1 without blinding: one kernel from wire bytes to wire bytes (k_g1_add_wire), only the prefix products
+  // of the shared inversions go through the workspace.  BGN_ADD_FUSED=0 keeps the decode / add / encode launches.
+  bool fused = level == 1 && !r_be;
+  if (const char* ev = getenv("BGN_ADD_FUSED"))
+    if (ev[0] == '0') fused = false;
+  if (fused) {
+    Ws w0(c, nullptr);
+    w0.fp(st);
+    int rc = ensure_arena(c, w0.cv.off);
+    if (rc) return rc;
+    Ws w(c, c->arena);
+    prefix = w.fp(st);
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    c->kt->g1_add_wire(s, c->d_params, c->d_consts, a, b, out, c->L, count, run_for(count), subtract ? 1 : 0, prefix, st);
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->last_kernel = "k_g1_add_wire";
+    c->ev_valid = true;
+    HIP_TRY(hipGetLastError());
+    return BGN_OK;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     if (level == 1) {
@@ -2041,6 +2074,42 @@ int bgn_check_plaintext_knowledge_batch(bgn_ctx* c, size_t count, const uint8_t*
   int rc = bgn_check_plaintext_knowledge_batch_dev(c, count, dct, dn, dc, c_len, dd, dl_len, dok, nullptr);
   if (rc) return rc;
   return S.down(ok, dok, count);
+}
+
+// Field arithmetic on its own, for the parity tests: xy holds count elements x||y
+// (L bytes each, big-endian residues below p); prod_inv[e] = x*y || x^-1 (0 for x = 0), sqr[e] = x^2 || y^2.
+int bgn_field_ops_batch(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* prod_inv, uint8_t* sqr) {
+  if (!c || (count && (!xy || !prod_inv || !sqr))) return fail(BGN_E_ARG, "null argument");
+  if (!count) return BGN_OK;
+  if (count > ((size_t)1 << 24)) return fail(BGN_E_ARG, "at most 2^24 elements");
+  std::lock_guard<std::mutex> lk(c->mu);
+  hipStream_t s = nullptr;
+  StreamOrder order(c, s);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t st = round_up(count, 64), eb = (size_t)2 * c->L * count;
+  SoA2 A{}, B{};
+  uint8_t *din = nullptr, *d1 = nullptr, *d2 = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    Ws w(c, pass ? c->arena : nullptr);
+    A = w.gt(st);
+    B = w.gt(st);
+    din = (uint8_t*)w.cv.take(eb);
+    d1 = (uint8_t*)w.cv.take(eb);
+    d2 = (uint8_t*)w.cv.take(eb);
+    if (!pass) {
+      int rc = ensure_arena(c, w.cv.off);
+      if (rc) return rc;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(din, xy, eb, hipMemcpyHostToDevice, s));
+  c->kt->field_ops(s, c->d_params, din, c->L, count, c->p_bits + 1, A, B);
+  c->kt->encode(s, nullptr, A.c0, A.c1, A.stride, c->L, count, d1);
+  c->kt->encode(s, nullptr, B.c0, B.c1, B.stride, c->L, count, d2);
+  HIP_TRY(hipMemcpyAsync(prod_inv, d1, eb, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(sqr, d2, eb, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return BGN_OK;
 }
 
 double bgn_last_aux_kernel_ms(bgn_ctx* c) {

@@ -128,6 +128,8 @@ struct BsgsParams {
   unsigned long long Mmax;          // largest accepted |m|
   const uint32_t* g0; const uint32_t* g1;     // g = e(P,P)^sk, canonical Montgomery, stride 1
   const uint32_t* gi0; const uint32_t* gi1;   // gamma^-1 = conj(g^stride), canonical Montgomery, stride 1
+  unsigned long long key_keep;      // fingerprint bits in use: all ones, ~0u in production (BGN_TEST_BSGS_FP_BITS
+  uint32_t check_keep;              // shortens them so that the tests see false hits rejected by the verification)
 };
 
 struct BsgsSearchArgs {
@@ -243,6 +245,14 @@ struct KernelTable {
   void (*poly_split)(hipStream_t s, const void* params, const PairingConsts* consts, PolySplitArgs a);
   void (*poly_combine)(hipStream_t s, const void* params, PolyCombineArgs a);
   const char* bsgs_kernel_name;
+  // field arithmetic on its own, for the parity tests: wire elements x||y -> prod_inv = (x*y, 1/x), sqr = (x^2, y^2),
+  // plain canonical SoA
+  void (*field_ops)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
+                    SoA2 prod_inv, SoA2 sqr);
+  // level-1 Add / Sub from wire bytes to wire bytes in one kernel (kernels_impl.hpp k_g1_add_wire); prefix:
+  // count F_p of workspace with limb stride sp; the grid covers ceil(count / run) lanes
+  void (*g1_add_wire)(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a, const uint8_t* b,
+                      uint8_t* out, int L, size_t count, int run, int negate_b, uint32_t* prefix, size_t sp);
 };
 
 const KernelTable* kernel_table_nl3();

@@ -7,7 +7,9 @@
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
 #include "polyops.hpp"
+#ifdef BGN_WITH_VM      // the compact-code interpreter: a kept negative result (22 % slower), opt-in at build time
 #include "vm.hpp"
+#endif
 
 namespace bgn {
 
@@ -191,8 +193,10 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     const size_t te = pair_index(op, e, mode, d1, d2);
     if (VARIANT == 1)
       miller_loop_fixed<NL>(S, L, op, fixed_tab, tab_stride, te, tab_normalized != 0, C, P);
+#ifdef BGN_WITH_VM
     else if (VARIANT == 2)
       miller_loop_vm<NL>(S, L, op, C, P);
+#endif
     else if (ws && C->wnaf_len > 0) {
       // windowed loop; its per-pairing table (dA, f_d) lives behind the three run arrays of ws
       WinTab W{ws + (size_t)3 * NL * sw, sw, e};
@@ -530,10 +534,12 @@ static void launch_pairing(hipStream_t s, const void* params, const PairingConst
     hipLaunchKernelGGL((k_pairing<NL_, 1>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab,
                        mode == 1 ? (size_t)1 : tab_stride, (mode == 1 && (variant & 2)) ? 1 : 0);
+#ifdef BGN_WITH_VM
   else if (variant == 1)
     hipLaunchKernelGGL((k_pairing<NL_, 2>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
                        (size_t)0, 0);
+#endif
   else
     hipLaunchKernelGGL((k_pairing<NL_, 0>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
@@ -762,6 +768,196 @@ static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
 }
 
 
+// ---- field arithmetic on its own (bgn_field_ops_batch: the parity tests' direct view of fp_mul / fp_sqr / the
+// division-step inversion).  in: elements x||y (L bytes each, any residues below p);
+// prod_inv[e] = x*y || x^-1 (0 for x = 0), sqr[e] = x^2 || y^2, all canonical.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_field_ops(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, int p_bits,
+            SoA2 prod_inv, SoA2 sqr) {
+  __shared__ LFp<NL> stage[2];
+  __shared__ WireStage<NL> ws;
+  const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
+  const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+  const size_t EB = (size_t)(2 * L);
+  const u32 mis = wire_stage_in<NL>(&ws, wire + e0 * EB, nel * EB);
+  if (threadIdx.x >= nel) return;
+  const size_t e = e0 + threadIdx.x;
+  const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
+  Fp<NL> x, y, xm, ym, r, o;
+  wire_to_limbs<NL>(x, src, L);
+  wire_to_limbs<NL>(y, src + L, L);
+  fp_to_mont<NL>(xm, x, P, stage);
+  fp_to_mont<NL>(ym, y, P, stage);
+  fp_mulv(r, xm, ym, P, stage);                // x*y*R <2
+  fp_from_mont<NL>(o, r, P, stage);
+  g_store<NL>(prod_inv.c0, prod_inv.stride, e, o);
+  fp_inv_mont<NL>(r, xm, p_bits, P, stage);    // R/x, canonical
+  fp_from_mont<NL>(o, r, P, stage);
+  g_store<NL>(prod_inv.c1, prod_inv.stride, e, o);
+  fp_sqrv(r, xm, P, stage);
+  fp_from_mont<NL>(o, r, P, stage);
+  g_store<NL>(sqr.c0, sqr.stride, e, o);
+  fp_sqrv(r, ym, P, stage);
+  fp_from_mont<NL>(o, r, P, stage);
+  g_store<NL>(sqr.c1, sqr.stride, e, o);
+}
+
+// ---- EAdd / ESub on level 1, wire bytes to wire bytes in ONE kernel (bgn.go:482, :419) ------------------------
+// The workgroup stages its 256 consecutive elements of a round between HBM and LDS with coalesced dword accesses
+// (codec.hpp), the lanes pick their operands out of LDS, add on plain residues (ops.hpp g1_add_run, PLAIN) and put
+// the sums back through the same stage: no SoA copy of operands or sums in HBM, no separate decode / encode
+// launches.  A lane still owns `run` elements (e = j*T + t) and shares one inversion among them, so the operands
+// are read twice (prefix pass, peel pass) and one F_p per element of prefix products goes through HBM:
+// 2*2*2L + 2*4*NL + 2L bytes per addition against 3*2L algorithmic.
+template <int NL>
+struct WireOperands {
+  Fp<NL> x1, y1, x2, y2;
+  bool i1, i2;
+};
+
+// Stage and decode the operands of round j for this workgroup.  Block-uniform control flow (barriers inside).
+template <int NL>
+__device__ __forceinline__ void g1_wire_load(WireOperands<NL>& o, WireStage<NL>* ws, const uint8_t* __restrict__ a,
+                                             const uint8_t* __restrict__ b, size_t e0, size_t nel, int L, int negate_b,
+                                             const FpParams<NL>* __restrict__ P) {
+  const size_t EB = (size_t)(2 * L);
+  const bool mine = threadIdx.x < nel;
+  u32 mis = wire_stage_in<NL>(ws, a + e0 * EB, nel * EB);
+  if (mine) {
+    const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
+    wire_to_limbs<NL>(o.x1, src, L);
+    wire_to_limbs<NL>(o.y1, src + L, L);
+  }
+  __syncthreads();
+  mis = wire_stage_in<NL>(ws, b + e0 * EB, nel * EB);
+  if (mine) {
+    const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
+    wire_to_limbs<NL>(o.x2, src, L);
+    wire_to_limbs<NL>(o.y2, src + L, L);
+  }
+  __syncthreads();
+  if (!mine) {
+    fp_zero(o.x1); fp_zero(o.y1); fp_zero(o.x2); fp_zero(o.y2);
+  }
+  o.i1 = fp_is_zero_limbs(o.x1) && fp_is_zero_limbs(o.y1);
+  o.i2 = fp_is_zero_limbs(o.x2) && fp_is_zero_limbs(o.y2);
+  if (negate_b) {
+    fp_neg<1>(o.y2, o.y2, P);
+    fp_reduce8(o.y2, o.y2, P);                  // p - 0 = p -> 0
+  }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_g1_add_wire(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, const uint8_t* __restrict__ a,
+              const uint8_t* __restrict__ b, uint8_t* __restrict__ out, int L_, size_t count, int run, int negate_b,
+              u32* __restrict__ prefix, size_t sp) {
+  __shared__ LFp<NL> L[2];
+  __shared__ WireStage<NL> ws;
+  const size_t T = (size_t)gridDim.x * FP_BLOCK;
+  const size_t EB = (size_t)(2 * L_);
+  Fp<NL> acc;
+  fp_set(acc, P->one);
+  // pass 1: prefix products of the denominators (acc_0 = R: see g1_add_run on the PLAIN representation)
+#pragma unroll 1
+  for (int j = 0; j < run; ++j) {
+    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
+    if (e0 >= count) break;                                        // block-uniform
+    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+    WireOperands<NL> o;
+    g1_wire_load<NL>(o, &ws, a, b, e0, nel, L_, negate_b, P);
+    if (threadIdx.x < nel) {
+      Fp<NL> d;
+      g1_classify<NL, true>(d, o.x1, o.y1, o.i1, o.x2, o.y2, o.i2, P);
+      g_store(prefix, sp, e0 + threadIdx.x, acc);
+      l_store(L, acc);
+      fp_mul(acc, L, d, P);                     // <2
+    }
+  }
+  Fp<NL> inv;
+  fp_inv<NL>(inv, acc, L, C, P);                // <1
+  // pass 2: walk back, peel one inverse per element, write the sums as wire bytes
+#pragma unroll 1
+  for (int j = run - 1; j >= 0; --j) {
+    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
+    if (e0 >= count) continue;                                     // block-uniform
+    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+    WireOperands<NL> o;
+    g1_wire_load<NL>(o, &ws, a, b, e0, nel, L_, negate_b, P);
+    uint8_t* g = out + e0 * EB;
+    if (threadIdx.x < nel) {
+      Fp<NL> d;
+      const int cs = g1_classify<NL, true>(d, o.x1, o.y1, o.i1, o.x2, o.y2, o.i2, P);
+      Fp<NL> dinv;
+      {
+        Fp<NL> pf;
+        g_load(pf, prefix, sp, e0 + threadIdx.x);
+        l_store(L, inv);
+        fp_mul(dinv, L, pf, P);                 // R^2/d <2
+        fp_mul(inv, L, d, P);                   // inverse of the shorter prefix <2
+      }
+      Fp<NL> num;
+      fp_sub<1>(num, o.y2, o.y1, P);            // <2
+      if (__ballot(cs == G1C_DBL)) {            // doubling numerator 3*x1^2 + 1 (rare)
+        Fp<NL> xx, t3, one;
+        fp_to_mont<NL>(t3, o.x1, P, L + 1);
+        fp_mulv(xx, t3, o.x1, P, L + 1);        // x1^2, plain <2
+        fp_dbl(t3, xx);
+        fp_add(t3, t3, xx);                     // <6
+        fp_zero(one);
+        one.v[0] = 1;
+        fp_add(t3, t3, one);                    // <7
+        fp_select(num, cs == G1C_DBL, t3, num);
+      }
+      l_store(L + 1, dinv);
+      Fp<NL> lam, lp, x3, y3;
+      fp_mul(lam, L + 1, num, P);               // lambda*R <2
+      fp_from_mont<NL>(lp, lam, P, L + 1);      // lambda, plain <1 ; L1 = lambda*R
+      fp_mul(x3, L + 1, lp, P);                 // lambda^2, plain <2
+      fp_sub<1>(x3, x3, o.x1, P);               // <3
+      fp_sub<1>(x3, x3, o.x2, P);               // <4
+      fp_sub<4>(y3, o.x1, x3, P);               // <5
+      fp_mul(y3, L + 1, y3, P);                 // <2
+      fp_sub<1>(y3, y3, o.y1, P);               // <3
+      const bool isA = cs == G1C_A, isB = cs == G1C_B;
+      fp_select(x3, isA, o.x1, x3);
+      fp_select(y3, isA, o.y1, y3);
+      fp_select(x3, isB, o.x2, x3);
+      fp_select(y3, isB, o.y2, y3);
+      Fp<NL> ox, oy;
+      fp_reduce8(ox, x3, P);
+      fp_reduce8(oy, y3, P);
+      if (cs == G1C_INF) {
+        fp_zero(ox);
+        fp_zero(oy);
+      }
+      uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
+      limbs_to_wire<NL>(dst, L_, ox);
+      limbs_to_wire<NL>(dst + L_, L_, oy);
+    }
+    wire_stage_out<NL>(&ws, g, nel * EB);
+    __syncthreads();
+  }
+}
+
+static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
+                             SoA2 prod_inv, SoA2 sqr) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_field_ops<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire, L,
+                     count, p_bits, prod_inv, sqr);
+}
+
+static void launch_g1_add_wire(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a,
+                               const uint8_t* b, uint8_t* out, int L, size_t count, int run, int negate_b,
+                               uint32_t* prefix, size_t sp) {
+  if (!count) return;
+  const size_t lanes = (count + run - 1) / run;
+  hipLaunchKernelGGL(k_g1_add_wire<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts,
+                     a, b, out, L, count, run, negate_b, prefix, sp);
+}
+
+
 const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {
       NL_,
@@ -796,6 +992,8 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_poly_split,
       launch_poly_combine,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
+      launch_field_ops,
+      launch_g1_add_wire,
   };
   return &t;
 }

@@ -264,6 +264,13 @@ int bgn_mdecrypt_batch_dev(bgn_mctx* m, size_t count, int level, const uint8_t* 
 int bgn_mpoly_mult_batch_dev(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
                              uint8_t* out, int root);
 
+/* ---- diagnostics ------------------------------------------------------------------------------------------
+ * Field arithmetic on its own (Montgomery product, squaring, division-step inversion of csrc/fp28.hpp and
+ * fpinv.hpp — what stands in for the mpz / PBC field calls behind every pbc.Element method),
+ * so that parity tests can compare it with big-integer arithmetic directly.  xy: count elements x||y, L bytes
+ * each, residues below p; prod_inv[e] = x*y || x^-1 (0 for x = 0); sqr[e] = x^2 || y^2; host buffers. */
+int bgn_field_ops_batch(bgn_ctx* ctx, size_t count, const uint8_t* xy, uint8_t* prod_inv, uint8_t* sqr);
+
 /* ---- measurement hooks (used by bench.py; not part of the drop-in surface) --- */
 /* Milliseconds spent in the dominant kernel of the most recent *_dev call on
  * this context, measured with HIP events on the stream it ran on; blocks until

@@ -390,9 +390,14 @@ def test_mult_runs_with_shared_inversion():
 
 
 def test_interpreter_variant_matches(monkeypatch):
-    """BGN_PAIRING_VM=1 routes Mult through the compact-code interpreter (vm.hpp): same bytes."""
+    """BGN_PAIRING_VM=1 routes Mult through the compact-code interpreter (vm.hpp): same bytes.  The interpreter
+    is a kept negative result and out of the default build (make CXXFLAGS+=-DBGN_WITH_VM puts it back); the host
+    emulator keeps its step programs covered (tests/test_emu_kernels.py)."""
     fx = load_fixture("k512")
     pk, _ = engine_key(fx)
+    if b"+vm" not in pk.engine._lib.bgn_version():
+        pytest.skip("library built without the interpreter variant")
+    monkeypatch.setenv("BGN_COOP_MAX", "0")
     cts = [e["ct"] for e in fx["encrypt"]]
     a = H([cts[v["a"]] for v in fx["mult"]])
     b = H([cts[v["b"]] for v in fx["mult"]])

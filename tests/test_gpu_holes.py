@@ -173,9 +173,9 @@ def test_decrypt_2_16_negatives_and_out_of_range_vs_known_and_c_oracle():
 
 
 # ---------------------------------------------------------------- BSGS: verification of table hits
-@pytest.mark.parametrize("bits", [6, 12])
+@pytest.mark.parametrize("bits", [10, 14])
 def test_bsgs_false_hits_are_rejected_by_the_full_width_check(bits, monkeypatch):
-    """With the table fingerprint cut to a few bits nearly every probe finds a slot whose short fingerprint matches;
+    """With the table fingerprint cut to a few bits a few probes of every walk find a slot whose short fingerprint matches;
     the candidate is verified by g^m == csk on every limb, a false hit resumes the walk behind the rejected slot,
     and the results are the plaintexts (gsbs.go:83,90 compare whole elements)."""
     import bgn_amd

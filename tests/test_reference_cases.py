@@ -172,9 +172,21 @@ def test_decryption_proof_bad(keys):                                # gadgets_te
     assert not pk.CheckDecryptionProof(ct, bgn_amd.NewDecryptionProof(r2, r))               # wrong value
 
 
+@pytest.fixture(scope="module")
+def keys_with_r():
+    """The prover needs SecretKey.R (gadgets.go:46), which the committed fixture key does not record: a fresh
+    seeded 512-bit key from the oracle's restatement of NewKeyGen (bgn.go:65-138), same constants."""
+    import bgn_amd
+    import bgn_ref as R
+    opk, osk = R.NewKeyGen(KEYBITS, MSGSPACE, POLYBASE, DET, 2025)
+    pk = bgn_amd.PublicKey(opk.p, opk.n, opk.l, R.elem_to_bytes(opk.P, opk.p), R.elem_to_bytes(opk.Q, opk.p), MSGSPACE,
+                           DET, POLYBASE)
+    return pk, bgn_amd.SecretKey(osk.Key, osk.R)
+
+
 @pytest.mark.gpu
-def test_proof_of_plaintext_knowledge_valid(keys):                  # gadgets_test.go:70-84
-    pk, sk, _ = keys
+def test_proof_of_plaintext_knowledge_valid(keys_with_r):           # gadgets_test.go:70-84
+    pk, sk = keys_with_r
     rng = random.Random(504)
     r, v = rng.randrange(pk.N), rng.randrange(pk.N)
     ct = pk.EncryptWithRandomness(v, r)
@@ -183,8 +195,8 @@ def test_proof_of_plaintext_knowledge_valid(keys):                  # gadgets_te
 
 
 @pytest.mark.gpu
-def test_proof_of_plaintext_knowledge_bad(keys):                    # gadgets_test.go:85-105
-    pk, sk, _ = keys
+def test_proof_of_plaintext_knowledge_bad(keys_with_r):             # gadgets_test.go:85-105
+    pk, sk = keys_with_r
     rng = random.Random(505)
     r, r2, v = (rng.randrange(pk.N) for _ in range(3))
     ct = pk.EncryptWithRandomness(v, r)

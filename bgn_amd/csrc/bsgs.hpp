@@ -354,25 +354,29 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
         fp_neg<1>(x1, x1, P);
         fp_reduce8(x1, x1, P);
       }
-      Fp<NL> im, t;
+      Fp<NL> im, re, t;
       fp_mulv(im, x0, g1, P, L);                   // x0*g1 <2   (6)
       fp_mulv(t, x1, g0, P, L);                    // x1*g0 <2   (4)
       fp_add(im, im, t);                           // <4
       fp_reduce8(im, im, P);
+      fp_mulv(re, x0, g0, P, L);                   // x0*g0 <2
+      fp_mulv(t, x1, g1, P, L);                    // x1*g1 <2
+      fp_sub<2>(re, re, t, P);                     // <4
+      fp_reduce8(re, re, P);
       const long long j = (long long)hit_j;
       const bool same = ((im.v[0] & 1u) == hit_par) || fp_is_zero_limbs(im);
       const long long m = (long long)(hit_i * B.stride) + (same ? j : -j);
-      // full-width verification: g^|m| against x (conj(x) in the retry mode) on every limb of both components;
-      // a negative candidate stands for conj(g^|m|)
+      // full-width verification: y_hit = x * gamma^-i must BE the baby step the slot stands for, g^j (its
+      // conjugate when the parities differ), on every limb of both components
       load_const_rows<NL>(L, B.g0, B.g1);
-      gt_pow_u64<NL>(g0, g1, hit ? (unsigned long long)(m < 0 ? -m : m) : 0ull, L, P);
+      gt_pow_u64<NL>(g0, g1, hit ? (unsigned long long)hit_j : 0ull, L, P);
       fp_reduce8(g0, g0, P);
       fp_reduce8(g1, g1, P);
-      if (m < 0) {
+      if (!same) {
         fp_neg<1>(g1, g1, P);
         fp_reduce8(g1, g1, P);
       }
-      const bool genuine = fp_eq_limbs(g0, x0) && fp_eq_limbs(g1, x1);
+      const bool genuine = fp_eq_limbs(g0, re) && fp_eq_limbs(g1, im);
       if (hit && genuine) {
         // m is unique: whatever the genuine hit decodes to decides the attempt (out of [1, Mmax]: no log here)
         if (m >= 1 && (unsigned long long)m <= B.Mmax) {

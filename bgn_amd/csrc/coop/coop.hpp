@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../fp28.hpp"
+#include "../fpinv.hpp"
 #include "../kernels.hpp"
 
 namespace bgn {
@@ -176,12 +177,21 @@ __device__ __forceinline__ u32 coop_canonical(u32 x, const CoopLane<NL>& c) {
   return top < 0 ? (u32)acc : (u32)d;
 }
 
+// Words of workspace per pairing of the three-launch form: the parked F0^2, F1^2, F0*F1 (64 lanes each) ...
+constexpr int COOP_PARK_WORDS = 3 * 64;
+
 // One pairing per workgroup of COOP_W waves.  Operands: canonical Montgomery SoA; result: plain canonical SoA
 // (what k_pairing<NL, 0> reads and writes).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point.
+// phase 0: the whole pairing, the inversion of the final exponentiation by Fermat on the waves (bits(p) rounds).
+// phase 1 / 2: the Miller loop and the norms, parked in `park` with N(f) written as tight limbs to nsoa —
+// then k_coop_invert inverts all the norms of the batch with the division steps of fpinv.hpp, one per lane, at
+// the cost of ~40 products instead of a chain of bits(p) — and the rest of the final exponentiation from the
+// parked values and the inverse in isoa (limb stride `ws`).
 template <int NL>
 __global__ void __launch_bounds__(COOP_BLOCK)
 k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
-               size_t count, int mode) {
+               size_t count, int mode, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
+               const u32* __restrict__ isoa, size_t ws) {
   __shared__ u32 V[COOP_NSLOTS][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -219,13 +229,14 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     V[COOP_SLOT_V0_0][lane] = o;
     V[COOP_SLOT_V2_0][lane] = o;
   }
+  int par = 0;
+  if (phase != 2) {
   __syncthreads();
   // Miller loop over the NAF of n (pairing.hpp miller_loop); the state ping-pongs between two slot sets
   // (steps scheduled as segments: a doubling and the addition of +-A that follows it, two consecutive plain
   // doublings, or one doubling; the last addition is skipped as in PBC)
   const u32* nafw = reinterpret_cast<const u32*>(C->naf);       // digits through dword loads (no scalar byte loads)
   auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
-  int par = 0;
   int i = C->naf_len - 2;
 #pragma unroll 1
   while (i >= 0) {
@@ -244,16 +255,40 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     coop_run<NL>(V, seg + 4 * par, wave, c);
     par ^= 1;
   }
-  // final exponentiation: N = F0^2 + F1^2, 1/N = N^(p-2), h = conj(f)^2/N, g = h^l
+  // final exponentiation: N = F0^2 + F1^2, 1/N, h = conj(f)^2/N, g = h^l
   coop_run<NL>(V, COOP_SEG_NORM0 + par, wave, c);
-  coop_run<NL>(V, COOP_SEG_INV0, wave, c);
-  // (right to left: the squaring chain and the running product advance in the same round on two waves)
+  }
   int ip = 0;
+  if (phase == 1) {
+    // park F0^2, F1^2, F0*F1 and hand N(f) = F0^2 + F1^2 to the inversion kernel as tight limbs (< 4p)
+    if (wave < 3) {
+      const int slot = wave == 0 ? COOP_SLOT_N1 : wave == 1 ? COOP_SLOT_N2 : COOP_SLOT_FM;
+      park[(e * 3 + wave) * 64 + lane] = V[slot][lane];
+    } else {
+      long long acc = (long long)(int)V[COOP_SLOT_N1][lane] + (long long)(int)V[COOP_SLOT_N2][lane];
 #pragma unroll 1
-  for (int i = 0; i < C->pm2_bits; ++i) {
-    const u32 bit = (C->pm2[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u;
-    coop_run<NL>(V, (bit ? COOP_SEG_IMU0 : COOP_SEG_ISQ0) + 2 * ip, wave, c);
-    ip ^= 1;
+      for (int k = 0; k < NL; ++k) acc = (long long)(int)coop_normalize<NL>(acc, c);
+      if (in) nsoa[(size_t)lj * ws + e] = (u32)acc;
+    }
+    return;
+  }
+  if (phase == 2) {
+    if (wave < 3) {
+      const int slot = wave == 0 ? COOP_SLOT_N1 : wave == 1 ? COOP_SLOT_N2 : COOP_SLOT_FM;
+      V[slot][lane] = park[(e * 3 + wave) * 64 + lane];
+    } else {
+      V[COOP_SLOT_ACC_0][lane] = in ? isoa[(size_t)lj * ws + e] : 0u;
+    }
+    __syncthreads();
+  } else {
+    // 1/N = N^(p-2), right to left: the squaring chain and the running product advance in the same round
+    coop_run<NL>(V, COOP_SEG_INV0, wave, c);
+#pragma unroll 1
+    for (int i = 0; i < C->pm2_bits; ++i) {
+      const u32 bit = (C->pm2[i / LIMB_BITS] >> (i % LIMB_BITS)) & 1u;
+      coop_run<NL>(V, (bit ? COOP_SEG_IMU0 : COOP_SEG_ISQ0) + 2 * ip, wave, c);
+      ip ^= 1;
+    }
   }
   coop_run<NL>(V, COOP_SEG_H0 + ip, wave, c);
   int lp = 0;
@@ -275,6 +310,23 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     u32* dst = wave == 0 ? out.c0 : out.c1;
     if (in) dst[(size_t)lj * out.stride + e] = r;
   }
+}
+
+// The norms of a batch inverted one per lane by the division steps (fpinv.hpp): nsoa holds N < 4p as tight limbs
+// (Montgomery form), isoa receives R/N canonical; limb stride ws.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_coop_invert(const FpParams<NL>* __restrict__ P, const u32* __restrict__ nsoa, u32* __restrict__ isoa, size_t ws,
+              size_t count, int p_bits) {
+  __shared__ LFp<NL> stage;
+  size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const bool live = e < count;
+  if (!__ballot(live)) return;
+  if (!live) e = count - 1;
+  Fp<NL> x, r;
+  g_load<NL>(x, nsoa, ws, e);
+  fp_inv_mont<NL>(r, x, p_bits, P, &stage);
+  if (live) g_store<NL>(isoa, ws, e, r);
 }
 
 }  // namespace bgn

@@ -6,7 +6,11 @@ namespace bgn {
 // out[e] = e(a[e], b[e]) (mode 0) or e(a[e], b[0]) (mode 1) for e < count, one workgroup per pairing; operands
 // canonical Montgomery SoA, results plain canonical SoA, as KernelTable::pairing.  Returns false when `nl` has no
 // instantiation.
+// ws: workspace of coop_ws_words(nl, sw) u32 (sw >= count, the limb stride of its arrays) — the pairing then runs
+// as Miller-loop kernel, batched inversion of the norms (division steps, one per lane), final-exponentiation
+// kernel; ws == nullptr: one launch with the Fermat inversion on the waves.
 bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                         size_t count, int mode);
+                         size_t count, int mode, uint32_t* ws, size_t sw, int p_bits);
+size_t coop_ws_words(int nl, size_t sw);
 const char* coop_pairing_kernel_name(int nl);
 }  // namespace bgn

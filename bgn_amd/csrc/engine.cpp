@@ -680,7 +680,10 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
-  probe.take((size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4);
+  const bool coop = mode <= 1 && count <= coop_limit(c, mode);
+  const size_t lane_ws = (size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4;
+  const size_t ws_bytes = coop ? coop_ws_words(c->nl, so) * 4 : lane_ws;
+  probe.take(ws_bytes);
   if (r_be) {
     probe.soa(c->nl, so, false);
     probe.soa(c->nl, so, false);
@@ -691,7 +694,7 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   SoA2 A = cv.soa(c->nl, sa, true);
   SoA2 B = nb ? cv.soa(c->nl, sb, true) : c->key_P();
   SoA2 O = cv.soa(c->nl, so, false);
-  uint32_t* ws = (uint32_t*)cv.take((size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4);   // room for the windowed loop's (dA, f_d)
+  uint32_t* ws = (uint32_t*)cv.take(ws_bytes);   // lane kernel: room for the windowed loop's (dA, f_d)
   SoA2 T1{}, T2{};
   if (r_be) {
     T1 = cv.soa(c->nl, so, false);
@@ -700,8 +703,10 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  if (mode <= 1 && count <= coop_limit(c, mode) &&
-      coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode)) {
+  // BGN_COOP_FERMAT=1: the one-launch form with the Fermat inversion on the waves (A/B measurements)
+  const char* cf = getenv("BGN_COOP_FERMAT");
+  if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode,
+                                  (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1)) {
     c->last_kernel = coop_pairing_kernel_name(c->nl);
   } else {
     kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,

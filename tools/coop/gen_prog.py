@@ -376,7 +376,8 @@ def emit(P, path):
     lines.append("#define COOP_W %d" % W)
     lines.append("#define COOP_NSLOTS %d" % P.nslots)
     lines.append("#define COOP_MAX_TERMS %d" % MAX_TERMS)
-    for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "v0@0", "v1@0", "v2@0"):
+    for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "v0@0", "v1@0", "v2@0",
+                  "n1", "n2", "fm", "acc@0"):
         lines.append("#define COOP_SLOT_%s %d" % (gname.replace("@", "_").upper(), P.phys[gname]))
     lines.append("enum CoopSeg {")
     for i, (name, _) in enumerate(P.segments):

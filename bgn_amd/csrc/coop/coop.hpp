@@ -111,30 +111,34 @@ __device__ __forceinline__ int coop_mul(u32 a, u32 b, const CoopLane<NL>& c) {
   return (int)acc;
 }
 
-// The two operand sums of a product with their LDS reads issued together: terms 0 and 1 of both unconditionally
-// (an unused term has coefficient 0 and reads slot 0), the rare third terms under a wave-uniform branch.
+// The two operand sums of a product.  Most operands are ONE stored value taken as it is (coefficient 1, no
+// multiple of p: the generator marks them in bit 8 / 9 of word 0): such a value was normalised when it was
+// stored and is used without a multiply-add or a carry pass.  Otherwise terms 0 and 1 are read together (an
+// unused term has coefficient 0 and reads slot 0) and the rare third term under a wave-uniform branch.
+template <int NL>
+__device__ __forceinline__ u32 coop_operand(const u32 (*V)[64], bool plain, u32 idx, u32 cf, int K, const CoopLane<NL>& c) {
+  const int v0 = (int)V[idx & 0xFFu][c.lane];
+  if (plain) return (u32)v0;
+  const int v1 = (int)V[(idx >> 8) & 0xFFu][c.lane];
+  long long s = (long long)K * (long long)c.p;
+  s += (long long)(int)(signed char)(cf & 0xFFu) * (long long)v0;
+  s += (long long)(int)(signed char)((cf >> 8) & 0xFFu) * (long long)v1;
+  if (cf & 0xFF0000u) {
+    const int v2 = (int)V[(idx >> 16) & 0xFFu][c.lane];
+    s += (long long)(int)(signed char)((cf >> 16) & 0xFFu) * (long long)v2;
+  }
+  return coop_normalize<NL>(s, c);
+}
+
 template <int NL>
 __device__ __forceinline__ void coop_operands(u32& a, u32& b, const u32 (*V)[64], const CoopWords& u, const CoopLane<NL>& c) {
-  const int a0 = (int)V[u.w[2] & 0xFFu][c.lane], a1 = (int)V[(u.w[2] >> 8) & 0xFFu][c.lane];
-  const int b0 = (int)V[u.w[4] & 0xFFu][c.lane], b1 = (int)V[(u.w[4] >> 8) & 0xFFu][c.lane];
-  long long sa = (long long)(int)((u.w[1] >> 8) & 0xFFu) * (long long)c.p;
-  long long sb = (long long)(int)((u.w[1] >> 16) & 0xFFu) * (long long)c.p;
-  sa += (long long)(int)(signed char)(u.w[3] & 0xFFu) * (long long)a0;
-  sb += (long long)(int)(signed char)(u.w[5] & 0xFFu) * (long long)b0;
-  sa += (long long)(int)(signed char)((u.w[3] >> 8) & 0xFFu) * (long long)a1;
-  sb += (long long)(int)(signed char)((u.w[5] >> 8) & 0xFFu) * (long long)b1;
-  if ((u.w[3] | u.w[5]) & 0xFF0000u) {
-    const int a2 = (int)V[(u.w[2] >> 16) & 0xFFu][c.lane], b2 = (int)V[(u.w[4] >> 16) & 0xFFu][c.lane];
-    sa += (long long)(int)(signed char)((u.w[3] >> 16) & 0xFFu) * (long long)a2;
-    sb += (long long)(int)(signed char)((u.w[5] >> 16) & 0xFFu) * (long long)b2;
-  }
-  a = coop_normalize<NL>(sa, c);
-  b = coop_normalize<NL>(sb, c);
+  a = coop_operand<NL>(V, (u.w[0] & 0x100u) != 0, u.w[2], u.w[3], (int)((u.w[1] >> 8) & 0xFFu), c);
+  b = coop_operand<NL>(V, (u.w[0] & 0x200u) != 0, u.w[4], u.w[5], (int)((u.w[1] >> 16) & 0xFFu), c);
 }
 
 template <int NL>
 __device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, const CoopLane<NL>& c) {
-  const int kind = (int)(u.w[0] & 0xFFu);
+  const int kind = (int)(u.w[0] & 0x0Fu);
   if (kind == 0) return;
   const int ne = (int)(u.w[1] & 0xFFu);
   long long t;
@@ -146,7 +150,7 @@ __device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, cons
   } else {
     t = coop_combo<NL>(V, ne, u.w[6], u.w[7], (int)(u.w[1] >> 24), c);
   }
-  V[(u.w[0] >> 8) & 0xFFu][c.lane] = coop_normalize<NL>(t, c);
+  V[(u.w[0] >> 16) & 0xFFu][c.lane] = coop_normalize<NL>(t, c);
 }
 
 // One segment: its rounds in order, a workgroup barrier after each; the next round's micro-op is fetched while

@@ -388,8 +388,9 @@ def emit(P, path):
                  ", ".join(str(seg_index[n][0]) for n, _ in P.segments))
     lines.append("static __device__ const unsigned int kCoopSegRounds[COOP_NSEG] = {%s};" %
                  ", ".join(str(seg_index[n][1]) for n, _ in P.segments))
-    lines.append("// eight dwords per micro-op (scalar loads have no byte form): kind | dst<<8 | na<<16 | nb<<24, "
-                 "ne | KA<<8 | KB<<16 | KE<<24,")
+    lines.append("// eight dwords per micro-op (scalar loads have no byte form): kind | A plain<<8 | B plain<<9 | dst<<16 | "
+                 "nb<<24, ne | KA<<8 | KB<<16 | KE<<24,")
+    lines.append("// (\"plain\": the operand is one stored value with coefficient 1 and no multiple of p, used as it is)")
     lines.append("// then slot indices and signed coefficients of A, B, E, four bytes each; kind: 0 nop, 1 mul, 2 lin")
     lines.append("alignas(32) static __device__ const unsigned int kCoopProg[%d][8] = {" % (rnd * W))
 
@@ -410,7 +411,9 @@ def emit(P, path):
             ne, ie, ce = terms(u.E)
             assert max(u.KA, u.KB, u.KE) <= 255
             pk = lambda v: sum((x & 0xFF) << (8 * i) for i, x in enumerate(v))
-            words = [pk([1 if u.kind == "mul" else 2, P.phys[u.dst], na, nb]), pk([ne, u.KA, u.KB, u.KE]),
+            plain = lambda f, K: int(f is not None and len(f) == 1 and list(f.values())[0] == 1 and K == 0)
+            w0 = (1 if u.kind == "mul" else 2) | plain(u.A, u.KA) << 8 | plain(u.B, u.KB) << 9 | P.phys[u.dst] << 16 | nb << 24
+            words = [w0, pk([ne, u.KA, u.KB, u.KE]),
                      pk(ia), pk(ca), pk(ib), pk(cb), pk(ie), pk(ce)]
             lines.append("  {%s},   // r%d %s" % (", ".join("0x%08xu" % w for w in words), r, u.dst))
     lines.append("};")

@@ -636,8 +636,11 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
 // The crossovers come from the committed sweep profiles/r02_small_batch.csv; BGN_COOP_MAX / BGN_COOP_MAX_L2
 // override them (0 disables the kernel).
 static size_t coop_limit(const bgn_ctx* c, int mode) {
-  const char* ev = getenv(mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
+  const char* ev = getenv(mode == 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
+  // mode 2: the lift of Decrypt, whose lane kernel walks the half-length table of the secret order (37 ms at
+  // 1024 bits, 5 ms at 512): the cooperative kernel (a whole e(C, P)) wins below ~2000 / ~800 ciphertexts
+  if (mode == 2) return c->nl >= 38 ? 2000 : c->nl >= 19 ? 800 : 512;
   // profiles/r02_small_batch.csv (MI355X): Mult at 1024 bits — 8192 pairings 121 ms cooperative against 164 ms,
   // 16384: 237 against 164; at 512 bits — 4096: 17.9 against 28.0 ms, 8192: 33.9 against 28.1.  makeL2 (the lane
   // kernel walks P's line table there, a third of the products): 1024 bits — 2048: 34 against 54 ms, 4096: 63
@@ -1574,7 +1577,10 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     A = (level == 1) ? w.g1(st) : w.gt(st);
     X = w.gt(st);
     Y = w.gt(st);
-    if (level == 1) pws = (uint32_t*)w.cv.take((size_t)3 * c->nl * st * 4);
+    if (level == 1) {
+      const size_t lane_b = (size_t)3 * c->nl * st * 4, coop_b = coop_ws_words(c->nl, st) * 4;
+      pws = (uint32_t*)w.cv.take(count <= coop_limit(c, 2) && coop_b > lane_b ? coop_b : lane_b);
+    }
     todo = (uint32_t*)w.cv.take(st * 4);
     todo_count = (uint32_t*)w.cv.take(256);
     if (!pass) {
@@ -1590,11 +1596,19 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
     const bool sk_tab = c->d_fixedpair_sk != nullptr;
     HIP_TRY(hipEventRecord(c->ev2, s));
-    kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
-                pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
+    // a small batch lifts with the wave-cooperative kernel: e(C, P) over all of n in a few milliseconds, against
+    // the latency of one whole table loop on a single lane (28 ms at a 1024-bit key); the power by q1 below
+    // gives the same e(C, P)^q1 either way
+    if (count <= coop_limit(c, 2) &&
+        coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, pws, st, c->p_bits + 1)) {
+      c->aux_kernel = coop_pairing_kernel_name(c->nl);
+    } else {
+      kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
+                  pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
+      c->aux_kernel = c->nl == 38 ? "k_pairing<38, 1>" : c->nl == 19 ? "k_pairing<19, 1>" : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
+    }
     HIP_TRY(hipEventRecord(c->ev3, s));
     c->ev2_valid = true;
-    c->aux_kernel = c->nl == 38 ? "k_pairing<38, 1>" : c->nl == 19 ? "k_pairing<19, 1>" : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }

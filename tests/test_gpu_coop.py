@@ -76,3 +76,35 @@ def test_coop_single_pairing_count_one(monkeypatch):
     out = pk.engine.mult(bytes.fromhex(cts[v["a"]]), bytes.fromhex(cts[v["b"]]))
     assert "coop" in pk.engine.last_kernel_name()
     assert bytes(out[0]).hex() == v["out"]
+
+
+@pytest.mark.parametrize("name", ["k256", "k512", "k1024"])
+def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch):
+    """Decrypt of a few level-1 ciphertexts lifts with the cooperative kernel (e(C, P) in full) instead of the
+    lane kernel's walk over the secret order's table: same plaintexts and statuses, negatives and an
+    out-of-range value included (bgn.go:218-250)."""
+    fx = load_fixture(name)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng = pk.engine
+    T = fx["msg_space"]
+    rng = random.Random(8)
+    n = int(fx["n"], 16)
+    ms = [0, 1, T - 1, 5 % T, 3 * T + 11] + [rng.randrange(T) for _ in range(20)]
+    cts = eng.encrypt(ms, [rng.randrange(n) for _ in ms])
+    cts[3] = eng.neg(1, cts[3:4])[0]
+    monkeypatch.setenv("BGN_COOP_MAX_DEC", "100000")
+    m1, s1 = eng.decrypt(1, cts.tobytes())
+    assert "coop" in eng.last_aux_kernel_name()
+    monkeypatch.setenv("BGN_COOP_MAX_DEC", "0")
+    m0, s0 = eng.decrypt(1, cts.tobytes())
+    assert "coop" not in eng.last_aux_kernel_name()
+    assert m1.tolist() == m0.tolist() and s1.tolist() == s0.tolist()
+    want = list(ms)
+    want[3] = -want[3]
+    for got, st, w in zip(m1.tolist(), s1.tolist(), want):
+        B = int(T ** 0.5) + (0 if int(T ** 0.5) ** 2 == T else 1)
+        if abs(w) > B * B + B + 2:
+            assert st == 1
+        else:
+            assert st == 0 and got == w

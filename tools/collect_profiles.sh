@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the measurements profiles/README.md lists for this round.
+#   tools/collect_profiles.sh OUTDIR
+# rocprofv3 is given the program itself (python3 bench.py ...), never a launcher; counter passes are separate
+# from each other and carry no trace other than the kernel trace.
+set -o pipefail
+OUT=${1:-gpurun_out/r02_profiles}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+echo "== bench (default line)"; python3 bench.py --steps 3 --warmup 1 > "$OUT/bench_line.json" 2> "$OUT/bench.err" || exit 1
+echo "== kernel stats, headline only"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/bench_line_profiled.json" 2> "$OUT/prof_bench.err" || exit 1
+echo "== kernel stats, extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_extra" -o extra -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/extra_line_profiled.json" 2> "$OUT/prof_extra.err" || exit 1
+echo "== PMC FETCH_SIZE"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || exit 1
+echo "== PMC WRITE_SIZE"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || exit 1
+echo "== small-batch sweep"; python3 tools/small_batch_sweep.py > "$OUT/small_batch.csv" 2> "$OUT/sweep.err" || exit 1
+find "$OUT" -name "*.csv" | head -40
+# keep the merge small: the raw traces are not needed
+find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
+du -sh "$OUT"

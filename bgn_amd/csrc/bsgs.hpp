@@ -368,8 +368,33 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       const long long m = (long long)(hit_i * B.stride) + (same ? j : -j);
       // full-width verification: y_hit = x * gamma^-i must BE the baby step the slot stands for, g^j (its
       // conjugate when the parities differ), on every limb of both components
-      load_const_rows<NL>(L, B.g0, B.g1);
-      gt_pow_u64<NL>(g0, g1, hit ? (unsigned long long)hit_j : 0ull, L, P);
+      if (B.vtab) {
+        // g^j as the product of one table entry per byte of j (12 products instead of a 31-bit power)
+        AFp<NL> A0, A1;
+        {
+          Fp<NL> t1;
+          fp_set(t1, P->one);
+          a_store(A0, t1);
+          fp_zero(t1);
+          a_store(A1, t1);
+        }
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+          const u32 dgt = hit ? ((hit_j >> (8 * w)) & 0xFFu) : 0u;
+          if (__ballot(dgt != 0)) {
+            const u32* ent = B.vtab + ((((size_t)w) << 8) + dgt) * (size_t)(2 * NL);
+            Fp<NL> b0, b1;
+            v_load2(b0, b1, ent);
+            gt_set_multiplier<NL>(L, b0, b1);
+            gt_acc_mul<NL>(A0, A1, dgt != 0, L, P);
+          }
+        }
+        a_load(g0, A0);
+        a_load(g1, A1);
+      } else {
+        load_const_rows<NL>(L, B.g0, B.g1);
+        gt_pow_u64<NL>(g0, g1, hit ? (unsigned long long)hit_j : 0ull, L, P);
+      }
       fp_reduce8(g0, g0, P);
       fp_reduce8(g1, g1, P);
       if (!same) {

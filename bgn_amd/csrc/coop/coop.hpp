@@ -12,8 +12,8 @@
 //     multiply-adds in one lane;
 //   * limbs are signed and lazily normalised (one carry pass per operand; values stay >= 0 because every
 //     subtraction adds a multiple of p chosen from static bounds), so additions and subtractions are lane-local;
-//   * the independent products of a step program run on the four waves at once: tools/coop/gen_prog.py
-//     schedules every segment of the pairing into rounds of at most four micro-ops
+//   * the independent products of a step program run on the waves at once: tools/coop/gen_prog.py
+//     schedules every segment of the pairing into rounds of micro-ops, one per wave (COOP_W waves per pairing)
 //         dst = (sum ca*V[ia] + KA*p) * (sum cb*V[ib] + KB*p) / R + sum ce*V[ie] + KE*p
 //     over value slots V[] in LDS, with a workgroup barrier between rounds (a Miller doubling step: 18
 //     products in 5 rounds; an addition step: 17 in 6).  This file interprets those tables.
@@ -227,7 +227,7 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     const u32 o = in ? P->one[lj] : 0u;
     V[COOP_SLOT_ONE][lane] = o;
     V[COOP_SLOT_Z_0][lane] = o;
-  } else {
+  } else if (wave == 3) {
     V[COOP_SLOT_BY][lane] = in ? b.c1[(size_t)lj * b.stride + eb] : 0u;
     const u32 o = in ? P->one[lj] : 0u;
     V[COOP_SLOT_V0_0][lane] = o;
@@ -268,7 +268,7 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     if (wave < 3) {
       const int slot = wave == 0 ? COOP_SLOT_N1 : wave == 1 ? COOP_SLOT_N2 : COOP_SLOT_FM;
       park[(e * 3 + wave) * 64 + lane] = V[slot][lane];
-    } else {
+    } else if (wave == 3) {
       long long acc = (long long)(int)V[COOP_SLOT_N1][lane] + (long long)(int)V[COOP_SLOT_N2][lane];
 #pragma unroll 1
       for (int k = 0; k < NL; ++k) acc = (long long)(int)coop_normalize<NL>(acc, c);
@@ -280,7 +280,7 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     if (wave < 3) {
       const int slot = wave == 0 ? COOP_SLOT_N1 : wave == 1 ? COOP_SLOT_N2 : COOP_SLOT_FM;
       V[slot][lane] = park[(e * 3 + wave) * 64 + lane];
-    } else {
+    } else if (wave == 3) {
       V[COOP_SLOT_ACC_0][lane] = in ? isoa[(size_t)lj * ws + e] : 0u;
     }
     __syncthreads();

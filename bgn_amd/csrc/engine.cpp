@@ -69,6 +69,7 @@ struct bgn_ctx {
   size_t sk_len = 0;
   uint32_t* d_gt = nullptr;            // g.re, g.im, gamma^-1.re, gamma^-1.im : 4 * nl limbs (Montgomery)
   BsgsSlot* d_table = nullptr;
+  uint32_t* d_tabV = nullptr;          // window table of g = e(P,P)^sk (8-bit windows x 4): the baby step g^j of a table hit
   // fixed-base window tables for P and Q (built on first use)
   uint32_t* d_tabP = nullptr;
   uint32_t* d_tabQ = nullptr;
@@ -280,6 +281,7 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   c->q1.wipe();
   if (c->d_gt) (void)hipFree(c->d_gt);
   if (c->d_table) (void)hipFree(c->d_table);
+  if (c->d_tabV) (void)hipFree(c->d_tabV);
   if (c->d_fixedpair) (void)hipFree(c->d_fixedpair);
   if (c->d_fixedpair_sk) (void)hipFree(c->d_fixedpair_sk);
   if (c->d_consts_sk) (void)hipFree(c->d_consts_sk);
@@ -579,6 +581,23 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   bp.G = G;
   bp.Mmax = Mmax;
   bp.g0 = g.c0; bp.g1 = g.c1; bp.gi0 = gi.c0; bp.gi1 = gi.c1;
+  // window table of g for the full-width verification of table hits (bsgs.hpp): g^j, j < 2^32, in 4 lookups
+  {
+    const int wbits = 8, W = 4;
+    const size_t bytes = ((size_t)W << wbits) * 2 * (size_t)c->nl * 4;
+    if (c->d_tabV) (void)hipFree(c->d_tabV);
+    c->d_tabV = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_tabV, bytes));
+    HIP_TRY(hipMemset(c->d_tabV, 0, bytes));
+    kt->gt_tab_pows(nullptr, c->d_params, g.c0, g.c1, wbits, W, c->d_tabV);
+    for (int k = 1; k < wbits; ++k) {
+      GtTabRoundArgs ta;
+      ta.tab = c->d_tabV; ta.wbits = wbits; ta.windows = W; ta.k = k;
+      ta.count = (size_t)W * (((size_t)1 << k) - 1);
+      kt->gt_tab_round(nullptr, c->d_params, ta);
+    }
+  }
+  bp.vtab = c->d_tabV;
   bp.key_keep = ~0ull;
   bp.check_keep = ~0u;
   if (const char* ev = getenv("BGN_TEST_BSGS_FP_BITS")) {        // tests: a fingerprint of only this many bits

@@ -128,6 +128,8 @@ struct BsgsParams {
   unsigned long long Mmax;          // largest accepted |m|
   const uint32_t* g0; const uint32_t* g1;     // g = e(P,P)^sk, canonical Montgomery, stride 1
   const uint32_t* gi0; const uint32_t* gi1;   // gamma^-1 = conj(g^stride), canonical Montgomery, stride 1
+  const uint32_t* vtab;             // window table of g (8-bit windows, 4 of them: g^j for j < 2^32), entries as the
+                                    // fixed-base tables (x limbs | y limbs, canonical Montgomery); null: square-and-multiply
   unsigned long long key_keep;      // fingerprint bits in use: all ones, ~0u in production (BGN_TEST_BSGS_FP_BITS
   uint32_t check_keep;              // shortens them so that the tests see false hits rejected by the verification)
 };

@@ -317,7 +317,7 @@ struct Emu {
     std::vector<BsgsSlot> table(slots);
     memset(table.data(), 0, slots * sizeof(BsgsSlot));
     BsgsParams B;
-    B.table = table.data(); B.mask = slots - 1; B.S = S; B.stride = 2 * S; B.G = G; B.Mmax = Mmax; B.key_keep = ~0ull; B.check_keep = ~0u;
+    B.table = table.data(); B.mask = slots - 1; B.S = S; B.stride = 2 * S; B.G = G; B.Mmax = Mmax; B.key_keep = ~0ull; B.check_keep = ~0u; B.vtab = nullptr;
     B.g0 = g; B.g1 = g + NL; B.gi0 = gi; B.gi1 = gi + NL;
     blockIdx.x = 0;
     bsgs_build_lane<NL>(B, S + 1, lds(), P);     // j in [0, S]

@@ -24,7 +24,8 @@ from __future__ import annotations
 import os
 import sys
 
-W = 4                 # waves per pairing
+W = 8                 # waves per pairing: two per SIMD; slots k and k + 4 of a round share a SIMD
+BASE = 4              # products a round takes freely (one per SIMD); more only when they are on the critical path
 MAX_TERMS = 4         # terms per linear operand
 BOUND_PRODUCT = 512   # bound(A) * bound(B) <= 2^9 <= R/p (engine.cpp chooses NL so)
 MUL_WEIGHT, LIN_WEIGHT = 10, 1
@@ -115,9 +116,13 @@ class Builder:
         return S(u.dst)
 
 
-def schedule(uops, w=W):
+def schedule(uops, w=W, base=BASE):
     """List scheduling into rounds of at most w micro-ops; a micro-op reads only slots written in earlier rounds
-    (or never written in this segment).  Priority: longest path to a sink."""
+    (or never written in this segment).  Priority: longest path to a sink.  A round takes its `base` best ready
+    micro-ops (one wave per SIMD) and fills the second wave of a SIMD only with micro-ops as critical as the best
+    one: two waves on a SIMD share its issue slots (a product takes ~1.33x as long beside another one), so a fifth
+    product pays only where it shortens the schedule.  Measured on the Miller segments against 4 waves: a doubling
+    4 rounds instead of 5, doubling + addition 7 instead of 9."""
     writer = {u.dst: i for i, u in enumerate(uops)}
     assert len(writer) == len(uops), "a slot is written twice in one segment"
     deps = [sorted(writer[s] for s in u.reads() if s in writer) for u in uops]
@@ -136,8 +141,9 @@ def schedule(uops, w=W):
         r = len(rounds)
         ready = [i for i in range(len(uops)) if i not in done and all(j in done and done[j] < r for j in deps[i])]
         ready.sort(key=lambda i: (-prio[i], i))
-        take = ready[:w]
+        take = ready[:base]
         assert take
+        take += [i for i in ready[base:w] if prio[i] >= prio[take[0]]]
         for i in take:
             done[i] = r
             uops[i].round = r

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turns the raw output of tools/collect_profiles.sh (gpurun_out/<dir>) into the tracked files under profiles/:
+python tools/summarize_profiles.py gpurun_out/r02_profiles r02"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(ROOT, "profiles")
+
+
+def last_json_line(path):
+    lines = [l for l in open(path) if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+shutil.copy(os.path.join(src, "prof_bench", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "prof_extra", "extra_kernel_stats.csv"), os.path.join(dst, f"{tag}_extra_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "small_batch.csv"), os.path.join(dst, f"{tag}_small_batch.csv"))
+for name, out in (("bench_line.json", f"{tag}_bench_line.json"), ("bench_line_profiled.json", f"{tag}_bench_line_profiled.json")):
+    with open(os.path.join(dst, out), "w") as f:
+        json.dump(last_json_line(os.path.join(src, name)), f, indent=1)
+        f.write("\n")
+
+summary = {}
+for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch", "fetch"), ("WRITE_SIZE", "pmc_write", "write")):
+    rows = [r for r in csv.DictReader(open(os.path.join(src, sub, f"{stem}_counter_collection.csv")))
+            if r["Kernel_Name"].startswith("void bgn::k_pairing<38, 0>") and r["Counter_Name"] == ctr]
+    vals = [float(r["Counter_Value"]) for r in rows]
+    keep = os.path.join(dst, f"{tag}_pmc_{ctr.lower()}_k_pairing.csv")
+    with open(keep, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    summary[ctr] = {"unit": "KB per launch (rocprofv3 counter value)", "launches": len(vals), "avg": sum(vals) / len(vals),
+                    "scratch_bytes_per_lane": int(rows[0]["Scratch_Size"]), "vgpr": int(rows[0]["VGPR_Count"]),
+                    "agpr": int(rows[0]["Accum_VGPR_Count"])}
+line = last_json_line(os.path.join(src, "bench_line.json"))
+alg = line["roofline"]["algorithmic_bytes_per_pairing"] * line["config"]["batch_per_gpu"]
+total = (summary["FETCH_SIZE"]["avg"] + summary["WRITE_SIZE"]["avg"]) * 1024
+summary.update({
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes, no tracing) --output-format csv -- python3 bench.py "
+               "--steps 1 --warmup 0 --no-cpu-baseline --no-extra",
+    "kernel": "k_pairing<38, 0>, 2^20 pairings per launch",
+    "hbm_bytes_per_launch": total,
+    "algorithmic_bytes_per_launch": alg,
+    "traffic_over_algorithmic": total / alg,
+    "note": "counter values are KB; MI355X_MICROARCH.md's x2 FETCH_SIZE correction is calibrated for 16-B-per-lane streaming "
+            "reads only, these are 4-B-per-lane SoA accesses (uncalibrated), so the raw value is reported: the true figure lies "
+            "between 1x and 2x of the fetch term",
+})
+with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+    f.write("\n")
+print(json.dumps(summary, indent=1))

@@ -757,14 +757,62 @@ int bgn_make_l2_batch_dev(bgn_ctx* c, size_t count, const uint8_t* a, uint8_t* o
 
 // Host-buffer wrappers: stage through device memory, synchronous.
 namespace {
+// Staging buffers of the host-buffer entry points.  A small call (the reference's own shape: one element per
+// call) would otherwise spend more time in hipMalloc / hipFree than in its kernels, so buffers of up to 4 MB
+// are kept in a small per-device pool and handed out again; larger ones are allocated and freed per call.
+struct StagePool {
+  struct Slot {
+    void* p;
+    size_t cap;
+    int device;
+  };
+  std::mutex mu;
+  std::vector<Slot> free_list;
+  static constexpr size_t kMaxKeep = (size_t)4 << 20;
+  static constexpr size_t kMaxSlots = 32;
+  void* take(int device, size_t bytes, size_t* cap) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].device == device && free_list[i].cap >= bytes && free_list[i].cap <= 4 * bytes + 4096) {
+        void* p = free_list[i].p;
+        *cap = free_list[i].cap;
+        free_list.erase(free_list.begin() + (long)i);
+        return p;
+      }
+    return nullptr;
+  }
+  bool give(int device, void* p, size_t cap) {
+    if (cap > kMaxKeep) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_list.size() >= kMaxSlots) return false;
+    free_list.push_back(Slot{p, cap, device});
+    return true;
+  }
+};
+StagePool g_stage_pool;
+
 struct DevBuf {
   void* p = nullptr;
+  size_t cap = 0;
+  int device = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), device(o.device) { o.p = nullptr; }
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p && !g_stage_pool.give(device, p, cap)) (void)hipFree(p);
   }
   int alloc(size_t bytes) {
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-    if (e != hipSuccess) return fail(BGN_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    if (!bytes) bytes = 1;
+    (void)hipGetDevice(&device);
+    p = g_stage_pool.take(device, bytes, &cap);
+    if (p) return BGN_OK;
+    cap = bytes <= StagePool::kMaxKeep ? round_up(bytes, 4096) : bytes;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(BGN_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
     return BGN_OK;
   }
 };

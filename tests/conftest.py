@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:                       # torch ships its own HIP runtime: load it BEFORE libbgn_amd.so pulls in /opt/rocm's, so that
+    import torch  # noqa: F401   # the process holds one runtime (a torch.cuda init after the engine's found no GPU)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

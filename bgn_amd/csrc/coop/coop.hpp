@@ -3,7 +3,7 @@
 //
 // Replaces `res.Pair(ct1.C, ct2.C)` (bgn.go:300) when a call carries too few pairings to fill the chip with
 // one pairing per lane (pairing.hpp: 166 ms per 1024-bit pairing whatever the batch below 65536).  Here ONE
-// pairing belongs to a workgroup of four waves, one per SIMD of a CU:
+// pairing belongs to a workgroup of COOP_W = 8 waves, two per SIMD of a CU:
 //   * a field element lies across the lanes of a wave, one 28-bit limb per lane (lane j = limb j, lanes >= NL
 //     hold zero), so a value is ONE VGPR, the whole Miller state a handful of LDS rows, and a Montgomery product
 //     is NL steps of {broadcast one limb of b (v_readlane), multiply-add into the lane accumulators, quotient

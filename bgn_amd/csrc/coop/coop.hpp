@@ -181,6 +181,23 @@ __device__ __forceinline__ u32 coop_canonical(u32 x, const CoopLane<NL>& c) {
   return top < 0 ? (u32)acc : (u32)d;
 }
 
+// The same for a value in [0, 16p): conditional subtractions of 8p, 4p, 2p, p.
+template <int NL>
+__device__ __forceinline__ u32 coop_canonical16(u32 x, const CoopLane<NL>& c) {
+  long long acc = (long long)(int)x;
+#pragma unroll 1
+  for (int i = 0; i < NL; ++i) acc = (long long)(int)coop_normalize<NL>(acc, c);
+#pragma unroll 1
+  for (int m = 8; m >= 1; m >>= 1) {
+    long long d = acc - (long long)m * (long long)c.p;
+#pragma unroll 1
+    for (int i = 0; i < NL; ++i) d = (long long)(int)coop_normalize<NL>(d, c);
+    const int top = __builtin_amdgcn_readlane((int)d, NL - 1);
+    if (top >= 0) acc = d;
+  }
+  return (u32)acc;
+}
+
 // Words of workspace per pairing of the three-launch form: the parked F0^2, F1^2, F0*F1 (64 lanes each) ...
 constexpr int COOP_PARK_WORDS = 3 * 64;
 
@@ -313,6 +330,91 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     if (ident) r = (wave == 0 && lane == 0) ? 1u : 0u;
     u32* dst = wave == 0 ? out.c0 : out.c1;
     if (in) dst[(size_t)lj * out.stride + e] = r;
+  }
+}
+
+// base^k in F_p^2 for a small batch (Decrypt's csk.PowBig(ct.C, sk.Key), bgn.go:223, 277: 9 ms per element on a
+// single lane of k_gt_pow at a 1024-bit key): one element per workgroup, square-and-multiply over the bits of k
+// with the segments of the final exponentiation's ^l (a squaring: 2 products in one round; a product by the base:
+// 4 in two rounds).  a: canonical Montgomery SoA (sa == 1: one base for all); k: big-endian bytes, klen each
+// (kstride 0: one exponent for all); out: canonical Montgomery SoA.  k = 0 gives 1.
+template <int NL>
+__global__ void __launch_bounds__(COOP_BLOCK)
+k_gt_pow_coop(const FpParams<NL>* __restrict__ P, const u32* __restrict__ a0, const u32* __restrict__ a1, size_t sa,
+              const uint8_t* __restrict__ k, size_t kstride, size_t klen, u32* __restrict__ o0, u32* __restrict__ o1,
+              size_t so, size_t count) {
+  __shared__ u32 V[COOP_NSLOTS][64];
+  __shared__ u32 kw[64];                       // the exponent, 32 bits per word, little-endian words (klen <= 256)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t e = blockIdx.x;
+  if (e >= count) return;
+  CoopLane<NL> c;
+  c.lane = lane;
+  c.p = lane < NL ? P->p[lane < NL ? lane : 0] : 0u;
+  c.keep = lane < NL - 1 ? LIMB_MASK : 0xFFFFFFFFu;
+  c.carry = lane < NL - 1 ? 0xFFFFFFFFu : 0u;
+  c.pinv = P->pinv;
+  const int lj = lane < NL ? lane : 0;
+  const bool in = lane < NL;
+  const size_t ea = sa == 1 ? 0 : e;
+  const int nwords = (int)((klen + 3) / 4);
+  if (wave == 0) {
+    const u32 x = in ? a0[(size_t)lj * sa + ea] : 0u;
+    V[COOP_SLOT_H0][lane] = x;
+    V[COOP_SLOT_R0_0][lane] = x;
+    V[COOP_SLOT_ZERO][lane] = 0;
+  } else if (wave == 1) {
+    const u32 y = in ? a1[(size_t)lj * sa + ea] : 0u;
+    V[COOP_SLOT_H1][lane] = y;
+    V[COOP_SLOT_R1_0][lane] = y;
+  } else if (wave == 2) {
+    V[COOP_SLOT_ONE][lane] = in ? P->one[lj] : 0u;
+    V[COOP_SLOT_RAW1][lane] = lane == 0 ? 1u : 0u;
+  } else if (wave == 3) {
+    // word w = bytes klen-1-4w .. klen-4-4w of the big-endian scalar
+    u32 wv = 0;
+    if (lane < nwords) {
+      const uint8_t* kp = k + e * kstride;
+      for (int bte = 0; bte < 4; ++bte) {
+        const long idx = (long)klen - 1 - 4 * lane - bte;
+        if (idx >= 0) wv |= (u32)kp[idx] << (8 * bte);
+      }
+    }
+    kw[lane] = wv;
+  }
+  __syncthreads();
+  // top set bit (wave-uniform: every wave scans the same words)
+  int top = -1;
+  for (int w = nwords - 1; w >= 0 && top < 0; --w) {
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)kw[w]);
+    if (wv) top = 32 * w + 31 - __builtin_clz(wv);
+  }
+  int lp = 0;
+  if (top >= 0) {
+    u32 cur = 0;
+    int curw = -1;
+#pragma unroll 1
+    for (int i = top - 1; i >= 0; --i) {
+      if ((i >> 5) != curw) {
+        curw = i >> 5;
+        cur = (u32)__builtin_amdgcn_readfirstlane((int)kw[curw]);
+      }
+      coop_run<NL>(V, lp ? COOP_SEG_LSQ1 : COOP_SEG_LSQ0, wave, c);
+      lp ^= 1;
+      if ((cur >> (i & 31)) & 1u) {
+        coop_run<NL>(V, lp ? COOP_SEG_LMU1 : COOP_SEG_LMU0, wave, c);
+        lp ^= 1;
+      }
+    }
+  }
+  if (wave < 2) {
+    // canonical Montgomery residues out (values < 9p: a few conditional subtractions after the carry resolution)
+    int slot = wave == 0 ? (lp ? COOP_SLOT_R0_1 : COOP_SLOT_R0_0) : (lp ? COOP_SLOT_R1_1 : COOP_SLOT_R1_0);
+    if (top < 0) slot = wave == 0 ? COOP_SLOT_ONE : COOP_SLOT_ZERO;
+    const u32 r = coop_canonical16<NL>(V[slot][lane], c);
+    u32* dst = wave == 0 ? o0 : o1;
+    if (in) dst[(size_t)lj * so + e] = r;
   }
 }
 

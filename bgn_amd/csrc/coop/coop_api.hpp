@@ -12,5 +12,9 @@ namespace bgn {
 bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                          size_t count, int mode, uint32_t* ws, size_t sw, int p_bits);
 size_t coop_ws_words(int nl, size_t sw);
+// out[e] = a[e]^k[e] in F_p^2, one element per workgroup: a canonical Montgomery SoA (sa == 1: one base), k big-endian
+// bytes (klen <= 256 each; kstride 0: one exponent), out canonical Montgomery SoA.
+bool coop_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa,
+                        const uint8_t* k, size_t kstride, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count);
 const char* coop_pairing_kernel_name(int nl);
 }  // namespace bgn

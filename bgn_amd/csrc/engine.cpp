@@ -655,11 +655,14 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
 // The crossovers come from the committed sweep profiles/r02_small_batch.csv; BGN_COOP_MAX / BGN_COOP_MAX_L2
 // override them (0 disables the kernel).
 static size_t coop_limit(const bgn_ctx* c, int mode) {
-  const char* ev = getenv(mode == 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
+  const char* ev = getenv(mode >= 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
   // mode 2: the lift of Decrypt, whose lane kernel walks the half-length table of the secret order (37 ms at
   // 1024 bits, 5 ms at 512): the cooperative kernel (a whole e(C, P)) wins below ~2000 / ~800 ciphertexts
   if (mode == 2) return c->nl >= 38 ? 2000 : c->nl >= 19 ? 800 : 512;
+  // mode 3: Decrypt's power by the secret key: 1.5 rounds per bit on the waves (≈ 1 ms at 1024 bits, one element
+  // per CU) against 2 products per bit on one lane (8 ms whatever the batch below 65536)
+  if (mode == 3) return c->nl >= 38 ? 2048 : c->nl >= 19 ? 1024 : 512;
   // profiles/r02_small_batch.csv (MI355X): Mult at 1024 bits — 8192 pairings 121 ms cooperative against 164 ms,
   // 16384: 237 against 164; at 512 bits — 4096: 17.9 against 28.0 ms, 8192: 33.9 against 28.1.  makeL2 (the lane
   // kernel walks P's line table there, a third of the products): 1024 bits — 2048: 34 against 54 ms, 4096: 63
@@ -1686,6 +1689,10 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     if (ev && ev[0] == '0') {
       gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);
       kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
+    } else if (count <= coop_limit(c, 3) &&
+               coop_gt_pow_launch(c->nl, s, c->d_params, base.c0, base.c1, base.stride, c->d_sk, 0, c->sk_len, Y.c0, Y.c1,
+                                  Y.stride, count)) {
+      // a small batch: square-and-multiply on the waves (0.9 ms at a 1024-bit key) instead of 8 ms on one lane
     } else {
       gt_pow_norm1_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);
     }

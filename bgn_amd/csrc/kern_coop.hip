@@ -37,6 +37,26 @@ bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const Pairin
   return false;
 }
 
+template <int NL>
+static void launch_pow(hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa, const uint8_t* k,
+                       size_t kstride, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count) {
+  hipLaunchKernelGGL((k_gt_pow_coop<NL>), dim3((unsigned)count), dim3(COOP_BLOCK), 0, s, (const FpParams<NL>*)params, a0, a1,
+                     sa, k, kstride, klen, o0, o1, so, count);
+}
+
+bool coop_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa,
+                        const uint8_t* k, size_t kstride, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count) {
+  if (!count) return true;
+  if (klen > 256) return false;
+  switch (nl) {
+    case 3: launch_pow<3>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
+    case 10: launch_pow<10>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
+    case 19: launch_pow<19>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
+    case 38: launch_pow<38>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
+  }
+  return false;
+}
+
 const char* coop_pairing_kernel_name(int nl) {
   switch (nl) {
     case 3: return "k_pairing_coop<3>";

@@ -102,6 +102,13 @@ def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch
     assert m1.tolist() == m0.tolist() and s1.tolist() == s0.tolist()
     want = list(ms)
     want[3] = -want[3]
+    # level 2: the power by the secret key alone is cooperative (k_gt_pow_coop)
+    l2 = eng.make_l2(cts.tobytes()).tobytes()
+    monkeypatch.setenv("BGN_COOP_MAX_DEC", "100000")
+    m2, s2 = eng.decrypt(2, l2)
+    monkeypatch.setenv("BGN_COOP_MAX_DEC", "0")
+    m3, s3 = eng.decrypt(2, l2)
+    assert m2.tolist() == m3.tolist() == m0.tolist() and s2.tolist() == s3.tolist() == s0.tolist()
     for got, st, w in zip(m1.tolist(), s1.tolist(), want):
         B = int(T ** 0.5) + (0 if int(T ** 0.5) ** 2 == T else 1)
         if abs(w) > B * B + B + 2:

@@ -383,7 +383,7 @@ def emit(P, path):
     lines.append("#define COOP_NSLOTS %d" % P.nslots)
     lines.append("#define COOP_MAX_TERMS %d" % MAX_TERMS)
     for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "v0@0", "v1@0", "v2@0",
-                  "n1", "n2", "fm", "acc@0"):
+                  "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1"):
         lines.append("#define COOP_SLOT_%s %d" % (gname.replace("@", "_").upper(), P.phys[gname]))
     lines.append("enum CoopSeg {")
     for i, (name, _) in enumerate(P.segments):

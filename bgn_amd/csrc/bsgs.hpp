@@ -215,7 +215,10 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
   if (n == 0) return;
   unsigned long long parts = lanes_total / n;
   if (parts < 1) parts = 1;
-  const unsigned long long max_parts = (B.G + 255) / 256;      // keep >= 256 steps per part
+  // keep >= 256 steps per part — a part begins with a power of gamma^-1, ~30 products — unless the batch is
+  // small: then latency counts and parts of 16 steps put a single element on 17 lanes instead of 2
+  const unsigned long long min_steps = n >= 4096 ? 256 : 16;
+  const unsigned long long max_parts = (B.G + min_steps - 1) / min_steps;
   if (parts > max_parts) parts = max_parts;
   const unsigned long long steps = (B.G + parts - 1) / parts;
   bool live = lane < n * parts;

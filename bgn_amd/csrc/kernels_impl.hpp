@@ -225,8 +225,14 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     Fp<NL> N, r;
     miller_norm<NL>(N, S, L, P);          // <4, never 0 for a valid pair (f != 0)
     {
-      // an identity operand runs the loop on placeholder coordinates: keep its norm out of the product
-      const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
+      // an identity operand runs the loop on placeholder coordinates: keep its norm out of the product.  So
+      // must a norm of zero — only an operand that is not on the curve can produce one (the batch calls do not
+      // validate, bgn_validate_batch does): it would zero the lane's shared product of norms and with it the
+      // results of the other pairings of the run.  Such a pairing yields the identity, as PBC's SetBytes maps
+      // an invalid point to O.
+      Fp<NL> nc;
+      fp_reduce8(nc, N, P);
+      const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]) || fp_is_zero_limbs(nc);
       fp_set(r, P->one);
       fp_select(N, ident, r, N);
     }
@@ -256,7 +262,9 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     g_load<NL>(r, wF1, sw, e);
     a_store(S.F1, r);
     miller_norm<NL>(N, S, L, P);
-    const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
+    Fp<NL> nc;
+    fp_reduce8(nc, N, P);
+    const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]) || fp_is_zero_limbs(nc);
     fp_set(r, P->one);
     fp_select(N, ident, r, N);
     g_load<NL>(r, wPf, sw, e);

@@ -338,7 +338,7 @@ struct Emu {
         u32 one_todo[1] = {0}; u32 one_count = 1;
         A.m = &mm; A.status = &st; A.todo = one_todo; A.todo_count = &one_count; A.count = 1; A.mode = mode;
         // all parts of the element's giant-step split, one emulated lane each
-        const unsigned long long max_parts = (G + 255) / 256;
+        const unsigned long long max_parts = (G + 15) / 16;          // a small batch: parts of 16 steps (bsgs.hpp)
         unsigned long long parts = 256 < max_parts ? 256 : max_parts;
         for (unsigned long long part = 0; part < parts; ++part) {
           threadIdx.x = (unsigned)part;

@@ -202,7 +202,8 @@ __device__ __forceinline__ u32 coop_canonical16(u32 x, const CoopLane<NL>& c) {
 constexpr int COOP_PARK_WORDS = 3 * 64;
 
 // One pairing per workgroup of COOP_W waves.  Operands: canonical Montgomery SoA; result: plain canonical SoA
-// (what k_pairing<NL, 0> reads and writes).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point.
+// (what k_pairing<NL, 0> reads and writes).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point; mode 2: the
+// coefficient pairs of polynomial products (d1, d2 coefficients).
 // phase 0: the whole pairing, the inversion of the final exponentiation by Fermat on the waves (bits(p) rounds).
 // phase 1 / 2: the Miller loop and the norms, parked in `park` with N(f) written as tight limbs to nsoa —
 // then k_coop_invert inverts all the norms of the batch with the division steps of fpinv.hpp, one per lane, at
@@ -211,14 +212,20 @@ constexpr int COOP_PARK_WORDS = 3 * 64;
 template <int NL>
 __global__ void __launch_bounds__(COOP_BLOCK)
 k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
-               size_t count, int mode, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
+               size_t count, int mode, size_t d1, size_t d2, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
                const u32* __restrict__ isoa, size_t ws) {
   __shared__ u32 V[COOP_NSLOTS][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t e = blockIdx.x;
   if (e >= count) return;
-  const size_t ea = e, eb = (mode == 1) ? 0 : e;
+  // mode 2 (MultPoly, poly.go:139-146): e = (q*d1 + i)*d2 + k pairs coefficient i of polynomial q of `a` with
+  // coefficient k of polynomial q of `b`
+  size_t ea = e, eb = (mode == 1) ? 0 : e;
+  if (mode == 2) {
+    ea = e / d2;
+    eb = (ea / d1) * d2 + e % d2;
+  }
   CoopLane<NL> c;
   c.lane = lane;
   c.p = lane < NL ? P->p[lane < NL ? lane : 0] : 0u;

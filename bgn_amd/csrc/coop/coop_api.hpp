@@ -3,14 +3,14 @@
 #include "../kernels.hpp"
 
 namespace bgn {
-// out[e] = e(a[e], b[e]) (mode 0) or e(a[e], b[0]) (mode 1) for e < count, one workgroup per pairing; operands
+// out[e] = e(a[e], b[e]) (mode 0), e(a[e], b[0]) (mode 1) or the coefficient pairs of MultPoly (mode 2, as KernelTable::pairing) for e < count, one workgroup per pairing; operands
 // canonical Montgomery SoA, results plain canonical SoA, as KernelTable::pairing.  Returns false when `nl` has no
 // instantiation.
 // ws: workspace of coop_ws_words(nl, sw) u32 (sw >= count, the limb stride of its arrays) — the pairing then runs
 // as Miller-loop kernel, batched inversion of the norms (division steps, one per lane), final-exponentiation
 // kernel; ws == nullptr: one launch with the Fermat inversion on the waves.
 bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                         size_t count, int mode, uint32_t* ws, size_t sw, int p_bits);
+                         size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits);
 size_t coop_ws_words(int nl, size_t sw);
 // out[e] = a[e]^k[e] in F_p^2, one element per workgroup: a canonical Montgomery SoA (sa == 1: one base), k big-endian
 // bytes (klen <= 256 each; kstride 0: one exponent), out canonical Montgomery SoA.

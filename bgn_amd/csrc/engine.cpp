@@ -730,7 +730,7 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   HIP_TRY(hipEventRecord(c->ev0, s));
   // BGN_COOP_FERMAT=1: the one-launch form with the Fermat inversion on the waves (A/B measurements)
   const char* cf = getenv("BGN_COOP_FERMAT");
-  if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode,
+  if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
                                   (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1)) {
     c->last_kernel = coop_pairing_kernel_name(c->nl);
   } else {
@@ -1672,7 +1672,7 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // the latency of one whole table loop on a single lane (28 ms at a 1024-bit key); the power by q1 below
     // gives the same e(C, P)^q1 either way
     if (count <= coop_limit(c, 2) &&
-        coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, pws, st, c->p_bits + 1)) {
+        coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pws, st, c->p_bits + 1)) {
       c->aux_kernel = coop_pairing_kernel_name(c->nl);
     } else {
       kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
@@ -1777,7 +1777,11 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   // tables on the operand with fewer coefficients (each table is then shared by more pairs)
   const bool tab_on_a = d1 <= d2;
   const size_t dt = tab_on_a ? d1 : d2;
-  const size_t chunk = (d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
+  // a product small enough for the wave-cooperative kernel (a few thousand coefficient pairs: the reference's own
+  // MultPoly calls are ONE product of ~10 x 10 coefficients) pairs directly, one pair per workgroup: tables and the
+  // one-pairing-per-lane kernels cost the latency of several whole pairings on single lanes
+  const bool coop = npoly * d1 * d2 <= coop_limit(c, 0);
+  const size_t chunk = (!coop && d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
   SoA2 E;
@@ -1785,7 +1789,8 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
-    pws = (uint32_t*)w.cv.take((size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4);
+    const size_t lane_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;
+    pws = (uint32_t*)w.cv.take(coop ? coop_ws_words(c->nl, sp) * 4 : lane_b);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
@@ -1818,6 +1823,8 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);
       kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(pairs), pws, sp,
                   tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
+    } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sp,
+                                           c->p_bits + 1)) {
     } else {
       kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(pairs), pws, sp, nullptr, 0,
                   pairing_variant());

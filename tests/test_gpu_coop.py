@@ -115,3 +115,26 @@ def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch
             assert st == 1
         else:
             assert st == 0 and got == w
+
+
+@pytest.mark.parametrize("name,npoly,d1,d2", [("k256", 3, 4, 3), ("k512", 1, 9, 13), ("k1024", 2, 4, 4)])
+def test_multpoly_small_products_on_both_kernels(name, npoly, d1, d2, monkeypatch):
+    """MultPoly of a few short polynomials (the reference's own call: ONE product of ~10 x 10 coefficients,
+    poly_test.go:173-189) pairs directly on the cooperative kernel; the lane kernels (line tables, Karatsuba
+    levels) and the C oracle give the same coefficients."""
+    import oracle_c
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    o = oracle_c.Oracle.from_fixture(fx)
+    rng = random.Random(d1 * 100 + d2)
+    n = int(fx["n"], 16)
+    ca = eng.encrypt([rng.randrange(3) for _ in range(npoly * d1)], [rng.randrange(n) for _ in range(npoly * d1)]).copy()
+    cb = eng.encrypt([rng.randrange(3) for _ in range(npoly * d2)], [rng.randrange(n) for _ in range(npoly * d2)]).copy()
+    ca[1] = 0                                                        # an identity coefficient
+    a, b = ca.tobytes(), cb.tobytes()
+    monkeypatch.setenv("BGN_COOP_MAX", "1000000")
+    got = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
+    monkeypatch.setenv("BGN_COOP_MAX", "0")
+    lane = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
+    assert got == lane == o.poly_mult(npoly, d1, d2, a, b)

@@ -38,6 +38,8 @@ def main():
             cts = eng.encrypt(xs, rs)
             a, b = cts[:cnt].tobytes(), cts[cnt:].tobytes()
             l2 = eng.mult(a, b).tobytes()
+            pc = eng.encrypt([i % 3 for i in range(20)], [(987654321 * (i + 1)) % n for i in range(20)])
+            pa, pb = pc[:10].tobytes(), pc[10:].tobytes()
             ops = {
                 "encrypt": lambda: eng.encrypt(xs[:cnt], rs[:cnt]),
                 "add_l1": lambda: eng.add(1, a, b),
@@ -46,6 +48,7 @@ def main():
                 "make_l2": lambda: eng.make_l2(a),
                 "multconst_l1_k40": lambda: eng.multconst(1, a, [(1 << 39) + i for i in range(cnt)]),
                 "multconst_l2_k40": lambda: eng.multconst(2, l2, [(1 << 39) + i for i in range(cnt)]),
+                "multpoly_10x10": lambda: eng.poly_mult(1, 10, 10, pa, pb),
                 "decrypt_l1": lambda: eng.decrypt(1, a),
                 "decrypt_l2": lambda: eng.decrypt(2, l2),
             }

@@ -2217,6 +2217,21 @@ int bgn_field_ops_batch(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* pr
   return BGN_OK;
 }
 
+// Page-locked host memory for the arrays of the host-buffer entry points: copies from and to it run at the full
+// PCIe rate (a pageable Go slice is staged by the runtime at roughly half of it).  bgn_host_free releases it.
+void* bgn_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)fail(BGN_E_NOMEM, "hipHostMalloc(%zu)", bytes);
+    return nullptr;
+  }
+  return p;
+}
+void bgn_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 double bgn_last_aux_kernel_ms(bgn_ctx* c) {
   if (!c || !c->ev2_valid) return -1.0;
   if (hipEventSynchronize(c->ev3) != hipSuccess) return -1.0;

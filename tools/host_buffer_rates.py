@@ -29,6 +29,24 @@ timed("encrypt", lambda: check(eng._lib.bgn_encrypt_batch(eng._h, n, P(xs), 5, P
 a, b = out[: n // 2].copy(), out[n // 2:].copy()
 o2 = np.zeros_like(a)
 timed("add L1", lambda: check(eng._lib.bgn_add_batch(eng._h, n // 2, 1, P(a), P(b), None, 0, P(o2)), "add"), n // 2)
+
+
+def pinned(shape):
+    """numpy view of page-locked memory from bgn_host_alloc (what a Go caller would wrap with unsafe.Slice)."""
+    nbytes = int(np.prod(shape))
+    ptr = eng._lib.bgn_host_alloc(nbytes)
+    assert ptr
+    return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).reshape(shape)
+
+
+pa, pb, po = pinned(a.shape), pinned(b.shape), pinned(o2.shape)
+pa[:], pb[:] = a, b
+timed("add L1 pinned", lambda: check(eng._lib.bgn_add_batch(eng._h, n // 2, 1, P(pa), P(pb), None, 0, P(po)), "add"), n // 2)
+assert (po == o2).all()
+px, pr, pout = pinned(xs.shape), pinned(rs.shape), pinned(out.shape)
+px[:], pr[:] = xs, rs
+timed("encrypt pinned", lambda: check(eng._lib.bgn_encrypt_batch(eng._h, n, P(px), 5, P(pr), 128, P(pout)), "enc"), n)
+assert (pout == out).all()
 m = min(n // 2, 1 << 16)
 timed("mult", lambda: check(eng._lib.bgn_mult_batch(eng._h, m, P(a), P(b), None, 0, P(o2)), "mult"), m)
 pk.SetupDecryption(sk)

@@ -248,8 +248,13 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
              "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
             syn.decrypt_products(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
         # the dominant kernel of Decrypt is the lift (k_pairing<38, 1>), timed by HIP events on its stream
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        if k == 20 and os.path.exists(pmc):                     # separate rocprofv3 --pmc passes of this command
+            with open(pmc) as f:
+                traffic = json.load(f).get("decrypt_lift_k_pairing_38_1", {}).get("hbm_bytes_per_launch")
         e["roofline"] = {"bound": "hbm", "achieved": alg * n_dec / (lift_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": alg * n_dec / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": alg * n_dec / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": eng.last_aux_kernel_name(), "kernel_ms": lift_ms,
                          "walk_kernel": eng.last_kernel_name(), "walk_kernels_ms": walk_ms,
                          "algorithmic_bytes_per_decrypt": alg}

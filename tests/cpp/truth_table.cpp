@@ -55,6 +55,19 @@ static int host_checks() {
                          0xb0, 0x03, 0x61, 0xa3, 0x96, 0x17, 0x7a, 0x9c, 0xb4, 0x10, 0xff, 0x61, 0xf2, 0x00, 0x15, 0xad};
   Bytes dg = sha256::digest(Bytes{'a', 'b', 'c'});
   if (memcmp(dg.data(), abc, 32) != 0) { printf("MISMATCH sha256\n"); bad++; }
+  // the shard split of the multi-GPU forms (no GPU needed): contiguous, ordered, sizes differ by at most one
+  for (size_t total : {(size_t)0, (size_t)1, (size_t)7, (size_t)1048579}) {
+    for (int world : {1, 2, 3, 8}) {
+      size_t prev = 0;
+      for (int r = 0; r < world; ++r) {
+        size_t lo = 99, hi = 99;
+        bgn_shard_range(total, world, r, &lo, &hi);
+        if (lo != prev || hi < lo || hi - lo > total / world + 1) { printf("MISMATCH bgn_shard_range\n"); bad++; }
+        prev = hi;
+      }
+      if (prev != total) { printf("MISMATCH bgn_shard_range end\n"); bad++; }
+    }
+  }
   std::vector<uint64_t> d100 = UnbalancedEncode(100, 3);
   if (d100 != std::vector<uint64_t>{1, 0, 2, 0, 1, 0}) { printf("MISMATCH UnbalancedEncode\n"); bad++; }
   return bad;
@@ -140,6 +153,40 @@ int main(int argc, char** argv) {
       broken.C.back() ^= 1;
       expect("validate good", ok[0] + ok[1] + ok[2], 3);
       expect("validate off-curve", pk.Validate({broken})[0], 0);
+    }
+    // one key on several devices from one process through the C ABI (bgn_mctx_*): the device list names GPU 0
+    // three times, which gives real multi-context sharding on a one-GPU box; ragged shards, MultPoly by polynomial
+    {
+      const Bytes pB = unhex(argv[1]), nB = unhex(argv[2]), PB = unhex(argv[4]), QB = unhex(argv[5]), q1 = unhex(argv[6]);
+      const int devs[3] = {0, 0, 0};
+      bgn_mctx* m = nullptr;
+      int rc = bgn_mctx_create(&m, pB.data(), pB.size(), nB.data(), nB.size(), strtoull(argv[3], nullptr, 10), PB.data(),
+                               QB.data(), 1, devs, 3);
+      if (rc != BGN_OK) throw Error(rc, "bgn_mctx_create");
+      expect("mctx devices", bgn_mctx_device_count(m), 3);
+      rc = bgn_mctx_set_secret(m, q1.data(), q1.size());
+      if (rc == BGN_OK) rc = bgn_mctx_setup_decryption(m, strtoull(argv[7], nullptr, 10));
+      if (rc != BGN_OK) throw Error(rc, "bgn_mctx_setup_decryption");
+      const size_t cnt = 7, E = pk.ElementBytes();
+      Bytes xs(cnt), rs2(cnt), cts(cnt * E), prod(cnt * E), sum(cnt * E), stat(cnt);
+      std::vector<int64_t> ms(cnt);
+      for (size_t i = 0; i < cnt; ++i) {
+        xs[i] = (uint8_t)(i + 1);
+        rs2[i] = (uint8_t)(40 + i);
+      }
+      rc = bgn_mencrypt_batch(m, cnt, xs.data(), 1, rs2.data(), 1, cts.data());
+      if (rc == BGN_OK) rc = bgn_mmult_batch(m, cnt, cts.data(), cts.data(), nullptr, 0, prod.data());
+      if (rc == BGN_OK) rc = bgn_madd_batch(m, cnt, 2, prod.data(), prod.data(), nullptr, 0, sum.data());
+      if (rc == BGN_OK) rc = bgn_mdecrypt_batch(m, cnt, 2, sum.data(), ms.data(), stat.data());
+      if (rc != BGN_OK) throw Error(rc, "bgn_m*_batch");
+      for (size_t i = 0; i < cnt; ++i) expect("mctx Dec(x*x + x*x)", stat[i] ? -1 : ms[i], 2 * (int64_t)(i + 1) * (int64_t)(i + 1));
+      // MultPoly: 3 polynomials of 2 x 2 coefficients, sharded by polynomial; against the single context
+      Bytes pout(3 * 4 * E), pref(3 * 4 * E);
+      rc = bgn_mpoly_mult_batch(m, 3, 2, 2, cts.data(), cts.data() + E, pout.data());
+      if (rc == BGN_OK) rc = bgn_poly_mult_batch(pk.handle(), 3, 2, 2, cts.data(), cts.data() + E, pref.data());
+      if (rc != BGN_OK) throw Error(rc, "bgn_mpoly_mult_batch");
+      if (pout != pref) { printf("MISMATCH mctx MultPoly\n"); bad++; }
+      bgn_mctx_destroy(m);
     }
     bool threw = false;
     try {

@@ -16,8 +16,15 @@ echo "== PMC FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || exit 1
 echo "== PMC WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || exit 1
+echo "== PMC FETCH_SIZE / WRITE_SIZE with the extras (Decrypt's lift kernel)"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_extra" -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch_extra.json" 2> "$OUT/pmc_fetch_extra.err" || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_extra" -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write_extra.json" 2> "$OUT/pmc_write_extra.err" || exit 1
 echo "== small-batch sweep"; python3 tools/small_batch_sweep.py > "$OUT/small_batch.csv" 2> "$OUT/sweep.err" || exit 1
 find "$OUT" -name "*.csv" | head -40
 # keep the merge small: the raw traces are not needed
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
+# the counter files of the runs with extras list every dispatch: keep the pairing kernels only
+for f in "$OUT"/pmc_fetch_extra/fetch_counter_collection.csv "$OUT"/pmc_write_extra/write_counter_collection.csv; do
+  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep "k_pairing<38, 1>" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
+done
 du -sh "$OUT"

@@ -236,3 +236,56 @@ def test_fused_add_matches_three_launch_path_and_c_oracle(name, count, monkeypat
         sample = min(count, 400)
         E = eng.elem_bytes
         assert fused[: sample * E] == o.add(1, a[: sample * E], b[: sample * E], subtract=sub)
+
+
+# ---------------------------------------------------------------- chunked host-buffer pipeline
+@pytest.mark.parametrize("name,count,chunk", [("k512", 5000, 700), ("toy64", 200000, 65536), ("k1024", 1500, 256)])
+def test_host_pipeline_matches_one_shot_staging(name, count, chunk, monkeypatch):
+    """The host-buffer entry points of Add / Sub / Neg run large calls in chunks over a ring of three staging
+    sets (upload / launch / download threads, engine.cpp host_pipeline).  With the chunk size forced small
+    (BGN_HOST_PIPE_CHUNK) the pipelined call must return the bytes of the one-shot staging path
+    (BGN_HOST_PIPE=0): Add / Sub plain and blinded, Neg, both levels, ragged last chunk; Encrypt and MultConst
+    (always one-shot) ride along unchanged; a sample against the C oracle."""
+    import oracle_c
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    o = oracle_c.Oracle.from_fixture(fx)
+    rng = random.Random(count)
+    n = int(fx["n"], 16)
+    T = fx["msg_space"]
+    xs = [rng.randrange(T) for _ in range(count)]
+    rs = [rng.randrange(n) for _ in range(count)]
+    ks = [rng.randrange(1, 1 << 20) for _ in range(count)]
+
+    def both(fn):
+        monkeypatch.setenv("BGN_HOST_PIPE", "0")
+        one = fn().tobytes()
+        monkeypatch.setenv("BGN_HOST_PIPE", "1")
+        monkeypatch.setenv("BGN_HOST_PIPE_CHUNK", str(chunk))
+        piped = fn().tobytes()
+        monkeypatch.delenv("BGN_HOST_PIPE_CHUNK")
+        assert piped == one
+        return one
+
+    ct = both(lambda: eng.encrypt(xs, rs))
+    det = both(lambda: eng.encrypt(xs))
+    E = eng.elem_bytes
+    s = min(count, 64)
+    assert ct[: s * E] == o.encrypt(xs[:s], rs[:s])
+    add = both(lambda: eng.add(1, ct, det))
+    assert add[: s * E] == o.add(1, ct[: s * E], det[: s * E])
+    both(lambda: eng.sub(1, ct, det))
+    both(lambda: eng.add(1, ct, det, r=rs))
+    both(lambda: eng.neg(1, ct))
+    mc = both(lambda: eng.multconst(1, ct, ks))
+    assert mc[: 8 * E] == o.multconst(1, ct[: 8 * E], ks[:8])
+    m = min(count, 1024)                                            # level 2 on a slice (a Mult per element)
+    l2 = eng.make_l2(ct[: m * E]).tobytes()
+    l2b = eng.make_l2(det[: m * E]).tobytes()
+    monkeypatch.setenv("BGN_HOST_PIPE_CHUNK", "100")
+    piped = eng.add(2, l2, l2b).tobytes()
+    piped_mc = eng.multconst(2, l2, ks[:m]).tobytes()
+    monkeypatch.setenv("BGN_HOST_PIPE", "0")
+    assert piped == eng.add(2, l2, l2b).tobytes()
+    assert piped_mc == eng.multconst(2, l2, ks[:m]).tobytes()

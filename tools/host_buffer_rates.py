@@ -19,10 +19,14 @@ out = np.zeros((n, eng.elem_bytes), dtype=np.uint8)
 P = lambda a: a.ctypes.data_as(C.c_void_p)
 
 
-def timed(label, fn, units, reps=2):
-    for _ in range(reps):
-        t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
-    print("%-14s n=%d  %.1f ms  %.3e /s" % (label, units, dt * 1e3, units / dt), flush=True)
+def timed(label, fn, units, reps=3):
+    """Each measurement with the one-shot staging path (BGN_HOST_PIPE=0) and with the chunked pipeline."""
+    for pipe in ("0", "1"):
+        os.environ["BGN_HOST_PIPE"] = pipe
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
+        print("%-16s pipeline=%s n=%d  %.1f ms  %.3e /s" % (label, pipe, units, best * 1e3, units / best), flush=True)
 
 
 timed("encrypt", lambda: check(eng._lib.bgn_encrypt_batch(eng._h, n, P(xs), 5, P(rs), 128, P(out)), "enc"), n)

@@ -16,7 +16,8 @@
 //     schedules every segment of the pairing into rounds of micro-ops, one per wave (COOP_W waves per pairing)
 //         dst = (sum ca*V[ia] + KA*p) * (sum cb*V[ib] + KB*p) / R + sum ce*V[ie] + KE*p
 //     over value slots V[] in LDS, with a workgroup barrier between rounds (a Miller doubling step: 18
-//     products in 5 rounds; an addition step: 17 in 6).  This file interprets those tables.
+//     products in 3 rounds; a doubling with the addition that follows it: 36 in 6).  This file interprets those
+//     tables.
 // The formulas are pairing.hpp's (Jacobian doubling / mixed addition, denominator elimination, NAF of n, final
 // exponent as conj(f)^2/N(f) then ^l); outputs are canonical, hence the same bytes as the one-pairing-per-lane
 // kernel.  The CPU tests hold a lane-level model of the arithmetic of this file.
@@ -251,6 +252,8 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     const u32 o = in ? P->one[lj] : 0u;
     V[COOP_SLOT_ONE][lane] = o;
     V[COOP_SLOT_Z_0][lane] = o;
+    V[COOP_SLOT_ZZ_0][lane] = o;
+    V[COOP_SLOT_W_0][lane] = o;
   } else if (wave == 3) {
     V[COOP_SLOT_BY][lane] = in ? b.c1[(size_t)lj * b.stride + eb] : 0u;
     const u32 o = in ? P->one[lj] : 0u;

@@ -96,7 +96,8 @@ class ValueMachine:
         V = self.V
         V.update({"ax": self.mont(ax), "ay": self.mont(ay), "bx": self.mont(bx), "by": self.mont(by),
                   "one": self.mont(1), "raw1": 1, "zero": 0})
-        V.update({"X@0": V["ax"], "Y@0": V["ay"], "Z@0": V["one"], "v0@0": V["one"], "v1@0": 0, "v2@0": V["one"]})
+        V.update({"X@0": V["ax"], "Y@0": V["ay"], "Z@0": V["one"], "ZZ@0": V["one"], "W@0": V["one"],
+                  "v0@0": V["one"], "v1@0": 0, "v2@0": V["one"]})
         par = 0
         d = naf(n)
         i = len(d) - 2
@@ -239,7 +240,8 @@ class LaneMachine(ValueMachine):
         for k, v in {"ax": self.mont(ax), "ay": self.mont(ay), "bx": self.mont(bx), "by": self.mont(by),
                      "one": self.mont(1), "raw1": 1, "zero": 0}.items():
             self.L[k] = to_lanes(v, self.nl)
-        for k, s in {"X@0": "ax", "Y@0": "ay", "Z@0": "one", "v0@0": "one", "v1@0": "zero", "v2@0": "one"}.items():
+        for k, s in {"X@0": "ax", "Y@0": "ay", "Z@0": "one", "ZZ@0": "one", "W@0": "one", "v0@0": "one", "v1@0": "zero",
+                     "v2@0": "one"}.items():
             self.L[k] = self.L[s].copy()
         self.V = _Unused()
         ValueMachine.pairing(self, ax, ay, bx, by, n, l)

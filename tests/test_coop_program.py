@@ -94,7 +94,7 @@ def test_schedule_properties():
                 assert not ({P.phys[s] for s in u.reads()} & (wr - {P.phys[u.dst]})), (name, r)
                 assert P.phys[u.dst] not in {P.phys[s] for s in u.reads()}, (name, r, u.dst)
     seg = dict(P.segments)
-    assert len(seg["DBL0"]) == 4 and len(seg["DAP0"]) == 7
+    assert len(seg["DBL0"]) == 3 and len(seg["DD0"]) == 6 and len(seg["DAP0"]) == 6
 
 
 def test_generated_table_is_current():

@@ -116,13 +116,20 @@ class Builder:
         return S(u.dst)
 
 
+# Round-time model of the search below (cycles at a 1024- / 512-bit key averaged): a round costs its fixed part
+# (barrier, operand reads, normalisation, store) plus one product, or ROUND_HEAVY products' worth when more than
+# `base` products make two waves share a SIMD.
+ROUND_FIXED, ROUND_PRODUCT, ROUND_HEAVY = 1000, 1700, 1.33
+
+
 def schedule(uops, w=W, base=BASE):
-    """List scheduling into rounds of at most w micro-ops; a micro-op reads only slots written in earlier rounds
-    (or never written in this segment).  Priority: longest path to a sink.  A round takes its `base` best ready
-    micro-ops (one wave per SIMD) and fills the second wave of a SIMD only with micro-ops as critical as the best
-    one: two waves on a SIMD share its issue slots (a product takes ~1.33x as long beside another one), so a fifth
-    product pays only where it shortens the schedule.  Measured on the Miller segments against 4 waves: a doubling
-    4 rounds instead of 5, doubling + addition 7 instead of 9."""
+    """Scheduling into rounds of at most w micro-ops; a micro-op reads only slots written in earlier rounds (or
+    never written in this segment).  Products are taken in order of their longest path to a sink.  Two waves on a
+    SIMD share its issue slots, so a round with more than `base` products takes about 1.33x as long (measured) as one with at
+    most `base` — but then it may as well hold w of them.  Every round therefore takes either its `base` best ready
+    products or up to w, and the choice per round is searched exhaustively against the round-time model above
+    (a segment is at most a dozen rounds).  Linear micro-ops cost no product: they fill free waves of the first
+    round they are ready in.  Measured against 4 waves with one product each: a doubling 3 rounds instead of 5."""
     writer = {u.dst: i for i, u in enumerate(uops)}
     assert len(writer) == len(uops), "a slot is written twice in one segment"
     deps = [sorted(writer[s] for s in u.reads() if s in writer) for u in uops]
@@ -136,19 +143,38 @@ def schedule(uops, w=W, base=BASE):
     for i in reversed(range(len(uops))):
         wgt = MUL_WEIGHT if uops[i].kind == "mul" else LIN_WEIGHT
         prio[i] = wgt + max((prio[j] for j in users[i]), default=0)
-    done, rounds = {}, []
-    while len(done) < len(uops):
+    n = len(uops)
+    best = [None, None]                       # cost, list of rounds (index lists)
+
+    def search(done, rounds, cost):
+        if best[0] is not None and cost >= best[0]:
+            return
+        if len(done) == n:
+            best[0], best[1] = cost, [list(r) for r in rounds]
+            return
         r = len(rounds)
-        ready = [i for i in range(len(uops)) if i not in done and all(j in done and done[j] < r for j in deps[i])]
-        ready.sort(key=lambda i: (-prio[i], i))
-        take = ready[:base]
-        assert take
-        take += [i for i in ready[base:w] if prio[i] >= prio[take[0]]]
+        ready = [i for i in range(n) if i not in done and all(j in done and done[j] < r for j in deps[i])]
+        assert ready
+        muls = sorted((i for i in ready if uops[i].kind == "mul"), key=lambda i: (-prio[i], i))
+        lins = sorted((i for i in ready if uops[i].kind != "mul"), key=lambda i: (-prio[i], i))
+        options = sorted({min(len(muls), base), min(len(muls), w)}, reverse=True)
+        for k in options:
+            take = muls[:k] + lins[: w - k]
+            if not take:
+                continue
+            c = ROUND_FIXED + (0 if k == 0 else ROUND_PRODUCT * (1 if k <= base else ROUND_HEAVY))
+            d2 = dict(done)
+            for i in take:
+                d2[i] = r
+            search(d2, rounds + [take], cost + c)
+
+    search({}, [], 0)
+    out = []
+    for r, take in enumerate(best[1]):
         for i in take:
-            done[i] = r
             uops[i].round = r
-        rounds.append([uops[i] for i in take])
-    return rounds
+        out.append([uops[i] for i in take])
+    return out
 
 
 class Program:
@@ -205,7 +231,9 @@ class Program:
 # ---------------------------------------------------------------------------------------------------------------
 # The pairing
 # ---------------------------------------------------------------------------------------------------------------
-STATE_BOUNDS = {"X": 19, "Y": 19, "Z": 2, "v0": 2, "v1": 2, "v2": 2}      # Miller state: V = (X, Y, Z), f = v-form
+# Miller state: V = (X, Y, Z) with ZZ = Z^2 and W = Z^4 carried along (the doubling then needs no product before
+# M = 3 X^2 + Z^4 and the line's Z^2 * xB, Z^2 * yB: three rounds deep instead of four), f = v-form
+STATE_BOUNDS = {"X": 19, "Y": 19, "Z": 2, "ZZ": 2, "W": 2, "v0": 2, "v1": 2, "v2": 2}
 
 
 def build_program():
@@ -241,51 +269,59 @@ def build_program():
         b.mul(F1, cim, out=name(so["v1"]))
         b.mul(F0 + F1, cre + cim, out=name(so["v2"]))
 
-    def dbl(b, si, so):
-        """pairing.hpp miller_double: f <- f^2 * l_{V,V}(phi(B)), V <- 2V (Jacobian, a = 1)."""
-        X, Y, Z = si["X"], si["Y"], si["Z"]
+    def dbl(b, si, so, want_w=True):
+        """pairing.hpp miller_double: f <- f^2 * l_{V,V}(phi(B)), V <- 2V (Jacobian, a = 1), arranged three products
+        deep: X3 = M^2 - 2S is never an operand of a product here (Y3 takes M^2 and X*YY directly), the line takes
+        ZZ and W from the state."""
+        X, Y, Z, ZZ, Wq = si["X"], si["Y"], si["Z"], si["ZZ"], si["W"]
         F0, F1 = f_of(si)
-        ZZ = b.mul(Z, Z)
         XX = b.mul(X, X)
         YY = b.mul(Y, Y)
         Z3 = b.mul(2 * Y, Z, out=name(so["Z"]))
         g0 = b.mul(F0 + F1, F0 - F1)
         g1h = b.mul(F0, F1)
-        Wq = b.mul(ZZ, ZZ)
+        ZZxB = b.mul(ZZ, bx)
+        ZZyB = b.mul(ZZ, by)
+        M = 3 * XX + Wq
+        M2 = b.mul(M, M)
         XYY = b.mul(X, YY)
         Y4 = b.mul(YY, YY)
-        ZZxB = b.mul(ZZ, bx)
-        Z3ZZ = b.mul(Z3, ZZ)
-        cim = b.mul(Z3ZZ, by)
-        M = 3 * XX + Wq
-        X3 = b.mul(M, M, E=-8 * XYY, out=name(so["X"]))                 # M^2 - 2S, S = 4 X YY
         cre = b.mul(M, ZZxB + X, E=-2 * YY)
-        b.mul(M, 4 * XYY - X3, E=-8 * Y4, out=name(so["Y"]))            # M (S - X3) - 8 YY^2
+        cim = b.mul(Z3, ZZyB)                                            # (Z3 ZZ) yB
+        ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
+        b.lin(M2 - 8 * XYY, out=name(so["X"]))                           # M^2 - 2S, S = 4 X YY
+        b.mul(M, 12 * XYY - M2, E=-8 * Y4, out=name(so["Y"]))            # M (S - X3) - 8 YY^2
+        if want_w:
+            b.mul(ZZ3, ZZ3, out=name(so["W"]))
         finish_f(b, g0, 2 * g1h, cre, cim, so)
 
     def add(sign):
         def build(b, si, so):
-            """pairing.hpp miller_add: f <- f * l_{V,sA}(phi(B)), V <- V + sA (mixed addition)."""
-            X, Y, Z = si["X"], si["Y"], si["Z"]
+            """pairing.hpp miller_add: f <- f * l_{V,sA}(phi(B)), V <- V + sA (mixed addition); ZZ comes with the
+            state, rr^2 and the line's rr*(xB + xA) are products of their own so that neither X3 nor cre sits on a
+            chain, and the new ZZ, W are made for the doubling that follows."""
+            X, Y, Z, ZZ = si["X"], si["Y"], si["Z"], si["ZZ"]
             F0, F1 = f_of(si)
             ysA = sign * ay
-            ZZ = b.mul(Z, Z)
             ZZZ = b.mul(ZZ, Z)
-            yZ3 = b.mul(ysA, ZZZ)
             xZZ = b.mul(ax, ZZ)
+            yZ3 = b.mul(ysA, ZZZ)
             rrr = yZ3 - Y
             H = xZZ - X
             Z3 = b.mul(Z, H, out=name(so["Z"]))
             HH = b.mul(H, H)
             HHH = b.mul(H, HH)
             XHH = b.mul(X, HH)
-            X3 = b.mul(rrr, rrr, E=-HHH - 2 * XHH, out=name(so["X"]))
-            YH = b.mul(Y, HHH)
-            b.mul(rrr, XHH - X3, E=-YH, out=name(so["Y"]))
+            rr2 = b.mul(rrr, rrr)
+            b.lin(rr2 - HHH - 2 * XHH, out=name(so["X"]))
+            YH = b.mul(b.mul(Y, H), HH)                                  # Y H^3 without waiting for H^3
+            b.mul(rrr, 3 * XHH + HHH - rr2, E=-YH, out=name(so["Y"]))    # rr (XHH - X3) - Y HHH
             Z3y = b.mul(Z3, ysA)
-            cre = b.mul(rrr, bx + ax, E=-Z3y)
+            T = b.mul(rrr, bx + ax)
             cim = b.mul(Z3, by)
-            finish_f(b, F0, F1, cre, cim, so)
+            ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
+            b.mul(ZZ3, ZZ3, out=name(so["W"]))
+            finish_f(b, F0, F1, T - Z3y, cim, so)
         return build
 
     # a NAF digit is followed by a zero, so the loop is a sequence of D (doubling) and DA+- (doubling, then the
@@ -307,7 +343,8 @@ def build_program():
                 mid = {k: S("%s%d.%s" % (nm, par, k)) for k in STATE_BOUNDS}
                 for k, f in mid.items():
                     b.bound[name(f)] = MID_BOUNDS[k]
-                dbl(b, si, mid)
+                del mid["W"]                                     # the addition does not read it
+                dbl(b, si, mid, want_w=False)
                 add(sign)(b, mid, so)
             P.segment("%s%d" % (nm, par), dbladd)
 
@@ -382,7 +419,7 @@ def emit(P, path):
     lines.append("#define COOP_W %d" % W)
     lines.append("#define COOP_NSLOTS %d" % P.nslots)
     lines.append("#define COOP_MAX_TERMS %d" % MAX_TERMS)
-    for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "v0@0", "v1@0", "v2@0",
+    for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "ZZ@0", "W@0", "v0@0", "v1@0", "v2@0",
                   "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1"):
         lines.append("#define COOP_SLOT_%s %d" % (gname.replace("@", "_").upper(), P.phys[gname]))
     lines.append("enum CoopSeg {")

@@ -30,7 +30,11 @@ rows = [
      f"{d['decrypt']['roofline']['kernel_ms']:.0f} ms per 2²⁰, the two walks with the full-width verification of hits "
      f"{d['decrypt']['roofline']['walk_kernels_ms']:.0f} ms; {ex['decrypt_2^20']['products_per_unit']:.0f} products per decrypt = "
      f"{ex['decrypt_2^20']['frac_of_product_ceiling']:.2f} of the product ceiling (8.15 × 10⁹ /s, `profiles/ubench_fp_rates_r01.txt`; the count "
-     f"prices squarings as products, hence a fraction near or above 1)"),
+     f"prices squarings as products, hence a fraction near or above 1)"
+     + (f"; HBM: {d['decrypt']['roofline']['achieved']:.2f} GB/s of algorithmic bytes = {d['decrypt']['roofline']['frac']:.1e} of 8 TB/s, PMC traffic of "
+        f"the lift {pmc['decrypt_lift_k_pairing_38_1']['hbm_bytes_per_launch']:.3g} B per 2²⁰ = "
+        f"{pmc['decrypt_lift_k_pairing_38_1']['hbm_bytes_per_launch'] / (274 * 2**20):.1f} × algorithmic (its SoA result and 636 B/lane of scratch)"
+        if 'decrypt_lift_k_pairing_38_1' in pmc else "")),
     ("Decrypt, level 2, 2¹⁶", f"{ex['decrypt_l2']['value']:.3g} /s"),
     ("Encrypt, 2²⁰", f"{ex['encrypt']['value']:.3g} /s (22-bit windows for Q since round 2; {ex['encrypt']['frac_of_product_ceiling']:.2f} of the "
                      f"product ceiling at the 20-bit count)"),

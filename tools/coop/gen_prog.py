@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Step programs of the wave-cooperative pairing kernel (bgn_amd/csrc/coop/), as scheduled micro-op tables.
 
-The small-batch kernel gives ONE pairing to a workgroup of W = 4 waves (one per SIMD of a CU).  A field element
+The small-batch kernel gives ONE pairing to a workgroup of W = 8 waves (two per SIMD of a CU).  A field element
 is spread over the lanes of a wave, one 28-bit limb per lane, so a value is one VGPR and a Montgomery product is
-NL broadcast-multiply-shift steps instead of 2*NL^2 multiply-adds in one lane.  What the four waves do is fixed by
+NL broadcast-multiply-shift steps instead of 2*NL^2 multiply-adds in one lane.  What the waves do is fixed by
 this file: every segment of the pairing (Miller doubling step, addition steps, the pieces of the final
 exponentiation; formulas of bgn_amd/csrc/pairing.hpp, which restates `Pair` of bgn.go:300) is a DAG of micro-ops
 
@@ -12,7 +12,7 @@ exponentiation; formulas of bgn_amd/csrc/pairing.hpp, which restates `Pair` of b
 
 over value slots V[] in LDS.  The generator tracks an upper bound (in units of p) for every slot, chooses the
 multiples of p that keep every operand non-negative, checks the Montgomery input condition
-bound(A) * bound(B) <= 2^9 <= R/p, list-schedules the DAG into rounds of at most W independent micro-ops
+bound(A) * bound(B) <= 2^9 <= R/p, schedules the DAG into rounds of at most W independent micro-ops
 (one per wave, a workgroup barrier between rounds) and assigns LDS slots by liveness.  Loop-carried state is
 ping-ponged between two slot sets so that no slot is read and written in the same round.
 

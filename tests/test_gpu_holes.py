@@ -289,3 +289,46 @@ def test_host_pipeline_matches_one_shot_staging(name, count, chunk, monkeypatch)
     monkeypatch.setenv("BGN_HOST_PIPE", "0")
     assert piped == eng.add(2, l2, l2b).tobytes()
     assert piped_mc == eng.multconst(2, l2, ks[:m]).tobytes()
+
+
+def test_host_pipeline_under_concurrent_callers(monkeypatch):
+    """Two host threads in bgn_add_batch on ONE context at the same time: one holds the context's staging ring
+    (pipelined), the other finds it taken and stages in one shot; a third thread runs a device-resident Mult on
+    its own stream meanwhile.  Every result equals the single-threaded one (the engine serialises launches per
+    context and orders its streams)."""
+    import threading
+    fx = load_fixture("k512")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    rng = random.Random(5)
+    n = int(fx["n"], 16)
+    count = 6000
+    pool = eng.encrypt([rng.randrange(fx["msg_space"]) for _ in range(32)], [rng.randrange(n) for _ in range(32)])
+    ia = np.array([rng.randrange(32) for _ in range(count)])
+    ib = np.array([rng.randrange(32) for _ in range(count)])
+    a, b = pool[ia].tobytes(), pool[ib].tobytes()
+    monkeypatch.setenv("BGN_HOST_PIPE", "0")
+    want_add = eng.add(1, a, b).tobytes()
+    want_sub = eng.sub(1, a, b).tobytes()
+    want_mul = eng.mult(a[: 64 * eng.elem_bytes], b[: 64 * eng.elem_bytes]).tobytes()
+    monkeypatch.setenv("BGN_HOST_PIPE", "1")
+    monkeypatch.setenv("BGN_HOST_PIPE_CHUNK", "500")
+    got, errs = {}, []
+
+    def run(key, fn):
+        try:
+            for _ in range(4):
+                got[key] = fn().tobytes()
+        except Exception as e:                                      # noqa: BLE001 - reported below
+            errs.append((key, repr(e)))
+
+    ts = [threading.Thread(target=run, args=("add", lambda: eng.add(1, a, b))),
+          threading.Thread(target=run, args=("sub", lambda: eng.sub(1, a, b))),
+          threading.Thread(target=run, args=("mul", lambda: eng.mult(a[: 64 * eng.elem_bytes], b[: 64 * eng.elem_bytes])))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in ts), "a caller is stuck"
+    assert got["add"] == want_add and got["sub"] == want_sub and got["mul"] == want_mul

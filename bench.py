@@ -198,9 +198,9 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
          "kernel": eng.last_kernel_name(), "kernel_ms_per_step": eng.last_kernel_ms(),
          "algorithmic_bytes_per_unit": xs.shape[1] + rs.shape[1] + EB},
         syn.encrypt_products(xs.shape[1] * 8, rs.shape[1] * 8), nl)
-    # --- EAdd (level 1): pairs of those ciphertexts
-    n_add = n_enc // 2
-    a1, b1 = cts[: n_add * EB], cts[n_add * EB: 2 * n_add * EB]
+    # --- EAdd (level 1): every ciphertext with its partner in a fixed permutation (the pairs of Config 3)
+    n_add = n_enc
+    a1, b1 = cts, syn.permuted_copy(cts, EB, seed=11)
     o1 = torch.empty(n_add * EB, dtype=torch.uint8, device=dev)
     dt = _timed(lambda: eng.add_dev(1, a1, b1, o1, n_add), sync)
     out["eadd_l1"] = op_rooflines(
@@ -208,7 +208,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
          "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion), wire bytes to wire bytes",
          "kernel": eng.last_kernel_name(), "algorithmic_bytes_per_unit": 3 * EB},
         syn.eadd_products(n_add), nl)
-    del o1
+    del o1, b1
     # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
     npoly, d1, d2 = 1 << 12, 16, 16
     pa = cts[: npoly * d1 * EB]

@@ -36,6 +36,89 @@ __device__ __forceinline__ void limbs_to_wire(uint8_t* __restrict__ dst, int L, 
   }
 }
 
+// ---- dword codec ---------------------------------------------------------------------------------
+// The byte-by-byte forms above cost seven LDS byte reads and a dozen shifts per limb pair: ~2.6 k instructions
+// per element, more than a field product.  When an element is a whole number of dwords (L even: every lane's
+// element then has the same alignment inside the stage) and the stage holds the slice dword-aligned, the same
+// conversion runs on dwords.  Decoding: a 28-bit limb lies inside four consecutive bytes of the big-endian
+// string, i.e. inside two adjacent dwords — one 8-byte LDS read, one v_perm_b32 (the four bytes, most
+// significant first), one shift-and-mask.  Encoding: the element x || y read backwards is the little-endian
+// number y + x * 2^(8L); its dwords are funnel shifts of the limbs, byte-swapped into place.  Every position
+// depends on the limb / dword index (compile time after unrolling) and on L (wave-uniform): scalar arithmetic.
+__device__ __forceinline__ u32 codec_perm(u32 hi, u32 lo, u32 sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const u64 both = ((u64)hi << 32) | lo;
+  u32 r = 0;
+  for (int i = 0; i < 4; ++i) r |= (u32)((both >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+  return r;
+#endif
+}
+
+__device__ __forceinline__ bool codec_dword_ok(int L, u32 mis) { return (L & 1) == 0 && L >= 4 && mis == 0; }
+
+// Limbs of the big-endian L-byte value that starts `off` bytes into the lane's element; `we` points at the
+// element's first dword.  Reads at most one dword past the value (the stage has the slack).
+template <int NL>
+__device__ __forceinline__ void wire_to_limbs_dw(Fp<NL>& r, const u32* __restrict__ we, int off, int L) {
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int bx = L - 1 - ((LIMB_BITS * k) >> 3);        // byte holding the limb's lowest bit, from the value's start
+    if (bx < 0) {                                         // wave-uniform
+      r.v[k] = 0;
+      continue;
+    }
+    const int a = bx >= 3 ? bx - 3 : 0;                   // the four bytes [a, a+4) hold the limb (clamped at the top)
+    const int sh = ((LIMB_BITS * k) & 7) + 8 * (bx >= 3 ? 0 : 3 - bx);
+    const u32 byte = (u32)(off + a);
+    const u32 q = byte >> 2, s = byte & 3u;
+    const u32 sel = (s << 24) | ((s + 1) << 16) | ((s + 2) << 8) | (s + 3);
+    const u32 v = codec_perm(we[q + 1], we[q], sel);      // bytes a .. a+3, most significant first
+    r.v[k] = (v >> sh) & LIMB_MASK;
+  }
+}
+
+// Little-endian dword i of sum v[k] * 2^(28 k) (i is a constant once the caller's loop is unrolled).
+template <int NL>
+__device__ __forceinline__ u32 limbs_dword(const Fp<NL>& a, int i) {
+  const int k0 = (32 * i) / LIMB_BITS, o = 32 * i - LIMB_BITS * k0;
+  u32 d = 0;
+  if (k0 < NL) d = a.v[k0 < NL ? k0 : 0] >> o;
+  if (k0 + 1 < NL) d |= a.v[k0 + 1 < NL ? k0 + 1 : 0] << (LIMB_BITS - o);
+  if (o > 2 * LIMB_BITS - 32 && k0 + 2 < NL) d |= a.v[k0 + 2 < NL ? k0 + 2 : 0] << (2 * LIMB_BITS - o);
+  return d;
+}
+
+// The element x || y (canonical values, each big-endian in L bytes) into the lane's 2L bytes at `we`.
+template <int NL>
+__device__ __forceinline__ void limbs_to_wire_dw(u32* __restrict__ we, int L, const Fp<NL>& x, const Fp<NL>& y) {
+  constexpr int ND = (LIMB_BITS * NL + 31) / 32;          // dwords a value can occupy
+  constexpr u32 BSWAP = 0x00010203u;
+  const int nd = L / 2;                                   // dwords per element
+  const int mL = L / 4;                                   // whole dwords of y
+  u32 ytop = 0;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const u32 yd = limbs_dword<NL>(y, i);
+    if (i < mL) we[nd - 1 - i] = codec_perm(0, yd, BSWAP);
+    if (i == mL) ytop = yd & 0xFFFFu;                     // L = 2 mod 4: y's top 16 bits share a dword with x
+  }
+  if ((L & 2) == 0) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      if (mL + i < nd) we[nd - 1 - (mL + i)] = codec_perm(0, limbs_dword<NL>(x, i), BSWAP);
+  } else {
+    u32 prev = ytop;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const u32 xd = limbs_dword<NL>(x, i);
+      if (mL + i < nd) we[nd - 1 - (mL + i)] = codec_perm(0, (xd << 16) | prev, BSWAP);
+      prev = xd >> 16;
+    }
+  }
+}
+
 // ---- LDS staging of a workgroup's slice of a wire array ---------------------------------------
 // Element e of a wire array starts at byte e*2L: a lane walking its own element touches a different
 // cache line than its neighbours on every byte.  The workgroup therefore moves its contiguous slice
@@ -45,17 +128,45 @@ __device__ __forceinline__ void limbs_to_wire(uint8_t* __restrict__ dst, int L, 
 template <int NL>
 struct WireStage {
   static constexpr int LMAX = (LIMB_BITS * NL - 9 + 7) / 8;            // largest L this limb count serves
-  static constexpr int WORDS = (FP_BLOCK * 2 * LMAX) / 4 + 2;
-  u32 w[WORDS];
+  static constexpr int WORDS = ((FP_BLOCK * 2 * LMAX) / 4 + 2 + 3) / 4 * 4;
+  alignas(16) u32 w[WORDS];
 };
 
 // HBM -> LDS.  Returns the byte offset of the slice inside the stage.  Ends with a barrier.
+// A workgroup runs one wave per SIMD, so nothing hides the latency of a load but other loads of the same wave:
+// the copy moves 16 bytes per lane and keeps eight loads in flight (a slice of 256 elements of 260 bytes is 17
+// such rows; one dword per lane and one load at a time took 65 round trips to HBM per slice — the whole cost of
+// the decode and encode kernels).
 template <int NL>
 __device__ __forceinline__ u32 wire_stage_in(WireStage<NL>* st, const uint8_t* __restrict__ g, size_t nbytes) {
   const u32 mis = (u32)((uintptr_t)g & 3u);
   const u32* __restrict__ ga = (const u32*)(g - mis);     // the dwords holding the first/last bytes are read whole
   const u32 nw = (u32)((mis + nbytes + 3) / 4);
-  for (u32 i = threadIdx.x; i < nw; i += FP_BLOCK) st->w[i] = ga[i];
+  u32 done = 0;
+  if (((uintptr_t)ga & 15u) == 0) {
+    const uint4* __restrict__ g4 = (const uint4*)ga;
+    uint4* s4 = (uint4*)st->w;
+    const u32 n4 = nw / 4;
+    u32 i = threadIdx.x;
+    for (; i + 7 * FP_BLOCK < n4; i += 8 * FP_BLOCK) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = g4[i + k * FP_BLOCK];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s4[i + k * FP_BLOCK] = v[k];
+    }
+    {                                                     // up to seven more rows, again all loads first
+      uint4 v[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        if (i + k * FP_BLOCK < n4) v[k] = g4[i + k * FP_BLOCK];
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        if (i + k * FP_BLOCK < n4) s4[i + k * FP_BLOCK] = v[k];
+    }
+    done = 4 * n4;
+  }
+  for (u32 i = done + threadIdx.x; i < nw; i += FP_BLOCK) st->w[i] = ga[i];
   __syncthreads();
   return mis;
 }
@@ -68,7 +179,15 @@ __device__ __forceinline__ void wire_stage_out(const WireStage<NL>* st, uint8_t*
   u32* __restrict__ ga = (u32*)(g - mis);
   const u32 end = mis + (u32)nbytes;
   const u32 nw = (end + 3) / 4;
-  for (u32 i = threadIdx.x; i < nw; i += FP_BLOCK) {
+  u32 first = 0;
+  if (mis == 0 && ((uintptr_t)ga & 15u) == 0) {            // whole 16-byte rows of the slice
+    uint4* __restrict__ g4 = (uint4*)ga;
+    const uint4* s4 = (const uint4*)st->w;
+    const u32 n4 = (u32)(nbytes / 16);
+    for (u32 i = threadIdx.x; i < n4; i += FP_BLOCK) g4[i] = s4[i];
+    first = 4 * n4;
+  }
+  for (u32 i = first + threadIdx.x; i < nw; i += FP_BLOCK) {
     const u32 lo = 4 * i;
     if (lo >= mis && lo + 4 <= end) {
       ga[i] = st->w[i];

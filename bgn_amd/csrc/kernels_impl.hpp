@@ -20,10 +20,11 @@ constexpr int NL_ = BGN_NL;
 #define BGN_STR2(x) #x
 #define BGN_STR(x) BGN_STR2(x)
 
-template <int NL>
+// PLAIN: limbs of the residues as they are (what EAdd / ESub work on) — no Montgomery conversion and therefore no
+// product slot in LDS, so two workgroups fit a CU and overlap their staging copies.
+template <int NL, bool PLAIN>
 __global__ void __launch_bounds__(FP_BLOCK)
-k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, SoA2 out, int plain) {
-  __shared__ LFp<NL> stage;
+k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, SoA2 out) {
   __shared__ WireStage<NL> ws;
   const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
   const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
@@ -31,21 +32,28 @@ k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, i
   const u32 mis = wire_stage_in<NL>(&ws, wire + e0 * EB, nel * EB);
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
-  const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
   Fp<NL> x, y;
-  wire_to_limbs<NL>(x, src, L);
-  wire_to_limbs<NL>(y, src + L, L);
+  if (codec_dword_ok(L, mis)) {                // wave-uniform: an element is a whole number of aligned dwords
+    const u32* we = ws.w + threadIdx.x * (u32)(EB / 4);
+    wire_to_limbs_dw<NL>(x, we, 0, L);
+    wire_to_limbs_dw<NL>(y, we, L, L);
+  } else {
+    const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
+    wire_to_limbs<NL>(x, src, L);
+    wire_to_limbs<NL>(y, src + L, L);
+  }
   if (out.inf) out.inf[e] = (fp_is_zero_limbs(x) && fp_is_zero_limbs(y)) ? 1 : 0;
-  if (plain) {                              // wave-uniform
+  if (PLAIN) {
     g_store<NL>(out.c0, out.stride, e, x);
     g_store<NL>(out.c1, out.stride, e, y);
-    return;
+  } else {
+    __shared__ LFp<NL> stage;
+    Fp<NL> m;
+    fp_to_mont<NL>(m, x, P, &stage);
+    g_store<NL>(out.c0, out.stride, e, m);
+    fp_to_mont<NL>(m, y, P, &stage);
+    g_store<NL>(out.c1, out.stride, e, m);
   }
-  Fp<NL> m;
-  fp_to_mont<NL>(m, x, P, &stage);
-  g_store<NL>(out.c0, out.stride, e, m);
-  fp_to_mont<NL>(m, y, P, &stage);
-  g_store<NL>(out.c1, out.stride, e, m);
 }
 
 // ok[e] = 1 iff element e of `wire` is a valid encoding: components below p and, level 1, on the curve
@@ -63,10 +71,16 @@ k_validate(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire,
   const u32 mis = wire_stage_in<NL>(&ws, wire + e0 * EB, nel * EB);
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
-  const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
   Fp<NL> x, y;
-  wire_to_limbs<NL>(x, src, L);
-  wire_to_limbs<NL>(y, src + L, L);
+  if (codec_dword_ok(L, mis)) {                // wave-uniform: an element is a whole number of aligned dwords
+    const u32* we = ws.w + threadIdx.x * (u32)(EB / 4);
+    wire_to_limbs_dw<NL>(x, we, 0, L);
+    wire_to_limbs_dw<NL>(y, we, L, L);
+  } else {
+    const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
+    wire_to_limbs<NL>(x, src, L);
+    wire_to_limbs<NL>(y, src + L, L);
+  }
   // range: v < p  <=>  v - p borrows
   bool in_range = true;
   {
@@ -111,7 +125,6 @@ k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32*
   uint8_t* g = wire + e0 * EB;
   if (threadIdx.x < nel) {
     const size_t e = e0 + threadIdx.x;
-    uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
     Fp<NL> x, y;
     g_load<NL>(x, c0, stride, e);
     g_load<NL>(y, c1, stride, e);
@@ -119,8 +132,13 @@ k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32*
       fp_zero(x);
       fp_zero(y);
     }
-    limbs_to_wire<NL>(dst, L, x);
-    limbs_to_wire<NL>(dst + L, L, y);
+    if (codec_dword_ok(L, (u32)((uintptr_t)g & 3u))) {
+      limbs_to_wire_dw<NL>(ws.w + threadIdx.x * (u32)(EB / 4), L, x, y);
+    } else {
+      uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
+      limbs_to_wire<NL>(dst, L, x);
+      limbs_to_wire<NL>(dst + L, L, y);
+    }
   }
   wire_stage_out<NL>(&ws, g, nel * EB);
 }
@@ -508,14 +526,14 @@ static inline unsigned grid_for(size_t count) { return (unsigned)((count + FP_BL
 
 static void launch_decode(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out) {
   if (!count) return;
-  hipLaunchKernelGGL(k_decode<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire,
-                     L, count, out, 0);
+  hipLaunchKernelGGL((k_decode<NL_, false>), dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     wire, L, count, out);
 }
 
 static void launch_decode_plain(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out) {
   if (!count) return;
-  hipLaunchKernelGGL(k_decode<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire,
-                     L, count, out, 1);
+  hipLaunchKernelGGL((k_decode<NL_, true>), dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params,
+                     wire, L, count, out);
 }
 
 static void launch_validate(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int level,
@@ -833,16 +851,28 @@ __device__ __forceinline__ void g1_wire_load(WireOperands<NL>& o, WireStage<NL>*
   const bool mine = threadIdx.x < nel;
   u32 mis = wire_stage_in<NL>(ws, a + e0 * EB, nel * EB);
   if (mine) {
-    const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
-    wire_to_limbs<NL>(o.x1, src, L);
-    wire_to_limbs<NL>(o.y1, src + L, L);
+    if (codec_dword_ok(L, mis)) {
+      const u32* we = ws->w + threadIdx.x * (u32)(EB / 4);
+      wire_to_limbs_dw<NL>(o.x1, we, 0, L);
+      wire_to_limbs_dw<NL>(o.y1, we, L, L);
+    } else {
+      const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
+      wire_to_limbs<NL>(o.x1, src, L);
+      wire_to_limbs<NL>(o.y1, src + L, L);
+    }
   }
   __syncthreads();
   mis = wire_stage_in<NL>(ws, b + e0 * EB, nel * EB);
   if (mine) {
-    const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
-    wire_to_limbs<NL>(o.x2, src, L);
-    wire_to_limbs<NL>(o.y2, src + L, L);
+    if (codec_dword_ok(L, mis)) {
+      const u32* we = ws->w + threadIdx.x * (u32)(EB / 4);
+      wire_to_limbs_dw<NL>(o.x2, we, 0, L);
+      wire_to_limbs_dw<NL>(o.y2, we, L, L);
+    } else {
+      const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
+      wire_to_limbs<NL>(o.x2, src, L);
+      wire_to_limbs<NL>(o.y2, src + L, L);
+    }
   }
   __syncthreads();
   if (!mine) {
@@ -940,9 +970,13 @@ k_g1_add_wire(const FpParams<NL>* __restrict__ P, const PairingConsts* __restric
         fp_zero(ox);
         fp_zero(oy);
       }
-      uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
-      limbs_to_wire<NL>(dst, L_, ox);
-      limbs_to_wire<NL>(dst + L_, L_, oy);
+      if (codec_dword_ok(L_, (u32)((uintptr_t)g & 3u))) {
+        limbs_to_wire_dw<NL>(ws.w + threadIdx.x * (u32)(EB / 4), L_, ox, oy);
+      } else {
+        uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
+        limbs_to_wire<NL>(dst, L_, ox);
+        limbs_to_wire<NL>(dst + L_, L_, oy);
+      }
     }
     wire_stage_out<NL>(&ws, g, nel * EB);
     __syncthreads();

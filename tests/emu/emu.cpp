@@ -48,6 +48,22 @@ struct Emu {
     limbs_to_wire<NL>(wire, Lb, x);
     limbs_to_wire<NL>(wire + Lb, Lb, y);
   }
+  // the dword codec on a staged slice: `n` elements of 2L bytes at the start of a dword-aligned stage (with the
+  // slack the kernels' WireStage has); lane `i` decodes element i, re-encodes it into a second stage
+  static void codec_dw(const uint8_t* wire, int Lb, int n, u32* limbs_out, uint8_t* wire_out) {
+    std::vector<u32> in((size_t)n * 2 * Lb / 4 + 4, 0xA5A5A5A5u), out((size_t)n * 2 * Lb / 4 + 4, 0);
+    memcpy(in.data(), wire, (size_t)n * 2 * Lb);
+    for (int i = 0; i < n; ++i) {
+      Fp<NL> x, y;
+      const u32* we = in.data() + (size_t)i * (2 * Lb / 4);
+      wire_to_limbs_dw<NL>(x, we, 0, Lb);
+      wire_to_limbs_dw<NL>(y, we, Lb, Lb);
+      memcpy(limbs_out + (size_t)i * 2 * NL, x.v, 4 * NL);
+      memcpy(limbs_out + (size_t)i * 2 * NL + NL, y.v, 4 * NL);
+      limbs_to_wire_dw<NL>(out.data() + (size_t)i * (2 * Lb / 4), Lb, x, y);
+    }
+    memcpy(wire_out, out.data(), (size_t)n * 2 * Lb);
+  }
   // Montgomery-form inverse of a Montgomery-form value (limbs in, limbs out)
   static void fp_inv(const u32* params, int p_bits, const u32* a, u32* out) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
@@ -399,6 +415,7 @@ struct Emu {
 extern "C" {
 int emu_decode(int nl, const u32* params, const uint8_t* wire, int Lb, u32* out, uint8_t* inf) { DISPATCH(nl, decode(params, wire, Lb, out, inf)) }
 int emu_encode(int nl, const u32* plain, int Lb, uint8_t inf, uint8_t* wire) { DISPATCH(nl, encode(plain, Lb, inf, wire)) }
+int emu_codec_dw(int nl, const uint8_t* wire, int Lb, int n, u32* limbs_out, uint8_t* wire_out) { DISPATCH(nl, codec_dw(wire, Lb, n, limbs_out, wire_out)) }
 int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing(params, (const PairingConsts*)C, a, b, out)) }
 int emu_pairing_w3(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_w3(params, (const PairingConsts*)C, a, b, out)) }
 int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, int window, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, window, out, oinf)) }

@@ -13,6 +13,7 @@
 #define __launch_bounds__(...)
 #define __restrict__
 struct EmuDim3 { unsigned x, y, z; };
+struct uint4 { unsigned x, y, z, w; };
 extern thread_local EmuDim3 threadIdx, blockIdx, gridDim, blockDim;
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 typedef void* hipStream_t;

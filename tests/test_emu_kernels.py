@@ -251,3 +251,30 @@ def test_emu_interpreter_miller_loop(ctx):
     cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
     for v in fx["mult"][:4]:
         assert E.pairing_vm(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+
+
+@pytest.mark.parametrize("nl", [3, 10, 19, 38])
+def test_emu_dword_codec_matches_the_byte_codec(nl):
+    """codec.hpp's dword forms (wire_to_limbs_dw / limbs_to_wire_dw: two-dword reads + byte permutes, used when an
+    element is a whole number of dwords) against Python integers for every even L the limb count serves: limbs of
+    random values incl. 0, 1, 2^(8L) - 1 patterns, and the re-encoded bytes equal the input."""
+    import ctypes as C
+    lib = emu.Emu.from_fixture(load_fixture("toy64")).lib
+    rng = random.Random(nl)
+    lmax = (28 * nl - 9 + 7) // 8
+    lmin = max(4, (28 * (nl - 1) + 7) // 8 - 6)
+    for L in range(lmin, lmax + 1):
+        if L % 2:
+            continue
+        n = 9
+        top = min(8 * L, 28 * nl)
+        vals = [0, 1, (1 << top) - 1, (1 << (top - 1)) + 1] + [rng.getrandbits(top) for _ in range(2 * n - 4)]
+        wire = b"".join(v.to_bytes(L, "big") for v in vals)
+        limbs_out = (C.c_uint32 * (2 * nl * n))()
+        wire_out = C.create_string_buffer(2 * L * n)
+        assert lib.emu_codec_dw(nl, wire, L, n, limbs_out, wire_out) == 0
+        for i, v in enumerate(vals):
+            got = sum(int(limbs_out[i * nl + j]) << (28 * j) for j in range(nl))
+            assert all(int(limbs_out[i * nl + j]) < (1 << 28) for j in range(nl))
+            assert got == v, (nl, L, i, hex(v), hex(got))
+        assert wire_out.raw == wire, (nl, L)

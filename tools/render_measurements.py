@@ -38,10 +38,10 @@ rows = [
     ("Decrypt, level 2, 2¹⁶", f"{ex['decrypt_l2']['value']:.3g} /s"),
     ("Encrypt, 2²⁰", f"{ex['encrypt']['value']:.3g} /s (22-bit windows for Q since round 2; {ex['encrypt']['frac_of_product_ceiling']:.2f} of the "
                      f"product ceiling at the 20-bit count)"),
-    ("EAdd level 1, 2¹⁹, three launches",
+    ("EAdd level 1, 2%s, three launches" % {19: "¹⁹", 20: "²⁰"}.get(ex['eadd_l1']['batch'].bit_length() - 1, "^?"),
      f"{ex['eadd_l1']['value']:.3g} /s = {ex['eadd_l1']['hbm']['achieved_GBps']:.0f} GB/s of wire traffic ({ex['eadd_l1']['hbm']['frac']:.3f} of HBM "
-     f"peak), {ex['eadd_l1']['frac_of_product_ceiling']:.2f} of the product ceiling at 13.9 product-equivalents per addition (7 + one shared "
-     f"inversion per run of 8)"),
+     f"peak), {ex['eadd_l1']['frac_of_product_ceiling']:.2f} of the product ceiling at {ex['eadd_l1']['products_per_unit']:.1f} product-equivalents "
+     f"per addition (7 + one shared inversion per run of {max(1, ex['eadd_l1']['batch'] // 65536)}); by batch size: `profiles/r02_eadd_sweep.csv`"),
     ("MultPoly 16×16, 4096 polynomials", f"{ex['multpoly']['value']:.3g} coefficient pairs/s"),
     ("configs[0]: 512-bit, 128 ciphertexts, host buffers",
      f"EMult **{c0['emult']['value']:.3g} ops/s** ({c0['emult']['wall_ms_for_128']:.2f} ms for the 128; 4.6 × 10³ in round 1; C oracle on one "

@@ -29,9 +29,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# profiles/ubench_valu_rates_r01.txt: v_mad_u64_u32 wave-instructions per second, whole chip
-VALU_MAD_PEAK_4W = 454.75e9 * 64   # lane-MADs/s at 4 waves per SIMD (the chip's ceiling)
-VALU_MAD_PEAK_1W = 378.08e9 * 64   # at 1 wave per SIMD — the occupancy these 512-register kernels run at
+# profiles/r02_occupancy_rates.txt (tools/ubench/occupancy_rates.hip: exactly k waves on every SIMD, wall clock):
+# v_mad_u64_u32 wave-instructions per second over the chip, mean of the two forms a Montgomery row alternates
+# between (VGPR multiplicand 369.5 / 508.7 G, scalar multiplicand 427.3 / 544.1 G at 1 / 4 waves per SIMD).
+# Round 1's table (ubench_valu_rates_r01.txt: 378 / 455 G) did not pin its occupancy and read low at 4 waves.
+VALU_MAD_PEAK_4W = 526.4e9 * 64    # lane-MADs/s at 4 waves per SIMD (the chip's ceiling)
+VALU_MAD_PEAK_1W = 398.4e9 * 64    # at 1 wave per SIMD — the occupancy these 512-register kernels run at
 # profiles/ubench_fp_rates_r01.txt: field products per second of the whole chip at NL = 38, one wave per SIMD
 PRODUCT_CEILING = {38: 8.15e9}
 

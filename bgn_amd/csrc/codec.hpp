@@ -79,6 +79,22 @@ __device__ __forceinline__ void wire_to_limbs_dw(Fp<NL>& r, const u32* __restric
   }
 }
 
+// x and y of lane `tid`'s element out of a dword-aligned stage (mis == 0, L >= 4), for either parity of L.  With L
+// odd an element is 2 mod 4 bytes long: even lanes start on a dword, odd lanes two bytes into one, so the two
+// parities decode with their own (compile-time) offsets under a lane-parity branch.
+template <int NL>
+__device__ __forceinline__ void wire_element_dw(Fp<NL>& x, Fp<NL>& y, const u32* __restrict__ w, u32 tid, int L) {
+  const u32 eb = tid * (u32)(2 * L);
+  const u32* we = w + (eb >> 2);
+  if ((L & 1) == 0 || (tid & 1u) == 0) {
+    wire_to_limbs_dw<NL>(x, we, 0, L);
+    wire_to_limbs_dw<NL>(y, we, L, L);
+  } else {
+    wire_to_limbs_dw<NL>(x, we, 2, L);
+    wire_to_limbs_dw<NL>(y, we, 2 + L, L);
+  }
+}
+
 // Little-endian dword i of sum v[k] * 2^(28 k) (i is a constant once the caller's loop is unrolled).
 template <int NL>
 __device__ __forceinline__ u32 limbs_dword(const Fp<NL>& a, int i) {

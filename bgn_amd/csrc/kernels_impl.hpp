@@ -33,10 +33,8 @@ k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, i
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
   Fp<NL> x, y;
-  if (codec_dword_ok(L, mis)) {                // wave-uniform: an element is a whole number of aligned dwords
-    const u32* we = ws.w + threadIdx.x * (u32)(EB / 4);
-    wire_to_limbs_dw<NL>(x, we, 0, L);
-    wire_to_limbs_dw<NL>(y, we, L, L);
+  if (mis == 0 && L >= 4) {                    // wave-uniform: the slice is staged dword-aligned
+    wire_element_dw<NL>(x, y, ws.w, threadIdx.x, L);
   } else {
     const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
     wire_to_limbs<NL>(x, src, L);
@@ -72,10 +70,8 @@ k_validate(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire,
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
   Fp<NL> x, y;
-  if (codec_dword_ok(L, mis)) {                // wave-uniform: an element is a whole number of aligned dwords
-    const u32* we = ws.w + threadIdx.x * (u32)(EB / 4);
-    wire_to_limbs_dw<NL>(x, we, 0, L);
-    wire_to_limbs_dw<NL>(y, we, L, L);
+  if (mis == 0 && L >= 4) {                    // wave-uniform: the slice is staged dword-aligned
+    wire_element_dw<NL>(x, y, ws.w, threadIdx.x, L);
   } else {
     const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
     wire_to_limbs<NL>(x, src, L);
@@ -851,10 +847,8 @@ __device__ __forceinline__ void g1_wire_load(WireOperands<NL>& o, WireStage<NL>*
   const bool mine = threadIdx.x < nel;
   u32 mis = wire_stage_in<NL>(ws, a + e0 * EB, nel * EB);
   if (mine) {
-    if (codec_dword_ok(L, mis)) {
-      const u32* we = ws->w + threadIdx.x * (u32)(EB / 4);
-      wire_to_limbs_dw<NL>(o.x1, we, 0, L);
-      wire_to_limbs_dw<NL>(o.y1, we, L, L);
+    if (mis == 0 && L >= 4) {
+      wire_element_dw<NL>(o.x1, o.y1, ws->w, threadIdx.x, L);
     } else {
       const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
       wire_to_limbs<NL>(o.x1, src, L);
@@ -864,10 +858,8 @@ __device__ __forceinline__ void g1_wire_load(WireOperands<NL>& o, WireStage<NL>*
   __syncthreads();
   mis = wire_stage_in<NL>(ws, b + e0 * EB, nel * EB);
   if (mine) {
-    if (codec_dword_ok(L, mis)) {
-      const u32* we = ws->w + threadIdx.x * (u32)(EB / 4);
-      wire_to_limbs_dw<NL>(o.x2, we, 0, L);
-      wire_to_limbs_dw<NL>(o.y2, we, L, L);
+    if (mis == 0 && L >= 4) {
+      wire_element_dw<NL>(o.x2, o.y2, ws->w, threadIdx.x, L);
     } else {
       const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
       wire_to_limbs<NL>(o.x2, src, L);

@@ -51,16 +51,19 @@ struct Emu {
   // the dword codec on a staged slice: `n` elements of 2L bytes at the start of a dword-aligned stage (with the
   // slack the kernels' WireStage has); lane `i` decodes element i, re-encodes it into a second stage
   static void codec_dw(const uint8_t* wire, int Lb, int n, u32* limbs_out, uint8_t* wire_out) {
-    std::vector<u32> in((size_t)n * 2 * Lb / 4 + 4, 0xA5A5A5A5u), out((size_t)n * 2 * Lb / 4 + 4, 0);
+    std::vector<u32> in(((size_t)n * 2 * Lb + 3) / 4 + 4, 0xA5A5A5A5u), out(((size_t)n * 2 * Lb + 3) / 4 + 4, 0);
     memcpy(in.data(), wire, (size_t)n * 2 * Lb);
     for (int i = 0; i < n; ++i) {
       Fp<NL> x, y;
-      const u32* we = in.data() + (size_t)i * (2 * Lb / 4);
-      wire_to_limbs_dw<NL>(x, we, 0, Lb);
-      wire_to_limbs_dw<NL>(y, we, Lb, Lb);
+      wire_element_dw<NL>(x, y, in.data(), (u32)i, Lb);
       memcpy(limbs_out + (size_t)i * 2 * NL, x.v, 4 * NL);
       memcpy(limbs_out + (size_t)i * 2 * NL + NL, y.v, 4 * NL);
-      limbs_to_wire_dw<NL>(out.data() + (size_t)i * (2 * Lb / 4), Lb, x, y);
+      if (codec_dword_ok(Lb, 0)) {
+        limbs_to_wire_dw<NL>(out.data() + (size_t)i * (2 * Lb / 4), Lb, x, y);
+      } else {
+        limbs_to_wire<NL>((uint8_t*)out.data() + (size_t)i * 2 * Lb, Lb, x);
+        limbs_to_wire<NL>((uint8_t*)out.data() + (size_t)i * 2 * Lb + Lb, Lb, y);
+      }
     }
     memcpy(wire_out, out.data(), (size_t)n * 2 * Lb);
   }

@@ -255,17 +255,16 @@ def test_emu_interpreter_miller_loop(ctx):
 
 @pytest.mark.parametrize("nl", [3, 10, 19, 38])
 def test_emu_dword_codec_matches_the_byte_codec(nl):
-    """codec.hpp's dword forms (wire_to_limbs_dw / limbs_to_wire_dw: two-dword reads + byte permutes, used when an
-    element is a whole number of dwords) against Python integers for every even L the limb count serves: limbs of
-    random values incl. 0, 1, 2^(8L) - 1 patterns, and the re-encoded bytes equal the input."""
+    """codec.hpp's dword forms (wire_element_dw: two-dword reads + byte permutes, odd lanes two bytes into a dword
+    when L is odd; limbs_to_wire_dw when an element is a whole number of dwords) against Python integers for every
+    L the limb count serves: limbs of random values incl. 0, 1, 2^(8L) - 1 patterns, and the re-encoded bytes
+    equal the input."""
     import ctypes as C
     lib = emu.Emu.from_fixture(load_fixture("toy64")).lib
     rng = random.Random(nl)
     lmax = (28 * nl - 9 + 7) // 8
     lmin = max(4, (28 * (nl - 1) + 7) // 8 - 6)
     for L in range(lmin, lmax + 1):
-        if L % 2:
-            continue
         n = 9
         top = min(8 * L, 28 * nl)
         vals = [0, 1, (1 << top) - 1, (1 << (top - 1)) + 1] + [rng.getrandbits(top) for _ in range(2 * n - 4)]

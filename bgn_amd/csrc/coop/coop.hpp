@@ -156,8 +156,11 @@ __device__ __forceinline__ void coop_exec(u32 (*V)[64], const CoopWords& u, cons
 
 // One segment: its rounds in order, a workgroup barrier after each; the next round's micro-op is fetched while
 // the current one computes.
+// pslot >= 0: this wave also puts `pval` (a value requested from HBM before the call — the next table step's
+// coefficient) into slot pslot ahead of the segment's last barrier.
 template <int NL>
-__device__ __forceinline__ void coop_run(u32 (*V)[64], int seg, int wave, const CoopLane<NL>& c) {
+__device__ __forceinline__ void coop_run(u32 (*V)[64], int seg, int wave, const CoopLane<NL>& c, int pslot = -1,
+                                         u32 pval = 0) {
   const int first = (int)kCoopSegFirst[seg], n = (int)kCoopSegRounds[seg];
   CoopWords cur = coop_fetch_wait(coop_fetch_start(first, wave));
 #pragma unroll 1
@@ -165,6 +168,7 @@ __device__ __forceinline__ void coop_run(u32 (*V)[64], int seg, int wave, const 
     const coop_u32x8 nxt = coop_fetch_start(first + (r + 1 < n ? r + 1 : r), wave);
     coop_exec<NL>(V, cur, c);
     cur = coop_fetch_wait(nxt);
+    if (r == n - 1 && pslot >= 0) V[pslot][c.lane] = pval;
     __syncthreads();
   }
 }
@@ -214,7 +218,7 @@ template <int NL>
 __global__ void __launch_bounds__(COOP_BLOCK)
 k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
                size_t count, int mode, size_t d1, size_t d2, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
-               const u32* __restrict__ isoa, size_t ws) {
+               const u32* __restrict__ isoa, size_t ws, const u32* __restrict__ tab) {
   __shared__ u32 V[COOP_NSLOTS][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -248,20 +252,55 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     V[COOP_SLOT_Y_0][lane] = y;
     V[COOP_SLOT_RAW1][lane] = lane == 0 ? 1u : 0u;
   } else if (wave == 2) {
-    V[COOP_SLOT_BX][lane] = in ? b.c0[(size_t)lj * b.stride + eb] : 0u;
+    V[COOP_SLOT_BX][lane] = (in && !tab) ? b.c0[(size_t)lj * b.stride + eb] : 0u;
     const u32 o = in ? P->one[lj] : 0u;
     V[COOP_SLOT_ONE][lane] = o;
     V[COOP_SLOT_Z_0][lane] = o;
     V[COOP_SLOT_ZZ_0][lane] = o;
     V[COOP_SLOT_W_0][lane] = o;
   } else if (wave == 3) {
-    V[COOP_SLOT_BY][lane] = in ? b.c1[(size_t)lj * b.stride + eb] : 0u;
+    V[COOP_SLOT_BY][lane] = (in && !tab) ? b.c1[(size_t)lj * b.stride + eb] : 0u;
     const u32 o = in ? P->one[lj] : 0u;
     V[COOP_SLOT_V0_0][lane] = o;
     V[COOP_SLOT_V2_0][lane] = o;
   }
   int par = 0;
-  if (phase != 2) {
+  if (phase != 2 && tab) {
+    // mode "table" (fixedpair.hpp miller_loop_fixed on the waves): `a` holds the evaluation points (ciphertexts), the
+    // first argument is the key point whose normalised line table `tab` (limb j of value v of step s at
+    // tab[(3 s + v) NL + j], v = 0: a_s/c_s, 1: b_s/c_s) was built for the scalar whose NAF is C->naf.  A segment is
+    // one doubling step (two rounds) or a doubling and the addition after a non-zero digit (three rounds); waves
+    // 4..7 request the next segment's coefficients from HBM before the current one starts and park them in the
+    // other slot set at its last barrier.
+    static_assert(COOP_SLOT_TB1_0 == COOP_SLOT_TA1_0 + 1 && COOP_SLOT_TA2_0 == COOP_SLOT_TA1_0 + 2 &&
+                  COOP_SLOT_TB2_0 == COOP_SLOT_TA1_0 + 3 && COOP_SLOT_TA1_1 == COOP_SLOT_TA1_0 + 4 &&
+                  COOP_SLOT_TB2_1 == COOP_SLOT_TA1_0 + 7, "coefficient slots are consecutive");
+    static_assert(COOP_SEG_TDA0 == COOP_SEG_TD0 + 1 && COOP_SEG_TD1 == COOP_SEG_TD0 + 2 && COOP_SEG_TDA1 == COOP_SEG_TD0 + 3,
+                  "table segments are consecutive");
+    const u32* nafw = reinterpret_cast<const u32*>(C->naf);
+    auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
+    const int k = wave - 4;                                      // this wave's coefficient: step k >> 1, value k & 1
+    auto coef = [&](size_t s) { return in ? tab[((size_t)3 * (s + (size_t)(k >> 1)) + (size_t)(k & 1)) * NL + lj] : 0u; };
+    size_t s = 0;
+    int i = C->naf_len - 2;
+    if (k >= 0 && i >= 0 && (k < 2 || (digit(i) != 0 && i != 0))) V[COOP_SLOT_TA1_0 + k][lane] = coef(0);
+    __syncthreads();
+#pragma unroll 1
+    for (; i >= 0; --i) {
+      const bool both = digit(i) != 0 && i != 0;
+      const size_t sn = s + (both ? 2 : 1);
+      int pslot = -1;
+      u32 pval = 0;
+      if (k >= 0 && i >= 1 && (k < 2 || (digit(i - 1) != 0 && i - 1 != 0))) {
+        pslot = COOP_SLOT_TA1_0 + 4 * (par ^ 1) + k;
+        pval = coef(sn);
+      }
+      coop_run<NL>(V, COOP_SEG_TD0 + 2 * par + (both ? 1 : 0), wave, c, pslot, pval);
+      s = sn;
+      par ^= 1;
+    }
+    coop_run<NL>(V, COOP_SEG_NORM0 + par, wave, c);
+  } else if (phase != 2) {
   __syncthreads();
   // Miller loop over the NAF of n (pairing.hpp miller_loop); the state ping-pongs between two slot sets
   // (steps scheduled as segments: a doubling and the addition of +-A that follows it, two consecutive plain
@@ -335,7 +374,7 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   coop_run<NL>(V, lp ? COOP_SEG_OUT1 : COOP_SEG_OUT0, wave, c);
   // canonical residues out: wave 0 the real part, wave 1 the imaginary part
   if (wave < 2) {
-    const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]);       // e(O, .) = e(., O) = 1
+    const bool ident = (a.inf && a.inf[ea]) || (!tab && b.inf && b.inf[eb]);   // e(O, .) = e(., O) = 1
     u32 r = coop_canonical<NL>(V[wave == 0 ? COOP_SLOT_OUT0 : COOP_SLOT_OUT1][lane], c);
     if (ident) r = (wave == 0 && lane == 0) ? 1u : 0u;
     u32* dst = wave == 0 ? out.c0 : out.c1;

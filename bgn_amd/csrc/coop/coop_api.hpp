@@ -9,8 +9,11 @@ namespace bgn {
 // ws: workspace of coop_ws_words(nl, sw) u32 (sw >= count, the limb stride of its arrays) — the pairing then runs
 // as Miller-loop kernel, batched inversion of the norms (division steps, one per lane), final-exponentiation
 // kernel; ws == nullptr: one launch with the Fermat inversion on the waves.
+// tab != nullptr: e(K, a[e]) over the NORMALISED line table of the key point K (fixedpair.hpp; limb stride 1) built
+// for the scalar whose NAF `consts` holds; b is not read (mode 1's shape).
 bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                         size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits);
+                         size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits,
+                         const uint32_t* tab = nullptr);
 size_t coop_ws_words(int nl, size_t sw);
 // out[e] = a[e]^k[e] in F_p^2, one element per workgroup: a canonical Montgomery SoA (sa == 1: one base), k big-endian
 // bytes (klen <= 256 each; kstride 0: one exponent), out canonical Montgomery SoA.

@@ -680,26 +680,34 @@ static int pairing_variant() {
 static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                          size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len);
 
-// Small batches go to the wave-cooperative kernel (coop/coop.hpp: one pairing per workgroup of four waves) —
+// Small batches go to the wave-cooperative kernel (coop/coop.hpp: one pairing per workgroup of eight waves) —
 // a lane of k_pairing runs a whole pairing alone, so any batch below one wave per SIMD (65536 pairings) costs
 // the latency of ONE pairing there (166 ms at a 1024-bit key, 28 ms at 512 bits), while the cooperative kernel
 // finishes a pairing in a few milliseconds and runs one per CU (several with more workgroups resident).
 // The crossovers come from the committed sweep profiles/r02_small_batch.csv; BGN_COOP_MAX / BGN_COOP_MAX_L2
 // override them (0 disables the kernel).
+static bool coop_table_walk(const bgn_ctx* c) {
+  const char* ct = getenv("BGN_COOP_TABLE");
+  return c->fixed_normalized && !(ct && ct[0] == '0');
+}
+
 static size_t coop_limit(const bgn_ctx* c, int mode) {
   const char* ev = getenv(mode >= 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
-  // mode 2: the lift of Decrypt, whose lane kernel walks the half-length table of the secret order (37 ms at
-  // 1024 bits, 5 ms at 512): the cooperative kernel (a whole e(C, P)) wins below ~2000 / ~800 ciphertexts
-  if (mode == 2) return c->nl >= 38 ? 2000 : c->nl >= 19 ? 800 : 512;
+  const bool tw = coop_table_walk(c);
+  // mode 2: the lift of Decrypt.  The lane kernel walks the half-length table of the secret order (29 ms at 1024
+  // bits, 4.5 ms at 512, whatever the batch below 65536); the cooperative kernel walks the same table in two or
+  // three rounds per step (8192 lifts in 13 ms at 1024 bits, 8 ms at 512) — without the table walk it runs a whole
+  // e(C, P) and wins only below ~2000 / ~800 ciphertexts
+  if (mode == 2) return tw ? (c->nl >= 38 ? 14000 : c->nl >= 19 ? 4000 : 2048) : (c->nl >= 38 ? 2000 : c->nl >= 19 ? 800 : 512);
   // mode 3: Decrypt's power by the secret key: 1.5 rounds per bit on the waves (≈ 1 ms at 1024 bits, one element
   // per CU) against 2 products per bit on one lane (8 ms whatever the batch below 65536)
   if (mode == 3) return c->nl >= 38 ? 2048 : c->nl >= 19 ? 1024 : 512;
-  // profiles/r02_small_batch.csv (MI355X): Mult at 1024 bits — 8192 pairings 121 ms cooperative against 164 ms,
-  // 16384: 237 against 164; at 512 bits — 4096: 17.9 against 28.0 ms, 8192: 33.9 against 28.1.  makeL2 (the lane
-  // kernel walks P's line table there, a third of the products): 1024 bits — 2048: 34 against 54 ms, 4096: 63
-  // against 54; 512 bits — 1024: 5.9 against 10.1 ms, 2048: 9.8 against 10.1.
-  if (mode == 1) return c->nl >= 38 ? 3000 : c->nl >= 19 ? 1800 : 1024;
+  // profiles/r02_small_batch.csv (MI355X): Mult at 1024 bits — 8192 pairings 114 ms cooperative against 166 ms,
+  // 16384: 225 against 166; at 512 bits — 4096: 17.1 against 28.2 ms, 8192: 33.0 against 28.2.  makeL2 (both
+  // kernels walk P's line table): 1024 bits — 8192: 52.5 against 54.3 ms, 16384: 103 against 54; 512 bits —
+  // 4096: 8.7 against 10.6 ms, 8192: 16.7 against 10.6 (general cooperative program: 3000 / 1800).
+  if (mode == 1) return tw ? (c->nl >= 38 ? 8000 : c->nl >= 19 ? 4800 : 2048) : (c->nl >= 38 ? 3000 : c->nl >= 19 ? 1800 : 1024);
   return c->nl >= 38 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
@@ -762,8 +770,11 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   HIP_TRY(hipEventRecord(c->ev0, s));
   // BGN_COOP_FERMAT=1: the one-launch form with the Fermat inversion on the waves (A/B measurements)
   const char* cf = getenv("BGN_COOP_FERMAT");
+  // makeL2 on the waves walks the key's normalised line table (6 / 4 products per step in 2 / 3 rounds instead of
+  // a full pairing's 18 / 36 in 3 / 6); BGN_COOP_TABLE=0 keeps the general program
+  const uint32_t* ctab = (mode == 1 && coop_table_walk(c)) ? c->d_fixedpair : nullptr;
   if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
-                                  (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1)) {
+                                  (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1, ctab)) {
     c->last_kernel = coop_pairing_kernel_name(c->nl);
   } else {
     kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
@@ -1916,11 +1927,13 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
     const bool sk_tab = c->d_fixedpair_sk != nullptr;
     HIP_TRY(hipEventRecord(c->ev2, s));
-    // a small batch lifts with the wave-cooperative kernel: e(C, P) over all of n in a few milliseconds, against
-    // the latency of one whole table loop on a single lane (28 ms at a 1024-bit key); the power by q1 below
-    // gives the same e(C, P)^q1 either way
+    // a small batch lifts with the wave-cooperative kernel over the same line table (two or three rounds of products
+    // per step instead of a whole table loop on a single lane: 28 ms at a 1024-bit key); the power by q1 below
+    // gives the same e(C, P)^q1 whichever scalar the loop ran over
+    const bool ctab = coop_table_walk(c);                            // the table walk, over q2 when its table exists
     if (count <= coop_limit(c, 2) &&
-        coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pws, st, c->p_bits + 1)) {
+        coop_pairing_launch(c->nl, s, c->d_params, (ctab && sk_tab) ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1,
+                            0, 0, pws, st, c->p_bits + 1, ctab ? (sk_tab ? c->d_fixedpair_sk : c->d_fixedpair) : nullptr)) {
       c->aux_kernel = coop_pairing_kernel_name(c->nl);
     } else {
       kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,

@@ -8,31 +8,32 @@ size_t coop_ws_words(int nl, size_t sw) { return (size_t)COOP_PARK_WORDS * sw + 
 
 template <int NL>
 static void launch(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out, size_t count,
-                   int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits) {
+                   int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits, const uint32_t* tab) {
   const FpParams<NL>* P = (const FpParams<NL>*)params;
   const dim3 grid((unsigned)count), block(COOP_BLOCK);
   if (!ws) {
     hipLaunchKernelGGL((k_pairing_coop<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 0, nullptr, nullptr,
-                       nullptr, (size_t)0);
+                       nullptr, (size_t)0, tab);
     return;
   }
   uint32_t* park = ws;
   uint32_t* nsoa = ws + (size_t)COOP_PARK_WORDS * sw;
   uint32_t* isoa = nsoa + (size_t)NL * sw;
-  hipLaunchKernelGGL((k_pairing_coop<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 1, park, nsoa, isoa, sw);
+  hipLaunchKernelGGL((k_pairing_coop<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 1, park, nsoa, isoa, sw, tab);
   hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P, nsoa,
                      isoa, sw, count, p_bits);
-  hipLaunchKernelGGL((k_pairing_coop<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 2, park, nsoa, isoa, sw);
+  hipLaunchKernelGGL((k_pairing_coop<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 2, park, nsoa, isoa, sw, tab);
 }
 
 bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
-                         size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits) {
+                         size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits,
+                         const uint32_t* tab) {
   if (!count) return true;
   switch (nl) {
-    case 3: launch<3>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
-    case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
-    case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
-    case 38: launch<38>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
+    case 3: launch<3>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 38: launch<38>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
   }
   return false;
 }

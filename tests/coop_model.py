@@ -112,6 +112,10 @@ class ValueMachine:
                 self.run("DBL%d" % par)
                 i -= 1
             par ^= 1
+        return self._finish(par, l)
+
+    def _finish(self, par, l):
+        V = self.V
         self.run("NORM%d" % par)
         self.run("INV0")
         ip = 0
@@ -129,6 +133,67 @@ class ValueMachine:
                 lp ^= 1
         self.run("OUT%d" % lp)
         return V["out0"] % self.p, V["out1"] % self.p
+
+
+
+def line_table(px, py, n, p):
+    """(a_s / c_s, b_s / c_s) of every Miller step of f_{n,P}: the per-key table of fixedpair.hpp after
+    fixed_normalize_lane, as plain residues (Jacobian doubling / mixed addition along the NAF of n; the line at
+    phi(C) is (a*xC + b) + i*c*yC)."""
+    X, Y, Z = px, py, 1
+    out = []
+    d = naf(n)
+    for i in range(len(d) - 2, -1, -1):
+        ZZ = Z * Z % p
+        M = (3 * X * X + ZZ * ZZ) % p
+        YY = Y * Y % p
+        S = 4 * X * YY % p
+        Z3 = 2 * Y * Z % p
+        a, b, c = M * ZZ % p, (M * X - 2 * YY) % p, Z3 * ZZ % p
+        ci = pow(c, p - 2, p)
+        out.append((a * ci % p, b * ci % p))
+        X3 = (M * M - 2 * S) % p
+        Y3 = (M * (S - X3) - 8 * YY * YY) % p
+        X, Y, Z = X3, Y3, Z3
+        if d[i] and i != 0:
+            ys = py if d[i] > 0 else (-py) % p
+            ZZ = Z * Z % p
+            rr = (ys * ZZ * Z - Y) % p
+            H = (px * ZZ - X) % p
+            Z3 = Z * H % p
+            a, b, c = rr, (rr * px - Z3 * ys) % p, Z3
+            ci = pow(c, p - 2, p)
+            out.append((a * ci % p, b * ci % p))
+            HH = H * H % p
+            HHH = H * HH % p
+            XHH = X * HH % p
+            X3 = (rr * rr - HHH - 2 * XHH) % p
+            Y3 = (rr * (XHH - X3) - Y * HHH) % p
+            X, Y, Z = X3, Y3, Z3
+    return out
+
+
+def _pairing_table(self, xc, yc, table, n, l):
+    """e(P, C) over P's line table as the kernel's controller sequences it (TD / TDA segments, the coefficients of
+    a segment's steps in the slot set of its parity); plain residues in and out."""
+    V = self.V
+    V.update({"ax": self.mont(xc), "ay": self.mont(yc), "one": self.mont(1), "raw1": 1, "zero": 0})
+    V.update({"v0@0": V["one"], "v1@0": 0, "v2@0": V["one"]})
+    par, s = 0, 0
+    d = naf(n)
+    for i in range(len(d) - 2, -1, -1):
+        both = bool(d[i]) and i != 0
+        V["ta1@%d" % par], V["tb1@%d" % par] = self.mont(table[s][0]), self.mont(table[s][1])
+        if both:
+            V["ta2@%d" % par], V["tb2@%d" % par] = self.mont(table[s + 1][0]), self.mont(table[s + 1][1])
+        self.run(("TDA%d" if both else "TD%d") % par)
+        s += 2 if both else 1
+        par ^= 1
+    assert s == len(table)
+    return self._finish(par, l)
+
+
+ValueMachine.pairing_table = _pairing_table
 
 
 # ---------------------------------------------------------------------------------------------------------------

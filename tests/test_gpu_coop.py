@@ -138,3 +138,41 @@ def test_multpoly_small_products_on_both_kernels(name, npoly, d1, d2, monkeypatc
     monkeypatch.setenv("BGN_COOP_MAX", "0")
     lane = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
     assert got == lane == o.poly_mult(npoly, d1, d2, a, b)
+
+
+@pytest.mark.parametrize("name,count", [("toy64", 70), ("k256", 40), ("k512", 24), ("k1024", 12)])
+def test_table_walk_on_the_waves_matches_the_general_program_and_the_lane_kernel(name, count, monkeypatch):
+    """makeL2 and the level-1 decryption lift of a small batch walk the key's normalised line table on the
+    cooperative kernel (TD / TDA segments of tools/coop/gen_prog.py: 6 / 10 products per step in 2 / 3 rounds,
+    coefficients prefetched one segment ahead).  Same bytes as the general cooperative program
+    (BGN_COOP_TABLE=0), as the lane kernel's table loop and as the C oracle; identities in the batch; Decrypt's
+    plaintexts and statuses equal on all three paths."""
+    import oracle_c
+    fx = load_fixture(name)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng = pk.engine
+    o = oracle_c.Oracle.from_fixture(fx)
+    rng = random.Random(count)
+    n = int(fx["n"], 16)
+    T = fx["msg_space"]
+    ms = [rng.randrange(T) for _ in range(count)]
+    cts = eng.encrypt(ms, [rng.randrange(n) for _ in ms])
+    cts[2] = 0                                                       # an identity
+    wire = cts.tobytes()
+    res = {}
+    for label, lim, tab in (("table", "1000000", "1"), ("general", "1000000", "0"), ("lane", "0", "1")):
+        monkeypatch.setenv("BGN_COOP_MAX_L2", lim)
+        monkeypatch.setenv("BGN_COOP_MAX_DEC", lim)
+        monkeypatch.setenv("BGN_COOP_TABLE", tab)
+        l2 = eng.make_l2(wire).tobytes()
+        assert ("coop" in eng.last_kernel_name()) == (label != "lane")
+        m, st = eng.decrypt(1, wire)
+        assert ("coop" in eng.last_aux_kernel_name()) == (label != "lane")
+        res[label] = (l2, m.tolist(), st.tolist())
+    assert res["table"] == res["general"] == res["lane"]
+    E = eng.elem_bytes
+    s = min(count, 8)
+    assert res["table"][0][: s * E] == o.mult(wire[: s * E])          # makeL2 = Pair(c, P), bgn.go:316-321
+    want = [0 if i == 2 else m for i, m in enumerate(ms)]
+    assert res["table"][1] == want and not any(res["table"][2])

@@ -251,6 +251,9 @@ def build_program():
     acc = [P.fixed("acc@%d" % par, 4) for par in (0, 1)]                 # inversion: running product
     sq = [P.fixed("sq@%d" % par, 4) for par in (0, 1)]                   # ... and the squaring chain N^(2^i)
     rr = [(P.fixed("r0@%d" % par, 9), P.fixed("r1@%d" % par, 9)) for par in (0, 1)]   # h^l ladder
+    # line coefficients (a_s/c_s, b_s/c_s) of the table steps a segment consumes (fixedpair.hpp), canonical; the
+    # kernel loads the next segment's into the other set while the current one runs
+    tc = [{k: P.fixed("%s@%d" % (k, par), 1) for k in ("ta1", "tb1", "ta2", "tb2")} for par in (0, 1)]
 
     def name(f):
         (k,) = f.keys()
@@ -348,6 +351,35 @@ def build_program():
                 add(sign)(b, mid, so)
             P.segment("%s%d" % (nm, par), dbladd)
 
+    # ---- Miller loop over a normalised per-key line table (fixedpair.hpp miller_loop_fixed: makeL2, the level-1
+    # decryption lift).  The evaluation point phi(C) sits in (ax, ay); a step's line is (a'*xC + b') + i*yC, so a
+    # doubling step is f <- f^2 * l (six products, two rounds) and the addition that follows a non-zero digit one
+    # more Karatsuba product with the next table entry (ten products, three rounds together).
+    def tab_line(b, t, which):
+        return b.mul(t["ta%d" % which], ax) + t["tb%d" % which], ay       # (cre, cim); cre < 3
+    for par in (0, 1):
+        si, so, t = st[par], st[1 - par], tc[par]
+        def tdbl(b, si=si, so=so, t=t):
+            F0, F1 = f_of(si)
+            cre, cim = tab_line(b, t, 1)
+            g0 = b.mul(F0 + F1, F0 - F1)
+            g1h = b.mul(F0, F1)
+            finish_f(b, g0, 2 * g1h, cre, cim, so)
+        P.segment("TD%d" % par, tdbl)
+        def tdbladd(b, si=si, so=so, t=t, par=par):
+            F0, F1 = f_of(si)
+            cre, cim = tab_line(b, t, 1)
+            cre2, cim2 = tab_line(b, t, 2)
+            g0 = b.mul(F0 + F1, F0 - F1)
+            g1h = b.mul(F0, F1)
+            mid = {k: S("TDA%d.%s" % (par, k)) for k in ("v0", "v1", "v2")}
+            for k, f in mid.items():
+                b.bound[name(f)] = STATE_BOUNDS[k]
+            finish_f(b, g0, 2 * g1h, cre, cim, mid)
+            M0, M1 = f_of(mid)
+            finish_f(b, M0, M1, cre2, cim2, so)
+        P.segment("TDA%d" % par, tdbladd)
+
     # ---- final exponentiation: f^(p-1) = conj(f)^2 / N(f), then ^l (pairing.hpp final_exp_with_inverse) ----
     for par in (0, 1):
         def norm(b, s=st[par], par=par):
@@ -420,7 +452,8 @@ def emit(P, path):
     lines.append("#define COOP_NSLOTS %d" % P.nslots)
     lines.append("#define COOP_MAX_TERMS %d" % MAX_TERMS)
     for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "ZZ@0", "W@0", "v0@0", "v1@0", "v2@0",
-                  "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1"):
+                  "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1",
+                  "ta1@0", "tb1@0", "ta2@0", "tb2@0", "ta1@1", "tb1@1", "ta2@1", "tb2@1", "v0@1", "v1@1", "v2@1"):
         lines.append("#define COOP_SLOT_%s %d" % (gname.replace("@", "_").upper(), P.phys[gname]))
     lines.append("enum CoopSeg {")
     for i, (name, _) in enumerate(P.segments):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Small-batch sweep: Mult / makeL2 wall time by batch size on the wave-cooperative kernel (coop/coop.hpp) and on
-the one-pairing-per-lane kernel, device-resident operands, best of three.  Writes the CSV the engine's crossovers
+"""Small-batch sweep: Mult / makeL2 / level-1 Decrypt wall time by batch size on the wave-cooperative kernel
+(coop/coop.hpp; makeL2 and Decrypt's lift walk the key's line table there) and on the one-pairing-per-lane kernel,
+device-resident operands, best of three.  Writes the CSV the engine's crossovers
 (coop_limit, engine.cpp) are chosen from:  python tools/small_batch_sweep.py > profiles/r02_small_batch.csv"""
 import os
 import sys
@@ -32,9 +33,13 @@ def main():
         b = syn.permuted_copy(cts, EB, seed=4)
         out = torch.empty(nmax * EB, dtype=torch.uint8, device=dev)
         ref = {}
-        for op in ("mult", "make_l2"):
+        pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+        msg = torch.empty(nmax, dtype=torch.int64, device=dev)
+        sta = torch.empty(nmax, dtype=torch.uint8, device=dev)
+        for op in ("mult", "make_l2", "decrypt_l1"):
             for kernel in ("coop", "lane"):
-                os.environ["BGN_COOP_MAX"] = os.environ["BGN_COOP_MAX_L2"] = "100000000" if kernel == "coop" else "0"
+                os.environ["BGN_COOP_MAX"] = os.environ["BGN_COOP_MAX_L2"] = os.environ["BGN_COOP_MAX_DEC"] = \
+                    "100000000" if kernel == "coop" else "0"
                 for n in counts:
                     if kernel == "coop" and n > 16384:
                         continue
@@ -44,14 +49,18 @@ def main():
                         t0 = time.perf_counter()
                         if op == "mult":
                             eng.mult_dev(cts[: n * EB], b[: n * EB], out, n)
-                        else:
+                        elif op == "make_l2":
                             eng.make_l2_dev(cts[: n * EB], out, n)
+                        else:
+                            eng.decrypt_dev(1, cts[: n * EB], msg, sta, n)
                         torch.cuda.synchronize()
                         dt = time.perf_counter() - t0
                         best = dt if best is None or dt < best else best
-                    digest = hash(out[: n * EB].cpu().numpy().tobytes())
+                    digest = hash(out[: n * EB].cpu().numpy().tobytes()) if op != "decrypt_l1" else \
+                        hash(msg[:n].cpu().numpy().tobytes() + sta[:n].cpu().numpy().tobytes())
                     assert ref.setdefault((op, n), digest) == digest, "kernels disagree"
-                    print("%s,%s,%d,%s,%.4f,%.1f,%s" % (key, op, n, kernel, best * 1e3, n / best, eng.last_kernel_name()),
+                    print("%s,%s,%d,%s,%.4f,%.1f,%s" % (key, op, n, kernel, best * 1e3, n / best,
+                                                       eng.last_aux_kernel_name() if op == "decrypt_l1" else eng.last_kernel_name()),
                           flush=True)
 
 

@@ -255,6 +255,11 @@ struct KernelTable {
   // count F_p of workspace with limb stride sp; the grid covers ceil(count / run) lanes
   void (*g1_add_wire)(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a, const uint8_t* b,
                       uint8_t* out, int L, size_t count, int run, int negate_b, uint32_t* prefix, size_t sp);
+  // the same in two launches split at the inversion (k_g1_add_front / k_g1_add_back): A, B SoA workspaces for the
+  // decoded coordinates, inv: NL * lanes words with lanes = ceil(ceil(count / run) / 256) * 256
+  void (*g1_add_split)(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a, const uint8_t* b,
+                       uint8_t* out, int L, size_t count, int run, int negate_b, SoA2 A, SoA2 B, uint32_t* prefix, size_t sp,
+                       uint32_t* inv);
 };
 
 const KernelTable* kernel_table_nl3();

@@ -208,7 +208,8 @@ def test_bsgs_false_hits_are_rejected_by_the_full_width_check(bits, monkeypatch)
 # ---------------------------------------------------------------- fused wire-to-wire Add
 @pytest.mark.parametrize("name,count", [("toy64", 1), ("toy64", 70000), ("k256", 300), ("k512", 257), ("k1024", 256)])
 def test_fused_add_matches_three_launch_path_and_c_oracle(name, count, monkeypatch):
-    """k_g1_add_wire (decode, affine addition with the shared inversion, encode in one kernel) against the
+    """k_g1_add_wire (decode, affine addition with the shared inversion, encode in one kernel) and the opt-in
+    two-launch form (k_g1_add_front / k_g1_add_back, split at the inversion) against the
     decode / k_g1_add / encode launches and the C oracle: ragged counts, runs longer than one (count > 65536),
     identities on either side, a + a (doubling) and a - a (identity out)."""
     import oracle_c
@@ -232,7 +233,11 @@ def test_fused_add_matches_three_launch_path_and_c_oracle(name, count, monkeypat
         monkeypatch.setenv("BGN_ADD_FUSED", "0")
         plain = fn(1, a, b).tobytes()
         assert eng.last_kernel_name() == "k_g1_add"
-        assert fused == plain
+        monkeypatch.setenv("BGN_ADD_SPLIT", "1")
+        split = fn(1, a, b).tobytes()                                  # front + back kernels, split at the inversion
+        assert eng.last_kernel_name() == "k_g1_add_front+back"
+        monkeypatch.delenv("BGN_ADD_SPLIT")
+        assert fused == plain == split
         sample = min(count, 400)
         E = eng.elem_bytes
         assert fused[: sample * E] == o.add(1, a[: sample * E], b[: sample * E], subtract=sub)

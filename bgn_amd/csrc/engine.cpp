@@ -285,11 +285,18 @@ extern "C" {
 const char* bgn_last_error(void) { return g_err.c_str(); }
 // multi.cpp reports a shard's failure (raised on that shard's thread) to the calling thread through this
 void bgn_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
+// build-time options that put kept negative results back in (kernels_impl.hpp) show in the version string
 #ifdef BGN_WITH_VM
-const char* bgn_version(void) { return "bgn_amd 0.2 (gfx950) +vm"; }
+#define BGN_VERSION_VM " +vm"
 #else
-const char* bgn_version(void) { return "bgn_amd 0.2 (gfx950)"; }
+#define BGN_VERSION_VM ""
 #endif
+#ifdef BGN_WITH_ADD_VARIANTS
+#define BGN_VERSION_ADDVAR " +addvar"
+#else
+#define BGN_VERSION_ADDVAR ""
+#endif
+const char* bgn_version(void) { return "bgn_amd 0.2 (gfx950)" BGN_VERSION_VM BGN_VERSION_ADDVAR; }
 
 size_t bgn_fp_bytes(const bgn_ctx* ctx) { return ctx ? (size_t)ctx->L : 0; }
 
@@ -1349,7 +1356,7 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   // lane sharing one inversion they have to do so twice (prefix pass, peel pass).  Kept as an opt-in variant.
   bool fused = false;
   if (const char* ev = getenv("BGN_ADD_FUSED"))
-    fused = ev[0] == '1' && level == 1 && !r_be;
+    fused = ev[0] == '1' && level == 1 && !r_be && c->kt->g1_add_wire;   // built with -DBGN_WITH_ADD_VARIANTS only
   if (fused) {
     Ws w0(c, nullptr);
     w0.fp(st);
@@ -1369,10 +1376,10 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   // products, inversion; back: peel, add, encode), every operand decoded once.  Measured 2.5 ms per 2^20 additions
   // against 2.0 ms for decode / decode / k_g1_add / encode: with one workgroup per CU the staging copies of a
   // round sit behind its barriers with nothing to overlap them, while the stand-alone decode kernels overlap
-  // each other's.  Opt-in like BGN_ADD_FUSED.
+  // each other's.  Opt-in like BGN_ADD_FUSED, and like it compiled only with -DBGN_WITH_ADD_VARIANTS.
   {
     const char* ev = getenv("BGN_ADD_SPLIT");
-    if (level == 1 && !r_be && ev && ev[0] == '1') {
+    if (level == 1 && !r_be && ev && ev[0] == '1' && c->kt->g1_add_split) {
       const int run = run_for(count);
       const size_t lanes = round_up((count + (size_t)run - 1) / (size_t)run, 256);
       uint32_t* inv = nullptr;

@@ -825,6 +825,7 @@ k_field_ops(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire
   g_store<NL>(sqr.c1, sqr.stride, e, o);
 }
 
+#ifdef BGN_WITH_ADD_VARIANTS   // two kept negative results (measured slower than decode / k_g1_add / encode): opt-in at build time
 // ---- EAdd / ESub on level 1, wire bytes to wire bytes in ONE kernel (bgn.go:482, :419) ------------------------
 // The workgroup stages its 256 consecutive elements of a round between HBM and LDS with coalesced dword accesses
 // (codec.hpp), the lanes pick their operands out of LDS, add on plain residues (ops.hpp g1_add_run, PLAIN) and put
@@ -1057,6 +1058,8 @@ k_g1_add_back(const FpParams<NL>* __restrict__ P, SoA2 A, SoA2 B, const u32* __r
   }
 }
 
+#endif  // BGN_WITH_ADD_VARIANTS
+
 static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
                              SoA2 prod_inv, SoA2 sqr) {
   if (!count) return;
@@ -1064,6 +1067,7 @@ static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* w
                      count, p_bits, prod_inv, sqr);
 }
 
+#ifdef BGN_WITH_ADD_VARIANTS
 static void launch_g1_add_wire(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a,
                                const uint8_t* b, uint8_t* out, int L, size_t count, int run, int negate_b,
                                uint32_t* prefix, size_t sp) {
@@ -1085,7 +1089,7 @@ static void launch_g1_add_split(hipStream_t s, const void* params, const Pairing
   hipLaunchKernelGGL(k_g1_add_back<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, A, B,
                      prefix, sp, inv, out, L, count, run);
 }
-
+#endif
 
 const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {
@@ -1122,8 +1126,13 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_poly_combine,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
       launch_field_ops,
+#ifdef BGN_WITH_ADD_VARIANTS
       launch_g1_add_wire,
       launch_g1_add_split,
+#else
+      nullptr,
+      nullptr,
+#endif
   };
   return &t;
 }

@@ -216,6 +216,9 @@ def test_fused_add_matches_three_launch_path_and_c_oracle(name, count, monkeypat
     fx = load_fixture(name)
     pk, _ = engine_key(fx)
     eng = pk.engine
+    if b"+addvar" not in eng._lib.bgn_version():
+        pytest.skip("the fused / split Add kernels are kept negative results, out of the default build "
+                    "(make CXXFLAGS+=-DBGN_WITH_ADD_VARIANTS puts them back)")
     o = oracle_c.Oracle.from_fixture(fx)
     rng = random.Random(count)
     n = int(fx["n"], 16)

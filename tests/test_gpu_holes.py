@@ -340,3 +340,52 @@ def test_host_pipeline_under_concurrent_callers(monkeypatch):
     assert not errs, errs
     assert not any(t.is_alive() for t in ts), "a caller is stuck"
     assert got["add"] == want_add and got["sub"] == want_sub and got["mul"] == want_mul
+
+
+# ---------------------------------------------------------------- device pointers at any byte offset
+@pytest.mark.parametrize("name", ["k512", "k1024"])
+def test_dev_calls_take_operands_at_any_byte_offset(name):
+    """A caller may pass sub-ranges of its device buffers: operands and results that start 1, 2, 3, 4, 8 or 12
+    bytes into an allocation (not dword-, not 16-byte-aligned).  The staging copies fall back from 16-byte rows to
+    dwords and to byte-masked edge dwords, the codec from dwords to bytes; results equal the aligned call's, the
+    bytes around the result array stay untouched.  L is even at the 512-bit key and odd at the 1024-bit one."""
+    import torch
+    fx = load_fixture(name)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    dev = torch.device("cuda", 0)
+    rng = random.Random(3)
+    n = int(fx["n"], 16)
+    cnt = 300                                                        # more than one staged slice of 256 elements
+    T = fx["msg_space"]
+    ms = [rng.randrange(min(T, 1 << 20)) for _ in range(cnt)]
+    cts = torch.from_numpy(eng.encrypt(ms, [rng.randrange(n) for _ in range(cnt)]).reshape(-1).copy()).to(dev)
+    perm = torch.randperm(cnt, generator=torch.Generator().manual_seed(1)).to(dev)
+    other = cts.view(cnt, EB)[perm].reshape(-1).contiguous()
+    want_add = torch.empty(cnt * EB, dtype=torch.uint8, device=dev)
+    eng.add_dev(1, cts, other, want_add, cnt)
+    want_mul = torch.empty(16 * EB, dtype=torch.uint8, device=dev)
+    eng.mult_dev(cts[: 16 * EB], other[: 16 * EB], want_mul, 16)
+    for off in (1, 2, 3, 4, 8, 12):
+        pad = 32
+        bufa = torch.zeros(cnt * EB + 2 * pad, dtype=torch.uint8, device=dev)
+        bufb = torch.zeros(cnt * EB + 2 * pad, dtype=torch.uint8, device=dev)
+        bufo = torch.full((cnt * EB + 2 * pad,), 0xA5, dtype=torch.uint8, device=dev)
+        a = bufa[off: off + cnt * EB]
+        b = bufb[pad - off: pad - off + cnt * EB]
+        o = bufo[off: off + cnt * EB]
+        a.copy_(cts)
+        b.copy_(other)
+        eng.add_dev(1, a, b, o, cnt)
+        assert bool((o == want_add).all().item()), (name, off, "add")
+        assert bool((bufo[:off] == 0xA5).all().item()) and bool((bufo[off + cnt * EB:] == 0xA5).all().item()), (name, off)
+        bufo.fill_(0xA5)
+        eng.mult_dev(a[: 16 * EB], b[: 16 * EB], o[: 16 * EB], 16)
+        assert bool((o[: 16 * EB] == want_mul).all().item()), (name, off, "mult")
+        assert bool((bufo[:off] == 0xA5).all().item()) and bool((bufo[off + 16 * EB:] == 0xA5).all().item()), (name, off)
+        m = torch.empty(cnt, dtype=torch.int64, device=dev)
+        st = torch.empty(cnt, dtype=torch.uint8, device=dev)
+        eng.decrypt_dev(1, a, m, st, cnt)
+        assert m.cpu().tolist() == ms and not bool(st.any().item()), (name, off, "decrypt")

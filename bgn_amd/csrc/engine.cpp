@@ -22,6 +22,7 @@
 #include "kernels.hpp"
 #include "consts.hpp"
 #include "coop/coop_api.hpp"
+#include "quad/quad_api.hpp"
 
 using namespace bgn;
 
@@ -718,6 +719,20 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   return c->nl >= 38 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
+// Between the cooperative kernel's saturation and one pairing per lane filling the chip sits the lane-group kernel
+// (quad/quad.hpp: sixteen lanes per pairing, 4096 pairings put one wave on every SIMD): Mult and MultPoly's
+// coefficient pairs above coop_limit and up to this many pairs.  BGN_QUAD_MAX overrides (0 disables the kernel),
+// BGN_QUAD_MIN moves the lower end (default: the cooperative crossover of the key size).
+static size_t quad_limit(const bgn_ctx* c) {
+  if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
+  return c->nl >= 38 ? 40000 : c->nl >= 19 ? 24000 : c->nl >= 10 ? 16384 : 0;
+}
+static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
+  size_t lo = coop_max;
+  if (const char* ev = getenv("BGN_QUAD_MIN")) lo = (size_t)strtoull(ev, nullptr, 10);
+  return count > lo && count <= quad_limit(c) && quad_ws_words(c->nl, 64) != 0;
+}
+
 // Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with
 // the width-5 loop) stays at 31 GB however long the arrays are.
 static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
@@ -752,9 +767,10 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
-  const bool coop = mode <= 1 && count <= coop_limit(c, mode);
+  const bool quad = mode == 0 && use_quad(c, count, coop_limit(c, 0));
+  const bool coop = !quad && mode <= 1 && count <= coop_limit(c, mode);
   const size_t lane_ws = (size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4;
-  const size_t ws_bytes = coop ? coop_ws_words(c->nl, so) * 4 : lane_ws;
+  const size_t ws_bytes = quad ? quad_ws_words(c->nl, so) * 4 : coop ? coop_ws_words(c->nl, so) * 4 : lane_ws;
   probe.take(ws_bytes);
   if (r_be) {
     probe.soa(c->nl, so, false);
@@ -780,8 +796,10 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   // makeL2 on the waves walks the key's normalised line table (6 / 4 products per step in 2 / 3 rounds instead of
   // a full pairing's 18 / 36 in 3 / 6); BGN_COOP_TABLE=0 keeps the general program
   const uint32_t* ctab = (mode == 1 && coop_table_walk(c)) ? c->d_fixedpair : nullptr;
-  if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
-                                  (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1, ctab)) {
+  if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0, ws, so, c->p_bits + 1)) {
+    c->last_kernel = quad_pairing_kernel_name(c->nl);
+  } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
+                                         (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1, ctab)) {
     c->last_kernel = coop_pairing_kernel_name(c->nl);
   } else {
     kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
@@ -2076,8 +2094,9 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   // a product small enough for the wave-cooperative kernel (a few thousand coefficient pairs: the reference's own
   // MultPoly calls are ONE product of ~10 x 10 coefficients) pairs directly, one pair per workgroup: tables and the
   // one-pairing-per-lane kernels cost the latency of several whole pairings on single lanes
-  const bool coop = npoly * d1 * d2 <= coop_limit(c, 0);
-  const size_t chunk = (!coop && d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
+  const bool quad = use_quad(c, npoly * d1 * d2, coop_limit(c, 0));
+  const bool coop = !quad && npoly * d1 * d2 <= coop_limit(c, 0);
+  const size_t chunk = (!coop && !quad && d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
   SoA2 E;
@@ -2086,7 +2105,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
     const size_t lane_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;
-    pws = (uint32_t*)w.cv.take(coop ? coop_ws_words(c->nl, sp) * 4 : lane_b);
+    pws = (uint32_t*)w.cv.take(quad ? quad_ws_words(c->nl, sp) * 4 : coop ? coop_ws_words(c->nl, sp) * 4 : lane_b);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
@@ -2119,6 +2138,8 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);
       kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(pairs), pws, sp,
                   tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
+    } else if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sp,
+                                           c->p_bits + 1)) {
     } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sp,
                                            c->p_bits + 1)) {
     } else {

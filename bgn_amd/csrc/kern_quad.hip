@@ -1,0 +1,55 @@
+// kern_quad.hip — instantiations of the lane-group pairing kernel (quad/quad.hpp).
+#include "quad/quad.hpp"
+#include "quad/quad_api.hpp"
+#include "coop/coop.hpp"
+
+namespace bgn {
+
+template <int NL>
+static size_t ws_words(size_t sw) { return (size_t)QuadDims<NL>::PARK_WORDS * sw + (size_t)2 * NL * sw; }
+
+size_t quad_ws_words(int nl, size_t sw) {
+  switch (nl) {
+    case 10: return ws_words<10>(sw);
+    case 19: return ws_words<19>(sw);
+    case 38: return ws_words<38>(sw);
+  }
+  return 0;
+}
+
+template <int NL>
+static void launch(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out, size_t count,
+                   int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits) {
+  const FpParams<NL>* P = (const FpParams<NL>*)params;
+  const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
+  uint32_t* park = ws;
+  uint32_t* nsoa = ws + (size_t)QuadDims<NL>::PARK_WORDS * sw;
+  uint32_t* isoa = nsoa + (size_t)NL * sw;
+  hipLaunchKernelGGL((k_pairing_quad<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 1, park, nsoa, isoa, sw);
+  hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P, nsoa,
+                     isoa, sw, count, p_bits);
+  hipLaunchKernelGGL((k_pairing_quad<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 2, park, nsoa, isoa, sw);
+}
+
+bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
+                         size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits) {
+  if (!count) return true;
+  if (!ws) return false;
+  switch (nl) {
+    case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
+    case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
+    case 38: launch<38>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
+  }
+  return false;
+}
+
+const char* quad_pairing_kernel_name(int nl) {
+  switch (nl) {
+    case 10: return "k_pairing_quad<10>";
+    case 19: return "k_pairing_quad<19>";
+    case 38: return "k_pairing_quad<38>";
+  }
+  return "";
+}
+
+}  // namespace bgn

@@ -1,0 +1,494 @@
+// quad.hpp — lane-group Type-A1 pairing for mid-size batches (a few thousand to a few ten thousand pairings).
+//
+// Replaces `res.Pair(ct1.C, ct2.C)` (bgn.go:300) — and with it the goroutine-per-coefficient-pair fan-out of
+// MultPoly (poly.go:139-153), a few hundred to a few thousand pairings per request — for batches too large for
+// the wave-cooperative kernel (coop/coop.hpp: one pairing per workgroup, saturated from ~2000 pairings on) and too
+// small to fill the chip with one pairing per lane (pairing.hpp: the latency of one lane's pairing, 166 ms at a
+// 1024-bit key, for anything below 65536).  Here ONE pairing belongs to 16 lanes of a wave:
+//   * four quads of lanes run the four micro-ops of a round of the step programs (tools/coop/gen_prog.py, the
+//     formulas of pairing.hpp scheduled for four workers: a Miller doubling step = 18 products in 5 rounds, a
+//     doubling with the addition after it 36 in 10).  The quads of a pairing sit in one wave, so a round needs no
+//     barrier: its reads precede its writes in the wave's own instruction order;
+//   * inside a quad a field element is split over the four lanes, M = ceil(NL / 4) limbs of 28 bits each (lane s
+//     holds limbs s*M .. s*M + M - 1).  A Montgomery product is NL rows of {broadcast one limb of a inside the quad
+//     (DPP quad_perm), M multiply-adds into the lane's accumulators, the quotient digit from lane 0 (broadcast), M
+//     multiply-adds of p, retire the lowest accumulator: its low 28 bits move to the lane below (DPP), the rest
+//     into the next accumulator} — 2 M + 9 instructions per row and lane, 1.1 k per product at a 1024-bit key
+//     against 3.2 k for a lane that multiplies alone;
+//   * limbs are signed and lazily normalised as in the cooperative kernel: a carry pass is exact inside a lane and
+//     hands the lane's carry-out to the two lowest limbs of the lane above; lane 3 keeps the whole top limb
+//     (position NL - 1), so no position beyond the NL rows of a product ever holds anything;
+//   * values live in LDS, slot v of a pairing in the lanes of quad v & 3, row block v >> 2: 64 value slots per
+//     pairing with one 256-thread workgroup (16 pairings) per CU.
+// Outputs are canonical, hence the same bytes as the other two pairing kernels.  tests/quad_model.py holds a
+// lane-level model of this arithmetic; tests/test_gpu_quad.py compares the kernel with the golden vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "../fp28.hpp"
+#include "../fpinv.hpp"
+#include "../imad.hpp"
+#include "../kernels.hpp"
+
+namespace bgn {
+
+#include "quad_prog.inc"
+
+constexpr int QUAD_BLOCK = 256;                       // four waves, one per SIMD
+constexpr int QUAD_LANES = 4 * QUAD_W;                // lanes per pairing
+constexpr int QUAD_PER_BLOCK = QUAD_BLOCK / QUAD_LANES;
+
+template <int NL>
+struct QuadDims {
+  static constexpr int M = (NL + 3) / 4;              // limbs per lane
+  static constexpr int MR = (M + 1) / 2;              // u64 rows per value and lane
+  static constexpr int JTOP = NL - 1 - 3 * M;         // index of the top limb (position NL - 1) in lane 3
+  static constexpr int ROW_BYTES = QUAD_BLOCK * 8;
+  static constexpr int SLOT_BYTES = MR * ROW_BYTES;   // one row block: a value for each quad of every pairing
+  static constexpr int SLOT_ROWS = (QUAD_NSLOTS + 3) / 4;
+  static constexpr int PARK_WORDS = 3 * 4 * M;        // per pairing: F0^2, F1^2, F0*F1 as they lie in the lanes
+  static_assert(M >= 2 && JTOP >= 0 && JTOP < M, "limb split");
+};
+
+// quad_perm moves (all four lanes of a quad are always active)
+template <int K>
+__device__ __forceinline__ int quad_bcast(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, K * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int quad_from_above(int x) {      // lane s reads lane (s + 1) & 3
+  return __builtin_amdgcn_update_dpp(0, x, 0x39, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int quad_from_below(int x) {      // lane s reads lane (s - 1) & 3
+  return __builtin_amdgcn_update_dpp(0, x, 0x93, 0xF, 0xF, true);
+}
+
+template <int NL>
+struct QuadLane {
+  u32 p[QuadDims<NL>::M];   // this lane's limbs of the modulus
+  u32 pinv;                 // -p^-1 mod 2^28
+  u32 keep_top;             // carry pass at index JTOP: bits kept (28; everything in lane 3)
+  u32 carry_top;            // ... and whether a carry goes on (not in lane 3)
+  u32 base;                 // LDS byte offset of this lane's column of row block 0, quad 0
+  int sub;                  // lane within the quad
+  int quad;                 // quad within the pairing
+};
+
+template <int NL>
+__device__ __forceinline__ u32 quad_addr(u32 v, const QuadLane<NL>& c) {
+  return c.base + (v >> 2) * (u32)QuadDims<NL>::SLOT_BYTES + (v & 3u) * 32u;
+}
+
+template <int NL>
+__device__ __forceinline__ void quad_load(int (&x)[QuadDims<NL>::M], const char* V, u32 addr) {
+  constexpr int M = QuadDims<NL>::M;
+#pragma unroll
+  for (int k = 0; k < QuadDims<NL>::MR; ++k) {
+    const u64 w = *reinterpret_cast<const u64*>(V + addr + k * QuadDims<NL>::ROW_BYTES);
+    x[2 * k] = (int)(u32)w;
+    if (2 * k + 1 < M) x[2 * k + 1] = (int)(u32)(w >> 32);
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void quad_store(char* V, u32 addr, const int (&x)[QuadDims<NL>::M]) {
+  constexpr int M = QuadDims<NL>::M;
+#pragma unroll
+  for (int k = 0; k < QuadDims<NL>::MR; ++k) {
+    const u64 w = (u64)(u32)x[2 * k] | (2 * k + 1 < M ? (u64)(u32)x[2 * k + 1] << 32 : 0ull);
+    *reinterpret_cast<u64*>(V + addr + k * QuadDims<NL>::ROW_BYTES) = w;
+  }
+}
+
+// One carry pass: exact inside the lane; the lane's carry-out goes to limb 0 of the lane above, whose own excess
+// moves on to its limb 1 and stays there.  Lane 3 keeps the top limb whole and passes nothing on.
+template <int NL>
+__device__ __forceinline__ void quad_normalize(int (&x)[QuadDims<NL>::M], const long long (&acc)[QuadDims<NL>::M],
+                                               const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M, JT = QuadDims<NL>::JTOP;
+  long long cy = 0;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const long long t = acc[j] + cy;
+    if (j == JT) {
+      x[j] = (int)((u32)t & c.keep_top);
+      const long long s = t >> LIMB_BITS;
+      cy = (long long)(((u64)((u32)(s >> 32) & c.carry_top) << 32) | (u64)((u32)s & c.carry_top));
+    } else {
+      x[j] = (int)((u32)t & LIMB_MASK);
+      cy = t >> LIMB_BITS;
+    }
+  }
+  const u32 cl = (u32)quad_from_below((int)(u32)cy);
+  const u32 ch = (u32)quad_from_below((int)(u32)(cy >> 32));
+  const long long t0 = (long long)x[0] + (long long)(((u64)ch << 32) | cl);
+  if (JT == 0) {
+    x[0] = (int)((u32)t0 & c.keep_top);
+    x[1] += (int)((u32)(t0 >> LIMB_BITS) & c.carry_top);
+  } else {
+    x[0] = (int)((u32)t0 & LIMB_MASK);
+    x[1] += (int)(t0 >> LIMB_BITS);
+  }
+}
+
+// Exact carry resolution of lazily normalised limbs: four passes, each exact inside the lanes, carries one lane up.
+template <int NL>
+__device__ __forceinline__ void quad_tight(int (&x)[QuadDims<NL>::M], const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M, JT = QuadDims<NL>::JTOP;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    int cy = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int t = x[j] + cy;
+      if (j == JT) {
+        x[j] = (int)((u32)t & c.keep_top);
+        cy = (int)((u32)(t >> LIMB_BITS) & c.carry_top);
+      } else {
+        x[j] = (int)((u32)t & LIMB_MASK);
+        cy = t >> LIMB_BITS;
+      }
+    }
+    x[0] += quad_from_below(cy);
+  }
+}
+
+// Tight limbs of the representative in [0, p) of a lazily normalised value in [0, 2p).
+template <int NL>
+__device__ __forceinline__ void quad_canonical(int (&x)[QuadDims<NL>::M], const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M, JT = QuadDims<NL>::JTOP;
+  quad_tight<NL>(x, c);
+  int d[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) d[j] = x[j] - (int)c.p[j];
+  quad_tight<NL>(d, c);
+  const int top = quad_bcast<3>(d[JT]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) x[j] = top < 0 ? x[j] : d[j];
+}
+
+// acc += sum of c_k * V[i_k] + K*p: n terms (the largest count among the quads of the round, wave-uniform; a quad
+// with fewer has coefficient 0 on slot 0), slot indices and signed coefficients one byte each.
+template <int NL>
+__device__ __forceinline__ void quad_combo(long long (&acc)[QuadDims<NL>::M], const char* V, int n, u32 idx, u32 cf, int K,
+                                           const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M;
+#pragma unroll
+  for (int t = 0; t < QUAD_MAX_TERMS; ++t) {
+    if (n > t) {
+      int v[M];
+      quad_load<NL>(v, V, quad_addr<NL>((idx >> (8 * t)) & 0xFFu, c));
+      const int k = (int)(signed char)((cf >> (8 * t)) & 0xFFu);
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc[j] = imad(k, v[j], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < M; ++j) acc[j] = imad(K, (int)c.p[j], acc[j]);
+}
+
+// One row of the Montgomery product (see the file header).
+template <int NL, int I>
+__device__ __forceinline__ void quad_row(long long (&acc)[QuadDims<NL>::M], const int (&a)[QuadDims<NL>::M],
+                                         const int (&b)[QuadDims<NL>::M], const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M;
+  const int ai = quad_bcast<I / M>(a[I % M]);
+#pragma unroll
+  for (int j = 0; j < M; ++j) acc[j] = imad(ai, b[j], acc[j]);
+  const u32 q = (u32)quad_bcast<0>((int)(((u32)acc[0] * c.pinv) & LIMB_MASK));
+#pragma unroll
+  for (int j = 0; j < M; ++j) acc[j] = (long long)((u64)acc[j] + (u64)q * (u64)c.p[j]);
+  const long long cy = acc[0] >> LIMB_BITS;
+  const u32 up = (u32)quad_from_above((int)((u32)acc[0] & LIMB_MASK));
+#pragma unroll
+  for (int j = 0; j < M - 1; ++j) acc[j] = acc[j + 1];
+  acc[M - 1] = (long long)(u64)up;
+  acc[0] += cy;
+}
+
+template <int NL, int... I>
+__device__ __forceinline__ void quad_rows(long long (&acc)[QuadDims<NL>::M], const int (&a)[QuadDims<NL>::M],
+                                          const int (&b)[QuadDims<NL>::M], const QuadLane<NL>& c,
+                                          std::integer_sequence<int, I...>) {
+  (quad_row<NL, I>(acc, a, b, c), ...);
+}
+
+// A micro-op: eight dwords, one copy per quad (quad_prog.inc documents the packing).
+struct QuadWords {
+  u32 w[8];
+};
+typedef unsigned int quad_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ QuadWords quad_fetch(int row, int quad) {
+  const quad_u32x4* q = reinterpret_cast<const quad_u32x4*>(kQuadProg[row * QUAD_W + quad]);
+  const quad_u32x4 lo = q[0], hi = q[1];
+  QuadWords u;
+  u.w[0] = lo[0]; u.w[1] = lo[1]; u.w[2] = lo[2]; u.w[3] = lo[3];
+  u.w[4] = hi[0]; u.w[5] = hi[1]; u.w[6] = hi[2]; u.w[7] = hi[3];
+  return u;
+}
+
+// One operand of a round's products: one stored value taken as it is when that holds for every quad of the round,
+// else the quads' linear combinations, normalised.
+template <int NL>
+__device__ __forceinline__ void quad_operand(int (&x)[QuadDims<NL>::M], const char* V, bool plain, int n, u32 idx, u32 cf,
+                                             int K, const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M;
+  if (plain) {
+    quad_load<NL>(x, V, quad_addr<NL>(idx & 0xFFu, c));
+    return;
+  }
+  long long acc[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) acc[j] = 0;
+  quad_combo<NL>(acc, V, n, idx, cf, K, c);
+  quad_normalize<NL>(x, acc, c);
+}
+
+// One round: every quad executes its micro-op  dst = A*B/R + E  (a linear micro-op or an idle quad multiplies
+// zero by zero).  `hdr` is the round's header word (wave-uniform).
+template <int NL>
+__device__ __forceinline__ void quad_round(char* V, const QuadWords& u, u32 hdr, const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M;
+  long long acc[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) acc[j] = 0;
+  if (hdr & 0x4000u) {
+    int a[M], b[M];
+    quad_operand<NL>(a, V, (hdr & 0x1000u) != 0, (int)(hdr & 0xFu), u.w[2], u.w[3], (int)((u.w[1] >> 8) & 0xFFu), c);
+    quad_operand<NL>(b, V, (hdr & 0x2000u) != 0, (int)((hdr >> 4) & 0xFu), u.w[4], u.w[5], (int)((u.w[1] >> 16) & 0xFFu), c);
+    quad_rows<NL>(acc, a, b, c, std::make_integer_sequence<int, NL>{});
+  }
+  const int ne = (int)((hdr >> 8) & 0xFu);
+  if (ne) quad_combo<NL>(acc, V, ne, u.w[6], u.w[7], (int)(u.w[1] >> 24), c);
+  int x[M];
+  quad_normalize<NL>(x, acc, c);
+  if (u.w[0] & 0xFu) quad_store<NL>(V, quad_addr<NL>((u.w[0] >> 16) & 0xFFu, c), x);
+}
+
+// One segment: its rounds in order; the next round's micro-ops are requested before the current round computes.
+template <int NL>
+__device__ __forceinline__ void quad_run(char* V, int seg, const QuadLane<NL>& c) {
+  const int first = (int)kQuadSegFirst[seg], n = (int)kQuadSegRounds[seg];
+  QuadWords cur = quad_fetch(first, c.quad);
+#pragma unroll 1
+  for (int r = 0; r < n; ++r) {
+    const QuadWords nxt = quad_fetch(first + (r + 1 < n ? r + 1 : r), c.quad);
+    const u32 hdr = kQuadRound[first + r];
+    quad_round<NL>(V, cur, hdr, c);
+    cur = nxt;
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void quad_lane_init(QuadLane<NL>& c, const FpParams<NL>* __restrict__ P) {
+  constexpr int M = QuadDims<NL>::M;
+  const int tid = threadIdx.x;
+  c.sub = tid & 3;
+  c.quad = (tid >> 2) & 3;
+  c.base = (u32)(((tid & ~15) + (tid & 3)) * 8);
+  c.pinv = P->pinv;
+  c.keep_top = c.sub == 3 ? 0xFFFFFFFFu : LIMB_MASK;
+  c.carry_top = c.sub == 3 ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int pos = c.sub * M + j;
+    c.p[j] = pos < NL ? P->p[pos < NL ? pos : 0] : 0u;
+  }
+}
+
+// limbs s*M .. s*M + M - 1 of element e of a limb-major SoA array (zero beyond NL)
+template <int NL>
+__device__ __forceinline__ void quad_gload(int (&x)[QuadDims<NL>::M], const u32* __restrict__ base, size_t stride, size_t e,
+                                           int sub) {
+  constexpr int M = QuadDims<NL>::M;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int pos = sub * M + j;
+    x[j] = pos < NL ? (int)base[(size_t)(pos < NL ? pos : 0) * stride + e] : 0;
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void quad_gstore(u32* __restrict__ base, size_t stride, size_t e, int sub,
+                                            const int (&x)[QuadDims<NL>::M]) {
+  constexpr int M = QuadDims<NL>::M;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int pos = sub * M + j;
+    if (pos < NL) base[(size_t)pos * stride + e] = (u32)x[j];
+  }
+}
+
+// Sixteen pairings per workgroup.  Operands: canonical Montgomery SoA; result: plain canonical SoA (what
+// k_pairing<NL, 0> and k_pairing_coop<NL> read and write).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point;
+// mode 2: the coefficient pairs of polynomial products (d1, d2 coefficients).
+// phase 1: the Miller loop and F0^2, F1^2, F0*F1, parked in `park` with N(f) written as tight limbs to nsoa — then
+// k_coop_invert (coop.hpp) inverts all the norms of the batch with the division steps of fpinv.hpp, one per lane —
+// phase 2: the rest of the final exponentiation from the parked values and the inverse in isoa (limb stride ws).
+template <int NL>
+__global__ void __launch_bounds__(QUAD_BLOCK)
+k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out, size_t count,
+               int mode, size_t d1, size_t d2, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
+               const u32* __restrict__ isoa, size_t ws) {
+  constexpr int M = QuadDims<NL>::M;
+  __shared__ u64 Vs[QuadDims<NL>::SLOT_ROWS * QuadDims<NL>::MR * QUAD_BLOCK];
+  char* V = reinterpret_cast<char*>(Vs);
+  QuadLane<NL> c;
+  quad_lane_init<NL>(c, P);
+  size_t e = (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);
+  const bool live = e < count;
+  if (!live) e = count - 1;                     // stands in for the last pairing (same wave, lockstep; stores suppressed)
+  size_t ea = e, eb = (mode == 1) ? 0 : e;
+  if (mode == 2) {                              // MultPoly, poly.go:139-146
+    ea = e / d2;
+    eb = (ea / d1) * d2 + e % d2;
+  }
+  int x[M];
+  auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
+  // constants and operands into their slots, one quad each
+  if (c.quad == 0) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[j] = 0;
+    put(QUAD_SLOT_ZERO);
+    put(QUAD_SLOT_V1_0);
+    if (c.sub == 0) x[0] = 1;
+    put(QUAD_SLOT_RAW1);
+  } else if (c.quad == 1) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int pos = c.sub * M + j;
+      x[j] = pos < NL ? (int)P->one[pos < NL ? pos : 0] : 0;
+    }
+    put(QUAD_SLOT_ONE);
+    put(QUAD_SLOT_Z_0);
+    put(QUAD_SLOT_ZZ_0);
+    put(QUAD_SLOT_W_0);
+    put(QUAD_SLOT_V0_0);
+    put(QUAD_SLOT_V2_0);
+  }
+  if (phase == 1) {
+    if (c.quad == 0) {
+      quad_gload<NL>(x, a.c0, a.stride, ea, c.sub);
+      put(QUAD_SLOT_AX);
+      put(QUAD_SLOT_X_0);
+    } else if (c.quad == 1) {
+      quad_gload<NL>(x, a.c1, a.stride, ea, c.sub);
+      put(QUAD_SLOT_AY);
+      put(QUAD_SLOT_Y_0);
+    } else if (c.quad == 2) {
+      quad_gload<NL>(x, b.c0, b.stride, eb, c.sub);
+      put(QUAD_SLOT_BX);
+    } else {
+      quad_gload<NL>(x, b.c1, b.stride, eb, c.sub);
+      put(QUAD_SLOT_BY);
+    }
+  } else {
+    if (c.quad < 3) {
+      const int slot = c.quad == 0 ? QUAD_SLOT_N1 : c.quad == 1 ? QUAD_SLOT_N2 : QUAD_SLOT_FM;
+      const u32* src = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+#pragma unroll
+      for (int j = 0; j < M; ++j) x[j] = (int)src[j];
+      put(slot);
+    } else {
+      quad_gload<NL>(x, isoa, ws, e, c.sub);
+      put(QUAD_SLOT_ACC_0);
+    }
+  }
+  // The controller: ONE loop with one call site of the round interpreter (the unrolled product is 9 KB of code),
+  // every decision wave-uniform.
+  //   phase 1: the Miller loop over the NAF of n (pairing.hpp miller_loop), sequenced as in coop.hpp — a doubling
+  //   and the addition of +-A that follows it, two plain doublings, or one doubling per segment; the last addition
+  //   is skipped as in PBC; the state ping-pongs between two slot sets — then the norms' segment.
+  //   phase 2: h = conj(f)^2 / N(f), g = h^l by square-and-multiply, the division by R.
+  const u32* nafw = reinterpret_cast<const u32*>(C->naf);
+  auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
+  int par = 0;                                   // parity of the state's slot set (phase 1) / of the ladder's (phase 2)
+  int i = phase == 1 ? C->naf_len - 2 : C->l_bits - 2;
+  int stage = 0;                                 // phase 1: 0 loop, 1 norms, 2 done; phase 2: 0 H, 1 square, 2 multiply?, 3 out, 4 done
+#pragma unroll 1
+  for (;;) {
+    int seg;
+    if (phase == 1) {
+      if (stage == 0 && i < 0) stage = 1;
+      if (stage == 0) {
+        const int d = digit(i);
+        if (d != 0 && i != 0) {
+          seg = d > 0 ? QUAD_SEG_DAP0 : QUAD_SEG_DAM0;
+          i -= 1;
+        } else if (i >= 1 && (i == 1 || digit(i - 1) == 0)) {
+          seg = QUAD_SEG_DD0;
+          i -= 2;
+        } else {
+          seg = QUAD_SEG_DBL0;
+          i -= 1;
+        }
+        seg += 4 * par;
+        par ^= 1;
+      } else if (stage == 1) {
+        seg = QUAD_SEG_NORM0 + par;
+        stage = 2;
+      } else {
+        break;
+      }
+    } else {
+      if (stage == 0) {
+        seg = QUAD_SEG_H0;
+        stage = i >= 0 ? 1 : 3;
+      } else if (stage == 1) {
+        seg = par ? QUAD_SEG_LSQ1 : QUAD_SEG_LSQ0;
+        par ^= 1;
+        stage = ((C->l >> i) & 1ull) ? 2 : (i > 0 ? 1 : 3);
+        if (stage != 2) --i;
+      } else if (stage == 2) {
+        seg = par ? QUAD_SEG_LMU1 : QUAD_SEG_LMU0;
+        par ^= 1;
+        stage = i > 0 ? 1 : 3;
+        --i;
+      } else if (stage == 3) {
+        seg = par ? QUAD_SEG_OUT1 : QUAD_SEG_OUT0;
+        stage = 4;
+      } else {
+        break;
+      }
+    }
+    quad_run<NL>(V, seg, c);
+  }
+  if (phase == 1) {
+    // park F0^2, F1^2, F0*F1 and hand N(f) = F0^2 + F1^2 to the inversion kernel as tight limbs (< 4p)
+    if (c.quad < 3) {
+      const int slot = c.quad == 0 ? QUAD_SLOT_N1 : c.quad == 1 ? QUAD_SLOT_N2 : QUAD_SLOT_FM;
+      quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c));
+      if (live) {
+        u32* dst = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+#pragma unroll
+        for (int j = 0; j < M; ++j) dst[j] = (u32)x[j];
+      }
+    } else {
+      int y[M];
+      quad_load<NL>(x, V, quad_addr<NL>((u32)QUAD_SLOT_N1, c));
+      quad_load<NL>(y, V, quad_addr<NL>((u32)QUAD_SLOT_N2, c));
+#pragma unroll
+      for (int j = 0; j < M; ++j) x[j] += y[j];
+      quad_tight<NL>(x, c);
+      if (live) quad_gstore<NL>(nsoa, ws, e, c.sub, x);
+    }
+    return;
+  }
+  // canonical residues out: quad 0 the real part, quad 1 the imaginary part
+  if (c.quad < 2) {
+    const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]);      // e(O, .) = e(., O) = 1
+    quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUAD_SLOT_OUT0 : QUAD_SLOT_OUT1), c));
+    quad_canonical<NL>(x, c);
+    if (ident) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) x[j] = 0;
+      if (c.quad == 0 && c.sub == 0) x[0] = 1;
+    }
+    if (live) quad_gstore<NL>(c.quad == 0 ? out.c0 : out.c1, out.stride, e, c.sub, x);
+  }
+}
+
+}  // namespace bgn

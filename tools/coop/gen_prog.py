@@ -26,6 +26,7 @@ import sys
 
 W = 8                 # waves per pairing: two per SIMD; slots k and k + 4 of a round share a SIMD
 BASE = 4              # products a round takes freely (one per SIMD); more only when they are on the critical path
+QUAD_W = 4            # lane-group kernel: quads of lanes per pairing (a round costs the same with one product or four)
 MAX_TERMS = 4         # terms per linear operand
 BOUND_PRODUCT = 512   # bound(A) * bound(B) <= 2^9 <= R/p (engine.cpp chooses NL so)
 MUL_WEIGHT, LIN_WEIGHT = 10, 1
@@ -178,7 +179,8 @@ def schedule(uops, w=W, base=BASE):
 
 
 class Program:
-    def __init__(self):
+    def __init__(self, w=W, base=BASE):
+        self.w, self.base = w, base
         self.globals = {}      # name -> physical slot (never written by a scheduled micro-op of a loop body reading it)
         self.segments = []     # (name, rounds)
         self.bound = {}
@@ -194,7 +196,7 @@ class Program:
     def segment(self, name, build):
         b = Builder(self.bound, name)
         build(b)
-        rounds = schedule(b.uops)
+        rounds = schedule(b.uops, self.w, self.base)
         self.segments.append((name, rounds))
         return rounds
 
@@ -236,8 +238,8 @@ class Program:
 STATE_BOUNDS = {"X": 19, "Y": 19, "Z": 2, "ZZ": 2, "W": 2, "v0": 2, "v1": 2, "v2": 2}
 
 
-def build_program():
-    P = Program()
+def build_program(w=W, base=BASE):
+    P = Program(w, base)
     # operands (canonical Montgomery, < p) and constants
     ax, ay, bx, by = (P.fixed(n, 1) for n in ("ax", "ay", "bx", "by"))
     one = P.fixed("one", 1)          # R mod p
@@ -435,40 +437,46 @@ def build_program():
 # ---------------------------------------------------------------------------------------------------------------
 # Emission
 # ---------------------------------------------------------------------------------------------------------------
-def emit(P, path):
+def emit(P, path, prefix="COOP", w=None, round_headers=False):
+    """Writes the tables as a C include.  prefix "COOP": the wave-cooperative kernel (one micro-op per wave);
+    "QUAD": the lane-group kernel (csrc/quad/: one micro-op per quad of lanes, w = 4), which also gets one header
+    word per round with what is uniform over its micro-ops (term counts, whether every operand is plain)."""
+    w = w or P.w
+    cap = prefix.capitalize()
     seg_index = {}
     rows = []
     rnd = 0
     for name, rounds in P.segments:
         seg_index[name] = (rnd, len(rounds))
         for us in rounds:
-            row = list(us) + [None] * (W - len(us))
+            row = list(us) + [None] * (w - len(us))
             rows.append(row)
             rnd += 1
     lines = []
-    lines.append("// GENERATED by tools/coop/gen_prog.py — do not edit.  Micro-op tables of the wave-cooperative pairing.")
-    lines.append("// %d segments, %d rounds of %d micro-ops, %d LDS value slots." % (len(P.segments), rnd, W, P.nslots))
-    lines.append("#define COOP_W %d" % W)
-    lines.append("#define COOP_NSLOTS %d" % P.nslots)
-    lines.append("#define COOP_MAX_TERMS %d" % MAX_TERMS)
+    what = "wave-cooperative pairing" if prefix == "COOP" else "lane-group pairing (csrc/quad/)"
+    lines.append("// GENERATED by tools/coop/gen_prog.py — do not edit.  Micro-op tables of the %s." % what)
+    lines.append("// %d segments, %d rounds of %d micro-ops, %d LDS value slots." % (len(P.segments), rnd, w, P.nslots))
+    lines.append("#define %s_W %d" % (prefix, w))
+    lines.append("#define %s_NSLOTS %d" % (prefix, P.nslots))
+    lines.append("#define %s_MAX_TERMS %d" % (prefix, MAX_TERMS))
     for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "ZZ@0", "W@0", "v0@0", "v1@0", "v2@0",
                   "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1",
                   "ta1@0", "tb1@0", "ta2@0", "tb2@0", "ta1@1", "tb1@1", "ta2@1", "tb2@1", "v0@1", "v1@1", "v2@1"):
-        lines.append("#define COOP_SLOT_%s %d" % (gname.replace("@", "_").upper(), P.phys[gname]))
-    lines.append("enum CoopSeg {")
+        lines.append("#define %s_SLOT_%s %d" % (prefix, gname.replace("@", "_").upper(), P.phys[gname]))
+    lines.append("enum %sSeg {" % cap)
     for i, (name, _) in enumerate(P.segments):
-        lines.append("  COOP_SEG_%s = %d," % (name, i))
-    lines.append("  COOP_NSEG = %d" % len(P.segments))
+        lines.append("  %s_SEG_%s = %d," % (prefix, name, i))
+    lines.append("  %s_NSEG = %d" % (prefix, len(P.segments)))
     lines.append("};")
-    lines.append("static __device__ const unsigned int kCoopSegFirst[COOP_NSEG] = {%s};" %
-                 ", ".join(str(seg_index[n][0]) for n, _ in P.segments))
-    lines.append("static __device__ const unsigned int kCoopSegRounds[COOP_NSEG] = {%s};" %
-                 ", ".join(str(seg_index[n][1]) for n, _ in P.segments))
+    lines.append("static __device__ const unsigned int k%sSegFirst[%s_NSEG] = {%s};" %
+                 (cap, prefix, ", ".join(str(seg_index[n][0]) for n, _ in P.segments)))
+    lines.append("static __device__ const unsigned int k%sSegRounds[%s_NSEG] = {%s};" %
+                 (cap, prefix, ", ".join(str(seg_index[n][1]) for n, _ in P.segments)))
     lines.append("// eight dwords per micro-op (scalar loads have no byte form): kind | A plain<<8 | B plain<<9 | dst<<16 | "
                  "nb<<24, ne | KA<<8 | KB<<16 | KE<<24,")
     lines.append("// (\"plain\": the operand is one stored value with coefficient 1 and no multiple of p, used as it is)")
     lines.append("// then slot indices and signed coefficients of A, B, E, four bytes each; kind: 0 nop, 1 mul, 2 lin")
-    lines.append("alignas(32) static __device__ const unsigned int kCoopProg[%d][8] = {" % (rnd * W))
+    lines.append("alignas(32) static __device__ const unsigned int k%sProg[%d][8] = {" % (cap, rnd * w))
 
     def terms(form):
         items = sorted(form.items(), key=lambda kv: P.phys[kv[0]]) if form else []
@@ -477,22 +485,40 @@ def emit(P, path):
         assert all(-128 <= c <= 127 for c in cf)
         return len(items), idx, cf
 
+    plain = lambda f, K: int(f is not None and len(f) == 1 and list(f.values())[0] == 1 and K == 0)
+    headers = []
     for r, row in enumerate(rows):
+        na_max = nb_max = ne_max = 0
+        all_plain_a = all_plain_b = 1
+        any_mul = 0
         for u in row:
             if u is None:
                 lines.append("  {0, 0, 0, 0, 0, 0, 0, 0},")
+                all_plain_a = all_plain_b = 0      # an idle quad multiplies zero by zero through the general path
                 continue
             na, ia, ca = terms(u.A)
             nb, ib, cb = terms(u.B)
             ne, ie, ce = terms(u.E)
             assert max(u.KA, u.KB, u.KE) <= 255
             pk = lambda v: sum((x & 0xFF) << (8 * i) for i, x in enumerate(v))
-            plain = lambda f, K: int(f is not None and len(f) == 1 and list(f.values())[0] == 1 and K == 0)
+            if u.kind == "mul":
+                any_mul = 1
+                na_max, nb_max = max(na_max, na), max(nb_max, nb)
+                all_plain_a &= plain(u.A, u.KA)
+                all_plain_b &= plain(u.B, u.KB)
+            else:
+                all_plain_a = all_plain_b = 0
+            ne_max = max(ne_max, ne)
             w0 = (1 if u.kind == "mul" else 2) | plain(u.A, u.KA) << 8 | plain(u.B, u.KB) << 9 | P.phys[u.dst] << 16 | nb << 24
             words = [w0, pk([ne, u.KA, u.KB, u.KE]),
                      pk(ia), pk(ca), pk(ib), pk(cb), pk(ie), pk(ce)]
-            lines.append("  {%s},   // r%d %s" % (", ".join("0x%08xu" % w for w in words), r, u.dst))
+            lines.append("  {%s},   // r%d %s" % (", ".join("0x%08xu" % x for x in words), r, u.dst))
+        headers.append(na_max | nb_max << 4 | ne_max << 8 | all_plain_a << 12 | all_plain_b << 13 | any_mul << 14)
     lines.append("};")
+    if round_headers:
+        lines.append("// one word per round: max terms of A | of B << 4 | of E << 8 | every A plain << 12 | every B plain << 13 | "
+                     "any product << 14")
+        lines.append("static __device__ const unsigned int k%sRound[%d] = {%s};" % (cap, rnd, ", ".join("0x%04xu" % h for h in headers)))
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return seg_index
@@ -514,3 +540,10 @@ if __name__ == "__main__":
     emit(P, path)
     print(summary(P))
     print("slots:", P.nslots, "->", path)
+    # the lane-group kernel (csrc/quad/): the same step programs scheduled for four quads of lanes per pairing
+    Q = build_program(QUAD_W, QUAD_W)
+    qpath = os.path.join(root, "bgn_amd", "csrc", "quad", "quad_prog.inc")
+    os.makedirs(os.path.dirname(qpath), exist_ok=True)
+    emit(Q, qpath, prefix="QUAD", round_headers=True)
+    print(summary(Q))
+    print("slots:", Q.nslots, "->", qpath)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Mid-size batches: Mult wall time by batch size on the three pairing kernels — the wave-cooperative one
+(coop/coop.hpp), the lane-group one (quad/quad.hpp) and one pairing per lane (pairing.hpp) — device-resident operands,
+best of three, results compared.  The crossovers of coop_limit / quad_limit (engine.cpp) are chosen from this CSV:
+    python tools/quad_sweep.py [k1024 ...] > profiles/r03_mid_batch.csv"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+from conftest import load_fixture  # noqa: E402
+import bgn_amd  # noqa: E402
+import bgn_amd.synthetic as syn  # noqa: E402
+
+
+def main():
+    keys = sys.argv[1:] or ["k512", "k1024"]
+    counts = [int(x) for x in os.environ.get("QUAD_SWEEP_COUNTS", "256,1024,2048,4096,6144,8192,12288,16384,32768,49152,65536").split(",")]
+    kernels = os.environ.get("QUAD_SWEEP_KERNELS", "quad,coop,lane").split(",")
+    print("key,op,count,kernel,ms,ops_per_s,kernel_name")
+    dev = torch.device("cuda", 0)
+    for key in keys:
+        fx = load_fixture(key)
+        pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                               fx["msg_space"], True, fx["poly_base"])
+        eng = pk.engine
+        EB = eng.elem_bytes
+        nmax = max(counts)
+        _, _, cts = syn.config2_ciphertexts(pk, nmax, seed=3, device=dev)
+        b = syn.permuted_copy(cts, EB, seed=4)
+        out = torch.empty(nmax * EB, dtype=torch.uint8, device=dev)
+        ref = {}
+        for kernel in kernels:
+            os.environ["BGN_QUAD_MIN"] = "0"
+            os.environ["BGN_QUAD_MAX"] = "100000000" if kernel == "quad" else "0"
+            os.environ["BGN_COOP_MAX"] = "100000000" if kernel == "coop" else "0"
+            for n in counts:
+                if kernel == "coop" and n > 16384:
+                    continue
+                best = None
+                for rep in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    eng.mult_dev(cts[: n * EB], b[: n * EB], out, n)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None or dt < best else best
+                digest = hash(out[: n * EB].cpu().numpy().tobytes())
+                assert ref.setdefault(n, digest) == digest, "kernels disagree at %d" % n
+                print("%s,mult,%d,%s,%.4f,%.1f,%s" % (key, n, kernel, best * 1e3, n / best, eng.last_kernel_name()), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,10 +25,10 @@ static void launch(hipStream_t s, const void* params, const PairingConsts* const
   uint32_t* park = ws;
   uint32_t* nsoa = ws + (size_t)QuadDims<NL>::PARK_WORDS * sw;
   uint32_t* isoa = nsoa + (size_t)NL * sw;
-  hipLaunchKernelGGL((k_pairing_quad<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 1, park, nsoa, isoa, sw);
+  hipLaunchKernelGGL((k_pairing_quad<NL, 1>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, park, nsoa, isoa, sw);
   hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P, nsoa,
                      isoa, sw, count, p_bits);
-  hipLaunchKernelGGL((k_pairing_quad<NL>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, 2, park, nsoa, isoa, sw);
+  hipLaunchKernelGGL((k_pairing_quad<NL, 2>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, park, nsoa, isoa, sw);
 }
 
 bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
@@ -45,9 +45,9 @@ bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const Pairin
 
 const char* quad_pairing_kernel_name(int nl) {
   switch (nl) {
-    case 10: return "k_pairing_quad<10>";
-    case 19: return "k_pairing_quad<19>";
-    case 38: return "k_pairing_quad<38>";
+    case 10: return "k_pairing_quad<10, 1>";
+    case 19: return "k_pairing_quad<19, 1>";
+    case 38: return "k_pairing_quad<38, 1>";
   }
   return "";
 }

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "../fp28.hpp"
@@ -37,9 +38,30 @@ namespace bgn {
 
 #include "quad_prog.inc"
 
+constexpr int QUAD_W = QUADM_W;                       // quads per pairing = micro-ops per round
+static_assert(QUADM_W == 4 && QUADF_W == 4 && QUADM_MAX_TERMS == QUADF_MAX_TERMS, "four quads of four lanes per pairing");
+constexpr int QUAD_MAX_TERMS = QUADM_MAX_TERMS;
 constexpr int QUAD_BLOCK = 256;                       // four waves, one per SIMD
 constexpr int QUAD_LANES = 4 * QUAD_W;                // lanes per pairing
 constexpr int QUAD_PER_BLOCK = QUAD_BLOCK / QUAD_LANES;
+
+// The two programs (tools/coop/gen_prog.py build_quad_programs): launch 1 = Miller loop and norms, launch 2 = the
+// rest of the final exponentiation.  Each has its own slot numbering, and needs at most 32 value slots per pairing
+// (the Miller state is updated in place: a round's reads precede its writes), so two workgroups share a CU.
+struct QuadMiller {
+  static constexpr int NSLOTS = QUADM_NSLOTS;
+  static __device__ __forceinline__ const u32* prog(int i) { return kQuadmProg[i]; }
+  static __device__ __forceinline__ u32 round_header(int r) { return kQuadmRound[r]; }
+  static __device__ __forceinline__ int seg_first(int s) { return (int)kQuadmSegFirst[s]; }
+  static __device__ __forceinline__ int seg_rounds(int s) { return (int)kQuadmSegRounds[s]; }
+};
+struct QuadFinal {
+  static constexpr int NSLOTS = QUADF_NSLOTS;
+  static __device__ __forceinline__ const u32* prog(int i) { return kQuadfProg[i]; }
+  static __device__ __forceinline__ u32 round_header(int r) { return kQuadfRound[r]; }
+  static __device__ __forceinline__ int seg_first(int s) { return (int)kQuadfSegFirst[s]; }
+  static __device__ __forceinline__ int seg_rounds(int s) { return (int)kQuadfSegRounds[s]; }
+};
 
 template <int NL>
 struct QuadDims {
@@ -48,7 +70,6 @@ struct QuadDims {
   static constexpr int JTOP = NL - 1 - 3 * M;         // index of the top limb (position NL - 1) in lane 3
   static constexpr int ROW_BYTES = QUAD_BLOCK * 8;
   static constexpr int SLOT_BYTES = MR * ROW_BYTES;   // one row block: a value for each quad of every pairing
-  static constexpr int SLOT_ROWS = (QUAD_NSLOTS + 3) / 4;
   static constexpr int PARK_WORDS = 3 * 4 * M;        // per pairing: F0^2, F1^2, F0*F1 as they lie in the lanes
   static_assert(M >= 2 && JTOP >= 0 && JTOP < M, "limb split");
 };
@@ -172,8 +193,8 @@ __device__ __forceinline__ void quad_canonical(int (&x)[QuadDims<NL>::M], const 
 // acc += sum of c_k * V[i_k] + K*p: n terms (the largest count among the quads of the round, wave-uniform; a quad
 // with fewer has coefficient 0 on slot 0), slot indices and signed coefficients one byte each.
 template <int NL>
-__device__ __forceinline__ void quad_combo(long long (&acc)[QuadDims<NL>::M], const char* V, int n, u32 idx, u32 cf, int K,
-                                           const QuadLane<NL>& c) {
+__device__ __forceinline__ void quad_combo(long long (&acc)[QuadDims<NL>::M], const char* V, int n, u32 idx, u32 cf, bool anyk,
+                                           int K, const QuadLane<NL>& c) {
   constexpr int M = QuadDims<NL>::M;
 #pragma unroll
   for (int t = 0; t < QUAD_MAX_TERMS; ++t) {
@@ -185,34 +206,42 @@ __device__ __forceinline__ void quad_combo(long long (&acc)[QuadDims<NL>::M], co
       for (int j = 0; j < M; ++j) acc[j] = imad(k, v[j], acc[j]);
     }
   }
+  if (anyk) {                                        // some quad of the round adds a multiple of p (wave-uniform)
 #pragma unroll
-  for (int j = 0; j < M; ++j) acc[j] = imad(K, (int)c.p[j], acc[j]);
+    for (int j = 0; j < M; ++j) acc[j] = imad(K, (int)c.p[j], acc[j]);
+  }
 }
 
-// One row of the Montgomery product (see the file header).
+// One row of the Montgomery product (see the file header).  `an` is this row's limb of a, already broadcast; the
+// next row's is requested here, and the quotient chain (lowest column, multiply, mask, broadcast) starts before the
+// other columns' multiply-adds so that those fill the wait states of the DPP moves.
 template <int NL, int I>
-__device__ __forceinline__ void quad_row(long long (&acc)[QuadDims<NL>::M], const int (&a)[QuadDims<NL>::M],
+__device__ __forceinline__ void quad_row(long long (&acc)[QuadDims<NL>::M], int& an, const int (&a)[QuadDims<NL>::M],
                                          const int (&b)[QuadDims<NL>::M], const QuadLane<NL>& c) {
   constexpr int M = QuadDims<NL>::M;
-  const int ai = quad_bcast<I / M>(a[I % M]);
+  const int ai = an;
+  acc[0] = imad(ai, b[0], acc[0]);
+  u32 q = ((u32)acc[0] * c.pinv) & LIMB_MASK;
+  if (I + 1 < NL) an = quad_bcast<(I + 1 < NL ? I + 1 : 0) / M>(a[(I + 1 < NL ? I + 1 : 0) % M]);
 #pragma unroll
-  for (int j = 0; j < M; ++j) acc[j] = imad(ai, b[j], acc[j]);
-  const u32 q = (u32)quad_bcast<0>((int)(((u32)acc[0] * c.pinv) & LIMB_MASK));
+  for (int j = 1; j < M; ++j) acc[j] = imad(ai, b[j], acc[j]);
+  q = (u32)quad_bcast<0>((int)q);
 #pragma unroll
   for (int j = 0; j < M; ++j) acc[j] = (long long)((u64)acc[j] + (u64)q * (u64)c.p[j]);
+  const u32 lo = (u32)acc[0] & LIMB_MASK;
   const long long cy = acc[0] >> LIMB_BITS;
-  const u32 up = (u32)quad_from_above((int)((u32)acc[0] & LIMB_MASK));
 #pragma unroll
   for (int j = 0; j < M - 1; ++j) acc[j] = acc[j + 1];
-  acc[M - 1] = (long long)(u64)up;
   acc[0] += cy;
+  acc[M - 1] = (long long)(u64)(u32)quad_from_above((int)lo);
 }
 
 template <int NL, int... I>
 __device__ __forceinline__ void quad_rows(long long (&acc)[QuadDims<NL>::M], const int (&a)[QuadDims<NL>::M],
                                           const int (&b)[QuadDims<NL>::M], const QuadLane<NL>& c,
                                           std::integer_sequence<int, I...>) {
-  (quad_row<NL, I>(acc, a, b, c), ...);
+  int an = quad_bcast<0>(a[0]);
+  (quad_row<NL, I>(acc, an, a, b, c), ...);
 }
 
 // A micro-op: eight dwords, one copy per quad (quad_prog.inc documents the packing).
@@ -221,8 +250,9 @@ struct QuadWords {
 };
 typedef unsigned int quad_u32x4 __attribute__((ext_vector_type(4)));
 
+template <class PG>
 __device__ __forceinline__ QuadWords quad_fetch(int row, int quad) {
-  const quad_u32x4* q = reinterpret_cast<const quad_u32x4*>(kQuadProg[row * QUAD_W + quad]);
+  const quad_u32x4* q = reinterpret_cast<const quad_u32x4*>(PG::prog(row * QUAD_W + quad));
   const quad_u32x4 lo = q[0], hi = q[1];
   QuadWords u;
   u.w[0] = lo[0]; u.w[1] = lo[1]; u.w[2] = lo[2]; u.w[3] = lo[3];
@@ -234,7 +264,7 @@ __device__ __forceinline__ QuadWords quad_fetch(int row, int quad) {
 // else the quads' linear combinations, normalised.
 template <int NL>
 __device__ __forceinline__ void quad_operand(int (&x)[QuadDims<NL>::M], const char* V, bool plain, int n, u32 idx, u32 cf,
-                                             int K, const QuadLane<NL>& c) {
+                                             bool anyk, int K, const QuadLane<NL>& c) {
   constexpr int M = QuadDims<NL>::M;
   if (plain) {
     quad_load<NL>(x, V, quad_addr<NL>(idx & 0xFFu, c));
@@ -243,7 +273,7 @@ __device__ __forceinline__ void quad_operand(int (&x)[QuadDims<NL>::M], const ch
   long long acc[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) acc[j] = 0;
-  quad_combo<NL>(acc, V, n, idx, cf, K, c);
+  quad_combo<NL>(acc, V, n, idx, cf, anyk, K, c);
   quad_normalize<NL>(x, acc, c);
 }
 
@@ -257,26 +287,28 @@ __device__ __forceinline__ void quad_round(char* V, const QuadWords& u, u32 hdr,
   for (int j = 0; j < M; ++j) acc[j] = 0;
   if (hdr & 0x4000u) {
     int a[M], b[M];
-    quad_operand<NL>(a, V, (hdr & 0x1000u) != 0, (int)(hdr & 0xFu), u.w[2], u.w[3], (int)((u.w[1] >> 8) & 0xFFu), c);
-    quad_operand<NL>(b, V, (hdr & 0x2000u) != 0, (int)((hdr >> 4) & 0xFu), u.w[4], u.w[5], (int)((u.w[1] >> 16) & 0xFFu), c);
+    quad_operand<NL>(a, V, (hdr & 0x1000u) != 0, (int)(hdr & 0xFu), u.w[2], u.w[3], (hdr & 0x8000u) != 0,
+                     (int)((u.w[1] >> 8) & 0xFFu), c);
+    quad_operand<NL>(b, V, (hdr & 0x2000u) != 0, (int)((hdr >> 4) & 0xFu), u.w[4], u.w[5], (hdr & 0x10000u) != 0,
+                     (int)((u.w[1] >> 16) & 0xFFu), c);
     quad_rows<NL>(acc, a, b, c, std::make_integer_sequence<int, NL>{});
   }
   const int ne = (int)((hdr >> 8) & 0xFu);
-  if (ne) quad_combo<NL>(acc, V, ne, u.w[6], u.w[7], (int)(u.w[1] >> 24), c);
+  if (ne) quad_combo<NL>(acc, V, ne, u.w[6], u.w[7], (hdr & 0x20000u) != 0, (int)(u.w[1] >> 24), c);
   int x[M];
   quad_normalize<NL>(x, acc, c);
   if (u.w[0] & 0xFu) quad_store<NL>(V, quad_addr<NL>((u.w[0] >> 16) & 0xFFu, c), x);
 }
 
 // One segment: its rounds in order; the next round's micro-ops are requested before the current round computes.
-template <int NL>
+template <int NL, class PG>
 __device__ __forceinline__ void quad_run(char* V, int seg, const QuadLane<NL>& c) {
-  const int first = (int)kQuadSegFirst[seg], n = (int)kQuadSegRounds[seg];
-  QuadWords cur = quad_fetch(first, c.quad);
+  const int first = PG::seg_first(seg), n = PG::seg_rounds(seg);
+  QuadWords cur = quad_fetch<PG>(first, c.quad);
 #pragma unroll 1
   for (int r = 0; r < n; ++r) {
-    const QuadWords nxt = quad_fetch(first + (r + 1 < n ? r + 1 : r), c.quad);
-    const u32 hdr = kQuadRound[first + r];
+    const QuadWords nxt = quad_fetch<PG>(first + (r + 1 < n ? r + 1 : r), c.quad);
+    const u32 hdr = PG::round_header(first + r);
     quad_round<NL>(V, cur, hdr, c);
     cur = nxt;
   }
@@ -325,16 +357,17 @@ __device__ __forceinline__ void quad_gstore(u32* __restrict__ base, size_t strid
 // Sixteen pairings per workgroup.  Operands: canonical Montgomery SoA; result: plain canonical SoA (what
 // k_pairing<NL, 0> and k_pairing_coop<NL> read and write).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point;
 // mode 2: the coefficient pairs of polynomial products (d1, d2 coefficients).
-// phase 1: the Miller loop and F0^2, F1^2, F0*F1, parked in `park` with N(f) written as tight limbs to nsoa — then
+// PHASE 1: the Miller loop and F0^2, F1^2, F0*F1, parked in `park` with N(f) written as tight limbs to nsoa — then
 // k_coop_invert (coop.hpp) inverts all the norms of the batch with the division steps of fpinv.hpp, one per lane —
-// phase 2: the rest of the final exponentiation from the parked values and the inverse in isoa (limb stride ws).
-template <int NL>
+// PHASE 2: the rest of the final exponentiation from the parked values and the inverse in isoa (limb stride ws).
+template <int NL, int PHASE>
 __global__ void __launch_bounds__(QUAD_BLOCK)
 k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out, size_t count,
-               int mode, size_t d1, size_t d2, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
+               int mode, size_t d1, size_t d2, u32* __restrict__ park, u32* __restrict__ nsoa,
                const u32* __restrict__ isoa, size_t ws) {
   constexpr int M = QuadDims<NL>::M;
-  __shared__ u64 Vs[QuadDims<NL>::SLOT_ROWS * QuadDims<NL>::MR * QUAD_BLOCK];
+  using PG = typename std::conditional<PHASE == 1, QuadMiller, QuadFinal>::type;
+  __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
   char* V = reinterpret_cast<char*>(Vs);
   QuadLane<NL> c;
   quad_lane_init<NL>(c, P);
@@ -348,118 +381,76 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   }
   int x[M];
   auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
-  // constants and operands into their slots, one quad each
-  if (c.quad == 0) {
-#pragma unroll
-    for (int j = 0; j < M; ++j) x[j] = 0;
-    put(QUAD_SLOT_ZERO);
-    put(QUAD_SLOT_V1_0);
-    if (c.sub == 0) x[0] = 1;
-    put(QUAD_SLOT_RAW1);
-  } else if (c.quad == 1) {
+  auto set_one = [&]() {
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       const int pos = c.sub * M + j;
       x[j] = pos < NL ? (int)P->one[pos < NL ? pos : 0] : 0;
     }
-    put(QUAD_SLOT_ONE);
-    put(QUAD_SLOT_Z_0);
-    put(QUAD_SLOT_ZZ_0);
-    put(QUAD_SLOT_W_0);
-    put(QUAD_SLOT_V0_0);
-    put(QUAD_SLOT_V2_0);
-  }
-  if (phase == 1) {
+  };
+  // The controller below is ONE loop with one call site of the round interpreter (the unrolled product is 9 KB of
+  // code); every decision in it is wave-uniform.
+  if constexpr (PHASE == 1) {
+    // operands and the initial state (V = A, f = 1 as the triple v0 = v2 = 1, v1 = 0), one quad each
     if (c.quad == 0) {
       quad_gload<NL>(x, a.c0, a.stride, ea, c.sub);
-      put(QUAD_SLOT_AX);
-      put(QUAD_SLOT_X_0);
+      put(QUADM_SLOT_AX);
+      put(QUADM_SLOT_X);
+      set_one();
+      put(QUADM_SLOT_Z);
+      put(QUADM_SLOT_V0);
     } else if (c.quad == 1) {
       quad_gload<NL>(x, a.c1, a.stride, ea, c.sub);
-      put(QUAD_SLOT_AY);
-      put(QUAD_SLOT_Y_0);
+      put(QUADM_SLOT_AY);
+      put(QUADM_SLOT_Y);
+      set_one();
+      put(QUADM_SLOT_ZZ);
+      put(QUADM_SLOT_V2);
     } else if (c.quad == 2) {
       quad_gload<NL>(x, b.c0, b.stride, eb, c.sub);
-      put(QUAD_SLOT_BX);
+      put(QUADM_SLOT_BX);
+      set_one();
+      put(QUADM_SLOT_W);
     } else {
       quad_gload<NL>(x, b.c1, b.stride, eb, c.sub);
-      put(QUAD_SLOT_BY);
-    }
-  } else {
-    if (c.quad < 3) {
-      const int slot = c.quad == 0 ? QUAD_SLOT_N1 : c.quad == 1 ? QUAD_SLOT_N2 : QUAD_SLOT_FM;
-      const u32* src = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+      put(QUADM_SLOT_BY);
 #pragma unroll
-      for (int j = 0; j < M; ++j) x[j] = (int)src[j];
-      put(slot);
-    } else {
-      quad_gload<NL>(x, isoa, ws, e, c.sub);
-      put(QUAD_SLOT_ACC_0);
+      for (int j = 0; j < M; ++j) x[j] = 0;
+      put(QUADM_SLOT_V1);
     }
-  }
-  // The controller: ONE loop with one call site of the round interpreter (the unrolled product is 9 KB of code),
-  // every decision wave-uniform.
-  //   phase 1: the Miller loop over the NAF of n (pairing.hpp miller_loop), sequenced as in coop.hpp — a doubling
-  //   and the addition of +-A that follows it, two plain doublings, or one doubling per segment; the last addition
-  //   is skipped as in PBC; the state ping-pongs between two slot sets — then the norms' segment.
-  //   phase 2: h = conj(f)^2 / N(f), g = h^l by square-and-multiply, the division by R.
-  const u32* nafw = reinterpret_cast<const u32*>(C->naf);
-  auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
-  int par = 0;                                   // parity of the state's slot set (phase 1) / of the ladder's (phase 2)
-  int i = phase == 1 ? C->naf_len - 2 : C->l_bits - 2;
-  int stage = 0;                                 // phase 1: 0 loop, 1 norms, 2 done; phase 2: 0 H, 1 square, 2 multiply?, 3 out, 4 done
+    // Miller loop over the NAF of n (pairing.hpp miller_loop), sequenced as in coop.hpp: a doubling and the
+    // addition of +-A that follows it, two plain doublings, or one doubling per segment; the last addition is
+    // skipped as in PBC; then the norms' segment.
+    const u32* nafw = reinterpret_cast<const u32*>(C->naf);
+    auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
+    int i = C->naf_len - 2;
+    bool norms = false;
 #pragma unroll 1
-  for (;;) {
-    int seg;
-    if (phase == 1) {
-      if (stage == 0 && i < 0) stage = 1;
-      if (stage == 0) {
+    for (;;) {
+      int seg;
+      if (i >= 0) {
         const int d = digit(i);
         if (d != 0 && i != 0) {
-          seg = d > 0 ? QUAD_SEG_DAP0 : QUAD_SEG_DAM0;
+          seg = d > 0 ? QUADM_SEG_DAP : QUADM_SEG_DAM;
           i -= 1;
         } else if (i >= 1 && (i == 1 || digit(i - 1) == 0)) {
-          seg = QUAD_SEG_DD0;
+          seg = QUADM_SEG_DD;
           i -= 2;
         } else {
-          seg = QUAD_SEG_DBL0;
+          seg = QUADM_SEG_DBL;
           i -= 1;
         }
-        seg += 4 * par;
-        par ^= 1;
-      } else if (stage == 1) {
-        seg = QUAD_SEG_NORM0 + par;
-        stage = 2;
+      } else if (!norms) {
+        seg = QUADM_SEG_NORM;
+        norms = true;
       } else {
         break;
       }
-    } else {
-      if (stage == 0) {
-        seg = QUAD_SEG_H0;
-        stage = i >= 0 ? 1 : 3;
-      } else if (stage == 1) {
-        seg = par ? QUAD_SEG_LSQ1 : QUAD_SEG_LSQ0;
-        par ^= 1;
-        stage = ((C->l >> i) & 1ull) ? 2 : (i > 0 ? 1 : 3);
-        if (stage != 2) --i;
-      } else if (stage == 2) {
-        seg = par ? QUAD_SEG_LMU1 : QUAD_SEG_LMU0;
-        par ^= 1;
-        stage = i > 0 ? 1 : 3;
-        --i;
-      } else if (stage == 3) {
-        seg = par ? QUAD_SEG_OUT1 : QUAD_SEG_OUT0;
-        stage = 4;
-      } else {
-        break;
-      }
+      quad_run<NL, PG>(V, seg, c);
     }
-    quad_run<NL>(V, seg, c);
-  }
-  if (phase == 1) {
     // park F0^2, F1^2, F0*F1 and hand N(f) = F0^2 + F1^2 to the inversion kernel as tight limbs (< 4p)
     if (c.quad < 3) {
-      const int slot = c.quad == 0 ? QUAD_SLOT_N1 : c.quad == 1 ? QUAD_SLOT_N2 : QUAD_SLOT_FM;
+      const int slot = c.quad == 0 ? QUADM_SLOT_N1 : c.quad == 1 ? QUADM_SLOT_N2 : QUADM_SLOT_FM;
       quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c));
       if (live) {
         u32* dst = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
@@ -468,26 +459,69 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
       }
     } else {
       int y[M];
-      quad_load<NL>(x, V, quad_addr<NL>((u32)QUAD_SLOT_N1, c));
-      quad_load<NL>(y, V, quad_addr<NL>((u32)QUAD_SLOT_N2, c));
+      quad_load<NL>(x, V, quad_addr<NL>((u32)QUADM_SLOT_N1, c));
+      quad_load<NL>(y, V, quad_addr<NL>((u32)QUADM_SLOT_N2, c));
 #pragma unroll
       for (int j = 0; j < M; ++j) x[j] += y[j];
       quad_tight<NL>(x, c);
       if (live) quad_gstore<NL>(nsoa, ws, e, c.sub, x);
     }
-    return;
-  }
-  // canonical residues out: quad 0 the real part, quad 1 the imaginary part
-  if (c.quad < 2) {
-    const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]);      // e(O, .) = e(., O) = 1
-    quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUAD_SLOT_OUT0 : QUAD_SLOT_OUT1), c));
-    quad_canonical<NL>(x, c);
-    if (ident) {
+  } else {
+    if (c.quad < 3) {
+      const int slot = c.quad == 0 ? QUADF_SLOT_N1 : c.quad == 1 ? QUADF_SLOT_N2 : QUADF_SLOT_FM;
+      const u32* src = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+#pragma unroll
+      for (int j = 0; j < M; ++j) x[j] = (int)src[j];
+      put(slot);
+    } else {
+      quad_gload<NL>(x, isoa, ws, e, c.sub);
+      put(QUADF_SLOT_INV);
 #pragma unroll
       for (int j = 0; j < M; ++j) x[j] = 0;
-      if (c.quad == 0 && c.sub == 0) x[0] = 1;
+      if (c.sub == 0) x[0] = 1;
+      put(QUADF_SLOT_RAW1);
     }
-    if (live) quad_gstore<NL>(c.quad == 0 ? out.c0 : out.c1, out.stride, e, c.sub, x);
+    // h = conj(f)^2 / N(f), g = h^l by square-and-multiply (pairing.hpp final_exp_with_inverse), the division by R
+    int i = C->l_bits - 2;
+    int stage = 0;                               // 0 H, 1 square, 2 multiply, 3 out, 4 done
+#pragma unroll 1
+    for (;;) {
+      int seg;
+      if (stage == 0) {
+        seg = QUADF_SEG_H;
+        stage = i >= 0 ? 1 : 3;
+      } else if (stage == 1) {
+        seg = QUADF_SEG_LSQ;
+        if ((C->l >> i) & 1ull) {
+          stage = 2;
+        } else {
+          stage = i > 0 ? 1 : 3;
+          --i;
+        }
+      } else if (stage == 2) {
+        seg = QUADF_SEG_LMU;
+        stage = i > 0 ? 1 : 3;
+        --i;
+      } else if (stage == 3) {
+        seg = QUADF_SEG_OUT;
+        stage = 4;
+      } else {
+        break;
+      }
+      quad_run<NL, PG>(V, seg, c);
+    }
+    // canonical residues out: quad 0 the real part, quad 1 the imaginary part
+    if (c.quad < 2) {
+      const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]);      // e(O, .) = e(., O) = 1
+      quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUADF_SLOT_OUT0 : QUADF_SLOT_OUT1), c));
+      quad_canonical<NL>(x, c);
+      if (ident) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) x[j] = 0;
+        if (c.quad == 0 && c.sub == 0) x[0] = 1;
+      }
+      if (live) quad_gstore<NL>(c.quad == 0 ? out.c0 : out.c1, out.stride, e, c.sub, x);
+    }
   }
 }
 

@@ -1,13 +1,15 @@
 """Models of the lane-group pairing kernel (bgn_amd/csrc/quad/) for the CPU tests.
 
 The kernel gives one pairing to 16 lanes of a wave: four quads, each running one micro-op of a round of the tables
-tools/coop/gen_prog.py schedules for four workers (the step programs of the wave-cooperative kernel, same
-formulas).  Inside a quad a field element is split over the four lanes, M = ceil(NL / 4) limbs of 28 bits per lane
-(lane s holds limbs s*M .. s*M + M - 1), and a Montgomery product is NL rows of {broadcast one limb of a inside the
-quad, multiply-add into the lane's M accumulators, quotient digit from lane 0, multiply-add of p, retire the lowest
-accumulator: its low 28 bits go to the lane below, the rest to the next accumulator}.
+tools/coop/gen_prog.py schedules for four workers (build_quad_programs: the formulas of the wave-cooperative
+kernel, the Miller state updated in place, one program per launch).  Inside a quad a field element is split over
+the four lanes, M = ceil(NL / 4) limbs of 28 bits per lane (lane s holds limbs s*M .. s*M + M - 1), and a
+Montgomery product is NL rows of {broadcast one limb of a inside the quad, multiply-add into the lane's M
+accumulators, quotient digit from lane 0, multiply-add of p, retire the lowest accumulator: its low 28 bits go to
+the lane below, the rest to the next accumulator}.
 
-  * QuadValueMachine — the four-worker tables on Python integers (program, schedule, slot allocation, bounds).
+  * QuadValueMachine — the tables on Python integers, values kept by PHYSICAL slot and every round's reads done
+    before its writes, as the kernel does: checks formulas, schedule, in-place updates, slot allocation, bounds.
   * QuadLaneMachine  — slots hold 4 x M signed 32-bit limbs (numpy) and every step is the kernel's instruction-level
     arithmetic with 32 / 64-bit wrap-around: what bgn_amd/csrc/quad/quad.hpp implements.
 TEST INFRASTRUCTURE: not used by the product.
@@ -17,21 +19,20 @@ from __future__ import annotations
 import numpy as np
 
 import coop_model as cm
-from coop_model import LIMB, MASK, gen_prog
+from coop_model import LIMB, MASK, gen_prog, naf
 
 I64 = np.int64
 I32 = np.int32
-U64 = np.uint64
-U32 = np.uint32
 
-_QPROGRAM = None
+_QPROGRAMS = None
 
 
-def program():
-    global _QPROGRAM
-    if _QPROGRAM is None:
-        _QPROGRAM = gen_prog.build_program(gen_prog.QUAD_W, gen_prog.QUAD_W)
-    return _QPROGRAM
+def programs():
+    """(Miller-loop program, final-exponentiation program)."""
+    global _QPROGRAMS
+    if _QPROGRAMS is None:
+        _QPROGRAMS = gen_prog.build_quad_programs()
+    return _QPROGRAMS
 
 
 def nl_for(p: int) -> int:
@@ -39,10 +40,110 @@ def nl_for(p: int) -> int:
     return next(x for x in (10, 19, 38) if x >= need)
 
 
-class QuadValueMachine(cm.ValueMachine):
+class QuadValueMachine:
     def __init__(self, p: int, nl: int):
-        super().__init__(p, nl)
-        self.P = program()
+        self.p, self.nl = p, nl
+        self.R = 1 << (LIMB * nl)
+        self.pinvR = (-pow(p, -1, self.R)) % self.R
+        self.PM, self.PF = programs()
+        self.P = self.PM
+        self.V = {}                      # physical slot -> value
+        self.rounds_run = 0
+        self.products = 0
+
+    def mont(self, x):
+        return x * self.R % self.p
+
+    # -- storage by physical slot --
+    def put(self, name, v):
+        self.V[self.P.phys[name]] = self.store(v)
+
+    def get(self, name):
+        return self.V[self.P.phys[name]]
+
+    def store(self, v):
+        return v
+
+    def value(self, x):
+        return x
+
+    def _combo(self, form, K):
+        v = sum(c * self.value(self.get(s)) for s, c in form.items()) + K * self.p
+        assert v >= 0, "negative operand"
+        return v
+
+    def _mul(self, A, B):
+        assert A * B < self.R * self.p, "Montgomery input condition violated"
+        Q = (A * B * self.pinvR) % self.R
+        self.products += 1
+        return (A * B + Q * self.p) // self.R
+
+    def exec_uop(self, u):
+        if u.kind == "mul":
+            v = self._mul(self._combo(u.A, u.KA), self._combo(u.B, u.KB))
+            if u.E:
+                v += self._combo(u.E, u.KE)
+        else:
+            v = self._combo(u.E, u.KE)
+        return v
+
+    def run(self, seg):
+        rounds = dict(self.P.segments)[seg]
+        for us in rounds:
+            assert len(us) <= self.P.w
+            res = [(u.dst, self.exec_uop(u)) for u in us]          # all reads of a round precede its writes
+            assert len({self.P.phys[k] for k, _ in res}) == len(res), "two micro-ops of a round write one slot"
+            for k, v in res:
+                assert 0 <= self.value(v) < self.P.bound[k] * self.p, "bound of %s exceeded" % k
+                self.V[self.P.phys[k]] = v
+            self.rounds_run += 1
+
+    def miller(self, ax, ay, bx, by, n):
+        """Launch 1 as the kernel's controller sequences it; returns the parked (F0^2, F1^2, F0*F1)."""
+        self.P = self.PM
+        self.V = {}
+        for k, v in (("ax", ax), ("ay", ay), ("bx", bx), ("by", by), ("X", ax), ("Y", ay), ("Z", 1), ("ZZ", 1), ("W", 1),
+                     ("v0", 1), ("v2", 1)):
+            self.put(k, self.mont(v))
+        self.put("v1", 0)
+        d = naf(n)
+        i = len(d) - 2
+        while i >= 0:
+            if d[i] and i != 0:
+                self.run("DAP" if d[i] > 0 else "DAM")                    # doubling + addition of +-A, one segment
+                i -= 1
+            elif i >= 1 and (i == 1 or d[i - 1] == 0):
+                self.run("DD")                                            # two plain doublings, one segment
+                i -= 2
+            else:
+                self.run("DBL")
+                i -= 1
+        self.run("NORM")
+        return [self.get(k) for k in ("n1", "n2", "fm")]
+
+    def final(self, parked, inv, l):
+        """Launch 2: parked values and inv = R^2 / N(f) mod p (what k_coop_invert writes) -> the two output slots."""
+        self.P = self.PF
+        self.V = {}
+        for k, v in zip(("n1", "n2", "fm"), parked):
+            self.V[self.P.phys[k]] = v
+        self.put("inv", inv)
+        self.put("raw1", 1)
+        self.run("H")
+        for i in range(l.bit_length() - 2, -1, -1):
+            self.run("LSQ")
+            if (l >> i) & 1:
+                self.run("LMU")
+        self.run("OUT")
+        return self.get("out0"), self.get("out1")
+
+    def pairing(self, ax, ay, bx, by, n, l):
+        """e(A, B); plain residues in and out."""
+        parked = self.miller(ax, ay, bx, by, n)
+        N = (self.value(parked[0]) + self.value(parked[1])) % self.p
+        inv = self.R * self.R * pow(N, -1, self.p) % self.p
+        o0, o1 = self.final(parked, inv, l)
+        return self.value(o0) % self.p, self.value(o1) % self.p
 
 
 def to_quad(v: int, nl: int) -> np.ndarray:
@@ -61,7 +162,7 @@ def from_quad(x: np.ndarray) -> int:
 
 
 class QuadLaneMachine(QuadValueMachine):
-    """Same controller; slots hold 4 x M lane limbs."""
+    """Same controller and slot handling; a slot holds 4 x M lane limbs."""
 
     def __init__(self, p: int, nl: int):
         super().__init__(p, nl)
@@ -70,10 +171,15 @@ class QuadLaneMachine(QuadValueMachine):
         assert self.m >= 2 and 0 <= self.jtop < self.m
         self.p_q = to_quad(p, nl).astype(I64)
         self.pinv = (-pow(p, -1, 1 << LIMB)) % (1 << LIMB)
-        self.L = {}
         self.max_limb = 0
 
-    # -- quad_perm moves: lane s reads lane (s + 1) & 3 / (s - 1) & 3 / lane k --
+    def store(self, v):
+        return v if isinstance(v, np.ndarray) else to_quad(v, self.nl)
+
+    def value(self, x):
+        return from_quad(x)
+
+    # -- quad_perm moves: lane s reads lane (s + 1) & 3 / (s - 1) & 3 --
     @staticmethod
     def rot_down(x):
         return np.roll(x, -1, axis=0)
@@ -117,7 +223,7 @@ class QuadLaneMachine(QuadValueMachine):
     def combo(self, form, K):
         acc = np.zeros((4, self.m), dtype=I64)
         for s, c in sorted(form.items(), key=lambda kv: self.P.phys[kv[0]]):
-            acc = acc + I64(c) * self.L[s].astype(I64)                       # v_mad_i64_i32
+            acc = acc + I64(c) * self.get(s).astype(I64)                     # v_mad_i64_i32
         return acc + I64(K) * self.p_q
 
     def mul(self, a, b):
@@ -150,16 +256,6 @@ class QuadLaneMachine(QuadValueMachine):
             return self.normalize(t)
         return self.normalize(self.combo(u.E, u.KE))
 
-    def run(self, seg):
-        rounds = dict(self.P.segments)[seg]
-        for us in rounds:
-            res = [(u.dst, self.exec_uop(u)) for u in us]
-            for k, v in res:
-                self.L[k] = v
-                val = from_quad(v)
-                assert 0 <= val < self.P.bound[k] * self.p, "lane value of %s out of its bound" % k
-            self.rounds_run += 1
-
     def tight(self, x):
         """Exact carry resolution (quad_tight): four passes, each exact inside the lanes and handing the carries one
         lane up."""
@@ -189,12 +285,10 @@ class QuadLaneMachine(QuadValueMachine):
         return r
 
     def pairing(self, ax, ay, bx, by, n, l):
-        for k, v in {"ax": self.mont(ax), "ay": self.mont(ay), "bx": self.mont(bx), "by": self.mont(by),
-                     "one": self.mont(1), "raw1": 1, "zero": 0}.items():
-            self.L[k] = to_quad(v, self.nl)
-        for k, s in {"X@0": "ax", "Y@0": "ay", "Z@0": "one", "ZZ@0": "one", "W@0": "one", "v0@0": "one", "v1@0": "zero",
-                     "v2@0": "one"}.items():
-            self.L[k] = self.L[s].copy()
-        self.V = cm._Unused()
-        cm.ValueMachine.pairing(self, ax, ay, bx, by, n, l)
-        return from_quad(self.canonical(self.L["out0"])), from_quad(self.canonical(self.L["out1"]))
+        parked = self.miller(ax, ay, bx, by, n)
+        nt = self.tight(parked[0].astype(I64) + parked[1].astype(I64))       # what launch 1 hands to the inversion kernel
+        N = from_quad(nt)
+        assert np.all(nt >= 0) and np.all(nt <= MASK) and 0 <= N < 4 * self.p
+        inv = self.R * self.R * pow(N, -1, self.p) % self.p
+        o0, o1 = self.final(parked, inv, l)
+        return from_quad(self.canonical(o0)), from_quad(self.canonical(o1))

@@ -123,14 +123,18 @@ class Builder:
 ROUND_FIXED, ROUND_PRODUCT, ROUND_HEAVY = 1000, 1700, 1.33
 
 
-def schedule(uops, w=W, base=BASE):
+def schedule(uops, w=W, base=BASE, anti=None):
     """Scheduling into rounds of at most w micro-ops; a micro-op reads only slots written in earlier rounds (or
     never written in this segment).  Products are taken in order of their longest path to a sink.  Two waves on a
     SIMD share its issue slots, so a round with more than `base` products takes about 1.33x as long (measured) as one with at
     most `base` — but then it may as well hold w of them.  Every round therefore takes either its `base` best ready
     products or up to w, and the choice per round is searched exhaustively against the round-time model above
     (a segment is at most a dozen rounds).  Linear micro-ops cost no product: they fill free waves of the first
-    round they are ready in.  Measured against 4 waves with one product each: a doubling 3 rounds instead of 5."""
+    round they are ready in.  Measured against 4 waves with one product each: a doubling 3 rounds instead of 5.
+    anti: {writer index: reader indices} — the writer overwrites (in place) a slot those micro-ops read, so it may not
+    run in an earlier round than any of them (the same round is fine where a round's reads precede its writes: the
+    lane-group kernel)."""
+    anti = anti or {}
     writer = {u.dst: i for i, u in enumerate(uops)}
     assert len(writer) == len(uops), "a slot is written twice in one segment"
     deps = [sorted(writer[s] for s in u.reads() if s in writer) for u in uops]
@@ -158,10 +162,36 @@ def schedule(uops, w=W, base=BASE):
         assert ready
         muls = sorted((i for i in ready if uops[i].kind == "mul"), key=lambda i: (-prio[i], i))
         lins = sorted((i for i in ready if uops[i].kind != "mul"), key=lambda i: (-prio[i], i))
+
+        def pick(k):
+            """At most k products and w micro-ops in priority order; an in-place writer only when every reader of
+            the old value has run or runs in this round (found as a fixpoint: drop writers whose readers are
+            missing, refill)."""
+            pool = list(muls) + list(lins)
+            while True:
+                sel, nm = [], 0
+                for i in pool:
+                    if len(sel) >= w:
+                        break
+                    if uops[i].kind == "mul":
+                        if nm >= k:
+                            continue
+                        nm += 1
+                    sel.append(i)
+                bad = [i for i in sel if not all(j == i or j in done or j in sel for j in anti.get(i, ()))]
+                if not bad:
+                    return sel
+                pool = [i for i in pool if i not in bad]
+
         options = sorted({min(len(muls), base), min(len(muls), w)}, reverse=True)
         for k in options:
-            take = muls[:k] + lins[: w - k]
+            if anti:
+                take = pick(k)
+            else:
+                take = muls[:k] + lins[: w - k]
             if not take:
+                if anti and k == options[-1]:
+                    raise AssertionError("in-place constraints leave nothing to run")
                 continue
             c = ROUND_FIXED + (0 if k == 0 else ROUND_PRODUCT * (1 if k <= base else ROUND_HEAVY))
             d2 = dict(done)
@@ -179,8 +209,9 @@ def schedule(uops, w=W, base=BASE):
 
 
 class Program:
-    def __init__(self, w=W, base=BASE):
+    def __init__(self, w=W, base=BASE, reads_first=False):
         self.w, self.base = w, base
+        self.reads_first = reads_first   # a round's reads all precede its writes (lane-group kernel: one wave, no barrier)
         self.globals = {}      # name -> physical slot (never written by a scheduled micro-op of a loop body reading it)
         self.segments = []     # (name, rounds)
         self.bound = {}
@@ -193,10 +224,26 @@ class Program:
         self.bound[name] = bound
         return S(name)
 
-    def segment(self, name, build):
+    def segment(self, name, build, inplace=None):
+        """inplace: {new name: old name} — the micro-op writing `new` stores into the slot of `old`, which other
+        micro-ops of the segment still read as the old value (needs reads_first)."""
         b = Builder(self.bound, name)
         build(b)
-        rounds = schedule(b.uops, self.w, self.base)
+        anti = None
+        if inplace:
+            assert self.reads_first
+            anti = {}
+            for i, u in enumerate(b.uops):
+                if u.dst in inplace:
+                    anti[i] = [j for j, v in enumerate(b.uops) if inplace[u.dst] in v.reads()]
+                    self.phys[u.dst] = self.phys[inplace[u.dst]]
+        rounds = schedule(b.uops, self.w, self.base, anti)
+        if inplace:
+            rnd = {u.dst: r for r, us in enumerate(rounds) for u in us}
+            for r, us in enumerate(rounds):
+                for u in us:
+                    for new, old in inplace.items():
+                        assert old not in u.reads() or new not in rnd or r <= rnd[new], (name, new, u.dst)
         self.segments.append((name, rounds))
         return rounds
 
@@ -213,7 +260,7 @@ class Program:
             free, busy = [], {}
             nxt = base
             for r, us in enumerate(rounds):
-                for s in [s for s, (ph, lr) in busy.items() if lr < r]:
+                for s in [s for s, (ph, lr) in busy.items() if lr < r or (self.reads_first and lr == r)]:
                     free.append(busy.pop(s)[0])
                 for u in us:
                     if u.dst in self.phys and not u.dst.startswith(name + ".t"):
@@ -238,6 +285,87 @@ class Program:
 STATE_BOUNDS = {"X": 19, "Y": 19, "Z": 2, "ZZ": 2, "W": 2, "v0": 2, "v1": 2, "v2": 2}
 
 
+def name(f):
+    (k,) = f.keys()
+    return k
+
+
+def f_of(s):      # f = F0 + i F1 from the stored Karatsuba triple
+    return s["v0"] - s["v1"], s["v2"] - s["v0"] - s["v1"]
+
+
+def finish_f(b, F0, F1, cre, cim, so):
+    """f <- (F0 + i F1) * (cre + i cim) as the triple (F0*cre, F1*cim, (F0+F1)(cre+cim))."""
+    b.mul(F0, cre, out=name(so["v0"]))
+    b.mul(F1, cim, out=name(so["v1"]))
+    b.mul(F0 + F1, cre + cim, out=name(so["v2"]))
+
+
+def dbl(b, si, so, O, want_w=True):
+    """pairing.hpp miller_double: f <- f^2 * l_{V,V}(phi(B)), V <- 2V (Jacobian, a = 1), arranged three products
+    deep: X3 = M^2 - 2S is never an operand of a product here (Y3 takes M^2 and X*YY directly), the line takes
+    ZZ and W from the state.  O: the operand slots ax, ay, bx, by."""
+    bx, by = O["bx"], O["by"]
+    X, Y, Z, ZZ, Wq = si["X"], si["Y"], si["Z"], si["ZZ"], si["W"]
+    F0, F1 = f_of(si)
+    XX = b.mul(X, X)
+    YY = b.mul(Y, Y)
+    Z3 = b.mul(2 * Y, Z, out=name(so["Z"]))
+    g0 = b.mul(F0 + F1, F0 - F1)
+    g1h = b.mul(F0, F1)
+    ZZxB = b.mul(ZZ, bx)
+    ZZyB = b.mul(ZZ, by)
+    M = 3 * XX + Wq
+    M2 = b.mul(M, M)
+    XYY = b.mul(X, YY)
+    Y4 = b.mul(YY, YY)
+    cre = b.mul(M, ZZxB + X, E=-2 * YY)
+    cim = b.mul(Z3, ZZyB)                                            # (Z3 ZZ) yB
+    ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
+    b.lin(M2 - 8 * XYY, out=name(so["X"]))                           # M^2 - 2S, S = 4 X YY
+    b.mul(M, 12 * XYY - M2, E=-8 * Y4, out=name(so["Y"]))            # M (S - X3) - 8 YY^2
+    if want_w:
+        b.mul(ZZ3, ZZ3, out=name(so["W"]))
+    finish_f(b, g0, 2 * g1h, cre, cim, so)
+
+
+def add(sign, O):
+    ax, ay, bx, by = O["ax"], O["ay"], O["bx"], O["by"]
+
+    def build(b, si, so):
+        """pairing.hpp miller_add: f <- f * l_{V,sA}(phi(B)), V <- V + sA (mixed addition); ZZ comes with the
+        state, rr^2 and the line's rr*(xB + xA) are products of their own so that neither X3 nor cre sits on a
+        chain, and the new ZZ, W are made for the doubling that follows."""
+        X, Y, Z, ZZ = si["X"], si["Y"], si["Z"], si["ZZ"]
+        F0, F1 = f_of(si)
+        ysA = sign * ay
+        ZZZ = b.mul(ZZ, Z)
+        xZZ = b.mul(ax, ZZ)
+        yZ3 = b.mul(ysA, ZZZ)
+        rrr = yZ3 - Y
+        H = xZZ - X
+        Z3 = b.mul(Z, H, out=name(so["Z"]))
+        HH = b.mul(H, H)
+        HHH = b.mul(H, HH)
+        XHH = b.mul(X, HH)
+        rr2 = b.mul(rrr, rrr)
+        b.lin(rr2 - HHH - 2 * XHH, out=name(so["X"]))
+        YH = b.mul(b.mul(Y, H), HH)                                  # Y H^3 without waiting for H^3
+        b.mul(rrr, 3 * XHH + HHH - rr2, E=-YH, out=name(so["Y"]))    # rr (XHH - X3) - Y HHH
+        Z3y = b.mul(Z3, ysA)
+        T = b.mul(rrr, bx + ax)
+        cim = b.mul(Z3, by)
+        ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
+        b.mul(ZZ3, ZZ3, out=name(so["W"]))
+        finish_f(b, F0, F1, T - Z3y, cim, so)
+    return build
+
+
+def tab_line(b, t, which, O):
+    """Line of a table step at phi(C) = (ax, ay): (a'*xC + b') + i*yC  (fixedpair.hpp); cre < 3."""
+    return b.mul(t["ta%d" % which], O["ax"]) + t["tb%d" % which], O["ay"]
+
+
 def build_program(w=W, base=BASE):
     P = Program(w, base)
     # operands (canonical Montgomery, < p) and constants
@@ -257,77 +385,7 @@ def build_program(w=W, base=BASE):
     # kernel loads the next segment's into the other set while the current one runs
     tc = [{k: P.fixed("%s@%d" % (k, par), 1) for k in ("ta1", "tb1", "ta2", "tb2")} for par in (0, 1)]
 
-    def name(f):
-        (k,) = f.keys()
-        return k
-
-    def name(f):
-        (k,) = f.keys()
-        return k
-
-    def f_of(s):      # f = F0 + i F1 from the stored Karatsuba triple
-        return s["v0"] - s["v1"], s["v2"] - s["v0"] - s["v1"]
-
-    def finish_f(b, F0, F1, cre, cim, so):
-        """f <- (F0 + i F1) * (cre + i cim) as the triple (F0*cre, F1*cim, (F0+F1)(cre+cim))."""
-        b.mul(F0, cre, out=name(so["v0"]))
-        b.mul(F1, cim, out=name(so["v1"]))
-        b.mul(F0 + F1, cre + cim, out=name(so["v2"]))
-
-    def dbl(b, si, so, want_w=True):
-        """pairing.hpp miller_double: f <- f^2 * l_{V,V}(phi(B)), V <- 2V (Jacobian, a = 1), arranged three products
-        deep: X3 = M^2 - 2S is never an operand of a product here (Y3 takes M^2 and X*YY directly), the line takes
-        ZZ and W from the state."""
-        X, Y, Z, ZZ, Wq = si["X"], si["Y"], si["Z"], si["ZZ"], si["W"]
-        F0, F1 = f_of(si)
-        XX = b.mul(X, X)
-        YY = b.mul(Y, Y)
-        Z3 = b.mul(2 * Y, Z, out=name(so["Z"]))
-        g0 = b.mul(F0 + F1, F0 - F1)
-        g1h = b.mul(F0, F1)
-        ZZxB = b.mul(ZZ, bx)
-        ZZyB = b.mul(ZZ, by)
-        M = 3 * XX + Wq
-        M2 = b.mul(M, M)
-        XYY = b.mul(X, YY)
-        Y4 = b.mul(YY, YY)
-        cre = b.mul(M, ZZxB + X, E=-2 * YY)
-        cim = b.mul(Z3, ZZyB)                                            # (Z3 ZZ) yB
-        ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
-        b.lin(M2 - 8 * XYY, out=name(so["X"]))                           # M^2 - 2S, S = 4 X YY
-        b.mul(M, 12 * XYY - M2, E=-8 * Y4, out=name(so["Y"]))            # M (S - X3) - 8 YY^2
-        if want_w:
-            b.mul(ZZ3, ZZ3, out=name(so["W"]))
-        finish_f(b, g0, 2 * g1h, cre, cim, so)
-
-    def add(sign):
-        def build(b, si, so):
-            """pairing.hpp miller_add: f <- f * l_{V,sA}(phi(B)), V <- V + sA (mixed addition); ZZ comes with the
-            state, rr^2 and the line's rr*(xB + xA) are products of their own so that neither X3 nor cre sits on a
-            chain, and the new ZZ, W are made for the doubling that follows."""
-            X, Y, Z, ZZ = si["X"], si["Y"], si["Z"], si["ZZ"]
-            F0, F1 = f_of(si)
-            ysA = sign * ay
-            ZZZ = b.mul(ZZ, Z)
-            xZZ = b.mul(ax, ZZ)
-            yZ3 = b.mul(ysA, ZZZ)
-            rrr = yZ3 - Y
-            H = xZZ - X
-            Z3 = b.mul(Z, H, out=name(so["Z"]))
-            HH = b.mul(H, H)
-            HHH = b.mul(H, HH)
-            XHH = b.mul(X, HH)
-            rr2 = b.mul(rrr, rrr)
-            b.lin(rr2 - HHH - 2 * XHH, out=name(so["X"]))
-            YH = b.mul(b.mul(Y, H), HH)                                  # Y H^3 without waiting for H^3
-            b.mul(rrr, 3 * XHH + HHH - rr2, E=-YH, out=name(so["Y"]))    # rr (XHH - X3) - Y HHH
-            Z3y = b.mul(Z3, ysA)
-            T = b.mul(rrr, bx + ax)
-            cim = b.mul(Z3, by)
-            ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
-            b.mul(ZZ3, ZZ3, out=name(so["W"]))
-            finish_f(b, F0, F1, T - Z3y, cim, so)
-        return build
+    O = {"ax": ax, "ay": ay, "bx": bx, "by": by}
 
     # a NAF digit is followed by a zero, so the loop is a sequence of D (doubling) and DA+- (doubling, then the
     # addition of +-A) steps; DA is scheduled as ONE segment so that the addition's first products overlap the
@@ -335,13 +393,13 @@ def build_program(w=W, base=BASE):
     MID_BOUNDS = dict(STATE_BOUNDS)
     for par in (0, 1):
         si, so = st[par], st[1 - par]
-        P.segment("DBL%d" % par, lambda b, si=si, so=so: dbl(b, si, so))
+        P.segment("DBL%d" % par, lambda b, si=si, so=so: dbl(b, si, so, O))
         def dbl2(b, si=si, so=so, par=par):                      # two doubling steps in one schedule
             mid = {k: S("DD%d.%s" % (par, k)) for k in STATE_BOUNDS}
             for k, f in mid.items():
                 b.bound[name(f)] = MID_BOUNDS[k]
-            dbl(b, si, mid)
-            dbl(b, mid, so)
+            dbl(b, si, mid, O)
+            dbl(b, mid, so, O)
         P.segment("DD%d" % par, dbl2)
         for sign, nm in ((1, "DAP"), (-1, "DAM")):
             def dbladd(b, si=si, so=so, sign=sign, nm=nm, par=par):
@@ -349,29 +407,27 @@ def build_program(w=W, base=BASE):
                 for k, f in mid.items():
                     b.bound[name(f)] = MID_BOUNDS[k]
                 del mid["W"]                                     # the addition does not read it
-                dbl(b, si, mid, want_w=False)
-                add(sign)(b, mid, so)
+                dbl(b, si, mid, O, want_w=False)
+                add(sign, O)(b, mid, so)
             P.segment("%s%d" % (nm, par), dbladd)
 
     # ---- Miller loop over a normalised per-key line table (fixedpair.hpp miller_loop_fixed: makeL2, the level-1
     # decryption lift).  The evaluation point phi(C) sits in (ax, ay); a step's line is (a'*xC + b') + i*yC, so a
     # doubling step is f <- f^2 * l (six products, two rounds) and the addition that follows a non-zero digit one
     # more Karatsuba product with the next table entry (ten products, three rounds together).
-    def tab_line(b, t, which):
-        return b.mul(t["ta%d" % which], ax) + t["tb%d" % which], ay       # (cre, cim); cre < 3
     for par in (0, 1):
         si, so, t = st[par], st[1 - par], tc[par]
         def tdbl(b, si=si, so=so, t=t):
             F0, F1 = f_of(si)
-            cre, cim = tab_line(b, t, 1)
+            cre, cim = tab_line(b, t, 1, O)
             g0 = b.mul(F0 + F1, F0 - F1)
             g1h = b.mul(F0, F1)
             finish_f(b, g0, 2 * g1h, cre, cim, so)
         P.segment("TD%d" % par, tdbl)
         def tdbladd(b, si=si, so=so, t=t, par=par):
             F0, F1 = f_of(si)
-            cre, cim = tab_line(b, t, 1)
-            cre2, cim2 = tab_line(b, t, 2)
+            cre, cim = tab_line(b, t, 1, O)
+            cre2, cim2 = tab_line(b, t, 2, O)
             g0 = b.mul(F0 + F1, F0 - F1)
             g1h = b.mul(F0, F1)
             mid = {k: S("TDA%d.%s" % (par, k)) for k in ("v0", "v1", "v2")}
@@ -435,9 +491,100 @@ def build_program(w=W, base=BASE):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# The lane-group kernel's programs (csrc/quad/)
+# ---------------------------------------------------------------------------------------------------------------
+# Same formulas, scheduled for QUAD_W quads of lanes.  The quads of a pairing share a wave, so a round's reads all
+# precede its writes: the Miller state is updated IN PLACE (no second slot set), a temporary's slot is reused in the
+# round of its last read, and the two launches (Miller loop + norms; final exponentiation) have their own slot
+# numbering.  That brings a pairing's values down to what two workgroups per CU can hold in LDS (32 slots of
+# 4 lanes x M limbs each at a 1024-bit key), i.e. two waves per SIMD.
+def build_quad_programs(w=QUAD_W):
+    # ---- launch 1: Miller loop over the NAF of n, then F0^2, F1^2, F0*F1 ----
+    M = Program(w, w, reads_first=True)
+    O = {k: M.fixed(k, 1) for k in ("ax", "ay", "bx", "by")}
+    st = {k: M.fixed(k, b) for k, b in STATE_BOUNDS.items()}
+    new = {k: S(k + "'") for k in STATE_BOUNDS}
+    inplace = {k + "'": k for k in STATE_BOUNDS}
+
+    def declare_new(b, keys=STATE_BOUNDS):
+        for k in keys:
+            b.bound[k + "'"] = STATE_BOUNDS[k]
+
+    def seg_dbl(b):
+        declare_new(b)
+        dbl(b, st, new, O)
+    M.segment("DBL", seg_dbl, inplace)
+
+    def seg_dd(b):
+        declare_new(b)
+        mid = {k: S("DD.%s" % k) for k in STATE_BOUNDS}
+        for k, f in mid.items():
+            b.bound[name(f)] = STATE_BOUNDS[k]
+        dbl(b, st, mid, O)
+        dbl(b, mid, new, O)
+    M.segment("DD", seg_dd, inplace)
+    for sign, nm in ((1, "DAP"), (-1, "DAM")):
+        def seg_da(b, sign=sign, nm=nm):
+            declare_new(b)
+            mid = {k: S("%s.%s" % (nm, k)) for k in STATE_BOUNDS}
+            for k, f in mid.items():
+                b.bound[name(f)] = STATE_BOUNDS[k]
+            del mid["W"]
+            dbl(b, st, mid, O, want_w=False)
+            add(sign, O)(b, mid, new)
+        M.segment(nm, seg_da, inplace)
+    n1, n2, fm = (M.fixed(k, 2) for k in ("n1", "n2", "fm"))
+
+    def seg_norm(b):
+        F0, F1 = f_of(st)
+        b.mul(F0, F0, out="n1")
+        b.mul(F1, F1, out="n2")
+        b.mul(F0, F1, out="fm")
+    M.segment("NORM", seg_norm)
+    M.allocate_temps()
+    # ---- launch 2: h = conj(f)^2 / N(f), g = h^l, division by R ----
+    F = Program(w, w, reads_first=True)
+    n1, n2, fm = (F.fixed(k, 2) for k in ("n1", "n2", "fm"))
+    inv = F.fixed("inv", 4)                                              # R / N(f), from the inversion kernel
+    raw1 = F.fixed("raw1", 1)
+    h0, h1 = F.fixed("h0", 2), F.fixed("h1", 2)
+    r0, r1 = F.fixed("r0", 9), F.fixed("r1", 9)
+    out0, out1 = F.fixed("out0", 2), F.fixed("out1", 2)
+
+    def seg_h(b):
+        b.mul(n1 - n2, inv, out="h0")
+        b.mul(-2 * fm, inv, out="h1")
+        b.mul(n1 - n2, inv, out="r0")
+        b.mul(-2 * fm, inv, out="r1")
+    F.segment("H", seg_h)
+    rin = {"r0'": "r0", "r1'": "r1"}
+
+    def seg_lsq(b):
+        b.bound["r0'"], b.bound["r1'"] = 9, 9
+        b.mul(r0 + r1, r0 - r1, out="r0'")
+        b.mul(2 * r0, r1, out="r1'")
+    F.segment("LSQ", seg_lsq, rin)
+
+    def seg_lmu(b):
+        b.bound["r0'"], b.bound["r1'"] = 9, 9
+        t1 = b.mul(r1, h1)
+        t2 = b.mul(r0, h1)
+        b.mul(r0, h0, E=-t1, out="r0'")
+        b.mul(r1, h0, E=t2, out="r1'")
+    F.segment("LMU", seg_lmu, rin)
+
+    def seg_out(b):
+        b.mul(r0, raw1, out="out0")
+        b.mul(r1, raw1, out="out1")
+    F.segment("OUT", seg_out)
+    F.allocate_temps()
+    return M, F
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Emission
 # ---------------------------------------------------------------------------------------------------------------
-def emit(P, path, prefix="COOP", w=None, round_headers=False):
+def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, append=False):
     """Writes the tables as a C include.  prefix "COOP": the wave-cooperative kernel (one micro-op per wave);
     "QUAD": the lane-group kernel (csrc/quad/: one micro-op per quad of lanes, w = 4), which also gets one header
     word per round with what is uniform over its micro-ops (term counts, whether every operand is plain)."""
@@ -459,9 +606,10 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False):
     lines.append("#define %s_W %d" % (prefix, w))
     lines.append("#define %s_NSLOTS %d" % (prefix, P.nslots))
     lines.append("#define %s_MAX_TERMS %d" % (prefix, MAX_TERMS))
-    for gname in ("ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "ZZ@0", "W@0", "v0@0", "v1@0", "v2@0",
-                  "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1",
-                  "ta1@0", "tb1@0", "ta2@0", "tb2@0", "ta1@1", "tb1@1", "ta2@1", "tb2@1", "v0@1", "v1@1", "v2@1"):
+    for gname in slot_names or (
+            "ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "ZZ@0", "W@0", "v0@0", "v1@0", "v2@0",
+            "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1",
+            "ta1@0", "tb1@0", "ta2@0", "tb2@0", "ta1@1", "tb1@1", "ta2@1", "tb2@1", "v0@1", "v1@1", "v2@1"):
         lines.append("#define %s_SLOT_%s %d" % (prefix, gname.replace("@", "_").upper(), P.phys[gname]))
     lines.append("enum %sSeg {" % cap)
     for i, (name, _) in enumerate(P.segments):
@@ -490,7 +638,7 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False):
     for r, row in enumerate(rows):
         na_max = nb_max = ne_max = 0
         all_plain_a = all_plain_b = 1
-        any_mul = 0
+        any_mul = any_ka = any_kb = any_ke = 0
         for u in row:
             if u is None:
                 lines.append("  {0, 0, 0, 0, 0, 0, 0, 0},")
@@ -509,19 +657,41 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False):
             else:
                 all_plain_a = all_plain_b = 0
             ne_max = max(ne_max, ne)
+            any_ka |= int(u.KA != 0)
+            any_kb |= int(u.KB != 0)
+            any_ke |= int(u.KE != 0)
             w0 = (1 if u.kind == "mul" else 2) | plain(u.A, u.KA) << 8 | plain(u.B, u.KB) << 9 | P.phys[u.dst] << 16 | nb << 24
             words = [w0, pk([ne, u.KA, u.KB, u.KE]),
                      pk(ia), pk(ca), pk(ib), pk(cb), pk(ie), pk(ce)]
             lines.append("  {%s},   // r%d %s" % (", ".join("0x%08xu" % x for x in words), r, u.dst))
-        headers.append(na_max | nb_max << 4 | ne_max << 8 | all_plain_a << 12 | all_plain_b << 13 | any_mul << 14)
+        headers.append(na_max | nb_max << 4 | ne_max << 8 | all_plain_a << 12 | all_plain_b << 13 | any_mul << 14 |
+                       any_ka << 15 | any_kb << 16 | any_ke << 17)
     lines.append("};")
     if round_headers:
         lines.append("// one word per round: max terms of A | of B << 4 | of E << 8 | every A plain << 12 | every B plain << 13 | "
-                     "any product << 14")
-        lines.append("static __device__ const unsigned int k%sRound[%d] = {%s};" % (cap, rnd, ", ".join("0x%04xu" % h for h in headers)))
-    with open(path, "w") as f:
+                     "any product << 14 |")
+        lines.append("// a multiple of p in any A << 15 | in any B << 16 | in any E << 17")
+        lines.append("static __device__ const unsigned int k%sRound[%d] = {%s};" % (cap, rnd, ", ".join("0x%05xu" % h for h in headers)))
+    with open(path, "a" if append else "w") as f:
         f.write("\n".join(lines) + "\n")
     return seg_index
+
+
+QUAD_MILLER_SLOTS = ("ax", "ay", "bx", "by", "X", "Y", "Z", "ZZ", "W", "v0", "v1", "v2", "n1", "n2", "fm")
+QUAD_FINAL_SLOTS = ("n1", "n2", "fm", "inv", "raw1", "h0", "h1", "r0", "r1", "out0", "out1")
+
+
+def emit_quad(path, verbose=True):
+    """Both programs of the lane-group kernel into one include: QUADM (Miller loop + norms), QUADF (the rest of the
+    final exponentiation)."""
+    M, F = build_quad_programs()
+    emit(M, path, prefix="QUADM", round_headers=True, slot_names=QUAD_MILLER_SLOTS)
+    emit(F, path, prefix="QUADF", round_headers=True, slot_names=QUAD_FINAL_SLOTS, append=True)
+    if verbose:
+        for P in (M, F):
+            print(summary(P))
+            print("slots:", P.nslots, "->", path)
+    return M, F
 
 
 def summary(P):
@@ -541,9 +711,6 @@ if __name__ == "__main__":
     print(summary(P))
     print("slots:", P.nslots, "->", path)
     # the lane-group kernel (csrc/quad/): the same step programs scheduled for four quads of lanes per pairing
-    Q = build_program(QUAD_W, QUAD_W)
     qpath = os.path.join(root, "bgn_amd", "csrc", "quad", "quad_prog.inc")
     os.makedirs(os.path.dirname(qpath), exist_ok=True)
-    emit(Q, qpath, prefix="QUAD", round_headers=True)
-    print(summary(Q))
-    print("slots:", Q.nslots, "->", qpath)
+    emit_quad(qpath)

@@ -288,30 +288,85 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
     return out, dec
 
 
-def spawn_ranks(n, argv):
+def rank_command(argv):
+    """Command line of one rank process (the CPU tests substitute their own children)."""
+    return [sys.executable, os.path.abspath(__file__)] + list(argv)
+
+
+def run_cap_seconds():
+    """Wall-clock cap of one bench run (BGN_BENCH_TIMEOUT_S; 0 disables): a rank stuck in a collective — its peer
+    died, a rendezvous that never completes — must end the run with a non-zero exit instead of sitting there until
+    whoever launched it gives up."""
+    try:
+        return float(os.environ.get("BGN_BENCH_TIMEOUT_S", "2400"))
+    except ValueError:
+        return 2400.0
+
+
+def spawn_ranks(n, argv, timeout_s=None, poll_s=0.2):
     """--gpus N without a launcher: start N fresh rank processes of this script, one per GPU, before anything in
-    this process has touched the GPU (this parent never does), and return the worst exit code.  Rank 0 prints the
-    JSON line on the shared stdout."""
+    this process has touched the GPU (this parent never does).  All ranks are polled together: the first non-zero
+    exit, or the wall-clock cap, ends the others within seconds (a failed rank leaves its peers in an RCCL barrier
+    that never completes) and the run returns non-zero.  Rank 0 prints the JSON line on the shared stdout."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    cap = run_cap_seconds() if timeout_s is None else timeout_s
     procs = []
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        procs.append(subprocess.Popen(rank_command(argv), env=env))
+    t0 = time.monotonic()
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:                                  # a failed rank leaves the others at a barrier: end them
+    try:
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [(r, st) for r, st in enumerate(states) if st not in (None, 0)]
+            if bad:
+                rc = bad[0][1] if 0 < bad[0][1] < 256 else 1
+                print("bench.py: rank %d exited with %d; ending the other ranks" % bad[0], file=sys.stderr, flush=True)
+                break
+            if all(st == 0 for st in states):
+                break
+            if cap and time.monotonic() - t0 > cap:
+                rc = 124
+                print("bench.py: no result after %.0f s (BGN_BENCH_TIMEOUT_S); ending the ranks" % cap, file=sys.stderr,
+                      flush=True)
+                break
+            time.sleep(poll_s)
+    finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
     return rc
+
+
+def start_watchdog():
+    """Inside a rank (spawned here or by torch.distributed.run): the same cap, enforced from a daemon thread, so a
+    rank hung in a collective exits non-zero by itself."""
+    import threading
+    cap = run_cap_seconds()
+    if not cap:
+        return None
+
+    def fire():
+        print("bench.py: rank %s still running after %.0f s (BGN_BENCH_TIMEOUT_S): exiting" %
+              (os.environ.get("RANK", "0"), cap), file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(cap, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -341,6 +396,7 @@ def main():
         if args.gpus != world:
             sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N")
 
+    start_watchdog()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -381,36 +437,68 @@ def main():
     a = cts
     b = syn.permuted_copy(cts, EB, seed=5)
     out = torch.empty(count * EB, dtype=torch.uint8, device=dev)
-    gathered = None
+
+    def timed_region(step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---- the headline: weak scaling, 2^20 pairs per GPU ----
+    gathered = [None]
+    kernel_ms = []
 
     def step():
-        nonlocal gathered
         eng.mult_dev(a, b, out, count)
-        if use_dist:
-            gathered = gather_shards(out, total, EB, world, rank, dist)
-
-    kernel_ms = []
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
         kernel_ms.append(eng.last_kernel_ms())          # HIP events on the kernel's own stream
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        if use_dist:
+            gathered[0] = gather_shards(out, total, EB, world, rank, dist)
+
+    dt = timed_region(step, args.steps, args.warmup)
+    kernel_ms = kernel_ms[args.warmup:]
     kernel_name = eng.last_kernel_name()
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        assert bool((gathered[lo * EB:hi * EB] == out).all().item()), "gather mismatch"
+        assert bool((gathered[0][lo * EB:hi * EB] == out).all().item()), "gather mismatch"
+    gathered[0] = None
+
+    # ---- strong scaling: the SAME global batch of 2^20 pairs over the ranks (2^17 per GPU at 8 GPUs) ----
+    strong = None
+    if use_dist:
+        s_total = per_gpu
+        s_lo, s_hi = shard_range(s_total, world, rank)
+        s_cnt = s_hi - s_lo
+        s_out = torch.empty(s_cnt * EB, dtype=torch.uint8, device=dev)
+        s_ms = []
+
+        def s_step():
+            eng.mult_dev(a[: s_cnt * EB], b[: s_cnt * EB], s_out, s_cnt)
+            s_ms.append(eng.last_kernel_ms())
+            gathered[0] = gather_shards(s_out, s_total, EB, world, rank, dist)
+
+        s_dt = timed_region(s_step, args.steps, args.warmup)
+        assert bool((s_out == out[: s_cnt * EB]).all().item()), "strong-scaling shard differs from the weak-scaling result"
+        strong = {"metric": "EMult pairings/sec at 1024-bit, global batch=2^%d over %d GPU(s)" % (args.batch_log2, world),
+                  "value": s_total * args.steps / s_dt, "unit": "pairings/s", "scaling": "strong", "global_batch": s_total,
+                  "batch_per_gpu": s_cnt, "ms_per_step": s_dt / args.steps * 1e3, "kernel": eng.last_kernel_name(),
+                  "kernel_ms": sum(s_ms[args.warmup:]) / max(1, len(s_ms[args.warmup:]))}
+        gathered[0] = None
+        del s_out
 
     # prefix of this rank's batch for the CPU leg (not timed): 4096 distinct pairs
     nchk = min(count, 4096)
@@ -420,9 +508,14 @@ def main():
     distinct = len({a_h[i * EB:(i + 1) * EB] + b_h[i * EB:(i + 1) * EB] for i in range(nchk)})
 
     extra = dec = None
-    if not args.no_extra and world == 1 and args.key == "k1024" and args.batch_log2 == 20:
+    full = args.key == "k1024" and args.batch_log2 == 20
+    if not args.no_extra and world == 1 and not use_dist and full:
         extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2])
         extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
+    elif not args.no_extra and use_dist and args.key == "k1024":
+        # the second half of BASELINE's metric on every GPU: Decrypt shards exactly like Mult (bgn.go:205-250 is per
+        # ciphertext); plaintexts and statuses are gathered like the result arrays
+        dec = {args.batch_log2: decrypt_sharded(pk, fx, dev, cts, xs, world, rank, dist, timed_region, args)}
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -434,14 +527,16 @@ def main():
             fx, run=max(1, min(16, -(-count // 65536))),
             window={"0": 2, "3": 3, "4": 4}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 5))
         traffic, traffic_src = None, None
-        for name in ("r02_pmc_summary.json", "r01e_pmc_summary.json"):
+        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc) and args.batch_log2 == 20 and args.key == "k1024":
+            if os.path.exists(pmc) and full:
                 with open(pmc) as f:
                     traffic = json.load(f)["hbm_bytes_per_launch"]     # separate rocprofv3 --pmc passes of this command
                 traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)" % name
                 break
         mad_rate = mads * count / (k_ms * 1e-3)
+        if use_dist:
+            assert rccl_ranks == world == args.gpus, "RCCL world differs from --gpus"
         line = {
             "metric": "EMult pairings/sec at 1024-bit, batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -458,27 +553,90 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_pairing": alg_bytes},
+                         "algorithmic_bytes_per_pairing": alg_bytes, "note": "per GPU (rank 0's kernel)"},
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads, "achieved": mad_rate,
                               "unit": "lane-MAD/s",
                               "peak": VALU_MAD_PEAK_4W, "frac": mad_rate / VALU_MAD_PEAK_4W,
                               "peak_at_1_wave_per_simd": VALU_MAD_PEAK_1W,
                               "frac_at_1_wave_per_simd": mad_rate / VALU_MAD_PEAK_1W},
         }
+        if strong:
+            line["strong_2^%d" % args.batch_log2] = strong
         if dec:
             # BASELINE's metric names "EMult pairings/sec + BSGS decrypts/sec": the second headline
             top = dec.get(20) or dec[max(dec)]
-            line["decrypt"] = {"metric": "BSGS decrypts/sec at 1024-bit, T=2^40, batch=2^%d" % (20 if 20 in dec else max(dec)),
-                               **top}
-            for k, e in dec.items():
-                extra["decrypt" if k == 16 else "decrypt_2^%d" % k] = e
+            line["decrypt"] = {"metric": "BSGS decrypts/sec at 1024-bit, T=2^40, batch=2^%d%s" %
+                                         (20 if 20 in dec else max(dec), " per GPU" if use_dist else ""), **top}
+            if extra is not None:
+                for k, e in dec.items():
+                    extra["decrypt" if k == 16 else "decrypt_2^%d" % k] = e
         if extra:
             line["extra"] = extra
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
         print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()                                   # the other ranks wait for rank 0's CPU leg here
         dist.destroy_process_group()
+
+
+def decrypt_sharded(pk, fx, dev, cts, xs, world, rank, dist, timed_region, args):
+    """configs[3] on every rank: T = 2^40 BSGS Decrypt of this rank's batch (its Config-2 ciphertexts, every 16th
+    negated, every 4096th out of range), plaintexts and statuses gathered to every rank (9 bytes per ciphertext:
+    int64 + status, one RCCL all-gather).  Tables are per key and per GPU: every rank sets them up (not timed)."""
+    import torch
+    import bgn_amd
+    import bgn_amd.synthetic as syn
+    from bgn_amd.sharding import gather_shards
+    eng = pk.engine
+    EB = eng.elem_bytes
+    t0 = time.perf_counter()
+    pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    mixed, want, want_st = syn.decrypt_mix(pk, fx, cts, xs, dev)
+    n = cts.numel() // EB
+    total = n * world
+    m = torch.empty(n, dtype=torch.int64, device=dev)
+    st = torch.empty(n, dtype=torch.uint8, device=dev)
+    packed = torch.empty(n, 9, dtype=torch.uint8, device=dev)
+    got = [None]
+    lift_ms = []
+
+    def step():
+        eng.decrypt_dev(1, mixed, m, st, n)
+        lift_ms.append(eng.last_aux_kernel_ms())
+        packed[:, :8] = m.view(torch.uint8).reshape(n, 8)
+        packed[:, 8] = st
+        got[0] = gather_shards(packed.reshape(-1), total, 9, world, rank, dist)
+
+    dt = timed_region(step, args.steps, args.warmup)
+    ok = bool((m.cpu() == want[:n]).all().item()) and bool((st.cpu() == want_st[:n]).all().item())
+    mine = got[0].reshape(total, 9)[rank * n:(rank + 1) * n]
+    ok = ok and bool((mine == packed).all().item())
+    S = int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))
+    alg = EB + 16
+    k_ms = sum(lift_ms[args.warmup:]) / max(1, len(lift_ms[args.warmup:]))
+    e = op_rooflines(
+        {"value": total * args.steps / dt, "unit": "decrypts/s", "n_gpus": world, "batch": n, "global_batch": total, "level": 1,
+         "scaling": "weak", "ms_per_step": dt / args.steps * 1e3,
+         "workload": "configs[3]: T=2^40 BSGS Decrypt, batch=2^%d per GPU, m uniform in [0,2^40), 1/16 negative, 1/4096 "
+                     "out of range; sharded by ciphertext, plaintexts and statuses all-gathered (RCCL); baby table of %d "
+                     "entries per GPU" % (args.batch_log2, S),
+         "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
+        syn.decrypt_products(fx, S), 38)
+    # fractions are per GPU: the aggregate rate over the ranks against one chip's ceilings times the ranks
+    for key in ("frac_of_product_ceiling",):
+        if key in e:
+            e[key] /= world
+    if "hbm" in e:
+        e["hbm"]["achieved_GBps"] /= world
+        e["hbm"]["frac"] /= world
+    e["roofline"] = {"bound": "hbm", "achieved": alg * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": eng.last_aux_kernel_name(), "kernel_ms": k_ms, "algorithmic_bytes_per_decrypt": alg,
+                     "note": "per GPU (rank 0's lift kernel)"}
+    return e
 
 
 def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):

@@ -286,18 +286,7 @@ extern "C" {
 const char* bgn_last_error(void) { return g_err.c_str(); }
 // multi.cpp reports a shard's failure (raised on that shard's thread) to the calling thread through this
 void bgn_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
-// build-time options that put kept negative results back in (kernels_impl.hpp) show in the version string
-#ifdef BGN_WITH_VM
-#define BGN_VERSION_VM " +vm"
-#else
-#define BGN_VERSION_VM ""
-#endif
-#ifdef BGN_WITH_ADD_VARIANTS
-#define BGN_VERSION_ADDVAR " +addvar"
-#else
-#define BGN_VERSION_ADDVAR ""
-#endif
-const char* bgn_version(void) { return "bgn_amd 0.2 (gfx950)" BGN_VERSION_VM BGN_VERSION_ADDVAR; }
+const char* bgn_version(void) { return "bgn_amd 0.3 (gfx950)"; }
 
 size_t bgn_fp_bytes(const bgn_ctx* ctx) { return ctx ? (size_t)ctx->L : 0; }
 
@@ -679,12 +668,6 @@ static int pairing_run(size_t count) {
   return (int)r;
 }
 
-// 0: inlined step programs; 1: compact-code interpreter (BGN_PAIRING_VM=1 selects it)
-static int pairing_variant() {
-  const char* ev = getenv("BGN_PAIRING_VM");
-  return (ev && ev[0] == '1') ? 1 : 0;
-}
-
 static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
                          size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len);
 
@@ -698,6 +681,8 @@ static bool coop_table_walk(const bgn_ctx* c) {
   const char* ct = getenv("BGN_COOP_TABLE");
   return c->fixed_normalized && !(ct && ct[0] == '0');
 }
+
+static size_t quad_limit(const bgn_ctx* c);
 
 static size_t coop_limit(const bgn_ctx* c, int mode) {
   const char* ev = getenv(mode >= 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
@@ -716,21 +701,38 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // kernels walk P's line table): 1024 bits — 8192: 52.5 against 54.3 ms, 16384: 103 against 54; 512 bits —
   // 4096: 8.7 against 10.6 ms, 8192: 16.7 against 10.6 (general cooperative program: 3000 / 1800).
   if (mode == 1) return tw ? (c->nl >= 38 ? 8000 : c->nl >= 19 ? 4800 : 2048) : (c->nl >= 38 ? 3000 : c->nl >= 19 ? 1800 : 1024);
+  // Mult: with the lane-group kernel above it (profiles/r03_mid_batch.csv: 1024 pairs 17.8 ms cooperative against
+  // 21.2 ms, 1536: 25.1 against 21.3 at 1024 bits; 512 bits: 1024 pairs 5.3 against 5.2 ms) the crossover is where
+  // that kernel's one-round time is reached; without it, the lane kernel's (r02_small_batch.csv)
+  if (quad_limit(c)) return c->nl >= 38 ? 1280 : c->nl >= 19 ? 1000 : 800;
   return c->nl >= 38 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
 // Between the cooperative kernel's saturation and one pairing per lane filling the chip sits the lane-group kernel
-// (quad/quad.hpp: sixteen lanes per pairing, 4096 pairings put one wave on every SIMD): Mult and MultPoly's
-// coefficient pairs above coop_limit and up to this many pairs.  BGN_QUAD_MAX overrides (0 disables the kernel),
-// BGN_QUAD_MIN moves the lower end (default: the cooperative crossover of the key size).
+// (quad/quad.hpp: sixteen lanes per pairing; 4096 pairings put one wave on every SIMD, two workgroups share a CU):
+// Mult and MultPoly's coefficient pairs above coop_limit and up to quad_limit pairs, from the committed sweep
+// profiles/r03_mid_batch.csv (MI355X, 1024 bits: 4096 pairs 21.5 ms, 16384 63.9 ms, 40960 153 ms against 166 ms
+// for ANY count up to 65536 on the lane kernel, 1024 pairs 21.2 ms against 17.8 ms cooperative; 512 bits: 4096
+// pairs 5.2 ms, 32768 23.5 ms against 28.7 ms, 1024 pairs 5.2 against 5.3 ms).  A lane of the lane kernel takes a
+// second pairing from 65537 pairs on, so the lane-group kernel also wins a stretch above 65536 at 1024 bits
+// (81920 pairs: 301 against 333 ms).  BGN_QUAD_MAX overrides the upper end (0 disables the kernel), BGN_QUAD_MIN
+// the lower one.
 static size_t quad_limit(const bgn_ctx* c) {
   if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
-  return c->nl >= 38 ? 40000 : c->nl >= 19 ? 24000 : c->nl >= 10 ? 16384 : 0;
+  if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
+  return c->nl >= 38 ? 44000 : c->nl >= 19 ? 40000 : 32768;
 }
 static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
   size_t lo = coop_max;
   if (const char* ev = getenv("BGN_QUAD_MIN")) lo = (size_t)strtoull(ev, nullptr, 10);
-  return count > lo && count <= quad_limit(c) && quad_ws_words(c->nl, 64) != 0;
+  // BGN_COOP_MAX alone keeps the meaning it had before this kernel existed (the A/B switch between the cooperative
+  // and the lane kernel: 0 = lane kernel always)
+  if (getenv("BGN_COOP_MAX") && !getenv("BGN_QUAD_MAX") && !getenv("BGN_QUAD_MIN")) return false;
+  const size_t hi = quad_limit(c);
+  if (!hi || count <= lo || quad_ws_words(c->nl, 64) == 0) return false;
+  if (count <= hi) return true;
+  // the second window: between one and two pairings per lane of the lane kernel (default limits only)
+  return !getenv("BGN_QUAD_MAX") && c->nl >= 38 && count > 65536 && count <= 88000;
 }
 
 // Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with
@@ -803,7 +805,7 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
     c->last_kernel = coop_pairing_kernel_name(c->nl);
   } else {
     kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
-                (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : pairing_variant());
+                (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : 0);
     c->last_kernel = kt->pairing_kernel_name;
   }
   HIP_TRY(hipEventRecord(c->ev1, s));
@@ -1367,57 +1369,6 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   const size_t st = round_up(count, 64);
   SoA2 A, B, O, T1, T2;
   uint32_t* prefix = nullptr;
-  // BGN_ADD_FUSED=1: level 1 without blinding as ONE kernel from wire bytes to wire bytes (k_g1_add_wire; only
-  // the prefix products of the shared inversions go through the workspace).  Measured on MI355X at 2^19
-  // additions it moves 2.2x fewer bytes but runs at 2.9e8 adds/s against 3.8e8 for the decode / add / encode
-  // launches: the lanes pick their operands out of the LDS stage byte by byte, and with a run of additions per
-  // lane sharing one inversion they have to do so twice (prefix pass, peel pass).  Kept as an opt-in variant.
-  bool fused = false;
-  if (const char* ev = getenv("BGN_ADD_FUSED"))
-    fused = ev[0] == '1' && level == 1 && !r_be && c->kt->g1_add_wire;   // built with -DBGN_WITH_ADD_VARIANTS only
-  if (fused) {
-    Ws w0(c, nullptr);
-    w0.fp(st);
-    int rc = ensure_arena(c, w0.cv.off);
-    if (rc) return rc;
-    Ws w(c, c->arena);
-    prefix = w.fp(st);
-    HIP_TRY(hipEventRecord(c->ev0, s));
-    c->kt->g1_add_wire(s, c->d_params, c->d_consts, a, b, out, c->L, count, run_for(count), subtract ? 1 : 0, prefix, st);
-    HIP_TRY(hipEventRecord(c->ev1, s));
-    c->last_kernel = "k_g1_add_wire";
-    c->ev_valid = true;
-    HIP_TRY(hipGetLastError());
-    return BGN_OK;
-  }
-  // BGN_ADD_SPLIT=1: level 1 without blinding as two launches split at the inversion (front: stage, decode, prefix
-  // products, inversion; back: peel, add, encode), every operand decoded once.  Measured 2.5 ms per 2^20 additions
-  // against 2.0 ms for decode / decode / k_g1_add / encode: with one workgroup per CU the staging copies of a
-  // round sit behind its barriers with nothing to overlap them, while the stand-alone decode kernels overlap
-  // each other's.  Opt-in like BGN_ADD_FUSED, and like it compiled only with -DBGN_WITH_ADD_VARIANTS.
-  {
-    const char* ev = getenv("BGN_ADD_SPLIT");
-    if (level == 1 && !r_be && ev && ev[0] == '1' && c->kt->g1_add_split) {
-      const int run = run_for(count);
-      const size_t lanes = round_up((count + (size_t)run - 1) / (size_t)run, 256);
-      uint32_t* inv = nullptr;
-      for (int pass = 0; pass < 2; ++pass) {
-        Ws w(c, pass ? c->arena : nullptr);
-        A = w.g1(st); B = w.g1(st); prefix = w.fp(st); inv = w.fp(lanes);
-        if (!pass) {
-          int rc = ensure_arena(c, w.cv.off);
-          if (rc) return rc;
-        }
-      }
-      HIP_TRY(hipEventRecord(c->ev0, s));
-      c->kt->g1_add_split(s, c->d_params, c->d_consts, a, b, out, c->L, count, run, subtract ? 1 : 0, A, B, prefix, st, inv);
-      HIP_TRY(hipEventRecord(c->ev1, s));
-      c->last_kernel = "k_g1_add_front+back";
-      c->ev_valid = true;
-      HIP_TRY(hipGetLastError());
-      return BGN_OK;
-    }
-  }
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     if (level == 1) {
@@ -2144,7 +2095,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
                                            c->p_bits + 1)) {
     } else {
       kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(pairs), pws, sp, nullptr, 0,
-                  pairing_variant());
+                  0);
     }
     kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, pairs);
     PolyAccArgs pa;

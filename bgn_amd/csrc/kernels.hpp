@@ -208,7 +208,7 @@ struct KernelTable {
   void (*pairing)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                   size_t count, int mode, size_t d1, size_t d2, int run, uint32_t* ws, size_t sw,
                   const uint32_t* fixed_tab, size_t tab_stride,
-                  int variant /* 0: inlined step programs, 1: interpreter (vm.hpp) */);
+                  int variant /* bit 1 with a key table: the table is normalised */);
   // builds the line table of e(P, .) : 3*NL u32 per Miller step (px, py canonical Montgomery, stride 1)
   void (*fixedpair_build)(hipStream_t s, const void* params, const PairingConsts* consts, const uint32_t* px,
                           const uint32_t* py, uint32_t* tab);
@@ -251,15 +251,6 @@ struct KernelTable {
   // plain canonical SoA
   void (*field_ops)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
                     SoA2 prod_inv, SoA2 sqr);
-  // level-1 Add / Sub from wire bytes to wire bytes in one kernel (kernels_impl.hpp k_g1_add_wire); prefix:
-  // count F_p of workspace with limb stride sp; the grid covers ceil(count / run) lanes
-  void (*g1_add_wire)(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a, const uint8_t* b,
-                      uint8_t* out, int L, size_t count, int run, int negate_b, uint32_t* prefix, size_t sp);
-  // the same in two launches split at the inversion (k_g1_add_front / k_g1_add_back): A, B SoA workspaces for the
-  // decoded coordinates, inv: NL * lanes words with lanes = ceil(ceil(count / run) / 256) * 256
-  void (*g1_add_split)(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a, const uint8_t* b,
-                       uint8_t* out, int L, size_t count, int run, int negate_b, SoA2 A, SoA2 B, uint32_t* prefix, size_t sp,
-                       uint32_t* inv);
 };
 
 const KernelTable* kernel_table_nl3();

@@ -7,9 +7,6 @@
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
 #include "polyops.hpp"
-#ifdef BGN_WITH_VM      // the compact-code interpreter: a kept negative result (22 % slower), opt-in at build time
-#include "vm.hpp"
-#endif
 
 namespace bgn {
 
@@ -175,8 +172,7 @@ __device__ __forceinline__ size_t pair_index(PairOperands& op, size_t e, int mod
 // parks f and the prefix product of the norms in the workspace; one Fermat inversion per lane; pass 2
 // peels 1/N(f_j) off and finishes the exponentiation.  ws: 3 F_p per element (F0, F1, prefix), plus 4 more
 // win_slots(w) for the windowed Miller loop of VARIANT 0: (3 + win_slots(w)) * NL * sw u32 in all.
-// VARIANT 0: inlined step programs (pairing.hpp); 1: key-constant first argument (fixedpair.hpp);
-// 2: compact-code interpreter (vm.hpp)
+// VARIANT 0: inlined step programs (pairing.hpp); 1: key-constant first argument (fixedpair.hpp)
 template <int NL, int VARIANT>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out,
@@ -207,10 +203,6 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     const size_t te = pair_index(op, e, mode, d1, d2);
     if (VARIANT == 1)
       miller_loop_fixed<NL>(S, L, op, fixed_tab, tab_stride, te, tab_normalized != 0, C, P);
-#ifdef BGN_WITH_VM
-    else if (VARIANT == 2)
-      miller_loop_vm<NL>(S, L, op, C, P);
-#endif
     else if (ws && C->wnaf_len > 0) {
       // windowed loop; its per-pairing table (dA, f_d) lives behind the three run arrays of ws
       WinTab W{ws + (size_t)3 * NL * sw, sw, e};
@@ -556,12 +548,6 @@ static void launch_pairing(hipStream_t s, const void* params, const PairingConst
     hipLaunchKernelGGL((k_pairing<NL_, 1>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, fixed_tab,
                        mode == 1 ? (size_t)1 : tab_stride, (mode == 1 && (variant & 2)) ? 1 : 0);
-#ifdef BGN_WITH_VM
-  else if (variant == 1)
-    hipLaunchKernelGGL((k_pairing<NL_, 2>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
-                       (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
-                       (size_t)0, 0);
-#endif
   else
     hipLaunchKernelGGL((k_pairing<NL_, 0>), dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s,
                        (const FpParams<NL_>*)params, consts, a, b, out, count, mode, d1, d2, run, ws, sw, nullptr,
@@ -825,240 +811,6 @@ k_field_ops(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire
   g_store<NL>(sqr.c1, sqr.stride, e, o);
 }
 
-#ifdef BGN_WITH_ADD_VARIANTS   // two kept negative results (measured slower than decode / k_g1_add / encode): opt-in at build time
-// ---- EAdd / ESub on level 1, wire bytes to wire bytes in ONE kernel (bgn.go:482, :419) ------------------------
-// The workgroup stages its 256 consecutive elements of a round between HBM and LDS with coalesced dword accesses
-// (codec.hpp), the lanes pick their operands out of LDS, add on plain residues (ops.hpp g1_add_run, PLAIN) and put
-// the sums back through the same stage: no SoA copy of operands or sums in HBM, no separate decode / encode
-// launches.  A lane still owns `run` elements (e = j*T + t) and shares one inversion among them, so the operands
-// are read twice (prefix pass, peel pass) and one F_p per element of prefix products goes through HBM:
-// 2*2*2L + 2*4*NL + 2L bytes per addition against 3*2L algorithmic.
-template <int NL>
-struct WireOperands {
-  Fp<NL> x1, y1, x2, y2;
-  bool i1, i2;
-};
-
-// Stage and decode the operands of round j for this workgroup.  Block-uniform control flow (barriers inside).
-template <int NL>
-__device__ __forceinline__ void g1_wire_load(WireOperands<NL>& o, WireStage<NL>* ws, const uint8_t* __restrict__ a,
-                                             const uint8_t* __restrict__ b, size_t e0, size_t nel, int L, int negate_b,
-                                             const FpParams<NL>* __restrict__ P) {
-  const size_t EB = (size_t)(2 * L);
-  const bool mine = threadIdx.x < nel;
-  u32 mis = wire_stage_in<NL>(ws, a + e0 * EB, nel * EB);
-  if (mine) {
-    if (mis == 0 && L >= 4) {
-      wire_element_dw<NL>(o.x1, o.y1, ws->w, threadIdx.x, L);
-    } else {
-      const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
-      wire_to_limbs<NL>(o.x1, src, L);
-      wire_to_limbs<NL>(o.y1, src + L, L);
-    }
-  }
-  __syncthreads();
-  mis = wire_stage_in<NL>(ws, b + e0 * EB, nel * EB);
-  if (mine) {
-    if (mis == 0 && L >= 4) {
-      wire_element_dw<NL>(o.x2, o.y2, ws->w, threadIdx.x, L);
-    } else {
-      const uint8_t* src = (const uint8_t*)ws->w + mis + threadIdx.x * EB;
-      wire_to_limbs<NL>(o.x2, src, L);
-      wire_to_limbs<NL>(o.y2, src + L, L);
-    }
-  }
-  __syncthreads();
-  if (!mine) {
-    fp_zero(o.x1); fp_zero(o.y1); fp_zero(o.x2); fp_zero(o.y2);
-  }
-  o.i1 = fp_is_zero_limbs(o.x1) && fp_is_zero_limbs(o.y1);
-  o.i2 = fp_is_zero_limbs(o.x2) && fp_is_zero_limbs(o.y2);
-  if (negate_b) {
-    fp_neg<1>(o.y2, o.y2, P);
-    fp_reduce8(o.y2, o.y2, P);                  // p - 0 = p -> 0
-  }
-}
-
-// One element of the peel pass on plain residues: its inverse off the running inverse, the sum, canonical, into
-// the lane's place in the output stage (the slice goes to `g`).
-template <int NL>
-__device__ __forceinline__ void g1_wire_peel(const WireOperands<NL>& o, Fp<NL>& inv, const u32* __restrict__ prefix, size_t sp,
-                                             size_t e, LFp<NL>* L, const FpParams<NL>* __restrict__ P, WireStage<NL>* ws,
-                                             const uint8_t* g, int L_) {
-  const size_t EB = (size_t)(2 * L_);
-  Fp<NL> d;
-  const int cs = g1_classify<NL, true>(d, o.x1, o.y1, o.i1, o.x2, o.y2, o.i2, P);
-  Fp<NL> dinv;
-  {
-    Fp<NL> pf;
-    g_load(pf, prefix, sp, e);
-    l_store(L, inv);
-    fp_mul(dinv, L, pf, P);                 // R^2/d <2
-    fp_mul(inv, L, d, P);                   // inverse of the shorter prefix <2
-  }
-  Fp<NL> num;
-  fp_sub<1>(num, o.y2, o.y1, P);            // <2
-  if (__ballot(cs == G1C_DBL)) {            // doubling numerator 3*x1^2 + 1 (rare)
-    Fp<NL> xx, t3, one;
-    fp_to_mont<NL>(t3, o.x1, P, L + 1);
-    fp_mulv(xx, t3, o.x1, P, L + 1);        // x1^2, plain <2
-    fp_dbl(t3, xx);
-    fp_add(t3, t3, xx);                     // <6
-    fp_zero(one);
-    one.v[0] = 1;
-    fp_add(t3, t3, one);                    // <7
-    fp_select(num, cs == G1C_DBL, t3, num);
-  }
-  l_store(L + 1, dinv);
-  Fp<NL> lam, lp, x3, y3;
-  fp_mul(lam, L + 1, num, P);               // lambda*R <2
-  fp_from_mont<NL>(lp, lam, P, L + 1);      // lambda, plain <1 ; L1 = lambda*R
-  fp_mul(x3, L + 1, lp, P);                 // lambda^2, plain <2
-  fp_sub<1>(x3, x3, o.x1, P);               // <3
-  fp_sub<1>(x3, x3, o.x2, P);               // <4
-  fp_sub<4>(y3, o.x1, x3, P);               // <5
-  fp_mul(y3, L + 1, y3, P);                 // <2
-  fp_sub<1>(y3, y3, o.y1, P);               // <3
-  const bool isA = cs == G1C_A, isB = cs == G1C_B;
-  fp_select(x3, isA, o.x1, x3);
-  fp_select(y3, isA, o.y1, y3);
-  fp_select(x3, isB, o.x2, x3);
-  fp_select(y3, isB, o.y2, y3);
-  Fp<NL> ox, oy;
-  fp_reduce8(ox, x3, P);
-  fp_reduce8(oy, y3, P);
-  if (cs == G1C_INF) {
-    fp_zero(ox);
-    fp_zero(oy);
-  }
-  if (codec_dword_ok(L_, (u32)((uintptr_t)g & 3u))) {
-    limbs_to_wire_dw<NL>(ws->w + threadIdx.x * (u32)(EB / 4), L_, ox, oy);
-  } else {
-    uint8_t* dst = (uint8_t*)ws->w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
-    limbs_to_wire<NL>(dst, L_, ox);
-    limbs_to_wire<NL>(dst + L_, L_, oy);
-  }
-}
-
-template <int NL>
-__global__ void __launch_bounds__(FP_BLOCK)
-k_g1_add_wire(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, const uint8_t* __restrict__ a,
-              const uint8_t* __restrict__ b, uint8_t* __restrict__ out, int L_, size_t count, int run, int negate_b,
-              u32* __restrict__ prefix, size_t sp) {
-  __shared__ LFp<NL> L[2];
-  __shared__ WireStage<NL> ws;
-  const size_t T = (size_t)gridDim.x * FP_BLOCK;
-  const size_t EB = (size_t)(2 * L_);
-  Fp<NL> acc;
-  fp_set(acc, P->one);
-  // pass 1: prefix products of the denominators (acc_0 = R: see g1_add_run on the PLAIN representation)
-#pragma unroll 1
-  for (int j = 0; j < run; ++j) {
-    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
-    if (e0 >= count) break;                                        // block-uniform
-    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
-    WireOperands<NL> o;
-    g1_wire_load<NL>(o, &ws, a, b, e0, nel, L_, negate_b, P);
-    if (threadIdx.x < nel) {
-      Fp<NL> d;
-      g1_classify<NL, true>(d, o.x1, o.y1, o.i1, o.x2, o.y2, o.i2, P);
-      g_store(prefix, sp, e0 + threadIdx.x, acc);
-      l_store(L, acc);
-      fp_mul(acc, L, d, P);                     // <2
-    }
-  }
-  Fp<NL> inv;
-  fp_inv<NL>(inv, acc, L, C, P);                // <1
-  // pass 2: walk back, peel one inverse per element, write the sums as wire bytes
-#pragma unroll 1
-  for (int j = run - 1; j >= 0; --j) {
-    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
-    if (e0 >= count) continue;                                     // block-uniform
-    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
-    WireOperands<NL> o;
-    g1_wire_load<NL>(o, &ws, a, b, e0, nel, L_, negate_b, P);
-    uint8_t* g = out + e0 * EB;
-    if (threadIdx.x < nel) g1_wire_peel<NL>(o, inv, prefix, sp, e0 + threadIdx.x, L, P, &ws, g, L_);
-    wire_stage_out<NL>(&ws, g, nel * EB);
-    __syncthreads();
-  }
-}
-
-// ---- level-1 Add / Sub in two launches --------------------------------------------------------------------
-// k_g1_add_wire pays for its one launch by staging and decoding every operand twice.  Split at the inversion,
-// the operands are decoded once: the FRONT kernel stages and decodes a round's two slices, keeps the prefix
-// products of the denominators (pass 1 of g1_add_run), leaves the coordinates as SoA limbs for the peel pass
-// and ends with the lane's inversion; the BACK kernel peels, adds and writes wire bytes through the stage.
-// Against decode / decode / k_g1_add / encode: the same seven products per addition, two launches instead of four,
-// no SoA read in pass 1, no SoA write + read of the sums, no encode launch.
-template <int NL>
-__global__ void __launch_bounds__(FP_BLOCK)
-k_g1_add_front(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, const uint8_t* __restrict__ a,
-               const uint8_t* __restrict__ b, int L_, size_t count, int run, int negate_b, SoA2 A, SoA2 B,
-               u32* __restrict__ prefix, size_t sp, u32* __restrict__ inv_out) {
-  __shared__ LFp<NL> L[2];
-  __shared__ WireStage<NL> ws;
-  const size_t T = (size_t)gridDim.x * FP_BLOCK;
-  Fp<NL> acc;
-  fp_set(acc, P->one);
-#pragma unroll 1
-  for (int j = 0; j < run; ++j) {
-    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
-    if (e0 >= count) break;                                        // block-uniform
-    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
-    WireOperands<NL> o;
-    g1_wire_load<NL>(o, &ws, a, b, e0, nel, L_, negate_b, P);
-    if (threadIdx.x < nel) {
-      const size_t e = e0 + threadIdx.x;
-      Fp<NL> d;
-      g1_classify<NL, true>(d, o.x1, o.y1, o.i1, o.x2, o.y2, o.i2, P);
-      g_store(A.c0, A.stride, e, o.x1);
-      g_store(A.c1, A.stride, e, o.y1);
-      g_store(B.c0, B.stride, e, o.x2);
-      g_store(B.c1, B.stride, e, o.y2);                            // already negated for a subtraction
-      g_store(prefix, sp, e, acc);
-      l_store(L, acc);
-      fp_mul(acc, L, d, P);                     // <2
-    }
-  }
-  Fp<NL> inv;
-  fp_inv<NL>(inv, acc, L, C, P);                // <1
-  g_store(inv_out, T, (size_t)blockIdx.x * FP_BLOCK + threadIdx.x, inv);
-}
-
-template <int NL>
-__global__ void __launch_bounds__(FP_BLOCK)
-k_g1_add_back(const FpParams<NL>* __restrict__ P, SoA2 A, SoA2 B, const u32* __restrict__ prefix, size_t sp,
-              const u32* __restrict__ inv_in, uint8_t* __restrict__ out, int L_, size_t count, int run) {
-  __shared__ LFp<NL> L[2];
-  __shared__ WireStage<NL> ws;
-  const size_t T = (size_t)gridDim.x * FP_BLOCK;
-  const size_t EB = (size_t)(2 * L_);
-  Fp<NL> inv;
-  g_load(inv, inv_in, T, (size_t)blockIdx.x * FP_BLOCK + threadIdx.x);
-#pragma unroll 1
-  for (int j = run - 1; j >= 0; --j) {
-    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
-    if (e0 >= count) continue;                                     // block-uniform
-    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
-    uint8_t* g = out + e0 * EB;
-    if (threadIdx.x < nel) {
-      const size_t e = e0 + threadIdx.x;
-      WireOperands<NL> o;
-      g_load(o.x1, A.c0, A.stride, e);
-      g_load(o.y1, A.c1, A.stride, e);
-      g_load(o.x2, B.c0, B.stride, e);
-      g_load(o.y2, B.c1, B.stride, e);
-      o.i1 = fp_is_zero_limbs(o.x1) && fp_is_zero_limbs(o.y1);
-      o.i2 = fp_is_zero_limbs(o.x2) && fp_is_zero_limbs(o.y2);
-      g1_wire_peel<NL>(o, inv, prefix, sp, e, L, P, &ws, g, L_);
-    }
-    wire_stage_out<NL>(&ws, g, nel * EB);
-    __syncthreads();
-  }
-}
-
-#endif  // BGN_WITH_ADD_VARIANTS
 
 static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
                              SoA2 prod_inv, SoA2 sqr) {
@@ -1067,29 +819,6 @@ static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* w
                      count, p_bits, prod_inv, sqr);
 }
 
-#ifdef BGN_WITH_ADD_VARIANTS
-static void launch_g1_add_wire(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a,
-                               const uint8_t* b, uint8_t* out, int L, size_t count, int run, int negate_b,
-                               uint32_t* prefix, size_t sp) {
-  if (!count) return;
-  const size_t lanes = (count + run - 1) / run;
-  hipLaunchKernelGGL(k_g1_add_wire<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts,
-                     a, b, out, L, count, run, negate_b, prefix, sp);
-}
-
-// level-1 Add / Sub, wire bytes to wire bytes, as front + back kernels; A, B: SoA workspaces of the coordinates,
-// inv: NL words per lane of the launch (grid_for(lanes) * FP_BLOCK lanes, limb stride = that lane count).
-static void launch_g1_add_split(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a,
-                                const uint8_t* b, uint8_t* out, int L, size_t count, int run, int negate_b, SoA2 A, SoA2 B,
-                                uint32_t* prefix, size_t sp, uint32_t* inv) {
-  if (!count) return;
-  const size_t lanes = (count + run - 1) / run;
-  hipLaunchKernelGGL(k_g1_add_front<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts,
-                     a, b, L, count, run, negate_b, A, B, prefix, sp, inv);
-  hipLaunchKernelGGL(k_g1_add_back<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, A, B,
-                     prefix, sp, inv, out, L, count, run);
-}
-#endif
 
 const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {
@@ -1126,13 +855,6 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_poly_combine,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
       launch_field_ops,
-#ifdef BGN_WITH_ADD_VARIANTS
-      launch_g1_add_wire,
-      launch_g1_add_split,
-#else
-      nullptr,
-      nullptr,
-#endif
   };
   return &t;
 }

@@ -14,7 +14,6 @@ thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 
 #include "bsgs.hpp"
 #include "fixedpair.hpp"
 #include "polyops.hpp"
-#include "vm.hpp"
 #include "fpinv.hpp"
 
 using namespace bgn;
@@ -117,22 +116,6 @@ struct Emu {
     WinTab W{win, 1, 0};
     Miller<NL> S;
     miller_loop_w<NL>(S, L, op, W, C, P);
-    Fp<NL> N, ninv, g0, g1, re, im;
-    miller_norm<NL>(N, S, L, P);
-    l_store(L + 1, N);
-    fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);
-    final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
-    fp_from_mont<NL>(im, g1, P, L);
-    fp_from_mont<NL>(re, g0, P, L);
-    memcpy(out, re.v, 4 * NL);
-    memcpy(out + NL, im.v, 4 * NL);
-  }
-  static void pairing_vm(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
-    const FpParams<NL>* P = (const FpParams<NL>*)params;
-    LFp<NL>* L = lds();
-    PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};
-    Miller<NL> S;
-    miller_loop_vm<NL>(S, L, op, C, P);
     Fp<NL> N, ninv, g0, g1, re, im;
     miller_norm<NL>(N, S, L, P);
     l_store(L + 1, N);
@@ -434,7 +417,6 @@ int emu_poly_lin(int nl, const u32* params, const void* C, int level, const u32*
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab, size_t ts, size_t te) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab, ts, te)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, int normalized, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, normalized, c, out)) }
 int emu_fixed_normalize(int nl, const u32* params, const void* C, u32* tab, size_t steps) { DISPATCH(nl, fixed_normalize(params, (const PairingConsts*)C, tab, steps)) }
-int emu_pairing_vm(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_vm(params, (const PairingConsts*)C, a, b, out)) }
 int emu_fp_inv(int nl, const u32* params, int p_bits, const u32* a, u32* out) { DISPATCH(nl, fp_inv(params, p_bits, a, out)) }
 int emu_gt_tab_build(int nl, const u32* params, int wbits, int windows, const u32* g, u32* tab) { DISPATCH(nl, gt_tab_build(params, wbits, windows, g, tab)) }
 int emu_gt_fixed(int nl, const u32* params, const u32* tab, int wbits, const uint8_t* k, size_t klen, const u32* R, u32* out) { DISPATCH(nl, gt_fixed(params, tab, wbits, k, klen, R, out)) }

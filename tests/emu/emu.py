@@ -18,7 +18,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "vm.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
+                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"), "-include", os.path.join(_HERE, "imad.hpp"),
@@ -136,15 +136,6 @@ class Emu:
         B, _ = self.decode(b)
         out = (C.c_uint32 * (2 * self.nl))()
         assert self.lib.emu_pairing_w3(self.nl, self.params, self.consts, A, B, out) == 0
-        return self.encode(out)
-
-    def pairing_vm(self, a: bytes, b: bytes) -> bytes:
-        A, ia = self.decode(a)
-        B, ib = self.decode(b)
-        out = (C.c_uint32 * (2 * self.nl))()
-        assert self.lib.emu_pairing_vm(self.nl, self.params, self.consts, A, B, out) == 0
-        if ia or ib:
-            return (1).to_bytes(self.L, "big") + bytes(self.L)
         return self.encode(out)
 
     def fixed_table(self, P_wire: bytes, ts: int = 1, te: int = 0, tab=None):

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 BENCH = os.path.join(ROOT, "bench.py")
@@ -25,56 +27,85 @@ def test_gpus_must_equal_the_launchers_world_size():
     assert "--gpus 2 but WORLD_SIZE=3" in (r.stderr + r.stdout)
 
 
-def test_spawn_starts_n_fresh_ranks_with_the_rendezvous_environment(monkeypatch):
+def _children(monkeypatch, bench, script):
+    """Real child processes in place of the rank processes: each runs `script` (a Python source reading RANK)."""
+    monkeypatch.setattr(bench, "rank_command", lambda argv: [sys.executable, "-c", script] + list(argv))
+
+
+def test_spawn_starts_n_fresh_ranks_with_the_rendezvous_environment(monkeypatch, tmp_path):
     bench = _load()
-    started = []
-
-    class FakeProc:
-        returncode = 0
-
-        def wait(self):
-            return 0
-
-        def poll(self):
-            return 0
-
-    def fake_popen(cmd, env=None, **kw):
-        started.append((cmd, env))
-        return FakeProc()
-
-    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
-    assert bench.spawn_ranks(4, ["--gpus", "4", "--steps", "2"]) == 0
-    assert len(started) == 4
+    script = (
+        "import os, sys, json\n"
+        "keys = ['RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY']\n"
+        "d = {k: os.environ.get(k) for k in keys}\n"
+        "d['argv'] = sys.argv[1:]\n"
+        "open(os.path.join(%r, 'rank%%s.json' %% os.environ['RANK']), 'w').write(json.dumps(d))\n" % str(tmp_path))
+    _children(monkeypatch, bench, script)
+    assert bench.spawn_ranks(4, ["--gpus", "4", "--steps", "2"], timeout_s=60) == 0
+    import json
     ports = set()
-    for rank, (cmd, env) in enumerate(started):
-        assert cmd[0] == sys.executable and os.path.abspath(cmd[1]) == BENCH and cmd[2:] == ["--gpus", "4", "--steps", "2"]
+    for rank in range(4):
+        env = json.load(open(tmp_path / ("rank%d.json" % rank)))
+        assert env["argv"] == ["--gpus", "4", "--steps", "2"]
         assert env["RANK"] == env["LOCAL_RANK"] == str(rank) and env["WORLD_SIZE"] == env["LOCAL_WORLD_SIZE"] == "4"
         assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
         ports.add(env["MASTER_PORT"])
     assert len(ports) == 1
 
 
-def test_a_failed_rank_fails_the_run(monkeypatch):
+def test_rank_command_is_this_script():
     bench = _load()
-    killed = []
+    cmd = bench.rank_command(["--gpus", "2"])
+    assert cmd[0] == sys.executable and os.path.abspath(cmd[1]) == BENCH and cmd[2:] == ["--gpus", "2"]
 
-    class Proc:
-        def __init__(self, rc, hangs):
-            self.returncode, self.hangs = rc, hangs
 
-        def wait(self):
-            return self.returncode
+def test_a_failed_rank_ends_the_others_within_seconds(monkeypatch, tmp_path):
+    """Rank 1 dies at once while rank 0 sits in its 'barrier' (a long sleep): the run must return non-zero within
+    seconds and rank 0 must be gone — real processes, the situation of a peer lost inside an RCCL collective."""
+    import time
+    bench = _load()
+    script = (
+        "import os, sys, time\n"
+        "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    sys.exit(3)\n"
+        "time.sleep(120)\n" % str(tmp_path))
+    _children(monkeypatch, bench, script)
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(2, [], timeout_s=100)
+    assert rc == 3
+    assert time.monotonic() - t0 < 20
+    pid0 = int(open(tmp_path / "pid0").read())
+    with pytest.raises(ProcessLookupError):
+        os.kill(pid0, 0)                          # reaped by spawn_ranks: no such process
 
-        def poll(self):
-            return None if self.hangs else self.returncode
 
-        def kill(self):
-            killed.append(self)
+def test_the_wall_clock_cap_ends_a_hung_run(monkeypatch, tmp_path):
+    import time
+    bench = _load()
+    script = (
+        "import os, time\n"
+        "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "time.sleep(120)\n" % str(tmp_path))
+    _children(monkeypatch, bench, script)
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(2, [], timeout_s=1.5) == 124
+    assert time.monotonic() - t0 < 20
+    for r in (0, 1):
+        with pytest.raises(ProcessLookupError):
+            os.kill(int(open(tmp_path / ("pid%d" % r)).read()), 0)
 
-    procs = [Proc(1, False), Proc(0, True)]
-    monkeypatch.setattr(bench.subprocess, "Popen", lambda cmd, env=None, **kw: procs.pop(0))
-    assert bench.spawn_ranks(2, []) != 0
-    assert len(killed) == 1                       # the rank left at the barrier is ended
+
+def test_the_watchdog_of_a_rank_exits_nonzero(tmp_path):
+    """Inside a rank the cap is a daemon timer that ends the process with 124 (a rank hung in a collective under
+    an external launcher)."""
+    code = ("import importlib.util, time\n"
+            "spec = importlib.util.spec_from_file_location('b', %r)\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "b.start_watchdog(); time.sleep(60)\n" % BENCH)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BGN_BENCH_TIMEOUT_S="1"), capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 124 and "BGN_BENCH_TIMEOUT_S" in r.stderr
 
 
 def test_no_gpu_is_an_error_not_a_cpu_run():

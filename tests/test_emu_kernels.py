@@ -245,14 +245,6 @@ def test_emu_per_coefficient_line_tables(ctx):
     assert E.pairing_fixed(tb, cts[v["a"]], 2, 1).hex() == v["out"]
 
 
-def test_emu_interpreter_miller_loop(ctx):
-    """The compact-code interpreter (vm.hpp) runs the same step programs as data: same pairing values."""
-    fx, E = ctx
-    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
-    for v in fx["mult"][:4]:
-        assert E.pairing_vm(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
-
-
 @pytest.mark.parametrize("nl", [3, 10, 19, 38])
 def test_emu_dword_codec_matches_the_byte_codec(nl):
     """codec.hpp's dword forms (wire_element_dw: two-dword reads + byte permutes, odd lanes two bytes into a dword

@@ -205,47 +205,6 @@ def test_bsgs_false_hits_are_rejected_by_the_full_width_check(bits, monkeypatch)
     assert m2.tolist() == m.tolist() and st2.tolist() == st.tolist()
 
 
-# ---------------------------------------------------------------- fused wire-to-wire Add
-@pytest.mark.parametrize("name,count", [("toy64", 1), ("toy64", 70000), ("k256", 300), ("k512", 257), ("k1024", 256)])
-def test_fused_add_matches_three_launch_path_and_c_oracle(name, count, monkeypatch):
-    """k_g1_add_wire (decode, affine addition with the shared inversion, encode in one kernel) and the opt-in
-    two-launch form (k_g1_add_front / k_g1_add_back, split at the inversion) against the
-    decode / k_g1_add / encode launches and the C oracle: ragged counts, runs longer than one (count > 65536),
-    identities on either side, a + a (doubling) and a - a (identity out)."""
-    import oracle_c
-    fx = load_fixture(name)
-    pk, _ = engine_key(fx)
-    eng = pk.engine
-    if b"+addvar" not in eng._lib.bgn_version():
-        pytest.skip("the fused / split Add kernels are kept negative results, out of the default build "
-                    "(make CXXFLAGS+=-DBGN_WITH_ADD_VARIANTS puts them back)")
-    o = oracle_c.Oracle.from_fixture(fx)
-    rng = random.Random(count)
-    n = int(fx["n"], 16)
-    pool = eng.encrypt([rng.randrange(fx["msg_space"]) for _ in range(24)], [rng.randrange(n) for _ in range(24)])
-    pool[7] = 0                                                      # an identity in the pool
-    ia = np.array([rng.randrange(24) for _ in range(count)])
-    ib = np.array([rng.randrange(24) for _ in range(count)])
-    ib[::11] = ia[::11]                                              # doublings / a - a
-    a, b = pool[ia].tobytes(), pool[ib].tobytes()
-    for sub in (False, True):
-        fn = eng.sub if sub else eng.add
-        monkeypatch.setenv("BGN_ADD_FUSED", "1")
-        fused = fn(1, a, b).tobytes()
-        assert eng.last_kernel_name() == "k_g1_add_wire"
-        monkeypatch.setenv("BGN_ADD_FUSED", "0")
-        plain = fn(1, a, b).tobytes()
-        assert eng.last_kernel_name() == "k_g1_add"
-        monkeypatch.setenv("BGN_ADD_SPLIT", "1")
-        split = fn(1, a, b).tobytes()                                  # front + back kernels, split at the inversion
-        assert eng.last_kernel_name() == "k_g1_add_front+back"
-        monkeypatch.delenv("BGN_ADD_SPLIT")
-        assert fused == plain == split
-        sample = min(count, 400)
-        E = eng.elem_bytes
-        assert fused[: sample * E] == o.add(1, a[: sample * E], b[: sample * E], subtract=sub)
-
-
 # ---------------------------------------------------------------- chunked host-buffer pipeline
 @pytest.mark.parametrize("name,count,chunk", [("k512", 5000, 700), ("toy64", 200000, 65536), ("k1024", 1500, 256)])
 def test_host_pipeline_matches_one_shot_staging(name, count, chunk, monkeypatch):

@@ -389,25 +389,6 @@ def test_mult_runs_with_shared_inversion():
     assert (out == exp[ia, ib]).all()
 
 
-def test_interpreter_variant_matches(monkeypatch):
-    """BGN_PAIRING_VM=1 routes Mult through the compact-code interpreter (vm.hpp): same bytes.  The interpreter
-    is a kept negative result and out of the default build (make CXXFLAGS+=-DBGN_WITH_VM puts it back); the host
-    emulator keeps its step programs covered (tests/test_emu_kernels.py)."""
-    fx = load_fixture("k512")
-    pk, _ = engine_key(fx)
-    if b"+vm" not in pk.engine._lib.bgn_version():
-        pytest.skip("library built without the interpreter variant")
-    monkeypatch.setenv("BGN_COOP_MAX", "0")
-    cts = [e["ct"] for e in fx["encrypt"]]
-    a = H([cts[v["a"]] for v in fx["mult"]])
-    b = H([cts[v["b"]] for v in fx["mult"]])
-    monkeypatch.setenv("BGN_PAIRING_VM", "1")
-    out = pk.engine.mult(a, b)
-    assert pk.engine.last_kernel_name().startswith("k_pairing")
-    for row, v in zip(out, fx["mult"]):
-        assert bytes(row).hex() == v["out"]
-
-
 def test_encrypt_runs_with_shared_inversion():
     """count > 2*65536: every lane owns a run of encryptions sharing one Jacobian->affine inversion; zero
     plaintext/randomness (identity results) inside the runs; ragged tail."""

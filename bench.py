@@ -35,8 +35,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Round 1's table (ubench_valu_rates_r01.txt: 378 / 455 G) did not pin its occupancy and read low at 4 waves.
 VALU_MAD_PEAK_4W = 526.4e9 * 64    # lane-MADs/s at 4 waves per SIMD (the chip's ceiling)
 VALU_MAD_PEAK_1W = 398.4e9 * 64    # at 1 wave per SIMD — the occupancy these 512-register kernels run at
-# profiles/ubench_fp_rates_r01.txt: field products per second of the whole chip at NL = 38, one wave per SIMD
-PRODUCT_CEILING = {38: 8.15e9}
 
 
 def cpu_budget():
@@ -161,16 +159,22 @@ def _timed(fn, sync, reps=2):
     return dt
 
 
-def op_rooflines(entry, products_per_unit, nl):
-    """Every secondary entry carries the two bounds: field products against the measured product ceiling of the
-    chip (the VALU bound that applies) and algorithmic bytes against the HBM peak."""
-    ceil = PRODUCT_CEILING.get(nl)
-    entry["products_per_unit"] = products_per_unit
-    if ceil:
-        entry["frac_of_product_ceiling"] = entry["value"] * products_per_unit / ceil
-        entry["product_ceiling_per_s"] = ceil
+def op_rooflines(entry, counts, nl, n_gpus=1):
+    """Every secondary entry carries the two bounds: its 32x32->64 multiply-adds — counts = (field products, how
+    many of them are squarings), priced by bgn_amd.synthetic.mads_from_counts — against the measured issue peaks of
+    v_mad_u64_u32 (the VALU bound that applies; both occupancies), and its algorithmic bytes against the HBM peak.
+    Aggregate rates over n_gpus ranks are held against n_gpus chips."""
+    import bgn_amd.synthetic as syn
+    products, squares = counts
+    mads = syn.mads_from_counts(products, squares, nl)
+    rate = entry["value"] * mads / n_gpus
+    entry["products_per_unit"] = products
+    entry["squarings_per_unit"] = squares
+    entry["roofline_valu"] = {"bound": "v_mad_u64_u32 issue", "mads_per_unit": mads, "achieved": rate, "unit": "lane-MAD/s",
+                              "peak": VALU_MAD_PEAK_4W, "frac": rate / VALU_MAD_PEAK_4W,
+                              "peak_at_1_wave_per_simd": VALU_MAD_PEAK_1W, "frac_at_1_wave_per_simd": rate / VALU_MAD_PEAK_1W}
     if "algorithmic_bytes_per_unit" in entry:
-        gbs = entry["value"] * entry["algorithmic_bytes_per_unit"] / 1e9
+        gbs = entry["value"] * entry["algorithmic_bytes_per_unit"] / 1e9 / n_gpus
         entry["hbm"] = {"achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
     return entry
 
@@ -200,7 +204,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
                      "inversion per run of 64",
          "kernel": eng.last_kernel_name(), "kernel_ms_per_step": eng.last_kernel_ms(),
          "algorithmic_bytes_per_unit": xs.shape[1] + rs.shape[1] + EB},
-        syn.encrypt_products(xs.shape[1] * 8, rs.shape[1] * 8), nl)
+        syn.encrypt_counts(xs.shape[1] * 8, rs.shape[1] * 8), nl)
     # --- EAdd (level 1): every ciphertext with its partner in a fixed permutation (the pairs of Config 3)
     n_add = n_enc
     a1, b1 = cts, syn.permuted_copy(cts, EB, seed=11)
@@ -210,7 +214,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
         {"value": n_add / dt, "unit": "adds/s", "batch": n_add,
          "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion), wire bytes to wire bytes",
          "kernel": eng.last_kernel_name(), "algorithmic_bytes_per_unit": 3 * EB},
-        syn.eadd_products(n_add), nl)
+        syn.eadd_counts(n_add), nl)
     del o1, b1
     # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
     npoly, d1, d2 = 1 << 12, 16, 16
@@ -224,7 +228,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
                      "(Karatsuba over the bilinear pairing, per-coefficient line tables, segmented GT accumulation), "
                      "sharded by polynomial across GPUs",
          "algorithmic_bytes_per_unit": 3 * EB},
-        syn.multpoly_products_per_pair(fx, d1), nl)
+        syn.multpoly_counts_per_pair(fx, d1), nl)
     del po
     # --- Decrypt: the first 2^k of those ciphertexts, every 16th negated and every 4096th out of range
     t0 = time.perf_counter()
@@ -249,7 +253,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
                          "exponentiation + ^sk, then giant steps 2S apart on an HBM-resident baby table (%d entries)"
                          % (k, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))),
              "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
-            syn.decrypt_products(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
+            syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
         # the dominant kernel of Decrypt is the lift (k_pairing<38, 1>), timed by HIP events on its stream
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
@@ -284,7 +288,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
          "workload": "configs[3], level 2: Decrypt of 2^16 products of two 20-bit messages (outputs of Mult): "
                      "^sk by the norm-1 ladder, then the same giant-step walk",
          "plaintexts_recovered_exactly": ok, "algorithmic_bytes_per_unit": EB + 16},
-        syn.decrypt_products(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h)), level=2), nl)
+        syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h)), level=2), nl)
     return out, dec
 
 
@@ -369,6 +373,18 @@ def start_watchdog():
     return t
 
 
+_JSON_FD = None
+
+
+def emit_line(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,6 +413,12 @@ def main():
             sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N")
 
     start_watchdog()
+    # stdout carries ONE JSON line: native libraries that write to file descriptor 1 (RCCL prints a version banner
+    # there when a communicator is created) are sent to stderr, the line goes to the original descriptor
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -574,7 +596,7 @@ def main():
             line["extra"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if use_dist:
         dist.barrier()                                   # the other ranks wait for rank 0's CPU leg here
         dist.destroy_process_group()
@@ -624,14 +646,7 @@ def decrypt_sharded(pk, fx, dev, cts, xs, world, rank, dist, timed_region, args)
                      "out of range; sharded by ciphertext, plaintexts and statuses all-gathered (RCCL); baby table of %d "
                      "entries per GPU" % (args.batch_log2, S),
          "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
-        syn.decrypt_products(fx, S), 38)
-    # fractions are per GPU: the aggregate rate over the ranks against one chip's ceilings times the ranks
-    for key in ("frac_of_product_ceiling",):
-        if key in e:
-            e[key] /= world
-    if "hbm" in e:
-        e["hbm"]["achieved_GBps"] /= world
-        e["hbm"]["frac"] /= world
+        syn.decrypt_counts(fx, S), 38, n_gpus=world)
     e["roofline"] = {"bound": "hbm", "achieved": alg * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "kernel": eng.last_aux_kernel_name(), "kernel_ms": k_ms, "algorithmic_bytes_per_decrypt": alg,
@@ -694,7 +709,8 @@ def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
     if rank == 0:
         pairs = npoly * d1 * d2
         value = pairs * args.steps / dt
-        ppp = syn.multpoly_products_per_pair(fx, d1)
+        ppp, sqp = syn.multpoly_counts_per_pair(fx, d1)
+        mpp = syn.mads_from_counts(ppp, sqp, 38)
         line = {"metric": "MultPoly coefficient pairs/sec at 1024-bit (configs[4])", "value": value,
                 "unit": "coefficient pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -707,8 +723,11 @@ def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
                 "roofline": {"bound": "hbm", "achieved": value * 3 * EB / 1e9 / world, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": value * 3 * EB / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
                              "algorithmic_bytes_per_pair": 3 * EB, "note": "per GPU, over the whole step (several kernels)"},
-                "roofline_valu": {"products_per_pair": ppp, "frac_of_product_ceiling": value / world * ppp / PRODUCT_CEILING[38]}}
-        print(json.dumps(line), flush=True)
+                "roofline_valu": {"bound": "v_mad_u64_u32 issue", "products_per_pair": ppp, "mads_per_unit": mpp,
+                                  "achieved": value / world * mpp, "unit": "lane-MAD/s (per GPU)", "peak": VALU_MAD_PEAK_4W,
+                                  "frac": value / world * mpp / VALU_MAD_PEAK_4W, "peak_at_1_wave_per_simd": VALU_MAD_PEAK_1W,
+                                  "frac_at_1_wave_per_simd": value / world * mpp / VALU_MAD_PEAK_1W}}
+        emit_line(line)
     if use_dist:
         dist.destroy_process_group()
 

@@ -381,20 +381,26 @@ class MultiEngine:
               "bgn_mpoly_mult_batch")
         return out
 
-    # device arrays (torch uint8 CUDA tensors) resident on device `root`; returns after the gather
+    # device arrays (torch uint8 CUDA tensors) resident on device `root`; every shard waits for the work queued on
+    # torch's current stream of that device (where the caller produced the arrays); returns after the gather
+    @staticmethod
+    def _root_stream(root: int):
+        import torch
+        return torch.cuda.current_stream(root).cuda_stream
+
     def mult_dev(self, a, b, out, root: int, count: Optional[int] = None) -> None:
         count = a.numel() // self.elem_bytes if count is None else count
-        check(self._lib.bgn_mmult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(), out.data_ptr(), root),
-              "bgn_mmult_batch_dev")
+        check(self._lib.bgn_mmult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(), out.data_ptr(), root,
+                                            self._root_stream(root)), "bgn_mmult_batch_dev")
 
     def decrypt_dev(self, level: int, ct, m, status, root: int, count: Optional[int] = None) -> None:
         count = ct.numel() // self.elem_bytes if count is None else count
         check(self._lib.bgn_mdecrypt_batch_dev(self._h, count, level, ct.data_ptr(), m.data_ptr(), status.data_ptr(),
-                                               root), "bgn_mdecrypt_batch_dev")
+                                               root, self._root_stream(root)), "bgn_mdecrypt_batch_dev")
 
     def poly_mult_dev(self, npoly: int, d1: int, d2: int, a, b, out, root: int) -> None:
         check(self._lib.bgn_mpoly_mult_batch_dev(self._h, npoly, d1, d2, a.data_ptr(), b.data_ptr(), out.data_ptr(),
-                                                 root), "bgn_mpoly_mult_batch_dev")
+                                                 root, self._root_stream(root)), "bgn_mpoly_mult_batch_dev")
 
 
 # ---------------------------------------------------------------------------

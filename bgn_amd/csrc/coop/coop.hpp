@@ -220,6 +220,7 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
                size_t count, int mode, size_t d1, size_t d2, int phase, u32* __restrict__ park, u32* __restrict__ nsoa,
                const u32* __restrict__ isoa, size_t ws, const u32* __restrict__ tab) {
   __shared__ u32 V[COOP_NSLOTS][64];
+  __shared__ u32 zero_norm;                     // N(f) = 0: only an operand that is not on the curve can produce it
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t e = blockIdx.x;
@@ -360,6 +361,12 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
       ip ^= 1;
     }
   }
+  // the inverse of a zero norm is zero (both inversions map 0 to 0): such a pairing yields the identity, as in
+  // k_pairing (PBC's SetBytes maps an invalid point to O); every limb of the zero product is zero
+  if (wave == 2) {
+    const bool nz = __ballot(V[ip ? COOP_SLOT_ACC_1 : COOP_SLOT_ACC_0][lane] != 0) != 0;
+    if (lane == 0) zero_norm = nz ? 0u : 1u;
+  }
   coop_run<NL>(V, COOP_SEG_H0 + ip, wave, c);
   int lp = 0;
 #pragma unroll 1
@@ -374,7 +381,7 @@ k_pairing_coop(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   coop_run<NL>(V, lp ? COOP_SEG_OUT1 : COOP_SEG_OUT0, wave, c);
   // canonical residues out: wave 0 the real part, wave 1 the imaginary part
   if (wave < 2) {
-    const bool ident = (a.inf && a.inf[ea]) || (!tab && b.inf && b.inf[eb]);   // e(O, .) = e(., O) = 1
+    const bool ident = (a.inf && a.inf[ea]) || (!tab && b.inf && b.inf[eb]) || zero_norm != 0;   // e(O, .) = e(., O) = 1
     u32 r = coop_canonical<NL>(V[wave == 0 ? COOP_SLOT_OUT0 : COOP_SLOT_OUT1][lane], c);
     if (ident) r = (wave == 0 && lane == 0) ? 1u : 0u;
     u32* dst = wave == 0 ? out.c0 : out.c1;

@@ -210,9 +210,16 @@ k_pairing(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ 
     } else
       miller_loop<NL>(S, L, op, C, P);
     if (run == 1) {
-      const bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
+      bool ident = (a.inf && a.inf[op.ea]) || (b.inf && b.inf[op.eb]);
       Fp<NL> N, ninv, g0, g1, re, im;
       miller_norm<NL>(N, S, L, P);
+      {
+        // a norm of zero (only an operand that is not on the curve produces one) yields the identity, as in the
+        // shared-inversion path below and in the other two pairing kernels
+        Fp<NL> nc;
+        fp_reduce8(nc, N, P);
+        ident = ident || fp_is_zero_limbs(nc);
+      }
       fp_inv_mont<NL>(ninv, N, C->pm2_bits + 1, P, L);
       final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
       fp_from_mont<NL>(im, g1, P, L);

@@ -90,6 +90,36 @@ bool on_root(const bgn_mctx* m, int i, int root) {
   return m->dev[i] == root && !(e && e[0] == '1');
 }
 
+// The calling thread's current HIP device, put back when an entry point that switches devices returns (a caller
+// mixing this library with its own HIP or torch code keeps its device).
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  }
+  ~DeviceGuard() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+  }
+};
+
+// Ordering of the device-resident forms against the caller's stream on the root device: an event recorded there
+// when the call starts, which every shard's stream waits for before it touches the root's arrays (its fetch of
+// operands, its write-back of results).  The calls return after every shard has finished, so work the caller
+// queues afterwards is ordered by the host.
+struct RootOrder {
+  hipEvent_t ev = nullptr;
+  ~RootOrder() {
+    if (ev) (void)hipEventDestroy(ev);
+  }
+  int record(int root, hipStream_t root_stream) {
+    DeviceGuard g;
+    if (hipSetDevice(root) != hipSuccess) return mfail(BGN_E_HIP, "hipSetDevice(root) failed");
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, root_stream) != hipSuccess)
+      return mfail(BGN_E_HIP, "event on the root stream failed");
+    return BGN_OK;
+  }
+};
+
 struct PeerBuf {   // scratch on the shard's device for a slice that lives on the root device
   void* p = nullptr;
   ~PeerBuf() {
@@ -144,6 +174,7 @@ int bgn_mctx_create(bgn_mctx** out, const uint8_t* p_be, size_t p_len, const uin
                     const uint8_t* P_wire, const uint8_t* Q_wire, int deterministic, const int* devices, int ndev) {
   if (!out) return mfail(BGN_E_ARG, "null argument");
   *out = nullptr;
+  DeviceGuard guard;
   if (!devices || ndev <= 0 || ndev > 64) return mfail(BGN_E_ARG, "device list empty or too long");
   bgn_mctx* m = new (std::nothrow) bgn_mctx();
   if (!m) return mfail(BGN_E_NOMEM, "out of memory");
@@ -180,6 +211,7 @@ int bgn_mctx_create(bgn_mctx** out, const uint8_t* p_be, size_t p_len, const uin
 
 void bgn_mctx_destroy(bgn_mctx* m) {
   if (!m) return;
+  DeviceGuard guard;
   for (size_t i = 0; i < m->ctx.size(); ++i) {
     (void)hipSetDevice(m->dev[i]);
     if (m->stream[i]) {
@@ -284,11 +316,15 @@ int bgn_mpoly_mult_batch(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const 
 
 // ---- device buffers resident on `root`: slices out and results back by peer DMA -----------------------------
 
-int bgn_mmult_batch_dev(bgn_mctx* m, size_t count, const uint8_t* a, const uint8_t* b, uint8_t* out, int root) {
+int bgn_mmult_batch_dev(bgn_mctx* m, size_t count, const uint8_t* a, const uint8_t* b, uint8_t* out, int root,
+                        void* root_stream) {
   if (!m || (count && (!a || !b || !out))) return mfail(BGN_E_ARG, "null argument");
   const size_t eb = 2 * m->L;
+  RootOrder order;
+  if (int rc = order.record(root, (hipStream_t)root_stream)) return rc;
   return run_sharded(m, count, [&](int i, size_t lo, size_t hi) {
     const size_t n = hi - lo, bytes = n * eb;
+    M_TRY(hipStreamWaitEvent(m->stream[i], order.ev, 0));
     PeerBuf ta, tb, to;
     const uint8_t *pa, *pb;
     int rc;
@@ -305,11 +341,15 @@ int bgn_mmult_batch_dev(bgn_mctx* m, size_t count, const uint8_t* a, const uint8
   });
 }
 
-int bgn_mdecrypt_batch_dev(bgn_mctx* m, size_t count, int level, const uint8_t* ct, int64_t* msg, uint8_t* status, int root) {
+int bgn_mdecrypt_batch_dev(bgn_mctx* m, size_t count, int level, const uint8_t* ct, int64_t* msg, uint8_t* status, int root,
+                           void* root_stream) {
   if (!m || (count && (!ct || !msg || !status))) return mfail(BGN_E_ARG, "null argument");
   const size_t eb = 2 * m->L;
+  RootOrder order;
+  if (int rc = order.record(root, (hipStream_t)root_stream)) return rc;
   return run_sharded(m, count, [&](int i, size_t lo, size_t hi) {
     const size_t n = hi - lo;
+    M_TRY(hipStreamWaitEvent(m->stream[i], order.ev, 0));
     PeerBuf tc, tm, ts;
     const uint8_t* pc;
     int rc;
@@ -332,11 +372,14 @@ int bgn_mdecrypt_batch_dev(bgn_mctx* m, size_t count, int level, const uint8_t* 
 }
 
 int bgn_mpoly_mult_batch_dev(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
-                             uint8_t* out, int root) {
+                             uint8_t* out, int root, void* root_stream) {
   if (!m || (npoly && (!a || !b || !out))) return mfail(BGN_E_ARG, "null argument");
   const size_t eb = 2 * m->L;
+  RootOrder order;
+  if (int rc = order.record(root, (hipStream_t)root_stream)) return rc;
   return run_sharded(m, npoly, [&](int i, size_t lo, size_t hi) {
     const size_t n = hi - lo, ob = n * (d1 + d2) * eb;
+    M_TRY(hipStreamWaitEvent(m->stream[i], order.ev, 0));
     PeerBuf ta, tb, to;
     const uint8_t *pa, *pb;
     int rc;

@@ -368,6 +368,7 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   constexpr int M = QuadDims<NL>::M;
   using PG = typename std::conditional<PHASE == 1, QuadMiller, QuadFinal>::type;
   __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
+  __shared__ u32 zero_norm[QUAD_PER_BLOCK];     // launch 2: N(f) = 0 (only an operand that is not on the curve gives it)
   char* V = reinterpret_cast<char*>(Vs);
   QuadLane<NL> c;
   quad_lane_init<NL>(c, P);
@@ -476,6 +477,14 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     } else {
       quad_gload<NL>(x, isoa, ws, e, c.sub);
       put(QUADF_SLOT_INV);
+      // the inverse of a zero norm is zero: such a pairing yields the identity, as in k_pairing (PBC's SetBytes maps
+      // an invalid point to O)
+      u32 any = 0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) any |= (u32)x[j];
+      any |= (u32)quad_from_above((int)any);
+      any |= (u32)quad_bcast<0>((int)any) | (u32)quad_bcast<2>((int)any);
+      if (c.sub == 0) zero_norm[threadIdx.x >> 4] = any ? 0u : 1u;
 #pragma unroll
       for (int j = 0; j < M; ++j) x[j] = 0;
       if (c.sub == 0) x[0] = 1;
@@ -512,7 +521,7 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     }
     // canonical residues out: quad 0 the real part, quad 1 the imaginary part
     if (c.quad < 2) {
-      const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]);      // e(O, .) = e(., O) = 1
+      const bool ident = (a.inf && a.inf[ea]) || (b.inf && b.inf[eb]) || zero_norm[threadIdx.x >> 4] != 0;   // e(O, .) = e(., O) = 1
       quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUADF_SLOT_OUT0 : QUADF_SLOT_OUT1), c));
       quad_canonical<NL>(x, c);
       if (ident) {

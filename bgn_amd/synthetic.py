@@ -155,22 +155,39 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: i
     return int((products - squares) * 2 * nl * nl + squares * square_mads(nl, segments))
 
 
-# ---- field products per unit of the other operations, for the product-ceiling fractions ----
+# ---- field products per unit of the other operations -----------------------------------------
+# Every *_counts function returns (field products, how many of them are squarings); mads_from_counts prices them in
+# 32x32->64 multiply-adds — a general product at 2*NL^2, a squaring at the segmented square's count — which is what
+# bench.py holds against the measured v_mad_u64_u32 issue peaks (roofline_valu).  An F_p inversion by division steps
+# is priced as INVERSION_PRODUCTS general products (its multiply-adds are of the same instruction, fpinv.hpp).
+def mads_from_counts(products: float, squares: float, nl: int = 38, segments: int = 5) -> float:
+    return (products - squares) * 2 * nl * nl + squares * square_mads(nl, segments)
+
+
 def _run_for(count: int) -> int:
     """Elements per lane of the batched-inversion kernels (engine.cpp run_for)."""
     return max(1, min(64, -(-count // 65536)))
 
 
+def eadd_counts(count: int):
+    """Affine addition with Montgomery's trick over a lane's run: 7 products (one of them lambda^2) + one inversion
+    per run."""
+    return 7 + INVERSION_PRODUCTS / _run_for(count), 1.0
+
+
 def eadd_products(count: int) -> float:
-    """Affine addition with Montgomery's trick over a lane's run: 7 products + one inversion per run."""
-    return 7 + INVERSION_PRODUCTS / _run_for(count)
+    return eadd_counts(count)[0]
+
+
+def encrypt_counts(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20):
+    """Fixed-base product P^m * Q^r: one affine addition per window (four accumulation chains, runs of 64) and
+    three more to sum the chains; one squaring (lambda^2) per addition."""
+    windows = -(-x_bits // wbits_p) + -(-r_bits // wbits_q)
+    return (windows + 3) * (7 + INVERSION_PRODUCTS / 64), float(windows + 3)
 
 
 def encrypt_products(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20) -> float:
-    """Fixed-base product P^m * Q^r: one affine addition per window (four accumulation chains, runs of 64) and
-    three more to sum the chains."""
-    windows = -(-x_bits // wbits_p) + -(-r_bits // wbits_q)
-    return (windows + 3) * (7 + INVERSION_PRODUCTS / 64)
+    return encrypt_counts(x_bits, r_bits, wbits_p, wbits_q)[0]
 
 
 def _naf_counts(n: int):
@@ -178,11 +195,12 @@ def _naf_counts(n: int):
     return len(d) - 1, sum(1 for i, x in enumerate(d[:-1]) if x and i != 0)
 
 
-def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
+def decrypt_counts(fx, baby_steps: int, level: int = 1):
     """Decrypt (bgn.go:218-250): level 1 lifts with the Miller loop over the normalised line table of q1*P along
-    the NAF of q2 = n/q1 (6 / 4 products per doubling / addition step) and the final exponentiation; both levels
-    raise to q1 on the norm-1 ladder (2 per bit, one inversion for the imaginary part) and walk G giant steps at
-    1.1 products each (bsgs.hpp)."""
+    the NAF of q2 = n/q1 (6 / 4 products per doubling / addition step, none of them a field squaring: f^2 is two
+    general products) and the final exponentiation (F0^2, F1^2 of the norm are squarings); both levels raise to q1
+    on the norm-1 ladder (per bit one squaring A_j^2 and one product, one inversion for the imaginary part) and
+    walk G giant steps at 1.1 products each (bsgs.hpp)."""
     import math
     n, q1, l, T = int(fx["n"], 16), int(fx["q1"], 16), int(fx["l"]), int(fx["msg_space"])
     B = math.isqrt(T - 1) + 1 if T > 1 else 1
@@ -190,17 +208,24 @@ def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
     S = max(1, int(baby_steps))
     G = (mmax + S) // (2 * S) + 1
     prods = 2 * q1.bit_length() + INVERSION_PRODUCTS + 1.1 * G + 40
+    squares = float(q1.bit_length())
     if level == 1:
         dbl, add = _naf_counts(n // q1)
         lb = l.bit_length()
         prods += dbl * 6 + add * 4 + 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
-    return prods
+        squares += 4
+    return prods, squares
 
 
-def multpoly_products_per_pair(fx, d: int) -> float:
+def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
+    return decrypt_counts(fx, baby_steps, level)[0]
+
+
+def multpoly_counts_per_pair(fx, d: int):
     """MultPoly of two d-coefficient polynomials (d a power of two >= 2) per coefficient pair: Karatsuba levels
     down to 2x2 products, each 4 evaluations over a per-coefficient line table (7 / 5 per step + final
-    exponentiation) and 2 table builds (11.5 per step)."""
+    exponentiation; squarings only in the norm) and 2 table builds (11.5 per step; the point arithmetic of a
+    doubling has 6 squarings, of an addition 3)."""
     n, l = int(fx["n"], 16), int(fx["l"])
     dbl, add = _naf_counts(n)
     lb = l.bit_length()
@@ -212,4 +237,8 @@ def multpoly_products_per_pair(fx, d: int) -> float:
     while k > 2:
         leaves *= 3
         k //= 2
-    return leaves * (4 * ev + 2 * build) / (d * d)
+    return leaves * (4 * ev + 2 * build) / (d * d), leaves * (4 * 4 + 2 * (dbl * 6 + add * 3)) / (d * d)
+
+
+def multpoly_products_per_pair(fx, d: int) -> float:
+    return multpoly_counts_per_pair(fx, d)[0]

@@ -257,12 +257,20 @@ int bgn_mdecrypt_batch(bgn_mctx* m, size_t count, int level, const uint8_t* ct, 
 int bgn_mpoly_mult_batch(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
                          uint8_t* out);
 
-/* Device buffers resident on HIP device `root` (one of the context's devices or any peer-accessible one). */
-int bgn_mmult_batch_dev(bgn_mctx* m, size_t count, const uint8_t* a, const uint8_t* b, uint8_t* out, int root);
+/* Device buffers resident on HIP device `root` (one of the context's devices or any peer-accessible one).
+ * Ordering contract: `root_stream` is the HIP stream ON `root` (null = its default stream) on which the caller
+ * produced the operand arrays and last touched the result arrays.  Every shard waits for the work queued on that
+ * stream at the moment of the call before it reads an operand slice or writes a result slice (an event on
+ * root_stream, waited for by each shard's own stream), so asynchronously produced inputs and a pending fill of
+ * `out` are safe.  The calls are synchronous towards the host: they return after every shard has written its
+ * results into the root's arrays, so whatever the caller queues afterwards — on any stream — sees them.  The
+ * calling thread's current device is left as it was. */
+int bgn_mmult_batch_dev(bgn_mctx* m, size_t count, const uint8_t* a, const uint8_t* b, uint8_t* out, int root,
+                        void* root_stream);
 int bgn_mdecrypt_batch_dev(bgn_mctx* m, size_t count, int level, const uint8_t* ct, int64_t* msg, uint8_t* status,
-                           int root);
+                           int root, void* root_stream);
 int bgn_mpoly_mult_batch_dev(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, const uint8_t* a, const uint8_t* b,
-                             uint8_t* out, int root);
+                             uint8_t* out, int root, void* root_stream);
 
 /* ---- page-locked host arrays ------------------------------------------------------------------------------
  * The host-buffer calls copy their arrays over PCIe.  Add / Sub / Neg on two or more chunks of 131072 elements

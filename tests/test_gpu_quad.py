@@ -107,3 +107,29 @@ def test_default_dispatch_uses_the_lane_group_kernel_between_the_crossovers():
         assert bytes(out[i]).hex() == want[i % len(want)]
     out = eng.mult(a[: 64 * eng.elem_bytes], b[: 64 * eng.elem_bytes])
     assert "coop" in eng.last_kernel_name()
+
+
+@pytest.mark.parametrize("name", ["k512", "k1024"])
+def test_zero_norm_yields_the_identity_on_every_kernel(name, monkeypatch):
+    """An operand that is not on the curve can drive f to zero: A = (a, 0) doubles to Z3 = 2YZ = 0 and its tangent
+    at phi(B), B = (-a, y), is (3a^2 + 1)(xB + a) + 0i = 0, so N(f) = 0 and its inverse is 0.  The lane kernel maps
+    such a pairing to the identity (as PBC's SetBytes maps an invalid point to O); the cooperative and the
+    lane-group kernel must return the same bytes, and the neighbours of the bad pair their own values."""
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    p = int(fx["p"], 16)
+    L = eng.elem_bytes // 2
+    cts = [e["ct"] for e in fx["encrypt"]]
+    good = [v for v in fx["mult"] if int(cts[v["a"]], 16) and int(cts[v["b"]], 16)][:2]
+    bad_a = (5).to_bytes(L, "big") + bytes(L)
+    bad_b = (p - 5).to_bytes(L, "big") + (7).to_bytes(L, "big")
+    a = bytes.fromhex(cts[good[0]["a"]]) + bad_a + bytes.fromhex(cts[good[1]["a"]])
+    b = bytes.fromhex(cts[good[0]["b"]]) + bad_b + bytes.fromhex(cts[good[1]["b"]])
+    one = (1).to_bytes(L, "big") + bytes(L)
+    for kernel in ("lane", "coop", "quad"):
+        force(monkeypatch, kernel)
+        out = eng.mult(a, b)
+        assert (kernel in eng.last_kernel_name()) == (kernel != "lane")
+        assert bytes(out[0]).hex() == good[0]["out"] and bytes(out[2]).hex() == good[1]["out"], kernel
+        assert bytes(out[1]) == one, kernel

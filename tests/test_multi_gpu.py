@@ -92,6 +92,37 @@ def test_mctx_device_resident_forms(multi, staging, monkeypatch):
     assert po.cpu().numpy().tobytes() == eng.poly_mult(npoly, d, d, a[: npoly * d * E], b[: npoly * d * E]).tobytes()
 
 
+def test_mctx_device_resident_forms_wait_for_the_callers_stream(multi, monkeypatch):
+    """The ordering contract of the _dev calls (include/bgn_amd.h): operands produced asynchronously on a side
+    stream of the root device — here behind tens of milliseconds of queued work — and a pending fill of the
+    result array are waited for by every shard (an event on the caller's stream), staging path forced.  Without
+    the wait the shards would pair the zero bytes the arrays held before."""
+    import torch
+    monkeypatch.setenv("BGN_MCTX_FORCE_STAGING", "1")
+    fx, me = multi
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    count, E = 13, eng.elem_bytes
+    a, b = _pool(fx, count), _pool(fx, count, 3, 1)
+    src_a = torch.frombuffer(bytearray(a), dtype=torch.uint8).cuda()
+    src_b = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    ta, tb = torch.zeros_like(src_a), torch.zeros_like(src_b)
+    out = torch.empty(count * E, dtype=torch.uint8, device="cuda")
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    before = torch.cuda.current_device()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(40):                       # queued work in front of the operands
+            big.fill_(7)
+        ta.copy_(src_a, non_blocking=True)
+        tb.copy_(src_b, non_blocking=True)
+        out.fill_(255)                            # a pending fill of the result array
+        me.mult_dev(ta, tb, out, root=0)          # takes torch's current stream of the root device: `side`
+    assert torch.cuda.current_device() == before
+    assert out.cpu().numpy().tobytes() == eng.mult(a, b).tobytes()
+
+
 def test_sharded_ops_world1_on_the_engine():
     """The sharder of the multi-process form (bgn_amd/sharding.py) driving the HIP engine at world = 1."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -608,7 +608,7 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, a
     lines.append("#define %s_MAX_TERMS %d" % (prefix, MAX_TERMS))
     for gname in slot_names or (
             "ax", "ay", "bx", "by", "one", "raw1", "zero", "out0", "out1", "X@0", "Y@0", "Z@0", "ZZ@0", "W@0", "v0@0", "v1@0", "v2@0",
-            "n1", "n2", "fm", "acc@0", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1",
+            "n1", "n2", "fm", "acc@0", "acc@1", "h0", "h1", "r0@0", "r1@0", "r0@1", "r1@1",
             "ta1@0", "tb1@0", "ta2@0", "tb2@0", "ta1@1", "tb1@1", "ta2@1", "tb2@1", "v0@1", "v1@1", "v2@1"):
         lines.append("#define %s_SLOT_%s %d" % (prefix, gname.replace("@", "_").upper(), P.phys[gname]))
     lines.append("enum %sSeg {" % cap)

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "bgn_mmultconst_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _sz, _u8p, _sz, _u8p]),
     "bgn_mdecrypt_batch": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p]),
     "bgn_mpoly_mult_batch": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p]),
+    "bgn_ctx_memory_bytes": (C.c_uint64, [_ctx]),
+    "bgn_ctx_set_memory_budget": (C.c_int, [_ctx, C.c_uint64]),
     "bgn_mmult_batch_dev": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p, C.c_int, C.c_void_p]),
     "bgn_mdecrypt_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, C.c_int, C.c_void_p]),
     "bgn_mpoly_mult_batch_dev": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p, C.c_int, C.c_void_p]),

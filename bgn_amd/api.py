@@ -256,6 +256,15 @@ class Engine:
         check(self._lib.bgn_field_ops_batch(self._h, len(A), _ptr(A), _ptr(o1), _ptr(o2)), "bgn_field_ops_batch")
         return o1, o2
 
+    def memory_bytes(self) -> int:
+        """Device memory the context holds now (tables of the key + workspace)."""
+        return int(self._lib.bgn_ctx_memory_bytes(self._h))
+
+    def set_memory_budget(self, nbytes: int) -> None:
+        """Cap on memory_bytes(): tables built afterwards are sized within it (0: none).  The reference keeps the tables
+        of every key it has seen (gsbs.go:12-15); with a budget per key several keys share one GPU."""
+        check(self._lib.bgn_ctx_set_memory_budget(self._h, int(nbytes)), "bgn_ctx_set_memory_budget")
+
     def last_kernel_ms(self) -> float:
         return float(self._lib.bgn_last_kernel_ms(self._h))
 

@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <new>
 #include <string>
@@ -101,6 +102,7 @@ struct bgn_ctx {
   size_t sk_len = 0;
   uint32_t* d_gt = nullptr;            // g.re, g.im, gamma^-1.re, gamma^-1.im : 4 * nl limbs (Montgomery)
   BsgsSlot* d_table = nullptr;
+  uint64_t bsgs_slots = 0;             // slots of d_table
   uint32_t* d_tabV = nullptr;          // window table of g = e(P,P)^sk (8-bit windows x 4): the baby step g^j of a table hit
   // fixed-base window tables for P and Q (built on first use)
   uint32_t* d_tabP = nullptr;
@@ -141,6 +143,13 @@ struct bgn_ctx {
   uint8_t* arena = nullptr;
   size_t arena_bytes = 0;
 
+  // device memory held by this context (ctx_malloc / ctx_free below), and the cap set through
+  // bgn_ctx_set_memory_budget (0: none)
+  std::mutex mem_mu;
+  std::unordered_map<void*, size_t> allocs;
+  size_t held = 0;
+  size_t mem_budget = 0;
+
   // measurement hooks
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
@@ -163,11 +172,76 @@ struct bgn_ctx {
 
 namespace {
 
+// Device memory of a context goes through these two: bgn_ctx_memory_bytes reports what it holds, and a budget
+// (bgn_ctx_set_memory_budget) is a hard cap — an allocation that would exceed it fails like an exhausted device,
+// and the tables that are sized "from the free memory" see no more than the budget leaves (ctx_free_memory).
+// The reference keeps the tables of every key it has seen (gsbs.go:12-15, package globals); several keys sharing
+// one GPU need a way to bound each other.
+hipError_t ctx_malloc(bgn_ctx* c, void** p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    if (c->mem_budget && c->held + bytes > c->mem_budget) {
+      *p = nullptr;
+      return hipErrorOutOfMemory;
+    }
+  }
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    c->allocs[*p] = bytes;
+    c->held += bytes;
+  }
+  return e;
+}
+
+hipError_t ctx_free(bgn_ctx* c, void* p) {
+  if (!p) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    auto it = c->allocs.find(p);
+    if (it != c->allocs.end()) {
+      c->held -= it->second;
+      c->allocs.erase(it);
+    }
+  }
+  return hipFree(p);
+}
+
+// For memory derived from the secret key (its bytes, the line table and NAF of the secret order, the baby-step and
+// window tables of g = e(P,P)^sk): zeroed before it goes back to the allocator.
+hipError_t ctx_wipe_free(bgn_ctx* c, void* p) {
+  if (!p) return hipSuccess;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    auto it = c->allocs.find(p);
+    if (it != c->allocs.end()) bytes = it->second;
+  }
+  if (bytes) (void)hipMemset(p, 0, bytes);
+  return ctx_free(c, p);
+}
+
+// What the sizing rules of the per-key tables may count as free: the device's free memory, and under a budget no
+// more than the budget leaves.  `reclaimable`: bytes this context holds that the caller is about to give back.
+bool ctx_free_memory(bgn_ctx* c, size_t* free_bytes, size_t reclaimable = 0) {
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+  fr += reclaimable;
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  if (c->mem_budget) {
+    const size_t used = c->held > reclaimable ? c->held - reclaimable : 0;
+    const size_t left = c->mem_budget > used ? c->mem_budget - used : 0;
+    if (left < fr) fr = left;
+  }
+  *free_bytes = fr;
+  return true;
+}
+
 // Give MultPoly's cached line tables back (before sizing another large table against the free memory).
 void release_poly_tables(bgn_ctx* c) {
   if (!c->poly_tab) return;
   (void)hipDeviceSynchronize();
-  (void)hipFree(c->poly_tab);
+  (void)ctx_free(c, c->poly_tab);
   c->poly_tab = nullptr;
   c->poly_tab_bytes = 0;
 }
@@ -192,12 +266,21 @@ int ensure_arena(bgn_ctx* c, size_t bytes) {
   if (bytes <= c->arena_bytes) return BGN_OK;
   if (c->arena) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFree(c->arena));
+    HIP_TRY(ctx_free(c, c->arena));
     c->arena = nullptr;
     c->arena_bytes = 0;
   }
-  const size_t want = round_up(bytes + bytes / 8, 1 << 20);
-  HIP_TRY(hipMalloc((void**)&c->arena, want));
+  // some slack for the next, slightly larger batch; the exact size when that does not fit (a tight budget)
+  size_t want = round_up(bytes + bytes / 8, 1 << 20);
+  if (ctx_malloc(c, (void**)&c->arena, want) != hipSuccess) {
+    (void)hipGetLastError();
+    want = round_up(bytes, 1 << 20);
+    if (ctx_malloc(c, (void**)&c->arena, want) != hipSuccess) {
+      (void)hipGetLastError();
+      c->arena = nullptr;
+      return fail(BGN_E_NOMEM, "workspace of %zu MB: device memory or the context's memory budget exhausted", want >> 20);
+    }
+  }
   c->arena_bytes = want;
   return BGN_OK;
 }
@@ -295,28 +378,28 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   c->pipe.release();
-  if (c->arena) (void)hipFree(c->arena);
-  if (c->chain_ws) (void)hipFree(c->chain_ws);
-  if (c->mul_ws) (void)hipFree(c->mul_ws);
-  if (c->poly_tab) (void)hipFree(c->poly_tab);
-  if (c->d_params) (void)hipFree(c->d_params);
-  if (c->d_consts) (void)hipFree(c->d_consts);
-  if (c->d_keypts) (void)hipFree(c->d_keypts);
-  if (c->d_keywire) (void)hipFree(c->d_keywire);
+  if (c->arena) (void)ctx_free(c, c->arena);
+  if (c->chain_ws) (void)ctx_free(c, c->chain_ws);
+  if (c->mul_ws) (void)ctx_free(c, c->mul_ws);
+  if (c->poly_tab) (void)ctx_free(c, c->poly_tab);
+  if (c->d_params) (void)ctx_free(c, c->d_params);
+  if (c->d_consts) (void)ctx_free(c, c->d_consts);
+  if (c->d_keypts) (void)ctx_free(c, c->d_keypts);
+  if (c->d_keywire) (void)ctx_free(c, c->d_keywire);
   if (c->d_sk) {
     (void)hipMemset(c->d_sk, 0, c->sk_len);
-    (void)hipFree(c->d_sk);
+    (void)ctx_wipe_free(c, c->d_sk);
   }
   c->q1.wipe();
-  if (c->d_gt) (void)hipFree(c->d_gt);
-  if (c->d_table) (void)hipFree(c->d_table);
-  if (c->d_tabV) (void)hipFree(c->d_tabV);
-  if (c->d_fixedpair) (void)hipFree(c->d_fixedpair);
-  if (c->d_fixedpair_sk) (void)hipFree(c->d_fixedpair_sk);
-  if (c->d_consts_sk) (void)hipFree(c->d_consts_sk);
-  if (c->d_tabP) (void)hipFree(c->d_tabP);
-  if (c->d_tabQ) (void)hipFree(c->d_tabQ);
-  if (c->d_tabG) (void)hipFree(c->d_tabG);
+  if (c->d_gt) (void)ctx_wipe_free(c, c->d_gt);
+  if (c->d_table) (void)ctx_wipe_free(c, c->d_table);
+  if (c->d_tabV) (void)ctx_wipe_free(c, c->d_tabV);
+  if (c->d_fixedpair) (void)ctx_free(c, c->d_fixedpair);
+  if (c->d_fixedpair_sk) (void)ctx_wipe_free(c, c->d_fixedpair_sk);
+  if (c->d_consts_sk) (void)ctx_wipe_free(c, c->d_consts_sk);
+  if (c->d_tabP) (void)ctx_free(c, c->d_tabP);
+  if (c->d_tabQ) (void)ctx_free(c, c->d_tabQ);
+  if (c->d_tabG) (void)ctx_free(c, c->d_tabG);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_busy) (void)hipEventDestroy(c->ev_busy);
@@ -359,6 +442,10 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   c->nl = kt->nl;
   c->kt = kt;
   c->deterministic = deterministic != 0;
+  if (const char* ev = getenv("BGN_CTX_MEMORY_BUDGET_MB")) {          // default budget of every context (0: none)
+    const long long v = atoll(ev);
+    if (v > 0) c->mem_budget = (size_t)v << 20;
+  }
 
   int rc = BGN_OK;
   do {
@@ -375,7 +462,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
       break;                                                                   \
     }                                                                          \
   }
-    HIP_BRK(hipMalloc(&c->d_params, kt->params_bytes));
+    HIP_BRK(ctx_malloc(c, (void**)&c->d_params, kt->params_bytes));
     HIP_BRK(hipMemcpy(c->d_params, img.data(), kt->params_bytes, hipMemcpyHostToDevice));
 
     PairingConsts pc;
@@ -405,15 +492,15 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
         c->pair_ws_slots = 3 + 4 + 6 * (((1 << (w - 1)) - 2) / 2);
       }
     }
-    HIP_BRK(hipMalloc((void**)&c->d_consts, sizeof pc));
+    HIP_BRK(ctx_malloc(c, (void**)&c->d_consts, sizeof pc));
     HIP_BRK(hipMemcpy(c->d_consts, &pc, sizeof pc, hipMemcpyHostToDevice));
     c->pc_host = pc;
 
     // key points -> Montgomery SoA (stride 1)
-    HIP_BRK(hipMalloc((void**)&c->d_keywire, (size_t)6 * c->L));
+    HIP_BRK(ctx_malloc(c, (void**)&c->d_keywire, (size_t)6 * c->L));
     HIP_BRK(hipMemcpy(c->d_keywire, P_wire, (size_t)2 * c->L, hipMemcpyHostToDevice));
     HIP_BRK(hipMemcpy(c->d_keywire + 2 * c->L, Q_wire, (size_t)2 * c->L, hipMemcpyHostToDevice));
-    HIP_BRK(hipMalloc((void**)&c->d_keypts, (size_t)8 * c->nl * 4));
+    HIP_BRK(ctx_malloc(c, (void**)&c->d_keypts, (size_t)8 * c->nl * 4));
     HIP_BRK(hipMemset(c->d_keypts, 0, (size_t)8 * c->nl * 4));
     kt->decode(nullptr, c->d_params, c->d_keywire, c->L, 1, SoA2{c->d_keypts, c->d_keypts + c->nl, nullptr, 1});
     kt->decode(nullptr, c->d_params, c->d_keywire + 2 * c->L, c->L, 1,
@@ -426,7 +513,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
       for (size_t i = 1; i + 1 < naf.size(); ++i)
         if (naf[i] != 0) steps++;
       c->miller_steps = steps;
-      HIP_BRK(hipMalloc((void**)&c->d_fixedpair, steps * 3 * (size_t)c->nl * 4));
+      HIP_BRK(ctx_malloc(c, (void**)&c->d_fixedpair, steps * 3 * (size_t)c->nl * 4));
       kt->fixedpair_build(nullptr, c->d_params, c->d_consts, c->d_keypts, c->d_keypts + c->nl, c->d_fixedpair);
       c->fixed_normalized = fixed_normalize_enabled();
       if (c->fixed_normalized && (rc = normalize_key_table(c, c->d_fixedpair, steps)) != BGN_OK) break;
@@ -462,8 +549,8 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
 // P' (a per-key constant like the table of P), and the power by q1 that decrypt performs anyway completes
 // the exponent.  Same value as before, bit for bit.  BGN_DECRYPT_ORDER_TABLE=0 keeps the e(P, .) table.
 int build_secret_order_table(bgn_ctx* c) {
-  if (c->d_fixedpair_sk) (void)hipFree(c->d_fixedpair_sk);
-  if (c->d_consts_sk) (void)hipFree(c->d_consts_sk);
+  if (c->d_fixedpair_sk) (void)ctx_wipe_free(c, c->d_fixedpair_sk);
+  if (c->d_consts_sk) (void)ctx_wipe_free(c, c->d_consts_sk);
   c->d_fixedpair_sk = nullptr;
   c->d_consts_sk = nullptr;
   if (const char* ev = getenv("BGN_DECRYPT_ORDER_TABLE"))
@@ -490,9 +577,9 @@ int build_secret_order_table(bgn_ctx* c) {
   size_t steps = naf.size() - 1;
   for (size_t i = 1; i + 1 < naf.size(); ++i)
     if (naf[i] != 0) steps++;
-  HIP_TRY(hipMalloc((void**)&c->d_consts_sk, sizeof pc));
+  HIP_TRY(ctx_malloc(c, (void**)&c->d_consts_sk, sizeof pc));
   HIP_TRY(hipMemcpy(c->d_consts_sk, &pc, sizeof pc, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&c->d_fixedpair_sk, steps * 3 * (size_t)c->nl * 4));
+  HIP_TRY(ctx_malloc(c, (void**)&c->d_fixedpair_sk, steps * 3 * (size_t)c->nl * 4));
   c->kt->fixedpair_build(nullptr, c->d_params, c->d_consts_sk, Pq.c0, Pq.c1, c->d_fixedpair_sk);
   if (c->fixed_normalized) {
     int rcn = normalize_key_table(c, c->d_fixedpair_sk, steps);
@@ -504,26 +591,47 @@ int build_secret_order_table(bgn_ctx* c) {
 }
 }  // namespace
 
+uint64_t bgn_ctx_memory_bytes(bgn_ctx* c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  return (uint64_t)c->held;
+}
+
+int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes) {
+  if (!c) return fail(BGN_E_ARG, "null context");
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  c->mem_budget = (size_t)bytes;
+  return BGN_OK;
+}
+
 int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   if (!c || !q1_be || !q1_len) return fail(BGN_E_ARG, "null argument");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  c->q1.wipe();
-  c->q1 = BigU::from_be(q1_be, q1_len);
-  if (c->q1.is_zero()) return fail(BGN_E_ARG, "secret key is zero");
-  HIP_TRY(hipDeviceSynchronize());
-  if (c->d_sk) {
-    (void)hipMemset(c->d_sk, 0, c->sk_len);
-    (void)hipFree(c->d_sk);
+  // validate before anything of the current key is touched: a rejected key leaves the context as it was
+  BigU q1 = BigU::from_be(q1_be, q1_len);
+  if (q1.is_zero()) {
+    q1.wipe();
+    return fail(BGN_E_ARG, "secret key is zero");
   }
-  c->d_sk = nullptr;
+  HIP_TRY(hipDeviceSynchronize());
   c->have_secret = false;
   c->have_tables = false;
-  HIP_TRY(hipMalloc((void**)&c->d_sk, q1_len));
+  c->q1.wipe();
+  c->q1 = q1;
+  q1.wipe();
+  (void)ctx_wipe_free(c, c->d_sk);
+  c->d_sk = nullptr;
+  // the decryption tables of the previous secret go with it (bgn_ctx_setup_decryption builds the new ones)
+  (void)ctx_wipe_free(c, c->d_table);
+  c->d_table = nullptr;
+  c->bsgs_slots = 0;
+  (void)ctx_wipe_free(c, c->d_tabV);
+  c->d_tabV = nullptr;
+  HIP_TRY(ctx_malloc(c, (void**)&c->d_sk, q1_len));
   HIP_TRY(hipMemcpy(c->d_sk, q1_be, q1_len, hipMemcpyHostToDevice));
   c->sk_len = q1_len;
   c->have_secret = true;
-  c->have_tables = false;
   return build_secret_order_table(c);
 }
 
@@ -556,8 +664,10 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   // BGN_BSGS_MAX_LOG2 overrides (4..31).  The build takes 0.73 s at 2^31 entries (two products per entry).
   int cap_log2 = 31;
   {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    // (the table this call replaces counts as free; under a memory budget "free" is what the budget leaves)
+    size_t free_b = 0;
+    const size_t old_table = c->d_table ? (size_t)c->bsgs_slots * sizeof(BsgsSlot) : 0;
+    if (ctx_free_memory(c, &free_b, old_table))
       while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > free_b / 3) cap_log2--;
   }
   if (const char* ev = getenv("BGN_BSGS_MAX_LOG2")) {
@@ -572,11 +682,17 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
 
   if (c->d_table) {
     HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(c->d_table);
+    (void)ctx_wipe_free(c, c->d_table);
   }
   c->d_table = nullptr;
-  if (!c->d_gt) HIP_TRY(hipMalloc((void**)&c->d_gt, (size_t)4 * c->nl * 4));
-  HIP_TRY(hipMalloc((void**)&c->d_table, slots * sizeof(BsgsSlot)));
+  if (!c->d_gt) HIP_TRY(ctx_malloc(c, (void**)&c->d_gt, (size_t)4 * c->nl * 4));
+  c->bsgs_slots = 0;
+  if (ctx_malloc(c, (void**)&c->d_table, slots * sizeof(BsgsSlot)) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(BGN_E_NOMEM, "baby-step table (%zu MB): device memory or the context's memory budget exhausted",
+                (size_t)(slots * sizeof(BsgsSlot)) >> 20);
+  }
+  c->bsgs_slots = slots;
   HIP_TRY(hipMemset(c->d_table, 0, slots * sizeof(BsgsSlot)));
   // scratch: two single GT elements and an 8-byte scalar
   int rc = ensure_arena(c, 1 << 16);
@@ -614,9 +730,9 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   {
     const int wbits = 8, W = 4;
     const size_t bytes = ((size_t)W << wbits) * 2 * (size_t)c->nl * 4;
-    if (c->d_tabV) (void)hipFree(c->d_tabV);
+    if (c->d_tabV) (void)ctx_wipe_free(c, c->d_tabV);
     c->d_tabV = nullptr;
-    HIP_TRY(hipMalloc((void**)&c->d_tabV, bytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_tabV, bytes));
     HIP_TRY(hipMemset(c->d_tabV, 0, bytes));
     kt->gt_tab_pows(nullptr, c->d_params, g.c0, g.c1, wbits, W, c->d_tabV);
     for (int k = 1; k < wbits; ++k) {
@@ -990,11 +1106,11 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
       // the thread's last error, which the callers' hipGetLastError() after the launches would report although
       // the binary-ladder fallback ran: clear it.  BGN_TEST_FAIL_MUL_WS forces the failure (tests).
       uint8_t* fresh = nullptr;
-      ok = !getenv("BGN_TEST_FAIL_MUL_WS") && hipMalloc((void**)&fresh, need) == hipSuccess;
+      ok = !getenv("BGN_TEST_FAIL_MUL_WS") && ctx_malloc(c, (void**)&fresh, need) == hipSuccess;
       if (ok) {
         if (c->mul_ws) {
           (void)hipDeviceSynchronize();
-          (void)hipFree(c->mul_ws);
+          (void)ctx_free(c, c->mul_ws);
         }
         c->mul_ws = fresh;
         c->mul_ws_bytes = need;
@@ -1025,10 +1141,10 @@ int fixed_window_bits(bgn_ctx* c) {
     if (v == 8 || v == 16) wbits = v;
   }
   if (wbits == 16) {   // fall back to the small layout when the device is short of memory
-    size_t fr = 0, tot = 0;
+    size_t fr = 0;
     const size_t W = (size_t)(c->n.bits() + 15) / 16 + 1;
     const size_t need = 2 * (W << 16) * 2 * (size_t)c->nl * 4;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 4 * need) wbits = 8;
+    if (!ctx_free_memory(c, &fr) || fr < 4 * need) wbits = 8;
   }
   return wbits;
 }
@@ -1046,10 +1162,10 @@ int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
   }
   if (wbits < wbits_p) wbits = wbits_p;
   while (wbits > wbits_p) {
-    size_t fr = 0, tot = 0;
+    size_t fr = 0;
     const size_t W = (size_t)(c->n.bits() + wbits - 1) / wbits + 1;
     const size_t need = (W << wbits) * 2 * (size_t)c->nl * 4;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= 4 * need) break;
+    if (ctx_free_memory(c, &fr) && fr >= 4 * need) break;
     wbits--;
   }
   return wbits;
@@ -1093,9 +1209,10 @@ int ensure_fixed_tables(bgn_ctx* c) {
   uint32_t* tabs[2] = {nullptr, nullptr};
   for (int b = 0; b < 2; ++b) {
     const size_t tab_bytes = ((size_t)W[b] << wb[b]) * 2 * (size_t)c->nl * 4;
-    if (hipMalloc((void**)&tabs[b], tab_bytes) != hipSuccess) {
-      if (tabs[0]) (void)hipFree(tabs[0]);
-      return fail(BGN_E_NOMEM, "fixed-base window tables");
+    if (ctx_malloc(c, (void**)&tabs[b], tab_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      if (tabs[0]) (void)ctx_free(c, tabs[0]);
+      return fail(BGN_E_NOMEM, "fixed-base window tables (%zu MB)", tab_bytes >> 20);
     }
     HIP_TRY(hipMemset(tabs[b], 0, tab_bytes));
   }
@@ -1170,12 +1287,12 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
     if (need > c->chain_ws_bytes) {
       if (c->chain_ws) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(c->chain_ws));
+        HIP_TRY(ctx_free(c, c->chain_ws));
         c->chain_ws = nullptr;
         c->chain_ws_bytes = 0;
       }
       const size_t want = round_up(need + need / 8, 1 << 20);
-      if (hipMalloc((void**)&c->chain_ws, want) != hipSuccess) return fail(BGN_E_NOMEM, "fixed-base chain workspace");
+      if (ctx_malloc(c, (void**)&c->chain_ws, want) != hipSuccess) return fail(BGN_E_NOMEM, "fixed-base chain workspace");
       c->chain_ws_bytes = want;
     }
     Carver cv(c->chain_ws);
@@ -1310,7 +1427,10 @@ int ensure_gt_table(bgn_ctx* c) {
   const int W = (c->n.bits() + wbits - 1) / wbits + 1;
   const size_t bytes = ((size_t)W << wbits) * 2 * (size_t)c->nl * 4;
   uint32_t* tab = nullptr;
-  if (hipMalloc((void**)&tab, bytes) != hipSuccess) return fail(BGN_E_NOMEM, "GT window table");
+  if (ctx_malloc(c, (void**)&tab, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(BGN_E_NOMEM, "GT window table");
+  }
   HIP_TRY(hipMemset(tab, 0, bytes));
   const SoA2 g = c->key_eQQ();
   // e(Q,Q) (bgn.go:306,469): one pairing per key, here rather than at context creation so that keys used
@@ -1643,10 +1763,10 @@ int host_pipeline(bgn_ctx* c, size_t count, const std::vector<PipeArray>& arrays
   for (size_t i = 0; i < na * kPipeSlots; ++i) {
     const size_t need = chunk * arrays[i % na].stride;
     if (S.cap[i] >= need) continue;
-    if (S.buf[i]) (void)hipFree(S.buf[i]);
+    if (S.buf[i]) (void)ctx_free(c, S.buf[i]);
     S.buf[i] = nullptr;
     S.cap[i] = 0;
-    hipError_t e = hipMalloc(&S.buf[i], need);
+    hipError_t e = ctx_malloc(c, &S.buf[i], need);
     if (e != hipSuccess) {
       S.buf[i] = nullptr;
       return fail(BGN_E_HIP, "hipMalloc(%zu): %s", need, hipGetErrorString(e));
@@ -2014,9 +2134,9 @@ namespace {
 size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
   if (const char* ev = getenv("BGN_POLY_TABLES"))
     if (ev[0] == '0') return 0;
-  size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-  size_t budget = (fr + c->poly_tab_bytes) / 3;          // the cached tables count as free
+  size_t fr = 0;
+  if (!ctx_free_memory(c, &fr, c->poly_tab_bytes)) return 0;   // the cached tables count as free
+  size_t budget = fr / 3;
   if (const char* ev = getenv("BGN_POLY_TABLE_MAX_MB")) {
     const long v = atol(ev);
     if (v > 0 && ((size_t)v << 20) < budget) budget = (size_t)v << 20;
@@ -2068,7 +2188,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     const size_t need = c->miller_steps * 3 * (size_t)c->nl * 4 * ts;
     if (need > c->poly_tab_bytes) {
       release_poly_tables(c);
-      if (hipMalloc((void**)&c->poly_tab, need) != hipSuccess) return fail(BGN_E_NOMEM, "MultPoly line tables (%zu MB)", need >> 20);
+      if (ctx_malloc(c, (void**)&c->poly_tab, need) != hipSuccess) return fail(BGN_E_NOMEM, "MultPoly line tables (%zu MB)", need >> 20);
       c->poly_tab_bytes = need;
     }
     tab = c->poly_tab;

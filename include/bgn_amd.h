@@ -81,6 +81,20 @@ const char* bgn_last_error(void);
 /* Library version string. */
 const char* bgn_version(void);
 
+/* Device memory.  The reference keeps the decryption tables of every key it has seen (gsbs.go:12-15: package
+ * globals filled by computeTableG1/GT, gsbs.go:41-51); here every per-key table (BSGS baby table, fixed-base window
+ * tables of P and Q, GT window tables, MultPoly's line tables) and the batch workspace belong to the context.
+ * bgn_ctx_memory_bytes: bytes of device memory the context holds now.
+ * bgn_ctx_set_memory_budget: a cap on that figure (0 = none, the default; BGN_CTX_MEMORY_BUDGET_MB sets a default
+ * for every context).  Tables built afterwards are sized within it — the rules that otherwise take a share of the
+ * device's free memory (a third for the baby table, a quarter for Q's windows, a third for MultPoly's tables) see no
+ * more than the budget leaves — and an allocation that would exceed it fails with BGN_E_NOMEM like an exhausted
+ * device; what the context already holds is not given back.  Set it right after bgn_ctx_create so that several
+ * keys can share one GPU (a 1024-bit key with T = 2^40 takes up to 69 GB for the baby table, 17 - 60 GB for Q's
+ * windows and 7.8 GB of workspace per 2^20-element batch without one). */
+uint64_t bgn_ctx_memory_bytes(bgn_ctx* c);
+int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes);
+
 /* Install the secret key q1 (SecretKey.Key, bgn.go:59) for decryption. */
 int bgn_ctx_set_secret(bgn_ctx* ctx, const uint8_t* q1_be, size_t q1_len);
 

@@ -129,6 +129,9 @@ CONFIGS = [
     ("k256", 256, 1021, 12, 8, 6, (2, 3)),
     ("k512", 512, 1021, 1, 8, 6, (2, 3)),          # bgn_test.go:8-13 constants
     ("k1024", 1024, 1 << 40, 1, 8, 6, (2, 2)),     # BASELINE.json configs[1..4]
+    # a second 1024-bit key (l = 6336: p has 1037 bits, the top of the range A1 parameters reach at this size) for
+    # the tests that keep two keys resident on one GPU
+    ("k1024b", 1024, 1 << 40, 4242, 8, 5, (2, 2)),
 ]
 
 if __name__ == "__main__":

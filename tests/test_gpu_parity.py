@@ -479,6 +479,22 @@ def test_decrypt_with_unusual_secrets_does_not_misbehave():
     assert not st.any() and [int(v) for v in m] == [5, 0, 9]
 
 
+def test_a_rejected_secret_leaves_the_context_as_it_was():
+    """bgn_ctx_set_secret validates before it touches the current key: a zero key is refused (BGN_E_ARG) and the
+    decryption state set up before keeps working."""
+    from bgn_amd._lib import BGN_E_ARG
+    fx = load_fixture("k256")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    cts = pk.EncryptBatch([5, 0, 9], [11, 0, 13])
+    wire = b"".join(c.C for c in cts)
+    eng = pk.engine
+    assert eng._lib.bgn_ctx_set_secret(eng._h, bytes(4), 4) == BGN_E_ARG       # four zero bytes: the key 0
+    assert b"zero" in eng._lib.bgn_last_error()
+    m, st = pk.engine.decrypt(1, wire)                        # same secret, same tables
+    assert not st.any() and [int(v) for v in m] == [5, 0, 9]
+
+
 @pytest.mark.parametrize("name,count", [("toy64", 300), ("k256", 65), ("k512", 5)])
 def test_multconst_windowed_vs_oracle(name, count):
     """MultConst on level 1 with scalars of 128 bits and more runs over a per-element table of multiples (4-bit

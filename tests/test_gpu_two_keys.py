@@ -1,0 +1,93 @@
+"""GPU: two 1024-bit keys with decryption set up (T = 2^40) resident on ONE GPU, each under a memory budget
+(bgn_ctx_set_memory_budget), Mult / Encrypt / Decrypt interleaved between them.  The reference keeps the tables of
+every key it has seen (gsbs.go:12-15: package globals filled by computeTableG1/GT, gsbs.go:41-51); without a budget
+one such key sizes its tables from the free memory at the moment they are built (up to 69 GB of baby steps, 17 - 60
+GB of window tables), which leaves a second key whatever happens to remain."""
+import random
+
+import numpy as np
+import pytest
+
+import bgn_amd
+from bgn_amd._lib import BGN_E_NOMEM, BgnError
+from conftest import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+GB = 1 << 30
+
+
+def fresh_key(fx):
+    pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                           fx["msg_space"], True, fx["poly_base"])
+    return pk, bgn_amd.SecretKey(int(fx["q1"], 16))
+
+
+def H(hexes):
+    return b"".join(bytes.fromhex(h) for h in hexes)
+
+
+def test_two_1024_bit_keys_decrypt_side_by_side_within_their_budgets():
+    fxs = [load_fixture("k1024"), load_fixture("k1024b")]
+    assert fxs[0]["msg_space"] == fxs[1]["msg_space"] == 1 << 40 and fxs[0]["p"] != fxs[1]["p"]
+    budget = 48 * GB
+    keys = []
+    for fx in fxs:
+        pk, sk = fresh_key(fx)
+        small = pk.engine.memory_bytes()
+        assert 0 < small < GB                                   # the key's own constants and line table only
+        pk.engine.set_memory_budget(budget)
+        keys.append((fx, pk, sk))
+    for fx, pk, sk in keys:                                     # both tables built before either key is used
+        pk.SetupDecryption(sk)
+        held = pk.engine.memory_bytes()
+        assert 8 * GB < held <= budget, held                    # a baby table within a third of the budget
+    rng = random.Random(2024)
+    T = 1 << 40
+    plain = {}
+    for rnd in range(2):                                        # interleaved: A, B, A, B
+        for fx, pk, sk in keys:
+            eng = pk.engine
+            n = int(fx["n"], 16)
+            cts = [e["ct"] for e in fx["encrypt"]]
+            # Mult: the key's golden vectors (single-key results)
+            out = eng.mult(H([cts[v["a"]] for v in fx["mult"]]), H([cts[v["b"]] for v in fx["mult"]]))
+            for row, v in zip(out, fx["mult"]):
+                assert bytes(row).hex() == v["out"], fx["name"]
+            # Encrypt (builds the window tables inside the budget) and Decrypt: full-range messages, a negative one,
+            # one beyond the bound
+            ms = [0, 1, T - 1, rng.randrange(T), rng.randrange(T), rng.randrange(1 << 20)]
+            enc = eng.encrypt(ms + [3 * T + 17], [rng.randrange(n) for _ in range(len(ms) + 1)]).copy()
+            enc[3] = eng.neg(1, enc[3:4])[0]
+            m, st = eng.decrypt(1, enc.tobytes())
+            want = list(ms)
+            want[3] = -want[3]
+            assert st.tolist() == [0] * len(ms) + [1]
+            assert m.tolist()[: len(ms)] == want
+            plain.setdefault(fx["name"], []).append(m.tolist())
+            # the golden Decrypt vectors of both levels
+            for lvl in (1, 2):
+                rows = [d for d in fx["decrypt"] if d["level"] == lvl]
+                m2, st2 = eng.decrypt(lvl, H([d["ct"] for d in rows]))
+                assert st2.tolist() == [0] * len(rows) and m2.tolist() == [d["m"] for d in rows]
+            assert eng.memory_bytes() <= budget
+    total = sum(pk.engine.memory_bytes() for _, pk, _ in keys)
+    assert total <= 2 * budget
+
+
+def test_the_budget_is_a_hard_cap_and_can_be_raised():
+    fx = load_fixture("k1024")
+    pk, sk = fresh_key(fx)
+    eng = pk.engine
+    eng.set_memory_budget(eng.memory_bytes() + (1 << 20))       # room for one more megabyte
+    cts = [e["ct"] for e in fx["encrypt"]]
+    reps = 3000                                                 # a batch whose workspace needs far more than that
+    a = H([cts[v["a"]] for v in fx["mult"]]) * reps
+    b = H([cts[v["b"]] for v in fx["mult"]]) * reps
+    with pytest.raises(BgnError) as ei:
+        eng.mult(a, b)
+    assert ei.value.code == BGN_E_NOMEM and "budget" in str(ei.value)
+    eng.set_memory_budget(0)
+    out = eng.mult(a, b)                                        # the context is usable again
+    assert bytes(out[1]).hex() == fx["mult"][1]["out"]
+    assert np.array_equal(out[: len(fx["mult"])], out[len(fx["mult"]): 2 * len(fx["mult"])])

@@ -189,7 +189,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
     import bgn_amd.synthetic as syn
     eng = pk.engine
     EB = eng.elem_bytes
-    nl = 38
+    nl = syn.limbs_for(int(fx["p"], 16))
     sync = torch.cuda.synchronize
     out = {}
     n_enc = xs.shape[0]
@@ -254,7 +254,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
                          % (k, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))),
              "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
             syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
-        # the dominant kernel of Decrypt is the lift (k_pairing<38, 1>), timed by HIP events on its stream
+        # the dominant kernel of Decrypt is the lift (k_pairing<NL, 1>), timed by HIP events on its stream
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
         if k == 20 and os.path.exists(pmc):                     # separate rocprofv3 --pmc passes of this command
@@ -563,11 +563,11 @@ def main():
             "metric": "EMult pairings/sec at 1024-bit, batch=2^%d per GPU" % args.batch_log2,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (28-bit limbs, 64-bit accumulators)", "data": "synthetic",
+            "dtype": "u32 (29-bit limbs, 64-bit accumulators)", "data": "synthetic",
             "config": {"workload": "configs[2]: 1024-bit params, batch=2^%d EMult (Tate pairing G1xG1->GT, "
                                    "Miller+final-exp) per MI355X; operands = Config 2's Encrypt outputs (random 40-bit "
                                    "m, full-length r) x a fixed permutation of them" % args.batch_log2,
-                       "key": fx["name"], "fp_bits": int(fx["p"], 16).bit_length(), "limbs28": 38,
+                       "key": fx["name"], "fp_bits": int(fx["p"], 16).bit_length(), "limbs29": syn.limbs_for(int(fx["p"], 16)),
                        "batch_per_gpu": per_gpu, "global_batch": total, "rccl_ranks": rccl_ranks,
                        "distinct_pairs_in_checked_prefix": distinct,
                        "parallelism": ("batch-sharded x%d, one process per GPU + RCCL all-gather of results" % world)
@@ -646,7 +646,7 @@ def decrypt_sharded(pk, fx, dev, cts, xs, world, rank, dist, timed_region, args)
                      "out of range; sharded by ciphertext, plaintexts and statuses all-gathered (RCCL); baby table of %d "
                      "entries per GPU" % (args.batch_log2, S),
          "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
-        syn.decrypt_counts(fx, S), 38, n_gpus=world)
+        syn.decrypt_counts(fx, S), syn.limbs_for(int(fx["p"], 16)), n_gpus=world)
     e["roofline"] = {"bound": "hbm", "achieved": alg * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "kernel": eng.last_aux_kernel_name(), "kernel_ms": k_ms, "algorithmic_bytes_per_decrypt": alg,
@@ -710,11 +710,11 @@ def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
         pairs = npoly * d1 * d2
         value = pairs * args.steps / dt
         ppp, sqp = syn.multpoly_counts_per_pair(fx, d1)
-        mpp = syn.mads_from_counts(ppp, sqp, 38)
+        mpp = syn.mads_from_counts(ppp, sqp, syn.limbs_for(int(fx["p"], 16)))
         line = {"metric": "MultPoly coefficient pairs/sec at 1024-bit (configs[4])", "value": value,
                 "unit": "coefficient pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "u32 (28-bit limbs, 64-bit accumulators)", "data": "synthetic",
+                "vs_baseline": None, "dtype": "u32 (29-bit limbs, 64-bit accumulators)", "data": "synthetic",
                 "config": {"workload": "configs[4]: 1024-bit poly.go MultPoly of 2^%d pairs of 16x16 coefficient "
                                        "polynomials (2^%d coefficient pairs) + one AddPoly, sharded by polynomial over "
                                        "%d GPU(s) + RCCL all-gather" % (args.polys_log2, args.polys_log2 + 8, world),

@@ -41,16 +41,16 @@ __device__ __forceinline__ unsigned long long bsgs_mix(unsigned long long x) {
   return x;
 }
 
-// 96-bit fingerprint of a canonical value (limbs 0..3 and 4 bits of limb 4)
+// 96-bit fingerprint of a canonical value: its low 64 bits (bit 63 forced) and the 32 bits above them
 template <int NL>
 __device__ __forceinline__ void bsgs_fingerprint(unsigned long long& key, u32& check, const Fp<NL>& c) {
-  u64 k = (u64)c.v[0] | ((u64)c.v[1] << 28);
-  if (NL > 2) k |= (u64)c.v[2] << 56;
+  u64 k = (u64)c.v[0] | ((u64)c.v[1] << LIMB_BITS);
+  if (NL > 2) k |= (u64)c.v[2] << (2 * LIMB_BITS);
   key = k | (1ull << 63);
-  u32 ck = 0;
-  if (NL > 3) ck = c.v[3];
-  if (NL > 4) ck |= c.v[4] << 28;
-  if (NL <= 3) ck = c.v[2] >> 8;
+  // bits 64 .. 95: what is left of limb 2 above bit 63, then limbs 3 and 4
+  constexpr int R2 = 3 * LIMB_BITS - 64;                     // bits of limb 2 beyond the key (23 at radix 2^29)
+  u32 ck = NL > 2 ? c.v[2 < NL ? 2 : 0] >> (LIMB_BITS - R2) : 0u;
+  if (NL > 3) ck |= c.v[3 < NL ? 3 : 0] << R2;
   check = ck;
 }
 // ... shortened to the bits the table was built with (BsgsParams::key_keep / check_keep: all of them in

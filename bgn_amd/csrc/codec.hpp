@@ -1,4 +1,4 @@
-// codec.hpp — PBC wire bytes <-> 28-bit limbs (device functions).
+// codec.hpp — PBC wire bytes <-> LIMB_BITS-bit limbs (device functions).
 #pragma once
 #include "fp28.hpp"
 
@@ -6,33 +6,32 @@ namespace bgn {
 
 // ---- wire codec -----------------------------------------------------------
 // PBC wire format (Element.Bytes(), ciphertext.go:79; SetBytes, bgn.go:518-521):
-// each F_p value big-endian in L bytes.  7 bytes = 56 bits = two 28-bit limbs.
+// each F_p value big-endian in L bytes.  Limb k holds bits [LIMB_BITS*k, LIMB_BITS*(k+1)) of the value: five
+// consecutive bytes always contain it.
 template <int NL>
 __device__ __forceinline__ void wire_to_limbs(Fp<NL>& r, const uint8_t* __restrict__ src, int L) {
 #pragma unroll
-  for (int k = 0; k < (NL + 1) / 2; ++k) {
+  for (int k = 0; k < NL; ++k) {
+    const int b0 = (LIMB_BITS * k) >> 3, sh = (LIMB_BITS * k) & 7;     // lowest byte (counted from the value's end)
     u64 v = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int idx = 7 * k + i;
+    for (int i = 0; i < 5; ++i) {
+      const int idx = b0 + i;
       if (idx < L) v |= (u64)src[L - 1 - idx] << (8 * i);
     }
-    r.v[2 * k] = (u32)v & LIMB_MASK;
-    if (2 * k + 1 < NL) r.v[2 * k + 1] = (u32)(v >> LIMB_BITS) & LIMB_MASK;
+    r.v[k] = (u32)(v >> sh) & LIMB_MASK;
   }
 }
 
 template <int NL>
 __device__ __forceinline__ void limbs_to_wire(uint8_t* __restrict__ dst, int L, const Fp<NL>& a) {
+  constexpr int BMAX = (LIMB_BITS * NL + 7) / 8;
 #pragma unroll
-  for (int k = 0; k < (NL + 1) / 2; ++k) {
-    u64 v = a.v[2 * k];
-    if (2 * k + 1 < NL) v |= (u64)a.v[2 * k + 1] << LIMB_BITS;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int idx = 7 * k + i;
-      if (idx < L) dst[L - 1 - idx] = (uint8_t)(v >> (8 * i));
-    }
+  for (int idx = 0; idx < BMAX; ++idx) {
+    const int k0 = (8 * idx) / LIMB_BITS, o = 8 * idx - LIMB_BITS * k0;
+    u32 v = a.v[k0 < NL ? k0 : 0] >> o;
+    if (k0 + 1 < NL && o + 8 > LIMB_BITS) v |= a.v[k0 + 1 < NL ? k0 + 1 : 0] << (LIMB_BITS - o);
+    if (idx < L) dst[L - 1 - idx] = (uint8_t)v;
   }
 }
 
@@ -40,9 +39,9 @@ __device__ __forceinline__ void limbs_to_wire(uint8_t* __restrict__ dst, int L, 
 // The byte-by-byte forms above cost seven LDS byte reads and a dozen shifts per limb pair: ~2.6 k instructions
 // per element, more than a field product.  When an element is a whole number of dwords (L even: every lane's
 // element then has the same alignment inside the stage) and the stage holds the slice dword-aligned, the same
-// conversion runs on dwords.  Decoding: a 28-bit limb lies inside four consecutive bytes of the big-endian
-// string, i.e. inside two adjacent dwords — one 8-byte LDS read, one v_perm_b32 (the four bytes, most
-// significant first), one shift-and-mask.  Encoding: the element x || y read backwards is the little-endian
+// conversion runs on dwords.  Decoding: a limb lies inside five consecutive bytes of the big-endian string, i.e.
+// inside two adjacent dwords — one 8-byte LDS read, one v_perm_b32, a bit-field extract and a funnel shift.
+// Encoding: the element x || y read backwards is the little-endian
 // number y + x * 2^(8L); its dwords are funnel shifts of the limbs, byte-swapped into place.  Every position
 // depends on the limb / dword index (compile time after unrolling) and on L (wave-uniform): scalar arithmetic.
 __device__ __forceinline__ u32 codec_perm(u32 hi, u32 lo, u32 sel) {
@@ -59,7 +58,9 @@ __device__ __forceinline__ u32 codec_perm(u32 hi, u32 lo, u32 sel) {
 __device__ __forceinline__ bool codec_dword_ok(int L, u32 mis) { return (L & 1) == 0 && L >= 4 && mis == 0; }
 
 // Limbs of the big-endian L-byte value that starts `off` bytes into the lane's element; `we` points at the
-// element's first dword.  Reads at most one dword past the value (the stage has the slack).
+// element's first dword.  A limb lies inside five consecutive bytes of the string, i.e. inside two adjacent
+// dwords: one 8-byte LDS read, one v_perm_b32 for the lower four bytes (most significant first), one bit-field
+// extract for the fifth, one funnel shift.  Reads at most one dword past the value (the stage has the slack).
 template <int NL>
 __device__ __forceinline__ void wire_to_limbs_dw(Fp<NL>& r, const u32* __restrict__ we, int off, int L) {
 #pragma unroll
@@ -69,13 +70,16 @@ __device__ __forceinline__ void wire_to_limbs_dw(Fp<NL>& r, const u32* __restric
       r.v[k] = 0;
       continue;
     }
-    const int a = bx >= 3 ? bx - 3 : 0;                   // the four bytes [a, a+4) hold the limb (clamped at the top)
-    const int sh = ((LIMB_BITS * k) & 7) + 8 * (bx >= 3 ? 0 : 3 - bx);
+    const int a = bx >= 4 ? bx - 4 : 0;                   // the five bytes [a, a+5) hold the limb (clamped at the top)
+    const int sh = ((LIMB_BITS * k) & 7) + 8 * (bx >= 4 ? 0 : 4 - bx);
     const u32 byte = (u32)(off + a);
     const u32 q = byte >> 2, s = byte & 3u;
-    const u32 sel = (s << 24) | ((s + 1) << 16) | ((s + 2) << 8) | (s + 3);
-    const u32 v = codec_perm(we[q + 1], we[q], sel);      // bytes a .. a+3, most significant first
-    r.v[k] = (v >> sh) & LIMB_MASK;
+    const u32 w0 = we[q], w1 = we[q + 1];
+    const u32 sel = ((s + 1) << 24) | ((s + 2) << 16) | ((s + 3) << 8) | (s + 4);
+    const u32 lo = codec_perm(w1, w0, sel);               // bytes a+1 .. a+4, most significant first
+    const u32 hi = (w0 >> (8 * s)) & 0xFFu;               // byte a
+    const u64 v = ((u64)hi << 32) | lo;
+    r.v[k] = (u32)(v >> sh) & LIMB_MASK;
   }
 }
 
@@ -95,7 +99,7 @@ __device__ __forceinline__ void wire_element_dw(Fp<NL>& x, Fp<NL>& y, const u32*
   }
 }
 
-// Little-endian dword i of sum v[k] * 2^(28 k) (i is a constant once the caller's loop is unrolled).
+// Little-endian dword i of sum v[k] * 2^(LIMB_BITS k) (i is a constant once the caller's loop is unrolled).
 template <int NL>
 __device__ __forceinline__ u32 limbs_dword(const Fp<NL>& a, int i) {
   const int k0 = (32 * i) / LIMB_BITS, o = 32 * i - LIMB_BITS * k0;

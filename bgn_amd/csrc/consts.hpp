@@ -9,7 +9,12 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int32_t i32;
 
-constexpr int LIMB_BITS = 28;
+// Radix 2^29 since round 3 (2^28 before): 36 limbs instead of 38 at a 1024-bit key whose p has at most 1035 bits
+// (37 up to 1037), i.e. 2*36^2 = 2592 multiply-adds per product instead of 2888; a 64-bit accumulator then holds
+// the 2*NL products of < 2^58 of a column only up to NL = 31, so fp_mul flushes its accumulators once, half way
+// (fp28.hpp).  Measured in isolation (tools/ubench/fp_rates.hip, profiles/r03_fp_experiments.txt): 6.5 us per
+// product and wave against 7.1 - 8.5.
+constexpr int LIMB_BITS = 29;
 constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1u;
 constexpr int FP_BLOCK = 256;        // threads per workgroup of every field kernel
 constexpr int KP_MAX = 32;           // K*p tables for K = 1..32
@@ -25,7 +30,7 @@ struct PairingConsts {
   int l_bits;
   int pad;
   signed char naf[MAX_NAF];    // little-endian signed digits of n
-  u32 pm2[MAX_EXP_LIMBS];      // p-2 as 28-bit limbs (little-endian)
+  u32 pm2[MAX_EXP_LIMBS];      // p-2 as LIMB_BITS-bit limbs (little-endian)
   // width-w NAF of n (w = 3: digits 0, +-1, +-3; w = 4: up to +-7) for the windowed Miller loop of
   // pairing.hpp; wnaf_len = 0: not used
   int wnaf_len;

@@ -83,7 +83,7 @@ struct bgn_ctx {
   HostPipeState pipe;
   int device = 0;
   int L = 0;          // bytes per F_p value on the wire
-  int nl = 0;         // 28-bit limbs per F_p value on the device
+  int nl = 0;         // limbs (LIMB_BITS bits each) per F_p value on the device
   int p_bits = 0;
   bool deterministic = true;
   const KernelTable* kt = nullptr;
@@ -323,7 +323,8 @@ struct Carver {
 };
 
 const KernelTable* pick_table(int need_nl) {
-  const KernelTable* ts[] = {kernel_table_nl3(), kernel_table_nl10(), kernel_table_nl19(), kernel_table_nl38()};
+  const KernelTable* ts[] = {kernel_table_nl3(), kernel_table_nl10(), kernel_table_nl19(), kernel_table_nl36(),
+                             kernel_table_nl37()};
   for (const KernelTable* t : ts)
     if (t->nl >= need_nl) return t;
   return nullptr;
@@ -337,24 +338,24 @@ std::vector<uint32_t> build_params(const BigU& p, int nl) {
   uint32_t* one = P + nl;
   uint32_t* r2 = one + nl;
   uint32_t* kp = r2 + nl;
-  p.to_limbs28(P, nl);
+  p.to_limbs(P, nl, LIMB_BITS);
   BigU x((uint64_t)1);
-  for (int i = 0; i < 28 * nl; ++i) {
+  for (int i = 0; i < LIMB_BITS * nl; ++i) {
     x.shl1();
     if (BigU::cmp(x, p) >= 0) x.sub(p);
   }
-  x.to_limbs28(one, nl);
-  for (int i = 0; i < 28 * nl; ++i) {
+  x.to_limbs(one, nl, LIMB_BITS);
+  for (int i = 0; i < LIMB_BITS * nl; ++i) {
     x.shl1();
     if (BigU::cmp(x, p) >= 0) x.sub(p);
   }
-  x.to_limbs28(r2, nl);
+  x.to_limbs(r2, nl, LIMB_BITS);
   BigU k;
   for (int K = 1; K <= KP_MAX; ++K) {
     k.add(p);
-    k.to_limbs28(kp + (size_t)(K - 1) * nl, nl);
+    k.to_limbs(kp + (size_t)(K - 1) * nl, nl, LIMB_BITS);
   }
-  // pinv = -p^{-1} mod 2^28 (Newton iteration on the low limb; p is odd)
+  // pinv = -p^{-1} mod 2^LIMB_BITS (Newton iteration on the low limb; p is odd)
   const uint32_t p0 = P[0];
   uint32_t inv = 1;
   for (int i = 0; i < 6; ++i) inv *= 2u - p0 * inv;
@@ -420,9 +421,9 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   p1.add_small(1);
   if (BigU::cmp(ln, p1) != 0) return fail(BGN_E_PARAM, "p + 1 != l * n");
   if ((p.w[0] & 3u) != 3u) return fail(BGN_E_PARAM, "p != 3 mod 4");
-  const int need_nl = (p.bits() + 9 + 27) / 28;
+  const int need_nl = (p.bits() + 9 + LIMB_BITS - 1) / LIMB_BITS;
   const KernelTable* kt = pick_table(need_nl);
-  if (!kt) return fail(BGN_E_PARAM, "field of %d bits needs %d limbs; this build supports up to 38", p.bits(), need_nl);
+  if (!kt) return fail(BGN_E_PARAM, "field of %d bits needs %d limbs; this build supports up to 37", p.bits(), need_nl);
   std::vector<signed char> naf = n.naf();
   if ((int)naf.size() > MAX_NAF) return fail(BGN_E_PARAM, "group order too large");
 
@@ -472,11 +473,11 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     BigU pm2 = p;
     pm2.sub(BigU((uint64_t)2));
     pc.pm2_bits = pm2.bits();
-    if ((pm2.bits() + 27) / 28 > MAX_EXP_LIMBS) {
+    if ((pm2.bits() + LIMB_BITS - 1) / LIMB_BITS > MAX_EXP_LIMBS) {
       rc = fail(BGN_E_PARAM, "field too large");
       break;
     }
-    pm2.to_limbs28(pc.pm2, MAX_EXP_LIMBS);
+    pm2.to_limbs(pc.pm2, MAX_EXP_LIMBS, LIMB_BITS);
     pc.l = l;
     pc.l_bits = BigU(l).bits();
     {

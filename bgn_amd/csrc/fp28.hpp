@@ -291,22 +291,56 @@ __device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
 // r = a*b/R mod p, lazy (r < 2p).  The multiplier `a` is an LDS element whose
 // rows are streamed (next row pair prefetched while the current one is
 // multiplied); the multiplicand `b` sits in VGPRs.  r may alias b.
+// A 64-bit accumulator takes at most kRowsPerFlush rows (two products of < 2^(2*LIMB_BITS) each, or a doubled one
+// and a plain one in a squaring: 3 * 2^(2*LIMB_BITS - 1) per row) before it must be carried out: 18 at radix 2^29
+// — more rows than that (NL = 36, 37) and the product flushes once, half way.
+constexpr int kRowsPerFlush = LIMB_BITS >= 29 ? 19 : 64;
+template <int NL>
+constexpr bool kNeedsFlush = NL > kRowsPerFlush;
+
+// carry pass over the accumulators in place: every one back below 2^LIMB_BITS, the excess moved up
+template <int NL>
+__device__ __forceinline__ void fp_flush(u64 (&t)[NL]) {
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const u64 s = t[j] + c;
+    t[j] = s & (u64)LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+  // (the top accumulator's excess stays in it: the value is below 2^(LIMB_BITS*NL) * small)
+  t[NL - 1] += c << LIMB_BITS;
+}
+
 template <int NL>
 __device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b,
                                        const FpParams<NL>* __restrict__ P) {
   const int tid = threadIdx.x;
   constexpr int NP = NL / 2;
+  constexpr int NP0 = kNeedsFlush<NL> ? (NP + 1) / 2 : NP;       // row pairs before the flush
+  static_assert(2 * NP0 <= kRowsPerFlush && 2 * (NP - NP0) + (NL & 1) <= kRowsPerFlush, "one flush is enough");
   u64 t[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) t[j] = 0;
   u64 aa = a->rows[0][tid];
 #pragma unroll 1
-  for (int k = 0; k < NP; ++k) {
+  for (int k = 0; k < NP0; ++k) {
     const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
     const u64 nx = a->rows[kn][tid];
     fp_row<NL>(t, (u32)aa, b, P);
     fp_row<NL>(t, (u32)(aa >> 32), b, P);
     aa = nx;
+  }
+  if constexpr (kNeedsFlush<NL>) {
+    fp_flush<NL>(t);
+#pragma unroll 1
+    for (int k = NP0; k < NP; ++k) {
+      const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
+      const u64 nx = a->rows[kn][tid];
+      fp_row<NL>(t, (u32)aa, b, P);
+      fp_row<NL>(t, (u32)(aa >> 32), b, P);
+      aa = nx;
+    }
   }
   if (NL & 1) fp_row<NL>(t, (u32)aa, b, P);
   u64 c = 0;
@@ -389,31 +423,35 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
 #pragma unroll
     for (int j = 0; j < NL; ++j) t[j] = 0;
     u64 aa = a->rows[0][tid];
+    // A row of a squaring adds at most three product units of 2^(2*LIMB_BITS) to an accumulator (one doubled
+    // product and one reduction product) and a 64-bit accumulator holds 2^(64 - 2*LIMB_BITS) of them: at radix 2^29
+    // that is 21 rows, so 36 or 37 rows flush once, in front of segment FS.
+    constexpr int FS = kSquareSegments / 2;
+    static_assert(!kNeedsFlush<NL> || (3 * FS * Q < (1 << (64 - 2 * LIMB_BITS)) && 3 * (NL - FS * Q) < (1 << (64 - 2 * LIMB_BITS))),
+                  "one flush is enough for the segmented square");
+    fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+    if constexpr (kNeedsFlush<NL> && FS == 1) fp_flush<NL>(t);
     if constexpr (kSquareSegments == 2) {
-      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, Q, NL>(t, aa, a, tid, av, P);
-    } else if constexpr (kSquareSegments == 3) {
-      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 2 * Q, NL>(t, aa, a, tid, av, P);
-    } else if constexpr (kSquareSegments == 4) {
-      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 3 * Q, NL>(t, aa, a, tid, av, P);
-    } else if constexpr (kSquareSegments == 5) {
-      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 4 * Q, NL>(t, aa, a, tid, av, P);
     } else {
-      fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
       fp_sqr_segment<NL, Q, 2 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 4 * Q, 5 * Q>(t, aa, a, tid, av, P);
-      fp_sqr_segment<NL, 5 * Q, NL>(t, aa, a, tid, av, P);
+      if constexpr (kNeedsFlush<NL> && FS == 2) fp_flush<NL>(t);
+      if constexpr (kSquareSegments == 3) {
+        fp_sqr_segment<NL, 2 * Q, NL>(t, aa, a, tid, av, P);
+      } else {
+        fp_sqr_segment<NL, 2 * Q, 3 * Q>(t, aa, a, tid, av, P);
+        if constexpr (kNeedsFlush<NL> && FS == 3) fp_flush<NL>(t);
+        if constexpr (kSquareSegments == 4) {
+          fp_sqr_segment<NL, 3 * Q, NL>(t, aa, a, tid, av, P);
+        } else if constexpr (kSquareSegments == 5) {
+          fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
+          fp_sqr_segment<NL, 4 * Q, NL>(t, aa, a, tid, av, P);
+        } else {
+          fp_sqr_segment<NL, 3 * Q, 4 * Q>(t, aa, a, tid, av, P);
+          fp_sqr_segment<NL, 4 * Q, 5 * Q>(t, aa, a, tid, av, P);
+          fp_sqr_segment<NL, 5 * Q, NL>(t, aa, a, tid, av, P);
+        }
+      }
     }
     u64 c = 0;
 #pragma unroll

@@ -28,7 +28,7 @@ struct DivMat {
 };
 
 // 28 division steps on the low words; eta = -delta.
-__device__ __forceinline__ i32 divsteps28(i32 eta, u32 f0, u32 g0, DivMat& t) {
+__device__ __forceinline__ i32 divsteps_limb(i32 eta, u32 f0, u32 g0, DivMat& t) {
   u32 u = 1, v = 0, q = 0, r = 1;
   u32 f = f0, g = g0;
 #pragma unroll 4
@@ -64,16 +64,16 @@ template <int NL>
 __device__ __forceinline__ void divmat_apply_fg(i32 (&f)[NL], i32 (&g)[NL], const DivMat& t) {
   i64 cf = imad(t.u, f[0], imad(t.v, g[0], 0));
   i64 cg = imad(t.q, f[0], imad(t.r, g[0], 0));
-  cf = sar28(cf);
-  cg = sar28(cg);
+  cf = sar_limb<LIMB_BITS>(cf);
+  cg = sar_limb<LIMB_BITS>(cg);
 #pragma unroll
   for (int j = 1; j < NL; ++j) {
     cf = imad(t.u, f[j], imad(t.v, g[j], cf));
     cg = imad(t.q, f[j], imad(t.r, g[j], cg));
     f[j - 1] = (i32)((u32)cf & LIMB_MASK);
     g[j - 1] = (i32)((u32)cg & LIMB_MASK);
-    cf = sar28(cf);
-    cg = sar28(cg);
+    cf = sar_limb<LIMB_BITS>(cf);
+    cg = sar_limb<LIMB_BITS>(cg);
   }
   f[NL - 1] = (i32)cf;
   g[NL - 1] = (i32)cg;
@@ -93,8 +93,8 @@ __device__ __forceinline__ void divmat_apply_de(i32 (&d)[NL], i32 (&e)[NL], cons
   me -= (i32)(((u32)me - P->pinv * (u32)ce) & LIMB_MASK);
   cd = imad_s(md, (i32)P->p[0], cd);
   ce = imad_s(me, (i32)P->p[0], ce);
-  cd = sar28(cd);
-  ce = sar28(ce);
+  cd = sar_limb<LIMB_BITS>(cd);
+  ce = sar_limb<LIMB_BITS>(ce);
 #pragma unroll
   for (int j = 1; j < NL; ++j) {
     cd = imad(t.u, d[j], imad(t.v, e[j], cd));
@@ -103,8 +103,8 @@ __device__ __forceinline__ void divmat_apply_de(i32 (&d)[NL], i32 (&e)[NL], cons
     ce = imad_s(me, (i32)P->p[j], ce);
     d[j - 1] = (i32)((u32)cd & LIMB_MASK);
     e[j - 1] = (i32)((u32)ce & LIMB_MASK);
-    cd = sar28(cd);
-    ce = sar28(ce);
+    cd = sar_limb<LIMB_BITS>(cd);
+    ce = sar_limb<LIMB_BITS>(ce);
   }
   d[NL - 1] = (i32)cd;
   e[NL - 1] = (i32)ce;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void fp_inv_plain(Fp<NL>& r, const Fp<NL>& x, int p_b
     DivMat t;
     const u32 f0 = (u32)f[0] | ((u32)f[1] << LIMB_BITS);
     const u32 g0 = (u32)g[0] | ((u32)g[1] << LIMB_BITS);
-    eta = divsteps28(eta, f0, g0, t);
+    eta = divsteps_limb(eta, f0, g0, t);
     divmat_apply_de<NL>(d, e, t, P);
     divmat_apply_fg<NL>(f, g, t);
   }

@@ -147,12 +147,12 @@ struct BigU {
     }
     q.trim();
   }
-  // 28-bit limbs, little-endian, zero padded to nl
-  void to_limbs28(uint32_t* out, int nl) const {
+  // limbs of `limb_bits` bits, little-endian, zero padded to nl
+  void to_limbs(uint32_t* out, int nl, int limb_bits) const {
     for (int j = 0; j < nl; ++j) {
       uint32_t v = 0;
-      for (int b = 0; b < 28; ++b)
-        if (bit(28 * j + b)) v |= 1u << b;
+      for (int b = 0; b < limb_bits; ++b)
+        if (bit(limb_bits * j + b)) v |= 1u << b;
       out[j] = v;
     }
   }

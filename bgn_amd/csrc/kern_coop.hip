@@ -33,7 +33,8 @@ bool coop_pairing_launch(int nl, hipStream_t s, const void* params, const Pairin
     case 3: launch<3>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
     case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
     case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
-    case 38: launch<38>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 36: launch<36>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 37: launch<37>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
   }
   return false;
 }
@@ -53,7 +54,8 @@ bool coop_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_
     case 3: launch_pow<3>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
     case 10: launch_pow<10>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
     case 19: launch_pow<19>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
-    case 38: launch_pow<38>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
+    case 36: launch_pow<36>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
+    case 37: launch_pow<37>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count); return true;
   }
   return false;
 }
@@ -63,7 +65,8 @@ const char* coop_pairing_kernel_name(int nl) {
     case 3: return "k_pairing_coop<3>";
     case 10: return "k_pairing_coop<10>";
     case 19: return "k_pairing_coop<19>";
-    case 38: return "k_pairing_coop<38>";
+    case 36: return "k_pairing_coop<36>";
+    case 37: return "k_pairing_coop<37>";
   }
   return "";
 }

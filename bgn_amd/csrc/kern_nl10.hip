@@ -1,3 +1,3 @@
-// Kernel instantiations for NL = 10 28-bit limbs.
+// Kernel instantiations for NL = 10 limbs.
 #define BGN_NL 10
 #include "kernels_impl.hpp"

@@ -1,3 +1,3 @@
-// Kernel instantiations for NL = 19 28-bit limbs.
+// Kernel instantiations for NL = 19 limbs.
 #define BGN_NL 19
 #include "kernels_impl.hpp"

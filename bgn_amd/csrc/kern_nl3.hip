@@ -1,3 +1,3 @@
-// Kernel instantiations for NL = 3 28-bit limbs.
+// Kernel instantiations for NL = 3 limbs.
 #define BGN_NL 3
 #include "kernels_impl.hpp"

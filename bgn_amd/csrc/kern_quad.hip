@@ -12,7 +12,8 @@ size_t quad_ws_words(int nl, size_t sw) {
   switch (nl) {
     case 10: return ws_words<10>(sw);
     case 19: return ws_words<19>(sw);
-    case 38: return ws_words<38>(sw);
+    case 36: return ws_words<36>(sw);
+    case 37: return ws_words<37>(sw);
   }
   return 0;
 }
@@ -38,7 +39,8 @@ bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const Pairin
   switch (nl) {
     case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
     case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
-    case 38: launch<38>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
+    case 36: launch<36>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
+    case 37: launch<37>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits); return true;
   }
   return false;
 }
@@ -47,7 +49,8 @@ const char* quad_pairing_kernel_name(int nl) {
   switch (nl) {
     case 10: return "k_pairing_quad<10, 1>";
     case 19: return "k_pairing_quad<19, 1>";
-    case 38: return "k_pairing_quad<38, 1>";
+    case 36: return "k_pairing_quad<36, 1>";
+    case 37: return "k_pairing_quad<37, 1>";
   }
   return "";
 }

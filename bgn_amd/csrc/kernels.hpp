@@ -256,6 +256,7 @@ struct KernelTable {
 const KernelTable* kernel_table_nl3();
 const KernelTable* kernel_table_nl10();
 const KernelTable* kernel_table_nl19();
-const KernelTable* kernel_table_nl38();
+const KernelTable* kernel_table_nl36();
+const KernelTable* kernel_table_nl37();
 
 }  // namespace bgn

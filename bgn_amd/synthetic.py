@@ -126,6 +126,21 @@ def miller_schedule(n: int, window: int = 5):
 INVERSION_PRODUCTS = 55
 
 
+LIMB_BITS = 29          # bgn_amd/csrc/consts.hpp
+
+
+def limbs_for(p: int) -> int:
+    """Limb count the engine instantiates for the field of p (engine.cpp pick_table)."""
+    need = (p.bit_length() + 9 + LIMB_BITS - 1) // LIMB_BITS
+    return next(x for x in (3, 10, 19, 36, 37) if x >= need)
+
+
+def flush_instructions(nl: int) -> int:
+    """The mid-product carry pass of fp_mul / fp_sqr at radix 2^29 (fp28.hpp fp_flush: add, mask, shift per
+    accumulator) from 32 limbs on; counted with the multiply-adds of a product (same issue cost)."""
+    return 3 * nl if nl > 19 else 0
+
+
 def square_mads(nl: int, segments: int = 5) -> int:
     """Multiply-adds of one Montgomery squaring by the segmented square of fp28.hpp: row i of segment
     [lo, hi) multiplies a_i by the limbs j >= lo (doubled beyond hi), plus the nl reduction MADs per row."""
@@ -134,15 +149,16 @@ def square_mads(nl: int, segments: int = 5) -> int:
     q = ((nl // segments + 1) // 2) * 2
     bounds = [k * q for k in range(segments)] + [nl]
     prod = sum((hi - lo) * (nl - lo) for lo, hi in zip(bounds[:-1], bounds[1:]))
-    return prod + nl * nl
+    return prod + nl * nl + flush_instructions(nl)
 
 
 def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: int = 5) -> int:
     """32x32->64 multiply-adds one pairing executes in this formulation: general field products at 2*NL^2
-    (schoolbook product + Montgomery reduction rows), squarings at the segmented square's count.
+    (schoolbook product + Montgomery reduction rows; + the 3*NL instructions of the mid-product flush at 36 / 37
+    limbs), squarings at the segmented square's count.
     The F_p inversion of the final exponentiation is shared by `run` pairings per lane."""
     p, n, l = int(fx["p"], 16), int(fx["n"], 16), int(fx["l"])
-    nl = 38 if p.bit_length() > 600 else (19 if p.bit_length() > 300 else (10 if p.bit_length() > 100 else 3))
+    nl = limbs_for(p)
     dbl, add, threes, pre = miller_schedule(n, window)
     lb = l.bit_length()
     lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l (no field squarings)
@@ -152,7 +168,7 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: i
     # windowed loop, 4 + 2 in the norms / conj(f)^2
     squares = dbl * 6 + add * 3 + ((6 + 3 * ((1 << (window - 2)) - 1) + 3) if window >= 3 else 0) + 6
     products = per_pairing + INVERSION_PRODUCTS / run
-    return int((products - squares) * 2 * nl * nl + squares * square_mads(nl, segments))
+    return int((products - squares) * (2 * nl * nl + flush_instructions(nl)) + squares * square_mads(nl, segments))
 
 
 # ---- field products per unit of the other operations -----------------------------------------
@@ -160,8 +176,8 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: i
 # 32x32->64 multiply-adds — a general product at 2*NL^2, a squaring at the segmented square's count — which is what
 # bench.py holds against the measured v_mad_u64_u32 issue peaks (roofline_valu).  An F_p inversion by division steps
 # is priced as INVERSION_PRODUCTS general products (its multiply-adds are of the same instruction, fpinv.hpp).
-def mads_from_counts(products: float, squares: float, nl: int = 38, segments: int = 5) -> float:
-    return (products - squares) * 2 * nl * nl + squares * square_mads(nl, segments)
+def mads_from_counts(products: float, squares: float, nl: int = 36, segments: int = 5) -> float:
+    return (products - squares) * (2 * nl * nl + flush_instructions(nl)) + squares * square_mads(nl, segments)
 
 
 def _run_for(count: int) -> int:

@@ -4,7 +4,7 @@ Two levels, both driven by the micro-op tables of tools/coop/gen_prog.py:
   * ValueMachine — slots hold Python integers; a micro-op is evaluated exactly as the kernel defines it
     (operands made non-negative with K*p, Montgomery product (A*B + Q*p)/R with the unique Q < R).  Checks the
     program: formulas, schedule (a round reads every operand before any write), slot allocation, bounds.
-  * LaneMachine — slots hold 64 lanes of 32-bit words (numpy), one 28-bit limb per lane, and every step is the
+  * LaneMachine — slots hold 64 lanes of 32-bit words (numpy), one 29-bit limb per lane, and every step is the
     kernel's own instruction-level arithmetic with its 32/64-bit wrap-around: signed multiply-add, quotient digit
     from lane 0, lane shifts, one-pass normalisation.  Checks the arithmetic the HIP code implements.
 TEST INFRASTRUCTURE: not used by the product.
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools", "coop"))
 import gen_prog  # noqa: E402
 
-LIMB = 28
+LIMB = 29                      # bgn_amd/csrc/consts.hpp LIMB_BITS
 MASK = (1 << LIMB) - 1
 _PROGRAM = None
 
@@ -33,8 +33,8 @@ def program():
 
 
 def nl_for(p: int) -> int:
-    need = (p.bit_length() + 9 + 27) // 28
-    return next(x for x in (3, 10, 19, 38) if x >= need)
+    need = (p.bit_length() + 9 + LIMB - 1) // LIMB
+    return next(x for x in (3, 10, 19, 36, 37) if x >= need)
 
 
 def naf(n: int):
@@ -273,7 +273,7 @@ class LaneMachine(ValueMachine):
         if u.kind == "mul":
             a = self.normalize64(self.combo(u.A, u.KA))
             b = self.normalize64(self.combo(u.B, u.KB))
-            assert np.all(np.abs(a.astype(I32).astype(I64)) <= (1 << 28) + (1 << 12))
+            assert np.all(np.abs(a.astype(I32).astype(I64)) <= (1 << LIMB) + (1 << 12))
             t = self.mul(a, b)
             if u.E:
                 t = t + self.combo(u.E, u.KE)

@@ -393,7 +393,8 @@ struct Emu {
     case 3: Emu<3>::call; break;      \
     case 10: Emu<10>::call; break;    \
     case 19: Emu<19>::call; break;    \
-    case 38: Emu<38>::call; break;    \
+    case 36: Emu<36>::call; break;    \
+    case 37: Emu<37>::call; break;    \
     default: return -1;               \
   }                                   \
   return 0;

@@ -12,7 +12,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libbgn_emu.so")
 _CSRC = os.path.join(_HERE, "..", "..", "bgn_amd", "csrc")
-KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << 28) - 1
+LIMB = 29                      # bgn_amd/csrc/consts.hpp LIMB_BITS
+KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << LIMB) - 1
 
 
 def build() -> str:
@@ -28,12 +29,12 @@ def build() -> str:
 
 
 def limbs(v: int, nl: int):
-    return [(v >> (28 * j)) & MASK for j in range(nl)]
+    return [(v >> (LIMB * j)) & MASK for j in range(nl)]
 
 
 def nl_for(p: int) -> int:
-    need = (p.bit_length() + 9 + 27) // 28
-    for nl in (3, 10, 19, 38):
+    need = (p.bit_length() + 9 + LIMB - 1) // LIMB
+    for nl in (3, 10, 19, 36, 37):
         if nl >= need:
             return nl
     raise ValueError("field too large")
@@ -74,7 +75,7 @@ class Emu:
         self.p, self.n, self.l = p, n, l
         self.nl = nl = nl_for(p)
         self.L = (p.bit_length() + 7) // 8
-        R = 1 << (28 * nl)
+        R = 1 << (LIMB * nl)
         img = limbs(p, nl) + limbs(R % p, nl) + limbs(R * R % p, nl)
         for K in range(1, KP_MAX + 1):
             img += limbs(K * p, nl)
@@ -119,7 +120,7 @@ class Emu:
         A = (C.c_uint32 * self.nl)(*limbs(a_mont, self.nl))
         out = (C.c_uint32 * self.nl)()
         assert self.lib.emu_fp_inv(self.nl, self.params, self.p.bit_length(), A, out) == 0
-        return sum(int(v) << (28 * j) for j, v in enumerate(out))
+        return sum(int(v) << (LIMB * j) for j, v in enumerate(out))
 
     def pairing(self, a: bytes, b: bytes) -> bytes:
         A, ia = self.decode(a)

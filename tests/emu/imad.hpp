@@ -4,6 +4,7 @@
 namespace bgn {
 inline long long imad(int a, int b, long long c) { return c + (long long)a * b; }
 inline long long imad_s(int a, int b, long long c) { return c + (long long)a * b; }
-inline long long sar28(long long c) { return c >> 28; }
+template <int BITS>
+inline long long sar_limb(long long c) { return c >> BITS; }
 }
 #endif

@@ -3,9 +3,9 @@
 The kernel gives one pairing to 16 lanes of a wave: four quads, each running one micro-op of a round of the tables
 tools/coop/gen_prog.py schedules for four workers (build_quad_programs: the formulas of the wave-cooperative
 kernel, the Miller state updated in place, one program per launch).  Inside a quad a field element is split over
-the four lanes, M = ceil(NL / 4) limbs of 28 bits per lane (lane s holds limbs s*M .. s*M + M - 1), and a
+the four lanes, M = ceil(NL / 4) limbs of 29 bits per lane (lane s holds limbs s*M .. s*M + M - 1), and a
 Montgomery product is NL rows of {broadcast one limb of a inside the quad, multiply-add into the lane's M
-accumulators, quotient digit from lane 0, multiply-add of p, retire the lowest accumulator: its low 28 bits go to
+accumulators, quotient digit from lane 0, multiply-add of p, retire the lowest accumulator: its low 29 bits go to
 the lane below, the rest to the next accumulator}.
 
   * QuadValueMachine — the tables on Python integers, values kept by PHYSICAL slot and every round's reads done
@@ -36,8 +36,8 @@ def programs():
 
 
 def nl_for(p: int) -> int:
-    need = (p.bit_length() + 9 + 27) // 28
-    return next(x for x in (10, 19, 38) if x >= need)
+    need = (p.bit_length() + 9 + LIMB - 1) // LIMB
+    return next(x for x in (10, 19, 36, 37) if x >= need)
 
 
 class QuadValueMachine:
@@ -147,7 +147,7 @@ class QuadValueMachine:
 
 
 def to_quad(v: int, nl: int) -> np.ndarray:
-    """4 x M tight limbs of a non-negative value below 2^(28 NL)."""
+    """4 x M tight limbs of a non-negative value below 2^(29 NL)."""
     m = (nl + 3) // 4
     out = np.zeros((4, m), dtype=I32)
     assert 0 <= v < 1 << (LIMB * nl)

@@ -245,7 +245,7 @@ def test_emu_per_coefficient_line_tables(ctx):
     assert E.pairing_fixed(tb, cts[v["a"]], 2, 1).hex() == v["out"]
 
 
-@pytest.mark.parametrize("nl", [3, 10, 19, 38])
+@pytest.mark.parametrize("nl", [3, 10, 19, 36, 37])
 def test_emu_dword_codec_matches_the_byte_codec(nl):
     """codec.hpp's dword forms (wire_element_dw: two-dword reads + byte permutes, odd lanes two bytes into a dword
     when L is odd; limbs_to_wire_dw when an element is a whole number of dwords) against Python integers for every
@@ -254,18 +254,18 @@ def test_emu_dword_codec_matches_the_byte_codec(nl):
     import ctypes as C
     lib = emu.Emu.from_fixture(load_fixture("toy64")).lib
     rng = random.Random(nl)
-    lmax = (28 * nl - 9 + 7) // 8
-    lmin = max(4, (28 * (nl - 1) + 7) // 8 - 6)
+    lmax = (emu.LIMB * nl - 9 + 7) // 8
+    lmin = max(4, (emu.LIMB * (nl - 1) + 7) // 8 - 6)
     for L in range(lmin, lmax + 1):
         n = 9
-        top = min(8 * L, 28 * nl)
+        top = min(8 * L, emu.LIMB * nl)
         vals = [0, 1, (1 << top) - 1, (1 << (top - 1)) + 1] + [rng.getrandbits(top) for _ in range(2 * n - 4)]
         wire = b"".join(v.to_bytes(L, "big") for v in vals)
         limbs_out = (C.c_uint32 * (2 * nl * n))()
         wire_out = C.create_string_buffer(2 * L * n)
         assert lib.emu_codec_dw(nl, wire, L, n, limbs_out, wire_out) == 0
         for i, v in enumerate(vals):
-            got = sum(int(limbs_out[i * nl + j]) << (28 * j) for j in range(nl))
-            assert all(int(limbs_out[i * nl + j]) < (1 << 28) for j in range(nl))
+            got = sum(int(limbs_out[i * nl + j]) << (emu.LIMB * j) for j in range(nl))
+            assert all(int(limbs_out[i * nl + j]) < (1 << emu.LIMB) for j in range(nl))
             assert got == v, (nl, L, i, hex(v), hex(got))
         assert wire_out.raw == wire, (nl, L)

@@ -22,7 +22,7 @@ def test_field_mul_sqr_inv_vs_python_integers(name, count):
     eng = pk.engine
     p, L = int(fx["p"], 16), eng.L
     rng = random.Random(2024)
-    special = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << (p.bit_length() - 1), (1 << 28) - 1, 1 << 28]
+    special = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << (p.bit_length() - 1), (1 << 28) - 1, 1 << 28, (1 << 29) - 1, 1 << 29]
     xs = [special[i % len(special)] if i < 3 * len(special) else rng.randrange(p) for i in range(count)]
     ys = [special[(i // len(special)) % len(special)] if i < len(special) ** 2 else rng.randrange(p) for i in range(count)]
     buf = b"".join(x.to_bytes(L, "big") + y.to_bytes(L, "big") for x, y in zip(xs, ys))

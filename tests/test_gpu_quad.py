@@ -10,7 +10,7 @@ from conftest import engine_key, load_fixture
 
 pytestmark = pytest.mark.gpu
 
-QUAD_KEYS = ["k256", "k512", "k1024"]        # limb counts 10, 19, 38: 3, 5, 10 limbs per lane
+QUAD_KEYS = ["k256", "k512", "k1024"]        # limb counts 10, 19, 36: 3, 5, 9 limbs per lane
 
 
 def H(hexes):

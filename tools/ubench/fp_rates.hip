@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include "fp28.hpp"
+#include "fp_experiments.hpp"
 using namespace bgn;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 constexpr int NL = 38;
@@ -29,6 +30,17 @@ __global__ void __launch_bounds__(FP_BLOCK) k_op(const FpParams<NL>* __restrict_
     if (OP == 5) { l_store(L, a); l_load(a, L); fp_add<NL>(a, a, b); }
     if (OP == 6) { AFp<NL> s0, s1; a_store(s0, a); a_store(s1, b); a_load(b, s0); a_load(a, s1); }
     if (OP == 7) { l_store(L, a); l_store(L + 1, b); l_load(b, L); l_load(a, L + 1); }
+    if (OP == 8) {     // radix 2^29, 36 limbs (fp_experiments.hpp): stage + product, like OP 0
+      u32 x[NL29], y[NL29];
+#pragma unroll
+      for (int j = 0; j < NL29; ++j) { x[j] = a.v[j] & M29; y[j] = b.v[j] | 1u; }
+#pragma unroll
+      for (int k = 0; k < NL29 / 2; ++k) L[0].rows[k][threadIdx.x] = (u64)x[2 * k] | ((u64)x[2 * k + 1] << 32);
+      fp29_mul(x, L[0].rows, y, reinterpret_cast<const Fp29Params*>(P));
+#pragma unroll
+      for (int j = 0; j < NL29; ++j) a.v[j] = x[j] & LIMB_MASK;
+    }
+    if (OP == 9) { fp_mul_kara(a, a, b, P); }   // one Karatsuba level on the a*b half
   }
   const unsigned long long t1 = memtime();
   g_store<NL>(out, stride, e, a);
@@ -67,10 +79,10 @@ int main() {
   u32 *din, *dout; FpParams<NL>* dP; unsigned long long* dc;
   CK(hipMalloc(&din, h.size() * 4)); CK(hipMalloc(&dout, (size_t)NL * N * 4)); CK(hipMalloc(&dP, sizeof(FpParams<NL>))); CK(hipMalloc(&dc, N / 64 * 8));
   CK(hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dP, hp.data(), sizeof(FpParams<NL>), hipMemcpyHostToDevice));
-  const char* names[] = {"fp_mul (stage + product)", "fp_sqr (stage + segmented square)", "fp_mul(a,a)", "fp_add", "fp_sub<8>", "l_store+l_load+fp_add", "2 a_store + 2 a_load", "2 l_store + 2 l_load"};
-  const int reps[] = {400, 400, 400, 4000, 4000, 4000, 4000, 4000};
+  const char* names[] = {"fp_mul (stage + product)", "fp_sqr (stage + segmented square)", "fp_mul(a,a)", "fp_add", "fp_sub<8>", "l_store+l_load+fp_add", "2 a_store + 2 a_load", "2 l_store + 2 l_load", "EXPERIMENT radix 2^29, 36 limbs (stage + product)", "EXPERIMENT Karatsuba level on a*b"};
+  const int reps[] = {400, 400, 400, 4000, 4000, 4000, 4000, 4000, 400, 400};
   std::vector<unsigned long long> hc(N / 64);
-  for (int op = 0; op < 8; ++op) {
+  for (int op = 0; op < 10; ++op) {
     for (int it = 0; it < 2; ++it) {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       CK(hipEventRecord(e0));
@@ -83,6 +95,8 @@ int main() {
         case 5: hipLaunchKernelGGL(k_op<5>, dim3(N / FP_BLOCK), dim3(FP_BLOCK), 0, 0, dP, din, dout, dc, reps[op], N); break;
         case 6: hipLaunchKernelGGL(k_op<6>, dim3(N / FP_BLOCK), dim3(FP_BLOCK), 0, 0, dP, din, dout, dc, reps[op], N); break;
         case 7: hipLaunchKernelGGL(k_op<7>, dim3(N / FP_BLOCK), dim3(FP_BLOCK), 0, 0, dP, din, dout, dc, reps[op], N); break;
+        case 8: hipLaunchKernelGGL(k_op<8>, dim3(N / FP_BLOCK), dim3(FP_BLOCK), 0, 0, dP, din, dout, dc, reps[op], N); break;
+        case 9: hipLaunchKernelGGL(k_op<9>, dim3(N / FP_BLOCK), dim3(FP_BLOCK), 0, 0, dP, din, dout, dc, reps[op], N); break;
       }
       CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -256,10 +256,12 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
             syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
         # the dominant kernel of Decrypt is the lift (k_pairing<NL, 1>), timed by HIP events on its stream
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-        if k == 20 and os.path.exists(pmc):                     # separate rocprofv3 --pmc passes of this command
-            with open(pmc) as f:
-                traffic = json.load(f).get("decrypt_lift_k_pairing_38_1", {}).get("hbm_bytes_per_launch")
+        for pname, key in (("r03_pmc_summary.json", "decrypt_lift_k_pairing_1"), ("r02_pmc_summary.json", "decrypt_lift_k_pairing_38_1")):
+            pmc = os.path.join(ROOT, "profiles", pname)
+            if k == 20 and os.path.exists(pmc):                 # separate rocprofv3 --pmc passes of this command
+                with open(pmc) as f:
+                    traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+                break
         e["roofline"] = {"bound": "hbm", "achieved": alg * n_dec / (lift_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg * n_dec / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": eng.last_aux_kernel_name(), "kernel_ms": lift_ms,

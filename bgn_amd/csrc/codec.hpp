@@ -1,6 +1,6 @@
 // codec.hpp — PBC wire bytes <-> LIMB_BITS-bit limbs (device functions).
 #pragma once
-#include "fp28.hpp"
+#include "fpmont.hpp"
 
 namespace bgn {
 

@@ -1,5 +1,5 @@
 // consts.hpp — plain-old-data definitions shared by host (engine.cpp) and
-// device code (fp28.hpp, pairing.hpp).  No device code here.
+// device code (fpmont.hpp, pairing.hpp).  No device code here.
 #pragma once
 #include <stdint.h>
 
@@ -12,7 +12,7 @@ typedef int32_t i32;
 // Radix 2^29 since round 3 (2^28 before): 36 limbs instead of 38 at a 1024-bit key whose p has at most 1035 bits
 // (37 up to 1037), i.e. 2*36^2 = 2592 multiply-adds per product instead of 2888; a 64-bit accumulator then holds
 // the 2*NL products of < 2^58 of a column only up to NL = 31, so fp_mul flushes its accumulators once, half way
-// (fp28.hpp).  Measured in isolation (tools/ubench/fp_rates.hip, profiles/r03_fp_experiments.txt): 6.5 us per
+// (fpmont.hpp).  Measured in isolation (tools/ubench/fp_rates.hip, profiles/r03_fp_experiments.txt): 6.5 us per
 // product and wave against 7.1 - 8.5.
 constexpr int LIMB_BITS = 29;
 constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1u;

@@ -25,7 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../fp28.hpp"
+#include "../fpmont.hpp"
 #include "../fpinv.hpp"
 #include "../kernels.hpp"
 

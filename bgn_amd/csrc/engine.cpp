@@ -330,7 +330,7 @@ const KernelTable* pick_table(int need_nl) {
   return nullptr;
 }
 
-// Fill the host image of FpParams<NL> (all fields are uint32_t, see fp28.hpp).
+// Fill the host image of FpParams<NL> (all fields are uint32_t, see fpmont.hpp).
 std::vector<uint32_t> build_params(const BigU& p, int nl) {
   // layout: p[nl] one[nl] r2[nl] kp[32][nl] pinv pad[3]
   std::vector<uint32_t> img((size_t)nl * (3 + KP_MAX) + 4, 0);

@@ -18,7 +18,7 @@
 // The loop runs until g == 0 in every lane of the wave (uniform exit through a ballot), with a hard
 // cap from the proven bound of the division-step count, so it cannot spin.
 #pragma once
-#include "fp28.hpp"
+#include "fpmont.hpp"
 #include "imad.hpp"
 
 namespace bgn {

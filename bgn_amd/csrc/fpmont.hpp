@@ -1,4 +1,4 @@
-// fp28.hpp — multi-precision Montgomery arithmetic over F_p for gfx950,
+// fpmont.hpp — multi-precision Montgomery arithmetic over F_p for gfx950,
 // one field element per lane.
 //
 // Replaces what the reference reaches through pbc.Element on G1/GT
@@ -6,34 +6,40 @@
 // bgn.go:300, :344-350, :460, :482) -> libpbc montfp.c -> GMP mpn_* .
 //
 // Representation (chosen from the measured VALU issue rates in
-// profiles/ubench_valu_rates_r01.txt): radix 2^28, NL limbs in 32-bit lanes,
-// Montgomery form with R = 2^(28*NL).  v_mad_u64_u32 issues at the same rate
-// as v_addc_co_u32 on gfx950, so a full-radix (2^32) schoolbook with explicit
-// carry instructions costs 2 issue slots per limb product; with 28-bit limbs a
-// 64-bit accumulator absorbs 2*NL products of 56 bits (NL <= 64) and the inner
-// loops are pure v_mad_u64_u32 chains with no carry instructions at all.
+// profiles/ubench_valu_rates_r01.txt and the product timings of
+// profiles/r03_fp_experiments.txt): radix 2^29 (LIMB_BITS, consts.hpp; 2^28 in
+// rounds 1 and 2), NL limbs in 32-bit lanes, Montgomery form with
+// R = 2^(29*NL).  v_mad_u64_u32 issues at the same rate as v_addc_co_u32 on
+// gfx950, so a full-radix (2^32) schoolbook with explicit carry instructions
+// costs 2 issue slots per limb product; with 29-bit limbs a 64-bit accumulator
+// absorbs 64 products of 58 bits: the inner loops are pure v_mad_u64_u32 chains
+// with no carry instructions, and a product of more than 31 rows (NL = 36, 37:
+// 1024-bit keys) carries its accumulators out once, half way (fp_flush).
+// 36 limbs instead of the 38 of radix 2^28: 2 592 multiply-adds + 108 flush
+// instructions per product instead of 2 888.
 //
-// Storage tiers per lane (a 1024-bit key has NL = 38, 152 B per element):
-//   Fp   — 38 VGPRs: operands/results of the op in flight.  Only the 256
+// Storage tiers per lane (a 1024-bit key has NL = 36, 144 B per element; 37
+// when p has 1036 or 1037 bits):
+//   Fp   — NL VGPRs: operands/results of the op in flight.  Only the 256
 //          architectural VGPRs are addressable by VALU instructions, and one
-//          Montgomery product keeps 76 (accumulators) + 38 (multiplicand)
+//          Montgomery product keeps 2 NL (accumulators) + NL (multiplicand)
 //          live, so at most two further Fp values may be live across a mul.
-//   AFp  — 38 AGPRs: the accumulation-register half of the unified file,
+//   AFp  — NL AGPRs: the accumulation-register half of the unified file,
 //          reached with v_accvgpr_read/write; holds the long-lived state
 //          (six elements per lane).
 //   LFp  — LDS, [row pair][thread] u64: four elements per lane at 256
-//          threads per workgroup (= all 160 KB).  An LFp can be consumed
-//          directly as the multiplier of fp_mul, whose rows are read with a
-//          run-time index (registers cannot be indexed dynamically).
+//          threads per workgroup (= all 160 KB at NL = 37, 38).  An LFp can be
+//          consumed directly as the multiplier of fp_mul, whose rows are read
+//          with a run-time index (registers cannot be indexed dynamically).
 // Workgroups are 256 threads = one wave per SIMD; there is no cross-lane
 // traffic, hence no barriers.
 //
 // Invariants:
-//   * every stored limb is "tight": < 2^28;
+//   * every stored limb is "tight": < 2^LIMB_BITS;
 //   * a value V represents x*R mod p and satisfies V < B*p for a small,
 //     statically known bound B (written "<B" at each call site);
-//   * fp_mul needs B_a * B_b < 2^(28*NL - bits(p)) (>= 2^9 by the choice of
-//     NL in engine.cpp) and returns V < 2p;
+//   * fp_mul needs B_a * B_b < 2^(LIMB_BITS*NL - bits(p)) (>= 2^9 by the
+//     choice of NL in engine.cpp) and returns V < 2p;
 //   * fp_sub<K>(a, b) computes a + K*p - b and needs B_b <= K (K = 1..32).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -51,7 +57,7 @@ struct FpParams {
   u32 one[NL];          // R mod p           (Montgomery 1)
   u32 r2[NL];           // R^2 mod p         (to-Montgomery factor)
   u32 kp[KP_MAX][NL];   // kp[K-1] = K*p, tight limbs
-  u32 pinv;             // -p^{-1} mod 2^28
+  u32 pinv;             // -p^{-1} mod 2^LIMB_BITS
   u32 pad[3];
 };
 
@@ -270,9 +276,8 @@ __device__ __forceinline__ void fp_select(Fp<NL>& r, bool c, const Fp<NL>& a, co
 }
 
 // ---- Montgomery product -----------------------------------------------------
-// One row: t += ai*b; m = t0*pinv mod 2^28; t += m*p; t >>= 28.
-// Over a whole product each 64-bit accumulator collects < 2*NL products of
-// < 2^56 plus carries: < 2^63 for NL <= 63.
+// One row: t += ai*b; m = t0*pinv mod 2^LIMB_BITS; t += m*p; t >>= LIMB_BITS.
+// Each row adds two products of < 2^(2*LIMB_BITS) to an accumulator: see fp_flush below.
 template <int NL>
 __device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
                                        const FpParams<NL>* __restrict__ P) {
@@ -548,7 +553,7 @@ __device__ __forceinline__ void fp_canon(Fp<NL>& r, const Fp<NL>& a, const FpPar
   fp_to_mont<NL>(r, x, P, stage);
 }
 
-// a^e for a wave-uniform exponent given as 28-bit limbs (little-endian),
+// a^e for a wave-uniform exponent given as LIMB_BITS-bit limbs (little-endian),
 // MSB-first square-and-multiply; control flow is uniform.  `a_rows` holds a in
 // an LDS slot for the whole loop.  a < 4; result < 2.
 template <int NL>

@@ -1,7 +1,7 @@
 // ops.hpp — batched group operations besides the pairing: GT (F_p^2)
 // product / power, G1 affine addition with batched inversion, G1 scalar
 // multiplication.  One element (or a short run of elements) per lane; same
-// storage tiers and bound notation as fp28.hpp / pairing.hpp.
+// storage tiers and bound notation as fpmont.hpp / pairing.hpp.
 #pragma once
 #include "kernels.hpp"
 #include "pairing.hpp"

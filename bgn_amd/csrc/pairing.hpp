@@ -16,12 +16,12 @@
 //   * final exponent split as f^(p-1) = conj(f)/f, then ^l  ((p+1)/n = l).
 //
 // The steps are written as explicit programs over storage slots (see
-// fp28.hpp): long-lived state in six AGPR slots, four LDS slots (S0 is the
+// fpmont.hpp): long-lived state in six AGPR slots, four LDS slots (S0 is the
 // multiplier stage), and at most two spare VGPR elements across any product.
 //
 // Bounds: "<k" means value < k*p.  Every product has bound-product <= 400 < 2^9.
 #pragma once
-#include "fp28.hpp"
+#include "fpmont.hpp"
 #include "fpinv.hpp"
 
 namespace bgn {

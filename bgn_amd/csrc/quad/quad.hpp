@@ -29,7 +29,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "../fp28.hpp"
+#include "../fpmont.hpp"
 #include "../fpinv.hpp"
 #include "../imad.hpp"
 #include "../kernels.hpp"

@@ -136,13 +136,13 @@ def limbs_for(p: int) -> int:
 
 
 def flush_instructions(nl: int) -> int:
-    """The mid-product carry pass of fp_mul / fp_sqr at radix 2^29 (fp28.hpp fp_flush: add, mask, shift per
+    """The mid-product carry pass of fp_mul / fp_sqr at radix 2^29 (fpmont.hpp fp_flush: add, mask, shift per
     accumulator) from 32 limbs on; counted with the multiply-adds of a product (same issue cost)."""
     return 3 * nl if nl > 19 else 0
 
 
 def square_mads(nl: int, segments: int = 5) -> int:
-    """Multiply-adds of one Montgomery squaring by the segmented square of fp28.hpp: row i of segment
+    """Multiply-adds of one Montgomery squaring by the segmented square of fpmont.hpp: row i of segment
     [lo, hi) multiplies a_i by the limbs j >= lo (doubled beyond hi), plus the nl reduction MADs per row."""
     if nl < 8 or segments <= 1:
         return 2 * nl * nl

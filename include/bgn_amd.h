@@ -296,7 +296,7 @@ void* bgn_host_alloc(size_t bytes);
 void bgn_host_free(void* p);
 
 /* ---- diagnostics ------------------------------------------------------------------------------------------
- * Field arithmetic on its own (Montgomery product, squaring, division-step inversion of csrc/fp28.hpp and
+ * Field arithmetic on its own (Montgomery product, squaring, division-step inversion of csrc/fpmont.hpp and
  * fpinv.hpp — what stands in for the mpz / PBC field calls behind every pbc.Element method),
  * so that parity tests can compare it with big-integer arithmetic directly.  xy: count elements x||y, L bytes
  * each, residues below p; prod_inv[e] = x*y || x^-1 (0 for x = 0); sqr[e] = x^2 || y^2; host buffers. */

@@ -1,5 +1,5 @@
 // emu.cpp — host emulation of the device lane programs (TEST INFRASTRUCTURE).
-// Compiles bgn_amd/csrc/{fp28,pairing,ops,codec}.hpp for the CPU with stand-in
+// Compiles bgn_amd/csrc/{fpmont,pairing,ops,codec}.hpp for the CPU with stand-in
 // headers (tests/emu/hip/hip_runtime.h, tests/emu/agpr.hpp, tests/emu/gmem.hpp) and runs one lane
 // at a time.  Lets CPU-only tests exercise the exact kernel logic (slot
 // programs, exception paths) against the oracle without a GPU.

@@ -19,7 +19,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << LIMB) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fp28.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
+                                                ("fpmont.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"), "-include", os.path.join(_HERE, "imad.hpp"),

@@ -1,4 +1,4 @@
-"""CPU: the device lane programs (bgn_amd/csrc/{fp28,pairing,ops,codec}.hpp) compiled
+"""CPU: the device lane programs (bgn_amd/csrc/{fpmont,pairing,ops,codec}.hpp) compiled
 for the host by the emulation harness (tests/emu) and checked against the golden
 vectors / oracle.  This is a test of kernel *logic* (slot programs, exception
 paths, bounds); it is not a product path — the product runs the same headers

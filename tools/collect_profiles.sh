@@ -4,7 +4,7 @@
 # rocprofv3 is given the program itself (python3 bench.py ...), never a launcher; counter passes are separate
 # from each other and carry no trace other than the kernel trace.
 set -o pipefail
-OUT=${1:-gpurun_out/r02_profiles}
+OUT=${1:-gpurun_out/r03_profiles}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "== bench (default line)"; python3 bench.py --steps 3 --warmup 1 > "$OUT/bench_line.json" 2> "$OUT/bench.err" || exit 1
@@ -20,11 +20,15 @@ echo "== PMC FETCH_SIZE / WRITE_SIZE with the extras (Decrypt's lift kernel)"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_extra" -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch_extra.json" 2> "$OUT/pmc_fetch_extra.err" || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_extra" -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write_extra.json" 2> "$OUT/pmc_write_extra.err" || exit 1
 echo "== small-batch sweep"; python3 tools/small_batch_sweep.py > "$OUT/small_batch.csv" 2> "$OUT/sweep.err" || exit 1
+echo "== mid-size batches: the three pairing kernels"; python3 tools/quad_sweep.py k512 k1024 > "$OUT/mid_batch.csv" 2> "$OUT/mid.err" || exit 1
+echo "== the lane-group kernel saturated, beside the lane kernel"
+QUAD_SWEEP_COUNTS=1048576 QUAD_SWEEP_KERNELS=quad,lane python3 tools/quad_sweep.py k1024 > "$OUT/quad_saturated.csv" 2>> "$OUT/mid.err" || exit 1
+echo "== single-call latencies"; python3 tools/single_op_latency.py > "$OUT/single_op_latency.csv" 2> "$OUT/single.err" || exit 1
 find "$OUT" -name "*.csv" | head -40
 # keep the merge small: the raw traces are not needed
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
 # the counter files of the runs with extras list every dispatch: keep the pairing kernels only
 for f in "$OUT"/pmc_fetch_extra/fetch_counter_collection.csv "$OUT"/pmc_write_extra/write_counter_collection.csv; do
-  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep "k_pairing<38, 1>" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
+  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 1>" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
 done
 du -sh "$OUT"

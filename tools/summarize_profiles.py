@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turns the raw output of tools/collect_profiles.sh (gpurun_out/<dir>) into the tracked files under profiles/:
-python tools/summarize_profiles.py gpurun_out/r02_profiles r02"""
+python tools/summarize_profiles.py gpurun_out/r03_profiles r03"""
+import re
 import csv
 import json
 import os
@@ -20,6 +21,11 @@ def last_json_line(path):
 shutil.copy(os.path.join(src, "prof_bench", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "prof_extra", "extra_kernel_stats.csv"), os.path.join(dst, f"{tag}_extra_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "small_batch.csv"), os.path.join(dst, f"{tag}_small_batch.csv"))
+for extra_csv in ("mid_batch.csv", "quad_saturated.csv", "single_op_latency.csv"):
+    if os.path.exists(os.path.join(src, extra_csv)):
+        shutil.copy(os.path.join(src, extra_csv), os.path.join(dst, f"{tag}_{extra_csv}"))
+LANE0 = re.compile(r"void bgn::k_pairing<\d+, 0>")       # the headline kernel, whatever the key's limb count
+LANE1 = re.compile(r"void bgn::k_pairing<\d+, 1>")       # ... and the walk over a key's line table (Decrypt's lift)
 for name, out in (("bench_line.json", f"{tag}_bench_line.json"), ("bench_line_profiled.json", f"{tag}_bench_line_profiled.json")):
     with open(os.path.join(dst, out), "w") as f:
         json.dump(last_json_line(os.path.join(src, name)), f, indent=1)
@@ -28,7 +34,7 @@ for name, out in (("bench_line.json", f"{tag}_bench_line.json"), ("bench_line_pr
 summary = {}
 for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch", "fetch"), ("WRITE_SIZE", "pmc_write", "write")):
     rows = [r for r in csv.DictReader(open(os.path.join(src, sub, f"{stem}_counter_collection.csv")))
-            if r["Kernel_Name"].startswith("void bgn::k_pairing<38, 0>") and r["Counter_Name"] == ctr]
+            if LANE0.match(r["Kernel_Name"]) and r["Counter_Name"] == ctr]
     vals = [float(r["Counter_Value"]) for r in rows]
     keep = os.path.join(dst, f"{tag}_pmc_{ctr.lower()}_k_pairing.csv")
     with open(keep, "w", newline="") as f:
@@ -38,15 +44,14 @@ for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch", "fetch"), ("WRITE_SIZE", "pmc
     summary[ctr] = {"unit": "KB per launch (rocprofv3 counter value)", "launches": len(vals), "avg": sum(vals) / len(vals),
                     "scratch_bytes_per_lane": int(rows[0]["Scratch_Size"]), "vgpr": int(rows[0]["VGPR_Count"]),
                     "agpr": int(rows[0]["Accum_VGPR_Count"])}
-# Decrypt's lift kernel (k_pairing<38, 1>) from the passes with the extras.  The same kernel also serves makeL2 and
+# Decrypt's lift kernel (k_pairing<NL, 1>) from the passes with the extras.  The same kernel also serves makeL2 and
 # MultPoly's table evaluations there; the 2^20 Decrypt is its LONGEST launch (16 lifts per lane over the key's table)
 lift = {}
 for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE", "pmc_write_extra", "write")):
     path = os.path.join(src, sub, f"{stem}_counter_collection.csv")
     if not os.path.exists(path):
         continue
-    rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith("void bgn::k_pairing<38, 1>")
-            and r["Counter_Name"] == ctr]
+    rows = [r for r in csv.DictReader(open(path)) if LANE1.match(r["Kernel_Name"]) and r["Counter_Name"] == ctr]
     if rows:
         dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         longest = max(dur(r) for r in rows)
@@ -55,7 +60,7 @@ for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE"
         lift[ctr] = {"launches": len(vals), "avg": sum(vals) / len(vals), "grid": int(sel[0]["Grid_Size"]),
                      "avg_ms": sum(dur(r) for r in sel) / len(sel) / 1e6, "scratch_bytes_per_lane": int(sel[0]["Scratch_Size"])}
 if len(lift) == 2:
-    summary["decrypt_lift_k_pairing_38_1"] = dict(lift, hbm_bytes_per_launch=(lift["FETCH_SIZE"]["avg"] + lift["WRITE_SIZE"]["avg"]) * 1024,
+    summary["decrypt_lift_k_pairing_1"] = dict(lift, hbm_bytes_per_launch=(lift["FETCH_SIZE"]["avg"] + lift["WRITE_SIZE"]["avg"]) * 1024,
                                                   note="the longest launches of this kernel in the run: the lift of the 2^20 Decrypt of bench.py's extras")
 line = last_json_line(os.path.join(src, "bench_line.json"))
 alg = line["roofline"]["algorithmic_bytes_per_pairing"] * line["config"]["batch_per_gpu"]
@@ -63,7 +68,7 @@ total = (summary["FETCH_SIZE"]["avg"] + summary["WRITE_SIZE"]["avg"]) * 1024
 summary.update({
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes, no tracing) --output-format csv -- python3 bench.py "
                "--steps 1 --warmup 0 --no-cpu-baseline --no-extra",
-    "kernel": "k_pairing<38, 0>, 2^20 pairings per launch",
+    "kernel": line["roofline"]["kernel"] + ", 2^20 pairings per launch",
     "hbm_bytes_per_launch": total,
     "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": total / alg,

@@ -1,4 +1,4 @@
-// fp_experiments.hpp — two product variants measured against fp_mul (bgn_amd/csrc/fp28.hpp) in fp_rates.hip.
+// fp_experiments.hpp — two product variants measured against fp_mul (bgn_amd/csrc/fpmont.hpp) in fp_rates.hip.
 // NOT part of the product: experiments of round 3 (the only untried levers on the multiply-add count
 // of a field product).  Timing only — both compute a correct Montgomery product for their own radix / splitting,
 // but nothing here is wired into a kernel.
@@ -7,7 +7,7 @@
 //   (ii) one Karatsuba level on the a*b half: three 19x19 schoolbook products (1083 multiply-adds instead of 1444)
 //        into 76 double-width columns, then the 38 reduction rows unchanged.
 #pragma once
-#include "fp28.hpp"
+#include "fpmont.hpp"
 
 namespace bgn {
 

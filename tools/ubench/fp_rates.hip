@@ -1,10 +1,10 @@
-// Cycles per field operation of bgn_amd/csrc/fp28.hpp at the kernels' launch geometry
+// Cycles per field operation of bgn_amd/csrc/fpmont.hpp at the kernels' launch geometry
 // (256-thread workgroups, one wave per SIMD).  Build:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../bgn_amd/csrc fp_rates.hip -o fp_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "fp28.hpp"
+#include "fpmont.hpp"
 #include "fp_experiments.hpp"
 using namespace bgn;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)

@@ -2063,7 +2063,8 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     } else {
       kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
                   pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
-      c->aux_kernel = c->nl == 38 ? "k_pairing<38, 1>" : c->nl == 19 ? "k_pairing<19, 1>" : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
+      c->aux_kernel = c->nl == 37 ? "k_pairing<37, 1>" : c->nl == 36 ? "k_pairing<36, 1>" : c->nl == 19 ? "k_pairing<19, 1>"
+                                    : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
     }
     HIP_TRY(hipEventRecord(c->ev3, s));
     c->ev2_valid = true;

@@ -805,24 +805,35 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   const char* ev = getenv(mode >= 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
   const bool tw = coop_table_walk(c);
+  // with the lane-group kernel's table walk and power above it (profiles/r03_mid_batch_table.csv, whole calls, 1024
+  // bits: Decrypt of 1024 ciphertexts 7.1 ms cooperative against 7.6, of 2048 12.3 against 7.6; makeL2 of 1024 7.9
+  // against 7.1 ms; 512 bits: Decrypt 1024: 2.1 against 1.9 ms, makeL2 1024: 2.7 against 2.1) the cooperative kernel
+  // keeps what is below that kernel's one-round time
+  const bool quad_tw = tw && quad_limit(c) != 0;
   // mode 2: the lift of Decrypt.  The lane kernel walks the half-length table of the secret order (29 ms at 1024
   // bits, 4.5 ms at 512, whatever the batch below 65536); the cooperative kernel walks the same table in two or
   // three rounds per step (8192 lifts in 13 ms at 1024 bits, 8 ms at 512) — without the table walk it runs a whole
   // e(C, P) and wins only below ~2000 / ~800 ciphertexts
-  if (mode == 2) return tw ? (c->nl >= 38 ? 14000 : c->nl >= 19 ? 4000 : 2048) : (c->nl >= 38 ? 2000 : c->nl >= 19 ? 800 : 512);
+  if (mode == 2 || (mode == 3 && quad_tw)) {
+    if (quad_tw) return c->nl >= 36 ? 1150 : c->nl >= 19 ? 900 : 512;
+    return tw ? (c->nl >= 36 ? 14000 : c->nl >= 19 ? 4000 : 2048) : (c->nl >= 36 ? 2000 : c->nl >= 19 ? 800 : 512);
+  }
   // mode 3: Decrypt's power by the secret key: 1.5 rounds per bit on the waves (≈ 1 ms at 1024 bits, one element
   // per CU) against 2 products per bit on one lane (8 ms whatever the batch below 65536)
-  if (mode == 3) return c->nl >= 38 ? 2048 : c->nl >= 19 ? 1024 : 512;
+  if (mode == 3) return c->nl >= 36 ? 2048 : c->nl >= 19 ? 1024 : 512;
   // profiles/r02_small_batch.csv (MI355X): Mult at 1024 bits — 8192 pairings 114 ms cooperative against 166 ms,
   // 16384: 225 against 166; at 512 bits — 4096: 17.1 against 28.2 ms, 8192: 33.0 against 28.2.  makeL2 (both
   // kernels walk P's line table): 1024 bits — 8192: 52.5 against 54.3 ms, 16384: 103 against 54; 512 bits —
   // 4096: 8.7 against 10.6 ms, 8192: 16.7 against 10.6 (general cooperative program: 3000 / 1800).
-  if (mode == 1) return tw ? (c->nl >= 38 ? 8000 : c->nl >= 19 ? 4800 : 2048) : (c->nl >= 38 ? 3000 : c->nl >= 19 ? 1800 : 1024);
+  if (mode == 1) {
+    if (quad_tw) return c->nl >= 36 ? 900 : c->nl >= 19 ? 700 : 512;
+    return tw ? (c->nl >= 36 ? 8000 : c->nl >= 19 ? 4800 : 2048) : (c->nl >= 36 ? 3000 : c->nl >= 19 ? 1800 : 1024);
+  }
   // Mult: with the lane-group kernel above it (profiles/r03_mid_batch.csv: 1024 pairs 17.8 ms cooperative against
   // 21.2 ms, 1536: 25.1 against 21.3 at 1024 bits; 512 bits: 1024 pairs 5.3 against 5.2 ms) the crossover is where
   // that kernel's one-round time is reached; without it, the lane kernel's (r02_small_batch.csv)
-  if (quad_limit(c)) return c->nl >= 38 ? 1280 : c->nl >= 19 ? 1000 : 800;
-  return c->nl >= 38 ? 10000 : c->nl >= 19 ? 6000 : 4096;
+  if (quad_limit(c)) return c->nl >= 36 ? 1280 : c->nl >= 19 ? 1000 : 800;
+  return c->nl >= 36 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
 // Between the cooperative kernel's saturation and one pairing per lane filling the chip sits the lane-group kernel
@@ -837,8 +848,31 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
 static size_t quad_limit(const bgn_ctx* c) {
   if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
-  return c->nl >= 38 ? 44000 : c->nl >= 19 ? 40000 : 32768;
+  return c->nl >= 36 ? 44000 : c->nl >= 19 ? 40000 : 32768;
 }
+// The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
+// (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts
+// (profiles/r03_mid_batch_table.csv); BGN_QUAD_MAX_L2 / BGN_QUAD_MAX_DEC / BGN_QUAD_MAX_POW override, 0 disables.
+static size_t quad_table_limit(const bgn_ctx* c, int mode) {
+  const char* ev = getenv(mode == 3 ? "BGN_QUAD_MAX_POW" : mode == 2 ? "BGN_QUAD_MAX_DEC" : "BGN_QUAD_MAX_L2");
+  if (ev) return (size_t)strtoull(ev, nullptr, 10);
+  if (quad_ws_words(c->nl, 64) == 0 || !quad_limit(c)) return 0;
+  // profiles/r03_mid_batch_table.csv, whole calls at 1024 / 512 bits: Decrypt of 16384 ciphertexts 21.0 / 4.3 ms
+  // against 36.6 / 6.9 on the lane kernels, of 32768 36.7 / 7.5 against 36.9 / 6.9; makeL2 of 32768 37.4 / 8.5 against
+  // 53.2 / 10.6, of 65536 72.2 / 15.9 against 53.7 / 10.8
+  if (mode == 3 || mode == 2) return c->nl >= 36 ? 32000 : c->nl >= 19 ? 28000 : 16384;
+  return c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 16384;
+}
+
+static size_t quad_table_floor(const bgn_ctx* c, int mode) {
+  if (const char* ev = getenv("BGN_QUAD_MIN")) return (size_t)strtoull(ev, nullptr, 10);
+  // an explicit cooperative limit alone keeps its A/B meaning (cooperative below it, lane kernel above)
+  if (getenv(mode == 3 || mode == 2 ? "BGN_COOP_MAX_DEC" : "BGN_COOP_MAX_L2") && !getenv("BGN_QUAD_MAX_L2") &&
+      !getenv("BGN_QUAD_MAX_DEC") && !getenv("BGN_QUAD_MAX_POW"))
+    return (size_t)-1;
+  return coop_limit(c, mode);
+}
+
 static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
   size_t lo = coop_max;
   if (const char* ev = getenv("BGN_QUAD_MIN")) lo = (size_t)strtoull(ev, nullptr, 10);
@@ -849,7 +883,7 @@ static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
   if (!hi || count <= lo || quad_ws_words(c->nl, 64) == 0) return false;
   if (count <= hi) return true;
   // the second window: between one and two pairings per lane of the lane kernel (default limits only)
-  return !getenv("BGN_QUAD_MAX") && c->nl >= 38 && count > 65536 && count <= 88000;
+  return !getenv("BGN_QUAD_MAX") && c->nl >= 36 && count > 65536 && count <= 88000;
 }
 
 // Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with
@@ -886,7 +920,9 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   probe.soa(c->nl, sa, true);
   if (nb) probe.soa(c->nl, sb, true);
   probe.soa(c->nl, so, false);
-  const bool quad = mode == 0 && use_quad(c, count, coop_limit(c, 0));
+  // makeL2 of a mid-size batch walks the key's normalised line table on the lane-group kernel
+  const bool quad_tab = mode == 1 && coop_table_walk(c) && count > quad_table_floor(c, 1) && count <= quad_table_limit(c, 1);
+  const bool quad = quad_tab || (mode == 0 && use_quad(c, count, coop_limit(c, 0)));
   const bool coop = !quad && mode <= 1 && count <= coop_limit(c, mode);
   const size_t lane_ws = (size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4;
   const size_t ws_bytes = quad ? quad_ws_words(c->nl, so) * 4 : coop ? coop_ws_words(c->nl, so) * 4 : lane_ws;
@@ -915,7 +951,8 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   // makeL2 on the waves walks the key's normalised line table (6 / 4 products per step in 2 / 3 rounds instead of
   // a full pairing's 18 / 36 in 3 / 6); BGN_COOP_TABLE=0 keeps the general program
   const uint32_t* ctab = (mode == 1 && coop_table_walk(c)) ? c->d_fixedpair : nullptr;
-  if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0, ws, so, c->p_bits + 1)) {
+  if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0, ws, so, c->p_bits + 1,
+                                  quad_tab ? c->d_fixedpair : nullptr)) {
     c->last_kernel = quad_pairing_kernel_name(c->nl);
   } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
                                          (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1, ctab)) {
@@ -2034,8 +2071,9 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     X = w.gt(st);
     Y = w.gt(st);
     if (level == 1) {
-      const size_t lane_b = (size_t)3 * c->nl * st * 4, coop_b = coop_ws_words(c->nl, st) * 4;
-      pws = (uint32_t*)w.cv.take(count <= coop_limit(c, 2) && coop_b > lane_b ? coop_b : lane_b);
+      const size_t lane_b = (size_t)3 * c->nl * st * 4, coop_b = coop_ws_words(c->nl, st) * 4, quad_b = quad_ws_words(c->nl, st) * 4;
+      const size_t small_b = coop_b > quad_b ? coop_b : quad_b;
+      pws = (uint32_t*)w.cv.take(count <= quad_table_limit(c, 2) || count <= coop_limit(c, 2) ? (small_b > lane_b ? small_b : lane_b) : lane_b);
     }
     todo = (uint32_t*)w.cv.take(st * 4);
     todo_count = (uint32_t*)w.cv.take(256);
@@ -2056,7 +2094,12 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     // per step instead of a whole table loop on a single lane: 28 ms at a 1024-bit key); the power by q1 below
     // gives the same e(C, P)^q1 whichever scalar the loop ran over
     const bool ctab = coop_table_walk(c);                            // the table walk, over q2 when its table exists
-    if (count <= coop_limit(c, 2) &&
+    // ... and a mid-size batch with the lane-group kernel (sixteen lanes per lift, two or three rounds per step)
+    if (ctab && count > quad_table_floor(c, 2) && count <= quad_table_limit(c, 2) &&
+        quad_pairing_launch(c->nl, s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pws,
+                            st, c->p_bits + 1, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair)) {
+      c->aux_kernel = quad_pairing_kernel_name(c->nl);
+    } else if (count <= coop_limit(c, 2) &&
         coop_pairing_launch(c->nl, s, c->d_params, (ctab && sk_tab) ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1,
                             0, 0, pws, st, c->p_bits + 1, ctab ? (sk_tab ? c->d_fixedpair_sk : c->d_fixedpair) : nullptr)) {
       c->aux_kernel = coop_pairing_kernel_name(c->nl);
@@ -2078,6 +2121,10 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
     if (ev && ev[0] == '0') {
       gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);
       kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
+    } else if (count > quad_table_floor(c, 3) && count <= quad_table_limit(c, 3) &&
+               quad_gt_pow_launch(c->nl, s, c->d_params, base.c0, base.c1, base.stride, c->d_sk, c->sk_len, Y.c0, Y.c1, Y.stride,
+                                  count)) {
+      // a mid-size batch: the same square-and-multiply on the lane groups, sixteen lanes per element
     } else if (count <= coop_limit(c, 3) &&
                coop_gt_pow_launch(c->nl, s, c->d_params, base.c0, base.c1, base.stride, c->d_sk, 0, c->sk_len, Y.c0, Y.c1,
                                   Y.stride, count)) {

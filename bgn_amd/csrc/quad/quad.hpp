@@ -39,7 +39,7 @@ namespace bgn {
 #include "quad_prog.inc"
 
 constexpr int QUAD_W = QUADM_W;                       // quads per pairing = micro-ops per round
-static_assert(QUADM_W == 4 && QUADF_W == 4 && QUADM_MAX_TERMS == QUADF_MAX_TERMS, "four quads of four lanes per pairing");
+static_assert(QUADM_W == 4 && QUADF_W == 4 && QUADT_W == 4 && QUADM_MAX_TERMS == QUADF_MAX_TERMS && QUADT_MAX_TERMS == QUADF_MAX_TERMS, "four quads of four lanes per pairing");
 constexpr int QUAD_MAX_TERMS = QUADM_MAX_TERMS;
 constexpr int QUAD_BLOCK = 256;                       // four waves, one per SIMD
 constexpr int QUAD_LANES = 4 * QUAD_W;                // lanes per pairing
@@ -61,6 +61,14 @@ struct QuadFinal {
   static __device__ __forceinline__ u32 round_header(int r) { return kQuadfRound[r]; }
   static __device__ __forceinline__ int seg_first(int s) { return (int)kQuadfSegFirst[s]; }
   static __device__ __forceinline__ int seg_rounds(int s) { return (int)kQuadfSegRounds[s]; }
+};
+
+struct QuadTable {
+  static constexpr int NSLOTS = QUADT_NSLOTS;
+  static __device__ __forceinline__ const u32* prog(int i) { return kQuadtProg[i]; }
+  static __device__ __forceinline__ u32 round_header(int r) { return kQuadtRound[r]; }
+  static __device__ __forceinline__ int seg_first(int s) { return (int)kQuadtSegFirst[s]; }
+  static __device__ __forceinline__ int seg_rounds(int s) { return (int)kQuadtSegRounds[s]; }
 };
 
 template <int NL>
@@ -531,6 +539,196 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
       }
       if (live) quad_gstore<NL>(c.quad == 0 ? out.c0 : out.c1, out.stride, e, c.sub, x);
     }
+  }
+}
+
+// Tight limbs of the representative in [0, p) of a lazily normalised value in [0, 16p): conditional subtractions
+// of 8p, 4p, 2p, p after the exact carry resolution.
+template <int NL>
+__device__ __forceinline__ void quad_canonical16(int (&x)[QuadDims<NL>::M], const QuadLane<NL>& c) {
+  constexpr int M = QuadDims<NL>::M, JT = QuadDims<NL>::JTOP;
+  quad_tight<NL>(x, c);
+#pragma unroll 1
+  for (int m = 8; m >= 1; m >>= 1) {
+    int d[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) d[j] = x[j] - m * (int)c.p[j];
+    quad_tight<NL>(d, c);
+    const int top = quad_bcast<3>(d[JT]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[j] = top < 0 ? x[j] : d[j];
+  }
+}
+
+// Launch 1 in its table form (fixedpair.hpp miller_loop_fixed on the lane groups): e(K, a[e]) over the NORMALISED line
+// table of the key point K — makeL2 over P's table along the NAF of n (bgn.go:316-321), the level-1 decryption lift
+// over the table of q1*P along the NAF of q2 = n / q1 (bgn.go:222-223).  tab: limb j of value v of step s at
+// tab[(3 s + v) NL + j], v = 0: a_s/c_s, 1: b_s/c_s, built for the scalar whose NAF C holds.  A segment is one
+// doubling step (TD: two rounds) or a doubling and the addition after a non-zero digit (TDA: three rounds); quad k
+// requests coefficient k of the NEXT segment (step k >> 1, value k & 1) from memory before the current segment runs
+// and stores it into its slot after the segment's last round — in place: the round's reads are done.
+// Ends like PHASE 1 of k_pairing_quad: F0^2, F1^2, F0*F1 parked, N(f) as tight limbs in nsoa.
+template <int NL>
+__global__ void __launch_bounds__(QUAD_BLOCK)
+k_pairing_quad_table(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, size_t count,
+                     const u32* __restrict__ tab, u32* __restrict__ park, u32* __restrict__ nsoa, size_t ws) {
+  constexpr int M = QuadDims<NL>::M;
+  using PG = QuadTable;
+  static_assert(QUADT_SLOT_TB1 == QUADT_SLOT_TA1 + 1 && QUADT_SLOT_TA2 == QUADT_SLOT_TA1 + 2 && QUADT_SLOT_TB2 == QUADT_SLOT_TA1 + 3,
+                "coefficient slots are consecutive");
+  __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
+  char* V = reinterpret_cast<char*>(Vs);
+  QuadLane<NL> c;
+  quad_lane_init<NL>(c, P);
+  size_t e = (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);
+  const bool live = e < count;
+  if (!live) e = count - 1;
+  int x[M];
+  auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
+  // coefficient k = c.quad of the segment that starts at table step s: this lane's limbs
+  auto coef = [&](size_t s) {
+    const u32* src = tab + ((size_t)3 * (s + (size_t)(c.quad >> 1)) + (size_t)(c.quad & 1)) * NL;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int pos = c.sub * M + j;
+      x[j] = pos < NL ? (int)src[pos < NL ? pos : 0] : 0;
+    }
+  };
+  if (c.quad == 0) {
+    quad_gload<NL>(x, a.c0, a.stride, e, c.sub);
+    put(QUADT_SLOT_AX);
+  } else if (c.quad == 1) {
+    quad_gload<NL>(x, a.c1, a.stride, e, c.sub);
+    put(QUADT_SLOT_AY);
+  } else if (c.quad == 2) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int pos = c.sub * M + j;
+      x[j] = pos < NL ? (int)P->one[pos < NL ? pos : 0] : 0;
+    }
+    put(QUADT_SLOT_V0);
+    put(QUADT_SLOT_V2);
+  } else {
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[j] = 0;
+    put(QUADT_SLOT_V1);
+  }
+  const u32* nafw = reinterpret_cast<const u32*>(C->naf);
+  auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
+  auto both_at = [&](int i) { return digit(i) != 0 && i != 0; };
+  int i = C->naf_len - 2;
+  size_t s = 0;
+  if (i >= 0 && (c.quad < 2 || both_at(i))) {      // the first segment's coefficients
+    coef(0);
+    put(QUADT_SLOT_TA1 + c.quad);
+  }
+  bool norms = false;
+#pragma unroll 1
+  for (;;) {
+    int seg;
+    bool fetch = false;
+    if (i >= 0) {
+      const bool both = both_at(i);
+      seg = both ? QUADT_SEG_TDA : QUADT_SEG_TD;
+      s += both ? 2 : 1;
+      i -= 1;
+      fetch = i >= 0 && (c.quad < 2 || both_at(i));   // this quad's coefficient of the next segment (per quad: divergent)
+      if (fetch) coef(s);
+    } else if (!norms) {
+      seg = QUADT_SEG_NORM;
+      norms = true;
+    } else {
+      break;
+    }
+    int pre[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) pre[j] = x[j];
+    quad_run<NL, PG>(V, seg, c);
+    if (fetch) quad_store<NL>(V, quad_addr<NL>((u32)(QUADT_SLOT_TA1 + c.quad), c), pre);
+  }
+  if (c.quad < 3) {
+    const int slot = c.quad == 0 ? QUADT_SLOT_N1 : c.quad == 1 ? QUADT_SLOT_N2 : QUADT_SLOT_FM;
+    quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c));
+    if (live) {
+      u32* dst = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+#pragma unroll
+      for (int j = 0; j < M; ++j) dst[j] = (u32)x[j];
+    }
+  } else {
+    int y[M];
+    quad_load<NL>(x, V, quad_addr<NL>((u32)QUADT_SLOT_N1, c));
+    quad_load<NL>(y, V, quad_addr<NL>((u32)QUADT_SLOT_N2, c));
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[j] += y[j];
+    quad_tight<NL>(x, c);
+    if (live) quad_gstore<NL>(nsoa, ws, e, c.sub, x);
+  }
+}
+
+// base^k in F_p^2 for mid-size batches with ONE exponent for all elements (Decrypt's csk.PowBig(ct.C, sk.Key),
+// bgn.go:223, 277): square-and-multiply over the bits of k with the segments of the final exponentiation's ^l (a
+// squaring: 2 products in one round; a product by the base: 4 in two rounds), sixteen lanes per element.
+// a: canonical Montgomery SoA; k: big-endian bytes (klen <= 256); out: canonical Montgomery SoA.  k = 0 gives 1.
+template <int NL>
+__global__ void __launch_bounds__(QUAD_BLOCK)
+k_gt_pow_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ a0, const u32* __restrict__ a1, size_t sa,
+              const uint8_t* __restrict__ k, size_t klen, u32* __restrict__ o0, u32* __restrict__ o1, size_t so, size_t count) {
+  constexpr int M = QuadDims<NL>::M;
+  using PG = QuadFinal;
+  __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
+  char* V = reinterpret_cast<char*>(Vs);
+  QuadLane<NL> c;
+  quad_lane_init<NL>(c, P);
+  size_t e = (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);
+  const bool live = e < count;
+  if (!live) e = count - 1;
+  int x[M];
+  auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
+  if (c.quad == 0) {
+    quad_gload<NL>(x, a0, sa, e, c.sub);
+    put(QUADF_SLOT_H0);
+    put(QUADF_SLOT_R0);
+  } else if (c.quad == 1) {
+    quad_gload<NL>(x, a1, sa, e, c.sub);
+    put(QUADF_SLOT_H1);
+    put(QUADF_SLOT_R1);
+  }
+  // top set bit of the exponent (wave-uniform: scalar byte loads)
+  int top = -1;
+  for (size_t b = 0; b < klen && top < 0; ++b) {
+    const u32 v = k[b];
+    if (v) top = (int)(8 * (klen - 1 - b)) + 31 - __builtin_clz(v);
+  }
+  auto bit = [&](int i) { return (k[klen - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u; };
+  int i = top - 1;
+  bool mul = false;
+#pragma unroll 1
+  for (;;) {
+    int seg;
+    if (mul) {
+      seg = QUADF_SEG_LMU;
+      mul = false;
+      --i;
+    } else if (i >= 0) {
+      seg = QUADF_SEG_LSQ;
+      if (bit(i)) mul = true;
+      else --i;
+    } else {
+      break;
+    }
+    quad_run<NL, PG>(V, seg, c);
+  }
+  if (c.quad < 2) {
+    quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUADF_SLOT_R0 : QUADF_SLOT_R1), c));
+    if (top < 0) {                                 // k = 0: the result is 1 (Montgomery one, zero)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int pos = c.sub * M + j;
+        x[j] = (c.quad == 0 && pos < NL) ? (int)P->one[pos < NL ? pos : 0] : 0;
+      }
+    }
+    quad_canonical16<NL>(x, c);
+    if (live) quad_gstore<NL>(c.quad == 0 ? o0 : o1, so, e, c.sub, x);
   }
 }
 

@@ -28,7 +28,7 @@ _QPROGRAMS = None
 
 
 def programs():
-    """(Miller-loop program, final-exponentiation program)."""
+    """(Miller-loop program, final-exponentiation program, Miller loop over a key's line table)."""
     global _QPROGRAMS
     if _QPROGRAMS is None:
         _QPROGRAMS = gen_prog.build_quad_programs()
@@ -45,7 +45,7 @@ class QuadValueMachine:
         self.p, self.nl = p, nl
         self.R = 1 << (LIMB * nl)
         self.pinvR = (-pow(p, -1, self.R)) % self.R
-        self.PM, self.PF = programs()
+        self.PM, self.PF, self.PT = programs()
         self.P = self.PM
         self.V = {}                      # physical slot -> value
         self.rounds_run = 0
@@ -121,6 +121,29 @@ class QuadValueMachine:
         self.run("NORM")
         return [self.get(k) for k in ("n1", "n2", "fm")]
 
+    def miller_table(self, xc, yc, table, n):
+        """Launch 1 in its table form: e(K, C) over the normalised line table of the key point K (TD / TDA segments;
+        the coefficients of a segment's steps are put in their slots before it, as the kernel's prefetch does)."""
+        self.P = self.PT
+        self.V = {}
+        for k, v in (("ax", xc), ("ay", yc), ("v0", 1), ("v2", 1)):
+            self.put(k, self.mont(v))
+        self.put("v1", 0)
+        s = 0
+        d = naf(n)
+        for i in range(len(d) - 2, -1, -1):
+            both = bool(d[i]) and i != 0
+            self.put("ta1", self.mont(table[s][0]))
+            self.put("tb1", self.mont(table[s][1]))
+            if both:
+                self.put("ta2", self.mont(table[s + 1][0]))
+                self.put("tb2", self.mont(table[s + 1][1]))
+            self.run("TDA" if both else "TD")
+            s += 2 if both else 1
+        assert s == len(table)
+        self.run("NORM")
+        return [self.get(k) for k in ("n1", "n2", "fm")]
+
     def final(self, parked, inv, l):
         """Launch 2: parked values and inv = R^2 / N(f) mod p (what k_coop_invert writes) -> the two output slots."""
         self.P = self.PF
@@ -137,13 +160,19 @@ class QuadValueMachine:
         self.run("OUT")
         return self.get("out0"), self.get("out1")
 
-    def pairing(self, ax, ay, bx, by, n, l):
-        """e(A, B); plain residues in and out."""
-        parked = self.miller(ax, ay, bx, by, n)
+    def _finish(self, parked, l):
         N = (self.value(parked[0]) + self.value(parked[1])) % self.p
         inv = self.R * self.R * pow(N, -1, self.p) % self.p
         o0, o1 = self.final(parked, inv, l)
         return self.value(o0) % self.p, self.value(o1) % self.p
+
+    def pairing(self, ax, ay, bx, by, n, l):
+        """e(A, B); plain residues in and out."""
+        return self._finish(self.miller(ax, ay, bx, by, n), l)
+
+    def pairing_table(self, xc, yc, table, n, l):
+        """e(K, C) from K's line table (coop_model.line_table)."""
+        return self._finish(self.miller_table(xc, yc, table, n), l)
 
 
 def to_quad(v: int, nl: int) -> np.ndarray:

@@ -178,29 +178,32 @@ def test_table_walk_on_the_waves_matches_the_general_program_and_the_lane_kernel
     assert res["table"][1] == want and not any(res["table"][2])
 
 
-def test_decrypt_between_the_two_crossovers_mixes_the_kernels():
-    """A Decrypt batch above the crossover of the power (k_gt_pow_coop) and below that of the lift takes the
-    cooperative table walk for the lift and the lane ladder for the power — the default dispatch, no overrides.
-    1000 ciphertexts at the 256-bit key (limits 2048 / 512 there): plaintexts and statuses as encrypted, and equal
-    to the all-lane path."""
+def test_decrypt_default_dispatch_by_batch_size():
+    """The default dispatch of Decrypt, no overrides, at the 256-bit key (cooperative crossover 512 there): 300
+    ciphertexts lift and power on the cooperative kernels, 1000 on the lane-group kernels (table walk over the secret
+    order's line table + square-and-multiply by the secret key); plaintexts and statuses as encrypted, and equal to
+    the all-lane path."""
     import os
     fx = load_fixture("k256")
     pk, sk = engine_key(fx)
     pk.SetupDecryption(sk)
     eng = pk.engine
-    for v in ("BGN_COOP_MAX_DEC", "BGN_COOP_TABLE"):
+    for v in ("BGN_COOP_MAX_DEC", "BGN_COOP_TABLE", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MIN"):
         assert v not in os.environ
     rng = random.Random(12)
     n, T = int(fx["n"], 16), fx["msg_space"]
     ms = [rng.randrange(T) for _ in range(1000)]
     cts = eng.encrypt(ms, [rng.randrange(n) for _ in ms]).tobytes()
     m, st = eng.decrypt(1, cts)
-    assert "coop" in eng.last_aux_kernel_name()
+    assert "quad" in eng.last_aux_kernel_name()
     assert m.tolist() == ms and not st.any()
+    ms3, st3 = eng.decrypt(1, cts[: 300 * eng.elem_bytes])
+    assert "coop" in eng.last_aux_kernel_name()
+    assert ms3.tolist() == ms[:300] and not st3.any()
     os.environ["BGN_COOP_MAX_DEC"] = "0"
     try:
         m0, st0 = eng.decrypt(1, cts)
-        assert "coop" not in eng.last_aux_kernel_name()
+        assert "coop" not in eng.last_aux_kernel_name() and "quad" not in eng.last_aux_kernel_name()
     finally:
         del os.environ["BGN_COOP_MAX_DEC"]
     assert m0.tolist() == ms and st0.tolist() == st.tolist()

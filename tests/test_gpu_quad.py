@@ -94,7 +94,7 @@ def test_default_dispatch_uses_the_lane_group_kernel_between_the_crossovers():
     pairing per lane filling the chip: the engine picks the lane-group kernel by itself; 64 pairs go to the
     cooperative kernel.  Both give the bytes of the golden vectors (the batch repeats them)."""
     fx = load_fixture("k1024")
-    pk, _ = engine_key(fx)
+    pk, sk = engine_key(fx)
     eng = pk.engine
     cts = [e["ct"] for e in fx["encrypt"]]
     reps = 12000 // len(fx["mult"]) + 1
@@ -107,6 +107,25 @@ def test_default_dispatch_uses_the_lane_group_kernel_between_the_crossovers():
         assert bytes(out[i]).hex() == want[i % len(want)]
     out = eng.mult(a[: 64 * eng.elem_bytes], b[: 64 * eng.elem_bytes])
     assert "coop" in eng.last_kernel_name()
+    # makeL2 and Decrypt of 5 000 ciphertexts walk the key's line tables on the lane-group kernel by default; 200 go
+    # to the cooperative kernel, 2^16 to the lane kernels
+    pk.SetupDecryption(sk)
+    five = a[: 5000 * eng.elem_bytes]
+    l2 = eng.make_l2(five)
+    assert "quad" in eng.last_kernel_name()
+    want_l2 = {v["a"]: v["out"] for v in fx["make_l2"]}
+    for i, v in enumerate(fx["mult"][:4]):
+        if v["a"] in want_l2:
+            assert bytes(l2[i]).hex() == want_l2[v["a"]]
+    m, st = eng.decrypt(1, five)
+    assert "quad" in eng.last_aux_kernel_name()
+    m200, st200 = eng.decrypt(1, five[: 200 * eng.elem_bytes])
+    assert "coop" in eng.last_aux_kernel_name()
+    assert m[:200].tolist() == m200.tolist() and st[:200].tolist() == st200.tolist()
+    big = a[: 65536 * eng.elem_bytes] if len(a) >= 65536 * eng.elem_bytes else (a * (65536 * eng.elem_bytes // len(a) + 1))[: 65536 * eng.elem_bytes]
+    mb, sb = eng.decrypt(1, big)
+    assert "quad" not in eng.last_aux_kernel_name() and "coop" not in eng.last_aux_kernel_name()
+    assert mb[:200].tolist() == m200.tolist() and sb[:200].tolist() == st200.tolist()
 
 
 @pytest.mark.parametrize("name", ["k512", "k1024"])
@@ -133,3 +152,72 @@ def test_zero_norm_yields_the_identity_on_every_kernel(name, monkeypatch):
         assert (kernel in eng.last_kernel_name()) == (kernel != "lane")
         assert bytes(out[0]).hex() == good[0]["out"] and bytes(out[2]).hex() == good[1]["out"], kernel
         assert bytes(out[1]) == one, kernel
+
+
+def force_table(monkeypatch, kernel):
+    """The walks over a key's line table (makeL2, Decrypt's lift) and Decrypt's power on 'quad', 'coop' or 'lane'."""
+    big = "100000000"
+    monkeypatch.setenv("BGN_QUAD_MIN", "0")
+    for v in ("BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
+        monkeypatch.setenv(v, big if kernel == "quad" else "0")
+    for v in ("BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
+        monkeypatch.setenv(v, big if kernel == "coop" else "0")
+
+
+@pytest.mark.parametrize("name", QUAD_KEYS)
+def test_make_l2_golden_on_the_lane_group_table_walk(name, monkeypatch):
+    force_table(monkeypatch, "quad")
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    cts = [e["ct"] for e in fx["encrypt"]]
+    out = eng.make_l2(H([cts[v["a"]] for v in fx["make_l2"]]))
+    assert "quad" in eng.last_kernel_name()
+    for row, v in zip(out, fx["make_l2"]):
+        assert bytes(row).hex() == v["out"], f"{name}: makeL2({v['a']}) on the lane-group kernel"
+
+
+@pytest.mark.parametrize("name,count", [("k256", 70), ("k512", 41), ("k1024", 33), ("k1024b", 17)])
+def test_table_walk_and_power_on_the_lane_groups_match_the_other_kernels(name, count, monkeypatch):
+    """makeL2 and level-1 / level-2 Decrypt of a batch with an identity, a negative and an out-of-range value: the
+    lane-group kernels (table walk over P's table / over the secret order's table, power by the secret key), the
+    cooperative kernels and the lane kernels give the same bytes, plaintexts and statuses; makeL2 also equals the C
+    oracle.  k1024b: 37 limbs (10 per lane, the top limb in lane 3 at index 6)."""
+    import oracle_c
+    import bgn_amd
+    fx = load_fixture(name)
+    if name == "k1024b":
+        pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                               fx["msg_space"], True, fx["poly_base"])
+        sk = bgn_amd.SecretKey(int(fx["q1"], 16))
+        pk.engine.set_memory_budget(40 << 30)
+    else:
+        pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng = pk.engine
+    o = oracle_c.Oracle.from_fixture(fx)
+    rng = random.Random(count)
+    n = int(fx["n"], 16)
+    T = fx["msg_space"]
+    ms = [rng.randrange(T) for _ in range(count)]
+    ms[4] = 3 * T + 11                                                # no discrete log in either direction
+    cts = eng.encrypt(ms, [rng.randrange(n) for _ in ms]).copy()
+    cts[2] = 0                                                       # an identity
+    cts[3] = eng.neg(1, cts[3:4])[0]
+    wire = cts.tobytes()
+    res = {}
+    for kernel in ("quad", "coop", "lane"):
+        force_table(monkeypatch, kernel)
+        l2 = eng.make_l2(wire).tobytes()
+        assert (kernel in eng.last_kernel_name()) == (kernel != "lane"), eng.last_kernel_name()
+        m1, s1 = eng.decrypt(1, wire)
+        assert (kernel in eng.last_aux_kernel_name()) == (kernel != "lane"), eng.last_aux_kernel_name()
+        m2, s2 = eng.decrypt(2, l2)
+        res[kernel] = (l2, m1.tolist(), s1.tolist(), m2.tolist(), s2.tolist())
+    assert res["quad"] == res["lane"] == res["coop"]
+    assert res["quad"][0] == o.mult(wire)                              # b = None: e(., P), makeL2
+    want = list(ms)
+    want[2], want[3] = 0, -ms[3]
+    st = res["quad"][2]
+    assert st[4] == 1 and not any(st[:4]) and not any(st[5:])
+    assert [v for i, v in enumerate(res["quad"][1]) if i != 4] == [v for i, v in enumerate(want) if i != 4]

@@ -578,7 +578,53 @@ def build_quad_programs(w=QUAD_W):
         b.mul(r1, raw1, out="out1")
     F.segment("OUT", seg_out)
     F.allocate_temps()
-    return M, F
+    # ---- launch 1, table form: the Miller loop over a key's normalised line table (fixedpair.hpp; makeL2 and the
+    # level-1 decryption lift).  The evaluation point phi(C) sits in (ax, ay); a segment consumes the coefficients
+    # (a_s/c_s, b_s/c_s) of one step (TD: f <- f^2 * l, six products in two rounds) or two (TDA: the addition after a
+    # non-zero digit, ten in three); the kernel fetches the next segment's coefficients while this one runs and
+    # stores them, in place, after its last round.
+    T = Program(w, w, reads_first=True)
+    OT = {k: T.fixed(k, 1) for k in ("ax", "ay")}
+    tc = {k: T.fixed(k, 1) for k in ("ta1", "tb1", "ta2", "tb2")}
+    fst = {k: T.fixed(k, STATE_BOUNDS[k]) for k in ("v0", "v1", "v2")}
+    fnew = {k: S(k + "'") for k in fst}
+    fin = {k + "'": k for k in fst}
+
+    def seg_td(b):
+        for k in fst:
+            b.bound[k + "'"] = STATE_BOUNDS[k]
+        F0, F1 = f_of(fst)
+        cre, cim = tab_line(b, tc, 1, OT)
+        g0 = b.mul(F0 + F1, F0 - F1)
+        g1h = b.mul(F0, F1)
+        finish_f(b, g0, 2 * g1h, cre, cim, fnew)
+    T.segment("TD", seg_td, fin)
+
+    def seg_tda(b):
+        for k in fst:
+            b.bound[k + "'"] = STATE_BOUNDS[k]
+        F0, F1 = f_of(fst)
+        cre, cim = tab_line(b, tc, 1, OT)
+        cre2, cim2 = tab_line(b, tc, 2, OT)
+        g0 = b.mul(F0 + F1, F0 - F1)
+        g1h = b.mul(F0, F1)
+        mid = {k: S("TDA.%s" % k) for k in fst}
+        for k, f in mid.items():
+            b.bound[name(f)] = STATE_BOUNDS[k]
+        finish_f(b, g0, 2 * g1h, cre, cim, mid)
+        M0, M1 = f_of(mid)
+        finish_f(b, M0, M1, cre2, cim2, fnew)
+    T.segment("TDA", seg_tda, fin)
+    tn1, tn2, tfm = (T.fixed(k, 2) for k in ("n1", "n2", "fm"))
+
+    def seg_tnorm(b):
+        F0, F1 = f_of(fst)
+        b.mul(F0, F0, out="n1")
+        b.mul(F1, F1, out="n2")
+        b.mul(F0, F1, out="fm")
+    T.segment("NORM", seg_tnorm)
+    T.allocate_temps()
+    return M, F, T
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -679,19 +725,21 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, a
 
 QUAD_MILLER_SLOTS = ("ax", "ay", "bx", "by", "X", "Y", "Z", "ZZ", "W", "v0", "v1", "v2", "n1", "n2", "fm")
 QUAD_FINAL_SLOTS = ("n1", "n2", "fm", "inv", "raw1", "h0", "h1", "r0", "r1", "out0", "out1")
+QUAD_TABLE_SLOTS = ("ax", "ay", "ta1", "tb1", "ta2", "tb2", "v0", "v1", "v2", "n1", "n2", "fm")
 
 
 def emit_quad(path, verbose=True):
     """Both programs of the lane-group kernel into one include: QUADM (Miller loop + norms), QUADF (the rest of the
     final exponentiation)."""
-    M, F = build_quad_programs()
+    M, F, T = build_quad_programs()
     emit(M, path, prefix="QUADM", round_headers=True, slot_names=QUAD_MILLER_SLOTS)
     emit(F, path, prefix="QUADF", round_headers=True, slot_names=QUAD_FINAL_SLOTS, append=True)
+    emit(T, path, prefix="QUADT", round_headers=True, slot_names=QUAD_TABLE_SLOTS, append=True)
     if verbose:
-        for P in (M, F):
+        for P in (M, F, T):
             print(summary(P))
             print("slots:", P.nslots, "->", path)
-    return M, F
+    return M, F, T
 
 
 def summary(P):

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Mid-size batches: Mult wall time by batch size on the three pairing kernels — the wave-cooperative one
-(coop/coop.hpp), the lane-group one (quad/quad.hpp) and one pairing per lane (pairing.hpp) — device-resident operands,
-best of three, results compared.  The crossovers of coop_limit / quad_limit (engine.cpp) are chosen from this CSV:
-    python tools/quad_sweep.py [k1024 ...] > profiles/r03_mid_batch.csv"""
+"""Mid-size batches: wall time by batch size on the three kernel families — the wave-cooperative one
+(coop/coop.hpp), the lane-group one (quad/quad.hpp) and one element per lane — device-resident operands, best of
+three, results compared.  Operations (QUAD_SWEEP_OPS, default "mult"): mult; make_l2 and decrypt_l1 (walks over a
+key's line table; Decrypt also its power by the secret key).  The crossovers of coop_limit / quad_limit /
+quad_table_limit (engine.cpp) are chosen from these CSVs:
+    python tools/quad_sweep.py [k1024 ...] > profiles/r03_mid_batch.csv
+    QUAD_SWEEP_OPS=make_l2,decrypt_l1 python tools/quad_sweep.py > profiles/r03_mid_batch_table.csv"""
 import os
 import sys
 import time
@@ -22,6 +25,7 @@ def main():
     keys = sys.argv[1:] or ["k512", "k1024"]
     counts = [int(x) for x in os.environ.get("QUAD_SWEEP_COUNTS", "256,1024,2048,4096,6144,8192,12288,16384,32768,49152,65536").split(",")]
     kernels = os.environ.get("QUAD_SWEEP_KERNELS", "quad,coop,lane").split(",")
+    ops = os.environ.get("QUAD_SWEEP_OPS", "mult").split(",")
     print("key,op,count,kernel,ms,ops_per_s,kernel_name")
     dev = torch.device("cuda", 0)
     for key in keys:
@@ -35,24 +39,39 @@ def main():
         b = syn.permuted_copy(cts, EB, seed=4)
         out = torch.empty(nmax * EB, dtype=torch.uint8, device=dev)
         ref = {}
-        for kernel in kernels:
-            os.environ["BGN_QUAD_MIN"] = "0"
-            os.environ["BGN_QUAD_MAX"] = "100000000" if kernel == "quad" else "0"
-            os.environ["BGN_COOP_MAX"] = "100000000" if kernel == "coop" else "0"
-            for n in counts:
-                if kernel == "coop" and n > 16384:
-                    continue
-                best = None
-                for rep in range(3):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    eng.mult_dev(cts[: n * EB], b[: n * EB], out, n)
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t0
-                    best = dt if best is None or dt < best else best
-                digest = hash(out[: n * EB].cpu().numpy().tobytes())
-                assert ref.setdefault(n, digest) == digest, "kernels disagree at %d" % n
-                print("%s,mult,%d,%s,%.4f,%.1f,%s" % (key, n, kernel, best * 1e3, n / best, eng.last_kernel_name()), flush=True)
+        if "decrypt_l1" in ops:
+            pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+        msg = torch.empty(nmax, dtype=torch.int64, device=dev)
+        sta = torch.empty(nmax, dtype=torch.uint8, device=dev)
+        big = "100000000"
+        for op in ops:
+            for kernel in kernels:
+                os.environ["BGN_QUAD_MIN"] = "0"
+                for v in ("BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
+                    os.environ[v] = big if kernel == "quad" else "0"
+                for v in ("BGN_COOP_MAX", "BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
+                    os.environ[v] = big if kernel == "coop" else "0"
+                for n in counts:
+                    if kernel == "coop" and n > 16384:
+                        continue
+                    best = None
+                    for rep in range(3):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        if op == "mult":
+                            eng.mult_dev(cts[: n * EB], b[: n * EB], out, n)
+                        elif op == "make_l2":
+                            eng.make_l2_dev(cts[: n * EB], out, n)
+                        else:
+                            eng.decrypt_dev(1, cts[: n * EB], msg, sta, n)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                        best = dt if best is None or dt < best else best
+                    digest = hash(out[: n * EB].cpu().numpy().tobytes()) if op != "decrypt_l1" else \
+                        hash(msg[:n].cpu().numpy().tobytes() + sta[:n].cpu().numpy().tobytes())
+                    assert ref.setdefault((op, n), digest) == digest, "kernels disagree at %s %d" % (op, n)
+                    name = eng.last_aux_kernel_name() if op == "decrypt_l1" else eng.last_kernel_name()
+                    print("%s,%s,%d,%s,%.4f,%.1f,%s" % (key, op, n, kernel, best * 1e3, n / best, name), flush=True)
 
 
 if __name__ == "__main__":

@@ -462,6 +462,11 @@ class PublicKey {
   // ---- bgn.go:195-201 ----
   void SetupDecryption(const SecretKey& sk) const;
 
+  // Device memory of this key's tables and workspace (the reference keeps the tables of every key in package
+  // globals, gsbs.go:12-15): a cap for the tables built from now on (0: none), and what the context holds.
+  void SetMemoryBudget(uint64_t bytes) const { check(bgn_ctx_set_memory_budget(h_, bytes), "bgn_ctx_set_memory_budget"); }
+  uint64_t MemoryBytes() const { return bgn_ctx_memory_bytes(h_); }
+
   // ---- wire envelopes: bgn.go:501-560 ----
   Ciphertext NewCiphertextFromBytes(const Bytes& data) const {
     gob::Envelope w = gob::decode(data);

@@ -79,7 +79,7 @@ class Emu:
         img = limbs(p, nl) + limbs(R % p, nl) + limbs(R * R % p, nl)
         for K in range(1, KP_MAX + 1):
             img += limbs(K * p, nl)
-        img += [(-pow(p, -1, 1 << 28)) % (1 << 28), 0, 0, 0]
+        img += [(-pow(p, -1, 1 << LIMB)) % (1 << LIMB), 0, 0, 0]
         self.params = (C.c_uint32 * len(img))(*img)
         d = naf(n)
         pm2 = p - 2

@@ -269,3 +269,18 @@ def test_emu_dword_codec_matches_the_byte_codec(nl):
             assert all(int(limbs_out[i * nl + j]) < (1 << emu.LIMB) for j in range(nl))
             assert got == v, (nl, L, i, hex(v), hex(got))
         assert wire_out.raw == wire, (nl, L)
+
+
+@pytest.mark.parametrize("name", ["k1024", "k1024b"])
+def test_emu_pairing_at_36_and_37_limbs(name):
+    """1024-bit keys: 36 limbs (p of 1031 bits) and 37 (1037 bits) — the products that flush their accumulators half
+    way (fpmont.hpp fp_flush; the segmented square in front of its third segment): one Mult golden vector each through
+    the general and the windowed Miller loop."""
+    fx = load_fixture(name)
+    E = emu.Emu.from_fixture(fx)
+    assert E.nl == (36 if name == "k1024" else 37)
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    v = [v for v in fx["mult"] if any(cts[v["a"]]) and any(cts[v["b"]])][0]
+    assert E.pairing(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+    E.set_window(5)
+    assert E.pairing_w3(cts[v["a"]], cts[v["b"]]).hex() == v["out"]

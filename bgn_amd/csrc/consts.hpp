@@ -16,7 +16,15 @@ typedef int32_t i32;
 // product and wave against 7.1 - 8.5.
 constexpr int LIMB_BITS = 29;
 constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1u;
-constexpr int FP_BLOCK = 256;        // threads per workgroup of every field kernel
+// Threads per workgroup of the field kernels: 256 (one wave per SIMD) up to 37 limbs; 128 for the 72-limb (2048-bit)
+// instantiation, whose four LDS product slots of 36 row pairs would not fit the 160 KB of a CU otherwise.  A
+// translation unit that instantiates one limb count (kern_nl*.hip define BGN_NL before any include) gets its own.
+constexpr int fp_block(int nl) { return nl > 40 ? 128 : 256; }
+#ifdef BGN_NL
+constexpr int FP_BLOCK = fp_block(BGN_NL);
+#else
+constexpr int FP_BLOCK = 256;
+#endif
 constexpr int KP_MAX = 32;           // K*p tables for K = 1..32
 
 constexpr int MAX_NAF = 2112;        // signed digits of n

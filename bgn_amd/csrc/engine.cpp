@@ -324,7 +324,7 @@ struct Carver {
 
 const KernelTable* pick_table(int need_nl) {
   const KernelTable* ts[] = {kernel_table_nl3(), kernel_table_nl10(), kernel_table_nl19(), kernel_table_nl36(),
-                             kernel_table_nl37()};
+                             kernel_table_nl37(), kernel_table_nl72()};
   for (const KernelTable* t : ts)
     if (t->nl >= need_nl) return t;
   return nullptr;
@@ -423,7 +423,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   if ((p.w[0] & 3u) != 3u) return fail(BGN_E_PARAM, "p != 3 mod 4");
   const int need_nl = (p.bits() + 9 + LIMB_BITS - 1) / LIMB_BITS;
   const KernelTable* kt = pick_table(need_nl);
-  if (!kt) return fail(BGN_E_PARAM, "field of %d bits needs %d limbs; this build supports up to 37", p.bits(), need_nl);
+  if (!kt) return fail(BGN_E_PARAM, "field of %d bits needs %d limbs; this build supports up to 72", p.bits(), need_nl);
   std::vector<signed char> naf = n.naf();
   if ((int)naf.size() > MAX_NAF) return fail(BGN_E_PARAM, "group order too large");
 
@@ -802,6 +802,7 @@ static bool coop_table_walk(const bgn_ctx* c) {
 static size_t quad_limit(const bgn_ctx* c);
 
 static size_t coop_limit(const bgn_ctx* c, int mode) {
+  if (c->nl > 64) return 0;      // one limb per lane of a wave: no cooperative kernel beyond 64 limbs (2048-bit keys)
   const char* ev = getenv(mode >= 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
   const bool tw = coop_table_walk(c);
@@ -848,6 +849,7 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
 static size_t quad_limit(const bgn_ctx* c) {
   if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
+  if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
   return c->nl >= 36 ? 44000 : c->nl >= 19 ? 40000 : 32768;
 }
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
@@ -857,6 +859,7 @@ static size_t quad_table_limit(const bgn_ctx* c, int mode) {
   const char* ev = getenv(mode == 3 ? "BGN_QUAD_MAX_POW" : mode == 2 ? "BGN_QUAD_MAX_DEC" : "BGN_QUAD_MAX_L2");
   if (ev) return (size_t)strtoull(ev, nullptr, 10);
   if (quad_ws_words(c->nl, 64) == 0 || !quad_limit(c)) return 0;
+  if (c->nl > 40) return kMaxBatch;
   // profiles/r03_mid_batch_table.csv, whole calls at 1024 / 512 bits: Decrypt of 16384 ciphertexts 21.0 / 4.3 ms
   // against 36.6 / 6.9 on the lane kernels, of 32768 36.7 / 7.5 against 36.9 / 6.9; makeL2 of 32768 37.4 / 8.5 against
   // 53.2 / 10.6, of 65536 72.2 / 15.9 against 53.7 / 10.8
@@ -925,7 +928,9 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   const bool quad = quad_tab || (mode == 0 && use_quad(c, count, coop_limit(c, 0)));
   const bool coop = !quad && mode <= 1 && count <= coop_limit(c, mode);
   const size_t lane_ws = (size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4;
-  const size_t ws_bytes = quad ? quad_ws_words(c->nl, so) * 4 : coop ? coop_ws_words(c->nl, so) * 4 : lane_ws;
+  // (never less than the lane kernel's workspace: it is the fallback when a launcher has no instantiation)
+  const size_t small_ws = quad ? quad_ws_words(c->nl, so) * 4 : coop ? coop_ws_words(c->nl, so) * 4 : 0;
+  const size_t ws_bytes = small_ws > lane_ws ? small_ws : lane_ws;
   probe.take(ws_bytes);
   if (r_be) {
     probe.soa(c->nl, so, false);
@@ -2225,7 +2230,10 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
     const size_t lane_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;
-    pws = (uint32_t*)w.cv.take(quad ? quad_ws_words(c->nl, sp) * 4 : coop ? coop_ws_words(c->nl, sp) * 4 : lane_b);
+    {
+      const size_t small_b = quad ? quad_ws_words(c->nl, sp) * 4 : coop ? coop_ws_words(c->nl, sp) * 4 : 0;
+      pws = (uint32_t*)w.cv.take(small_b > lane_b ? small_b : lane_b);       // the lane kernel is the fallback
+    }
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;

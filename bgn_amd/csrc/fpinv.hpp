@@ -132,8 +132,8 @@ __host__ __device__ constexpr int fpinv_batch_cap(int bits) { return ((49 * bits
 
 // r = 1/x mod p for a plain (non-Montgomery) canonical x in [0, p); r canonical, 0 for x = 0.
 template <int NL>
-__device__ __forceinline__ void fp_inv_plain(Fp<NL>& r, const Fp<NL>& x, int p_bits,
-                                             const FpParams<NL>* __restrict__ P) {
+__device__ __forceinline__ void fp_inv_plain_inl(Fp<NL>& r, const Fp<NL>& x, int p_bits,
+                                                 const FpParams<NL>* __restrict__ P) {
   i32 f[NL], g[NL], d[NL], e[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
@@ -164,6 +164,21 @@ __device__ __forceinline__ void fp_inv_plain(Fp<NL>& r, const Fp<NL>& x, int p_b
   signed_fix<NL>(d, 0, d[NL - 1] >> 31, P);
 #pragma unroll
   for (int j = 0; j < NL; ++j) r.v[j] = (u32)d[j];
+}
+
+// (one copy per kernel at 72 limbs, as fp_mul)
+template <int NL>
+__device__ __noinline__ void fp_inv_plain_out(Fp<NL>& r, const Fp<NL>& x, int p_bits, const FpParams<NL>* __restrict__ P) {
+  fp_inv_plain_inl<NL>(r, x, p_bits, P);
+}
+
+template <int NL>
+__device__ __forceinline__ void fp_inv_plain(Fp<NL>& r, const Fp<NL>& x, int p_bits,
+                                             const FpParams<NL>* __restrict__ P) {
+  if constexpr (NL > 40)
+    fp_inv_plain_out<NL>(r, x, p_bits, P);
+  else
+    fp_inv_plain_inl<NL>(r, x, p_bits, P);
 }
 
 // r = 1/a in Montgomery form: a < 4 (lazy, Montgomery), r canonical.  0 -> 0.  Uses the LDS slot `stage`.

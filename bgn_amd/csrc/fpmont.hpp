@@ -78,16 +78,29 @@ struct LFp {
 };
 
 // ---- tier moves -----------------------------------------------------------
+// (Beyond 40 limbs six such slots exceed the 256 accumulation registers: the slots are then plain per-lane
+// arrays, which the compiler keeps in what registers it has and in scratch otherwise — the 72-limb instantiation
+// is a functional one, not a fast one.)
 template <int NL>
 __device__ __forceinline__ void a_load(Fp<NL>& r, const AFp<NL>& s) {
 #pragma unroll
-  for (int j = 0; j < NL; ++j) agpr_read(r.v[j], s.a[j]);
+  for (int j = 0; j < NL; ++j) {
+    if constexpr (NL > 40)
+      r.v[j] = s.a[j];
+    else
+      agpr_read(r.v[j], s.a[j]);
+  }
 }
 
 template <int NL>
 __device__ __forceinline__ void a_store(AFp<NL>& s, const Fp<NL>& r) {
 #pragma unroll
-  for (int j = 0; j < NL; ++j) agpr_write(s.a[j], r.v[j]);
+  for (int j = 0; j < NL; ++j) {
+    if constexpr (NL > 40)
+      s.a[j] = r.v[j];
+    else
+      agpr_write(s.a[j], r.v[j]);
+  }
 }
 
 template <int NL>
@@ -318,28 +331,25 @@ __device__ __forceinline__ void fp_flush(u64 (&t)[NL]) {
 }
 
 template <int NL>
-__device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b,
-                                       const FpParams<NL>* __restrict__ P) {
+__device__ __forceinline__ void fp_mul_inl(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b,
+                                           const FpParams<NL>* __restrict__ P) {
   const int tid = threadIdx.x;
   constexpr int NP = NL / 2;
-  constexpr int NP0 = kNeedsFlush<NL> ? (NP + 1) / 2 : NP;       // row pairs before the flush
-  static_assert(2 * NP0 <= kRowsPerFlush && 2 * (NP - NP0) + (NL & 1) <= kRowsPerFlush, "one flush is enough");
+  // intervals of at most kRowsPerFlush rows, a flush between them: one interval up to 19 limbs, two at 36 / 37
+  // limbs (18 + 18 or 19 rows), four at 72
+  constexpr int NI = kNeedsFlush<NL> ? (NL + kRowsPerFlush - 1) / kRowsPerFlush : 1;
+  constexpr int NPI = (NP + NI - 1) / NI;                        // row pairs per interval
+  static_assert(2 * NPI + (NL & 1) <= kRowsPerFlush || !kNeedsFlush<NL>, "interval too long");
   u64 t[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) t[j] = 0;
   u64 aa = a->rows[0][tid];
+#pragma unroll
+  for (int iv = 0; iv < NI; ++iv) {
+    if (iv) fp_flush<NL>(t);
+    const int k1 = (iv + 1) * NPI < NP ? (iv + 1) * NPI : NP;
 #pragma unroll 1
-  for (int k = 0; k < NP0; ++k) {
-    const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
-    const u64 nx = a->rows[kn][tid];
-    fp_row<NL>(t, (u32)aa, b, P);
-    fp_row<NL>(t, (u32)(aa >> 32), b, P);
-    aa = nx;
-  }
-  if constexpr (kNeedsFlush<NL>) {
-    fp_flush<NL>(t);
-#pragma unroll 1
-    for (int k = NP0; k < NP; ++k) {
+    for (int k = iv * NPI; k < k1; ++k) {
       const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
       const u64 nx = a->rows[kn][tid];
       fp_row<NL>(t, (u32)aa, b, P);
@@ -355,6 +365,23 @@ __device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>
     r.v[j] = (u32)s & LIMB_MASK;
     c = s >> LIMB_BITS;
   }
+}
+
+// Up to 40 limbs every product is inlined into its step program (the hand-scheduled slot machine of pairing.hpp /
+// ops.hpp).  The 72-limb instantiation calls ONE copy per kernel instead: its products are 10 k instructions each and
+// a Miller step has eighteen of them — inlined, a kernel takes half an hour to compile.
+template <int NL>
+__device__ __noinline__ void fp_mul_out(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b, const FpParams<NL>* __restrict__ P) {
+  fp_mul_inl<NL>(r, a, b, P);
+}
+
+template <int NL>
+__device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b,
+                                       const FpParams<NL>* __restrict__ P) {
+  if constexpr (NL > 40)
+    fp_mul_out<NL>(r, a, b, P);
+  else
+    fp_mul_inl<NL>(r, a, b, P);
 }
 
 // ---- Montgomery squaring --------------------------------------------------------------------
@@ -417,7 +444,7 @@ static_assert(kSquareSegments >= 2 && kSquareSegments <= 6, "2 to 6 segments");
 template <int NL>
 __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& av,
                                            const FpParams<NL>* __restrict__ P) {
-  if constexpr (NL < 8) {
+  if constexpr (NL < 8 || NL > 40) {          // (72 limbs: the functional instantiation squares by fp_mul)
     fp_mul<NL>(r, a, av, P);
   } else {
     // even segment length: 10 at NL = 38 with four segments

@@ -14,6 +14,7 @@ size_t quad_ws_words(int nl, size_t sw) {
     case 19: return ws_words<19>(sw);
     case 36: return ws_words<36>(sw);
     case 37: return ws_words<37>(sw);
+    case 72: return ws_words<72>(sw);
   }
   return 0;
 }
@@ -45,6 +46,7 @@ bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const Pairin
     case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
     case 36: launch<36>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
     case 37: launch<37>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 72: launch<72>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
   }
   return false;
 }
@@ -65,6 +67,7 @@ bool quad_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_
     case 19: launch_pow<19>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
     case 36: launch_pow<36>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
     case 37: launch_pow<37>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
+    case 72: launch_pow<72>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
   }
   return false;
 }
@@ -75,6 +78,7 @@ const char* quad_pairing_kernel_name(int nl) {
     case 19: return "k_pairing_quad<19, 1>";
     case 36: return "k_pairing_quad<36, 1>";
     case 37: return "k_pairing_quad<37, 1>";
+    case 72: return "k_pairing_quad<72, 1>";
   }
   return "";
 }

@@ -258,5 +258,6 @@ const KernelTable* kernel_table_nl10();
 const KernelTable* kernel_table_nl19();
 const KernelTable* kernel_table_nl36();
 const KernelTable* kernel_table_nl37();
+const KernelTable* kernel_table_nl72();
 
 }  // namespace bgn

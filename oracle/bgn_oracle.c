@@ -29,7 +29,7 @@
 typedef uint64_t u64;
 typedef unsigned __int128 u128;
 
-#define MAXW 18
+#define MAXW 34     /* 64-bit limbs: fields of up to 2176 bits (2048-bit keys) */
 
 typedef struct {
   int W;              /* 64-bit limbs */

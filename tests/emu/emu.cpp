@@ -395,6 +395,7 @@ struct Emu {
     case 19: Emu<19>::call; break;    \
     case 36: Emu<36>::call; break;    \
     case 37: Emu<37>::call; break;    \
+    case 72: Emu<72>::call; break;    \
     default: return -1;               \
   }                                   \
   return 0;

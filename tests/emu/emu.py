@@ -34,7 +34,7 @@ def limbs(v: int, nl: int):
 
 def nl_for(p: int) -> int:
     need = (p.bit_length() + 9 + LIMB - 1) // LIMB
-    for nl in (3, 10, 19, 36, 37):
+    for nl in (3, 10, 19, 36, 37, 72):
         if nl >= need:
             return nl
     raise ValueError("field too large")

@@ -8,6 +8,7 @@
 #define __host__
 #define __global__
 #define __forceinline__ inline
+#define __noinline__ inline
 #define __shared__ static
 #define __constant__
 #define __launch_bounds__(...)

@@ -132,6 +132,8 @@ CONFIGS = [
     # a second 1024-bit key (l = 6336: p has 1037 bits, the top of the range A1 parameters reach at this size) for
     # the tests that keep two keys resident on one GPU
     ("k1024b", 1024, 1 << 40, 4242, 8, 5, (2, 2)),
+    # a 2048-bit key (bgn.go:65-73 accepts any even key size): the 72-limb instantiation
+    ("k2048", 2048, 1021, 7, 8, 5, (2, 2)),
 ]
 
 if __name__ == "__main__":

@@ -271,14 +271,14 @@ def test_emu_dword_codec_matches_the_byte_codec(nl):
         assert wire_out.raw == wire, (nl, L)
 
 
-@pytest.mark.parametrize("name", ["k1024", "k1024b"])
+@pytest.mark.parametrize("name", ["k1024", "k1024b", "k2048"])
 def test_emu_pairing_at_36_and_37_limbs(name):
     """1024-bit keys: 36 limbs (p of 1031 bits) and 37 (1037 bits) — the products that flush their accumulators half
     way (fpmont.hpp fp_flush; the segmented square in front of its third segment): one Mult golden vector each through
     the general and the windowed Miller loop."""
     fx = load_fixture(name)
     E = emu.Emu.from_fixture(fx)
-    assert E.nl == (36 if name == "k1024" else 37)
+    assert E.nl == {"k1024": 36, "k1024b": 37, "k2048": 72}[name]        # 72: four flush intervals, squarings by fp_mul
     cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
     v = [v for v in fx["mult"] if any(cts[v["a"]]) and any(cts[v["b"]])][0]
     assert E.pairing(cts[v["a"]], cts[v["b"]]).hex() == v["out"]

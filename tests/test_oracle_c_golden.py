@@ -22,7 +22,7 @@ def J(hexes):
     return b"".join(bytes.fromhex(h) for h in hexes)
 
 
-@pytest.mark.parametrize("name", KEYS)
+@pytest.mark.parametrize("name", KEYS + ["k1024b", "k2048"])       # + the 37-limb 1024-bit key and the 2048-bit key
 def test_c_oracle_matches_golden(oc, name):
     fx = load_fixture(name)
     o = oc.Oracle.from_fixture(fx)

@@ -4,11 +4,11 @@
 // Replaces `res.Pair(ct1.C, ct2.C)` (bgn.go:300) when a call carries too few pairings to fill the chip with
 // one pairing per lane (pairing.hpp: 166 ms per 1024-bit pairing whatever the batch below 65536).  Here ONE
 // pairing belongs to a workgroup of COOP_W = 8 waves, two per SIMD of a CU:
-//   * a field element lies across the lanes of a wave, one 28-bit limb per lane (lane j = limb j, lanes >= NL
+//   * a field element lies across the lanes of a wave, one 29-bit limb per lane (lane j = limb j, lanes >= NL
 //     hold zero), so a value is ONE VGPR, the whole Miller state a handful of LDS rows, and a Montgomery product
 //     is NL steps of {broadcast one limb of b (v_readlane), multiply-add into the lane accumulators, quotient
 //     digit from lane 0 (v_readfirstlane + scalar multiply), multiply-add of p, shift the accumulators down one
-//     lane (DPP wave_shl) with the 28-bit carry split} — about 10 instructions per limb instead of 2*NL^2
+//     lane (DPP wave_shl) with the 29-bit carry split} — about 10 instructions per limb instead of 2*NL^2
 //     multiply-adds in one lane;
 //   * limbs are signed and lazily normalised (one carry pass per operand; values stay >= 0 because every
 //     subtraction adds a multiple of p chosen from static bounds), so additions and subtractions are lane-local;
@@ -42,13 +42,13 @@ __device__ __forceinline__ u32 coop_shl1(u32 x) { return (u32)__builtin_amdgcn_u
 template <int NL>
 struct CoopLane {
   u32 p;       // limb `lane` of the modulus (0 beyond NL)
-  u32 keep;    // normalisation: bits a lane keeps (28 below the top limb, all of them in the top limb)
+  u32 keep;    // normalisation: bits a lane keeps (29 below the top limb, all of them in the top limb)
   u32 carry;   // ... and whether it passes a carry up (not from the top limb)
-  u32 pinv;    // -p^-1 mod 2^28 (wave-uniform)
+  u32 pinv;    // -p^-1 mod 2^29 (wave-uniform)
   int lane;
 };
 
-// One carry pass: every limb keeps its low 28 bits and takes the (signed) excess of the limb below.
+// One carry pass: every limb keeps its low 29 bits and takes the (signed) excess of the limb below.
 template <int NL>
 __device__ __forceinline__ u32 coop_normalize(long long acc, const CoopLane<NL>& c) {
   const u32 lo = (u32)acc & c.keep;

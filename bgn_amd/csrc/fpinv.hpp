@@ -4,14 +4,14 @@
 // (result.Mul / result.Div on level-1 ciphertexts, bgn.go:482, :419, :350) -> libpbc -> mpz_invert.
 //
 // Why not Fermat: a^(p-2) at a 1031-bit p is ~1550 Montgomery products per lane.  A division step only
-// looks at the low bits of (f, g); 28 of them are run on one 32-bit word per lane, branch-free, and
-// summarised as a 2x2 integer matrix with entries in [-2^28, 2^28]; that matrix is then applied once
+// looks at the low bits of (f, g); LIMB_BITS = 29 of them are run on one 32-bit word per lane, branch-free, and
+// summarised as a 2x2 integer matrix with entries in [-2^29, 2^29]; that matrix is then applied once
 // to the full-length (f, g) and, modulo p, to the Bezout pair (d, e) with v_mad_i64_i32 chains in the
-// same radix-2^28 limbs the field uses.  About 1.2k VALU instructions per batch of 28 steps and
-// <= ceil(2.9 * bits(p) / 28) batches: the cost of roughly 30 products instead of 1550.
+// same radix-2^29 limbs the field uses.  About 1.2k VALU instructions per batch of 29 steps and
+// <= ceil(2.9 * bits(p) / 29) batches: the cost of roughly 30 products instead of 1550.
 //
-// Number format inside this file: NL signed limbs, value = sum v[j] * 2^(28 j); limbs 0..NL-2 are in
-// [0, 2^28), the top limb carries the sign (NL is chosen with >= 9 spare bits above p, so |value| < 4p
+// Number format inside this file: NL signed limbs, value = sum v[j] * 2^(29 j); limbs 0..NL-2 are in
+// [0, 2^29), the top limb carries the sign (NL is chosen with >= 9 spare bits above p, so |value| < 4p
 // always fits).  Invariants of the loop (x the input, all congruences mod p):
 //     d * x == f,   e * x == g,   f odd,   d, e in (-2p, p).
 // When g reaches 0, f = +-gcd(p, x) = +-1 and the inverse is sign(f) * d.
@@ -24,10 +24,10 @@
 namespace bgn {
 
 struct DivMat {
-  i32 u, v, q, r;   // (f, g) <- (u f + v g, q f + r g) / 2^28
+  i32 u, v, q, r;   // (f, g) <- (u f + v g, q f + r g) / 2^29
 };
 
-// 28 division steps on the low words; eta = -delta.
+// LIMB_BITS division steps on the low words; eta = -delta.
 __device__ __forceinline__ i32 divsteps_limb(i32 eta, u32 f0, u32 g0, DivMat& t) {
   u32 u = 1, v = 0, q = 0, r = 1;
   u32 f = f0, g = g0;
@@ -59,7 +59,7 @@ __device__ __forceinline__ i32 divsteps_limb(i32 eta, u32 f0, u32 g0, DivMat& t)
 
 typedef long long i64;
 
-// (f, g) <- t * (f, g) / 2^28   (exact)
+// (f, g) <- t * (f, g) / 2^29   (exact)
 template <int NL>
 __device__ __forceinline__ void divmat_apply_fg(i32 (&f)[NL], i32 (&g)[NL], const DivMat& t) {
   i64 cf = imad(t.u, f[0], imad(t.v, g[0], 0));
@@ -79,7 +79,7 @@ __device__ __forceinline__ void divmat_apply_fg(i32 (&f)[NL], i32 (&g)[NL], cons
   g[NL - 1] = (i32)cg;
 }
 
-// (d, e) <- t * (d, e) / 2^28 mod p, staying in (-2p, p): a multiple of p is added that clears the low limb.
+// (d, e) <- t * (d, e) / 2^29 mod p, staying in (-2p, p): a multiple of p is added that clears the low limb.
 template <int NL>
 __device__ __forceinline__ void divmat_apply_de(i32 (&d)[NL], i32 (&e)[NL], const DivMat& t,
                                                 const FpParams<NL>* __restrict__ P) {
@@ -88,7 +88,7 @@ __device__ __forceinline__ void divmat_apply_de(i32 (&d)[NL], i32 (&e)[NL], cons
   i32 me = (t.q & sd) + (t.r & se);
   i64 cd = imad(t.u, d[0], imad(t.v, e[0], 0));
   i64 ce = imad(t.q, d[0], imad(t.r, e[0], 0));
-  // P->pinv = -p^{-1} mod 2^28: the new md is == pinv * cd, so cd + p * md == 0 (mod 2^28)
+  // P->pinv = -p^{-1} mod 2^29: the new md is == pinv * cd, so cd + p * md == 0 (mod 2^29)
   md -= (i32)(((u32)md - P->pinv * (u32)cd) & LIMB_MASK);
   me -= (i32)(((u32)me - P->pinv * (u32)ce) & LIMB_MASK);
   cd = imad_s(md, (i32)P->p[0], cd);
@@ -126,7 +126,7 @@ __device__ __forceinline__ void signed_fix(i32 (&v)[NL], i32 neg, i32 addp, cons
   }
 }
 
-// Upper bound on the number of 28-step batches for a modulus of `bits` bits: the division-step count is
+// Upper bound on the number of LIMB_BITS-step batches for a modulus of `bits` bits: the division-step count is
 // below (49 bits + 80) / 17 (Bernstein–Yang, Theorem 11.2); the loop normally leaves through g == 0.
 __host__ __device__ constexpr int fpinv_batch_cap(int bits) { return ((49 * bits + 80) / 17 + LIMB_BITS - 1) / LIMB_BITS + 1; }
 

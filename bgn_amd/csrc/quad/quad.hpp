@@ -9,10 +9,10 @@
 //     formulas of pairing.hpp scheduled for four workers: a Miller doubling step = 18 products in 5 rounds, a
 //     doubling with the addition after it 36 in 10).  The quads of a pairing sit in one wave, so a round needs no
 //     barrier: its reads precede its writes in the wave's own instruction order;
-//   * inside a quad a field element is split over the four lanes, M = ceil(NL / 4) limbs of 28 bits each (lane s
+//   * inside a quad a field element is split over the four lanes, M = ceil(NL / 4) limbs of 29 bits each (lane s
 //     holds limbs s*M .. s*M + M - 1).  A Montgomery product is NL rows of {broadcast one limb of a inside the quad
 //     (DPP quad_perm), M multiply-adds into the lane's accumulators, the quotient digit from lane 0 (broadcast), M
-//     multiply-adds of p, retire the lowest accumulator: its low 28 bits move to the lane below (DPP), the rest
+//     multiply-adds of p, retire the lowest accumulator: its low 29 bits move to the lane below (DPP), the rest
 //     into the next accumulator} — 2 M + 9 instructions per row and lane, 1.1 k per product at a 1024-bit key
 //     against 3.2 k for a lane that multiplies alone;
 //   * limbs are signed and lazily normalised as in the cooperative kernel: a carry pass is exact inside a lane and
@@ -97,8 +97,8 @@ __device__ __forceinline__ int quad_from_below(int x) {      // lane s reads lan
 template <int NL>
 struct QuadLane {
   u32 p[QuadDims<NL>::M];   // this lane's limbs of the modulus
-  u32 pinv;                 // -p^-1 mod 2^28
-  u32 keep_top;             // carry pass at index JTOP: bits kept (28; everything in lane 3)
+  u32 pinv;                 // -p^-1 mod 2^29
+  u32 keep_top;             // carry pass at index JTOP: bits kept (29; everything in lane 3)
   u32 carry_top;            // ... and whether a carry goes on (not in lane 3)
   u32 base;                 // LDS byte offset of this lane's column of row block 0, quad 0
   int sub;                  // lane within the quad

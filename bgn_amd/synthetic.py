@@ -132,7 +132,7 @@ LIMB_BITS = 29          # bgn_amd/csrc/consts.hpp
 def limbs_for(p: int) -> int:
     """Limb count the engine instantiates for the field of p (engine.cpp pick_table)."""
     need = (p.bit_length() + 9 + LIMB_BITS - 1) // LIMB_BITS
-    return next(x for x in (3, 10, 19, 36, 37) if x >= need)
+    return next(x for x in (3, 10, 19, 36, 37, 72) if x >= need)
 
 
 def flush_instructions(nl: int) -> int:

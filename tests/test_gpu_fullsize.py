@@ -153,3 +153,86 @@ def test_mult_longer_than_one_piece():
     eng.mult_dev(a, b, out, count)
     torch.cuda.synchronize()
     assert bool((out.view(count, EB) == want[idx]).all().item())
+
+
+@pytest.mark.parametrize("name,count", [("k1024", 1 << 16), ("k1024b", 1 << 14), ("k512", 1 << 16), ("k2048", 1 << 11)])
+def test_pairing_kernels_agree_on_large_random_batches(name, count, monkeypatch):
+    """Three formulations of `res.Pair` (bgn.go:300) — one pairing per lane (unsigned lazy limbs, Jacobian,
+    windowed NAF), sixteen lanes per pairing and one workgroup per pairing (signed lazy limbs, generated step
+    programs, plain NAF) — on the same seeded random ciphertext pairs with full-length randomness: every byte of
+    every result equal.  A rare carry pattern mishandled by one of them shows here (65536 pairings x ~21 000 field
+    products each); the C oracle checks a sample of the same batch."""
+    import oracle_c
+    from bgn_amd.synthetic import config2_ciphertexts, permuted_copy
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng, dev = pk.engine, torch.device("cuda")
+    EB = eng.elem_bytes
+    _, _, ca = config2_ciphertexts(pk, count, 4242, dev)
+    cb = permuted_copy(ca, EB, 4243)
+    kernels = ("quad", "lane") if name == "k2048" else ("quad", "coop", "lane")   # no cooperative kernel at 72 limbs
+    outs = {}
+    for kernel in kernels:
+        monkeypatch.setenv("BGN_QUAD_MIN", "0")
+        monkeypatch.setenv("BGN_QUAD_MAX", "100000000" if kernel == "quad" else "0")
+        monkeypatch.setenv("BGN_COOP_MAX", "100000000" if kernel == "coop" else "0")
+        n = count if kernel != "lane" or name != "k2048" else 256                 # the 72-limb lane kernel is the functional one
+        out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+        eng.mult_dev(ca[: n * EB], cb[: n * EB], out, n)
+        torch.cuda.synchronize()
+        assert (kernel in eng.last_kernel_name()) == (kernel != "lane"), eng.last_kernel_name()
+        outs[kernel] = out
+    for kernel in kernels[1:]:
+        n = outs[kernel].numel()
+        assert torch.equal(outs["quad"][:n], outs[kernel]), (name, kernel)
+    k = 24 if name != "k2048" else 6
+    o = oracle_c.Oracle.from_fixture(fx)
+    sel = slice((count - k) * EB, count * EB)
+    assert bytes(outs["quad"][sel].cpu().numpy()) == o.mult(bytes(ca[sel].cpu().numpy()), bytes(cb[sel].cpu().numpy()))
+
+
+@pytest.mark.parametrize("name,count", [("k1024", 1 << 15)])
+def test_table_walks_and_decrypt_agree_across_kernels_on_large_batches(name, count, monkeypatch):
+    """makeL2 (the walk over P's line table, bgn.go:316-321) and Decrypt of both levels (lift over the secret order's
+    table, power by q1, BSGS; bgn.go:205-250) on 32768 random ciphertexts, every 16th negated: the lane-group kernels,
+    the cooperative kernels and the lane kernels return the same bytes / plaintexts / statuses, and the plaintexts
+    are the ones encrypted."""
+    from bgn_amd.synthetic import config2_ciphertexts, decrypt_mix
+    fx = load_fixture(name)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng, dev = pk.engine, torch.device("cuda")
+    EB = eng.elem_bytes
+    xs, _, ca = config2_ciphertexts(pk, count, 777, dev)
+    assert fx["msg_space"] >= (1 << 40)                  # the synthetic plaintexts have 40 bits
+    mixed, want, want_st = decrypt_mix(pk, fx, ca, xs, dev)
+    big = "100000000"
+    res = {}
+    for kernel in ("quad", "coop", "lane"):
+        monkeypatch.setenv("BGN_QUAD_MIN", "0")
+        for v in ("BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
+            monkeypatch.setenv(v, big if kernel == "quad" else "0")
+        for v in ("BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
+            monkeypatch.setenv(v, big if kernel == "coop" else "0")
+        l2 = torch.empty(count * EB, dtype=torch.uint8, device=dev)
+        eng.make_l2_dev(mixed, l2, count)
+        torch.cuda.synchronize()
+        assert (kernel in eng.last_kernel_name()) == (kernel != "lane"), eng.last_kernel_name()
+        m1 = torch.empty(count, dtype=torch.int64, device=dev)
+        s1 = torch.empty(count, dtype=torch.uint8, device=dev)
+        eng.decrypt_dev(1, mixed, m1, s1, count)
+        torch.cuda.synchronize()
+        assert (kernel in eng.last_aux_kernel_name()) == (kernel != "lane"), eng.last_aux_kernel_name()
+        m2 = torch.empty_like(m1)
+        s2 = torch.empty_like(s1)
+        eng.decrypt_dev(2, l2, m2, s2, count)
+        torch.cuda.synchronize()
+        res[kernel] = (l2, m1.cpu(), s1.cpu(), m2.cpu(), s2.cpu())
+    for kernel in ("coop", "lane"):
+        assert torch.equal(res["quad"][0], res[kernel][0]), (name, kernel, "makeL2 bytes")
+        for i in range(1, 5):
+            assert torch.equal(res["quad"][i], res[kernel][i]), (name, kernel, i)
+    _, m1, s1, m2, s2 = res["quad"]
+    assert torch.equal(s1, want_st) and torch.equal(s2, want_st)
+    ok = want_st == 0
+    assert torch.equal(m1[ok], want[ok]) and torch.equal(m2[ok], want[ok])

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ---------------------------------------------------------------- field arithmetic
-@pytest.mark.parametrize("name,count", [("toy64", 5000), ("k256", 20000), ("k512", 20000), ("k1024", 100000)])
+@pytest.mark.parametrize("name,count", [("toy64", 5000), ("k256", 20000), ("k512", 20000), ("k1024", 100000), ("k1024b", 20000), ("k2048", 4000)])
 def test_field_mul_sqr_inv_vs_python_integers(name, count):
     fx = load_fixture(name)
     pk, _ = engine_key(fx)
@@ -23,6 +23,18 @@ def test_field_mul_sqr_inv_vs_python_integers(name, count):
     p, L = int(fx["p"], 16), eng.L
     rng = random.Random(2024)
     special = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << (p.bit_length() - 1), (1 << 28) - 1, 1 << 28, (1 << 29) - 1, 1 << 29]
+    # operands whose MONTGOMERY residues (what the product's rows multiply) have extreme limbs: every limb below the
+    # top one all ones — the column sums that make the mid-product accumulator flush necessary at 36 limbs —,
+    # alternating full and empty limbs, a lone top limb
+    from bgn_amd.synthetic import LIMB_BITS, limbs_for
+    nl = limbs_for(p)
+    R_inv = pow(1 << (LIMB_BITS * nl), -1, p)
+    low = LIMB_BITS * ((p.bit_length() - 1) // LIMB_BITS)
+    full = ((p >> low) - 1 << low) | ((1 << low) - 1) if (p >> low) > 1 else (1 << low) - 1
+    alt = sum(((1 << LIMB_BITS) - 1) << (LIMB_BITS * j) for j in range(0, low // LIMB_BITS, 2))
+    residues = [full, alt, (alt << LIMB_BITS) % (1 << low), (p >> low) << low, full - alt]
+    assert all(0 <= v < p for v in residues)
+    special += [v * R_inv % p for v in residues]
     xs = [special[i % len(special)] if i < 3 * len(special) else rng.randrange(p) for i in range(count)]
     ys = [special[(i // len(special)) % len(special)] if i < len(special) ** 2 else rng.randrange(p) for i in range(count)]
     buf = b"".join(x.to_bytes(L, "big") + y.to_bytes(L, "big") for x, y in zip(xs, ys))

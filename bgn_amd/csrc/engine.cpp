@@ -843,8 +843,8 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
 // profiles/r03_mid_batch.csv (MI355X, 1024 bits: 4096 pairs 21.5 ms, 16384 63.9 ms, 40960 153 ms against 166 ms
 // for ANY count up to 65536 on the lane kernel, 1024 pairs 21.2 ms against 17.8 ms cooperative; 512 bits: 4096
 // pairs 5.2 ms, 32768 23.5 ms against 28.7 ms, 1024 pairs 5.2 against 5.3 ms).  A lane of the lane kernel takes a
-// second pairing from 65537 pairs on, so the lane-group kernel also wins a stretch above 65536 at 1024 bits
-// (81920 pairs: 301 against 333 ms).  BGN_QUAD_MAX overrides the upper end (0 disables the kernel), BGN_QUAD_MIN
+// second pairing from 65537 pairs on: such a batch is cut into whole rounds of that kernel and a remainder that
+// comes back here (lane_rounds_head).  BGN_QUAD_MAX overrides the upper end (0 disables the kernel), BGN_QUAD_MIN
 // the lower one.
 static size_t quad_limit(const bgn_ctx* c) {
   if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
@@ -884,9 +884,31 @@ static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
   if (getenv("BGN_COOP_MAX") && !getenv("BGN_QUAD_MAX") && !getenv("BGN_QUAD_MIN")) return false;
   const size_t hi = quad_limit(c);
   if (!hi || count <= lo || quad_ws_words(c->nl, 64) == 0) return false;
-  if (count <= hi) return true;
-  // the second window: between one and two pairings per lane of the lane kernel (default limits only)
-  return !getenv("BGN_QUAD_MAX") && c->nl >= 36 && count > 65536 && count <= 88000;
+  return count <= hi;      // (a batch just above 65536 is cut into lane-kernel rounds and a remainder: lane_rounds_head)
+}
+
+// The lane kernel runs `pairing_run` pairings on each of at most 65536 lanes — one wave per SIMD, 512 registers — so
+// its time is a step function of the count: 65537 pairs cost two pairings' latency, 2^20 + 1 pairs two rounds of
+// sixteen.  A batch that does not fill whole rounds is therefore cut: the largest head that does (a multiple of
+// 2^20 above 2^20, of 65536 below) goes first, the remainder follows as a call of its own and takes whichever
+// kernel is fastest at ITS size (1024 bits: 70 000 Mults 310 -> 176 ms, 2^20 + 1000: 5.0 -> 2.5 s).  Below 2^20 the
+// cut is made only when the remainder lands on the cooperative or the lane-group kernel (a remainder on the lane
+// kernel costs the same extra round either way).  Element-wise modes only (Mult, makeL2).
+static size_t lane_rounds_head(const bgn_ctx* c, size_t n, int mode) {
+  constexpr size_t kLanes = 65536, kFull = kLanes * 16;
+  if (mode > 1 || n <= kLanes) return n;
+  if (const char* ev = getenv("BGN_SPLIT_ROUNDS"))
+    if (ev[0] == '0') return n;
+  // (a batch the lane-group kernel takes whole — every size at 72 limbs — is not cut)
+  if (mode == 0 ? use_quad(c, n, coop_limit(c, 0))
+                : (coop_table_walk(c) && n > quad_table_floor(c, 1) && n <= quad_table_limit(c, 1)))
+    return n;
+  if (n > kFull) return n % kFull ? n - n % kFull : n;
+  const size_t rem = n % kLanes;
+  if (!rem) return n;
+  const bool small = mode == 0 ? (rem <= coop_limit(c, 0) || use_quad(c, rem, coop_limit(c, 0)))
+                               : (coop_table_walk(c) && (rem <= coop_limit(c, 1) || rem <= quad_table_limit(c, 1)));
+  return small ? n - rem : n;
 }
 
 // Mult / makeL2 over `count` pairs, in pieces of at most 2^22: the workspace of a piece (7.4 KB per pairing with
@@ -897,11 +919,13 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   if (!count) return BGN_OK;
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
   const size_t piece = (size_t)1 << 22, eb = (size_t)2 * c->L;
-  for (size_t off = 0; off < count; off += piece) {
-    const size_t n = count - off < piece ? count - off : piece;
+  for (size_t off = 0; off < count;) {
+    size_t n = count - off < piece ? count - off : piece;
+    n = lane_rounds_head(c, n, mode);
     int rc = pairing_chunk(c, n, a + off * eb, n, b ? b + off * eb : nullptr, b ? n : 0, mode, d1, d2, out + off * eb, s,
                            r_be ? r_be + off * r_len : nullptr, r_len);
     if (rc) return rc;
+    off += n;
   }
   (void)na;
   (void)nb;
@@ -2053,6 +2077,23 @@ int bgn_multconst_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, c
 }
 
 // ---- Decrypt ---------------------------------------------------------------------------------
+static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status, void* stream);
+
+// The level-1 lift runs on the lane kernel like Mult: whole rounds of it first, the remainder as a piece of its own
+// on whichever kernel is fastest at its size (lane_rounds_head).
+static size_t decrypt_rounds_head(const bgn_ctx* c, size_t n, int level) {
+  constexpr size_t kLanes = 65536, kFull = kLanes * 16;
+  if (level != 1 || n <= kLanes) return n;
+  if (const char* ev = getenv("BGN_SPLIT_ROUNDS"))
+    if (ev[0] == '0') return n;
+  const bool tw = coop_table_walk(c);
+  if (tw && n > quad_table_floor(c, 2) && n <= quad_table_limit(c, 2)) return n;      // the lane groups take it whole
+  if (n > kFull) return n % kFull ? n - n % kFull : n;
+  const size_t rem = n % kLanes;
+  if (!rem) return n;
+  return (rem <= coop_limit(c, 2) || (tw && rem <= quad_table_limit(c, 2))) ? n - rem : n;
+}
+
 int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status,
                           void* stream) {
   if (!c || (count && (!ct || !m || !status))) return fail(BGN_E_ARG, "null argument");
@@ -2061,6 +2102,17 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   if (!c->have_tables) return fail(BGN_E_STATE, "DL tables not computed!");          // gsbs.go:56-58 (panic)
   if (!count) return BGN_OK;
   if (count > kMaxBatch) return fail(BGN_E_ARG, "batch too large (max 2^28 elements per call)");
+  const size_t eb = (size_t)2 * c->L;
+  for (size_t off = 0; off < count;) {
+    const size_t n = decrypt_rounds_head(c, count - off, level);
+    int rc = decrypt_piece(c, n, level, ct + off * eb, m + off, status + off, stream);
+    if (rc) return rc;
+    off += n;
+  }
+  return BGN_OK;
+}
+
+static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
   StreamOrder order(c, s);

@@ -236,3 +236,49 @@ def test_table_walks_and_decrypt_agree_across_kernels_on_large_batches(name, cou
     assert torch.equal(s1, want_st) and torch.equal(s2, want_st)
     ok = want_st == 0
     assert torch.equal(m1[ok], want[ok]) and torch.equal(m2[ok], want[ok])
+
+
+def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
+    """65536 + r elements: the engine runs whole rounds of the lane kernel and hands the remainder to the kernel that
+    is fastest at ITS size (engine.cpp lane_rounds_head / decrypt_rounds_head).  Same bytes / plaintexts as the single
+    launch (BGN_SPLIT_ROUNDS=0), for Mult, makeL2 and level-1 Decrypt; the kernel reported last is the remainder's."""
+    from bgn_amd.synthetic import config2_ciphertexts, permuted_copy
+    dev = torch.device("cuda")
+    for name, count in (("k512", 65536 + 1500), ("k1024", 65536 + 700)):
+        fx = load_fixture(name)
+        pk, sk = engine_key(fx)
+        eng = pk.engine
+        EB = eng.elem_bytes
+        xs, _, ca = config2_ciphertexts(pk, count, 99, dev)
+        cb = permuted_copy(ca, EB, 98)
+        res = {}
+        for split in ("1", "0"):
+            monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+            prod = torch.empty(count * EB, dtype=torch.uint8, device=dev)
+            eng.mult_dev(ca, cb, prod, count)
+            torch.cuda.synchronize()
+            k_mult = eng.last_kernel_name()
+            l2 = torch.empty_like(prod)
+            eng.make_l2_dev(ca, l2, count)
+            torch.cuda.synchronize()
+            k_l2 = eng.last_kernel_name()
+            res[split] = (prod, l2, k_mult, k_l2)
+        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), name
+        assert "k_pairing<" in res["0"][2] and "k_pairing<" in res["0"][3]
+        assert "quad" in res["1"][2] or "coop" in res["1"][2], res["1"][2]
+        assert "quad" in res["1"][3] or "coop" in res["1"][3], res["1"][3]
+        if name == "k1024":
+            pk.SetupDecryption(sk)
+            want = torch.zeros(count, dtype=torch.int64)
+            xb = xs.cpu().to(torch.int64)
+            for j in range(xb.shape[1]):
+                want = want * 256 + xb[:, j]
+            for split in ("1", "0"):
+                monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+                m = torch.empty(count, dtype=torch.int64, device=dev)
+                st = torch.empty(count, dtype=torch.uint8, device=dev)
+                eng.decrypt_dev(1, ca, m, st, count)
+                torch.cuda.synchronize()
+                assert not bool(st.any().item()) and torch.equal(m.cpu(), want), split
+                aux = eng.last_aux_kernel_name()
+                assert ("coop" in aux or "quad" in aux) == (split == "1"), aux

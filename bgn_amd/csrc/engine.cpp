@@ -1119,10 +1119,11 @@ int bgn_make_l2_batch(bgn_ctx* c, size_t count, const uint8_t* a, uint8_t* out) 
 namespace {
 
 int run_for(size_t count) {
-  // elements per lane of the batched-inversion kernels: keep >= 65536 lanes busy, cap the run
+  // elements per lane of the batched-inversion kernels (512 registers: one wave per SIMD, 65536 lanes at a time).
+  // The run is the ceiling of count / 65536 whatever the count: a cap would put the lanes beyond 65536 into a second
+  // round of workgroups, and a nearly empty last round costs as much as a full one (4M + 1000 additions: 2x).
   size_t r = (count + 65535) / 65536;
   if (r < 1) r = 1;
-  if (r > 64) r = 64;
   return (int)r;
 }
 

@@ -282,3 +282,29 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
                 assert not bool(st.any().item()) and torch.equal(m.cpu(), want), split
                 aux = eng.last_aux_kernel_name()
                 assert ("coop" in aux or "quad" in aux) == (split == "1"), aux
+
+
+def test_add_beyond_64_elements_per_lane():
+    """EAdd over 2^22 + 1000 pairs (65 additions on the busiest lanes of the batched-inversion kernel: the run is the
+    ceiling of count / 65536 whatever the count): the same bytes as the four 2^20 slices and the remainder added
+    on their own."""
+    from bgn_amd.synthetic import config2_ciphertexts, permuted_copy
+    fx = load_fixture("k1024")
+    pk, _ = engine_key(fx)
+    eng, dev = pk.engine, torch.device("cuda")
+    EB = eng.elem_bytes
+    base = 1 << 20
+    _, _, c0 = config2_ciphertexts(pk, base, 31, dev)
+    n = 4 * base + 1000
+    ca = torch.cat([c0, c0, c0, c0, c0[: 1000 * EB]])
+    cb = torch.cat([permuted_copy(c0, EB, 32 + k) for k in range(4)] + [c0[2000 * EB: 3000 * EB]])
+    whole = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+    eng.add_dev(1, ca, cb, whole, n)
+    torch.cuda.synchronize()
+    piece = torch.empty(base * EB, dtype=torch.uint8, device=dev)
+    for k in range(5):
+        m = base if k < 4 else 1000
+        lo = k * base * EB
+        eng.add_dev(1, ca[lo: lo + m * EB], cb[lo: lo + m * EB], piece[: m * EB], m)
+        torch.cuda.synchronize()
+        assert torch.equal(whole[lo: lo + m * EB], piece[: m * EB]), k

@@ -208,44 +208,79 @@ class Engine:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    @staticmethod
+    def _need(what: str, t, nbytes: int) -> None:
+        """The C ABI takes bare pointers: a device array shorter than the call reads or writes would fault the GPU,
+        so the host mirror refuses it here."""
+        if t is None:
+            return
+        have = t.numel() * t.element_size()
+        if have < nbytes:
+            raise ValueError(f"{what}: {have} bytes on the device, the call needs {nbytes}")
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError(f"{what}: a contiguous CUDA tensor is required")
+
     def mult_dev(self, a, b, out, count: Optional[int] = None, r=None, r_len: int = 0) -> None:
         """Device-resident Mult; r (count x r_len big-endian bytes on the device) blinds with e(Q,Q)^r."""
         count = a.numel() // self.elem_bytes if count is None else count
+        for what, t in (("a", a), ("b", b), ("out", out)):
+            self._need(what, t, count * self.elem_bytes)
+        self._need("r", r, count * r_len)
         check(self._lib.bgn_mult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(),
                                            r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
                                            self._stream()), "bgn_mult_batch_dev")
 
     def make_l2_dev(self, a, out, count: Optional[int] = None) -> None:
         count = a.numel() // self.elem_bytes if count is None else count
+        self._need("a", a, count * self.elem_bytes)
+        self._need("out", out, count * self.elem_bytes)
         check(self._lib.bgn_make_l2_batch_dev(self._h, count, a.data_ptr(), out.data_ptr(), self._stream()),
               "bgn_make_l2_batch_dev")
 
     def encrypt_dev(self, x, x_len: int, r, r_len: int, out, count: int) -> None:
+        self._need("x", x, count * x_len)
+        self._need("r", r, count * r_len)
+        self._need("out", out, count * self.elem_bytes)
         check(self._lib.bgn_encrypt_batch_dev(self._h, count, x.data_ptr(), x_len, r.data_ptr() if r is not None else None,
                                               r_len, out.data_ptr(), self._stream()), "bgn_encrypt_batch_dev")
 
     def add_dev(self, level: int, a, b, out, count: Optional[int] = None, r=None, r_len: int = 0) -> None:
         """Device-resident Add; r blinds with Q^r (level 1) resp. e(Q,Q)^r (level 2)."""
         count = a.numel() // self.elem_bytes if count is None else count
+        for what, t in (("a", a), ("b", b), ("out", out)):
+            self._need(what, t, count * self.elem_bytes)
+        self._need("r", r, count * r_len)
         check(self._lib.bgn_add_batch_dev(self._h, count, level, a.data_ptr(), b.data_ptr(),
                                           r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
                                           self._stream()), "bgn_add_batch_dev")
 
     def decrypt_dev(self, level: int, ct, m, status, count: Optional[int] = None) -> None:
         count = ct.numel() // self.elem_bytes if count is None else count
+        self._need("ct", ct, count * self.elem_bytes)
+        self._need("m", m, count * 8)
+        self._need("status", status, count)
         check(self._lib.bgn_decrypt_batch_dev(self._h, count, level, ct.data_ptr(), m.data_ptr(), status.data_ptr(),
                                               self._stream()), "bgn_decrypt_batch_dev")
 
     def poly_mult_dev(self, npoly: int, d1: int, d2: int, a, b, out) -> None:
+        """out: npoly x (d1 + d2) level-2 coefficients (the last one of each product is the identity)."""
+        self._need("a", a, npoly * d1 * self.elem_bytes)
+        self._need("b", b, npoly * d2 * self.elem_bytes)
+        self._need("out", out, npoly * (d1 + d2) * self.elem_bytes)
         check(self._lib.bgn_poly_mult_batch_dev(self._h, npoly, d1, d2, a.data_ptr(), b.data_ptr(), out.data_ptr(),
                                                 self._stream()), "bgn_poly_mult_batch_dev")
 
     def poly_multconst_dev(self, npoly: int, d: int, dp: int, level: int, ct, p, k_len: int, per_poly: bool, out) -> None:
+        self._need("ct", ct, npoly * d * self.elem_bytes)
+        self._need("p", p, (npoly if per_poly else 1) * dp * k_len)
+        self._need("out", out, npoly * (d + dp) * self.elem_bytes)
         check(self._lib.bgn_poly_multconst_batch_dev(self._h, npoly, d, dp, level, ct.data_ptr(), p.data_ptr(), k_len,
                                                      1 if per_poly else 0, out.data_ptr(), self._stream()),
               "bgn_poly_multconst_batch_dev")
 
     def poly_eval_dev(self, npoly: int, d: int, level: int, ct, base: int, out) -> None:
+        self._need("ct", ct, npoly * d * self.elem_bytes)
+        self._need("out", out, npoly * self.elem_bytes)
         check(self._lib.bgn_poly_eval_batch_dev(self._h, npoly, d, level, ct.data_ptr(), base, out.data_ptr(),
                                                 self._stream()), "bgn_poly_eval_batch_dev")
 
@@ -399,15 +434,23 @@ class MultiEngine:
 
     def mult_dev(self, a, b, out, root: int, count: Optional[int] = None) -> None:
         count = a.numel() // self.elem_bytes if count is None else count
+        for what, t in (("a", a), ("b", b), ("out", out)):
+            Engine._need(what, t, count * self.elem_bytes)
         check(self._lib.bgn_mmult_batch_dev(self._h, count, a.data_ptr(), b.data_ptr(), out.data_ptr(), root,
                                             self._root_stream(root)), "bgn_mmult_batch_dev")
 
     def decrypt_dev(self, level: int, ct, m, status, root: int, count: Optional[int] = None) -> None:
         count = ct.numel() // self.elem_bytes if count is None else count
+        Engine._need("ct", ct, count * self.elem_bytes)
+        Engine._need("m", m, count * 8)
+        Engine._need("status", status, count)
         check(self._lib.bgn_mdecrypt_batch_dev(self._h, count, level, ct.data_ptr(), m.data_ptr(), status.data_ptr(),
                                                root, self._root_stream(root)), "bgn_mdecrypt_batch_dev")
 
     def poly_mult_dev(self, npoly: int, d1: int, d2: int, a, b, out, root: int) -> None:
+        Engine._need("a", a, npoly * d1 * self.elem_bytes)
+        Engine._need("b", b, npoly * d2 * self.elem_bytes)
+        Engine._need("out", out, npoly * (d1 + d2) * self.elem_bytes)
         check(self._lib.bgn_mpoly_mult_batch_dev(self._h, npoly, d1, d2, a.data_ptr(), b.data_ptr(), out.data_ptr(),
                                                  root, self._root_stream(root)), "bgn_mpoly_mult_batch_dev")
 

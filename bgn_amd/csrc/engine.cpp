@@ -2272,21 +2272,48 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   // a product small enough for the wave-cooperative kernel (a few thousand coefficient pairs: the reference's own
   // MultPoly calls are ONE product of ~10 x 10 coefficients) pairs directly, one pair per workgroup: tables and the
   // one-pairing-per-lane kernels cost the latency of several whole pairings on single lanes
-  const bool quad = use_quad(c, npoly * d1 * d2, coop_limit(c, 0));
-  const bool coop = !quad && npoly * d1 * d2 <= coop_limit(c, 0);
-  const size_t chunk = (!coop && !quad && d1 * d2 >= 2) ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
+  const size_t total_pairs = npoly * d1 * d2;
+  const bool quad = use_quad(c, total_pairs, coop_limit(c, 0));
+  const bool coop = !quad && total_pairs <= coop_limit(c, 0);
+  // Up to 65536 pairs the lane kernel pairs directly in ONE pairing's latency; a table round costs a table build (as
+  // long as a pairing) plus the walks (1024 bits, 512 products of 16 x 16: 195 ms with tables).
+  size_t kLanes = 65536;
+  if (const char* ev = getenv("BGN_POLY_ROUND")) {             // tests: the round size of this logic (not of the kernels)
+    const long v = atol(ev);
+    if (v > 0) kLanes = (size_t)v;
+  }
+  const char* force = getenv("BGN_POLY_TABLES");
+  const bool forced = force && force[0] == '1';                // tests: tables whatever the size
+  const bool one_round = total_pairs <= kLanes;
+  size_t chunk = (forced || (!coop && !quad && !one_round)) && d1 * d2 >= 2 ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
+  // One lane builds one table and runs for the whole kernel, so the time of the table path is a step function of the
+  // table count (1213 products of 16 x 16 = 65502 tables: 260 ms, 1300: 450 ms).  Whole rounds of 65536 tables go
+  // first; a remainder of at most 65536 pairs then pairs directly on the kernel that is fastest at its size.
+  const size_t round_polys = kLanes / dt;
+  if (chunk && round_polys && chunk > round_polys) chunk -= chunk % round_polys;
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
+  // (the remainder: what is left below one round of tables once the whole rounds are taken out of the last chunk)
+  size_t tail_polys = chunk ? npoly % cp : 0;
+  if (round_polys && tail_polys > round_polys) tail_polys %= round_polys;
+  const size_t tail_pairs = tail_polys * d1 * d2;
+  const bool tail_direct = tail_pairs != 0 && tail_pairs <= kLanes;
+  const size_t tail_sp = round_up(tail_pairs ? tail_pairs : 1, 64);
   SoA2 E;
   uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
-    const size_t lane_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;
-    {
-      const size_t small_b = quad ? quad_ws_words(c->nl, sp) * 4 : coop ? coop_ws_words(c->nl, sp) * 4 : 0;
-      pws = (uint32_t*)w.cv.take(small_b > lane_b ? small_b : lane_b);       // the lane kernel is the fallback
+    size_t ws_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;         // the lane kernel is the fallback
+    auto at_least = [&](size_t b) { if (b > ws_b) ws_b = b; };
+    if (quad) at_least(quad_ws_words(c->nl, sp) * 4);
+    if (coop) at_least(coop_ws_words(c->nl, sp) * 4);
+    if (tail_direct) {
+      at_least((size_t)c->pair_ws_slots * c->nl * tail_sp * 4);
+      at_least(quad_ws_words(c->nl, tail_sp) * 4);
+      at_least(coop_ws_words(c->nl, tail_sp) * 4);
     }
+    pws = (uint32_t*)w.cv.take(ws_b);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
@@ -2310,22 +2337,33 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     if (v.inf) v.inf += off;
     return v;
   };
-  for (size_t q0 = 0; q0 < npoly; q0 += cp) {
-    const size_t nq = (npoly - q0 < cp) ? npoly - q0 : cp;
+  bool tables_used = false;
+  for (size_t q0 = 0, nq = 0; q0 < npoly; q0 += nq) {
+    nq = (npoly - q0 < cp) ? npoly - q0 : cp;
+    if (tail_direct && nq < cp && nq > tail_polys) nq -= tail_polys;              // the last chunk: its whole rounds first
     const size_t pairs = nq * d1 * d2;
     const SoA2 Aq = view(A, q0 * d1), Bq = view(Bv, q0 * d2);
-    if (chunk) {
+    const bool tail = tail_direct && nq == tail_polys && q0 + nq == npoly;        // the remainder after the whole rounds
+    const bool direct = !chunk || tail;
+    const size_t sw = tail ? tail_sp : sp;
+    const bool q_quad = tail ? use_quad(c, pairs, coop_limit(c, 0)) : quad;
+    const bool q_coop = tail ? (!q_quad && pairs <= coop_limit(c, 0)) : coop;
+    if (!direct) {
       const SoA2 T = tab_on_a ? Aq : Bq, V = tab_on_a ? Bq : Aq;
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);
       kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(pairs), pws, sp,
                   tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
-    } else if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sp,
-                                           c->p_bits + 1)) {
-    } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sp,
-                                           c->p_bits + 1)) {
+      tables_used = true;
+    } else if (q_quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sw,
+                                             c->p_bits + 1)) {
+      c->last_kernel = quad_pairing_kernel_name(c->nl);
+    } else if (q_coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sw,
+                                             c->p_bits + 1)) {
+      c->last_kernel = coop_pairing_kernel_name(c->nl);
     } else {
-      kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(pairs), pws, sp, nullptr, 0,
+      kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(pairs), pws, sw, nullptr, 0,
                   0);
+      c->last_kernel = kt->pairing_kernel_name;
     }
     kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, pairs);
     PolyAccArgs pa;
@@ -2336,7 +2374,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     kt->poly_acc(s, c->d_params, pa);                                              // result[i+k] = Add(result[i+k], coeff), poly.go:148
   }
   HIP_TRY(hipGetLastError());
-  if (used_tables) *used_tables = chunk != 0;
+  if (used_tables) *used_tables = tables_used;
   return BGN_OK;
 }
 }  // namespace
@@ -2422,7 +2460,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   }
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
-  c->last_kernel = used_tables ? "k_fixedpair_build_batch + k_pairing<.,1>" : kt->pairing_kernel_name;
+  if (used_tables) c->last_kernel = "k_fixedpair_build_batch + k_pairing<.,1>";      // (else: the pairing kernel the core chose)
   kt->encode(s, nullptr, R[0].c0, R[0].c1, R[0].stride, c->L, npoly * (d1 + d2), out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));            // the scratch arrays are released on return

@@ -63,3 +63,18 @@ def test_product_never_references_the_oracle():
                 if re.search(r"oracle|bgn_ref|bgn_oracle|tests[/.]emu", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_host_mirror_refuses_device_arrays_shorter_than_the_call_needs():
+    """The C ABI takes bare pointers (include/bgn_amd.h): the Python mirror checks the byte length of every device
+    array before it hands the pointer over — a short `out` is a ValueError, not a GPU fault."""
+    import pytest
+    import torch
+    from bgn_amd.api import Engine
+    with pytest.raises(ValueError, match="the call needs 4"):
+        Engine._need("out", torch.empty(3, dtype=torch.uint8), 4)
+    with pytest.raises(ValueError, match="the call needs 16"):
+        Engine._need("m", torch.empty(1, dtype=torch.int64), 16)
+    with pytest.raises(ValueError, match="CUDA tensor"):
+        Engine._need("a", torch.empty(8, dtype=torch.uint8), 8)
+    Engine._need("r", None, 100)                      # optional operands

@@ -308,3 +308,19 @@ def test_add_beyond_64_elements_per_lane():
         eng.add_dev(1, ca[lo: lo + m * EB], cb[lo: lo + m * EB], piece[: m * EB], m)
         torch.cuda.synchronize()
         assert torch.equal(whole[lo: lo + m * EB], piece[: m * EB]), k
+
+
+def test_short_device_arrays_are_refused_by_the_host_mirror():
+    """MultPoly writes npoly * (d1 + d2) coefficients (include/bgn_amd.h): an output array of npoly * (d1 + d2 - 1)
+    is refused before the call; so are short operands of Mult / Decrypt."""
+    fx = load_fixture("k256")
+    pk, _ = engine_key(fx)
+    eng, dev = pk.engine, torch.device("cuda")
+    EB = eng.elem_bytes
+    a = torch.zeros(4 * 3 * EB, dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError, match="out"):
+        eng.poly_mult_dev(4, 3, 3, a, a, torch.empty(4 * 5 * EB, dtype=torch.uint8, device=dev))
+    with pytest.raises(ValueError, match="b:"):
+        eng.mult_dev(a, a[: 5 * EB], torch.empty_like(a), 12)
+    with pytest.raises(ValueError, match="status"):
+        eng.decrypt_dev(1, a, torch.empty(12, dtype=torch.int64, device=dev), torch.empty(11, dtype=torch.uint8, device=dev), 12)

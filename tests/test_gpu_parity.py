@@ -305,23 +305,34 @@ def test_poly_mult_many_vs_c_oracle_and_decrypt():
         assert [int(v) for v in m[q * (d1 + d2):(q + 1) * (d1 + d2)]] == conv
 
 
+T1 = {"BGN_POLY_TABLES": "1"}                    # the table path whatever the size (by default products of up to 65536
+                                                 # coefficient pairs pair directly: one pairing's latency)
+
+
 @pytest.mark.parametrize("d1,d2,env", [
-    (4, 3, {}),                                  # tables on the second polynomial (fewer coefficients)
-    (2, 5, {}),                                  # tables on the first
-    (3, 3, {"BGN_POLY_TABLE_MAX_MB": "3"}),      # table budget of 3 MB = 64 columns: 21 polynomials per chunk
+    (4, 3, T1),                                  # tables on the second polynomial (fewer coefficients)
+    (2, 5, T1),                                  # tables on the first
+    (3, 3, {**T1, "BGN_POLY_TABLE_MAX_MB": "3"}),      # table budget of 3 MB = 64 columns: 21 polynomials per chunk
+    # whole rounds of tables first, the remainder pairs directly (rounds of 64 / 16 lanes instead of 65536 here):
+    (3, 3, {**T1, "BGN_POLY_TABLE_MAX_MB": "3", "BGN_POLY_ROUND": "64"}),                # 70 = 3 x 21 + 7: 63 pairs direct
+    (2, 2, {**T1, "BGN_POLY_ROUND": "32", "npoly": "37"}),                               # one chunk of 32 + 5 direct
+    (2, 2, {**T1, "BGN_POLY_TABLE_MAX_MB": "3", "BGN_POLY_ROUND": "16", "npoly": "43"}), # 32, then 8 by tables + 3 direct
     (4, 3, {"BGN_POLY_TABLES": "0"}),            # direct d1*d2 full pairings
-    (1, 4, {}), (4, 1, {}), (1, 1, {}),          # degenerate shapes
-    (2, 2, {}),                                  # square, below the Karatsuba threshold
-    (4, 4, {}), (8, 8, {}),                      # Karatsuba: one and two levels down to 2 x 2
-    (6, 6, {}),                                  # one level, odd leaves 3 x 3
-    (8, 8, {"BGN_POLY_KARATSUBA": "0"}),         # the same product without it
+    (4, 3, {}), (2, 5, {}),                      # the default dispatch at this size
+    (1, 4, T1), (4, 1, T1), (1, 1, {}),          # degenerate shapes
+    (2, 2, T1),                                  # square, below the Karatsuba threshold
+    (4, 4, T1), (8, 8, T1),                      # Karatsuba: one and two levels down to 2 x 2
+    (6, 6, T1),                                  # one level, odd leaves 3 x 3
+    (8, 8, {**T1, "BGN_POLY_KARATSUBA": "0"}),   # the same product without it
     (4, 4, {"BGN_POLY_TABLES": "0"}),            # Karatsuba over direct pairings at the leaves
 ])
 def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
     """MultPoly over per-coefficient line tables (fixedpair.hpp) == the oracle's d1*d2 full pairings +
-    accumulation, for either table side, chunked tables, identity coefficients (Enc(0) deterministic) and
-    the direct path."""
+    accumulation, for either table side, chunked tables, whole rounds + direct remainder, identity coefficients
+    (Enc(0) deterministic) and the direct path."""
     import oracle_c
+    env = dict(env)
+    npoly = int(env.pop("npoly", 70 if env.get("BGN_POLY_TABLE_MAX_MB") else 9))
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     fx = load_fixture("k256")
@@ -329,7 +340,6 @@ def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
     pk, _ = engine_key(fx)
     rng = random.Random(100 * d1 + d2)
     n = int(fx["n"], 16)
-    npoly = 70 if env.get("BGN_POLY_TABLE_MAX_MB") else 9
     xa = [rng.choice([0, 1, 2, n - 1]) for _ in range(npoly * d1)]
     xb = [rng.choice([0, 1, 2, n - 1]) for _ in range(npoly * d2)]
     # r = 0 with x = 0 is the identity of G1 (encryptZero in deterministic mode, bgn.go:562-564)
@@ -337,6 +347,8 @@ def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
     eb = o.encrypt(xb, [rng.choice([0, rng.randrange(n)]) for _ in xb])
     out = pk.engine.poly_mult(npoly, d1, d2, ea, eb)
     assert out.tobytes() == o.poly_mult(npoly, d1, d2, ea, eb)
+    if env.get("BGN_POLY_TABLES") == "1" and d1 * d2 >= 2 and "BGN_POLY_ROUND" not in env:
+        assert "fixedpair" in pk.engine.last_kernel_name()
 
 
 def test_decrypt_large_message_space_1024():

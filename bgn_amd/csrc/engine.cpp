@@ -2379,6 +2379,55 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
 }
 }  // namespace
 
+// How many Karatsuba levels pay.  Every level turns a product into three of half the length: fewer coefficient pairs
+// (x 3/4), but on the table path also shorter leaves, i.e. fewer pairs per table — and a round of table builds
+// (65536 lanes, one table each, as long as a whole pairing) is amortised over the walks of the pairs that share a
+// table.  The estimate below prices a leaf shape the way poly_mult_core runs it, in units of the walk of one pair
+// (profiles/r03_multpoly_sizes.csv at 1024 bits: table build 129 ms, walk 53 ms, direct pairing 155 ms per round of
+// 65536 lanes; lane-group kernel 3.4 us per pair, cooperative 14.5 us; the ratios hold across key sizes), and the
+// level count with the smallest estimate wins (ties: more levels, fewer pairs).  16 x 16 at 1024 bits: 2048 products
+// run two levels (leaves 4 x 4: one round of tables + a direct remainder, 451 ms) instead of three (two rounds,
+// 517 ms); 4096 products keep three.  BGN_POLY_LEVELS forces a count.
+static int poly_plan_levels(const bgn_ctx* c, size_t npoly, size_t d, int max_levels) {
+  if (const char* ev = getenv("BGN_POLY_LEVELS")) {
+    const int v = atoi(ev);
+    return v < 0 ? 0 : v > max_levels ? max_levels : v;
+  }
+  if (max_levels == 0) return 0;
+  const double B = 129, W = 65, D = 160, kLanes = 65536.0;            // ms at 1024 bits; only the ratios matter
+  const double quad_pair = 3.44e-3, quad_floor = 19, coop_pair = 14.5e-3, coop_floor = 6.8;
+  const size_t coop_max = coop_limit(c, 0);
+  auto direct = [&](double pairs) {                      // one launch of the kernel poly_mult_core picks for `pairs`
+    if (pairs <= (double)coop_max) return coop_floor > pairs * coop_pair ? coop_floor : pairs * coop_pair;
+    if (use_quad(c, (size_t)pairs, coop_max)) return quad_floor > pairs * quad_pair ? quad_floor : pairs * quad_pair;
+    return D * __builtin_ceil(pairs / kLanes);
+  };
+  int best = 0;
+  double best_t = 0;
+  size_t n = npoly, dk = d;
+  for (int L = 0; L <= max_levels; ++L) {
+    const double pairs = (double)n * (double)dk * (double)dk, tables = (double)n * (double)dk;
+    double t;
+    if (pairs <= kLanes || dk < 2) {
+      t = direct(pairs);
+    } else {
+      // whole rounds of 65536 tables (each lane then walks dk pairs), then the remainder: directly if it has at most
+      // 65536 pairs, else one more build and its walks spread over all lanes
+      const double rounds = __builtin_floor(tables / kLanes);
+      const double tail_pairs = (tables - rounds * kLanes) * (double)dk;
+      t = rounds * (B + (double)dk * W);
+      if (tail_pairs != 0) t += tail_pairs <= kLanes ? direct(tail_pairs) : B + W * __builtin_ceil(tail_pairs / kLanes);
+    }
+    if (L == 0 || t <= best_t) {
+      best = L;
+      best_t = t;
+    }
+    n *= 3;
+    dk /= 2;
+  }
+  return best;
+}
+
 // Square products of even length run as Karatsuba over the bilinear pairing (polyops.hpp): L levels turn npoly
 // products of d x d coefficients into 3^L * npoly products of d/2^L x d/2^L, which go through the table path
 // above; 16 x 16 becomes 27 products of 2 x 2 = 108 table evaluations + 54 tables instead of 256 + 16.
@@ -2399,6 +2448,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
     const char* ev = getenv("BGN_POLY_KARATSUBA");
     if (d1 == d2 && !(ev && ev[0] == '0'))
       for (size_t dk = d1; dk % 2 == 0 && dk >= 4; dk /= 2) levels++;
+    levels = poly_plan_levels(c, npoly, d1, levels);
   }
   // level k holds n[k] = 3^k * npoly polynomials of dk[k] = d / 2^k coefficients
   std::vector<size_t> n(levels + 1), dk(levels + 1);

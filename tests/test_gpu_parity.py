@@ -324,6 +324,8 @@ T1 = {"BGN_POLY_TABLES": "1"}                    # the table path whatever the s
     (4, 4, T1), (8, 8, T1),                      # Karatsuba: one and two levels down to 2 x 2
     (6, 6, T1),                                  # one level, odd leaves 3 x 3
     (8, 8, {**T1, "BGN_POLY_KARATSUBA": "0"}),   # the same product without it
+    (8, 8, {**T1, "BGN_POLY_LEVELS": "1"}),      # one level where two are possible (engine.cpp poly_plan_levels picks by cost)
+    (16, 16, {"BGN_POLY_LEVELS": "2", "npoly": "5"}), (16, 16, {"npoly": "5"}),
     (4, 4, {"BGN_POLY_TABLES": "0"}),            # Karatsuba over direct pairings at the leaves
 ])
 def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):

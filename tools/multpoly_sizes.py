@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """MultPoly (poly.go:123-156) wall time by the number of polynomial pairs, d1 x d2 coefficients each, device-resident
-operands, best of three: where the time steps.
+operands, best of three: where the time steps.  BGN_POLY_LEVELS=n forces the number of Karatsuba levels (column
+karatsuba_levels; "planned" = engine.cpp poly_plan_levels chooses).
     python tools/multpoly_sizes.py [k1024] > profiles/r03_multpoly_sizes.csv"""
 import os
 import sys
@@ -21,7 +22,8 @@ def main():
     keys = sys.argv[1:] or ["k1024"]
     shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ.get("MP_SHAPES", "16x16,4x4,10x10").split(",")]
     npolys = [int(x) for x in os.environ.get("MP_NPOLY", "16,64,128,170,200,256,260,300,400,512,600,1024,1100,2048,4096,4200").split(",")]
-    print("key,d1,d2,npoly,pairs,ms,pairs_per_s,kernel")
+    if not os.environ.get("MP_NO_HEADER"):
+        print("key,d1,d2,npoly,karatsuba_levels,pairs,ms,pairs_per_s,kernel")
     dev = torch.device("cuda", 0)
     for key in keys:
         fx = load_fixture(key)
@@ -43,7 +45,7 @@ def main():
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                     best = dt if best is None else min(best, dt)
-                print("%s,%d,%d,%d,%d,%.2f,%.1f,%s" % (key, d1, d2, n, n * d1 * d2, best * 1e3, n * d1 * d2 / best,
+                print("%s,%d,%d,%d,%s,%d,%.2f,%.1f,%s" % (key, d1, d2, n, os.environ.get("BGN_POLY_LEVELS", "planned"), n * d1 * d2, best * 1e3, n * d1 * d2 / best,
                                                       eng.last_kernel_name()), flush=True)
 
 

@@ -382,9 +382,12 @@ def test_repeated_setup_keeps_key_tables_alive():
         assert sk.Decrypt(c, pk) == 7
 
 
-def test_mult_runs_with_shared_inversion():
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_mult_runs_with_shared_inversion(split, monkeypatch):
     """count > 2*65536 makes every lane own a run of pairings that share one F_p inversion
-    (Montgomery's trick in the final exponentiation); ragged tail; identities inside the runs."""
+    (Montgomery's trick in the final exponentiation); ragged tail; identities inside the runs.
+    split = 0: one launch, the last run ragged; 1 (the default): three whole rounds, then the 77 on their own."""
+    monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
     fx = load_fixture("toy64")
     opk, _ = oracle_key(fx)
     pk, _ = engine_key(fx)

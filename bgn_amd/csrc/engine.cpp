@@ -2084,9 +2084,16 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
 // on whichever kernel is fastest at its size (lane_rounds_head).
 static size_t decrypt_rounds_head(const bgn_ctx* c, size_t n, int level) {
   constexpr size_t kLanes = 65536, kFull = kLanes * 16;
-  if (level != 1 || n <= kLanes) return n;
+  if (n <= kLanes) return n;
   if (const char* ev = getenv("BGN_SPLIT_ROUNDS"))
     if (ev[0] == '0') return n;
+  if (level == 2) {
+    // the power by the secret key: one element per lane, rounds of 65536; the cooperative and the lane-group kernel
+    // take a remainder in their ranges (1024 bits: 66 000 level-2 Decrypts 21.4 -> 13 ms)
+    const size_t rem = n % kLanes;
+    if (n > quad_table_floor(c, 3) && n <= quad_table_limit(c, 3)) return n;
+    return (rem && (rem <= coop_limit(c, 3) || rem <= quad_table_limit(c, 3))) ? n - rem : n;
+  }
   const bool tw = coop_table_walk(c);
   if (tw && n > quad_table_floor(c, 2) && n <= quad_table_limit(c, 2)) return n;      // the lane groups take it whole
   if (n > kFull) return n % kFull ? n - n % kFull : n;

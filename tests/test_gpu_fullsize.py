@@ -282,6 +282,9 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
                 assert not bool(st.any().item()) and torch.equal(m.cpu(), want), split
                 aux = eng.last_aux_kernel_name()
                 assert ("coop" in aux or "quad" in aux) == (split == "1"), aux
+                eng.decrypt_dev(2, res["1"][1], m, st, count)                  # level 2: the power by q1 + BSGS
+                torch.cuda.synchronize()
+                assert not bool(st.any().item()) and torch.equal(m.cpu(), want), ("level 2", split)
 
 
 def test_add_beyond_64_elements_per_lane():

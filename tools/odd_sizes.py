@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batch sizes that do not fill whole rounds of the lane kernel (65536 lanes, up to sixteen pairings each): wall
-time of Mult, makeL2 and level-1 Decrypt under the default dispatch with the cut into whole rounds + remainder
+time of Mult, makeL2 and Decrypt of both levels under the default dispatch with the cut into whole rounds + remainder
 (engine.cpp lane_rounds_head / decrypt_rounds_head) and without it (BGN_SPLIT_ROUNDS=0); device-resident operands,
 best of three, results of the two compared.
     python tools/odd_sizes.py [k1024] > profiles/r03_odd_sizes.csv"""
@@ -37,7 +37,9 @@ def main():
         out = torch.empty(nmax * EB, dtype=torch.uint8, device=dev)
         msg = torch.empty(nmax, dtype=torch.int64, device=dev)
         sta = torch.empty(nmax, dtype=torch.uint8, device=dev)
-        for op in ("mult", "make_l2", "decrypt_l1"):
+        l2 = torch.empty(nmax * EB, dtype=torch.uint8, device=dev)
+        eng.make_l2_dev(cts, l2, nmax)
+        for op in ("mult", "make_l2", "decrypt_l1", "decrypt_l2"):
             for n in counts:
                 ref = None
                 for split in ("1", "0"):
@@ -50,15 +52,17 @@ def main():
                             eng.mult_dev(cts[: n * EB], b[: n * EB], out[: n * EB], n)
                         elif op == "make_l2":
                             eng.make_l2_dev(cts[: n * EB], out[: n * EB], n)
-                        else:
+                        elif op == "decrypt_l1":
                             eng.decrypt_dev(1, cts[: n * EB], msg[:n], sta[:n], n)
+                        else:
+                            eng.decrypt_dev(2, l2[: n * EB], msg[:n], sta[:n], n)
                         torch.cuda.synchronize()
                         dt = time.perf_counter() - t0
                         best = dt if best is None else min(best, dt)
-                    got = (msg[:n].clone(), sta[:n].clone()) if op == "decrypt_l1" else out[: n * EB].clone()
+                    got = (msg[:n].clone(), sta[:n].clone()) if op.startswith("decrypt") else out[: n * EB].clone()
                     if ref is None:
                         ref = got
-                    elif op == "decrypt_l1":
+                    elif op.startswith("decrypt"):
                         assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (key, op, n)
                     else:
                         assert torch.equal(ref, got), (key, op, n)

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Randomised differential run on the GPU: random operations at random batch sizes (log-uniform, so the dispatch
+boundaries between the cooperative, the lane-group and the one-element-per-lane kernels and the cuts into whole
+rounds are crossed all the time), each computed under the default dispatch and again with a kernel family forced or a
+planner switched off; every byte / plaintext / status must agree, and a sample of every batch is checked against
+the C oracle (test infrastructure: this tool is not part of the product).
+    python tools/soak.py [seconds] [seed] > profiles/r03_soak.txt"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import torch  # noqa: E402
+
+from conftest import load_fixture  # noqa: E402
+import bgn_amd  # noqa: E402
+import bgn_amd.synthetic as syn  # noqa: E402
+import oracle_c  # noqa: E402
+
+BIG = "100000000"
+KERNEL_ENV = ("BGN_QUAD_MIN", "BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW", "BGN_COOP_MAX", "BGN_COOP_MAX_L2",
+              "BGN_COOP_MAX_DEC", "BGN_SPLIT_ROUNDS", "BGN_POLY_TABLES", "BGN_POLY_KARATSUBA", "BGN_POLY_LEVELS")
+
+
+def force(kernel):
+    for v in KERNEL_ENV:
+        os.environ.pop(v, None)
+    if kernel == "default":
+        return
+    if kernel == "one launch":
+        os.environ["BGN_SPLIT_ROUNDS"] = "0"
+        return
+    os.environ["BGN_QUAD_MIN"] = "0"
+    for v in ("BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
+        os.environ[v] = BIG if kernel == "quad" else "0"
+    for v in ("BGN_COOP_MAX", "BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
+        os.environ[v] = BIG if kernel == "coop" else "0"
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    dev = torch.device("cuda", 0)
+    keys = {}
+    NMAX = 1 << 18
+    for name in ("k256", "k512", "k1024", "k1024b"):
+        fx = load_fixture(name)
+        pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                               fx["msg_space"], True, fx["poly_base"])
+        pk.engine.set_memory_budget(60 << 30)
+        pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+        eng = pk.engine
+        EB = eng.elem_bytes
+        T = fx["msg_space"]
+        g = torch.Generator().manual_seed(seed * 7 + len(keys))
+        nbytes = 3 if T >= (1 << 24) else 1
+        vals = torch.randint(0, min(T, 1 << (8 * nbytes)) - 1, (NMAX,), generator=g, dtype=torch.int64)
+        xs = torch.empty((NMAX, nbytes), dtype=torch.uint8)
+        v = vals.clone()
+        for j in range(nbytes - 1, -1, -1):
+            xs[:, j] = (v & 0xFF).to(torch.uint8)
+            v >>= 8
+        r_len, top_mask = syn._r_shape(int(fx["n"], 16))
+        rs = torch.randint(0, 256, (NMAX, r_len), dtype=torch.uint8, generator=g)
+        rs[:, 0] &= top_mask
+        xs, rs = xs.to(dev), rs.to(dev)
+        cts = torch.empty(NMAX * EB, dtype=torch.uint8, device=dev)
+        eng.encrypt_dev(xs, nbytes, rs, r_len, cts, NMAX)
+        perm = syn.permuted_copy(cts, EB, seed + 5)
+        l2 = torch.empty_like(cts)
+        force("default")
+        eng.make_l2_dev(cts, l2, NMAX)
+        torch.cuda.synchronize()
+        keys[name] = dict(fx=fx, pk=pk, eng=eng, EB=EB, vals=vals, cts=cts, perm=perm, l2=l2, xs=xs, rs=rs, nbytes=nbytes, r_len=r_len,
+                          oracle=oracle_c.Oracle.from_fixture(fx))
+    print("# soak: %d s, seed %d, keys %s" % (seconds, seed, ",".join(keys)), flush=True)
+    t_end = time.time() + seconds
+    done = {}
+    elements = 0
+    while time.time() < t_end:
+        name = rng.choice(list(keys))
+        K = keys[name]
+        eng, EB = K["eng"], K["EB"]
+        op = rng.choice(["mult", "mult", "make_l2", "decrypt_l1", "decrypt_l2", "multpoly", "add_l1", "encrypt"])
+        hi = {"k256": 18, "k512": 17.6, "k1024": 17.2, "k1024b": 16.5}[name]
+        n = max(1, int(2 ** rng.uniform(0, hi)))
+        if rng.random() < 0.25:                              # around the round boundaries
+            n = min(NMAX, rng.choice([65536, 131072]) + rng.randrange(-3000, 3000))
+        off = rng.randrange(0, NMAX - n + 1)
+        a = K["cts"][off * EB: (off + n) * EB]
+        b = K["perm"][off * EB: (off + n) * EB]
+        variants = ["default"]
+        if n <= 20000:
+            variants += ["coop"]
+        variants += [rng.choice(["quad", "lane"])]
+        if n > 65536:
+            variants += ["one launch"]
+        ref = None
+        if op in ("mult", "make_l2"):
+            for kv in variants:
+                force(kv)
+                out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+                if op == "mult":
+                    eng.mult_dev(a, b, out, n)
+                else:
+                    eng.make_l2_dev(a, out, n)
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = out
+                    k = min(n, 3)
+                    sa, sb = bytes(a[: k * EB].cpu().numpy()), bytes(b[: k * EB].cpu().numpy())
+                    want = K["oracle"].mult(sa, sb) if op == "mult" else K["oracle"].mult(sa)      # makeL2 = e(., P)
+                    assert bytes(out[: k * EB].cpu().numpy()) == want, (name, op, n, "oracle")
+                else:
+                    assert torch.equal(ref, out), (name, op, n, kv)
+        elif op in ("decrypt_l1", "decrypt_l2"):
+            lvl = 1 if op == "decrypt_l1" else 2
+            src = a if lvl == 1 else K["l2"][off * EB: (off + n) * EB]
+            want = K["vals"][off: off + n]
+            for kv in variants:
+                force(kv)
+                m = torch.empty(n, dtype=torch.int64, device=dev)
+                st = torch.empty(n, dtype=torch.uint8, device=dev)
+                eng.decrypt_dev(lvl, src, m, st, n)
+                torch.cuda.synchronize()
+                assert not bool(st.any().item()) and torch.equal(m.cpu(), want), (name, op, n, kv)
+        elif op == "add_l1":
+            force("default")
+            out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+            eng.add_dev(1, a, b, out, n)
+            torch.cuda.synchronize()
+            k = min(n, 4)
+            j = rng.randrange(0, n - k + 1)
+            sa, sb = bytes(a[j * EB: (j + k) * EB].cpu().numpy()), bytes(b[j * EB: (j + k) * EB].cpu().numpy())
+            assert bytes(out[j * EB: (j + k) * EB].cpu().numpy()) == K["oracle"].add(1, sa, sb), (name, op, n)
+        elif op == "encrypt":
+            force("default")
+            out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+            eng.encrypt_dev(K["xs"][off: off + n], K["nbytes"], K["rs"][off: off + n], K["r_len"], out, n)
+            torch.cuda.synchronize()
+            assert torch.equal(out, a), (name, op, n)               # the same inputs gave cts at set-up (one launch of 2^18)
+        else:
+            d1, d2 = rng.choice([(2, 2), (3, 5), (4, 4), (8, 8), (5, 1), (6, 6), (16, 16), (7, 3)])
+            npoly = max(1, min(n // (d1 * d2), NMAX // max(d1, d2) - 1, 3000))
+            pa = K["cts"][: npoly * d1 * EB]
+            pb = K["perm"][: npoly * d2 * EB]
+            n = npoly * d1 * d2
+            for kv, env in (("default", {}), ("direct", {"BGN_POLY_TABLES": "0", "BGN_POLY_KARATSUBA": "0"}), ("tables", {"BGN_POLY_TABLES": "1"}),
+                            ("levels", {"BGN_POLY_LEVELS": str(rng.randrange(0, 4))})):
+                if kv == "direct" and n > 70000:
+                    continue
+                force("default")
+                os.environ.update(env)
+                out = torch.empty(npoly * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+                eng.poly_mult_dev(npoly, d1, d2, pa, pb, out)
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = out
+                else:
+                    assert torch.equal(ref, out), (name, op, npoly, d1, d2, kv)
+        done[(name, op)] = done.get((name, op), 0) + 1
+        elements += n
+    force("default")
+    print("# %d calls compared, %d elements; no difference" % (sum(done.values()), elements))
+    for (name, op), c in sorted(done.items()):
+        print("%s,%s,%d" % (name, op, c))
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,8 @@ def main():
     dev = torch.device("cuda", 0)
     keys = {}
     NMAX = 1 << 18
-    for name in ("k256", "k512", "k1024", "k1024b"):
+    names = os.environ.get("SOAK_KEYS", "k256,k512,k1024,k1024b").split(",")
+    for name in names:
         fx = load_fixture(name)
         pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
                                fx["msg_space"], True, fx["poly_base"])
@@ -88,17 +89,20 @@ def main():
         K = keys[name]
         eng, EB = K["eng"], K["EB"]
         op = rng.choice(["mult", "mult", "make_l2", "decrypt_l1", "decrypt_l2", "multpoly", "add_l1", "encrypt"])
-        hi = {"k256": 18, "k512": 17.6, "k1024": 17.2, "k1024b": 16.5}[name]
+        hi = {"k256": 18, "k512": 17.6, "k1024": 17.2, "k1024b": 16.5, "k2048": 12.5}[name]
         n = max(1, int(2 ** rng.uniform(0, hi)))
-        if rng.random() < 0.25:                              # around the round boundaries
+        if rng.random() < 0.25 and name != "k2048":          # around the round boundaries
             n = min(NMAX, rng.choice([65536, 131072]) + rng.randrange(-3000, 3000))
         off = rng.randrange(0, NMAX - n + 1)
         a = K["cts"][off * EB: (off + n) * EB]
         b = K["perm"][off * EB: (off + n) * EB]
         variants = ["default"]
-        if n <= 20000:
-            variants += ["coop"]
-        variants += [rng.choice(["quad", "lane"])]
+        if name == "k2048":                                   # 72 limbs: no cooperative kernel, the lane kernels are the slow functional ones
+            variants += ["lane"] if n <= 48 else []
+        else:
+            if n <= 20000:
+                variants += ["coop"]
+            variants += [rng.choice(["quad", "lane"])]
         if n > 65536:
             variants += ["one launch"]
         ref = None

@@ -84,6 +84,7 @@ def main():
     t_end = time.time() + seconds
     done = {}
     elements = 0
+    last_note = time.time()
     while time.time() < t_end:
         name = rng.choice(list(keys))
         K = keys[name]
@@ -170,6 +171,9 @@ def main():
                     assert torch.equal(ref, out), (name, op, npoly, d1, d2, kv)
         done[(name, op)] = done.get((name, op), 0) + 1
         elements += n
+        if time.time() - last_note > 30:                     # a sign of life (a silent command is taken to be hung)
+            last_note = time.time()
+            print("# ... %d calls, %d elements so far" % (sum(done.values()), elements), flush=True)
     force("default")
     print("# %d calls compared, %d elements; no difference" % (sum(done.values()), elements))
     for (name, op), c in sorted(done.items()):

@@ -838,11 +838,11 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
 }
 
 // Between the cooperative kernel's saturation and one pairing per lane filling the chip sits the lane-group kernel
-// (quad/quad.hpp: sixteen lanes per pairing; 4096 pairings put one wave on every SIMD, two workgroups share a CU):
+// (quad/quad.hpp: sixteen lanes per pairing; 4096 pairings put one wave on every SIMD, three workgroups share a CU):
 // Mult and MultPoly's coefficient pairs above coop_limit and up to quad_limit pairs, from the committed sweep
-// profiles/r03_mid_batch.csv (MI355X, 1024 bits: 4096 pairs 21.5 ms, 16384 63.9 ms, 40960 153 ms against 166 ms
+// profiles/r03_mid_batch.csv (MI355X, 1024 bits: 4096 pairs 18.9 ms, 16384 54.9 ms, 49152 153.3 ms against 155.5 ms
 // for ANY count up to 65536 on the lane kernel, 1024 pairs 21.2 ms against 17.8 ms cooperative; 512 bits: 4096
-// pairs 5.2 ms, 32768 23.5 ms against 28.7 ms, 1024 pairs 5.2 against 5.3 ms).  A lane of the lane kernel takes a
+// pairs 5.1 ms, 40960 27.9 ms against 28.2 ms, 1024 pairs 5.2 against 5.3 ms).  A lane of the lane kernel takes a
 // second pairing from 65537 pairs on: such a batch is cut into whole rounds of that kernel and a remainder that
 // comes back here (lane_rounds_head).  BGN_QUAD_MAX overrides the upper end (0 disables the kernel), BGN_QUAD_MIN
 // the lower one.
@@ -850,7 +850,7 @@ static size_t quad_limit(const bgn_ctx* c) {
   if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
-  return c->nl >= 36 ? 44000 : c->nl >= 19 ? 40000 : 32768;
+  return c->nl >= 36 ? 49000 : c->nl >= 19 ? 40000 : 32768;
 }
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
 // (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts

@@ -46,8 +46,9 @@ constexpr int QUAD_LANES = 4 * QUAD_W;                // lanes per pairing
 constexpr int QUAD_PER_BLOCK = QUAD_BLOCK / QUAD_LANES;
 
 // The two programs (tools/coop/gen_prog.py build_quad_programs): launch 1 = Miller loop and norms, launch 2 = the
-// rest of the final exponentiation.  Each has its own slot numbering, and needs at most 32 value slots per pairing
-// (the Miller state is updated in place: a round's reads precede its writes), so two workgroups share a CU.
+// rest of the final exponentiation.  Each has its own slot numbering; the Miller loop needs 20 value slots per
+// pairing (the state is updated in place — also the intermediate state between the doubling and the addition of a
+// DAP / DAM segment: a round's reads precede its writes), five row blocks of LDS: three workgroups share a CU.
 struct QuadMiller {
   static constexpr int NSLOTS = QUADM_NSLOTS;
   static __device__ __forceinline__ const u32* prog(int i) { return kQuadmProg[i]; }
@@ -427,8 +428,8 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
       for (int j = 0; j < M; ++j) x[j] = 0;
       put(QUADM_SLOT_V1);
     }
-    // Miller loop over the NAF of n (pairing.hpp miller_loop), sequenced as in coop.hpp: a doubling and the
-    // addition of +-A that follows it, two plain doublings, or one doubling per segment; the last addition is
+    // Miller loop over the NAF of n (pairing.hpp miller_loop): a doubling and the addition of +-A that follows it
+    // (one segment, ten rounds) or one doubling per segment (five); the last addition is
     // skipped as in PBC; then the norms' segment.
     const u32* nafw = reinterpret_cast<const u32*>(C->naf);
     auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
@@ -441,14 +442,10 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
         const int d = digit(i);
         if (d != 0 && i != 0) {
           seg = d > 0 ? QUADM_SEG_DAP : QUADM_SEG_DAM;
-          i -= 1;
-        } else if (i >= 1 && (i == 1 || digit(i - 1) == 0)) {
-          seg = QUADM_SEG_DD;
-          i -= 2;
         } else {
           seg = QUADM_SEG_DBL;
-          i -= 1;
         }
+        i -= 1;
       } else if (!norms) {
         seg = QUADM_SEG_NORM;
         norms = true;

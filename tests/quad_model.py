@@ -112,9 +112,6 @@ class QuadValueMachine:
             if d[i] and i != 0:
                 self.run("DAP" if d[i] > 0 else "DAM")                    # doubling + addition of +-A, one segment
                 i -= 1
-            elif i >= 1 and (i == 1 or d[i - 1] == 0):
-                self.run("DD")                                            # two plain doublings, one segment
-                i -= 2
             else:
                 self.run("DBL")
                 i -= 1

@@ -244,6 +244,8 @@ class Program:
                 for u in us:
                     for new, old in inplace.items():
                         assert old not in u.reads() or new not in rnd or r <= rnd[new], (name, new, u.dst)
+            for new, old in inplace.items():       # two generations in one slot: the later one is written in a later round
+                assert old not in rnd or new not in rnd or rnd[old] < rnd[new], (name, new, old)
         self.segments.append((name, rounds))
         return rounds
 
@@ -515,14 +517,13 @@ def build_quad_programs(w=QUAD_W):
         dbl(b, st, new, O)
     M.segment("DBL", seg_dbl, inplace)
 
-    def seg_dd(b):
-        declare_new(b)
-        mid = {k: S("DD.%s" % k) for k in STATE_BOUNDS}
-        for k, f in mid.items():
-            b.bound[name(f)] = STATE_BOUNDS[k]
-        dbl(b, st, mid, O)
-        dbl(b, mid, new, O)
-    M.segment("DD", seg_dd, inplace)
+    # (two plain doublings in one segment take the rounds of two DBL segments here — four quads leave nothing to
+    # overlap across the steps — and would only cost value slots: the controller runs DBL twice.)
+    # A doubling and the addition after it: ten rounds for the 38 micro-ops, two fewer than DBL and a lone addition
+    # take.  The intermediate state (after the doubling) lives in the state's own slots, like the new one after it:
+    # two generations per slot in one segment, each written when every reader of the one before it has run.  With
+    # that the Miller loop needs 8 temporaries beside the 12 operand / state slots: 20 value slots, five row blocks
+    # of LDS — three workgroups per CU instead of two.
     for sign, nm in ((1, "DAP"), (-1, "DAM")):
         def seg_da(b, sign=sign, nm=nm):
             declare_new(b)
@@ -532,15 +533,24 @@ def build_quad_programs(w=QUAD_W):
             del mid["W"]
             dbl(b, st, mid, O, want_w=False)
             add(sign, O)(b, mid, new)
-        M.segment(nm, seg_da, inplace)
-    n1, n2, fm = (M.fixed(k, 2) for k in ("n1", "n2", "fm"))
+        chain = {}
+        for k in STATE_BOUNDS:
+            if k == "W":
+                chain["W'"] = "W"                       # the doubling half makes no W: the addition writes the new one
+            else:
+                chain["%s.%s" % (nm, k)] = k
+                chain[k + "'"] = "%s.%s" % (nm, k)
+        M.segment(nm, seg_da, chain)
 
+    # the norms go where X, Y, Z were (dead once the loop is over)
     def seg_norm(b):
+        for k in ("n1", "n2", "fm"):
+            b.bound[k] = 2
         F0, F1 = f_of(st)
         b.mul(F0, F0, out="n1")
         b.mul(F1, F1, out="n2")
         b.mul(F0, F1, out="fm")
-    M.segment("NORM", seg_norm)
+    M.segment("NORM", seg_norm, {"n1": "X", "n2": "Y", "fm": "Z"})
     M.allocate_temps()
     # ---- launch 2: h = conj(f)^2 / N(f), g = h^l, division by R ----
     F = Program(w, w, reads_first=True)

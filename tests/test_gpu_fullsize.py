@@ -264,6 +264,21 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
             k_l2 = eng.last_kernel_name()
             res[split] = (prod, l2, k_mult, k_l2)
         assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), name
+        if name == "k512":
+            # blinded Mult (Deterministic == false, bgn.go:302-311): the randomness array is cut with the batch
+            r_len = (int(fx["n"], 16).bit_length() + 7) // 8
+            g = torch.Generator().manual_seed(5)
+            r = torch.randint(0, 256, (count, r_len), dtype=torch.uint8, generator=g)
+            r[:, 0] &= 0x3F
+            r = r.to(dev)
+            blinded = {}
+            for split in ("1", "0"):
+                monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+                o = torch.empty(count * EB, dtype=torch.uint8, device=dev)
+                eng.mult_dev(ca, cb, o, count, r=r, r_len=r_len)
+                torch.cuda.synchronize()
+                blinded[split] = o
+            assert torch.equal(blinded["1"], blinded["0"]) and not torch.equal(blinded["1"], res["1"][0])
         assert "k_pairing<" in res["0"][2] and "k_pairing<" in res["0"][3]
         assert "quad" in res["1"][2] or "coop" in res["1"][2], res["1"][2]
         assert "quad" in res["1"][3] or "coop" in res["1"][3], res["1"][3]

@@ -62,9 +62,10 @@ def cpu_budget():
     return info
 
 
-def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0):
-    """The oracle timed on this box's host cores on a bounded sample of the same workload: the first pairs of the
-    very batch the GPU just processed.  Its outputs are compared byte for byte with the GPU's.
+def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0, sample_note=""):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload: pairs of the very batch
+    the GPU just processed, strided over it so that every position of a lane's run of sixteen pairings is in the
+    sample.  Its outputs are compared byte for byte with the GPU's.
     Test-infrastructure code used as the reported baseline and checker only; never on the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     res = None
@@ -91,6 +92,31 @@ def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0):
                "sample": f"first {n} pairs of the GPU batch, pure-Python big-int oracle (oracle/bgn_ref.py), "
                          f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
     res["host_cpu"] = cpu_budget()      # `cores` = threads started; the cgroup quota says what they could get
+    if sample_note:
+        res["sample"] = res["sample"].replace("first ", "", 1) + "; " + sample_note
+    return res
+
+
+def decrypt_cpu_baseline(fx, mixed, want, want_st, n_dec, EB):
+    """The second half of BASELINE's metric beside its CPU figure: 32 ciphertexts of the mixed Decrypt batch the GPU
+    just processed — 31 strided over it (two of them negated) and one out of range — decrypted by the C oracle on
+    the host cores (oracle/oracle_c.py bench_decrypt says which route and why).  Checker / baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c
+        if not oracle_c.available():
+            return None
+    except ImportError:
+        return None
+    import torch
+    stride = n_dec // 32 + 1
+    idx = [i * stride for i in range(31) if i * stride < n_dec]
+    if 7 < n_dec and 7 not in idx:
+        idx.append(7)                                    # decrypt_mix puts an out-of-range message at 7 mod 4096
+    sel = torch.tensor(idx, dtype=torch.int64)
+    ct = mixed.view(-1, EB)[sel.to(mixed.device)].cpu().numpy().tobytes()
+    res = oracle_c.bench_decrypt(fx, ct, want[sel].tolist(), want_st[sel].tolist(), int(fx["msg_space"]))
+    res["host_cpu"] = cpu_budget()
     return res
 
 
@@ -179,7 +205,7 @@ def op_rooflines(entry, counts, nl, n_gpus=1):
     return entry
 
 
-def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
+def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
     """BASELINE configs[1] (Encrypt), EAdd, configs[4]'s shape on one GPU and configs[3] (BSGS Decrypt, T = 2^40),
     on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used.  Inputs resident in HBM; one warm-up pass
     then one timed pass each."""
@@ -268,6 +294,11 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s):
                          "walk_kernel": eng.last_kernel_name(), "walk_kernels_ms": walk_ms,
                          "algorithmic_bytes_per_decrypt": alg}
         dec[k] = e
+    if dec and not no_cpu:
+        top = max(dec)
+        cb = decrypt_cpu_baseline(fx, mixed, want, want_st, 1 << top, EB)
+        if cb:
+            dec[top]["cpu_baseline"] = cb
     # --- Decrypt of level-2 ciphertexts (configs[3] asks for both levels): products of 20-bit messages
     n2 = 1 << 16
     g = torch.Generator(device="cpu")
@@ -524,17 +555,23 @@ def main():
         gathered[0] = None
         del s_out
 
-    # prefix of this rank's batch for the CPU leg (not timed): 4096 distinct pairs
+    # sample of this rank's batch for the CPU leg (not timed): 4096 distinct pairs STRIDED over the batch (every
+    # 256th pair at 2^20).  A lane of k_pairing owns a run of up to sixteen pairings that share one inversion, pair e
+    # sitting at position e / 65536 of its lane's run: a prefix would check position 0 only.
     nchk = min(count, 4096)
-    a_h = a[: nchk * EB].cpu().numpy().tobytes()
-    b_h = b[: nchk * EB].cpu().numpy().tobytes()
-    o_h = out[: nchk * EB].cpu().numpy().tobytes()
+    chk_stride = max(1, count // nchk)
+    sel = torch.arange(nchk, device=dev) * chk_stride
+    a_h = a.view(count, EB)[sel].cpu().numpy().tobytes()
+    b_h = b.view(count, EB)[sel].cpu().numpy().tobytes()
+    o_h = out.view(count, EB)[sel].cpu().numpy().tobytes()
     distinct = len({a_h[i * EB:(i + 1) * EB] + b_h[i * EB:(i + 1) * EB] for i in range(nchk)})
+    run_positions = sorted({int(e) // 65536 for e in sel.tolist()}) if count > 65536 else [0]
 
     extra = dec = None
     full = args.key == "k1024" and args.batch_log2 == 20
     if not args.no_extra and world == 1 and not use_dist and full:
-        extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2])
+        extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2],
+                                       no_cpu=args.no_cpu_baseline)
         extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
     elif not args.no_extra and use_dist and args.key == "k1024":
         # the second half of BASELINE's metric on every GPU: Decrypt shards exactly like Mult (bgn.go:205-250 is per
@@ -549,7 +586,7 @@ def main():
         achieved = alg_bytes * count / (k_ms * 1e-3) / 1e9
         mads = syn.algorithmic_mads_per_pairing(
             fx, run=max(1, min(16, -(-count // 65536))),
-            window={"0": 2, "3": 3, "4": 4}.get(os.environ.get("BGN_MILLER_WINDOW", ""), 5))
+            window={0: 2, 3: 3, 4: 4}.get(eng.get_option("miller_window"), 5))
         traffic, traffic_src = None, None
         for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
@@ -571,7 +608,8 @@ def main():
                                    "m, full-length r) x a fixed permutation of them" % args.batch_log2,
                        "key": fx["name"], "fp_bits": int(fx["p"], 16).bit_length(), "limbs29": syn.limbs_for(int(fx["p"], 16)),
                        "batch_per_gpu": per_gpu, "global_batch": total, "rccl_ranks": rccl_ranks,
-                       "distinct_pairs_in_checked_prefix": distinct,
+                       "distinct_pairs_in_checked_sample": distinct, "checked_sample_stride": chk_stride,
+                       "checked_run_positions": run_positions,
                        "parallelism": ("batch-sharded x%d, one process per GPU + RCCL all-gather of results" % world)
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -597,7 +635,9 @@ def main():
         if extra:
             line["extra"] = extra
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fx, a_h, b_h, o_h)
+            line["cpu_baseline"] = cpu_baseline(
+                fx, a_h, b_h, o_h, sample_note="the sample is every %d-th pair of the batch (run positions %d..%d of "
+                "the lanes' shared-inversion runs)" % (chk_stride, run_positions[0], run_positions[-1]))
         emit_line(line)
     if use_dist:
         dist.barrier()                                   # the other ranks wait for rank 0's CPU leg here

@@ -28,6 +28,13 @@ PROTOTYPES = {
     "bgn_fp_bytes": (_sz, [_ctx]),
     "bgn_last_error": (C.c_char_p, []),
     "bgn_version": (C.c_char_p, []),
+    "bgn_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
+    "bgn_ctx_get_option": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_int64)]),
+    "bgn_ctx_reset_options": (C.c_int, [_ctx]),
+    "bgn_option_name": (C.c_char_p, [_sz]),
+    "bgn_ctx_calibrate": (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
+    "bgn_ctx_combiner_stats": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
+    "bgn_mctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_int64]),
     "bgn_ctx_set_secret": (C.c_int, [_ctx, _u8p, _sz]),
     "bgn_ctx_setup_decryption": (C.c_int, [_ctx, C.c_uint64]),
     "bgn_encrypt_batch": (C.c_int, [_ctx, _sz, _u8p, _sz, _u8p, _sz, _u8p]),

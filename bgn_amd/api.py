@@ -300,6 +300,67 @@ class Engine:
         of every key it has seen (gsbs.go:12-15); with a budget per key several keys share one GPU."""
         check(self._lib.bgn_ctx_set_memory_budget(self._h, int(nbytes)), "bgn_ctx_set_memory_budget")
 
+    # ---- options / calibration / combiner ---------------------------------------
+    def set_option(self, name: str, value: int) -> None:
+        """bgn_ctx_set_option: a named knob of this context (include/bgn_amd.h; names in csrc/options.hpp)."""
+        check(self._lib.bgn_ctx_set_option(self._h, name.encode(), int(value)), "bgn_ctx_set_option(%s)" % name)
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        check(self._lib.bgn_ctx_get_option(self._h, name.encode(), C.byref(v)), "bgn_ctx_get_option(%s)" % name)
+        return int(v.value)
+
+    def reset_options(self) -> None:
+        check(self._lib.bgn_ctx_reset_options(self._h), "bgn_ctx_reset_options")
+
+    def options(self, **kw):
+        """Context manager: set the given options, restore their previous values on exit."""
+        eng = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.keep = {k: eng.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    eng.set_option(k, v)
+                return eng
+
+            def __exit__(self_, *exc):
+                for k, v in self_.keep.items():
+                    eng.set_option(k, v)
+                return False
+
+        return _Scope()
+
+    def force_kernel(self, kernel: Optional[str]) -> None:
+        """'coop', 'quad' or 'lane': every Mult / makeL2 / Decrypt / MultConst batch on that kernel family whatever
+        its size; None: back to the dispatch by batch size."""
+        names = ("coop_max", "coop_max_l2", "coop_max_dec", "quad_max", "quad_max_l2", "quad_max_dec", "quad_max_pow",
+                 "quad_max_mc", "quad_min")
+        if kernel is None:
+            for k in names:
+                self.set_option(k, -1)
+            return
+        if kernel not in ("coop", "quad", "lane"):
+            raise ValueError(kernel)
+        big = 1 << 40
+        self.set_option("quad_min", 0)
+        for k in names[:3]:
+            self.set_option(k, big if kernel == "coop" else 0)
+        for k in names[3:8]:
+            self.set_option(k, big if kernel == "quad" else 0)
+
+    def calibrate(self):
+        """bgn_ctx_calibrate: crossovers re-derived from timed probes on this device.  Returns
+        {'coop': [Mult, makeL2, lift, power], 'quad': [...]} in elements (-1: not calibrated)."""
+        out = (C.c_int64 * 8)()
+        check(self._lib.bgn_ctx_calibrate(self._h, out), "bgn_ctx_calibrate")
+        return {"coop": [int(v) for v in out[:4]], "quad": [int(v) for v in out[4:]]}
+
+    def combiner_stats(self):
+        out = (C.c_uint64 * 5)()
+        check(self._lib.bgn_ctx_combiner_stats(self._h, out), "bgn_ctx_combiner_stats")
+        return dict(zip(("calls", "rounds", "groups", "elements", "max_group"), (int(v) for v in out)))
+
     def last_kernel_ms(self) -> float:
         return float(self._lib.bgn_last_kernel_ms(self._h))
 
@@ -359,6 +420,9 @@ class MultiEngine:
 
     def setup_decryption(self, msg_space: int) -> None:
         check(self._lib.bgn_mctx_setup_decryption(self._h, int(msg_space)), "bgn_mctx_setup_decryption")
+
+    def set_option(self, name: str, value: int) -> None:
+        check(self._lib.bgn_mctx_set_option(self._h, name.encode(), int(value)), "bgn_mctx_set_option(%s)" % name)
 
     def _out(self, count: int) -> np.ndarray:
         return np.zeros((count, self.elem_bytes), dtype=np.uint8)

@@ -1,0 +1,255 @@
+// combiner.hpp — merges concurrent small host-buffer calls on one context into one launch.
+//
+// The reference's own call shape is one goroutine per coefficient pair, each calling pk.Mult / pk.MultConst on ONE
+// ciphertext (poly.go:139-153, :97-109; the benchmarks are one op per call, bgn_test.go:97-140; pk.mu, bgn.go:40,
+// guards only allocation).  Behind a single-element call the engine still pays a whole launch chain — 6.8 ms for a
+// 1024-bit Mult on the cooperative kernel, which does 256 pairings in the same 6.8 ms — and calls on one context
+// serialise on its workspace.  The combiner is a group commit: the first caller to arrive becomes the leader and
+// launches at once (a lone caller keeps its latency); callers that arrive while that launch is in flight queue up,
+// and the next leader takes everything queued, grouped by kind of call (operation, level, scalar lengths, blinded or
+// not), gathers each group's operands into one staging array, issues ONE upload, one launch chain per group on the
+// combiner's stream, ONE download, and hands every caller its slice and its status.  Results are those of the
+// batch entry points (every element of a batch is independent), so a combined call returns the bytes a lone call
+// would.  No timer is involved unless option combine_wait_us asks a lone leader to wait for company.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace bgn {
+
+enum CombineOp { COMB_ENCRYPT = 1, COMB_ADD, COMB_SUB, COMB_NEG, COMB_MULT, COMB_MAKE_L2, COMB_MULTCONST, COMB_DECRYPT };
+
+// The kind of a call: requests with equal keys are elements of one batch.  Plain data, compared bytewise.
+struct CombineKey {
+  int32_t op = 0;
+  int32_t level = 0;
+  uint32_t w_in[3] = {0, 0, 0};     // bytes per element of each input array; 0: the array is absent (null)
+  uint32_t w_out[2] = {0, 0};       // bytes per element of each output array
+  bool operator==(const CombineKey& o) const { return memcmp(this, &o, sizeof *this) == 0; }
+};
+
+struct CombineReq {
+  CombineKey key;
+  size_t count = 0;
+  const uint8_t* in[3] = {nullptr, nullptr, nullptr};
+  uint8_t* out[2] = {nullptr, nullptr};
+  int rc = 0;
+  std::string err;
+  bool done = false;
+};
+
+struct CombineStats {
+  uint64_t calls = 0, rounds = 0, groups = 0, elements = 0, max_group = 0;
+};
+
+struct Combiner {
+  // launch(key, n, dev_in, dev_out, stream): the `_dev` entry point of key.op over n elements; returns its status
+  // (and leaves the message in the thread's last error, which error_text() fetches)
+  typedef std::function<int(const CombineKey&, size_t, uint8_t* const*, uint8_t* const*, hipStream_t)> Launch;
+  Launch launch;
+  std::function<const char*()> error_text;
+  std::function<hipError_t(void**, size_t)> dev_alloc;     // the context's accounted allocator
+  std::function<void(void*)> dev_free;
+  int device = 0;
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<CombineReq*> queue;
+  bool leader_active = false;
+  CombineStats stats;
+
+  hipStream_t stream = nullptr;
+  uint8_t* h_stage = nullptr;      // page-locked: [inputs of every group | outputs of every group]
+  uint8_t* d_stage = nullptr;
+  size_t stage_cap = 0;
+
+  ~Combiner() {
+    if (stream) (void)hipStreamDestroy(stream);
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (d_stage && dev_free) dev_free(d_stage);
+  }
+
+  struct Group {
+    CombineKey key;
+    std::vector<CombineReq*> reqs;
+    size_t total = 0;
+    size_t in_off[3] = {0, 0, 0}, out_off[2] = {0, 0};
+  };
+
+  static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+  int ensure_stage(size_t bytes, std::string* err) {
+    if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+      stream = nullptr;
+      *err = "combiner: stream creation failed";
+      return -3;
+    }
+    if (bytes <= stage_cap) return 0;
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (d_stage) dev_free(d_stage);
+    h_stage = d_stage = nullptr;
+    stage_cap = 0;
+    const size_t want = align_up(bytes + bytes / 2 + 65536);
+    if (hipHostMalloc((void**)&h_stage, want, hipHostMallocDefault) != hipSuccess || dev_alloc((void**)&d_stage, want) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h_stage) (void)hipHostFree(h_stage);
+      h_stage = nullptr;
+      d_stage = nullptr;
+      *err = "combiner: staging buffers: device memory or the context's memory budget exhausted";
+      return -6;
+    }
+    stage_cap = want;
+    return 0;
+  }
+
+  // One round of the leader: everything that was queued, grouped by key (at most max_batch elements per group).
+  void run_round(std::vector<Group>& groups) {
+    size_t in_bytes = 0, out_bytes = 0;
+    for (Group& g : groups) {
+      for (int k = 0; k < 3; ++k)
+        if (g.key.w_in[k]) {
+          g.in_off[k] = in_bytes;
+          in_bytes += align_up(g.total * g.key.w_in[k]);
+        }
+    }
+    for (Group& g : groups)
+      for (int k = 0; k < 2; ++k)
+        if (g.key.w_out[k]) {
+          g.out_off[k] = in_bytes + out_bytes;
+          out_bytes += align_up(g.total * g.key.w_out[k]);
+        }
+    std::string err;
+    int rc = hipSetDevice(device) == hipSuccess ? 0 : -3;
+    if (rc) err = "combiner: hipSetDevice failed";
+    if (!rc) rc = ensure_stage(in_bytes + out_bytes, &err);
+    if (!rc) {
+      for (Group& g : groups)
+        for (int k = 0; k < 3; ++k) {
+          if (!g.key.w_in[k]) continue;
+          uint8_t* dst = h_stage + g.in_off[k];
+          for (CombineReq* r : g.reqs) {
+            const size_t b = r->count * g.key.w_in[k];
+            memcpy(dst, r->in[k], b);
+            dst += b;
+          }
+        }
+      if (hipMemcpyAsync(d_stage, h_stage, in_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+        rc = -3;
+        err = "combiner: upload failed";
+      }
+    }
+    if (rc) {
+      for (Group& g : groups)
+        for (CombineReq* r : g.reqs) {
+          r->rc = rc;
+          r->err = err;
+        }
+      return;
+    }
+    for (Group& g : groups) {
+      uint8_t* din[3] = {nullptr, nullptr, nullptr};
+      uint8_t* dout[2] = {nullptr, nullptr};
+      for (int k = 0; k < 3; ++k)
+        if (g.key.w_in[k]) din[k] = d_stage + g.in_off[k];
+      for (int k = 0; k < 2; ++k)
+        if (g.key.w_out[k]) dout[k] = d_stage + g.out_off[k];
+      const int grc = launch(g.key, g.total, din, dout, stream);
+      if (grc) {
+        const char* t = error_text ? error_text() : "";
+        for (CombineReq* r : g.reqs) {
+          r->rc = grc;
+          r->err = t ? t : "";
+        }
+      }
+    }
+    hipError_t e = hipMemcpyAsync(h_stage + in_bytes, d_stage + in_bytes, out_bytes, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    for (Group& g : groups) {
+      if (e != hipSuccess) {
+        for (CombineReq* r : g.reqs)
+          if (!r->rc) {
+            r->rc = -3;
+            r->err = std::string("combiner: ") + hipGetErrorString(e);
+          }
+        continue;
+      }
+      for (int k = 0; k < 2; ++k) {
+        if (!g.key.w_out[k]) continue;
+        const uint8_t* src = h_stage + g.out_off[k];
+        for (CombineReq* r : g.reqs) {
+          const size_t b = r->count * g.key.w_out[k];
+          if (!r->rc) memcpy(r->out[k], src, b);
+          src += b;
+        }
+      }
+    }
+  }
+
+  // Called by every host-buffer entry point whose call is small enough.  Returns the call's status; *err receives
+  // the message of a failure.
+  int submit(CombineReq& req, size_t max_batch, int64_t wait_us, std::string* err) {
+    std::unique_lock<std::mutex> lk(mu);
+    queue.push_back(&req);
+    stats.calls++;
+    while (!req.done) {
+      if (leader_active) {
+        cv.wait(lk);
+        continue;
+      }
+      leader_active = true;
+      if (wait_us > 0 && queue.size() == 1) {
+        // a lone leader may wait for company (off by default): the others queue up behind leader_active
+        lk.unlock();
+        std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
+        lk.lock();
+      }
+      std::vector<Group> groups;
+      for (auto it = queue.begin(); it != queue.end();) {
+        CombineReq* r = *it;
+        Group* g = nullptr;
+        for (Group& x : groups)
+          if (x.key == r->key) g = &x;
+        if (g && g->total + r->count > max_batch) {      // this kind is full for this round: the request waits for the next
+          ++it;
+          continue;
+        }
+        if (!g) {
+          groups.emplace_back();
+          g = &groups.back();
+          g->key = r->key;
+        }
+        g->reqs.push_back(r);
+        g->total += r->count;
+        it = queue.erase(it);
+      }
+      stats.rounds++;
+      stats.groups += groups.size();
+      for (const Group& g : groups) {
+        stats.elements += g.total;
+        if (g.total > stats.max_group) stats.max_group = g.total;
+      }
+      lk.unlock();
+      run_round(groups);
+      lk.lock();
+      for (Group& g : groups)
+        for (CombineReq* r : g.reqs) r->done = true;
+      leader_active = false;
+      cv.notify_all();
+    }
+    if (req.rc && err) *err = req.err;
+    return req.rc;
+  }
+};
+
+}  // namespace bgn

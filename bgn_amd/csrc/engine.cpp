@@ -24,6 +24,8 @@
 #include "consts.hpp"
 #include "coop/coop_api.hpp"
 #include "quad/quad_api.hpp"
+#include "options.hpp"
+#include "combiner.hpp"
 
 using namespace bgn;
 
@@ -52,6 +54,20 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // lane offsets inside a limb row are 32-bit byte offsets (gmem.hpp): at most 2^28 elements per call
 constexpr size_t kMaxBatch = (size_t)1 << 28;
 
+struct CombArr {
+  const void* p;
+  size_t w;
+};
+// A small host-buffer call joins the context's combiner (combiner.hpp); *taken = false: the caller stages by itself.
+int combine_call(bgn_ctx* c, int op, int level, size_t count, CombArr in0, CombArr in1, CombArr in2, CombArr out0,
+                 CombArr out1, bool* taken);
+#define COMBINE(op, level, count, i0, i1, i2, o0, o1)                                        \
+  {                                                                                          \
+    bool taken_ = false;                                                                     \
+    const int rc_ = combine_call(c, op, level, count, i0, i1, i2, o0, o1, &taken_);          \
+    if (taken_) return rc_;                                                                  \
+  }
+
 }  // namespace
 
 // Staging ring, streams and events of the chunked host-buffer pipeline (host_pipeline below): made on the first
@@ -79,8 +95,20 @@ struct HostPipeState {
   }
 };
 
+// Crossovers between the three pairing-kernel families, in elements per call; index = mode (0 Mult, 1 makeL2,
+// 2 Decrypt's lift, 3 Decrypt's power).  -1: the constants of the committed sweeps (coop_limit / quad_limit below);
+// bgn_ctx_calibrate replaces them by what two timed probes per kernel say on THIS device.
+struct Crossovers {
+  int64_t coop[4] = {-1, -1, -1, -1};
+  int64_t quad[4] = {-1, -1, -1, -1};
+};
+
 struct bgn_ctx {
   HostPipeState pipe;
+  Options opt;                         // the knobs of this context (options.hpp): environment at creation, then
+  Options opt_initial;                 // bgn_ctx_set_option; opt_initial: what bgn_ctx_reset_options goes back to
+  Crossovers xo;
+  Combiner* comb = nullptr;            // combiner of concurrent small host-buffer calls
   int device = 0;
   int L = 0;          // bytes per F_p value on the wire
   int nl = 0;         // limbs (LIMB_BITS bits each) per F_p value on the device
@@ -172,6 +200,8 @@ struct bgn_ctx {
 
 namespace {
 
+inline int64_t opt(const bgn_ctx* c, Options::V Options::*f) { return (c->opt.*f).load(std::memory_order_relaxed); }
+
 // Device memory of a context goes through these two: bgn_ctx_memory_bytes reports what it holds, and a budget
 // (bgn_ctx_set_memory_budget) is a hard cap — an allocation that would exceed it fails like an exhausted device,
 // and the tables that are sized "from the free memory" see no more than the budget leaves (ctx_free_memory).
@@ -248,10 +278,7 @@ void release_poly_tables(bgn_ctx* c) {
 
 // Divide every line of a per-key table by its c (fixedpair.hpp fixed_normalize_lane): one product less per
 // Miller step for every ciphertext paired with the key.  BGN_FIXED_NORMALIZE=0 keeps (a, b, c).
-bool fixed_normalize_enabled() {
-  const char* ev = getenv("BGN_FIXED_NORMALIZE");
-  return !(ev && ev[0] == '0');
-}
+bool fixed_normalize_enabled(const bgn_ctx* c) { return opt(c, &Options::fixed_normalize) != 0; }
 int normalize_key_table(bgn_ctx* c, uint32_t* tab, size_t steps) {
   uint32_t* pfx = nullptr;
   if (hipMalloc((void**)&pfx, steps * (size_t)c->nl * 4) != hipSuccess) return fail(BGN_E_NOMEM, "line-table scratch");
@@ -378,6 +405,8 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  delete c->comb;
+  c->comb = nullptr;
   c->pipe.release();
   if (c->arena) (void)ctx_free(c, c->arena);
   if (c->chain_ws) (void)ctx_free(c, c->chain_ws);
@@ -443,10 +472,9 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   c->nl = kt->nl;
   c->kt = kt;
   c->deterministic = deterministic != 0;
-  if (const char* ev = getenv("BGN_CTX_MEMORY_BUDGET_MB")) {          // default budget of every context (0: none)
-    const long long v = atoll(ev);
-    if (v > 0) c->mem_budget = (size_t)v << 20;
-  }
+  options_from_environment(c->opt);                  // the only read of the environment (options.hpp)
+  options_copy(c->opt_initial, c->opt);
+  if (opt(c, &Options::memory_budget_mb) > 0) c->mem_budget = (size_t)opt(c, &Options::memory_budget_mb) << 20;
 
   int rc = BGN_OK;
   do {
@@ -481,12 +509,11 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     pc.l = l;
     pc.l_bits = BigU(l).bits();
     {
-      // width-w NAF for the windowed Miller loop: BGN_MILLER_WINDOW = 3, 4, 5 (default 5), 0 = the plain NAF
-      const char* ev = getenv("BGN_MILLER_WINDOW");
-      int w = 5;
-      if (ev && ev[0] >= '3' && ev[0] <= '5') w = ev[0] - '0';
+      // width-w NAF for the windowed Miller loop: option miller_window = 3, 4, 5 (default 5), 0 = the plain NAF
+      const int64_t mw = opt(c, &Options::miller_window);
+      const int w = (mw >= 3 && mw <= 5) ? (int)mw : 5;
       std::vector<signed char> wn = n.wnaf(w);
-      if (!(ev && ev[0] == '0') && (int)wn.size() <= MAX_NAF && wn.size() >= 4) {
+      if (mw != 0 && (int)wn.size() <= MAX_NAF && wn.size() >= 4) {
         pc.wnaf_len = (int)wn.size();
         pc.wnaf_w = w;
         memcpy(pc.wnaf, wn.data(), wn.size());
@@ -516,7 +543,7 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
       c->miller_steps = steps;
       HIP_BRK(ctx_malloc(c, (void**)&c->d_fixedpair, steps * 3 * (size_t)c->nl * 4));
       kt->fixedpair_build(nullptr, c->d_params, c->d_consts, c->d_keypts, c->d_keypts + c->nl, c->d_fixedpair);
-      c->fixed_normalized = fixed_normalize_enabled();
+      c->fixed_normalized = fixed_normalize_enabled(c);
       if (c->fixed_normalized && (rc = normalize_key_table(c, c->d_fixedpair, steps)) != BGN_OK) break;
     }
     HIP_BRK(hipGetLastError());
@@ -554,8 +581,7 @@ int build_secret_order_table(bgn_ctx* c) {
   if (c->d_consts_sk) (void)ctx_wipe_free(c, c->d_consts_sk);
   c->d_fixedpair_sk = nullptr;
   c->d_consts_sk = nullptr;
-  if (const char* ev = getenv("BGN_DECRYPT_ORDER_TABLE"))
-    if (ev[0] == '0') return BGN_OK;
+  if (opt(c, &Options::decrypt_order_table) == 0) return BGN_OK;
   BigU q2, rem;
   BigU::divmod(c->n, c->q1, q2, rem);
   if (!rem.is_zero() || q2.bits() < 2 || !(q2.w[0] & 1u)) return BGN_OK;   // not a factor of n: generic path
@@ -603,6 +629,35 @@ int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes) {
   std::lock_guard<std::mutex> lk(c->mem_mu);
   c->mem_budget = (size_t)bytes;
   return BGN_OK;
+}
+
+int bgn_ctx_set_option(bgn_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return fail(BGN_E_ARG, "null argument");
+  const OptionDesc* d = option_find(name);
+  if (!d) return fail(BGN_E_ARG, "unknown option '%s'", name);
+  (c->opt.*(d->field)).store(value, std::memory_order_relaxed);
+  if (d->field == &Options::memory_budget_mb) return bgn_ctx_set_memory_budget(c, value > 0 ? (uint64_t)value << 20 : 0);
+  return BGN_OK;
+}
+
+int bgn_ctx_get_option(const bgn_ctx* c, const char* name, int64_t* value) {
+  if (!c || !name || !value) return fail(BGN_E_ARG, "null argument");
+  const OptionDesc* d = option_find(name);
+  if (!d) return fail(BGN_E_ARG, "unknown option '%s'", name);
+  *value = (c->opt.*(d->field)).load(std::memory_order_relaxed);
+  return BGN_OK;
+}
+
+int bgn_ctx_reset_options(bgn_ctx* c) {
+  if (!c) return fail(BGN_E_ARG, "null context");
+  options_copy(c->opt, c->opt_initial);
+  return BGN_OK;
+}
+
+const char* bgn_option_name(size_t index) {
+  size_t n = 0;
+  const OptionDesc* t = option_table(&n);
+  return index < n ? t[index].name : nullptr;
 }
 
 int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
@@ -671,9 +726,9 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
     if (ctx_free_memory(c, &free_b, old_table))
       while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > free_b / 3) cap_log2--;
   }
-  if (const char* ev = getenv("BGN_BSGS_MAX_LOG2")) {
-    const int v = atoi(ev);
-    if (v >= 4 && v <= 31) cap_log2 = v;
+  {
+    const int64_t v = opt(c, &Options::bsgs_max_log2);
+    if (v >= 4 && v <= 31) cap_log2 = (int)v;
   }
   while (S < Mmax + 1 && S < ((uint64_t)1 << cap_log2)) S <<= 1;
   // a probe resolves m = i*2S +- j with j in [0, S] (bsgs.hpp): giant steps are 2S apart, the last one
@@ -746,8 +801,8 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   bp.vtab = c->d_tabV;
   bp.key_keep = ~0ull;
   bp.check_keep = ~0u;
-  if (const char* ev = getenv("BGN_TEST_BSGS_FP_BITS")) {        // tests: a fingerprint of only this many bits
-    const int v = atoi(ev);
+  {
+    const int64_t v = opt(c, &Options::test_bsgs_fp_bits);       // tests: a fingerprint of only this many bits
     if (v >= 1 && v < 63) {
       bp.key_keep = (1ull << v) - 1;
       bp.check_keep = 0u;
@@ -774,14 +829,12 @@ int ensure_gt_table(bgn_ctx* c);
 // pairings per lane: one wave per SIMD on every CU first (65536 lanes), then lengthen the runs (measured best
 // at 16).  A lane runs for the whole kernel, so the lanes must fit ONE round of 65536: the run is the ceiling
 // of count / 65536 (a floor leaves a second, nearly empty round that doubles the kernel time).
-static int pairing_run(size_t count) {
+static int pairing_run(const bgn_ctx* c, size_t count) {
   size_t r = (count + 65535) / 65536;
   if (r < 1) r = 1;
   if (r > 16) r = 16;
-  if (const char* ev = getenv("BGN_PAIRING_RUN")) {     // tuning knob for experiments
-    const int v = atoi(ev);
-    if (v >= 1 && v <= 64) r = (size_t)v;
-  }
+  const int64_t v = opt(c, &Options::pairing_run);     // tuning knob for experiments
+  if (v >= 1 && v <= 64) r = (size_t)v;
   return (int)r;
 }
 
@@ -794,17 +847,14 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
 // finishes a pairing in a few milliseconds and runs one per CU (several with more workgroups resident).
 // The crossovers come from the committed sweep profiles/r02_small_batch.csv; BGN_COOP_MAX / BGN_COOP_MAX_L2
 // override them (0 disables the kernel).
-static bool coop_table_walk(const bgn_ctx* c) {
-  const char* ct = getenv("BGN_COOP_TABLE");
-  return c->fixed_normalized && !(ct && ct[0] == '0');
-}
+static bool coop_table_walk(const bgn_ctx* c) { return c->fixed_normalized && opt(c, &Options::coop_table) != 0; }
 
 static size_t quad_limit(const bgn_ctx* c);
 
 static size_t coop_limit(const bgn_ctx* c, int mode) {
   if (c->nl > 64) return 0;      // one limb per lane of a wave: no cooperative kernel beyond 64 limbs (2048-bit keys)
-  const char* ev = getenv(mode >= 2 ? "BGN_COOP_MAX_DEC" : mode == 1 ? "BGN_COOP_MAX_L2" : "BGN_COOP_MAX");
-  if (ev) return (size_t)strtoull(ev, nullptr, 10);
+  const int64_t ov = opt(c, mode >= 2 ? &Options::coop_max_dec : mode == 1 ? &Options::coop_max_l2 : &Options::coop_max);
+  if (ov >= 0) return (size_t)ov;
   const bool tw = coop_table_walk(c);
   // with the lane-group kernel's table walk and power above it (profiles/r03_mid_batch_table.csv, whole calls, 1024
   // bits: Decrypt of 1024 ciphertexts 7.1 ms cooperative against 7.6, of 2048 12.3 against 7.6; makeL2 of 1024 7.9
@@ -815,6 +865,7 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // bits, 4.5 ms at 512, whatever the batch below 65536); the cooperative kernel walks the same table in two or
   // three rounds per step (8192 lifts in 13 ms at 1024 bits, 8 ms at 512) — without the table walk it runs a whole
   // e(C, P) and wins only below ~2000 / ~800 ciphertexts
+  if (quad_tw && c->xo.coop[mode] >= 0) return (size_t)c->xo.coop[mode];        // bgn_ctx_calibrate
   if (mode == 2 || (mode == 3 && quad_tw)) {
     if (quad_tw) return c->nl >= 36 ? 1150 : c->nl >= 19 ? 900 : 512;
     return tw ? (c->nl >= 36 ? 14000 : c->nl >= 19 ? 4000 : 2048) : (c->nl >= 36 ? 2000 : c->nl >= 19 ? 800 : 512);
@@ -833,7 +884,7 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // Mult: with the lane-group kernel above it (profiles/r03_mid_batch.csv: 1024 pairs 17.8 ms cooperative against
   // 21.2 ms, 1536: 25.1 against 21.3 at 1024 bits; 512 bits: 1024 pairs 5.3 against 5.2 ms) the crossover is where
   // that kernel's one-round time is reached; without it, the lane kernel's (r02_small_batch.csv)
-  if (quad_limit(c)) return c->nl >= 36 ? 1280 : c->nl >= 19 ? 1000 : 800;
+  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 1280 : c->nl >= 19 ? 1000 : 800;
   return c->nl >= 36 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
@@ -847,19 +898,21 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
 // comes back here (lane_rounds_head).  BGN_QUAD_MAX overrides the upper end (0 disables the kernel), BGN_QUAD_MIN
 // the lower one.
 static size_t quad_limit(const bgn_ctx* c) {
-  if (const char* ev = getenv("BGN_QUAD_MAX")) return (size_t)strtoull(ev, nullptr, 10);
+  if (opt(c, &Options::quad_max) >= 0) return (size_t)opt(c, &Options::quad_max);
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
+  if (c->xo.quad[0] >= 0) return (size_t)c->xo.quad[0];                // bgn_ctx_calibrate
   return c->nl >= 36 ? 49000 : c->nl >= 19 ? 40000 : 32768;
 }
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
 // (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts
 // (profiles/r03_mid_batch_table.csv); BGN_QUAD_MAX_L2 / BGN_QUAD_MAX_DEC / BGN_QUAD_MAX_POW override, 0 disables.
 static size_t quad_table_limit(const bgn_ctx* c, int mode) {
-  const char* ev = getenv(mode == 3 ? "BGN_QUAD_MAX_POW" : mode == 2 ? "BGN_QUAD_MAX_DEC" : "BGN_QUAD_MAX_L2");
-  if (ev) return (size_t)strtoull(ev, nullptr, 10);
+  const int64_t ov = opt(c, mode == 3 ? &Options::quad_max_pow : mode == 2 ? &Options::quad_max_dec : &Options::quad_max_l2);
+  if (ov >= 0) return (size_t)ov;
   if (quad_ws_words(c->nl, 64) == 0 || !quad_limit(c)) return 0;
   if (c->nl > 40) return kMaxBatch;
+  if (c->xo.quad[mode] >= 0) return (size_t)c->xo.quad[mode];          // bgn_ctx_calibrate
   // profiles/r03_mid_batch_table.csv, whole calls at 1024 / 512 bits: Decrypt of 16384 ciphertexts 21.0 / 4.3 ms
   // against 36.6 / 6.9 on the lane kernels, of 32768 36.7 / 7.5 against 36.9 / 6.9; makeL2 of 32768 37.4 / 8.5 against
   // 53.2 / 10.6, of 65536 72.2 / 15.9 against 53.7 / 10.8
@@ -868,20 +921,20 @@ static size_t quad_table_limit(const bgn_ctx* c, int mode) {
 }
 
 static size_t quad_table_floor(const bgn_ctx* c, int mode) {
-  if (const char* ev = getenv("BGN_QUAD_MIN")) return (size_t)strtoull(ev, nullptr, 10);
+  if (opt(c, &Options::quad_min) >= 0) return (size_t)opt(c, &Options::quad_min);
   // an explicit cooperative limit alone keeps its A/B meaning (cooperative below it, lane kernel above)
-  if (getenv(mode == 3 || mode == 2 ? "BGN_COOP_MAX_DEC" : "BGN_COOP_MAX_L2") && !getenv("BGN_QUAD_MAX_L2") &&
-      !getenv("BGN_QUAD_MAX_DEC") && !getenv("BGN_QUAD_MAX_POW"))
+  if (opt(c, mode == 3 || mode == 2 ? &Options::coop_max_dec : &Options::coop_max_l2) >= 0 && opt(c, &Options::quad_max_l2) < 0 &&
+      opt(c, &Options::quad_max_dec) < 0 && opt(c, &Options::quad_max_pow) < 0)
     return (size_t)-1;
   return coop_limit(c, mode);
 }
 
 static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
   size_t lo = coop_max;
-  if (const char* ev = getenv("BGN_QUAD_MIN")) lo = (size_t)strtoull(ev, nullptr, 10);
-  // BGN_COOP_MAX alone keeps the meaning it had before this kernel existed (the A/B switch between the cooperative
+  if (opt(c, &Options::quad_min) >= 0) lo = (size_t)opt(c, &Options::quad_min);
+  // coop_max alone keeps the meaning it had before this kernel existed (the A/B switch between the cooperative
   // and the lane kernel: 0 = lane kernel always)
-  if (getenv("BGN_COOP_MAX") && !getenv("BGN_QUAD_MAX") && !getenv("BGN_QUAD_MIN")) return false;
+  if (opt(c, &Options::coop_max) >= 0 && opt(c, &Options::quad_max) < 0 && opt(c, &Options::quad_min) < 0) return false;
   const size_t hi = quad_limit(c);
   if (!hi || count <= lo || quad_ws_words(c->nl, 64) == 0) return false;
   return count <= hi;      // (a batch just above 65536 is cut into lane-kernel rounds and a remainder: lane_rounds_head)
@@ -897,8 +950,7 @@ static bool use_quad(const bgn_ctx* c, size_t count, size_t coop_max) {
 static size_t lane_rounds_head(const bgn_ctx* c, size_t n, int mode) {
   constexpr size_t kLanes = 65536, kFull = kLanes * 16;
   if (mode > 1 || n <= kLanes) return n;
-  if (const char* ev = getenv("BGN_SPLIT_ROUNDS"))
-    if (ev[0] == '0') return n;
+  if (opt(c, &Options::split_rounds) == 0) return n;
   // (a batch the lane-group kernel takes whole — every size at 72 limbs — is not cut)
   if (mode == 0 ? use_quad(c, n, coop_limit(c, 0))
                 : (coop_table_walk(c) && n > quad_table_floor(c, 1) && n <= quad_table_limit(c, 1)))
@@ -975,8 +1027,8 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
   HIP_TRY(hipEventRecord(c->ev0, s));
-  // BGN_COOP_FERMAT=1: the one-launch form with the Fermat inversion on the waves (A/B measurements)
-  const char* cf = getenv("BGN_COOP_FERMAT");
+  // coop_fermat=1: the one-launch form with the Fermat inversion on the waves (A/B measurements)
+  const bool cf = opt(c, &Options::coop_fermat) == 1;
   // makeL2 on the waves walks the key's normalised line table (6 / 4 products per step in 2 / 3 rounds instead of
   // a full pairing's 18 / 36 in 3 / 6); BGN_COOP_TABLE=0 keeps the general program
   const uint32_t* ctab = (mode == 1 && coop_table_walk(c)) ? c->d_fixedpair : nullptr;
@@ -984,10 +1036,10 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
                                   quad_tab ? c->d_fixedpair : nullptr)) {
     c->last_kernel = quad_pairing_kernel_name(c->nl);
   } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
-                                         (cf && cf[0] == '1') ? nullptr : ws, so, c->p_bits + 1, ctab)) {
+                                         cf ? nullptr : ws, so, c->p_bits + 1, ctab)) {
     c->last_kernel = coop_pairing_kernel_name(c->nl);
   } else {
-    kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(count), ws, so,
+    kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(c, count), ws, so,
                 (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : 0);
     c->last_kernel = kt->pairing_kernel_name;
   }
@@ -1077,7 +1129,10 @@ struct DevBuf {
 int bgn_mult_batch(bgn_ctx* c, size_t count, const uint8_t* a, const uint8_t* b, const uint8_t* r_be, size_t r_len,
                    uint8_t* out) {
   if (!c || (count && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (r_be && !r_len) return fail(BGN_E_ARG, "r_len == 0");
   if (!count) return BGN_OK;
+  COMBINE(COMB_MULT, 2, count, (CombArr{a, (size_t)2 * c->L}), (CombArr{b, (size_t)2 * c->L}), (CombArr{r_be, r_len}),
+          (CombArr{out, (size_t)2 * c->L}), (CombArr{nullptr, 0}));
   HIP_TRY(hipSetDevice(c->device));
   const size_t eb = (size_t)2 * c->L * count;
   DevBuf da, db, dout;
@@ -1101,6 +1156,8 @@ int bgn_mult_batch(bgn_ctx* c, size_t count, const uint8_t* a, const uint8_t* b,
 int bgn_make_l2_batch(bgn_ctx* c, size_t count, const uint8_t* a, uint8_t* out) {
   if (!c || (count && (!a || !out))) return fail(BGN_E_ARG, "null argument");
   if (!count) return BGN_OK;
+  COMBINE(COMB_MAKE_L2, 1, count, (CombArr{a, (size_t)2 * c->L}), (CombArr{nullptr, 0}), (CombArr{nullptr, 0}),
+          (CombArr{out, (size_t)2 * c->L}), (CombArr{nullptr, 0}));
   HIP_TRY(hipSetDevice(c->device));
   const size_t eb = (size_t)2 * c->L * count;
   DevBuf da, dout;
@@ -1164,17 +1221,17 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
   // per-element bases with scalars of 128 bits and more: 4-bit windows over a table of 1*B .. 15*B per element
   // (ops.hpp), 12 KB of scratch each (measured at 2^16 elements: 1.4x at 256 bits, 1.67x at 1024 bits, 0.9x at
   // 64 bits); BGN_G1_MUL_WINDOW=0 keeps the binary ladder
-  const char* ev = getenv("BGN_G1_MUL_WINDOW");
+  const bool fail_ws = opt(c, &Options::test_fail_mul_ws) != 0;
   const size_t per = (size_t)5 * c->nl * 16 * 4 + 16;
-  if (!(ev && ev[0] == '0') && B.stride != 1 && klen >= 16 && count * per <= ((size_t)24 << 30)) {
+  if (opt(c, &Options::g1_mul_window) != 0 && B.stride != 1 && klen >= 16 && count * per <= ((size_t)24 << 30)) {
     const size_t cap = round_up(count, 64), need = cap * per + 4096;
     bool ok = true;
-    if (need > c->mul_ws_bytes || getenv("BGN_TEST_FAIL_MUL_WS")) {
+    if (need > c->mul_ws_bytes || fail_ws) {
       // allocate the larger table first and free the old one only then; a failed hipMalloc leaves its error as
       // the thread's last error, which the callers' hipGetLastError() after the launches would report although
-      // the binary-ladder fallback ran: clear it.  BGN_TEST_FAIL_MUL_WS forces the failure (tests).
+      // the binary-ladder fallback ran: clear it.  Option test_fail_mul_ws forces the failure (tests).
       uint8_t* fresh = nullptr;
-      ok = !getenv("BGN_TEST_FAIL_MUL_WS") && ctx_malloc(c, (void**)&fresh, need) == hipSuccess;
+      ok = !fail_ws && ctx_malloc(c, (void**)&fresh, need) == hipSuccess;
       if (ok) {
         if (c->mul_ws) {
           (void)hipDeviceSynchronize();
@@ -1204,9 +1261,9 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
 // Must be called with c->mu held; uses the arena.
 int fixed_window_bits(bgn_ctx* c) {
   int wbits = 16;
-  if (const char* e = getenv("BGN_FIXED_WINDOW_BITS")) {
-    const int v = atoi(e);
-    if (v == 8 || v == 16) wbits = v;
+  {
+    const int64_t v = opt(c, &Options::fixed_window_bits);
+    if (v == 8 || v == 16) wbits = (int)v;
   }
   if (wbits == 16) {   // fall back to the small layout when the device is short of memory
     size_t fr = 0;
@@ -1224,9 +1281,9 @@ int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
   // (22-bit windows: 47 windows instead of 52 at a 1024-bit key, 60 GB; measured +7 % on Encrypt over 20 bits —
   // taken when a quarter of the free HBM holds the table, which the loop below checks)
   int wbits = wbits_p == 16 ? 22 : wbits_p;
-  if (const char* e = getenv("BGN_FIXED_WINDOW_BITS_Q")) {
-    const int v = atoi(e);
-    if (v >= 8 && v <= 22) wbits = v;
+  {
+    const int64_t v = opt(c, &Options::fixed_window_bits_q);
+    if (v >= 8 && v <= 22) wbits = (int)v;
   }
   if (wbits < wbits_p) wbits = wbits_p;
   while (wbits > wbits_p) {
@@ -1343,8 +1400,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
   const int wr = r_be ? (int)((r_len * 8 + wbq - 1) / wbq) : 0;
   const int steps = wx + wr;
   bool chains = steps >= 2 * kFixedChains;
-  if (const char* ev = getenv("BGN_FIXED_CHAINS"))
-    if (ev[0] == '1') chains = false;
+  if (opt(c, &Options::fixed_chains) == 1) chains = false;
   if (chains) {
     const size_t pitch = round_up(count, 64);
     const size_t slots = (size_t)kFixedChains * pitch;
@@ -1799,13 +1855,12 @@ struct PipeArray {
 constexpr int kPipeSlots = 3;
 constexpr size_t kPipeChunkBytes = (size_t)48 << 20;   // of the widest array, rounded down to whole rounds of 65536 lanes
 
-size_t pipe_chunk(const std::vector<PipeArray>& arrays, size_t count) {
+size_t pipe_chunk(const bgn_ctx* c, const std::vector<PipeArray>& arrays, size_t count) {
   size_t widest = 1;
   for (const PipeArray& a : arrays) widest = std::max(widest, a.stride);
   size_t chunk = kPipeChunkBytes / widest;
   chunk = chunk >= 65536 ? (chunk / 65536) * 65536 : 65536;     // 131072 elements (34 MB) at a 1024-bit key
-  const char* e = getenv("BGN_HOST_PIPE_CHUNK");                 // test hook: elements per chunk
-  if (e && atol(e) > 0) chunk = (size_t)atol(e);
+  if (opt(c, &Options::host_pipe_chunk) > 0) chunk = (size_t)opt(c, &Options::host_pipe_chunk);   // test hook: elements per chunk
   (void)count;
   return chunk;
 }
@@ -1816,7 +1871,7 @@ int host_pipeline(bgn_ctx* c, size_t count, const std::vector<PipeArray>& arrays
                   const std::function<int(size_t, uint8_t* const*, hipStream_t)>& op) {
   const size_t nchunks = (count + chunk - 1) / chunk;
   const size_t na = arrays.size();
-  const bool trace = getenv("BGN_HOST_PIPE_TRACE") != nullptr;
+  const bool trace = opt(c, &Options::host_pipe_trace) != 0;
   const auto t_begin = std::chrono::steady_clock::now();
   auto stamp = [&](const char* what, size_t k) {
     if (trace)
@@ -1958,9 +2013,8 @@ int host_pipeline(bgn_ctx* c, size_t count, const std::vector<PipeArray>& arrays
 }
 
 // A call is worth the pipeline from two full chunks on.  BGN_HOST_PIPE=0 keeps every call on the one-shot path.
-bool pipe_worthwhile(size_t count, size_t chunk) {
-  const char* e = getenv("BGN_HOST_PIPE");
-  if (e && e[0] == '0') return false;
+bool pipe_worthwhile(const bgn_ctx* c, size_t count, size_t chunk) {
+  if (opt(c, &Options::host_pipe) == 0) return false;
   return count >= 2 * chunk;
 }
 
@@ -1982,7 +2036,10 @@ int run_pipelined(bgn_ctx* c, size_t count, const std::vector<PipeArray>& arrays
 int bgn_encrypt_batch(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be, size_t r_len,
                       uint8_t* out) {
   if (!c || (count && (!x_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (!x_len || (r_be && !r_len)) return fail(BGN_E_ARG, "zero scalar length");
   if (!count) return BGN_OK;
+  COMBINE(COMB_ENCRYPT, 1, count, (CombArr{x_be, x_len}), (CombArr{r_be, r_len}), (CombArr{nullptr, 0}),
+          (CombArr{out, (size_t)2 * c->L}), (CombArr{nullptr, 0}));
   HIP_TRY(hipSetDevice(c->device));
   Staged S;
   S.bufs.reserve(4);
@@ -1998,15 +2055,19 @@ int bgn_encrypt_batch(bgn_ctx* c, size_t count, const uint8_t* x_be, size_t x_le
 static int addsub_host(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,
                        size_t r_len, uint8_t* out, bool subtract) {
   if (!c || (count && (!a || !b || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (r_be && !r_len) return fail(BGN_E_ARG, "r_len == 0");
   if (!count) return BGN_OK;
+  COMBINE(subtract ? COMB_SUB : COMB_ADD, level, count, (CombArr{a, (size_t)2 * c->L}), (CombArr{b, (size_t)2 * c->L}),
+          (CombArr{r_be, r_len}), (CombArr{out, (size_t)2 * c->L}), (CombArr{nullptr, 0}));
   HIP_TRY(hipSetDevice(c->device));
   const size_t eb = count * 2 * (size_t)c->L;
   {
     const size_t w = 2 * (size_t)c->L;
     std::vector<PipeArray> arrays = {{a, nullptr, w}, {b, nullptr, w}, {nullptr, out, w}};
     if (r_be) arrays.push_back({r_be, nullptr, r_len});
-    const size_t chunk = pipe_chunk(arrays, count);
-    if (pipe_worthwhile(count, chunk)) {
+    const size_t chunk = pipe_chunk(c, arrays, count);
+    if (pipe_worthwhile(c, count, chunk)) {
       bool ran = false;
       int rc = run_pipelined(c, count, arrays, chunk, [&](size_t n, uint8_t* const* d, hipStream_t s) {
         return addsub_dev(c, n, level, d[0], d[1], r_be ? d[3] : nullptr, r_len, d[2], s, subtract);
@@ -2035,14 +2096,17 @@ int bgn_sub_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, const u
 }
 int bgn_neg_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, uint8_t* out) {
   if (!c || (count && (!a || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
   if (!count) return BGN_OK;
+  COMBINE(COMB_NEG, level, count, (CombArr{a, (size_t)2 * c->L}), (CombArr{nullptr, 0}), (CombArr{nullptr, 0}),
+          (CombArr{out, (size_t)2 * c->L}), (CombArr{nullptr, 0}));
   HIP_TRY(hipSetDevice(c->device));
   const size_t eb = count * 2 * (size_t)c->L;
   {
     const size_t w = 2 * (size_t)c->L;
     std::vector<PipeArray> arrays = {{a, nullptr, w}, {nullptr, out, w}};
-    const size_t chunk = pipe_chunk(arrays, count);
-    if (pipe_worthwhile(count, chunk)) {
+    const size_t chunk = pipe_chunk(c, arrays, count);
+    if (pipe_worthwhile(c, count, chunk)) {
       bool ran = false;
       int rc = run_pipelined(c, count, arrays, chunk, [&](size_t n, uint8_t* const* d, hipStream_t s) {
         return bgn_neg_batch_dev(c, n, level, d[0], d[1], s);
@@ -2062,7 +2126,11 @@ int bgn_neg_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, uint8_t
 int bgn_multconst_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint8_t* k_be, size_t k_len,
                         const uint8_t* r_be, size_t r_len, uint8_t* out) {
   if (!c || (count && (!a || !k_be || !out))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!k_len || (r_be && !r_len)) return fail(BGN_E_ARG, "zero scalar length");
   if (!count) return BGN_OK;
+  COMBINE(COMB_MULTCONST, level, count, (CombArr{a, (size_t)2 * c->L}), (CombArr{k_be, k_len}), (CombArr{r_be, r_len}),
+          (CombArr{out, (size_t)2 * c->L}), (CombArr{nullptr, 0}));
   HIP_TRY(hipSetDevice(c->device));
   const size_t eb = count * 2 * (size_t)c->L;
   Staged S;
@@ -2085,8 +2153,7 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
 static size_t decrypt_rounds_head(const bgn_ctx* c, size_t n, int level) {
   constexpr size_t kLanes = 65536, kFull = kLanes * 16;
   if (n <= kLanes) return n;
-  if (const char* ev = getenv("BGN_SPLIT_ROUNDS"))
-    if (ev[0] == '0') return n;
+  if (opt(c, &Options::split_rounds) == 0) return n;
   if (level == 2) {
     // the power by the secret key: one element per lane, rounds of 65536; the cooperative and the lane-group kernel
     // take a remainder in their ranges (1024 bits: 66 000 level-2 Decrypts 21.4 -> 13 ms)
@@ -2170,7 +2237,7 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
       c->aux_kernel = coop_pairing_kernel_name(c->nl);
     } else {
       kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
-                  pairing_run(count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
+                  pairing_run(c, count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
       c->aux_kernel = c->nl == 37 ? "k_pairing<37, 1>" : c->nl == 36 ? "k_pairing<36, 1>" : c->nl == 19 ? "k_pairing<19, 1>"
                                     : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
     }
@@ -2182,8 +2249,7 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
   // csk.PowBig(ct.C, sk.Key), bgn.go:223.  Level-2 ciphertexts and the lift both have norm 1: the power runs
   // on the real part (two products per bit).  BGN_DECRYPT_LUCAS=0 selects square-and-multiply in F_p^2.
   {
-    const char* ev = getenv("BGN_DECRYPT_LUCAS");
-    if (ev && ev[0] == '0') {
+    if (opt(c, &Options::decrypt_lucas) == 0) {
       gt_pow_launch(c, s, base, c->d_sk, 0, c->sk_len, Y, count);
       kt->to_mont(s, c->d_params, Y.c0, Y.c1, Y.stride, count);
     } else if (count > quad_table_floor(c, 3) && count <= quad_table_limit(c, 3) &&
@@ -2220,7 +2286,12 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
 
 int bgn_decrypt_batch(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status) {
   if (!c || (count && (!ct || !m || !status))) return fail(BGN_E_ARG, "null argument");
+  if (level != 1 && level != 2) return fail(BGN_E_ARG, "level must be 1 or 2");
+  if (!c->have_secret) return fail(BGN_E_STATE, "secret key not set");
+  if (!c->have_tables) return fail(BGN_E_STATE, "DL tables not computed!");          // gsbs.go:56-58 (panic)
   if (!count) return BGN_OK;
+  COMBINE(COMB_DECRYPT, level, count, (CombArr{ct, (size_t)2 * c->L}), (CombArr{nullptr, 0}), (CombArr{nullptr, 0}),
+          (CombArr{m, 8}), (CombArr{status, 1}));
   HIP_TRY(hipSetDevice(c->device));
   Staged S;
   S.bufs.reserve(3);
@@ -2246,13 +2317,12 @@ int bgn_decrypt_batch(bgn_ctx* c, size_t count, int level, const uint8_t* ct, in
 // BGN_POLY_TABLE_MAX_MB caps the table size (tests use it to force several chunks).
 namespace {
 size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
-  if (const char* ev = getenv("BGN_POLY_TABLES"))
-    if (ev[0] == '0') return 0;
+  if (opt(c, &Options::poly_tables) == 0) return 0;
   size_t fr = 0;
   if (!ctx_free_memory(c, &fr, c->poly_tab_bytes)) return 0;   // the cached tables count as free
   size_t budget = fr / 3;
-  if (const char* ev = getenv("BGN_POLY_TABLE_MAX_MB")) {
-    const long v = atol(ev);
+  {
+    const int64_t v = opt(c, &Options::poly_table_max_mb);
     if (v > 0 && ((size_t)v << 20) < budget) budget = (size_t)v << 20;
   }
   const size_t per_coeff = c->miller_steps * 3 * (size_t)c->nl * 4;
@@ -2285,12 +2355,8 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   // Up to 65536 pairs the lane kernel pairs directly in ONE pairing's latency; a table round costs a table build (as
   // long as a pairing) plus the walks (1024 bits, 512 products of 16 x 16: 195 ms with tables).
   size_t kLanes = 65536;
-  if (const char* ev = getenv("BGN_POLY_ROUND")) {             // tests: the round size of this logic (not of the kernels)
-    const long v = atol(ev);
-    if (v > 0) kLanes = (size_t)v;
-  }
-  const char* force = getenv("BGN_POLY_TABLES");
-  const bool forced = force && force[0] == '1';                // tests: tables whatever the size
+  if (opt(c, &Options::poly_round) > 0) kLanes = (size_t)opt(c, &Options::poly_round);   // tests: the round size of this logic (not of the kernels)
+  const bool forced = opt(c, &Options::poly_tables) == 1;      // tests: tables whatever the size
   const bool one_round = total_pairs <= kLanes;
   size_t chunk = (forced || (!coop && !quad && !one_round)) && d1 * d2 >= 2 ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
   // One lane builds one table and runs for the whole kernel, so the time of the table path is a step function of the
@@ -2358,7 +2424,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     if (!direct) {
       const SoA2 T = tab_on_a ? Aq : Bq, V = tab_on_a ? Bq : Aq;
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);
-      kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(pairs), pws, sp,
+      kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(c, pairs), pws, sp,
                   tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
       tables_used = true;
     } else if (q_quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sw,
@@ -2368,7 +2434,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
                                              c->p_bits + 1)) {
       c->last_kernel = coop_pairing_kernel_name(c->nl);
     } else {
-      kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(pairs), pws, sw, nullptr, 0,
+      kt->pairing(s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pairing_run(c, pairs), pws, sw, nullptr, 0,
                   0);
       c->last_kernel = kt->pairing_kernel_name;
     }
@@ -2396,9 +2462,9 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
 // run two levels (leaves 4 x 4: one round of tables + a direct remainder, 451 ms) instead of three (two rounds,
 // 517 ms); 4096 products keep three.  BGN_POLY_LEVELS forces a count.
 static int poly_plan_levels(const bgn_ctx* c, size_t npoly, size_t d, int max_levels) {
-  if (const char* ev = getenv("BGN_POLY_LEVELS")) {
-    const int v = atoi(ev);
-    return v < 0 ? 0 : v > max_levels ? max_levels : v;
+  if (opt(c, &Options::poly_levels) >= 0) {
+    const int v = (int)opt(c, &Options::poly_levels);
+    return v > max_levels ? max_levels : v;
   }
   if (max_levels == 0) return 0;
   const double B = 129, W = 65, D = 160, kLanes = 65536.0;            // ms at 1024 bits; only the ratios matter
@@ -2452,8 +2518,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   HIP_TRY(hipSetDevice(c->device));
   int levels = 0;
   {
-    const char* ev = getenv("BGN_POLY_KARATSUBA");
-    if (d1 == d2 && !(ev && ev[0] == '0'))
+    if (d1 == d2 && opt(c, &Options::poly_karatsuba) != 0)
       for (size_t dk = d1; dk % 2 == 0 && dk >= 4; dk /= 2) levels++;
     levels = poly_plan_levels(c, npoly, d1, levels);
   }
@@ -2772,6 +2837,199 @@ int bgn_check_plaintext_knowledge_batch(bgn_ctx* c, size_t count, const uint8_t*
   int rc = bgn_check_plaintext_knowledge_batch_dev(c, count, dct, dn, dc, c_len, dd, dl_len, dok, nullptr);
   if (rc) return rc;
   return S.down(ok, dok, count);
+}
+
+// ---- the combiner of concurrent small host-buffer calls (combiner.hpp) -------------------------------------------
+namespace {
+int comb_launch(bgn_ctx* c, const CombineKey& k, size_t n, uint8_t* const* in, uint8_t* const* out, hipStream_t s) {
+  switch (k.op) {
+    case COMB_ENCRYPT: return bgn_encrypt_batch_dev(c, n, in[0], k.w_in[0], in[1], k.w_in[1], out[0], s);
+    case COMB_ADD: return addsub_dev(c, n, k.level, in[0], in[1], in[2], k.w_in[2], out[0], s, false);
+    case COMB_SUB: return addsub_dev(c, n, k.level, in[0], in[1], in[2], k.w_in[2], out[0], s, true);
+    case COMB_NEG: return bgn_neg_batch_dev(c, n, k.level, in[0], out[0], s);
+    case COMB_MULT: return bgn_mult_batch_dev(c, n, in[0], in[1], in[2], k.w_in[2], out[0], s);
+    case COMB_MAKE_L2: return bgn_make_l2_batch_dev(c, n, in[0], out[0], s);
+    case COMB_MULTCONST: return bgn_multconst_batch_dev(c, n, k.level, in[0], in[1], k.w_in[1], in[2], k.w_in[2], out[0], s);
+    case COMB_DECRYPT: return bgn_decrypt_batch_dev(c, n, k.level, in[0], (int64_t*)out[0], out[1], s);
+  }
+  return fail(BGN_E_ARG, "combiner: unknown operation");
+}
+
+Combiner* get_combiner(bgn_ctx* c) {
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  if (!c->comb) {
+    Combiner* cb = new (std::nothrow) Combiner();
+    if (!cb) return nullptr;
+    cb->device = c->device;
+    cb->launch = [c](const CombineKey& k, size_t n, uint8_t* const* in, uint8_t* const* out, hipStream_t s) {
+      return comb_launch(c, k, n, in, out, s);
+    };
+    cb->error_text = [] { return bgn_last_error(); };
+    cb->dev_alloc = [c](void** p, size_t b) { return ctx_malloc(c, p, b); };
+    cb->dev_free = [c](void* p) { (void)ctx_free(c, p); };
+    c->comb = cb;
+  }
+  return c->comb;
+}
+
+int combine_call(bgn_ctx* c, int op, int level, size_t count, CombArr in0, CombArr in1, CombArr in2, CombArr out0,
+                 CombArr out1, bool* taken) {
+  *taken = false;
+  if (opt(c, &Options::combine) == 0 || (int64_t)count > opt(c, &Options::combine_max_count)) return BGN_OK;
+  const CombArr ins[3] = {in0, in1, in2}, outs[2] = {out0, out1};
+  CombineReq req;
+  req.key.op = op;
+  req.key.level = level;
+  req.count = count;
+  for (int k = 0; k < 3; ++k)
+    if (ins[k].p) {
+      if (ins[k].w > 0xffffffffu) return BGN_OK;
+      req.key.w_in[k] = (uint32_t)ins[k].w;
+      req.in[k] = (const uint8_t*)ins[k].p;
+    }
+  for (int k = 0; k < 2; ++k)
+    if (outs[k].p) {
+      req.key.w_out[k] = (uint32_t)outs[k].w;
+      req.out[k] = (uint8_t*)const_cast<void*>(outs[k].p);
+    }
+  Combiner* cb = get_combiner(c);
+  if (!cb) return BGN_OK;
+  *taken = true;
+  int64_t cap = opt(c, &Options::combine_max_batch);
+  if (cap < (int64_t)count) cap = (int64_t)count;
+  std::string err;
+  const int rc = cb->submit(req, (size_t)cap, opt(c, &Options::combine_wait_us), &err);
+  if (rc) return fail(rc, "%s", err.c_str());
+  return BGN_OK;
+}
+}  // namespace
+
+// ---- calibration of the batch-size crossovers ----------------------------------------------------------------------
+// The three pairing-kernel families have different shapes of time against batch size: the cooperative kernel is
+// linear from a few hundred pairs on (one pairing per workgroup), the lane-group kernel has a floor (one wave per
+// SIMD at 4096 pairs) and is linear above it, the lane kernel costs one pairing's latency for anything up to 65536.
+// Two probes per linear kernel and one of the lane kernel give the two crossovers of an operation.
+namespace {
+struct SavedOptions {
+  bgn_ctx* c;
+  Options keep;
+  explicit SavedOptions(bgn_ctx* c_) : c(c_) { options_copy(keep, c->opt); }
+  ~SavedOptions() { options_copy(c->opt, keep); }
+};
+
+void force_family(bgn_ctx* c, int mode, int family /* 0 coop, 1 quad, 2 lane */) {
+  const int64_t big = (int64_t)1 << 40;
+  auto set = [&](Options::V Options::*f, int64_t v) { (c->opt.*f).store(v, std::memory_order_relaxed); };
+  set(&Options::quad_min, 0);
+  if (mode == 0) {
+    set(&Options::coop_max, family == 0 ? big : 0);
+    set(&Options::quad_max, family == 1 ? big : 0);
+  } else if (mode == 1) {
+    set(&Options::coop_max_l2, family == 0 ? big : 0);
+    set(&Options::quad_max_l2, family == 1 ? big : 0);
+  } else {
+    set(&Options::coop_max_dec, family == 0 ? big : 0);
+    set(&Options::quad_max_dec, family == 1 ? big : 0);
+    set(&Options::quad_max_pow, family == 1 ? big : 0);
+  }
+}
+}  // namespace
+
+int bgn_ctx_calibrate(bgn_ctx* c, int64_t out[8]) {
+  if (!c) return fail(BGN_E_ARG, "null context");
+  if (out)
+    for (int i = 0; i < 8; ++i) out[i] = -1;
+  if (c->nl > 40 || quad_ws_words(c->nl, 64) == 0 || !c->fixed_normalized) return BGN_OK;   // one family only: nothing to cross
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t N = 32768, eb = (size_t)2 * c->L;
+  DevBuf da, db, dout, dm, dst;
+  int rc;
+  if ((rc = da.alloc(N * eb)) || (rc = db.alloc(N * eb)) || (rc = dout.alloc(N * eb)) || (rc = dm.alloc(N * 8)) ||
+      (rc = dst.alloc(N)))
+    return rc;
+  {
+    std::vector<uint8_t> key(2 * eb), h(N * eb);
+    HIP_TRY(hipMemcpy(key.data(), c->d_keywire, 2 * eb, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i) memcpy(&h[i * eb], key.data(), eb);                   // a[i] = P
+    HIP_TRY(hipMemcpy(da.p, h.data(), N * eb, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < N; ++i) memcpy(&h[i * eb], key.data() + eb, eb);              // b[i] = Q
+    HIP_TRY(hipMemcpy(db.p, h.data(), N * eb, hipMemcpyHostToDevice));
+  }
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const uint8_t* a = (const uint8_t*)da.p;
+  const uint8_t* b = (const uint8_t*)db.p;
+  uint8_t* o = (uint8_t*)dout.p;
+  auto run = [&](int mode, size_t n) -> int {
+    if (mode == 0) return bgn_mult_batch_dev(c, n, a, b, nullptr, 0, o, s);
+    if (mode == 1) return bgn_make_l2_batch_dev(c, n, a, o, s);
+    return bgn_decrypt_batch_dev(c, n, 1, a, (int64_t*)dm.p, (uint8_t*)dst.p, s);
+  };
+  int err = BGN_OK;
+  auto time_ms = [&](int mode, int family, size_t n) -> double {
+    force_family(c, mode, family);
+    double best = 1e30;
+    for (int rep = 0; rep < 3 && !err; ++rep) {           // the first run also grows the workspace
+      const auto t0 = std::chrono::steady_clock::now();
+      err = run(mode, n);
+      if (!err && hipStreamSynchronize(s) != hipSuccess) err = fail(BGN_E_HIP, "calibration run failed");
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (rep && ms < best) best = ms;
+    }
+    return best;
+  };
+  Crossovers xo;
+  {
+    SavedOptions keep(c);
+    const int modes = (c->have_secret && c->have_tables) ? 3 : 2;
+    for (int mode = 0; mode < modes && !err; ++mode) {
+      const double c1 = time_ms(mode, 0, 256), c2 = time_ms(mode, 0, 1024);
+      const double q1 = time_ms(mode, 1, 4096), q2 = time_ms(mode, 1, 16384), q3 = time_ms(mode, 1, 32768);
+      const double ln = time_ms(mode, 2, 4096);
+      if (err) break;
+      const double sc = (c2 - c1) / 768.0, ic = c1 - sc * 256.0;               // cooperative: ic + sc * n
+      const double sq = (q3 - q2) / 16384.0, iq = q2 - sq * 16384.0;           // lane groups above their floor: iq + sq * n
+      int64_t xc = sc > 0 ? (int64_t)((q1 - ic) / sc) : 4096;
+      int64_t xq = sq > 0 ? (int64_t)((ln - iq) / sq) : 65536;
+      if (xc < 64) xc = 64;
+      if (xc > 4096) xc = 4096;                    // the floor q1 was measured at 4096 pairs
+      if (xq < xc) xq = xc;
+      if (xq > 65536) xq = 65536;                  // from 65537 on the batch is cut into rounds anyway
+      xo.coop[mode] = xc;
+      xo.quad[mode] = xq;
+      if (mode == 2) {
+        xo.coop[3] = xc;
+        xo.quad[3] = xq;
+      }
+    }
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipStreamDestroy(s);
+  if (err) return err;
+  c->xo = xo;
+  if (out)
+    for (int i = 0; i < 4; ++i) {
+      out[i] = xo.coop[i];
+      out[4 + i] = xo.quad[i];
+    }
+  return BGN_OK;
+}
+
+// Counters of the context's combiner since its creation: host-buffer calls taken, leader rounds, launch groups,
+// elements, the largest group.
+int bgn_ctx_combiner_stats(bgn_ctx* c, uint64_t out[5]) {
+  if (!c || !out) return fail(BGN_E_ARG, "null argument");
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  Combiner* cb = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    cb = c->comb;
+  }
+  if (!cb) return BGN_OK;
+  std::lock_guard<std::mutex> lk(cb->mu);
+  out[0] = cb->stats.calls; out[1] = cb->stats.rounds; out[2] = cb->stats.groups; out[3] = cb->stats.elements;
+  out[4] = cb->stats.max_group;
+  return BGN_OK;
 }
 
 // Field arithmetic on its own, for the parity tests: xy holds count elements x||y

@@ -83,11 +83,13 @@ int run_sharded(bgn_mctx* m, size_t units, const std::function<int(int, size_t, 
   return BGN_OK;
 }
 
-// BGN_MCTX_FORCE_STAGING=1 sends every shard through the peer-copy path even on the root device (a device to
-// itself is an ordinary copy): the staging code can then be tested on a one-GPU box.
+// Option mctx_force_staging = 1 (bgn_mctx_set_option; BGN_MCTX_FORCE_STAGING when the contexts are created) sends
+// every shard through the peer-copy path even on the root device (a device to itself is an ordinary copy): the
+// staging code can then be tested on a one-GPU box.
 bool on_root(const bgn_mctx* m, int i, int root) {
-  const char* e = getenv("BGN_MCTX_FORCE_STAGING");
-  return m->dev[i] == root && !(e && e[0] == '1');
+  int64_t force = 0;
+  (void)bgn_ctx_get_option(m->ctx[i], "mctx_force_staging", &force);
+  return m->dev[i] == root && force != 1;
 }
 
 // The calling thread's current HIP device, put back when an entry point that switches devices returns (a caller
@@ -229,6 +231,15 @@ bgn_ctx* bgn_mctx_ctx(bgn_mctx* m, int i) { return (m && i >= 0 && i < (int)m->c
 int bgn_mctx_set_secret(bgn_mctx* m, const uint8_t* q1_be, size_t q1_len) {
   if (!m) return mfail(BGN_E_ARG, "null context");
   return run_sharded(m, m->ctx.size(), [&](int i, size_t, size_t) { return bgn_ctx_set_secret(m->ctx[i], q1_be, q1_len); });
+}
+
+int bgn_mctx_set_option(bgn_mctx* m, const char* name, int64_t value) {
+  if (!m) return mfail(BGN_E_ARG, "null context");
+  for (bgn_ctx* c : m->ctx) {
+    const int rc = bgn_ctx_set_option(c, name, value);
+    if (rc) return rc;
+  }
+  return BGN_OK;
 }
 
 int bgn_mctx_setup_decryption(bgn_mctx* m, uint64_t msg_space) {

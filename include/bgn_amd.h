@@ -27,8 +27,9 @@
  *     NULL = default stream), enqueue work and return without synchronising.
  *   - The caller owns every buffer; the engine keeps no pointer after return
  *     (cgo pointer rules).  A context is immutable after setup and may be used
- *     from many threads; concurrent calls on one context serialise on its
- *     internal workspace (the reference serialises on pk.mu, bgn.go:40).
+ *     from many threads; concurrent `_dev` calls on one context serialise on its
+ *     internal workspace (the reference serialises on pk.mu, bgn.go:40), concurrent
+ *     small host-buffer calls are merged into one launch (bgn_ctx_combiner_stats).
  *   - `_dev` calls use the context's workspace.  Calls on one context are
  *     ordered by the engine: a call issued on another stream than the previous
  *     one waits on the device for that call's work before touching the
@@ -94,6 +95,41 @@ const char* bgn_version(void);
  * windows and 7.8 GB of workspace per 2^20-element batch without one). */
 uint64_t bgn_ctx_memory_bytes(bgn_ctx* c);
 int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes);
+
+/* Options: the named integer knobs of a context — kernel crossovers by batch size, table shapes, the A/B
+ * alternatives of DESIGN.md section 11, the combiner's limits.  The library reads the environment ONCE, inside
+ * bgn_ctx_create (BGN_<NAME IN UPPER CASE> for every option that is not a test hook), into the new context's own
+ * copy; no other entry point calls getenv, so a host that changes its environment concurrently (os.Setenv in a Go
+ * process) cannot race the library, and two contexts of one process may run different settings side by side.
+ * bgn_ctx_set_option takes effect from the next call on (options read only while a table is built — miller_window,
+ * fixed_normalize at creation; decrypt_order_table by bgn_ctx_set_secret; bsgs_max_log2 by bgn_ctx_setup_decryption;
+ * fixed_window_bits* on first Encrypt — must be in place before that step).  bgn_ctx_reset_options goes back to
+ * the values the context was created with.  bgn_option_name(i) enumerates the names (null past the end).
+ * Unknown name: BGN_E_ARG.  There is no counterpart in the reference (PBC has no tunables on this path); the
+ * nearest is the package-level state of gsbs.go:12-15. */
+int bgn_ctx_set_option(bgn_ctx* ctx, const char* name, int64_t value);
+int bgn_ctx_get_option(const bgn_ctx* ctx, const char* name, int64_t* value);
+int bgn_ctx_reset_options(bgn_ctx* ctx);
+const char* bgn_option_name(size_t index);
+
+/* Re-derive the batch-size crossovers between the three pairing-kernel families (one pairing per workgroup / per
+ * sixteen lanes / per lane) for Mult, makeL2 and — when a secret key is installed — Decrypt's lift and power from
+ * timed probes on THIS device: two sizes on the cooperative kernel, two on the lane-group kernel, one round of the
+ * lane kernel per operation (about a second at a 1024-bit key).  Without it the context uses the constants of the
+ * committed sweeps (profiles/r03_mid_batch*.csv); boxes of one pool differ by several percent.  Explicit options
+ * (coop_max, quad_max, ...) still take precedence.  out, when non-null, receives the eight crossovers in elements:
+ * cooperative up to out[0..3], lane-group up to out[4..7] for Mult, makeL2, lift, power (-1: not calibrated). */
+int bgn_ctx_calibrate(bgn_ctx* ctx, int64_t out[8]);
+
+/* Concurrent small calls.  The reference runs one goroutine per coefficient pair, each calling Mult / MultConst
+ * on ONE ciphertext (poly.go:139-153, :97-109; pk.mu, bgn.go:40, guards only allocation).  Host-buffer calls of at
+ * most `combine_max_count` elements (default 1024) therefore go through a per-context combiner: the first caller
+ * launches at once; callers arriving while a launch is in flight are merged per kind of call (operation, level,
+ * scalar lengths, blinded or not) into ONE batch of up to `combine_max_batch` elements (default 16384), launched once,
+ * and every caller gets its slice and its status.  A lone caller never waits (option combine_wait_us > 0 makes a
+ * lone leader wait that long for company; combine = 0 turns the combiner off).  Results are byte-identical to
+ * separate calls.  bgn_ctx_combiner_stats: calls taken, leader rounds, launch groups, elements, largest group. */
+int bgn_ctx_combiner_stats(bgn_ctx* ctx, uint64_t out[5]);
 
 /* Install the secret key q1 (SecretKey.Key, bgn.go:59) for decryption. */
 int bgn_ctx_set_secret(bgn_ctx* ctx, const uint8_t* q1_be, size_t q1_len);
@@ -253,6 +289,8 @@ bgn_ctx* bgn_mctx_ctx(bgn_mctx* m, int i);
 /* bgn_ctx_set_secret / bgn_ctx_setup_decryption on every device (in parallel). */
 int bgn_mctx_set_secret(bgn_mctx* m, const uint8_t* q1_be, size_t q1_len);
 int bgn_mctx_setup_decryption(bgn_mctx* m, uint64_t msg_space);
+/* bgn_ctx_set_option on every device's context. */
+int bgn_mctx_set_option(bgn_mctx* m, const char* name, int64_t value);
 
 /* Host buffers; arguments as the single-device calls (Encrypt bgn.go:325-353, Add :442-497, Sub :375-433,
  * Mult :294-314, makeL2 :316-321, MultConst :253-291, Decrypt :205-250, MultPoly poly.go:123-156). */

@@ -45,6 +45,7 @@ typedef struct {
   u64 sk[MAXW];
   int sk_bits;
   int have_sk;
+  int have_g1_table;  /* 0 after orc_setup_decryption_gt (bench.py's Decrypt leg at T = 2^40) */
   /* BSGS tables (gsbs.go:12-13), open addressing on a 64-bit key */
   u64 T, B;
   u64 tabsize;        /* power of two */
@@ -618,7 +619,14 @@ int orc_set_secret(octx* c, const uint8_t* q1, size_t len) {
   return 0;
 }
 /* SetupDecryption + PrecomputeTables (bgn.go:195-201, gsbs.go:17-51): gen^(j+1) -> j, j = 0..bound */
-int orc_setup_decryption(octx* c, u64 T) {
+static int setup_tables(octx* c, u64 T, int with_g1);
+int orc_setup_decryption(octx* c, u64 T) { return setup_tables(c, T, 1); }
+/* The GT table alone: the G1 table of gsbs.go:17-26 costs one field inversion per entry (2^20 + 2 entries at
+ * T = 2^40), which this plain-C port pays with a Fermat power; bench.py's bounded CPU leg for Decrypt runs the
+ * reference's level-2 getDL on lifted ciphertexts and needs only computeTableGT (gsbs.go:28-37).  Level-1
+ * orc_decrypt returns -1 afterwards. */
+int orc_setup_decryption_gt(octx* c, u64 T) { return setup_tables(c, T, 0); }
+static int setup_tables(octx* c, u64 T, int with_g1) {
   if (!c->have_sk) return -1;
   const int W = c->W;
   c->T = T;
@@ -645,7 +653,8 @@ int orc_setup_decryption(octx* c, u64 T) {
   memcpy(c->gt1, gt.b, sizeof gt.b);
   /* G1 table: projective running sum, affine via one inversion each (small tables only in tests) */
   apt aux = g1;
-  for (u64 j = 0; j <= bound; ++j) {                /* gsbs.go:22-25 */
+  c->have_g1_table = with_g1;
+  for (u64 j = 0; with_g1 && j <= bound; ++j) {     /* gsbs.go:22-25 */
     tab_put(c, c->key1, c->full1, c->val1, aux.x, aux.y, (int32_t)j);
     apt_add(c, &aux, &aux, &g1);
   }
@@ -697,6 +706,7 @@ static int get_dl(const octx* c, int level, const apt* csk1, const f2* csk2, int
 /* decrypt (bgn.go:218-250) with recoverMessage (bgn.go:357-372): status 0 ok, 1 = error */
 int orc_decrypt(const octx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status) {
   if (!c->have_sk || !c->tabsize) return -1;
+  if (level == 1 && !c->have_g1_table) return -1;
   const size_t E = 2 * (size_t)c->L;
   for (size_t i = 0; i < count; ++i) {
     m[i] = 0;

@@ -35,6 +35,7 @@ def _load():
         lib.orc_multconst.argtypes = [vp, sz, C.c_int, vp, vp, sz, vp]
         lib.orc_set_secret.argtypes = [vp, vp, sz]
         lib.orc_setup_decryption.argtypes = [vp, u64]
+        lib.orc_setup_decryption_gt.argtypes = [vp, u64]
         lib.orc_decrypt.argtypes = [vp, sz, C.c_int, vp, vp, vp]
         lib.orc_poly_mult.argtypes = [vp, sz, sz, sz, vp, vp, vp]
         _lib = lib
@@ -108,6 +109,15 @@ class Oracle:
         if rc:
             raise RuntimeError(f"orc_setup_decryption -> {rc}")
 
+    def setup_decryption_gt(self, q1: int, T: int) -> None:
+        """The GT table only (computeTableGT, gsbs.go:28-37): level-2 decrypt at message spaces whose G1 table this
+        port cannot build in bounded time (one Fermat inversion per entry)."""
+        qb = _ib(q1)
+        self.lib.orc_set_secret(self.h, qb, len(qb))
+        rc = self.lib.orc_setup_decryption_gt(self.h, T)
+        if rc:
+            raise RuntimeError(f"orc_setup_decryption_gt -> {rc}")
+
     def decrypt(self, level: int, ct: bytes):
         n = len(ct) // self.E
         m = (C.c_int64 * n)()
@@ -162,3 +172,51 @@ def bench_pairings(fx, a_host: bytes, b_host: bytes, gpu_out_host: bytes, second
                       f"(64-bit limbs, unsigned __int128 CIOS Montgomery, projective Miller loop), "
                       f"{cores} threads x {per_thread} pairings, {dt:.1f} s",
             "matches_gpu_bit_exact": bool(ok)}
+
+
+def bench_decrypt(fx, ct_host: bytes, want_m, want_status, T: int, max_threads: int = 32) -> dict:
+    """bench.py's CPU leg for the second half of BASELINE's metric (BSGS decrypts/s): a bounded sample of the GPU's own
+    mixed batch (positives, negatives, out-of-range) decrypted by the reference's algorithm on the host cores.
+
+    The reference decrypts a level-1 ciphertext with a G1 walk (gsbs.go:77-103: one affine subtraction, i.e. one
+    field inversion, per giant step, up to 2^20 of them at T = 2^40) — minutes per ciphertext in this plain-C port.
+    The leg therefore takes the route that FAVOURS the CPU: lift each sampled ciphertext to level 2 (makeL2 =
+    Pair(c, P), bgn.go:316-321, one pairing) and run the reference's level-2 decrypt (power by the secret key, GT
+    giant steps of one F_p^2 product each, negative retry, bgn.go:225-242) — the same lift the GPU path makes.  One
+    thread per sampled ciphertext over a shared table (read-only); the table build (computeTableGT, 2^20 + 2
+    entries) is timed separately, like SetupDecryption on the GPU side."""
+    orc = Oracle.from_fixture(fx)
+    E = orc.E
+    n = len(ct_host) // E
+    t0 = time.time()
+    orc.setup_decryption_gt(int(fx["q1"], 16), T)
+    t_setup = time.time() - t0
+    threads = max(1, min(n, max_threads))
+    per = (n + threads - 1) // threads
+    res = [None] * threads
+
+    def work(i):
+        lo, hi = i * per, min(n, (i + 1) * per)
+        if lo >= hi:
+            res[i] = ([], [])
+            return
+        l2 = orc.mult(ct_host[lo * E:hi * E])           # makeL2
+        res[i] = orc.decrypt(2, l2)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    m = [v for r in res for v in r[0]]
+    st = [v for r in res for v in r[1]]
+    ok = m == [int(v) for v in want_m] and st == [int(v) for v in want_status]
+    return {"value": n / dt, "unit": "decrypts/s", "cores": threads, "kind": "port",
+            "sample": f"{n} ciphertexts strided over the GPU's mixed batch ({sum(1 for v in want_m if v < 0)} negative, "
+                      f"{sum(1 for v in want_status if v)} out of range), lifted to level 2 (one pairing) and decrypted by "
+                      f"the reference's level-2 getDL (up to {int(-(-T ** 0.5 // 1))} GT giant steps) in oracle/bgn_oracle.c — cheaper than "
+                      f"the reference's own level-1 G1 walk; {threads} threads, {dt:.1f} s; table build "
+                      f"{t_setup:.1f} s not included",
+            "table_setup_s": t_setup, "matches_gpu_exact": bool(ok)}

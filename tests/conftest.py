@@ -44,6 +44,17 @@ def oracle_key(fx):
 
 
 _ENGINES = {}
+_PENDING = {}        # options of the running test (engopts below): applied to every engine the test looks up
+
+
+def _option_name(name):
+    return name[4:].lower() if name.startswith("BGN_") else name
+
+
+def _apply_pending(eng):
+    eng.reset_options()
+    for k, v in _PENDING.items():
+        eng.set_option(k, v)
 
 
 def engine_key(fx):
@@ -55,4 +66,62 @@ def engine_key(fx):
                                bytes.fromhex(fx["Q"]), fx["msg_space"], True, fx["poly_base"])
         sk = bgn_amd.SecretKey(int(fx["q1"], 16))
         _ENGINES[name] = (pk, sk)
+    _apply_pending(_ENGINES[name][0].engine)
     return _ENGINES[name]
+
+
+class EngineOptions:
+    """What a test uses to select kernels and alternatives: every setting goes through bgn_ctx_set_option
+    (include/bgn_amd.h) on the engines of the session — those that exist and those the test looks up later — and is
+    taken back when the test ends.  The library does not read the environment after a context exists."""
+
+    def __init__(self):
+        self.extra = []
+
+    def _engines(self):
+        return [pk.engine for pk, _ in _ENGINES.values()] + self.extra
+
+    def register(self, eng):
+        """An engine the test created itself."""
+        self.extra.append(eng)
+        for k, v in _PENDING.items():
+            eng.set_option(k, v)
+        return eng
+
+    def set(self, name, value):
+        _PENDING[_option_name(name)] = int(value)
+        for e in self._engines():
+            e.set_option(_option_name(name), int(value))
+
+    def unset(self, name):
+        _PENDING.pop(_option_name(name), None)
+        for e in self._engines():
+            _apply_pending(e)
+
+    def force(self, kernel):
+        """'coop', 'quad' or 'lane' for every batch size of every operation; None: dispatch by size."""
+        names = ("coop_max", "coop_max_l2", "coop_max_dec", "quad_max", "quad_max_l2", "quad_max_dec", "quad_max_pow",
+                 "quad_max_mc", "quad_min")
+        if kernel is None:
+            for k in names:
+                self.unset(k)
+            return
+        big = 1 << 40
+        self.set("quad_min", 0)
+        for k in names[:3]:
+            self.set(k, big if kernel == "coop" else 0)
+        for k in names[3:8]:
+            self.set(k, big if kernel == "quad" else 0)
+
+
+@pytest.fixture
+def engopts():
+    _PENDING.clear()
+    o = EngineOptions()
+    yield o
+    _PENDING.clear()
+    for e in o._engines():
+        try:
+            e.reset_options()
+        except Exception:
+            pass

@@ -78,3 +78,35 @@ def test_host_mirror_refuses_device_arrays_shorter_than_the_call_needs():
     with pytest.raises(ValueError, match="CUDA tensor"):
         Engine._need("a", torch.empty(8, dtype=torch.uint8), 8)
     Engine._need("r", None, 100)                      # optional operands
+
+
+def test_options_are_named_and_the_library_reads_no_environment_per_call():
+    """The options surface (bgn_ctx_set_option): every name of csrc/options.hpp is enumerable through the ABI, a
+    null context or an unknown option is BGN_E_ARG — and the host sources call getenv in exactly one place, the
+    parse of the environment when a context is created (options_from_environment)."""
+    from bgn_amd import _lib
+    lib = _lib.load()
+    names = []
+    while True:
+        n = lib.bgn_option_name(len(names))
+        if not n:
+            break
+        names.append(n.decode())
+    assert len(names) == len(set(names)) >= 30
+    for must in ("coop_max", "quad_max", "quad_min", "split_rounds", "combine", "combine_max_count", "test_bsgs_fp_bits"):
+        assert must in names
+    v = ctypes.c_int64()
+    assert lib.bgn_ctx_set_option(None, b"coop_max", 1) == -1
+    assert lib.bgn_ctx_get_option(None, b"coop_max", ctypes.byref(v)) == -1
+    csrc = os.path.join(ROOT, "bgn_amd", "csrc")
+    hits = {}
+    for fn in os.listdir(csrc):
+        if fn.endswith((".cpp", ".hpp", ".hip")):
+            c = len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, fn)).read()))
+            if c:
+                hits[fn] = c
+    assert hits == {"options.hpp": 1}, hits
+    src = open(os.path.join(csrc, "options.hpp")).read()
+    for n in names:                                    # test hooks are not reachable from the environment
+        m = re.search(r'\{"%s", &Options::%s, (true|false)' % (n, n), src)
+        assert m and (m.group(1) == "false") == n.startswith("test_"), n

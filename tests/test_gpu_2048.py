@@ -51,13 +51,13 @@ def test_encrypt_add_multconst_golden(key):
 
 
 @pytest.mark.parametrize("kernel", ["quad", "lane"])
-def test_mult_and_make_l2_golden(key, kernel, monkeypatch):
+def test_mult_and_make_l2_golden(key, kernel, engopts):
     fx, pk, _ = key
     eng = pk.engine
     big = "100000000"
-    monkeypatch.setenv("BGN_QUAD_MIN", "0")
-    for v in ("BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
-        monkeypatch.setenv(v, big if kernel == "quad" else "0")
+    engopts.set("quad_min", "0")
+    for v in ("quad_max", "quad_max_l2", "quad_max_dec", "quad_max_pow"):
+        engopts.set(v, big if kernel == "quad" else "0")
     ct = [e["ct"] for e in fx["encrypt"]]
     out = eng.mult(H([ct[v["a"]] for v in fx["mult"]]), H([ct[v["b"]] for v in fx["mult"]]))
     assert ("quad" in eng.last_kernel_name()) == (kernel == "quad")

@@ -1,6 +1,6 @@
 """GPU: the wave-cooperative small-batch pairing kernel (bgn_amd/csrc/coop/) against the golden vectors, the
-one-pairing-per-lane kernel and the C oracle.  The engine picks the kernel by batch size (BGN_COOP_MAX /
-BGN_COOP_MAX_L2 override the crossovers; 0 disables the cooperative kernel), so both kernels are driven through
+one-pairing-per-lane kernel and the C oracle.  The engine picks the kernel by batch size (options coop_max /
+coop_max_l2 override the crossovers; 0 disables the cooperative kernel), so both kernels are driven through
 the same C-ABI calls here."""
 import random
 
@@ -19,10 +19,10 @@ def H(hexes):
 
 @pytest.mark.parametrize("name", KEYS)
 @pytest.mark.parametrize("kernel", ["coop", "lane"])
-def test_mult_and_make_l2_golden_on_both_kernels(name, kernel, monkeypatch):
+def test_mult_and_make_l2_golden_on_both_kernels(name, kernel, engopts):
     lim = "1000000" if kernel == "coop" else "0"
-    monkeypatch.setenv("BGN_COOP_MAX", lim)
-    monkeypatch.setenv("BGN_COOP_MAX_L2", lim)
+    engopts.set("coop_max", lim)
+    engopts.set("coop_max_l2", lim)
     fx = load_fixture(name)
     pk, _ = engine_key(fx)
     eng = pk.engine
@@ -38,7 +38,7 @@ def test_mult_and_make_l2_golden_on_both_kernels(name, kernel, monkeypatch):
 
 
 @pytest.mark.parametrize("name,count", [("toy64", 333), ("k256", 130), ("k512", 64), ("k1024", 48)])
-def test_coop_random_pairs_vs_c_oracle_and_lane_kernel(name, count, monkeypatch):
+def test_coop_random_pairs_vs_c_oracle_and_lane_kernel(name, count, engopts):
     """Seeded random ciphertext pairs (Encrypt outputs with full-length randomness, a few identities): the
     cooperative kernel, the lane kernel and the C oracle give the same bytes."""
     import oracle_c
@@ -54,10 +54,10 @@ def test_coop_random_pairs_vs_c_oracle_and_lane_kernel(name, count, monkeypatch)
     cts[5] = 0                      # identity operands (2L zero bytes)
     cts[count + 9] = 0
     a, b = cts[:count].tobytes(), cts[count:].tobytes()
-    monkeypatch.setenv("BGN_COOP_MAX", "1000000")
+    engopts.set("coop_max", "1000000")
     got = eng.mult(a, b).tobytes()
     assert "coop" in eng.last_kernel_name()
-    monkeypatch.setenv("BGN_COOP_MAX", "0")
+    engopts.set("coop_max", "0")
     lane = eng.mult(a, b).tobytes()
     assert "coop" not in eng.last_kernel_name()
     assert got == lane
@@ -67,7 +67,7 @@ def test_coop_random_pairs_vs_c_oracle_and_lane_kernel(name, count, monkeypatch)
     assert got[5 * E: 6 * E] == one and got[9 * E: 10 * E] == one
 
 
-def test_coop_single_pairing_count_one(monkeypatch):
+def test_coop_single_pairing_count_one(engopts):
     """count = 1, the reference's own call shape (bgn_test.go:127-140: one Mult per iteration)."""
     fx = load_fixture("k1024")
     pk, _ = engine_key(fx)
@@ -79,7 +79,7 @@ def test_coop_single_pairing_count_one(monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["k256", "k512", "k1024"])
-def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch):
+def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, engopts):
     """Decrypt of a few level-1 ciphertexts lifts with the cooperative kernel (e(C, P) in full) instead of the
     lane kernel's walk over the secret order's table: same plaintexts and statuses, negatives and an
     out-of-range value included (bgn.go:218-250)."""
@@ -93,10 +93,10 @@ def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch
     ms = [0, 1, T - 1, 5 % T, 3 * T + 11] + [rng.randrange(T) for _ in range(20)]
     cts = eng.encrypt(ms, [rng.randrange(n) for _ in ms])
     cts[3] = eng.neg(1, cts[3:4])[0]
-    monkeypatch.setenv("BGN_COOP_MAX_DEC", "100000")
+    engopts.set("coop_max_dec", "100000")
     m1, s1 = eng.decrypt(1, cts.tobytes())
     assert "coop" in eng.last_aux_kernel_name()
-    monkeypatch.setenv("BGN_COOP_MAX_DEC", "0")
+    engopts.set("coop_max_dec", "0")
     m0, s0 = eng.decrypt(1, cts.tobytes())
     assert "coop" not in eng.last_aux_kernel_name()
     assert m1.tolist() == m0.tolist() and s1.tolist() == s0.tolist()
@@ -104,9 +104,9 @@ def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch
     want[3] = -want[3]
     # level 2: the power by the secret key alone is cooperative (k_gt_pow_coop)
     l2 = eng.make_l2(cts.tobytes()).tobytes()
-    monkeypatch.setenv("BGN_COOP_MAX_DEC", "100000")
+    engopts.set("coop_max_dec", "100000")
     m2, s2 = eng.decrypt(2, l2)
-    monkeypatch.setenv("BGN_COOP_MAX_DEC", "0")
+    engopts.set("coop_max_dec", "0")
     m3, s3 = eng.decrypt(2, l2)
     assert m2.tolist() == m3.tolist() == m0.tolist() and s2.tolist() == s3.tolist() == s0.tolist()
     for got, st, w in zip(m1.tolist(), s1.tolist(), want):
@@ -118,7 +118,7 @@ def test_decrypt_small_batch_lifts_with_the_cooperative_kernel(name, monkeypatch
 
 
 @pytest.mark.parametrize("name,npoly,d1,d2", [("k256", 3, 4, 3), ("k512", 1, 9, 13), ("k1024", 2, 4, 4)])
-def test_multpoly_small_products_on_both_kernels(name, npoly, d1, d2, monkeypatch):
+def test_multpoly_small_products_on_both_kernels(name, npoly, d1, d2, engopts):
     """MultPoly of a few short polynomials (the reference's own call: ONE product of ~10 x 10 coefficients,
     poly_test.go:173-189) pairs directly on the cooperative kernel; the lane kernels (line tables, Karatsuba
     levels) and the C oracle give the same coefficients."""
@@ -133,19 +133,19 @@ def test_multpoly_small_products_on_both_kernels(name, npoly, d1, d2, monkeypatc
     cb = eng.encrypt([rng.randrange(3) for _ in range(npoly * d2)], [rng.randrange(n) for _ in range(npoly * d2)]).copy()
     ca[1] = 0                                                        # an identity coefficient
     a, b = ca.tobytes(), cb.tobytes()
-    monkeypatch.setenv("BGN_COOP_MAX", "1000000")
+    engopts.set("coop_max", "1000000")
     got = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
-    monkeypatch.setenv("BGN_COOP_MAX", "0")
+    engopts.set("coop_max", "0")
     lane = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
     assert got == lane == o.poly_mult(npoly, d1, d2, a, b)
 
 
 @pytest.mark.parametrize("name,count", [("toy64", 70), ("k256", 40), ("k512", 24), ("k1024", 12)])
-def test_table_walk_on_the_waves_matches_the_general_program_and_the_lane_kernel(name, count, monkeypatch):
+def test_table_walk_on_the_waves_matches_the_general_program_and_the_lane_kernel(name, count, engopts):
     """makeL2 and the level-1 decryption lift of a small batch walk the key's normalised line table on the
     cooperative kernel (TD / TDA segments of tools/coop/gen_prog.py: 6 / 10 products per step in 2 / 3 rounds,
     coefficients prefetched one segment ahead).  Same bytes as the general cooperative program
-    (BGN_COOP_TABLE=0), as the lane kernel's table loop and as the C oracle; identities in the batch; Decrypt's
+    (option coop_table = 0), as the lane kernel's table loop and as the C oracle; identities in the batch; Decrypt's
     plaintexts and statuses equal on all three paths."""
     import oracle_c
     fx = load_fixture(name)
@@ -162,9 +162,9 @@ def test_table_walk_on_the_waves_matches_the_general_program_and_the_lane_kernel
     wire = cts.tobytes()
     res = {}
     for label, lim, tab in (("table", "1000000", "1"), ("general", "1000000", "0"), ("lane", "0", "1")):
-        monkeypatch.setenv("BGN_COOP_MAX_L2", lim)
-        monkeypatch.setenv("BGN_COOP_MAX_DEC", lim)
-        monkeypatch.setenv("BGN_COOP_TABLE", tab)
+        engopts.set("coop_max_l2", lim)
+        engopts.set("coop_max_dec", lim)
+        engopts.set("coop_table", tab)
         l2 = eng.make_l2(wire).tobytes()
         assert ("coop" in eng.last_kernel_name()) == (label != "lane")
         m, st = eng.decrypt(1, wire)
@@ -183,13 +183,12 @@ def test_decrypt_default_dispatch_by_batch_size():
     ciphertexts lift and power on the cooperative kernels, 1000 on the lane-group kernels (table walk over the secret
     order's line table + square-and-multiply by the secret key); plaintexts and statuses as encrypted, and equal to
     the all-lane path."""
-    import os
     fx = load_fixture("k256")
     pk, sk = engine_key(fx)
     pk.SetupDecryption(sk)
     eng = pk.engine
-    for v in ("BGN_COOP_MAX_DEC", "BGN_COOP_TABLE", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MIN"):
-        assert v not in os.environ
+    for v, dflt in (("coop_max_dec", -1), ("coop_table", 1), ("quad_max_dec", -1), ("quad_min", -1)):
+        assert eng.get_option(v) == dflt
     rng = random.Random(12)
     n, T = int(fx["n"], 16), fx["msg_space"]
     ms = [rng.randrange(T) for _ in range(1000)]
@@ -200,10 +199,7 @@ def test_decrypt_default_dispatch_by_batch_size():
     ms3, st3 = eng.decrypt(1, cts[: 300 * eng.elem_bytes])
     assert "coop" in eng.last_aux_kernel_name()
     assert ms3.tolist() == ms[:300] and not st3.any()
-    os.environ["BGN_COOP_MAX_DEC"] = "0"
-    try:
+    with eng.options(coop_max_dec=0):
         m0, st0 = eng.decrypt(1, cts)
         assert "coop" not in eng.last_aux_kernel_name() and "quad" not in eng.last_aux_kernel_name()
-    finally:
-        del os.environ["BGN_COOP_MAX_DEC"]
     assert m0.tolist() == ms and st0.tolist() == st.tolist()

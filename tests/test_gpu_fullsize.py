@@ -156,7 +156,7 @@ def test_mult_longer_than_one_piece():
 
 
 @pytest.mark.parametrize("name,count", [("k1024", 1 << 16), ("k1024b", 1 << 14), ("k512", 1 << 16), ("k2048", 1 << 11)])
-def test_pairing_kernels_agree_on_large_random_batches(name, count, monkeypatch):
+def test_pairing_kernels_agree_on_large_random_batches(name, count, engopts):
     """Three formulations of `res.Pair` (bgn.go:300) — one pairing per lane (unsigned lazy limbs, Jacobian,
     windowed NAF), sixteen lanes per pairing and one workgroup per pairing (signed lazy limbs, generated step
     programs, plain NAF) — on the same seeded random ciphertext pairs with full-length randomness: every byte of
@@ -173,9 +173,9 @@ def test_pairing_kernels_agree_on_large_random_batches(name, count, monkeypatch)
     kernels = ("quad", "lane") if name == "k2048" else ("quad", "coop", "lane")   # no cooperative kernel at 72 limbs
     outs = {}
     for kernel in kernels:
-        monkeypatch.setenv("BGN_QUAD_MIN", "0")
-        monkeypatch.setenv("BGN_QUAD_MAX", "100000000" if kernel == "quad" else "0")
-        monkeypatch.setenv("BGN_COOP_MAX", "100000000" if kernel == "coop" else "0")
+        engopts.set("quad_min", "0")
+        engopts.set("quad_max", "100000000" if kernel == "quad" else "0")
+        engopts.set("coop_max", "100000000" if kernel == "coop" else "0")
         n = count if kernel != "lane" or name != "k2048" else 256                 # the 72-limb lane kernel is the functional one
         out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
         eng.mult_dev(ca[: n * EB], cb[: n * EB], out, n)
@@ -192,7 +192,7 @@ def test_pairing_kernels_agree_on_large_random_batches(name, count, monkeypatch)
 
 
 @pytest.mark.parametrize("name,count", [("k1024", 1 << 15)])
-def test_table_walks_and_decrypt_agree_across_kernels_on_large_batches(name, count, monkeypatch):
+def test_table_walks_and_decrypt_agree_across_kernels_on_large_batches(name, count, engopts):
     """makeL2 (the walk over P's line table, bgn.go:316-321) and Decrypt of both levels (lift over the secret order's
     table, power by q1, BSGS; bgn.go:205-250) on 32768 random ciphertexts, every 16th negated: the lane-group kernels,
     the cooperative kernels and the lane kernels return the same bytes / plaintexts / statuses, and the plaintexts
@@ -209,11 +209,11 @@ def test_table_walks_and_decrypt_agree_across_kernels_on_large_batches(name, cou
     big = "100000000"
     res = {}
     for kernel in ("quad", "coop", "lane"):
-        monkeypatch.setenv("BGN_QUAD_MIN", "0")
-        for v in ("BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
-            monkeypatch.setenv(v, big if kernel == "quad" else "0")
-        for v in ("BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
-            monkeypatch.setenv(v, big if kernel == "coop" else "0")
+        engopts.set("quad_min", "0")
+        for v in ("quad_max_l2", "quad_max_dec", "quad_max_pow"):
+            engopts.set(v, big if kernel == "quad" else "0")
+        for v in ("coop_max_l2", "coop_max_dec"):
+            engopts.set(v, big if kernel == "coop" else "0")
         l2 = torch.empty(count * EB, dtype=torch.uint8, device=dev)
         eng.make_l2_dev(mixed, l2, count)
         torch.cuda.synchronize()
@@ -238,7 +238,7 @@ def test_table_walks_and_decrypt_agree_across_kernels_on_large_batches(name, cou
     assert torch.equal(m1[ok], want[ok]) and torch.equal(m2[ok], want[ok])
 
 
-def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
+def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(engopts):
     """65536 + r elements: the engine runs whole rounds of the lane kernel and hands the remainder to the kernel that
     is fastest at ITS size (engine.cpp lane_rounds_head / decrypt_rounds_head).  Same bytes / plaintexts as the single
     launch (BGN_SPLIT_ROUNDS=0), for Mult, makeL2 and level-1 Decrypt; the kernel reported last is the remainder's."""
@@ -253,7 +253,7 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
         cb = permuted_copy(ca, EB, 98)
         res = {}
         for split in ("1", "0"):
-            monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+            engopts.set("split_rounds", split)
             prod = torch.empty(count * EB, dtype=torch.uint8, device=dev)
             eng.mult_dev(ca, cb, prod, count)
             torch.cuda.synchronize()
@@ -273,7 +273,7 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
             r = r.to(dev)
             blinded = {}
             for split in ("1", "0"):
-                monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+                engopts.set("split_rounds", split)
                 o = torch.empty(count * EB, dtype=torch.uint8, device=dev)
                 eng.mult_dev(ca, cb, o, count, r=r, r_len=r_len)
                 torch.cuda.synchronize()
@@ -289,7 +289,7 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(monkeypatch):
             for j in range(xb.shape[1]):
                 want = want * 256 + xb[:, j]
             for split in ("1", "0"):
-                monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+                engopts.set("split_rounds", split)
                 m = torch.empty(count, dtype=torch.int64, device=dev)
                 st = torch.empty(count, dtype=torch.uint8, device=dev)
                 eng.decrypt_dev(1, ca, m, st, count)

@@ -105,7 +105,7 @@ def test_windowed_multconst_1024_vs_c_oracle():
         assert eng.multconst(1, a, ks).tobytes() == o.multconst(1, a, ks)
 
 
-def test_multconst_falls_back_when_its_table_cannot_be_allocated(monkeypatch):
+def test_multconst_falls_back_when_its_table_cannot_be_allocated(engopts):
     """a failed allocation of the window table must fall back to the binary ladder AND leave no
     sticky HIP error behind (the call used to return BGN_E_HIP although the fallback had run)."""
     import oracle_c
@@ -117,9 +117,9 @@ def test_multconst_falls_back_when_its_table_cannot_be_allocated(monkeypatch):
     cts = pk.engine.encrypt([5, 6, 7], [rng.randrange(n) for _ in range(3)]).tobytes()
     ks = [rng.randrange(n) for _ in range(3)]
     want = o.multconst(1, cts, ks)
-    monkeypatch.setenv("BGN_TEST_FAIL_MUL_WS", "1")
+    engopts.set("test_fail_mul_ws", "1")
     assert pk.engine.multconst(1, cts, ks).tobytes() == want        # binary ladder
-    monkeypatch.delenv("BGN_TEST_FAIL_MUL_WS")
+    engopts.unset("test_fail_mul_ws")
     assert pk.engine.multconst(1, cts, ks).tobytes() == want        # window table again
 
 
@@ -186,16 +186,17 @@ def test_decrypt_2_16_negatives_and_out_of_range_vs_known_and_c_oracle():
 
 # ---------------------------------------------------------------- BSGS: verification of table hits
 @pytest.mark.parametrize("bits", [10, 14])
-def test_bsgs_false_hits_are_rejected_by_the_full_width_check(bits, monkeypatch):
+def test_bsgs_false_hits_are_rejected_by_the_full_width_check(bits, engopts):
     """With the table fingerprint cut to a few bits a few probes of every walk find a slot whose short fingerprint matches;
     the candidate is verified by g^m == csk on every limb, a false hit resumes the walk behind the rejected slot,
     and the results are the plaintexts (gsbs.go:83,90 compare whole elements)."""
     import bgn_amd
     fx = load_fixture("k256")
-    monkeypatch.setenv("BGN_TEST_BSGS_FP_BITS", str(bits))
-    monkeypatch.setenv("BGN_BSGS_MAX_LOG2", "6")                     # 64 baby steps: many giant steps to walk
     pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
                            1 << 16, True, fx["poly_base"])
+    engopts.register(pk.engine)
+    engopts.set("test_bsgs_fp_bits", bits)                # read by bgn_ctx_setup_decryption
+    engopts.set("bsgs_max_log2", 6)                       # 64 baby steps: many giant steps to walk
     pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
     rng = random.Random(3)
     n = int(fx["n"], 16)
@@ -219,7 +220,7 @@ def test_bsgs_false_hits_are_rejected_by_the_full_width_check(bits, monkeypatch)
 
 # ---------------------------------------------------------------- chunked host-buffer pipeline
 @pytest.mark.parametrize("name,count,chunk", [("k512", 5000, 700), ("toy64", 200000, 65536), ("k1024", 1500, 256)])
-def test_host_pipeline_matches_one_shot_staging(name, count, chunk, monkeypatch):
+def test_host_pipeline_matches_one_shot_staging(name, count, chunk, engopts):
     """The host-buffer entry points of Add / Sub / Neg run large calls in chunks over a ring of three staging
     sets (upload / launch / download threads, engine.cpp host_pipeline).  With the chunk size forced small
     (BGN_HOST_PIPE_CHUNK) the pipelined call must return the bytes of the one-shot staging path
@@ -238,12 +239,12 @@ def test_host_pipeline_matches_one_shot_staging(name, count, chunk, monkeypatch)
     ks = [rng.randrange(1, 1 << 20) for _ in range(count)]
 
     def both(fn):
-        monkeypatch.setenv("BGN_HOST_PIPE", "0")
+        engopts.set("host_pipe", "0")
         one = fn().tobytes()
-        monkeypatch.setenv("BGN_HOST_PIPE", "1")
-        monkeypatch.setenv("BGN_HOST_PIPE_CHUNK", str(chunk))
+        engopts.set("host_pipe", "1")
+        engopts.set("host_pipe_chunk", str(chunk))
         piped = fn().tobytes()
-        monkeypatch.delenv("BGN_HOST_PIPE_CHUNK")
+        engopts.unset("host_pipe_chunk")
         assert piped == one
         return one
 
@@ -262,15 +263,15 @@ def test_host_pipeline_matches_one_shot_staging(name, count, chunk, monkeypatch)
     m = min(count, 1024)                                            # level 2 on a slice (a Mult per element)
     l2 = eng.make_l2(ct[: m * E]).tobytes()
     l2b = eng.make_l2(det[: m * E]).tobytes()
-    monkeypatch.setenv("BGN_HOST_PIPE_CHUNK", "100")
+    engopts.set("host_pipe_chunk", "100")
     piped = eng.add(2, l2, l2b).tobytes()
     piped_mc = eng.multconst(2, l2, ks[:m]).tobytes()
-    monkeypatch.setenv("BGN_HOST_PIPE", "0")
+    engopts.set("host_pipe", "0")
     assert piped == eng.add(2, l2, l2b).tobytes()
     assert piped_mc == eng.multconst(2, l2, ks[:m]).tobytes()
 
 
-def test_host_pipeline_under_concurrent_callers(monkeypatch):
+def test_host_pipeline_under_concurrent_callers(engopts):
     """Two host threads in bgn_add_batch on ONE context at the same time: one holds the context's staging ring
     (pipelined), the other finds it taken and stages in one shot; a third thread runs a device-resident Mult on
     its own stream meanwhile.  Every result equals the single-threaded one (the engine serialises launches per
@@ -286,12 +287,12 @@ def test_host_pipeline_under_concurrent_callers(monkeypatch):
     ia = np.array([rng.randrange(32) for _ in range(count)])
     ib = np.array([rng.randrange(32) for _ in range(count)])
     a, b = pool[ia].tobytes(), pool[ib].tobytes()
-    monkeypatch.setenv("BGN_HOST_PIPE", "0")
+    engopts.set("host_pipe", "0")
     want_add = eng.add(1, a, b).tobytes()
     want_sub = eng.sub(1, a, b).tobytes()
     want_mul = eng.mult(a[: 64 * eng.elem_bytes], b[: 64 * eng.elem_bytes]).tobytes()
-    monkeypatch.setenv("BGN_HOST_PIPE", "1")
-    monkeypatch.setenv("BGN_HOST_PIPE_CHUNK", "500")
+    engopts.set("host_pipe", "1")
+    engopts.set("host_pipe_chunk", "500")
     got, errs = {}, []
 
     def run(key, fn):

@@ -305,38 +305,38 @@ def test_poly_mult_many_vs_c_oracle_and_decrypt():
         assert [int(v) for v in m[q * (d1 + d2):(q + 1) * (d1 + d2)]] == conv
 
 
-T1 = {"BGN_POLY_TABLES": "1"}                    # the table path whatever the size (by default products of up to 65536
+T1 = {"poly_tables": "1"}                    # the table path whatever the size (by default products of up to 65536
                                                  # coefficient pairs pair directly: one pairing's latency)
 
 
 @pytest.mark.parametrize("d1,d2,env", [
     (4, 3, T1),                                  # tables on the second polynomial (fewer coefficients)
     (2, 5, T1),                                  # tables on the first
-    (3, 3, {**T1, "BGN_POLY_TABLE_MAX_MB": "3"}),      # table budget of 3 MB = 64 columns: 21 polynomials per chunk
+    (3, 3, {**T1, "poly_table_max_mb": "3"}),      # table budget of 3 MB = 64 columns: 21 polynomials per chunk
     # whole rounds of tables first, the remainder pairs directly (rounds of 64 / 16 lanes instead of 65536 here):
-    (3, 3, {**T1, "BGN_POLY_TABLE_MAX_MB": "3", "BGN_POLY_ROUND": "64"}),                # 70 = 3 x 21 + 7: 63 pairs direct
-    (2, 2, {**T1, "BGN_POLY_ROUND": "32", "npoly": "37"}),                               # one chunk of 32 + 5 direct
-    (2, 2, {**T1, "BGN_POLY_TABLE_MAX_MB": "3", "BGN_POLY_ROUND": "16", "npoly": "43"}), # 32, then 8 by tables + 3 direct
-    (4, 3, {"BGN_POLY_TABLES": "0"}),            # direct d1*d2 full pairings
+    (3, 3, {**T1, "poly_table_max_mb": "3", "poly_round": "64"}),                # 70 = 3 x 21 + 7: 63 pairs direct
+    (2, 2, {**T1, "poly_round": "32", "npoly": "37"}),                               # one chunk of 32 + 5 direct
+    (2, 2, {**T1, "poly_table_max_mb": "3", "poly_round": "16", "npoly": "43"}), # 32, then 8 by tables + 3 direct
+    (4, 3, {"poly_tables": "0"}),            # direct d1*d2 full pairings
     (4, 3, {}), (2, 5, {}),                      # the default dispatch at this size
     (1, 4, T1), (4, 1, T1), (1, 1, {}),          # degenerate shapes
     (2, 2, T1),                                  # square, below the Karatsuba threshold
     (4, 4, T1), (8, 8, T1),                      # Karatsuba: one and two levels down to 2 x 2
     (6, 6, T1),                                  # one level, odd leaves 3 x 3
-    (8, 8, {**T1, "BGN_POLY_KARATSUBA": "0"}),   # the same product without it
-    (8, 8, {**T1, "BGN_POLY_LEVELS": "1"}),      # one level where two are possible (engine.cpp poly_plan_levels picks by cost)
-    (16, 16, {"BGN_POLY_LEVELS": "2", "npoly": "5"}), (16, 16, {"npoly": "5"}),
-    (4, 4, {"BGN_POLY_TABLES": "0"}),            # Karatsuba over direct pairings at the leaves
+    (8, 8, {**T1, "poly_karatsuba": "0"}),   # the same product without it
+    (8, 8, {**T1, "poly_levels": "1"}),      # one level where two are possible (engine.cpp poly_plan_levels picks by cost)
+    (16, 16, {"poly_levels": "2", "npoly": "5"}), (16, 16, {"npoly": "5"}),
+    (4, 4, {"poly_tables": "0"}),            # Karatsuba over direct pairings at the leaves
 ])
-def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
+def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, engopts):
     """MultPoly over per-coefficient line tables (fixedpair.hpp) == the oracle's d1*d2 full pairings +
     accumulation, for either table side, chunked tables, whole rounds + direct remainder, identity coefficients
     (Enc(0) deterministic) and the direct path."""
     import oracle_c
     env = dict(env)
-    npoly = int(env.pop("npoly", 70 if env.get("BGN_POLY_TABLE_MAX_MB") else 9))
+    npoly = int(env.pop("npoly", 70 if env.get("poly_table_max_mb") else 9))
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        engopts.set(k, v)
     fx = load_fixture("k256")
     o = oracle_c.Oracle.from_fixture(fx)
     pk, _ = engine_key(fx)
@@ -349,7 +349,7 @@ def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, monkeypatch):
     eb = o.encrypt(xb, [rng.choice([0, rng.randrange(n)]) for _ in xb])
     out = pk.engine.poly_mult(npoly, d1, d2, ea, eb)
     assert out.tobytes() == o.poly_mult(npoly, d1, d2, ea, eb)
-    if env.get("BGN_POLY_TABLES") == "1" and d1 * d2 >= 2 and "BGN_POLY_ROUND" not in env:
+    if env.get("poly_tables") == "1" and d1 * d2 >= 2 and "poly_round" not in env:
         assert "fixedpair" in pk.engine.last_kernel_name()
 
 
@@ -383,11 +383,11 @@ def test_repeated_setup_keeps_key_tables_alive():
 
 
 @pytest.mark.parametrize("split", ["0", "1"])
-def test_mult_runs_with_shared_inversion(split, monkeypatch):
+def test_mult_runs_with_shared_inversion(split, engopts):
     """count > 2*65536 makes every lane own a run of pairings that share one F_p inversion
     (Montgomery's trick in the final exponentiation); ragged tail; identities inside the runs.
     split = 0: one launch, the last run ragged; 1 (the default): three whole rounds, then the 77 on their own."""
-    monkeypatch.setenv("BGN_SPLIT_ROUNDS", split)
+    engopts.set("split_rounds", split)
     fx = load_fixture("toy64")
     opk, _ = oracle_key(fx)
     pk, _ = engine_key(fx)

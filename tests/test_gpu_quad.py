@@ -1,6 +1,6 @@
 """GPU: the lane-group pairing kernel (bgn_amd/csrc/quad/: sixteen lanes per pairing, a field element over the four
 lanes of a quad) against the golden vectors, the other two pairing kernels and the C oracle.  The engine picks the
-kernel by batch size; BGN_QUAD_MIN / BGN_QUAD_MAX move the range of the lane-group kernel (BGN_QUAD_MAX=0 disables
+kernel by batch size; options quad_min / quad_max move the range of the lane-group kernel (quad_max = 0 disables
 it), so every kernel is driven through the same C-ABI calls here."""
 import random
 
@@ -17,16 +17,16 @@ def H(hexes):
     return b"".join(bytes.fromhex(h) for h in hexes)
 
 
-def force(monkeypatch, kernel):
+def force(engopts, kernel):
     """kernel: 'quad', 'coop' or 'lane' for every batch size."""
-    monkeypatch.setenv("BGN_QUAD_MIN", "0")
-    monkeypatch.setenv("BGN_QUAD_MAX", "100000000" if kernel == "quad" else "0")
-    monkeypatch.setenv("BGN_COOP_MAX", "100000000" if kernel == "coop" else "0")
+    engopts.set("quad_min", "0")
+    engopts.set("quad_max", "100000000" if kernel == "quad" else "0")
+    engopts.set("coop_max", "100000000" if kernel == "coop" else "0")
 
 
 @pytest.mark.parametrize("name", QUAD_KEYS)
-def test_mult_golden_on_the_lane_group_kernel(name, monkeypatch):
-    force(monkeypatch, "quad")
+def test_mult_golden_on_the_lane_group_kernel(name, engopts):
+    force(engopts, "quad")
     fx = load_fixture(name)
     pk, _ = engine_key(fx)
     eng = pk.engine
@@ -38,7 +38,7 @@ def test_mult_golden_on_the_lane_group_kernel(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name,count", [("k256", 131), ("k512", 65), ("k1024", 49), ("k1024", 16)])
-def test_quad_random_pairs_vs_c_oracle_and_the_other_kernels(name, count, monkeypatch):
+def test_quad_random_pairs_vs_c_oracle_and_the_other_kernels(name, count, engopts):
     """Seeded random ciphertext pairs (Encrypt outputs with full-length randomness, two identities; counts that
     leave the last workgroup and the last wave ragged): the three pairing kernels and the C oracle give the same
     bytes."""
@@ -57,7 +57,7 @@ def test_quad_random_pairs_vs_c_oracle_and_the_other_kernels(name, count, monkey
     a, b = cts[:count].tobytes(), cts[count:].tobytes()
     got = {}
     for kernel in ("quad", "coop", "lane"):
-        force(monkeypatch, kernel)
+        force(engopts, kernel)
         got[kernel] = eng.mult(a, b).tobytes()
         assert (kernel in eng.last_kernel_name()) == (kernel != "lane"), eng.last_kernel_name()
     assert got["quad"] == got["lane"] == got["coop"]
@@ -68,7 +68,7 @@ def test_quad_random_pairs_vs_c_oracle_and_the_other_kernels(name, count, monkey
 
 
 @pytest.mark.parametrize("name,npoly,d1,d2", [("k256", 3, 4, 3), ("k512", 1, 9, 13), ("k1024", 2, 4, 4)])
-def test_multpoly_direct_pairs_on_the_lane_group_kernel(name, npoly, d1, d2, monkeypatch):
+def test_multpoly_direct_pairs_on_the_lane_group_kernel(name, npoly, d1, d2, engopts):
     """MultPoly's coefficient pairs (poly.go:139-146) on the lane-group kernel: same coefficients as the lane
     kernels (line tables, Karatsuba levels) and the C oracle."""
     import oracle_c
@@ -82,9 +82,9 @@ def test_multpoly_direct_pairs_on_the_lane_group_kernel(name, npoly, d1, d2, mon
     cb = eng.encrypt([rng.randrange(3) for _ in range(npoly * d2)], [rng.randrange(n) for _ in range(npoly * d2)]).copy()
     ca[1] = 0                                                        # an identity coefficient
     a, b = ca.tobytes(), cb.tobytes()
-    force(monkeypatch, "quad")
+    force(engopts, "quad")
     got = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
-    force(monkeypatch, "lane")
+    force(engopts, "lane")
     lane = eng.poly_mult(npoly, d1, d2, a, b).tobytes()
     assert got == lane == o.poly_mult(npoly, d1, d2, a, b)
 
@@ -129,7 +129,7 @@ def test_default_dispatch_uses_the_lane_group_kernel_between_the_crossovers():
 
 
 @pytest.mark.parametrize("name", ["k512", "k1024"])
-def test_zero_norm_yields_the_identity_on_every_kernel(name, monkeypatch):
+def test_zero_norm_yields_the_identity_on_every_kernel(name, engopts):
     """An operand that is not on the curve can drive f to zero: A = (a, 0) doubles to Z3 = 2YZ = 0 and its tangent
     at phi(B), B = (-a, y), is (3a^2 + 1)(xB + a) + 0i = 0, so N(f) = 0 and its inverse is 0.  The lane kernel maps
     such a pairing to the identity (as PBC's SetBytes maps an invalid point to O); the cooperative and the
@@ -147,26 +147,26 @@ def test_zero_norm_yields_the_identity_on_every_kernel(name, monkeypatch):
     b = bytes.fromhex(cts[good[0]["b"]]) + bad_b + bytes.fromhex(cts[good[1]["b"]])
     one = (1).to_bytes(L, "big") + bytes(L)
     for kernel in ("lane", "coop", "quad"):
-        force(monkeypatch, kernel)
+        force(engopts, kernel)
         out = eng.mult(a, b)
         assert (kernel in eng.last_kernel_name()) == (kernel != "lane")
         assert bytes(out[0]).hex() == good[0]["out"] and bytes(out[2]).hex() == good[1]["out"], kernel
         assert bytes(out[1]) == one, kernel
 
 
-def force_table(monkeypatch, kernel):
+def force_table(engopts, kernel):
     """The walks over a key's line table (makeL2, Decrypt's lift) and Decrypt's power on 'quad', 'coop' or 'lane'."""
     big = "100000000"
-    monkeypatch.setenv("BGN_QUAD_MIN", "0")
-    for v in ("BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
-        monkeypatch.setenv(v, big if kernel == "quad" else "0")
-    for v in ("BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
-        monkeypatch.setenv(v, big if kernel == "coop" else "0")
+    engopts.set("quad_min", "0")
+    for v in ("quad_max_l2", "quad_max_dec", "quad_max_pow"):
+        engopts.set(v, big if kernel == "quad" else "0")
+    for v in ("coop_max_l2", "coop_max_dec"):
+        engopts.set(v, big if kernel == "coop" else "0")
 
 
 @pytest.mark.parametrize("name", QUAD_KEYS)
-def test_make_l2_golden_on_the_lane_group_table_walk(name, monkeypatch):
-    force_table(monkeypatch, "quad")
+def test_make_l2_golden_on_the_lane_group_table_walk(name, engopts):
+    force_table(engopts, "quad")
     fx = load_fixture(name)
     pk, _ = engine_key(fx)
     eng = pk.engine
@@ -178,7 +178,7 @@ def test_make_l2_golden_on_the_lane_group_table_walk(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name,count", [("k256", 70), ("k512", 41), ("k1024", 33), ("k1024b", 17)])
-def test_table_walk_and_power_on_the_lane_groups_match_the_other_kernels(name, count, monkeypatch):
+def test_table_walk_and_power_on_the_lane_groups_match_the_other_kernels(name, count, engopts):
     """makeL2 and level-1 / level-2 Decrypt of a batch with an identity, a negative and an out-of-range value: the
     lane-group kernels (table walk over P's table / over the secret order's table, power by the secret key), the
     cooperative kernels and the lane kernels give the same bytes, plaintexts and statuses; makeL2 also equals the C
@@ -207,7 +207,7 @@ def test_table_walk_and_power_on_the_lane_groups_match_the_other_kernels(name, c
     wire = cts.tobytes()
     res = {}
     for kernel in ("quad", "coop", "lane"):
-        force_table(monkeypatch, kernel)
+        force_table(engopts, kernel)
         l2 = eng.make_l2(wire).tobytes()
         assert (kernel in eng.last_kernel_name()) == (kernel != "lane"), eng.last_kernel_name()
         m1, s1 = eng.decrypt(1, wire)

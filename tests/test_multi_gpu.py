@@ -22,12 +22,26 @@ def _pool(fx, n, step=1, off=0):
     return b"".join(cts[(step * i + off) % len(cts)] for i in range(n))
 
 
-@pytest.fixture(scope="module")
-def multi():
+def _device_lists():
+    """[0, 0, 0] always: three contexts on one device are real multi-context sharding on a one-GPU box.  On a box with
+    two or more GPUs the same tests also run over [0, 1] and over every visible device — the first thing a
+    multi-GPU run proves: peer access enabled, hipMemcpyPeerAsync across xGMI, a root that is
+    not every shard's device.  device_count() does not initialise the GPU (safe at collection time)."""
+    import torch
+    n = torch.cuda.device_count()
+    skip = pytest.mark.skip(reason="needs more GPUs: this box shows %d" % n)
+    return [pytest.param([0, 0, 0], id="same3"),
+            pytest.param([0, 1], id="two", marks=[] if n >= 2 else [skip]),
+            pytest.param(list(range(max(n, 3))), id="all", marks=[] if n >= 3 else [skip])]
+
+
+@pytest.fixture(scope="module", params=_device_lists())
+def multi(request):
     import bgn_amd
+    devices = request.param
     fx = load_fixture("k256")
     me = bgn_amd.MultiEngine(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
-                             True, devices=[0, 0, 0])
+                             True, devices=devices)
     me.set_secret(int(fx["q1"], 16))
     me.setup_decryption(fx["msg_space"])
     yield fx, me
@@ -66,12 +80,13 @@ def test_mctx_multpoly_shards_by_polynomial(multi, npoly, d1, d2):
 
 
 @pytest.mark.parametrize("staging", ["0", "1"])
-def test_mctx_device_resident_forms(multi, staging, monkeypatch):
-    """Arrays resident on cuda:0, gathered into one output array on cuda:0; BGN_MCTX_FORCE_STAGING=1 sends every
-    shard through the peer-copy path (scratch on the shard's device, hipMemcpyPeerAsync in and out)."""
+def test_mctx_device_resident_forms(multi, staging):
+    """Arrays resident on cuda:0, gathered into one output array on cuda:0; option mctx_force_staging = 1 sends every
+    shard through the peer-copy path (scratch on the shard's device, hipMemcpyPeerAsync in and out).  With more than
+    one device in the list the shards of the other devices take that path by themselves."""
     import torch
-    monkeypatch.setenv("BGN_MCTX_FORCE_STAGING", staging)
     fx, me = multi
+    me.set_option("mctx_force_staging", int(staging))
     pk, _ = engine_key(fx)
     eng = pk.engine
     count, E = 11, eng.elem_bytes
@@ -92,14 +107,14 @@ def test_mctx_device_resident_forms(multi, staging, monkeypatch):
     assert po.cpu().numpy().tobytes() == eng.poly_mult(npoly, d, d, a[: npoly * d * E], b[: npoly * d * E]).tobytes()
 
 
-def test_mctx_device_resident_forms_wait_for_the_callers_stream(multi, monkeypatch):
+def test_mctx_device_resident_forms_wait_for_the_callers_stream(multi):
     """The ordering contract of the _dev calls (include/bgn_amd.h): operands produced asynchronously on a side
     stream of the root device — here behind tens of milliseconds of queued work — and a pending fill of the
     result array are waited for by every shard (an event on the caller's stream), staging path forced.  Without
     the wait the shards would pair the zero bytes the arrays held before."""
     import torch
-    monkeypatch.setenv("BGN_MCTX_FORCE_STAGING", "1")
     fx, me = multi
+    me.set_option("mctx_force_staging", 1)
     pk, _ = engine_key(fx)
     eng = pk.engine
     count, E = 13, eng.elem_bytes
@@ -172,3 +187,52 @@ def test_sharded_ops_two_ranks_share_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def test_mctx_root_is_not_a_shard_device():
+    """Operands resident on the LAST visible device while the contexts live on the others: every shard fetches its
+    slice by peer DMA and writes its results back the same way (asynchronously produced operands).  Two GPUs or more."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs two or more GPUs: this box shows %d" % n)
+    import bgn_amd
+    fx = load_fixture("k256")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    root = n - 1
+    me = bgn_amd.MultiEngine(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                             True, devices=list(range(n - 1)) or [0])
+    try:
+        count, E = 37, eng.elem_bytes
+        a, b = _pool(fx, count), _pool(fx, count, 3, 1)
+        dev = torch.device("cuda", root)
+        src_a = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+        src_b = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        ta, tb = torch.zeros_like(src_a), torch.zeros_like(src_b)
+        out = torch.zeros(count * E, dtype=torch.uint8, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            ta.copy_(src_a, non_blocking=True)
+            tb.copy_(src_b, non_blocking=True)
+            me.mult_dev(ta, tb, out, root=root)
+        assert out.cpu().numpy().tobytes() == eng.mult(a, b).tobytes()
+    finally:
+        me.close()
+
+
+def test_bench_two_ranks_over_rccl():
+    """bench.py --gpus 2 --steps 1: two rank processes, one per GPU, RCCL all-gather of the shards — the bench
+    contract's N > 1 form, on a box that has the GPUs for it."""
+    import json
+    import subprocess
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs two or more GPUs: this box shows %d" % n)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BGN_BENCH_TIMEOUT_S="900")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch-log2", "16", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["value"] > 0

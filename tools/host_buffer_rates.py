@@ -20,9 +20,9 @@ P = lambda a: a.ctypes.data_as(C.c_void_p)
 
 
 def timed(label, fn, units, reps=3):
-    """Each measurement with the one-shot staging path (BGN_HOST_PIPE=0) and with the chunked pipeline."""
+    """Each measurement with the one-shot staging path (option host_pipe = 0) and with the chunked pipeline."""
     for pipe in ("0", "1"):
-        os.environ["BGN_HOST_PIPE"] = pipe
+        eng.set_option("host_pipe", int(pipe))
         best = 1e9
         for _ in range(reps):
             t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)

@@ -45,7 +45,7 @@ def main():
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                     best = dt if best is None else min(best, dt)
-                print("%s,%d,%d,%d,%s,%d,%.2f,%.1f,%s" % (key, d1, d2, n, os.environ.get("BGN_POLY_LEVELS", "planned"), n * d1 * d2, best * 1e3, n * d1 * d2 / best,
+                print("%s,%d,%d,%d,%s,%d,%.2f,%.1f,%s" % (key, d1, d2, n, ("planned" if eng.get_option("poly_levels") < 0 else str(eng.get_option("poly_levels"))), n * d1 * d2, best * 1e3, n * d1 * d2 / best,
                                                       eng.last_kernel_name()), flush=True)
 
 

@@ -43,7 +43,7 @@ def main():
             for n in counts:
                 ref = None
                 for split in ("1", "0"):
-                    os.environ["BGN_SPLIT_ROUNDS"] = split
+                    eng.set_option("split_rounds", int(split))
                     best = None
                     for rep in range(3 if n < (1 << 19) else 2):
                         torch.cuda.synchronize()

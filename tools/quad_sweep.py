@@ -46,11 +46,7 @@ def main():
         big = "100000000"
         for op in ops:
             for kernel in kernels:
-                os.environ["BGN_QUAD_MIN"] = "0"
-                for v in ("BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
-                    os.environ[v] = big if kernel == "quad" else "0"
-                for v in ("BGN_COOP_MAX", "BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
-                    os.environ[v] = big if kernel == "coop" else "0"
+                eng.force_kernel(kernel)              # options of the context (bgn_ctx_set_option), not the environment
                 for n in counts:
                     if kernel == "coop" and n > 16384:
                         continue

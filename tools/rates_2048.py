@@ -49,7 +49,7 @@ def main():
     dt, (m, st) = best(lambda: eng.decrypt(1, a))
     assert m.tolist() == xs[:N] and not st.any()
     print("decrypt_l1,%d,%.2f,%.1f,%s" % (N, dt * 1e3, N / dt, eng.last_aux_kernel_name()))
-    os.environ["BGN_QUAD_MAX"] = "0"
+    eng.set_option("quad_max", 0)
     dt, out2 = best(lambda: eng.mult(a[: 256 * eng.elem_bytes], b[: 256 * eng.elem_bytes]), reps=1)
     assert out2.tobytes() == eng.mult(a[: 256 * eng.elem_bytes], b[: 256 * eng.elem_bytes]).tobytes()
     print("mult (lane kernel: the functional fallback),%d,%.2f,%.1f,%s" % (256, dt * 1e3, 256 / dt, eng.last_kernel_name()))

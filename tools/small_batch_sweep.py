@@ -38,8 +38,8 @@ def main():
         sta = torch.empty(nmax, dtype=torch.uint8, device=dev)
         for op in ("mult", "make_l2", "decrypt_l1"):
             for kernel in ("coop", "lane"):
-                os.environ["BGN_COOP_MAX"] = os.environ["BGN_COOP_MAX_L2"] = os.environ["BGN_COOP_MAX_DEC"] = \
-                    "100000000" if kernel == "coop" else "0"
+                for v in ("coop_max", "coop_max_l2", "coop_max_dec"):     # alone: the cooperative / lane kernel A/B
+                    eng.set_option(v, 100000000 if kernel == "coop" else 0)
                 for n in counts:
                     if kernel == "coop" and n > 16384:
                         continue

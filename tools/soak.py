@@ -22,24 +22,20 @@ import bgn_amd  # noqa: E402
 import bgn_amd.synthetic as syn  # noqa: E402
 import oracle_c  # noqa: E402
 
-BIG = "100000000"
-KERNEL_ENV = ("BGN_QUAD_MIN", "BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW", "BGN_COOP_MAX", "BGN_COOP_MAX_L2",
-              "BGN_COOP_MAX_DEC", "BGN_SPLIT_ROUNDS", "BGN_POLY_TABLES", "BGN_POLY_KARATSUBA", "BGN_POLY_LEVELS")
+ENGINES = []
 
 
-def force(kernel):
-    for v in KERNEL_ENV:
-        os.environ.pop(v, None)
-    if kernel == "default":
-        return
-    if kernel == "one launch":
-        os.environ["BGN_SPLIT_ROUNDS"] = "0"
-        return
-    os.environ["BGN_QUAD_MIN"] = "0"
-    for v in ("BGN_QUAD_MAX", "BGN_QUAD_MAX_L2", "BGN_QUAD_MAX_DEC", "BGN_QUAD_MAX_POW"):
-        os.environ[v] = BIG if kernel == "quad" else "0"
-    for v in ("BGN_COOP_MAX", "BGN_COOP_MAX_L2", "BGN_COOP_MAX_DEC"):
-        os.environ[v] = BIG if kernel == "coop" else "0"
+def force(kernel, **extra):
+    """Every dispatch alternative is an option of the contexts (bgn_ctx_set_option); nothing goes through the
+    environment."""
+    for eng in ENGINES:
+        eng.reset_options()
+        if kernel == "one launch":
+            eng.set_option("split_rounds", 0)
+        elif kernel != "default":
+            eng.force_kernel(kernel)
+        for k, v in extra.items():
+            eng.set_option(k, v)
 
 
 def main():
@@ -57,6 +53,7 @@ def main():
         pk.engine.set_memory_budget(60 << 30)
         pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
         eng = pk.engine
+        ENGINES.append(eng)
         EB = eng.elem_bytes
         T = fx["msg_space"]
         g = torch.Generator().manual_seed(seed * 7 + len(keys))
@@ -156,12 +153,11 @@ def main():
             pa = K["cts"][: npoly * d1 * EB]
             pb = K["perm"][: npoly * d2 * EB]
             n = npoly * d1 * d2
-            for kv, env in (("default", {}), ("direct", {"BGN_POLY_TABLES": "0", "BGN_POLY_KARATSUBA": "0"}), ("tables", {"BGN_POLY_TABLES": "1"}),
-                            ("levels", {"BGN_POLY_LEVELS": str(rng.randrange(0, 4))})):
+            for kv, env in (("default", {}), ("direct", {"poly_tables": 0, "poly_karatsuba": 0}), ("tables", {"poly_tables": 1}),
+                            ("levels", {"poly_levels": rng.randrange(0, 4)})):
                 if kv == "direct" and n > 70000:
                     continue
-                force("default")
-                os.environ.update(env)
+                force("default", **env)
                 out = torch.empty(npoly * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
                 eng.poly_mult_dev(npoly, d1, d2, pa, pb, out)
                 torch.cuda.synchronize()

@@ -10,7 +10,11 @@
 // not), gathers each group's operands into one staging array, issues ONE upload, one launch chain per group on the
 // combiner's stream, ONE download, and hands every caller its slice and its status.  Results are those of the
 // batch entry points (every element of a batch is independent), so a combined call returns the bytes a lone call
-// would.  No timer is involved unless option combine_wait_us asks a lone leader to wait for company.
+// would.  One refinement keeps steady callers together: the callers a round has just released are on their way
+// back, so the next leader waits for them — until as many requests have been pushed as the last round released, and
+// never longer than `regroup_pct` percent of that round's duration (default 10; a lone caller has itself as the
+// only one released and never waits).  Without it a pool of callers splits into two cohorts that alternate, each
+// launch half as full as it could be.  Option combine_wait_us asks a lone leader to wait for company (off).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -67,6 +71,11 @@ struct Combiner {
   std::deque<CombineReq*> queue;
   bool leader_active = false;
   CombineStats stats;
+  // regrouping (see the header comment): what the last round released and when it ended
+  std::condition_variable cv_arrive;
+  bool regrouping = false;
+  size_t last_round_reqs = 0, pushed_since_round_end = 0;
+  double last_round_us = 0;
 
   hipStream_t stream = nullptr;
   uint8_t* h_stage = nullptr;      // page-locked: [inputs of every group | outputs of every group]
@@ -198,16 +207,29 @@ struct Combiner {
 
   // Called by every host-buffer entry point whose call is small enough.  Returns the call's status; *err receives
   // the message of a failure.
-  int submit(CombineReq& req, size_t max_batch, int64_t wait_us, std::string* err) {
+  int submit(CombineReq& req, size_t max_batch, int64_t wait_us, int64_t regroup_pct, std::string* err) {
     std::unique_lock<std::mutex> lk(mu);
     queue.push_back(&req);
     stats.calls++;
+    pushed_since_round_end++;
+    if (regrouping) cv_arrive.notify_one();
     while (!req.done) {
       if (leader_active) {
         cv.wait(lk);
         continue;
       }
       leader_active = true;
+      if (regroup_pct > 0 && last_round_reqs > pushed_since_round_end) {
+        // the callers the last round released have not all come back yet
+        const size_t target = queue.size() + (last_round_reqs - pushed_since_round_end);
+        double budget_us = last_round_us * (double)regroup_pct / 100.0;
+        if (budget_us > 2000.0) budget_us = 2000.0;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds((int64_t)budget_us);
+        regrouping = true;
+        while (queue.size() < target && cv_arrive.wait_until(lk, deadline) != std::cv_status::timeout) {
+        }
+        regrouping = false;
+      }
       if (wait_us > 0 && queue.size() == 1) {
         // a lone leader may wait for company (off by default): the others queue up behind leader_active
         lk.unlock();
@@ -240,10 +262,19 @@ struct Combiner {
         if (g.total > stats.max_group) stats.max_group = g.total;
       }
       lk.unlock();
+      const auto t_round = std::chrono::steady_clock::now();
       run_round(groups);
+      const double round_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_round).count();
       lk.lock();
+      size_t released = 0;
       for (Group& g : groups)
-        for (CombineReq* r : g.reqs) r->done = true;
+        for (CombineReq* r : g.reqs) {
+          r->done = true;
+          released++;
+        }
+      last_round_reqs = released;
+      last_round_us = round_us;
+      pushed_since_round_end = 0;
       leader_active = false;
       cv.notify_all();
     }

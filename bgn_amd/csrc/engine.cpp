@@ -267,6 +267,22 @@ bool ctx_free_memory(bgn_ctx* c, size_t* free_bytes, size_t reclaimable = 0) {
   return true;
 }
 
+// Default size rule of the per-key tables (include/bgn_amd.h "Device memory"): a table may take up to 1 / share_den
+// of the device's TOTAL memory — a constant of the device, so the same key gets the same tables whatever else is
+// resident and in whatever order the tables are built — and what is free right now (under a budget: what the budget
+// leaves) only clamps it from above.  `reclaimable` as in ctx_free_memory.
+size_t ctx_table_cap(bgn_ctx* c, size_t share_den, size_t reclaimable = 0) {
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+  size_t cap = tot / share_den;
+  size_t avail = 0;
+  if (ctx_free_memory(c, &avail, reclaimable)) {
+    // ... to half of it: the other tables of the key and the workspace of the calls that will use them come next
+    if (cap > avail / 2) cap = avail / 2;
+  }
+  return cap;
+}
+
 // Give MultPoly's cached line tables back (before sizing another large table against the free memory).
 void release_poly_tables(bgn_ctx* c) {
   if (!c->poly_tab) return;
@@ -280,11 +296,15 @@ void release_poly_tables(bgn_ctx* c) {
 // Miller step for every ciphertext paired with the key.  BGN_FIXED_NORMALIZE=0 keeps (a, b, c).
 bool fixed_normalize_enabled(const bgn_ctx* c) { return opt(c, &Options::fixed_normalize) != 0; }
 int normalize_key_table(bgn_ctx* c, uint32_t* tab, size_t steps) {
+  // (the prefix products of the secret order's table are secret-derived: accounted, and wiped before they go back)
   uint32_t* pfx = nullptr;
-  if (hipMalloc((void**)&pfx, steps * (size_t)c->nl * 4) != hipSuccess) return fail(BGN_E_NOMEM, "line-table scratch");
+  if (ctx_malloc(c, (void**)&pfx, steps * (size_t)c->nl * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(BGN_E_NOMEM, "line-table scratch");
+  }
   c->kt->fixedpair_normalize(nullptr, c->d_params, tab, steps, pfx, c->p_bits + 1);
   hipError_t e = hipDeviceSynchronize();
-  (void)hipFree(pfx);
+  (void)ctx_wipe_free(c, pfx);
   if (e != hipSuccess) return fail(BGN_E_HIP, "fixedpair_normalize: %s", hipGetErrorString(e));
   return BGN_OK;
 }
@@ -684,6 +704,9 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   c->bsgs_slots = 0;
   (void)ctx_wipe_free(c, c->d_tabV);
   c->d_tabV = nullptr;
+  (void)ctx_wipe_free(c, c->d_gt);                   // g = e(P,P)^sk and gamma^-1 of the previous secret
+  c->d_gt = nullptr;
+  if (c->arena) (void)hipMemset(c->arena, 0, c->arena_bytes);   // the workspace held ct^sk values of earlier Decrypts
   HIP_TRY(ctx_malloc(c, (void**)&c->d_sk, q1_len));
   HIP_TRY(hipMemcpy(c->d_sk, q1_be, q1_len, hipMemcpyHostToDevice));
   c->sk_len = q1_len;
@@ -715,16 +738,19 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if ((double)B < sq) B++;
   const uint64_t Mmax = B * B + B + 2;
   uint64_t S = 2;
-  // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Take up to a
-  // third of the free HBM, at most 2^31 steps (69 GB; the slot's value field holds j <= 2^31);
-  // BGN_BSGS_MAX_LOG2 overrides (4..31).  The build takes 0.73 s at 2^31 entries (two products per entry).
+  // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Default: at most 2^31 steps
+  // (69 GB; the slot's value field holds j <= 2^31) within a quarter of the device's total memory — on a 288-GB
+  // MI355X that IS 2^31: profiles/r04_decrypt_vs_table.csv has decrypts/s and set-up time for 2^24 .. 2^31 entries at
+  // T = 2^40 (the walk is (T / 2S) products per ciphertext beside a lift of ~3.8 k products, so every halving of the
+  // table below 2^31 is paid in Decrypt's rate).  Free memory — under a budget, what the budget leaves — only clamps.
+  // Option bsgs_max_log2 overrides (4..31).  The build takes 0.73 s at 2^31 entries (two products per entry).
   int cap_log2 = 31;
   {
-    // (the table this call replaces counts as free; under a memory budget "free" is what the budget leaves)
-    size_t free_b = 0;
+    // (the table this call replaces counts as free)
     const size_t old_table = c->d_table ? (size_t)c->bsgs_slots * sizeof(BsgsSlot) : 0;
-    if (ctx_free_memory(c, &free_b, old_table))
-      while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > free_b / 3) cap_log2--;
+    const size_t cap = ctx_table_cap(c, 4, old_table);
+    if (cap)
+      while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > cap) cap_log2--;
   }
   {
     const int64_t v = opt(c, &Options::bsgs_max_log2);
@@ -839,7 +865,8 @@ static int pairing_run(const bgn_ctx* c, size_t count) {
 }
 
 static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
-                         size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len);
+                         size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len,
+                         bool first_piece, bool last_piece);
 
 // Small batches go to the wave-cooperative kernel (coop/coop.hpp: one pairing per workgroup of eight waves) —
 // a lane of k_pairing runs a whole pairing alone, so any batch below one wave per SIMD (65536 pairings) costs
@@ -920,6 +947,20 @@ static size_t quad_table_limit(const bgn_ctx* c, int mode) {
   return c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 16384;
 }
 
+// MultConst with per-element scalars on the lane groups (quad/quad_g1.hpp: sixteen lanes per element, level 1 a
+// windowed Jacobian ladder, level 2 a windowed power in F_p^2): from ONE element on — there is no cooperative variant,
+// and a lone lane of k_g1_mul / k_gt_pow needs the latency of a whole ladder (96 ms for a 1024-bit scalar at a
+// 1024-bit key) — up to where one element per lane fills the chip better (profiles/r04_multconst_mid_batch.csv).
+// A larger batch is cut into whole rounds of 65536 lanes for the lane kernel and a remainder that comes back here.
+// Option quad_max_mc overrides (0: never).
+static size_t quad_mc_limit(const bgn_ctx* c) {
+  const int64_t ov = opt(c, &Options::quad_max_mc);
+  if (ov >= 0) return (size_t)ov;
+  if (quad_g1_mul_ws_words(c->nl, 64, 1) == 0) return 0;             // no instantiation for this limb count
+  if (c->nl > 40) return kMaxBatch;                                   // 72 limbs: the lane kernels are the functional fallback
+  return c->nl >= 36 ? 40000 : c->nl >= 19 ? 36000 : 24576;
+}
+
 static size_t quad_table_floor(const bgn_ctx* c, int mode) {
   if (opt(c, &Options::quad_min) >= 0) return (size_t)opt(c, &Options::quad_min);
   // an explicit cooperative limit alone keeps its A/B meaning (cooperative below it, lane kernel above)
@@ -974,8 +1015,10 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
   for (size_t off = 0; off < count;) {
     size_t n = count - off < piece ? count - off : piece;
     n = lane_rounds_head(c, n, mode);
+    // the measurement hooks span the whole call: first event on the head piece, second on the last one; the kernel
+    // reported is the head piece's (it does nearly all the work of a batch cut into rounds + remainder)
     int rc = pairing_chunk(c, n, a + off * eb, n, b ? b + off * eb : nullptr, b ? n : 0, mode, d1, d2, out + off * eb, s,
-                           r_be ? r_be + off * r_len : nullptr, r_len);
+                           r_be ? r_be + off * r_len : nullptr, r_len, off == 0, off + n >= count);
     if (rc) return rc;
     off += n;
   }
@@ -985,7 +1028,8 @@ static int pairing_common(bgn_ctx* c, size_t count, const uint8_t* a, size_t na,
 }
 
 static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, const uint8_t* b, size_t nb, int mode,
-                         size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len) {
+                         size_t d1, size_t d2, uint8_t* out, hipStream_t s, const uint8_t* r_be, size_t r_len,
+                         bool first_piece, bool last_piece) {
   std::lock_guard<std::mutex> lk(c->mu);
   StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
@@ -1026,7 +1070,8 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   }
   kt->decode(s, c->d_params, a, c->L, na, A);
   if (nb) kt->decode(s, c->d_params, b, c->L, nb, B);
-  HIP_TRY(hipEventRecord(c->ev0, s));
+  if (first_piece) HIP_TRY(hipEventRecord(c->ev0, s));
+  const char* kname = "";
   // coop_fermat=1: the one-launch form with the Fermat inversion on the waves (A/B measurements)
   const bool cf = opt(c, &Options::coop_fermat) == 1;
   // makeL2 on the waves walks the key's normalised line table (6 / 4 products per step in 2 / 3 rounds instead of
@@ -1034,17 +1079,20 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   const uint32_t* ctab = (mode == 1 && coop_table_walk(c)) ? c->d_fixedpair : nullptr;
   if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0, ws, so, c->p_bits + 1,
                                   quad_tab ? c->d_fixedpair : nullptr)) {
-    c->last_kernel = quad_pairing_kernel_name(c->nl);
+    kname = quad_pairing_kernel_name(c->nl);
   } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
                                          cf ? nullptr : ws, so, c->p_bits + 1, ctab)) {
-    c->last_kernel = coop_pairing_kernel_name(c->nl);
+    kname = coop_pairing_kernel_name(c->nl);
   } else {
     kt->pairing(s, c->d_params, c->d_consts, A, B, O, count, mode, d1, d2, pairing_run(c, count), ws, so,
                 (mode == 1) ? c->d_fixedpair : nullptr, 1, (mode == 1) ? (c->fixed_normalized ? 2 : 0) : 0);
-    c->last_kernel = kt->pairing_kernel_name;
+    kname = mode == 1 ? kt->pairing_table_kernel_name : kt->pairing_kernel_name;
   }
-  HIP_TRY(hipEventRecord(c->ev1, s));
-  c->ev_valid = true;
+  if (first_piece) c->last_kernel = kname;
+  if (last_piece) {
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->ev_valid = true;
+  }
   if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);      // res.Mul(res, e(Q,Q)^r), bgn.go:302-311
   kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
   HIP_TRY(hipGetLastError());
@@ -1218,6 +1266,7 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
   a.ox = O.c0; a.oy = O.c1; a.oinf = O.inf; a.so = O.stride;
   a.count = count;
   a.wtab = nullptr; a.winf = nullptr; a.wcap = 0;
+  a.only = nullptr; a.only_mask = 0;
   // per-element bases with scalars of 128 bits and more: 4-bit windows over a table of 1*B .. 15*B per element
   // (ops.hpp), 12 KB of scratch each (measured at 2^16 elements: 1.4x at 256 bits, 1.67x at 1024 bits, 0.9x at
   // 64 bits); BGN_G1_MUL_WINDOW=0 keeps the binary ladder
@@ -1266,10 +1315,9 @@ int fixed_window_bits(bgn_ctx* c) {
     if (v == 8 || v == 16) wbits = (int)v;
   }
   if (wbits == 16) {   // fall back to the small layout when the device is short of memory
-    size_t fr = 0;
     const size_t W = (size_t)(c->n.bits() + 15) / 16 + 1;
     const size_t need = 2 * (W << 16) * 2 * (size_t)c->nl * 4;
-    if (!ctx_free_memory(c, &fr) || fr < 4 * need) wbits = 8;
+    if (ctx_table_cap(c, 4) < need) wbits = 8;
   }
   return wbits;
 }
@@ -1278,8 +1326,9 @@ int fixed_window_bits(bgn_ctx* c) {
 // of it is used by every encryption: 20-bit windows (52 additions instead of 64 at a 1024-bit key) for 17 GB
 // of HBM.  BGN_FIXED_WINDOW_BITS_Q overrides (8..22); never narrower than P's table.
 int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
-  // (22-bit windows: 47 windows instead of 52 at a 1024-bit key, 60 GB; measured +7 % on Encrypt over 20 bits —
-  // taken when a quarter of the free HBM holds the table, which the loop below checks)
+  // (22-bit windows: 47 windows instead of 52 at a 1024-bit key, 60 GB; measured +7 % on Encrypt over 20 bits,
+  // profiles/r04_encrypt_vs_window.csv — the default wherever a quarter of the device's total memory holds the table,
+  // which on a 288-GB MI355X it does; free memory or a budget only clamp, by the loop below)
   int wbits = wbits_p == 16 ? 22 : wbits_p;
   {
     const int64_t v = opt(c, &Options::fixed_window_bits_q);
@@ -1287,10 +1336,9 @@ int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
   }
   if (wbits < wbits_p) wbits = wbits_p;
   while (wbits > wbits_p) {
-    size_t fr = 0;
     const size_t W = (size_t)(c->n.bits() + wbits - 1) / wbits + 1;
     const size_t need = (W << wbits) * 2 * (size_t)c->nl * 4;
-    if (ctx_free_memory(c, &fr) && fr >= 4 * need) break;
+    if (ctx_table_cap(c, 4) >= need) break;
     wbits--;
   }
   return wbits;
@@ -1351,6 +1399,7 @@ int ensure_fixed_tables(bgn_ctx* c) {
     a.ox = pw.c0 + o; a.oy = pw.c1 + o; a.oinf = pw.inf + o; a.so = pw.stride;
     a.count = np[b];
     a.wtab = nullptr; a.winf = nullptr; a.wcap = 0;
+  a.only = nullptr; a.only_mask = 0;
     kt->g1_mul(nullptr, c->d_params, c->d_consts, a);
   }
   kt->to_mont(nullptr, c->d_params, pw.c0, pw.c1, pw.stride, npt);
@@ -1712,8 +1761,13 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
     if (rc) return rc;
   }
   const size_t st = round_up(count, 64);
+  // the lane groups take up to quad_mc_limit elements (a whole small batch, or the remainder of a large one)
+  const size_t qlim = k_len <= 1024 ? quad_mc_limit(c) : 0;
+  const size_t qmax = round_up(count < qlim ? count : qlim, 64);
+  const size_t qws_bytes = !qlim ? 0 : 4 * (level == 1 ? quad_g1_mul_ws_words(c->nl, qmax, k_len) : quad_gt_pow_each_ws_words(c->nl, qmax));
   SoA2 A, O, T1, T2;
   uint32_t* prefix = nullptr;
+  uint32_t* qws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     if (level == 1) {
@@ -1723,6 +1777,7 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
       A = w.gt(st); O = w.gt(st);
       if (r_be) { T1 = w.gt(st); T2 = w.gt(st); }
     }
+    if (qws_bytes) qws = (uint32_t*)w.cv.take(qws_bytes);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
@@ -1730,12 +1785,63 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   }
   const KernelTable* kt = c->kt;
   kt->decode(s, c->d_params, a, c->L, count, A);
+  auto view = [](SoA2 v, size_t off) {
+    v.c0 += off;
+    v.c1 += off;
+    if (v.inf) v.inf += off;
+    return v;
+  };
+  HIP_TRY(hipEventRecord(c->ev0, s));
+  c->last_kernel = "";
+  for (size_t off = 0; off < count;) {
+    // res.PowBig(c.C, constant), bgn.go:258 / :277.  The lane kernels run one element per lane, rounds of 65536:
+    // whole rounds go to them, what the lane groups can take goes there.
+    size_t n = count - off;
+    bool quad = qws && n <= qlim;
+    if (!quad && qws && opt(c, &Options::split_rounds) != 0) {
+      const size_t rem = n % 65536;
+      if (rem && rem <= qlim && n > rem) n -= rem;
+    }
+    const SoA2 Av = view(A, off), Ov = view(O, off);
+    const uint8_t* kv = k_be + off * k_len;
+    const char* kname = nullptr;
+    if (quad && level == 1) {
+      uint8_t* flags = quad_g1_mul_launch(c->nl, s, c->d_params, Av, kv, k_len, k_len, Ov, n, qws, round_up(n, 64), c->p_bits + 1);
+      if (flags) {
+        // the elements whose ladder met an exceptional case of the formulas (flag bit 1): the exact lane kernel
+        G1MulArgs g;
+        g.bx = Av.c0; g.by = Av.c1; g.binf = Av.inf; g.sb = Av.stride;
+        g.bdiv = 0;
+        g.k = kv; g.kstride = k_len; g.klen = k_len;
+        g.ox = Ov.c0; g.oy = Ov.c1; g.oinf = Ov.inf; g.so = Ov.stride;
+        g.count = n;
+        g.wtab = nullptr; g.winf = nullptr; g.wcap = 0;
+        g.only = flags; g.only_mask = 2u;
+        kt->g1_mul(s, c->d_params, c->d_consts, g);
+        kname = "k_g1_mul_quad";
+      } else {
+        quad = false;
+      }
+    } else if (quad) {
+      if (quad_gt_pow_each_launch(c->nl, s, c->d_params, Av.c0, Av.c1, Av.stride, kv, k_len, k_len, Ov.c0, Ov.c1, Ov.stride, n, qws))
+        kname = "k_gt_pow_quad_each";
+      else
+        quad = false;
+    }
+    if (!quad) {
+      if (level == 1) g1_mul_launch(c, s, Av, kv, k_len, k_len, Ov, n);
+      else gt_pow_launch(c, s, Av, kv, k_len, k_len, Ov, n);
+      kname = level == 1 ? "k_g1_mul" : "k_gt_pow";
+    }
+    if (off == 0) c->last_kernel = kname;
+    off += n;
+  }
+  HIP_TRY(hipEventRecord(c->ev1, s));
+  c->ev_valid = true;
   if (level == 1) {
-    g1_mul_launch(c, s, A, k_be, k_len, k_len, O, count);                       // res.PowBig(c.C, constant), bgn.go:258
     if (r_be) blind_l1(c, s, O, r_be, r_len, T1, T2, prefix, count);            // bgn.go:260-268
     kt->encode(s, O.inf, O.c0, O.c1, O.stride, c->L, count, out);
   } else {
-    gt_pow_launch(c, s, A, k_be, k_len, k_len, O, count);                       // bgn.go:277
     if (r_be) blind_l2(c, s, O, r_be, r_len, T1, T2, count);                    // bgn.go:279-287
     kt->encode(s, nullptr, O.c0, O.c1, O.stride, c->L, count, out);
   }
@@ -2146,7 +2252,8 @@ int bgn_multconst_batch(bgn_ctx* c, size_t count, int level, const uint8_t* a, c
 }
 
 // ---- Decrypt ---------------------------------------------------------------------------------
-static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status, void* stream);
+static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status, void* stream,
+                         bool first_piece, bool last_piece);
 
 // The level-1 lift runs on the lane kernel like Mult: whole rounds of it first, the remainder as a piece of its own
 // on whichever kernel is fastest at its size (lane_rounds_head).
@@ -2180,16 +2287,20 @@ int bgn_decrypt_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* ct
   const size_t eb = (size_t)2 * c->L;
   for (size_t off = 0; off < count;) {
     const size_t n = decrypt_rounds_head(c, count - off, level);
-    int rc = decrypt_piece(c, n, level, ct + off * eb, m + off, status + off, stream);
+    int rc = decrypt_piece(c, n, level, ct + off * eb, m + off, status + off, stream, off == 0, off + n >= count);
     if (rc) return rc;
     off += n;
   }
   return BGN_OK;
 }
 
-static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status, void* stream) {
+static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct, int64_t* m, uint8_t* status, void* stream,
+                         bool first_piece, bool last_piece) {
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(c->mu);
+  // (the entry point checked these without the lock; a bgn_ctx_set_secret between two pieces must not leave this
+  // piece walking a freed table)
+  if (!c->have_secret || !c->have_tables) return fail(BGN_E_STATE, "secret key or DL tables replaced during the call");
   StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   const size_t st = round_up(count, 64);
@@ -2221,7 +2332,8 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
     // lift to GT: e(C, P) — the discrete log is the same (see bsgs.hpp).  With the secret-order table the
     // lift is f_{q2,q1*P}(phi(C))^((p-1)*l), which the power by q1 below turns into the same e(C, P)^q1.
     const bool sk_tab = c->d_fixedpair_sk != nullptr;
-    HIP_TRY(hipEventRecord(c->ev2, s));
+    if (first_piece) HIP_TRY(hipEventRecord(c->ev2, s));
+    const char* aname = "";
     // a small batch lifts with the wave-cooperative kernel over the same line table (two or three rounds of products
     // per step instead of a whole table loop on a single lane: 28 ms at a 1024-bit key); the power by q1 below
     // gives the same e(C, P)^q1 whichever scalar the loop ran over
@@ -2230,19 +2342,21 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
     if (ctab && count > quad_table_floor(c, 2) && count <= quad_table_limit(c, 2) &&
         quad_pairing_launch(c->nl, s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0, pws,
                             st, c->p_bits + 1, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair)) {
-      c->aux_kernel = quad_pairing_kernel_name(c->nl);
+      aname = quad_pairing_kernel_name(c->nl);
     } else if (count <= coop_limit(c, 2) &&
         coop_pairing_launch(c->nl, s, c->d_params, (ctab && sk_tab) ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1,
                             0, 0, pws, st, c->p_bits + 1, ctab ? (sk_tab ? c->d_fixedpair_sk : c->d_fixedpair) : nullptr)) {
-      c->aux_kernel = coop_pairing_kernel_name(c->nl);
+      aname = coop_pairing_kernel_name(c->nl);
     } else {
       kt->pairing(s, c->d_params, sk_tab ? c->d_consts_sk : c->d_consts, A, c->key_P(), X, count, 1, 0, 0,
                   pairing_run(c, count), pws, st, sk_tab ? c->d_fixedpair_sk : c->d_fixedpair, 1, c->fixed_normalized ? 2 : 0);
-      c->aux_kernel = c->nl == 37 ? "k_pairing<37, 1>" : c->nl == 36 ? "k_pairing<36, 1>" : c->nl == 19 ? "k_pairing<19, 1>"
-                                    : c->nl == 10 ? "k_pairing<10, 1>" : "k_pairing<3, 1>";
+      aname = kt->pairing_table_kernel_name;
     }
-    HIP_TRY(hipEventRecord(c->ev3, s));
-    c->ev2_valid = true;
+    if (first_piece) c->aux_kernel = aname;
+    if (last_piece) {
+      HIP_TRY(hipEventRecord(c->ev3, s));
+      c->ev2_valid = true;
+    }
     kt->to_mont(s, c->d_params, X.c0, X.c1, X.stride, count);
     base = X;
   }
@@ -2273,13 +2387,17 @@ static int decrypt_piece(bgn_ctx* c, size_t count, int level, const uint8_t* ct,
   a.todo = todo; a.todo_count = todo_count;
   a.count = count;
   a.mode = 0;
-  HIP_TRY(hipEventRecord(c->ev0, s));
+  // (the walk's events bracket the LAST piece's two searches: with the lift's events spanning the call, a walk
+  // event on the first piece would span the later pieces' lifts as well)
+  if (last_piece) HIP_TRY(hipEventRecord(c->ev0, s));
   kt->bsgs_search(s, c->d_params, c->bsgs, a);                                       // getDL, gsbs.go:54-106
   a.mode = 1;
   kt->bsgs_search(s, c->d_params, c->bsgs, a);                                       // retry on Neg(ct), bgn.go:235-242
-  HIP_TRY(hipEventRecord(c->ev1, s));
-  c->ev_valid = true;
-  c->last_kernel = kt->bsgs_kernel_name;
+  if (last_piece) {
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->ev_valid = true;
+    c->last_kernel = kt->bsgs_kernel_name;
+  }
   HIP_TRY(hipGetLastError());
   return BGN_OK;
 }
@@ -2318,9 +2436,10 @@ int bgn_decrypt_batch(bgn_ctx* c, size_t count, int level, const uint8_t* ct, in
 namespace {
 size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
   if (opt(c, &Options::poly_tables) == 0) return 0;
-  size_t fr = 0;
-  if (!ctx_free_memory(c, &fr, c->poly_tab_bytes)) return 0;   // the cached tables count as free
-  size_t budget = fr / 3;
+  // one whole round of 65536 tables is 38 GB at a 1024-bit key: up to a sixth of the device's total memory (48 GB
+  // on MI355X), clamped by what is free (the cached tables count as free)
+  size_t budget = ctx_table_cap(c, 6, c->poly_tab_bytes);
+  if (!budget) return 0;
   {
     const int64_t v = opt(c, &Options::poly_table_max_mb);
     if (v > 0 && ((size_t)v << 20) < budget) budget = (size_t)v << 20;
@@ -2898,7 +3017,7 @@ int combine_call(bgn_ctx* c, int op, int level, size_t count, CombArr in0, CombA
   int64_t cap = opt(c, &Options::combine_max_batch);
   if (cap < (int64_t)count) cap = (int64_t)count;
   std::string err;
-  const int rc = cb->submit(req, (size_t)cap, opt(c, &Options::combine_wait_us), &err);
+  const int rc = cb->submit(req, (size_t)cap, opt(c, &Options::combine_wait_us), opt(c, &Options::combine_regroup_pct), &err);
   if (rc) return fail(rc, "%s", err.c_str());
   return BGN_OK;
 }

@@ -1,5 +1,6 @@
 // kern_quad.hip — instantiations of the lane-group pairing kernel (quad/quad.hpp).
 #include "quad/quad.hpp"
+#include "quad/quad_g1.hpp"
 #include "quad/quad_api.hpp"
 #include "coop/coop.hpp"
 
@@ -68,6 +69,100 @@ bool quad_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_
     case 36: launch_pow<36>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
     case 37: launch_pow<37>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
     case 72: launch_pow<72>(s, params, a0, a1, sa, k, klen, o0, o1, so, count); return true;
+  }
+  return false;
+}
+
+// ---- per-element powers (quad/quad_g1.hpp) -------------------------------------------------------------------------
+namespace {
+// workspace of the G1 scalar multiplication, in u32 words: tables | parked X, Y | Z limbs | 1/Z limbs | digits | flags
+template <int NL>
+struct G1Ws {
+  size_t tab, park, zsoa, isoa, dig, flags, total;
+  G1Ws(size_t sw, size_t klen) {
+    const size_t nwin = 2 * klen + 1;
+    tab = 0;
+    park = tab + g1q_table_words<NL>() * sw;
+    zsoa = park + g1q_park_words<NL>() * sw;
+    isoa = zsoa + (size_t)NL * sw;
+    dig = isoa + (size_t)NL * sw;
+    flags = dig + (nwin * sw + 3) / 4;
+    total = flags + (sw + 3) / 4;
+  }
+};
+
+template <int NL>
+uint8_t* launch_g1_mul(hipStream_t s, const void* params, SoA2 B, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
+                       size_t count, uint32_t* ws, size_t sw, int p_bits) {
+  const FpParams<NL>* P = (const FpParams<NL>*)params;
+  const G1Ws<NL> L(sw, klen);
+  signed char* dig = reinterpret_cast<signed char*>(ws + L.dig);
+  uint8_t* flags = reinterpret_cast<uint8_t*>(ws + L.flags);
+  const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
+  hipLaunchKernelGGL(k_recode_w4, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k, kstride, klen, dig, sw, count);
+  hipLaunchKernelGGL((k_g1_mul_quad<NL>), grid, block, 0, s, P, B.c0, B.c1, B.inf, B.stride, dig, (int)(2 * klen + 1), sw,
+                     ws + L.tab, ws + L.park, ws + L.zsoa, sw, flags, count);
+  hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P,
+                     ws + L.zsoa, ws + L.isoa, sw, count, p_bits);
+  hipLaunchKernelGGL((k_g1_aff_quad<NL>), grid, block, 0, s, P, ws + L.park, ws + L.isoa, sw, flags, O.c0, O.c1, O.inf, O.stride,
+                     count);
+  return flags;
+}
+
+template <int NL>
+void launch_gt_pow_each(hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa, const uint8_t* k,
+                        size_t kstride, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count, uint32_t* ws) {
+  hipLaunchKernelGGL((k_gt_pow_quad_each<NL>), dim3((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), dim3(QUAD_BLOCK), 0,
+                     s, (const FpParams<NL>*)params, a0, a1, sa, k, kstride, klen, ws, o0, o1, so, count);
+}
+}  // namespace
+
+size_t quad_g1_mul_ws_words(int nl, size_t sw, size_t klen) {
+  switch (nl) {
+    case 10: return G1Ws<10>(sw, klen).total;
+    case 19: return G1Ws<19>(sw, klen).total;
+    case 36: return G1Ws<36>(sw, klen).total;
+    case 37: return G1Ws<37>(sw, klen).total;
+    case 72: return G1Ws<72>(sw, klen).total;
+  }
+  return 0;
+}
+
+uint8_t* quad_g1_mul_launch(int nl, hipStream_t s, const void* params, SoA2 B, const uint8_t* k, size_t kstride, size_t klen,
+                            SoA2 O, size_t count, uint32_t* ws, size_t sw, int p_bits) {
+  if (!count || !ws || B.stride == 1 || klen > 1024) return nullptr;
+  switch (nl) {
+    case 10: return launch_g1_mul<10>(s, params, B, k, kstride, klen, O, count, ws, sw, p_bits);
+    case 19: return launch_g1_mul<19>(s, params, B, k, kstride, klen, O, count, ws, sw, p_bits);
+    case 36: return launch_g1_mul<36>(s, params, B, k, kstride, klen, O, count, ws, sw, p_bits);
+    case 37: return launch_g1_mul<37>(s, params, B, k, kstride, klen, O, count, ws, sw, p_bits);
+    case 72: return launch_g1_mul<72>(s, params, B, k, kstride, klen, O, count, ws, sw, p_bits);
+  }
+  return nullptr;
+}
+
+size_t quad_gt_pow_each_ws_words(int nl, size_t sw) {
+  switch (nl) {
+    case 10: return gtq_table_words<10>() * sw;
+    case 19: return gtq_table_words<19>() * sw;
+    case 36: return gtq_table_words<36>() * sw;
+    case 37: return gtq_table_words<37>() * sw;
+    case 72: return gtq_table_words<72>() * sw;
+  }
+  return 0;
+}
+
+bool quad_gt_pow_each_launch(int nl, hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa,
+                             const uint8_t* k, size_t kstride, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count,
+                             uint32_t* ws) {
+  if (!count) return true;
+  if (!ws || sa == 1 || !klen || klen > 1024) return false;
+  switch (nl) {
+    case 10: launch_gt_pow_each<10>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count, ws); return true;
+    case 19: launch_gt_pow_each<19>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count, ws); return true;
+    case 36: launch_gt_pow_each<36>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count, ws); return true;
+    case 37: launch_gt_pow_each<37>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count, ws); return true;
+    case 72: launch_gt_pow_each<72>(s, params, a0, a1, sa, k, kstride, klen, o0, o1, so, count, ws); return true;
   }
   return false;
 }

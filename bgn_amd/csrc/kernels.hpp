@@ -79,6 +79,9 @@ struct G1MulArgs {
   // 4-bit fixed windows over a per-element table of 1*B .. 15*B (ops.hpp g1_scalarmul_win_lane): five arrays of
   // NL rows x 16*wcap u32 (x, y, Z, prefix, spare) behind wtab, 16*wcap identity flags behind winf; null: binary ladder
   uint32_t* wtab; uint8_t* winf; size_t wcap;
+  // non-null: only the elements e with only[e] & only_mask are computed and written (the exact lane kernel as the
+  // fallback of the lane-group scalar multiplication for the elements that kernel flagged: quad/quad_g1.hpp)
+  const uint8_t* only; unsigned only_mask;
 };
 
 // GT product / quotient and power (ops.hpp).
@@ -182,6 +185,7 @@ struct KernelTable {
   int nl;
   size_t params_bytes;   // sizeof(FpParams<NL>)
   const char* pairing_kernel_name;
+  const char* pairing_table_kernel_name;   // the mode-1 instantiation (walk over a key's line table)
 
   // wire bytes (2L per element, big-endian) -> SoA, canonical Montgomery form.
   void (*decode)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, SoA2 out);

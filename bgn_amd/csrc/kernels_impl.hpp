@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(FP_BLOCK)
 k_g1_mul(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1MulArgs A) {
   __shared__ LFp<NL> L[4];
   size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
-  const bool live = e < A.count;
+  const bool live = e < A.count && (!A.only || (A.only[e] & A.only_mask) != 0);
   // a wave without live lanes leaves: the windowed variant writes a per-element table, and a whole wave of
   // stand-ins for the last element would race with the wave that owns it (lanes of ONE wave run in lockstep
   // and write identical values, which is harmless)
@@ -832,6 +832,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       NL_,
       sizeof(FpParams<NL_>),
       "k_pairing<" BGN_STR(BGN_NL) ", 0>",
+      "k_pairing<" BGN_STR(BGN_NL) ", 1>",
       launch_decode,
       launch_decode_plain,
       launch_validate,

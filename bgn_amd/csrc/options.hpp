@@ -55,6 +55,8 @@ struct Options {
   V combine_max_count{1024};   // a call of more elements than this goes its own way
   V combine_max_batch{16384};  // elements per combined launch
   V combine_wait_us{0};    // a lone caller waits this long for company before it launches (0: never waits)
+  V combine_regroup_pct{10};   // a leader waits for the callers the last round released, at most this share of that
+                               // round's duration (0: never; a lone caller never waits either way)
   // ---- several devices (multi.cpp) ----
   V mctx_force_staging{0}; // every shard through the peer-copy path, also on the root device (tests on a one-GPU box)
   // ---- test hooks: reachable through bgn_ctx_set_option only, never from the environment ----
@@ -106,6 +108,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"combine_max_count", &Options::combine_max_count, true, nullptr},
       {"combine_max_batch", &Options::combine_max_batch, true, nullptr},
       {"combine_wait_us", &Options::combine_wait_us, true, nullptr},
+      {"combine_regroup_pct", &Options::combine_regroup_pct, true, nullptr},
       {"mctx_force_staging", &Options::mctx_force_staging, true, nullptr},
       {"test_bsgs_fp_bits", &Options::test_bsgs_fp_bits, false, nullptr},
       {"test_fail_mul_ws", &Options::test_fail_mul_ws, false, nullptr},

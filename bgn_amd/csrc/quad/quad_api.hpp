@@ -18,5 +18,21 @@ bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const Pairin
 bool quad_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa,
                         const uint8_t* k, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count);
 size_t quad_ws_words(int nl, size_t sw);
+// Per-element powers on the lane groups (quad_g1.hpp): MultConst of mid-size batches.
+// out[e] = k[e] * B[e] in G1: B canonical Montgomery SoA with identity flags (B.stride == 1 — one base — is not
+// served); k big-endian, klen <= 1024 bytes each, kstride apart; O plain canonical affine SoA with identity flags
+// (what KernelTable::g1_mul writes).  ws: quad_g1_mul_ws_words(nl, sw, klen) u32, sw >= count.  Four launches
+// (recoding, ladder, inversion of Z, affine coordinates).  Returns the per-element flag bytes inside ws — bit 1 set:
+// the formulas met an exceptional case and the caller recomputes that element with the lane kernel
+// (G1MulArgs::only, only_mask = 2) — or null when `nl` has no instantiation (nothing was launched).
+uint8_t* quad_g1_mul_launch(int nl, hipStream_t s, const void* params, SoA2 B, const uint8_t* k, size_t kstride, size_t klen,
+                            SoA2 O, size_t count, uint32_t* ws, size_t sw, int p_bits);
+size_t quad_g1_mul_ws_words(int nl, size_t sw, size_t klen);
+// out[e] = a[e]^k[e] in F_p^2 with per-element exponents (kstride 0: one for all): a canonical Montgomery SoA, out
+// PLAIN canonical SoA (what KernelTable::gt_pow writes); ws: quad_gt_pow_each_ws_words(nl, sw) u32.
+bool quad_gt_pow_each_launch(int nl, hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa,
+                             const uint8_t* k, size_t kstride, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count,
+                             uint32_t* ws);
+size_t quad_gt_pow_each_ws_words(int nl, size_t sw);
 const char* quad_pairing_kernel_name(int nl);
 }  // namespace bgn

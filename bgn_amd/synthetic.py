@@ -136,9 +136,11 @@ def limbs_for(p: int) -> int:
 
 
 def flush_instructions(nl: int) -> int:
-    """The mid-product carry pass of fp_mul / fp_sqr at radix 2^29 (fpmont.hpp fp_flush: add, mask, shift per
-    accumulator) from 32 limbs on; counted with the multiply-adds of a product (same issue cost)."""
-    return 3 * nl if nl > 19 else 0
+    """The mid-product carry passes of fp_mul / fp_sqr at radix 2^29 (fpmont.hpp fp_flush: add, mask, shift per
+    accumulator): a product runs in NI = ceil(NL / kRowsPerFlush) intervals of at most 19 rows with a flush between
+    them — none up to 19 limbs, one at 36 / 37, three at 72; counted with the multiply-adds of a product (same issue
+    cost)."""
+    return 3 * nl * (-(-nl // 19) - 1)
 
 
 def square_mads(nl: int, segments: int = 5) -> int:
@@ -181,8 +183,8 @@ def mads_from_counts(products: float, squares: float, nl: int = 36, segments: in
 
 
 def _run_for(count: int) -> int:
-    """Elements per lane of the batched-inversion kernels (engine.cpp run_for)."""
-    return max(1, min(64, -(-count // 65536)))
+    """Elements per lane of the batched-inversion kernels (engine.cpp run_for: the ceiling of count / 65536, no cap)."""
+    return max(1, -(-count // 65536))
 
 
 def eadd_counts(count: int):

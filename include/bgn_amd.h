@@ -85,14 +85,25 @@ const char* bgn_version(void);
 /* Device memory.  The reference keeps the decryption tables of every key it has seen (gsbs.go:12-15: package
  * globals filled by computeTableG1/GT, gsbs.go:41-51); here every per-key table (BSGS baby table, fixed-base window
  * tables of P and Q, GT window tables, MultPoly's line tables) and the batch workspace belong to the context.
- * bgn_ctx_memory_bytes: bytes of device memory the context holds now.
+ * Default sizes are a function of the key, of T and of the device's TOTAL memory — not of what happens to be free:
+ *   baby-step table   32 B per baby step, 2^ceil(log2(B*B + B + 3)) steps, at most 2^31 and at most 1/4 of the
+ *                     device (MI355X, T = 2^40: 2^31 steps = 69 GB; profiles/r04_decrypt_vs_table.csv is the
+ *                     decrypts/s and set-up time this buys against 2^24 .. 2^30)
+ *   windows of P      16-bit windows, 2 * NL * 4 B per entry (1024-bit key: 1.2 GB); the GT table of e(Q,Q) likewise
+ *   windows of Q      22-bit windows where 1/4 of the device holds them (1024-bit key: 60 GB), else the widest that
+ *                     fit (20 bits: 17 GB; profiles/r04_encrypt_vs_window.csv)
+ *   MultPoly tables   whole rounds of 65536 coefficient tables (38 GB at a 1024-bit key) within 1/6 of the device
+ *   workspace         7.4 KB per pairing of the largest batch seen (7.8 GB at 2^20)
+ * What is free at the moment of the call — under a budget, what the budget leaves — only clamps these from above
+ * (a table never takes more than half of it), so the same key gets the same tables in whatever order they are
+ * built, unless memory is short.  Options bsgs_max_log2, fixed_window_bits, fixed_window_bits_q, poly_table_max_mb
+ * choose smaller ones.
+ * bgn_ctx_memory_bytes: bytes of device memory the context holds now (the staging buffers of the combiner included;
+ * not included: the small per-device pool of staging buffers the host-buffer calls share, at most 32 x 4 MB).
  * bgn_ctx_set_memory_budget: a cap on that figure (0 = none, the default; BGN_CTX_MEMORY_BUDGET_MB sets a default
- * for every context).  Tables built afterwards are sized within it — the rules that otherwise take a share of the
- * device's free memory (a third for the baby table, a quarter for Q's windows, a third for MultPoly's tables) see no
- * more than the budget leaves — and an allocation that would exceed it fails with BGN_E_NOMEM like an exhausted
- * device; what the context already holds is not given back.  Set it right after bgn_ctx_create so that several
- * keys can share one GPU (a 1024-bit key with T = 2^40 takes up to 69 GB for the baby table, 17 - 60 GB for Q's
- * windows and 7.8 GB of workspace per 2^20-element batch without one). */
+ * for every context).  Tables built afterwards are sized within it and an allocation that would exceed it fails
+ * with BGN_E_NOMEM like an exhausted device; what the context already holds is not given back.  Set it right
+ * after bgn_ctx_create so that several keys can share one GPU. */
 uint64_t bgn_ctx_memory_bytes(bgn_ctx* c);
 int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes);
 

@@ -53,7 +53,7 @@ def test_encrypt_add_multconst_golden(key):
 @pytest.mark.parametrize("kernel", ["quad", "lane"])
 def test_mult_and_make_l2_golden(key, kernel, engopts):
     fx, pk, _ = key
-    eng = pk.engine
+    eng = engopts.register(pk.engine)
     big = "100000000"
     engopts.set("quad_min", "0")
     for v in ("quad_max", "quad_max_l2", "quad_max_dec", "quad_max_pow"):

@@ -191,6 +191,7 @@ def test_table_walk_and_power_on_the_lane_groups_match_the_other_kernels(name, c
                                fx["msg_space"], True, fx["poly_base"])
         sk = bgn_amd.SecretKey(int(fx["q1"], 16))
         pk.engine.set_memory_budget(40 << 30)
+        engopts.register(pk.engine)
     else:
         pk, sk = engine_key(fx)
     pk.SetupDecryption(sk)

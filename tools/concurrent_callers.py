@@ -4,6 +4,11 @@ point on ONE context in a loop (poly.go:139-153: one goroutine per coefficient p
 one op per call), with the combiner of concurrent small calls (csrc/combiner.hpp) on and off, and the latency of a
 lone caller either way.  ctypes releases the GIL inside the call, so the threads are concurrent inside the library.
 
+Two caller pools: `native` — tools/concurrent_callers.cpp, std::thread callers of the C ABI, what a Go host's
+goroutines look like to the library (run as a child process on inputs this script prepares) — and `python`, the same
+loop from Python threads (CC_PYTHON=1), where the interpreter lock spreads the callers' re-submissions over
+milliseconds.
+
     python tools/concurrent_callers.py [k1024] > profiles/r04_concurrent_callers.csv
 """
 import ctypes as C
@@ -23,6 +28,36 @@ import bgn_amd  # noqa: E402
 
 def P(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def native_rows(fx, key, eng, N, A, B, L2, K, xs, want_mult, want_add, seconds, threads_list, ops):
+    """Write the inputs, build the native caller pool and run it as a child process (it creates its own context)."""
+    import struct
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "tools", "concurrent_callers.cpp")
+    exe = os.path.join(ROOT, "tools", "_build", "concurrent_callers")
+    lib = os.path.join(ROOT, "bgn_amd", "lib")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-L" + lib,
+                               "-lbgn_amd", "-Wl,-rpath," + lib, "-o", exe])
+    want_mc = eng.multconst(1, A.tobytes(), [int.from_bytes(bytes(k), "big") for k in K])
+    ib = lambda v: int(v).to_bytes((int(v).bit_length() + 7) // 8, "big")
+    p, n, q1 = ib(int(fx["p"], 16)), ib(int(fx["n"], 16)), ib(int(fx["q1"], 16))
+    kb = key.encode()
+    blob = b"BGNCC1\0\0" + struct.pack("<IIQQIIII", eng.L, N, fx["l"], fx["msg_space"], len(p), len(n), len(q1), len(kb))
+    blob += p + n + q1 + bytes.fromhex(fx["P"]) + bytes.fromhex(fx["Q"])
+    blob += A.tobytes() + B.tobytes() + L2.tobytes() + K.tobytes() + want_mult.tobytes() + want_add.tobytes() + want_mc.tobytes()
+    blob += struct.pack("<%dq" % N, *xs[:N]) + kb
+    with tempfile.NamedTemporaryFile(suffix=".bgncc", delete=False) as f:
+        f.write(blob)
+        path = f.name
+    try:
+        sys.stdout.flush()
+        subprocess.check_call([exe, path, str(seconds), ",".join(str(t) for t in threads_list), ",".join(ops)])
+    finally:
+        os.unlink(path)
 
 
 def main():
@@ -76,8 +111,10 @@ def main():
         keep = (out, m, st, a, b, l2, k)
         return fn, args, keep
 
-    print("key,op,threads,combine,seconds,calls,calls_per_s,ms_per_call_per_thread,launch_groups,largest_group,check")
     ops = os.environ.get("CC_OPS", "mult,add_l1,decrypt_l1,multconst_l1_k40,add_l2,decrypt_l2").split(",")
+    native_rows(fx, key, eng, N, A, B, L2, K, xs, want_mult, want_add, seconds, threads_list, ops)
+    if os.environ.get("CC_PYTHON") != "1":
+        return
     for op in ops:
         for combine in (1, 0):
             eng.set_option("combine", combine)
@@ -123,7 +160,7 @@ def main():
                     ok = all(calls[t][2][0].tobytes() == want_add[t % N].tobytes() for t in range(T))
                 elif op == "decrypt_l1":
                     ok = all(int(calls[t][2][1][0]) == xs[t % N] and int(calls[t][2][2][0]) == 0 for t in range(T))
-                print("%s,%s,%d,%d,%.2f,%d,%.1f,%.3f,%d,%d,%s" % (
+                print("%s,%s,python,%d,%d,%.2f,%d,%.1f,%.3f,%d,%d,%s" % (
                     key, op, T, combine, dt, total, total / dt, dt / max(1, total) * T * 1e3,
                     s1["groups"] - s0["groups"], s1["max_group"], ok), flush=True)
     eng.set_option("combine", 1)

@@ -638,6 +638,114 @@ def build_quad_programs(w=QUAD_W):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# The lane-group kernel's G1 scalar multiplication (csrc/quad/quad_g1.hpp): MultConst with per-element scalars
+# ---------------------------------------------------------------------------------------------------------------
+# `res.PowBig(c.C, constant)` on level 1 (bgn.go:258) for mid-size batches: sixteen lanes per element, fixed signed
+# 4-bit windows over a per-element table of 1*B .. 8*B.  Jacobian coordinates with Z^2 carried along (X, Y, Z, ZZ);
+# the table entries are Jacobian too (X, Y, Z, ZZ, ZZZ = Z^3) — with four quads the full addition takes as many
+# rounds as the mixed one, so no inversion is spent on making them affine.  Every lane group of a wave runs the same
+# segment sequence (a window = four doublings, then one addition of the entry its own digit selects, its stores to
+# the state suppressed where the digit is zero or the accumulator still the identity).  The exceptional cases of the
+# formulas — a doubling of a point of order two, an addition of equal or opposite points — make Z zero and keep it
+# zero to the end, where the kernel tests it once and hands such an element to the exact lane kernel.
+G1_STATE_BOUNDS = {"X": 19, "Y": 19, "Z": 2, "ZZ": 2}
+G1_ENTRY_BOUNDS = {"tx": 19, "ty": 19, "tz": 2, "tzz": 2, "tzzz": 2}
+
+
+def build_quad_g1_programs(w=QUAD_W):
+    G = Program(w, w, reads_first=True)
+    st = {k: G.fixed(k, b) for k, b in G1_STATE_BOUNDS.items()}
+    T = {k: G.fixed(k, b) for k, b in G1_ENTRY_BOUNDS.items()}
+    zzz = G.fixed("zzz", 2)                                   # Z^3 of the state, for the table's entries
+    inplace = {k + "'": k for k in G1_STATE_BOUNDS}
+
+    def declare_new(b):
+        for k, v in G1_STATE_BOUNDS.items():
+            b.bound[k + "'"] = v
+
+    def seg_gdbl(b):
+        """Jacobian doubling, a = 1 (y^2 = x^3 + x): the point half of pairing.hpp miller_double, Z^4 made here."""
+        declare_new(b)
+        X, Y, Z, ZZ = st["X"], st["Y"], st["Z"], st["ZZ"]
+        XX = b.mul(X, X)
+        YY = b.mul(Y, Y)
+        Z3 = b.mul(2 * Y, Z, out="Z'")
+        Wq = b.mul(ZZ, ZZ)
+        M = 3 * XX + Wq
+        M2 = b.mul(M, M)
+        XYY = b.mul(X, YY)
+        Y4 = b.mul(YY, YY)
+        b.mul(Z3, Z3, out="ZZ'")
+        b.lin(M2 - 8 * XYY, out="X'")                                    # M^2 - 2S, S = 4 X YY
+        b.mul(M, 12 * XYY - M2, E=-8 * Y4, out="Y'")                     # M (S - X3) - 8 YY^2
+    G.segment("GDBL", seg_gdbl, inplace)
+
+    def seg_gadd(b):
+        """(X, Y, Z, ZZ) + (tx, ty, tz, tzz, tzzz), both Jacobian: U1 = X tzz, U2 = tx ZZ, S1 = Y tzzz, S2 = ty Z^3,
+        H = U2 - U1, r = S2 - S1, Z3 = Z tz H, X3 = r^2 - H^3 - 2 U1 H^2, Y3 = r (U1 H^2 - X3) - S1 H^3."""
+        declare_new(b)
+        X, Y, Z, ZZ = st["X"], st["Y"], st["Z"], st["ZZ"]
+        U1 = b.mul(X, T["tzz"])
+        U2 = b.mul(T["tx"], ZZ)
+        ZZZ = b.mul(Z, ZZ)
+        S1 = b.mul(Y, T["tzzz"])
+        S2 = b.mul(T["ty"], ZZZ)
+        ZtZ = b.mul(Z, T["tz"])
+        H = U2 - U1
+        r = S2 - S1
+        Z3 = b.mul(ZtZ, H, out="Z'")
+        HH = b.mul(H, H)
+        S1H = b.mul(S1, H)
+        HHH = b.mul(H, HH)
+        UHH = b.mul(U1, HH)
+        rr2 = b.mul(r, r)
+        SH3 = b.mul(S1H, HH)
+        b.lin(rr2 - HHH - 2 * UHH, out="X'")
+        b.mul(r, 3 * UHH + HHH - rr2, E=-SH3, out="Y'")
+        b.mul(Z3, Z3, out="ZZ'")
+    G.segment("GADD", seg_gadd, inplace)
+
+    def seg_gzzz(b):
+        b.mul(st["Z"], st["ZZ"], out="zzz")
+    G.segment("GZZZ", seg_gzzz)
+    G.allocate_temps()
+    # ---- the last launch: affine coordinates from the parked (X, Y) and R / Z of the inversion kernel, then the
+    # division by R (plain residues, as the ladder kernel of ops.hpp writes them)
+    A = Program(w, w, reads_first=True)
+    X, Y = A.fixed("X", 19), A.fixed("Y", 19)
+    zi = A.fixed("zi", 4)
+    raw1 = A.fixed("raw1", 1)
+    A.fixed("out0", 2)
+    A.fixed("out1", 2)
+
+    def seg_aff(b):
+        zi2 = b.mul(zi, zi)
+        zi3 = b.mul(zi2, zi)
+        xm = b.mul(X, zi2)
+        ym = b.mul(Y, zi3)
+        b.mul(xm, raw1, out="out0")
+        b.mul(ym, raw1, out="out1")
+    A.segment("AFF", seg_aff)
+    A.allocate_temps()
+    return G, A
+
+
+QUAD_G1_SLOTS = ("X", "Y", "Z", "ZZ", "tx", "ty", "tz", "tzz", "tzzz", "zzz")
+QUAD_AFF_SLOTS = ("X", "Y", "zi", "raw1", "out0", "out1")
+
+
+def emit_quad_g1(path, verbose=True):
+    G, A = build_quad_g1_programs()
+    emit(G, path, prefix="QUADG", round_headers=True, slot_names=QUAD_G1_SLOTS)
+    emit(A, path, prefix="QUADA", round_headers=True, slot_names=QUAD_AFF_SLOTS, append=True)
+    if verbose:
+        for P in (G, A):
+            print(summary(P))
+            print("slots:", P.nslots, "->", path)
+    return G, A
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Emission
 # ---------------------------------------------------------------------------------------------------------------
 def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, append=False):
@@ -656,7 +764,7 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, a
             rows.append(row)
             rnd += 1
     lines = []
-    what = "wave-cooperative pairing" if prefix == "COOP" else "lane-group pairing (csrc/quad/)"
+    what = "wave-cooperative pairing" if prefix == "COOP" else "lane-group kernels (csrc/quad/)"
     lines.append("// GENERATED by tools/coop/gen_prog.py — do not edit.  Micro-op tables of the %s." % what)
     lines.append("// %d segments, %d rounds of %d micro-ops, %d LDS value slots." % (len(P.segments), rnd, w, P.nslots))
     lines.append("#define %s_W %d" % (prefix, w))
@@ -772,3 +880,4 @@ if __name__ == "__main__":
     qpath = os.path.join(root, "bgn_amd", "csrc", "quad", "quad_prog.inc")
     os.makedirs(os.path.dirname(qpath), exist_ok=True)
     emit_quad(qpath)
+    emit_quad_g1(os.path.join(root, "bgn_amd", "csrc", "quad", "quad_g1_prog.inc"))

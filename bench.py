@@ -241,6 +241,19 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
          "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion), wire bytes to wire bytes",
          "kernel": eng.last_kernel_name(), "algorithmic_bytes_per_unit": 3 * EB},
         syn.eadd_counts(n_add), nl)
+    # HBM-side traffic of that call's four launches (k_decode_plain x 2, k_g1_add, k_encode) from the committed PMC
+    # passes of this command (tools/summarize_profiles.py), next to its algorithmic bytes
+    eadd_traffic, eadd_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+    if os.path.exists(pmc) and n_add == 1 << 20:
+        with open(pmc) as f:
+            eadd_traffic = json.load(f).get("eadd_l1", {}).get("hbm_bytes_per_call")
+        eadd_src = "profiles/r04_pmc_summary.json eadd_l1 (FETCH_SIZE + WRITE_SIZE of the call's four launches, KB * 1024)"
+    alg_add = 3 * EB * n_add
+    out["eadd_l1"]["roofline"] = {"bound": "hbm", "achieved": alg_add / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": alg_add / dt / 1e9 / HBM_PEAK_GBS, "traffic": eadd_traffic, "traffic_source": eadd_src,
+                                  "algorithmic_bytes_per_call": alg_add, "kernel": eng.last_kernel_name(),
+                                  "kernel_ms": eng.last_kernel_ms(), "call_ms": dt * 1e3}
     del o1, b1
     # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
     npoly, d1, d2 = 1 << 12, 16, 16
@@ -282,7 +295,8 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
             syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
         # the dominant kernel of Decrypt is the lift (k_pairing<NL, 1>), timed by HIP events on its stream
         traffic = None
-        for pname, key in (("r03_pmc_summary.json", "decrypt_lift_k_pairing_1"), ("r02_pmc_summary.json", "decrypt_lift_k_pairing_38_1")):
+        for pname, key in (("r04_pmc_summary.json", "decrypt_lift_k_pairing_1"), ("r03_pmc_summary.json", "decrypt_lift_k_pairing_1"),
+                           ("r02_pmc_summary.json", "decrypt_lift_k_pairing_38_1")):
             pmc = os.path.join(ROOT, "profiles", pname)
             if k == 20 and os.path.exists(pmc):                 # separate rocprofv3 --pmc passes of this command
                 with open(pmc) as f:
@@ -588,7 +602,7 @@ def main():
             fx, run=max(1, min(16, -(-count // 65536))),
             window={0: 2, 3: 3, 4: 4}.get(eng.get_option("miller_window"), 5))
         traffic, traffic_src = None, None
-        for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
+        for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and full:
                 with open(pmc) as f:

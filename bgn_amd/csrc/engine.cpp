@@ -1817,7 +1817,16 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
         g.count = n;
         g.wtab = nullptr; g.winf = nullptr; g.wcap = 0;
         g.only = flags; g.only_mask = 2u;
-        kt->g1_mul(s, c->d_params, c->d_consts, g);
+        const int64_t hook = opt(c, &Options::test_mc_fallback);
+        if (hook == 2) {                               // tests: how many elements did the lane groups flag?
+          std::vector<uint8_t> h(n);
+          HIP_TRY(hipStreamSynchronize(s));
+          HIP_TRY(hipMemcpy(h.data(), flags, n, hipMemcpyDeviceToHost));
+          int64_t flagged = 0;
+          for (uint8_t v : h) flagged += (v & 2u) ? 1 : 0;
+          c->opt.test_mc_flagged.store(flagged, std::memory_order_relaxed);
+        }
+        if (hook != 1) kt->g1_mul(s, c->d_params, c->d_consts, g);
         kname = "k_g1_mul_quad";
       } else {
         quad = false;

@@ -62,6 +62,8 @@ struct Options {
   // ---- test hooks: reachable through bgn_ctx_set_option only, never from the environment ----
   V test_bsgs_fp_bits{0};  // a table fingerprint of that many bits (false hits that the verification must reject)
   V test_fail_mul_ws{0};   // the allocation of the scalar-multiplication table fails (fallback path)
+  V test_mc_fallback{0};   // lane-group MultConst: 1 = skip the lane kernel's pass over the flagged elements; 2 = count
+  V test_mc_flagged{0};    // the flagged elements of the last call into this option (synchronises the stream)
 };
 
 struct OptionDesc {
@@ -112,6 +114,8 @@ inline const OptionDesc* option_table(size_t* n) {
       {"mctx_force_staging", &Options::mctx_force_staging, true, nullptr},
       {"test_bsgs_fp_bits", &Options::test_bsgs_fp_bits, false, nullptr},
       {"test_fail_mul_ws", &Options::test_fail_mul_ws, false, nullptr},
+      {"test_mc_fallback", &Options::test_mc_fallback, false, nullptr},
+      {"test_mc_flagged", &Options::test_mc_flagged, false, nullptr},
   };
   *n = sizeof t / sizeof t[0];
   return t;

@@ -4,7 +4,7 @@
 # rocprofv3 is given the program itself (python3 bench.py ...), never a launcher; counter passes are separate
 # from each other and carry no trace other than the kernel trace.
 set -o pipefail
-OUT=${1:-gpurun_out/r03_profiles}
+OUT=${1:-gpurun_out/r04_profiles}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "== bench (default line)"; python3 bench.py --steps 3 --warmup 1 > "$OUT/bench_line.json" 2> "$OUT/bench.err" || exit 1
@@ -24,11 +24,19 @@ echo "== mid-size batches: the three pairing kernels"; python3 tools/quad_sweep.
 echo "== the lane-group kernel saturated, beside the lane kernel"
 QUAD_SWEEP_COUNTS=1048576 QUAD_SWEEP_KERNELS=quad,lane python3 tools/quad_sweep.py k1024 > "$OUT/quad_saturated.csv" 2>> "$OUT/mid.err" || exit 1
 echo "== single-call latencies"; python3 tools/single_op_latency.py > "$OUT/single_op_latency.csv" 2> "$OUT/single.err" || exit 1
+echo "== concurrent single-element callers (the reference's call shape), combiner on / off"
+CC_SECONDS=3 python3 tools/concurrent_callers.py k1024 > "$OUT/concurrent_callers.csv" 2> "$OUT/concurrent.err" || exit 1
+echo "== MultConst by batch size: lane groups against one element per lane"
+python3 tools/multconst_mid_batch.py k1024 k512 > "$OUT/multconst_mid_batch.csv" 2> "$OUT/multconst.err" || exit 1
+echo "== EAdd by batch size"; python3 tools/eadd_sweep.py > "$OUT/eadd_sweep.csv" 2> "$OUT/eadd.err" || exit 1
+echo "== what the default table sizes buy"
+python3 tools/decrypt_vs_table.py > "$OUT/decrypt_vs_table.csv" 2> "$OUT/dvt.err" || exit 1
+python3 tools/decrypt_vs_table.py encrypt > "$OUT/encrypt_vs_window.csv" 2>> "$OUT/dvt.err" || exit 1
 find "$OUT" -name "*.csv" | head -40
 # keep the merge small: the raw traces are not needed
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
-# the counter files of the runs with extras list every dispatch: keep the pairing kernels only
+# the counter files of the runs with extras list every dispatch: keep Decrypt's lift and the kernels of an EAdd call
 for f in "$OUT"/pmc_fetch_extra/fetch_counter_collection.csv "$OUT"/pmc_write_extra/write_counter_collection.csv; do
-  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 1>" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
+  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 1>|k_g1_add<|k_decode_plain<|k_encode<" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
 done
 du -sh "$OUT"

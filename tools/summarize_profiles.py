@@ -21,7 +21,8 @@ def last_json_line(path):
 shutil.copy(os.path.join(src, "prof_bench", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "prof_extra", "extra_kernel_stats.csv"), os.path.join(dst, f"{tag}_extra_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "small_batch.csv"), os.path.join(dst, f"{tag}_small_batch.csv"))
-for extra_csv in ("mid_batch.csv", "quad_saturated.csv", "single_op_latency.csv"):
+for extra_csv in ("mid_batch.csv", "quad_saturated.csv", "single_op_latency.csv", "concurrent_callers.csv", "multconst_mid_batch.csv",
+                  "eadd_sweep.csv", "decrypt_vs_table.csv", "encrypt_vs_window.csv"):
     if os.path.exists(os.path.join(src, extra_csv)):
         shutil.copy(os.path.join(src, extra_csv), os.path.join(dst, f"{tag}_{extra_csv}"))
 LANE0 = re.compile(r"void bgn::k_pairing<\d+, 0>")       # the headline kernel, whatever the key's limb count
@@ -62,6 +63,32 @@ for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE"
 if len(lift) == 2:
     summary["decrypt_lift_k_pairing_1"] = dict(lift, hbm_bytes_per_launch=(lift["FETCH_SIZE"]["avg"] + lift["WRITE_SIZE"]["avg"]) * 1024,
                                                   note="the longest launches of this kernel in the run: the lift of the 2^20 Decrypt of bench.py's extras")
+# One EAdd call of the extras (wire bytes to wire bytes at 2^20): its four launches are k_decode_plain x 2, k_g1_add,
+# k_encode in consecutive dispatches (k_decode_plain is used by Add / Sub / Neg only; Neg has no k_g1_add behind it).
+eadd = {}
+for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE", "pmc_write_extra", "write")):
+    path = os.path.join(src, sub, f"{stem}_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    rows = sorted((r for r in csv.DictReader(open(path)) if r["Counter_Name"] == ctr), key=lambda r: int(r["Dispatch_Id"]))
+    short = lambda r: r["Kernel_Name"].split("bgn::")[-1].split("<")[0]
+    calls = []
+    for i in range(len(rows) - 3):
+        if [short(r) for r in rows[i:i + 4]] == ["k_decode_plain", "k_decode_plain", "k_g1_add", "k_encode"]:
+            calls.append(rows[i:i + 4])
+    if calls:
+        big = max(int(c[2]["Grid_Size"]) for c in calls)
+        calls = [c for c in calls if int(c[2]["Grid_Size"]) == big]
+        per_kernel = {}
+        for c in calls:
+            for r in c:
+                per_kernel.setdefault(short(r), []).append(float(r["Counter_Value"]))
+        eadd[ctr] = {"calls": len(calls), "kb_per_call": sum(sum(v) for v in per_kernel.values()) / len(calls),
+                     "kb_per_call_by_kernel": {k: sum(v) / len(calls) for k, v in per_kernel.items()},
+                     "k_g1_add_scratch_bytes_per_lane": int(calls[0][2]["Scratch_Size"]), "k_g1_add_grid": big}
+if len(eadd) == 2:
+    summary["eadd_l1"] = dict(eadd, hbm_bytes_per_call=(eadd["FETCH_SIZE"]["kb_per_call"] + eadd["WRITE_SIZE"]["kb_per_call"]) * 1024,
+                              note="one bgn_add_batch_dev of 2^20 level-1 ciphertexts (bench.py extras): k_decode_plain x 2, k_g1_add, k_encode")
 line = last_json_line(os.path.join(src, "bench_line.json"))
 alg = line["roofline"]["algorithmic_bytes_per_pairing"] * line["config"]["batch_per_gpu"]
 total = (summary["FETCH_SIZE"]["avg"] + summary["WRITE_SIZE"]["avg"]) * 1024

@@ -953,12 +953,18 @@ static size_t quad_table_limit(const bgn_ctx* c, int mode) {
 // 1024-bit key) — up to where one element per lane fills the chip better (profiles/r04_multconst_mid_batch.csv).
 // A larger batch is cut into whole rounds of 65536 lanes for the lane kernel and a remainder that comes back here.
 // Option quad_max_mc overrides (0: never).
-static size_t quad_mc_limit(const bgn_ctx* c) {
+static size_t quad_mc_limit(const bgn_ctx* c, int level, size_t klen) {
   const int64_t ov = opt(c, &Options::quad_max_mc);
   if (ov >= 0) return (size_t)ov;
   if (quad_g1_mul_ws_words(c->nl, 64, 1) == 0) return 0;             // no instantiation for this limb count
   if (c->nl > 40) return kMaxBatch;                                   // 72 limbs: the lane kernels are the functional fallback
-  return c->nl >= 36 ? 40000 : c->nl >= 19 ? 36000 : 24576;
+  // profiles/r04_multconst_mid_batch.csv (MI355X, 1024-bit key, ms for 49152 / 65536 elements, lane groups against one
+  // element per lane): level 1, 1024-bit scalars 98 / 129 against 94 / 96; 256-bit 25.5 / 33.6 against 26.9 / 29.0;
+  // 40-bit (the lane kernel's binary ladder) 5.2 / 6.7 against 6.7 / 7.0.  Level 2: 1024-bit 35.7 / 47.0 against
+  // 35.5 / 35.6; 40-bit 2.1 / 2.7 against 1.5 / 1.5 (32768: 1.5 against 1.5).
+  const bool short_k = klen < 16;
+  if (level == 1) return short_k ? 65536 : c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 32768;
+  return short_k ? 32768 : c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 32768;
 }
 
 static size_t quad_table_floor(const bgn_ctx* c, int mode) {
@@ -1762,7 +1768,7 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   }
   const size_t st = round_up(count, 64);
   // the lane groups take up to quad_mc_limit elements (a whole small batch, or the remainder of a large one)
-  const size_t qlim = k_len <= 1024 ? quad_mc_limit(c) : 0;
+  const size_t qlim = k_len <= 1024 ? quad_mc_limit(c, level, k_len) : 0;
   const size_t qmax = round_up(count < qlim ? count : qlim, 64);
   const size_t qws_bytes = !qlim ? 0 : 4 * (level == 1 ? quad_g1_mul_ws_words(c->nl, qmax, k_len) : quad_gt_pow_each_ws_words(c->nl, qmax));
   SoA2 A, O, T1, T2;

@@ -962,9 +962,12 @@ static size_t quad_mc_limit(const bgn_ctx* c, int level, size_t klen) {
   // element per lane): level 1, 1024-bit scalars 98 / 129 against 94 / 96; 256-bit 25.5 / 33.6 against 26.9 / 29.0;
   // 40-bit (the lane kernel's binary ladder) 5.2 / 6.7 against 6.7 / 7.0.  Level 2: 1024-bit 35.7 / 47.0 against
   // 35.5 / 35.6; 40-bit 2.1 / 2.7 against 1.5 / 1.5 (32768: 1.5 against 1.5).
+  // 512-bit key, 32768 / 49152 elements: level 1, 256-bit scalars 7.6 / 10.9 against 8.5 / 9.0, 40-bit 1.6 / 2.2 against
+  // 2.2 / 2.2; level 2, 256-bit 2.9 / 4.1 against 3.3 / 3.3, 40-bit 0.66 / 0.93 against 0.58 / 0.60.
   const bool short_k = klen < 16;
-  if (level == 1) return short_k ? 65536 : c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 32768;
-  return short_k ? 32768 : c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 32768;
+  if (c->nl >= 36) return level == 1 ? (short_k ? 65536 : 46000) : (short_k ? 32768 : 46000);
+  if (c->nl >= 19) return level == 1 ? (short_k ? 48000 : 38000) : (short_k ? 28000 : 37000);
+  return level == 1 ? 32768 : 24576;
 }
 
 static size_t quad_table_floor(const bgn_ctx* c, int mode) {

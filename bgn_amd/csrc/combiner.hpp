@@ -50,6 +50,7 @@ struct CombineReq {
   int rc = 0;
   std::string err;
   bool done = false;
+  std::condition_variable cv;       // its own: a round wakes the callers it served and ONE queued caller (the next leader)
 };
 
 struct CombineStats {
@@ -67,7 +68,6 @@ struct Combiner {
   int device = 0;
 
   std::mutex mu;
-  std::condition_variable cv;
   std::deque<CombineReq*> queue;
   bool leader_active = false;
   CombineStats stats;
@@ -215,7 +215,7 @@ struct Combiner {
     if (regrouping) cv_arrive.notify_one();
     while (!req.done) {
       if (leader_active) {
-        cv.wait(lk);
+        req.cv.wait(lk);
         continue;
       }
       leader_active = true;
@@ -271,12 +271,15 @@ struct Combiner {
         for (CombineReq* r : g.reqs) {
           r->done = true;
           released++;
+          if (r != &req) r->cv.notify_one();
         }
       last_round_reqs = released;
       last_round_us = round_us;
       pushed_since_round_end = 0;
       leader_active = false;
-      cv.notify_all();
+      // one of those still queued (a kind that was full this round, or a late arrival) leads the next round; a caller
+      // that arrives first does so itself — either way nobody waits for a round that nobody runs
+      if (!queue.empty() && queue.front() != &req) queue.front()->cv.notify_one();
     }
     if (req.rc && err) *err = req.err;
     return req.rc;

@@ -271,7 +271,7 @@ int bgn_check_plaintext_knowledge_batch_dev(bgn_ctx* ctx, size_t count, const ui
                                             const uint8_t* c_be, size_t c_len, const uint8_t* dl_be, size_t dl_len,
                                             uint8_t* ok, void* stream);
 
-/* bgn_poly_mult_batch_dev builds per-coefficient line tables in an allocation of up to a third of the free device
+/* bgn_poly_mult_batch_dev builds per-coefficient line tables in an allocation of up to a sixth of the device's
  * memory, kept by the context between calls and given back when another per-key table is built (BGN_POLY_TABLES=0
  * disables the tables); it synchronises the stream before returning (it owns scratch arrays). */
 

@@ -41,7 +41,9 @@ rows = [
      f"`bench.py`, {float(kp['AverageNs']) / 1e6:.1f} ms average of {kp['Calls']} launches in `profiles/{tag}_bench_kernel_stats.csv`).  HBM: "
      f"{d['roofline']['achieved']:.3f} GB/s of algorithmic bytes = {d['roofline']['frac']:.2e} of 8 TB/s; PMC traffic "
      f"{pmc['hbm_bytes_per_launch']:.3g} B per launch = {pmc['traffic_over_algorithmic']:.0f} × algorithmic ≈ "
-     f"{pmc['hbm_bytes_per_launch'] / d['roofline']['kernel_ms'] / 1e6:.0f} GB/s (`profiles/{tag}_pmc_summary.json`; "
+     f"{pmc['hbm_bytes_per_launch'] / d['roofline']['kernel_ms'] / 1e6:.0f} GB/s (`profiles/{tag}_pmc_summary.json`"
+     + (f": FETCH_SIZE × {pmc['fetch_calibration']['factor']:.2f} + WRITE_SIZE, the factor calibrated on `k_encode`'s known read volume; the uncorrected sum "
+        f"earlier rounds quoted is {pmc['hbm_bytes_per_launch_raw'] / pmc['algorithmic_bytes_per_launch']:.0f} ×" if pmc.get("fetch_calibration") else "") + "; "
      f"{pmc['FETCH_SIZE']['scratch_bytes_per_lane']} B/lane of spill scratch).  VALU: {rv(d)['mads_per_pairing'] / 1e6:.1f} M MADs per pairing → "
      f"{rv(d)['frac']:.3f} of the 4-waves/SIMD issue peak, **{rv(d)['frac_at_1_wave_per_simd']:.3f} of the 1-wave/SIMD ceiling** this "
      f"512-register kernel can reach"),
@@ -82,6 +84,68 @@ if sat:
         rows.insert(2, ("the lane-group kernel saturated (2²⁰ pairs) beside the lane kernel",
                         f"{(1 << 20) / q * 1e3:.3g} against {(1 << 20) / l * 1e3:.3g} pairings/s ({q:.0f} against {l:.0f} ms, `profiles/{tag}_quad_saturated.csv`): "
                         f"{q / l:.2f} × the time — it is the mid-batch kernel"))
+# ---- round 4 additions: the files exist from r04 on ----
+def csv_rows(name):
+    path = P(name)
+    return list(csv.DictReader(l for l in open(path) if not l.startswith("#"))) if os.path.exists(path) else []
+
+
+cc = csv_rows("concurrent_callers.csv")
+if cc:
+    def rate(op, threads, combine):
+        r = [x for x in cc if x["op"] == op and int(x["threads"]) == threads and int(x["combine"]) == combine]
+        return float(r[0]["calls_per_s"]) if r else None
+    def lat(op, combine):
+        r = [x for x in cc if x["op"] == op and int(x["threads"]) == 1 and int(x["combine"]) == combine]
+        return float(r[0]["ms_per_call_per_thread"]) if r else None
+    tmax = max(int(x["threads"]) for x in cc)
+    parts = []
+    for op, label in (("mult", "Mult"), ("decrypt_l1", "Decrypt"), ("add_l1", "Add"), ("multconst_l1_k40", "MultConst (40-bit k)")):
+        if rate(op, tmax, 1):
+            parts.append("%s **%.3g /s** (%.3g /s with the combiner off; one caller alone %.2f ms per call, %.2f off)" %
+                         (label, rate(op, tmax, 1), rate(op, tmax, 0) or 0, lat(op, 1) or 0, lat(op, 0) or 0))
+    rows.append(("the reference's call shape: %d native threads, each calling a single-element entry point on ONE context "
+                 "(`profiles/%s_concurrent_callers.csv`, `tools/concurrent_callers.cpp`)" % (tmax, tag), "; ".join(parts)))
+mc = csv_rows("multconst_mid_batch.csv")
+if mc:
+    def mcms(level, bits, count, kernel):
+        r = [x for x in mc if x["key"] == "k1024" and int(x["level"]) == level and int(x["scalar_bits"]) == bits and
+             int(x["count"]) == count and x["kernel"] == kernel]
+        return float(r[0]["ms"]) if r else None
+    cells = []
+    for level in (1, 2):
+        for bits in (1024, 40):
+            seg = []
+            for n in (1, 4096, 16384, 66000):
+                q = mcms(level, bits, n, "quad") or mcms(level, bits, n, "default")
+                l = mcms(level, bits, n, "lane")
+                if q and l:
+                    seg.append("%d: %.1f / %.1f" % (n, q, l))
+            if seg:
+                cells.append("level %d, %d-bit scalars — %s" % (level, bits, ", ".join(seg)))
+    rows.append(("MultConst with per-element scalars by batch size, ms: lane groups (cut into lane rounds + remainder above 65536) / one "
+                 "element per lane (`profiles/%s_multconst_mid_batch.csv`)" % tag, "; ".join(cells)))
+dcb = d.get("decrypt", {}).get("cpu_baseline")
+if dcb:
+    rows.append(("CPU baseline of Decrypt (C oracle, same ciphertexts, plaintexts and statuses equal)",
+                 f"{dcb['value']:.2f} decrypts/s with {dcb['cores']} threads on a bounded sample ({dcb['sample'].split(';')[0].split(',')[0]}); "
+                 f"table build {dcb['table_setup_s']:.1f} s"))
+er = ex.get("eadd_l1", {}).get("roofline")
+if er and er.get("traffic"):
+    rows.append(("EAdd level 1, HBM-side traffic of the call's four launches",
+                 f"{er['traffic']:.3g} B per 2²⁰ additions = {er['traffic'] / er['algorithmic_bytes_per_call']:.2f} × the algorithmic bytes "
+                 f"(`profiles/{tag}_pmc_summary.json` `eadd_l1`; FETCH_SIZE × {pmc.get('fetch_calibration', {}).get('factor', 1):.2f}, calibrated on "
+                 f"`k_encode`'s known read volume)"))
+dvt = csv_rows("decrypt_vs_table.csv")
+if dvt:
+    big = {int(r["table_log2"]): r for r in dvt if int(r["batch"]) == 1 << 20}
+    rows.append(("Decrypt at 2²⁰ against the size of the baby-step table (`profiles/%s_decrypt_vs_table.csv`)" % tag,
+                 "; ".join("2^%d entries (%.1f GB, set up in %.2f s): %.3g /s" % (k, float(r["table_GB"]), float(r["setup_s"]), float(r["decrypts_per_s"]))
+                           for k, r in sorted(big.items(), reverse=True) if k in (31, 30, 29, 28, 26, 24))))
+evw = csv_rows("encrypt_vs_window.csv")
+if evw:
+    rows.append(("Encrypt at 2²⁰ against the window width of Q's table (`profiles/%s_encrypt_vs_window.csv`)" % tag,
+                 "; ".join("%s bits (%.1f GB): %.3g /s" % (r["q_window_bits"], float(r["q_table_GB"]), float(r["encrypts_per_s"])) for r in evw)))
 table = "| | value |\n|---|---|\n" + "".join(f"| {a} | {b} |\n" for a, b in rows)
 
 

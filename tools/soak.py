@@ -86,7 +86,8 @@ def main():
         name = rng.choice(list(keys))
         K = keys[name]
         eng, EB = K["eng"], K["EB"]
-        op = rng.choice(["mult", "mult", "make_l2", "decrypt_l1", "decrypt_l2", "multpoly", "add_l1", "encrypt"])
+        op = rng.choice(["mult", "mult", "make_l2", "decrypt_l1", "decrypt_l2", "multpoly", "add_l1", "encrypt", "multconst_l1",
+                         "multconst_l2", "callers"])
         hi = {"k256": 18, "k512": 17.6, "k1024": 17.2, "k1024b": 16.5, "k2048": 12.5}[name]
         n = max(1, int(2 ** rng.uniform(0, hi)))
         if rng.random() < 0.25 and name != "k2048":          # around the round boundaries
@@ -132,6 +133,74 @@ def main():
                 eng.decrypt_dev(lvl, src, m, st, n)
                 torch.cuda.synchronize()
                 assert not bool(st.any().item()) and torch.equal(m.cpu(), want), (name, op, n, kv)
+        elif op in ("multconst_l1", "multconst_l2"):
+            # per-element scalars of a random length, the special ones among them (0, 1, chains of the digits 8 / -1,
+            # multiples of the group order: the ladder's flagged fallback); lane groups against one element per lane
+            lvl = 1 if op == "multconst_l1" else 2
+            nn = int(K["fx"]["n"], 16)
+            klen = rng.choice([1, 5, 8, 16, 32, (nn.bit_length() + 7) // 8, (nn.bit_length() + 7) // 8 + 1])
+            n = min(n, 70000 if klen <= 16 else 8192 if name != "k2048" else 64)
+            src = (a if lvl == 1 else K["l2"][off * EB: (off + n) * EB])[: n * EB]
+            g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+            ks = torch.randint(0, 256, (n, klen), dtype=torch.uint8, generator=g)
+            special = [0, 1, int("8" * (2 * klen), 16), (16 ** (2 * klen - 1)) - 1]
+            if 8 * klen > nn.bit_length():
+                special += [nn, 2 * nn, nn - 1]
+            for i, v in enumerate(special[: n]):
+                ks[i] = torch.tensor(list(int(v % (1 << (8 * klen))).to_bytes(klen, "big")), dtype=torch.uint8)
+            ksd = ks.to(dev)
+            kvs = ["default"] + (["quad", "lane"] if (name != "k2048" or n <= 48) else [])
+            for kv in kvs:
+                force(kv)
+                out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+                eng._lib.bgn_multconst_batch_dev(eng._h, n, lvl, src.data_ptr(), ksd.data_ptr(), klen, None, 0, out.data_ptr(), eng._stream())
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = out
+                    k = min(n, 6 if klen > 16 else 12)
+                    want = K["oracle"].multconst(lvl, bytes(src[: k * EB].cpu().numpy()),
+                                                 [int.from_bytes(bytes(ks[i].numpy()), "big") for i in range(k)])
+                    assert bytes(out[: k * EB].cpu().numpy()) == want, (name, op, n, klen, "oracle")
+                else:
+                    assert torch.equal(ref, out), (name, op, n, klen, kv)
+        elif op == "callers":
+            # the reference's call shape: threads issuing small host-buffer calls of mixed kinds on this context at
+            # once (the combiner merges them); every result equals the device-resident batch
+            import threading
+            force("default")
+            nthreads, per = rng.choice([(8, 4), (32, 2), (64, 1)]), None
+            nthreads, per = nthreads
+            tot = nthreads * per
+            n = tot
+            off2 = rng.randrange(0, NMAX - tot + 1)
+            ha = K["cts"][off2 * EB: (off2 + tot) * EB].cpu().numpy().reshape(tot, EB)
+            hb = K["perm"][off2 * EB: (off2 + tot) * EB].cpu().numpy().reshape(tot, EB)
+            want_m = eng.mult(ha.tobytes(), hb.tobytes())
+            want_a = eng.add(1, ha.tobytes(), hb.tobytes())
+            want_d = K["vals"][off2: off2 + tot].tolist()
+            errs = []
+
+            def worker(t):
+                try:
+                    for j in range(per):
+                        i = t * per + j
+                        which = (t + j) % 3
+                        if which == 0:
+                            assert eng.mult(ha[i].tobytes(), hb[i].tobytes()).tobytes() == want_m[i].tobytes()
+                        elif which == 1:
+                            assert eng.add(1, ha[i].tobytes(), hb[i].tobytes()).tobytes() == want_a[i].tobytes()
+                        else:
+                            m, st = eng.decrypt(1, ha[i].tobytes())
+                            assert int(m[0]) == want_d[i] and int(st[0]) == 0
+                except Exception as e:                        # noqa: BLE001
+                    errs.append((t, repr(e)))
+
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert not errs, (name, op, errs[:2])
         elif op == "add_l1":
             force("default")
             out = torch.empty(n * EB, dtype=torch.uint8, device=dev)

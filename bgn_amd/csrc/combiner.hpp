@@ -16,7 +16,6 @@
 // only one released and never waits).  Without it a pool of callers splits into two cohorts that alternate, each
 // launch half as full as it could be.  Option combine_wait_us asks a lone leader to wait for company (off).
 #pragma once
-#include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -57,35 +56,48 @@ struct CombineStats {
   uint64_t calls = 0, rounds = 0, groups = 0, elements = 0, max_group = 0;
 };
 
+// What the combiner needs from the device runtime, as callbacks: engine.cpp fills them with HIP calls (a stream of the
+// context's device, page-locked staging, the context's accounted allocator); tests/cpp/combiner_test.cpp fills them
+// with host memory so that the queueing logic runs under ThreadSanitizer on a machine without a GPU.  Every callback
+// returns 0 on success.
+struct CombinerBackend {
+  std::function<int()> bind;                                        // make the context's device current in this thread
+  std::function<int(void**)> stream_create;
+  std::function<void(void*)> stream_destroy;
+  std::function<int(void*)> stream_sync;
+  std::function<int(void**, size_t)> host_alloc;                    // page-locked
+  std::function<void(void*)> host_free;
+  std::function<int(void**, size_t)> dev_alloc;                     // the context's accounted allocator
+  std::function<void(void*)> dev_free;
+  std::function<int(void*, const void*, size_t, void*)> upload;     // (dev, host, bytes, stream), asynchronous
+  std::function<int(void*, const void*, size_t, void*)> download;   // (host, dev, bytes, stream), asynchronous
+};
+
 struct Combiner {
   // launch(key, n, dev_in, dev_out, stream): the `_dev` entry point of key.op over n elements; returns its status
   // (and leaves the message in the thread's last error, which error_text() fetches)
-  typedef std::function<int(const CombineKey&, size_t, uint8_t* const*, uint8_t* const*, hipStream_t)> Launch;
+  typedef std::function<int(const CombineKey&, size_t, uint8_t* const*, uint8_t* const*, void*)> Launch;
   Launch launch;
   std::function<const char*()> error_text;
-  std::function<hipError_t(void**, size_t)> dev_alloc;     // the context's accounted allocator
-  std::function<void(void*)> dev_free;
-  int device = 0;
+  CombinerBackend be;
 
   std::mutex mu;
   std::deque<CombineReq*> queue;
   bool leader_active = false;
   CombineStats stats;
-  // regrouping (see the header comment): what the last round released and when it ended
-  std::condition_variable cv_arrive;
-  bool regrouping = false;
+  // regrouping (see the header comment): what the last round released and how long it took
   size_t last_round_reqs = 0, pushed_since_round_end = 0;
   double last_round_us = 0;
 
-  hipStream_t stream = nullptr;
+  void* stream = nullptr;
   uint8_t* h_stage = nullptr;      // page-locked: [inputs of every group | outputs of every group]
   uint8_t* d_stage = nullptr;
   size_t stage_cap = 0;
 
   ~Combiner() {
-    if (stream) (void)hipStreamDestroy(stream);
-    if (h_stage) (void)hipHostFree(h_stage);
-    if (d_stage && dev_free) dev_free(d_stage);
+    if (stream) be.stream_destroy(stream);
+    if (h_stage) be.host_free(h_stage);
+    if (d_stage) be.dev_free(d_stage);
   }
 
   struct Group {
@@ -98,21 +110,20 @@ struct Combiner {
   static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
   int ensure_stage(size_t bytes, std::string* err) {
-    if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!stream && be.stream_create(&stream) != 0) {
       stream = nullptr;
       *err = "combiner: stream creation failed";
       return -3;
     }
     if (bytes <= stage_cap) return 0;
-    if (stream) (void)hipStreamSynchronize(stream);
-    if (h_stage) (void)hipHostFree(h_stage);
-    if (d_stage) dev_free(d_stage);
+    if (stream) (void)be.stream_sync(stream);
+    if (h_stage) be.host_free(h_stage);
+    if (d_stage) be.dev_free(d_stage);
     h_stage = d_stage = nullptr;
     stage_cap = 0;
     const size_t want = align_up(bytes + bytes / 2 + 65536);
-    if (hipHostMalloc((void**)&h_stage, want, hipHostMallocDefault) != hipSuccess || dev_alloc((void**)&d_stage, want) != hipSuccess) {
-      (void)hipGetLastError();
-      if (h_stage) (void)hipHostFree(h_stage);
+    if (be.host_alloc((void**)&h_stage, want) != 0 || be.dev_alloc((void**)&d_stage, want) != 0) {
+      if (h_stage) be.host_free(h_stage);
       h_stage = nullptr;
       d_stage = nullptr;
       *err = "combiner: staging buffers: device memory or the context's memory budget exhausted";
@@ -139,8 +150,8 @@ struct Combiner {
           out_bytes += align_up(g.total * g.key.w_out[k]);
         }
     std::string err;
-    int rc = hipSetDevice(device) == hipSuccess ? 0 : -3;
-    if (rc) err = "combiner: hipSetDevice failed";
+    int rc = be.bind() == 0 ? 0 : -3;
+    if (rc) err = "combiner: the context's device could not be made current";
     if (!rc) rc = ensure_stage(in_bytes + out_bytes, &err);
     if (!rc) {
       for (Group& g : groups)
@@ -153,7 +164,7 @@ struct Combiner {
             dst += b;
           }
         }
-      if (hipMemcpyAsync(d_stage, h_stage, in_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+      if (be.upload(d_stage, h_stage, in_bytes, stream) != 0) {
         rc = -3;
         err = "combiner: upload failed";
       }
@@ -182,14 +193,14 @@ struct Combiner {
         }
       }
     }
-    hipError_t e = hipMemcpyAsync(h_stage + in_bytes, d_stage + in_bytes, out_bytes, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    int e = be.download(h_stage + in_bytes, d_stage + in_bytes, out_bytes, stream);
+    if (e == 0) e = be.stream_sync(stream);
     for (Group& g : groups) {
-      if (e != hipSuccess) {
+      if (e != 0) {
         for (CombineReq* r : g.reqs)
           if (!r->rc) {
             r->rc = -3;
-            r->err = std::string("combiner: ") + hipGetErrorString(e);
+            r->err = "combiner: download or synchronisation of the round failed";
           }
         continue;
       }
@@ -212,7 +223,6 @@ struct Combiner {
     queue.push_back(&req);
     stats.calls++;
     pushed_since_round_end++;
-    if (regrouping) cv_arrive.notify_one();
     while (!req.done) {
       if (leader_active) {
         req.cv.wait(lk);
@@ -224,11 +234,14 @@ struct Combiner {
         const size_t target = queue.size() + (last_round_reqs - pushed_since_round_end);
         double budget_us = last_round_us * (double)regroup_pct / 100.0;
         if (budget_us > 2000.0) budget_us = 2000.0;
+        // (a yield loop on the steady clock, not a timed wait on a condition variable: the budget is a fraction of a
+        // launch, below the granularity of a timer sleep, and only this one thread spins)
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds((int64_t)budget_us);
-        regrouping = true;
-        while (queue.size() < target && cv_arrive.wait_until(lk, deadline) != std::cv_status::timeout) {
+        while (queue.size() < target && std::chrono::steady_clock::now() < deadline) {
+          lk.unlock();
+          std::this_thread::yield();
+          lk.lock();
         }
-        regrouping = false;
       }
       if (wait_us > 0 && queue.size() == 1) {
         // a lone leader may wait for company (off by default): the others queue up behind leader_active

@@ -2997,13 +2997,33 @@ Combiner* get_combiner(bgn_ctx* c) {
   if (!c->comb) {
     Combiner* cb = new (std::nothrow) Combiner();
     if (!cb) return nullptr;
-    cb->device = c->device;
-    cb->launch = [c](const CombineKey& k, size_t n, uint8_t* const* in, uint8_t* const* out, hipStream_t s) {
-      return comb_launch(c, k, n, in, out, s);
+    cb->launch = [c](const CombineKey& k, size_t n, uint8_t* const* in, uint8_t* const* out, void* s) {
+      return comb_launch(c, k, n, in, out, (hipStream_t)s);
     };
     cb->error_text = [] { return bgn_last_error(); };
-    cb->dev_alloc = [c](void** p, size_t b) { return ctx_malloc(c, p, b); };
-    cb->dev_free = [c](void* p) { (void)ctx_free(c, p); };
+    CombinerBackend& be = cb->be;
+    be.bind = [c] { return hipSetDevice(c->device) == hipSuccess ? 0 : -1; };
+    be.stream_create = [](void** s) { return hipStreamCreateWithFlags((hipStream_t*)s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; };
+    be.stream_destroy = [](void* s) { (void)hipStreamDestroy((hipStream_t)s); };
+    be.stream_sync = [](void* s) { return hipStreamSynchronize((hipStream_t)s) == hipSuccess ? 0 : -1; };
+    be.host_alloc = [](void** p, size_t b) {
+      if (hipHostMalloc(p, b, hipHostMallocDefault) == hipSuccess) return 0;
+      (void)hipGetLastError();
+      return -1;
+    };
+    be.host_free = [](void* p) { (void)hipHostFree(p); };
+    be.dev_alloc = [c](void** p, size_t b) {
+      if (ctx_malloc(c, p, b) == hipSuccess) return 0;
+      (void)hipGetLastError();
+      return -1;
+    };
+    be.dev_free = [c](void* p) { (void)ctx_free(c, p); };
+    be.upload = [](void* d, const void* h, size_t b, void* s) {
+      return hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, (hipStream_t)s) == hipSuccess ? 0 : -1;
+    };
+    be.download = [](void* h, const void* d, size_t b, void* s) {
+      return hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, (hipStream_t)s) == hipSuccess ? 0 : -1;
+    };
     c->comb = cb;
   }
   return c->comb;

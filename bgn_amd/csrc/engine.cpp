@@ -3144,6 +3144,9 @@ int bgn_ctx_calibrate(bgn_ctx* c, int64_t out[8]) {
       const double q1 = time_ms(mode, 1, 4096), q2 = time_ms(mode, 1, 16384), q3 = time_ms(mode, 1, 32768);
       const double ln = time_ms(mode, 2, 4096);
       if (err) break;
+      if (keep.keep.test_calibrate_trace.load() != 0)
+        fprintf(stderr, "[calibrate] mode %d: coop 256 / 1024: %.2f / %.2f ms; quad 4096 / 16384 / 32768: %.2f / %.2f / %.2f ms; lane 4096: %.2f ms\n",
+                mode, c1, c2, q1, q2, q3, ln);
       const double sc = (c2 - c1) / 768.0, ic = c1 - sc * 256.0;               // cooperative: ic + sc * n
       const double sq = (q3 - q2) / 16384.0, iq = q2 - sq * 16384.0;           // lane groups above their floor: iq + sq * n
       int64_t xc = sc > 0 ? (int64_t)((q1 - ic) / sc) : 4096;

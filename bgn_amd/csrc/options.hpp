@@ -64,6 +64,7 @@ struct Options {
   V test_fail_mul_ws{0};   // the allocation of the scalar-multiplication table fails (fallback path)
   V test_mc_fallback{0};   // lane-group MultConst: 1 = skip the lane kernel's pass over the flagged elements; 2 = count
   V test_mc_flagged{0};    // the flagged elements of the last call into this option (synchronises the stream)
+  V test_calibrate_trace{0};   // bgn_ctx_calibrate prints its probe times to stderr
 };
 
 struct OptionDesc {
@@ -116,6 +117,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"test_fail_mul_ws", &Options::test_fail_mul_ws, false, nullptr},
       {"test_mc_fallback", &Options::test_mc_fallback, false, nullptr},
       {"test_mc_flagged", &Options::test_mc_flagged, false, nullptr},
+      {"test_calibrate_trace", &Options::test_calibrate_trace, false, nullptr},
   };
   *n = sizeof t / sizeof t[0];
   return t;

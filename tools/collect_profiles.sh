@@ -49,6 +49,7 @@ CC_SECONDS=3 python3 tools/concurrent_callers.py k1024 > "$OUT/concurrent_caller
 echo "== MultConst by batch size: lane groups against one element per lane"
 python3 tools/multconst_mid_batch.py k1024 k512 > "$OUT/multconst_mid_batch.csv" 2> "$OUT/multconst.err" || exit 1
 echo "== EAdd by batch size"; python3 tools/eadd_sweep.py > "$OUT/eadd_sweep.csv" 2> "$OUT/eadd.err" || exit 1
+echo "== bgn_ctx_calibrate beside the committed crossovers"; python3 tools/calibrate_report.py > "$OUT/calibrate.csv" 2> "$OUT/calibrate.err" || exit 1
 echo "== what the default table sizes buy"
 python3 tools/decrypt_vs_table.py > "$OUT/decrypt_vs_table.csv" 2> "$OUT/dvt.err" || exit 1
 python3 tools/decrypt_vs_table.py encrypt > "$OUT/encrypt_vs_window.csv" 2>> "$OUT/dvt.err" || exit 1

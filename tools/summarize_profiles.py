@@ -22,7 +22,7 @@ shutil.copy(os.path.join(src, "prof_bench", "bench_kernel_stats.csv"), os.path.j
 shutil.copy(os.path.join(src, "prof_extra", "extra_kernel_stats.csv"), os.path.join(dst, f"{tag}_extra_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "small_batch.csv"), os.path.join(dst, f"{tag}_small_batch.csv"))
 for extra_csv in ("mid_batch.csv", "quad_saturated.csv", "single_op_latency.csv", "concurrent_callers.csv", "multconst_mid_batch.csv",
-                  "eadd_sweep.csv", "decrypt_vs_table.csv", "encrypt_vs_window.csv"):
+                  "eadd_sweep.csv", "decrypt_vs_table.csv", "encrypt_vs_window.csv", "calibrate.csv"):
     if os.path.exists(os.path.join(src, extra_csv)):
         shutil.copy(os.path.join(src, extra_csv), os.path.join(dst, f"{tag}_{extra_csv}"))
 LANE0 = re.compile(r"void bgn::k_pairing<\d+, 0>")       # the headline kernel, whatever the key's limb count

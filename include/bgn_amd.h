@@ -128,7 +128,10 @@ const char* bgn_option_name(size_t index);
  * timed probes on THIS device: two sizes on the cooperative kernel, two on the lane-group kernel, one round of the
  * lane kernel per operation (about a second at a 1024-bit key).  Without it the context uses the constants of the
  * committed sweeps (profiles/r03_mid_batch*.csv); boxes of one pool differ by several percent.  Explicit options
- * (coop_max, quad_max, ...) still take precedence.  out, when non-null, receives the eight crossovers in elements:
+ * (coop_max, quad_max, ...) still take precedence.  Call it once the context is set up the way it will be used — after
+ * bgn_ctx_setup_decryption, so that Decrypt's probes walk the production table — and not concurrently with other calls
+ * on the context (it forces kernels through the options while it measures).  out, when non-null, receives the eight
+ * crossovers in elements:
  * cooperative up to out[0..3], lane-group up to out[4..7] for Mult, makeL2, lift, power (-1: not calibrated). */
 int bgn_ctx_calibrate(bgn_ctx* ctx, int64_t out[8]);
 

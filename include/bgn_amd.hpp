@@ -466,6 +466,16 @@ class PublicKey {
   // globals, gsbs.go:12-15): a cap for the tables built from now on (0: none), and what the context holds.
   void SetMemoryBudget(uint64_t bytes) const { check(bgn_ctx_set_memory_budget(h_, bytes), "bgn_ctx_set_memory_budget"); }
   uint64_t MemoryBytes() const { return bgn_ctx_memory_bytes(h_); }
+  // per-context options (include/bgn_amd.h "Options"): kernel crossovers, table shapes, the combiner's limits
+  void SetOption(const char* name, int64_t value) const { check(bgn_ctx_set_option(h_, name, value), "bgn_ctx_set_option"); }
+  int64_t GetOption(const char* name) const {
+    int64_t v = 0;
+    check(bgn_ctx_get_option(h_, name, &v), "bgn_ctx_get_option");
+    return v;
+  }
+  // crossovers between the kernel families re-derived from timed probes on this device (after SetupDecryption, so
+  // that Decrypt's probes walk the production table)
+  void Calibrate() const { check(bgn_ctx_calibrate(h_, nullptr), "bgn_ctx_calibrate"); }
 
   // ---- wire envelopes: bgn.go:501-560 ----
   Ciphertext NewCiphertextFromBytes(const Bytes& data) const {

@@ -3,6 +3,7 @@
 bgn_test.go:97-140 benchmark one op per call).  The host-buffer entry points merge such calls into one launch per
 kind of call (csrc/combiner.hpp); every caller must get exactly the bytes a lone call returns — here checked
 against the C oracle — and per-context options must let two keys run different kernels side by side."""
+import os
 import random
 import threading
 
@@ -234,3 +235,21 @@ def test_calibration_yields_ordered_crossovers_and_leaves_results_alone():
     with eng.options(combine=0):
         eng.mult(aa, bb)
     assert "quad" in eng.last_kernel_name(), (xo, eng.last_kernel_name())
+
+
+def test_native_caller_pool_through_the_c_abi():
+    """tools/concurrent_callers.cpp — std::thread callers of the C ABI with no interpreter lock between them, what a
+    Go host's goroutines look like to the library — for a second per operation at the 256-bit key: every caller's last
+    result equals the batch call's, with the combiner on and off (the tool exits non-zero otherwise)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CC_SECONDS="1", CC_THREADS="1,48", CC_OPS="mult,add_l1,decrypt_l1,multconst_l1_k40,decrypt_l2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "concurrent_callers.py"), "k256"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    rows = [l.split(",") for l in r.stdout.strip().splitlines()[1:]]
+    assert len(rows) == 5 * 4 and all(row[-1] == "True" for row in rows), r.stdout
+    merged = [row for row in rows if row[3] == "48" and row[4] == "1"]
+    assert all(float(row[7]) > 3 * float(solo[7]) for row in merged for solo in rows
+               if solo[1] == row[1] and solo[3] == "1" and solo[4] == "1"), r.stdout      # 48 callers get well beyond one caller's rate

@@ -1457,6 +1457,43 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
   const int wx = x_be ? (int)((x_len * 8 + wbp - 1) / wbp) : 0;
   const int wr = r_be ? (int)((r_len * 8 + wbq - 1) / wbq) : 0;
   const int steps = wx + wr;
+  // The lane groups (quad/quad_g1.hpp k_g1_fixed_quad: one Jacobian addition per window, sixteen lanes per element,
+  // exceptional cases resolved in the kernel, one inversion per element at the end).  At 72 limbs (2048-bit keys) they
+  // are the fast path at every size — the 72-limb instantiation of the chain kernels below is the functional one (1.0 x 10^5
+  // encryptions/s, profiles/r03_rates_2048.csv); at the other key sizes the chains are faster from a few thousand
+  // elements on and as fast below, so option quad_max_enc is what selects this path there (tests).
+  {
+    const int64_t ov = opt(c, &Options::quad_max_enc);
+    const size_t lim = ov >= 0 ? (size_t)ov : (c->nl > 40 ? kMaxBatch : 0);
+    const size_t sw = round_up(count, 64);
+    const size_t need = quad_g1_fixed_ws_words(c->nl, sw) * 4;
+    if (count <= lim && need && steps > 0) {
+      if (need > c->chain_ws_bytes) {
+        if (c->chain_ws) {
+          HIP_TRY(hipDeviceSynchronize());
+          HIP_TRY(ctx_free(c, c->chain_ws));
+          c->chain_ws = nullptr;
+          c->chain_ws_bytes = 0;
+        }
+        const size_t want = round_up(need + need / 8, 1 << 20);
+        if (ctx_malloc(c, (void**)&c->chain_ws, want) != hipSuccess) {
+          (void)hipGetLastError();
+          return fail(BGN_E_NOMEM, "fixed-base workspace");
+        }
+        c->chain_ws_bytes = want;
+      }
+      if (timed) HIP_TRY(hipEventRecord(c->ev0, s));
+      if (quad_g1_fixed_launch(c->nl, s, c->d_params, c->d_tabP, c->d_tabQ, wbp, wbq, x_be, x_len, wx, r_be, r_len, wr, S, count,
+                               (uint32_t*)c->chain_ws, sw, c->p_bits + 1)) {
+        if (timed) {
+          HIP_TRY(hipEventRecord(c->ev1, s));
+          c->ev_valid = true;
+          c->last_kernel = "k_g1_fixed_quad";
+        }
+        return BGN_OK;
+      }
+    }
+  }
   bool chains = steps >= 2 * kFixedChains;
   if (opt(c, &Options::fixed_chains) == 1) chains = false;
   if (chains) {

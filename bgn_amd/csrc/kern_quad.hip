@@ -141,6 +141,63 @@ uint8_t* quad_g1_mul_launch(int nl, hipStream_t s, const void* params, SoA2 B, c
   return nullptr;
 }
 
+namespace {
+// workspace of the fixed-base product, in u32 words: parked X, Y | Z limbs | 1/Z limbs | flags
+template <int NL>
+struct FixWs {
+  size_t park, zsoa, isoa, flags, total;
+  explicit FixWs(size_t sw) {
+    park = 0;
+    zsoa = park + g1q_park_words<NL>() * sw;
+    isoa = zsoa + (size_t)NL * sw;
+    flags = isoa + (size_t)NL * sw;
+    total = flags + (sw + 3) / 4;
+  }
+};
+
+template <int NL>
+void launch_g1_fixed(hipStream_t s, const void* params, const uint32_t* tabP, const uint32_t* tabQ, int wbp, int wbq, const uint8_t* x,
+                     size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count, uint32_t* ws, size_t sw,
+                     int p_bits) {
+  const FpParams<NL>* P = (const FpParams<NL>*)params;
+  const FixWs<NL> L(sw);
+  uint8_t* flags = reinterpret_cast<uint8_t*>(ws + L.flags);
+  const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
+  hipLaunchKernelGGL((k_g1_fixed_quad<NL>), grid, block, 0, s, P, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, ws + L.park,
+                     ws + L.zsoa, sw, flags, count);
+  hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P,
+                     ws + L.zsoa, ws + L.isoa, sw, count, p_bits);
+  hipLaunchKernelGGL((k_g1_aff_quad<NL>), grid, block, 0, s, P, ws + L.park, ws + L.isoa, sw, flags, O.c0, O.c1, O.inf, O.stride,
+                     count);
+}
+}  // namespace
+
+size_t quad_g1_fixed_ws_words(int nl, size_t sw) {
+  switch (nl) {
+    case 10: return FixWs<10>(sw).total;
+    case 19: return FixWs<19>(sw).total;
+    case 36: return FixWs<36>(sw).total;
+    case 37: return FixWs<37>(sw).total;
+    case 72: return FixWs<72>(sw).total;
+  }
+  return 0;
+}
+
+bool quad_g1_fixed_launch(int nl, hipStream_t s, const void* params, const uint32_t* tabP, const uint32_t* tabQ, int wbp, int wbq,
+                          const uint8_t* x, size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count,
+                          uint32_t* ws, size_t sw, int p_bits) {
+  if (!count) return true;
+  if (!ws || wbp > 24 || wbq > 24 || (wx && !x) || (wr && !r)) return false;
+  switch (nl) {
+    case 10: launch_g1_fixed<10>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 19: launch_g1_fixed<19>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 36: launch_g1_fixed<36>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 37: launch_g1_fixed<37>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 72: launch_g1_fixed<72>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+  }
+  return false;
+}
+
 size_t quad_gt_pow_each_ws_words(int nl, size_t sw) {
   switch (nl) {
     case 10: return gtq_table_words<10>() * sw;

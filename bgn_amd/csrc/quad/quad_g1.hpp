@@ -293,6 +293,155 @@ k_g1_mul_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ bx, co
   }
 }
 
+// ---- fixed-base products on the lane groups ------------------------------------------------------------------------
+// S = P^x * Q^r (EncryptWithRandomness, bgn.go:344-350; the blinding terms Q^r) from the key's window tables
+// (engine.cpp ensure_fixed_tables: entry (w, d) = d * 2^(wbits*w) * B, x limbs then y limbs, canonical Montgomery,
+// all-zero = the identity), sixteen lanes per element: one GADD per window with the entry as (x, y, 1, 1, 1).
+// Every case of the addition is exact INSIDE the kernel: after an addition whose result becomes the state the
+// canonical Z' and X' are tested — Z' = 0 means the accumulator met the entry or its negative (H = 0); then X' = r^2
+// tells which: zero for equal points (the state becomes the entry and one GDBL doubles it, its stores suppressed for
+// the neighbours), non-zero for opposite ones (the sum is the identity).  Ends like k_g1_mul_quad: X, Y parked, Z
+// canonical for the inversion, flags (the identity; never "exceptional").
+// Digit `window` (wbits <= 24) of a big-endian scalar, as ops.hpp scalar_window.
+__device__ __forceinline__ u32 quad_scalar_window(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
+  const size_t bit0 = (size_t)window * (size_t)wbits;
+  const size_t byte = bit0 >> 3;
+  u32 v = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (byte + i < klen) v |= (u32)k[klen - 1 - (byte + i)] << (8 * i);
+  return (v >> (bit0 & 7)) & ((1u << wbits) - 1u);
+}
+
+template <int NL>
+__global__ void __launch_bounds__(QUAD_BLOCK)
+k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP, const u32* __restrict__ tabQ, int wbits_p,
+                int wbits_q, const uint8_t* __restrict__ xk, size_t xlen, int wx, const uint8_t* __restrict__ rk, size_t rlen, int wr,
+                u32* __restrict__ park, u32* __restrict__ zsoa, size_t sw, uint8_t* __restrict__ flags, size_t count) {
+  constexpr int M = QuadDims<NL>::M;
+  using PG = QuadG1;
+  __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
+  __shared__ u32 note[QUAD_PER_BLOCK][4];         // per element: entry is all zero (quads 0, 1) | X' = 0 | Z' = 0
+  char* V = reinterpret_cast<char*>(Vs);
+  QuadLane<NL> c;
+  quad_lane_init<NL>(c, P);
+  size_t e = (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);
+  const bool live = e < count;
+  if (!__ballot(live)) return;
+  if (!live) e = count - 1;
+  const int el = (int)(threadIdx.x >> 4);
+  int x[M];
+  auto get = [&](int slot) { quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c)); };
+  auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
+  // state and the constant part of the entry slots: everything = 1 (bounded values for the additions whose results
+  // are thrown away while the accumulator is still the identity)
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int pos = c.sub * M + j;
+    x[j] = pos < NL ? (int)P->one[pos < NL ? pos : 0] : 0;
+  }
+  put(c.quad);
+  put(QUADG_SLOT_TX + c.quad);
+  if (c.quad == 0) put(QUADG_SLOT_TZZZ);
+  bool acc_inf = true, need_dbl = false, took = false;
+  int i = 0;
+  const int nwin = wx + wr;
+#pragma unroll 1
+  for (;;) {
+    int seg;
+    bool keep;
+    if (__ballot(need_dbl)) {
+      // acc == entry: the state becomes the entry (Z = Z^2 = 1 are in its slots) and is doubled
+      if (need_dbl) {
+        get(QUADG_SLOT_TX + c.quad);
+        put(c.quad);
+      }
+      seg = QUADG_SEG_GDBL;
+      keep = !need_dbl;
+      took = need_dbl;
+      need_dbl = false;
+    } else {
+      if (i >= nwin) break;
+      const bool isx = i < wx;
+      const int lw = isx ? i : i - wx, wb = isx ? wbits_p : wbits_q;
+      const u32 d = isx ? quad_scalar_window(xk + e * xlen, xlen, wb, lw) : quad_scalar_window(rk + e * rlen, rlen, wb, lw);
+      ++i;
+      if (!__ballot(d != 0)) continue;
+      bool ent_inf = true;
+      if (c.quad < 2) {
+        const u32* ent = (isx ? tabP : tabQ) + ((((size_t)lw) << wb) + d) * (size_t)(2 * NL) + (size_t)c.quad * NL;
+        u32 any = 0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const int pos = c.sub * M + j;
+          x[j] = pos < NL ? (int)ent[pos < NL ? pos : 0] : 0;
+          any |= (u32)x[j];
+        }
+        put(QUADG_SLOT_TX + c.quad);
+        any |= (u32)quad_from_above((int)any);
+        any |= (u32)quad_bcast<0>((int)any) | (u32)quad_bcast<2>((int)any);
+        if (c.sub == 0) note[el][c.quad] = any;
+      }
+      ent_inf = (note[el][0] | note[el][1]) == 0;      // (same wave: the LDS writes above precede these reads)
+      const bool use = d != 0 && !ent_inf;
+      seg = QUADG_SEG_GADD;
+      took = use && !acc_inf;
+      keep = !took;
+      if (use && acc_inf) {                             // identity + T = T (Z, Z^2 = 1 from the entry's slots)
+        get(QUADG_SLOT_TX + c.quad);
+        put(c.quad);
+        acc_inf = false;
+      }
+    }
+    quad_run_p<NL, PG>(V, seg, c, keep, G1Q_STATE_SLOTS);
+    // the exceptional cases of the step that just became the state: Z' = 0 (H = 0, or a doubled point of order two)
+    if (__ballot(took)) {
+      if (c.quad == 0 || c.quad == 2) {
+        get(c.quad == 0 ? QUADG_SLOT_X : QUADG_SLOT_Z);
+        if (c.quad == 0) {
+          // X' < 19 p: the representative is reduced in steps (canonical16 takes values below 16 p; X' of an addition
+          // is below 8 p, of a doubling below 19 p: one subtraction of 8 p first, kept when it stays non-negative)
+          constexpr int JT = QuadDims<NL>::JTOP;
+          int dd[M];
+#pragma unroll
+          for (int j = 0; j < M; ++j) dd[j] = x[j] - 8 * (int)c.p[j];
+          quad_tight<NL>(dd, c);
+          const int top = quad_bcast<3>(dd[JT]);
+          if (top >= 0) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) x[j] = dd[j];
+          }
+          quad_canonical16<NL>(x, c);
+        } else {
+          quad_canonical<NL>(x, c);
+        }
+        const bool zero = quad_is_zero<NL>(x);
+        if (c.sub == 0) note[el][c.quad == 0 ? 2 : 3] = zero ? 1u : 0u;
+      }
+      const bool zx = note[el][2] != 0, zz = note[el][3] != 0;
+      if (took && zz) {
+        if (seg == QUADG_SEG_GADD && zx) need_dbl = true;      // acc == entry
+        else acc_inf = true;                                   // acc == -entry, or 2 * (a point of order two)
+      }
+    }
+  }
+  if (c.quad < 2) {
+    get(c.quad);
+    if (live) {
+      u32* dst = park + e * g1q_park_words<NL>() + (size_t)c.quad * (4 * M) + (size_t)c.sub * M;
+#pragma unroll
+      for (int j = 0; j < M; ++j) dst[j] = (u32)x[j];
+    }
+  } else if (c.quad == 2) {
+    get(QUADG_SLOT_Z);
+    quad_canonical<NL>(x, c);
+    if (live) {
+      quad_gstore<NL>(zsoa, sw, e, c.sub, x);
+      if (c.sub == 0) flags[e] = (uint8_t)(acc_inf ? G1Q_FLAG_INF : 0u);
+    }
+  }
+}
+
 // ---- the last launch: affine coordinates, plain canonical residues (what k_g1_mul writes) ----------------------------
 template <int NL>
 __global__ void __launch_bounds__(QUAD_BLOCK)

@@ -134,6 +134,60 @@ class PowerMixin:
         self.run("AFF")
         return ("pt", self.value(self.get("out0")) % self.p, self.value(self.get("out1")) % self.p)
 
+    def g1_fixed(self, tab_p, tab_q, wbits, x, xlen, r, rlen, force_dummy_adds=True):
+        """P^x * Q^r as k_g1_fixed_quad computes it from window tables tab[w][d] = affine point d * 2^(wbits*w) * B (None:
+        the identity; d = 0 never read).  Returns ("inf",) or ("pt", x, y), plain residues."""
+        G, A = g1_programs()
+        self.P, self.V = G, {}
+        protect = {G.phys[s] for s in STATE}
+        one = self.mont(1)
+        for s_ in STATE + ENTRY:
+            self.put(s_, one)
+        acc_inf = True
+        wx = (8 * xlen + wbits - 1) // wbits if x is not None else 0
+        wr = (8 * rlen + wbits - 1) // wbits if r is not None else 0
+        dbls = 0
+        for i in range(wx + wr):
+            isx = i < wx
+            lw = i if isx else i - wx
+            k = x if isx else r
+            d = (k >> (wbits * lw)) & ((1 << wbits) - 1)
+            ent = (tab_p if isx else tab_q)[lw][d] if d else None
+            use = d != 0 and ent is not None
+            if not use and not force_dummy_adds:
+                continue
+            src = ent if use else (tab_p[0][1])
+            self.put("tx", self.mont(src[0]))
+            self.put("ty", self.mont(src[1]))
+            took = use and not acc_inf
+            if use and acc_inf:
+                for s_, t in zip(STATE, ENTRY):
+                    self.V[G.phys[s_]] = self.get(t)
+                acc_inf = False
+            self.run_protected("GADD", not took, protect)
+            if took and self.value(self.get("Z")) % self.p == 0:
+                if self.value(self.get("X")) % self.p == 0:                     # acc == entry: double the entry
+                    for s_, t in zip(STATE, ENTRY):
+                        self.V[G.phys[s_]] = self.get(t)
+                    self.run_protected("GDBL", False, protect)
+                    dbls += 1
+                    if self.value(self.get("Z")) % self.p == 0:
+                        acc_inf = True
+                else:
+                    acc_inf = True                                              # acc == -entry
+        self.doublings = dbls
+        if acc_inf:
+            return ("inf",)
+        X, Y = self.get("X"), self.get("Y")
+        zi = self.R * self.R * pow(self.value(self.get("Z")) % self.p, -1, self.p) % self.p
+        self.P, self.V = A, {}
+        self.V[A.phys["X"]] = X
+        self.V[A.phys["Y"]] = Y
+        self.put("zi", zi)
+        self.put("raw1", 1)
+        self.run("AFF")
+        return ("pt", self.value(self.get("out0")) % self.p, self.value(self.get("out1")) % self.p)
+
     def gt_pow(self, g0, g1, k, klen, wave_top=None):
         """(g0 + i g1)^k with plain residues in and out, as k_gt_pow_quad_each computes it.  wave_top: the highest
         window the wave starts from (another element's exponent may be longer)."""

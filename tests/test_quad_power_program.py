@@ -94,6 +94,61 @@ def test_gt_power_on_integers_matches_the_oracle(key):
     assert m.gt_pow(g[0], g[1], k, 5) == R.f2_pow(g, k, p)
 
 
+def _window_table(R, B, p, wbits, windows):
+    """tab[w][d] = d * 2^(wbits*w) * B as affine points (None: the identity)."""
+    tab = []
+    for w in range(windows):
+        base = R.pt_mul(B, 1 << (wbits * w), p)
+        row = [None]
+        for d in range(1, 1 << wbits):
+            row.append(R.pt_mul(base, d, p))
+        tab.append([None if (pt is None or pt == (0, 0) or pt == "O") else pt for pt in row])
+    return tab
+
+
+def test_fixed_base_product_on_integers_matches_the_oracle_and_resolves_the_exceptional_cases():
+    """P^x * Q^r over window tables (k_g1_fixed_quad's controller): random scalars; then tables in which the
+    accumulator MUST meet the entry — Q = P with x = r (the sum is a doubling: the state becomes the entry, one GDBL) —
+    and its negative — Q = -P with x = r (the sum is the identity)."""
+    import bgn_ref as R
+    fx = load_fixture("k256")
+    p = int(fx["p"], 16)
+    Pp = R.elem_from_bytes(bytes.fromhex(fx["P"]), p)
+    Qp = R.elem_from_bytes(bytes.fromhex(fx["Q"]), p)
+    nl = qm.nl_for(p)
+    wbits, xlen, rlen = 4, 1, 2
+    tp = _window_table(R, Pp, p, wbits, 4)
+    tq = _window_table(R, Qp, p, wbits, 4)
+    rng = random.Random(11)
+    for x, r in [(0x5a, 0x1234), (0, 0x00f0), (0x30, 0), (rng.randrange(256), rng.randrange(65536))]:
+        m = qpm.PowerValueMachine(p, nl)
+        got = m.g1_fixed(tp, tq, wbits, x, xlen, r, rlen)
+        want = R.pt_add(R.pt_mul(Pp, x, p), R.pt_mul(Qp, r, p), p)
+        assert got == ("pt", want[0], want[1]), (hex(x), hex(r))
+        assert m.doublings == 0
+    assert qpm.PowerValueMachine(p, nl).g1_fixed(tp, tq, wbits, 0, xlen, 0, rlen) == ("inf",)
+    # deterministic Encrypt: no r at all
+    m = qpm.PowerValueMachine(p, nl)
+    want = R.pt_mul(Pp, 0x77, p)
+    assert m.g1_fixed(tp, tq, wbits, 0x77, 1, None, 0) == ("pt", want[0], want[1])
+    # acc == entry: Q's table is P's, x = r = one digit in window 0
+    m = qpm.PowerValueMachine(p, nl)
+    want = R.pt_mul(Pp, 2 * 0x05, p)
+    assert m.g1_fixed(tp, tp, wbits, 0x05, 1, 0x05, 1) == ("pt", want[0], want[1]) and m.doublings == 1
+    # acc == -entry: Q = -P
+    tn = _window_table(R, R.pt_neg(Pp, p), p, wbits, 4)
+    m = qpm.PowerValueMachine(p, nl)
+    assert m.g1_fixed(tp, tn, wbits, 0x05, 1, 0x05, 1) == ("inf",)
+    # ... and the accumulator goes on from the identity: x = 0x35, r = 0x05 -> (5 + 48 - 5) P
+    m = qpm.PowerValueMachine(p, nl)
+    want = R.pt_mul(Pp, 0x30, p)
+    assert m.g1_fixed(tp, tn, wbits, 0x35, 1, 0x05, 1) in (("pt", want[0], want[1]),)
+    # the lane-level model on one random product
+    m = qpm.PowerLaneMachine(p, nl)
+    want = R.pt_add(R.pt_mul(Pp, 0xa7, p), R.pt_mul(Qp, 0x0c31, p), p)
+    assert m.g1_fixed(tp, tq, wbits, 0xa7, xlen, 0x0c31, rlen) == ("pt", want[0], want[1])
+
+
 def test_quad_power_schedules():
     """Three rounds per doubling, five per addition, seventeen value slots: five row blocks of LDS, three workgroups
     per CU like the Miller loop; every round at most four micro-ops that read only earlier rounds' values."""

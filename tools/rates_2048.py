@@ -38,7 +38,18 @@ def main():
     eng.encrypt(xs[:64], rs[:64])
     dt, cts = best(lambda: eng.encrypt(xs, rs))
     print("encrypt,%d,%.2f,%.1f,%s" % (2 * N, dt * 1e3, 2 * N / dt, eng.last_kernel_name()))
+    with eng.options(quad_max_enc=0):                    # the 72-limb chain kernels (functional) beside it
+        dt, cts0 = best(lambda: eng.encrypt(xs[:N], rs[:N]), reps=1)
+        assert cts0.tobytes() == cts[:N].tobytes()
+        print("encrypt (chain kernels: the functional fallback),%d,%.2f,%.1f,%s" % (N, dt * 1e3, N / dt, eng.last_kernel_name()))
     a, b = cts[:N].tobytes(), cts[N:].tobytes()
+    ks = [rng.randrange(n) for _ in range(N)]
+    dt, mc = best(lambda: eng.multconst(1, a, ks))
+    print("multconst_l1 (2048-bit k),%d,%.2f,%.1f,%s" % (N, dt * 1e3, N / dt, eng.last_kernel_name()))
+    with eng.options(quad_max_mc=0):
+        dt, mc0 = best(lambda: eng.multconst(1, a[: 64 * eng.elem_bytes], ks[:64]), reps=1)
+        assert mc0.tobytes() == mc[:64].tobytes()
+        print("multconst_l1 (lane kernel: the functional fallback),%d,%.2f,%.1f,%s" % (64, dt * 1e3, 64 / dt, eng.last_kernel_name()))
     dt, _ = best(lambda: eng.add(1, a, b))
     print("add_l1,%d,%.2f,%.1f,%s" % (N, dt * 1e3, N / dt, eng.last_kernel_name()))
     for cnt in (256, 4096):

@@ -81,8 +81,9 @@ struct QuadDims {
   static constexpr int SLOT_BYTES = MR * ROW_BYTES;   // one row block: a value for each quad of every pairing
   static constexpr int PARK_WORDS = 3 * 4 * M;        // per pairing: F0^2, F1^2, F0*F1 as they lie in the lanes
   static_assert(M >= 2 && JTOP >= 0 && JTOP < M, "limb split");
-  // 64-bit signed accumulators: 2 * min(M, 8 + ...) products of < 2^(2 * LIMB_BITS + 1) between carries (quad_row)
-  static_assert(M <= 15 || 2ull * 16 * (1ull << (2 * LIMB_BITS + 1)) < (1ull << 63), "accumulator headroom");
+  // 64-bit signed accumulators: at most 2 * min(M, 15) products of < 2^(2 * LIMB_BITS) and a carry between two
+  // carry-outs (quad_row: one mid-life carry per accumulator from 16 limbs per lane on)
+  static_assert(M <= 30 && (M <= 15 ? 2ull * M : 2ull * (M - M / 2 + 1)) * (1ull << (2 * LIMB_BITS)) < (1ull << 63), "accumulator headroom");
 };
 
 // quad_perm moves (all four lanes of a quad are always active)
@@ -246,17 +247,19 @@ __device__ __forceinline__ void quad_row(long long (&acc)[QuadDims<NL>::M], int&
   acc[0] += cy;
   acc[M - 1] = (long long)(u64)(u32)quad_from_above((int)lo);
   // An accumulator collects two products of up to 2^(2 * LIMB_BITS) per row for the M rows it lives: 2 M * 2^58 stays
-  // below 2^63 up to M = 15 (1024-bit keys: M = 9 / 10).  At 18 limbs per lane (2048-bit keys) the lane's accumulators
-  // carry into each other every eighth row — exact inside the lane, as in quad_normalize — so that none of them ever
-  // holds more than 16 products and a carry (the one-element-per-lane kernels flush likewise: fpmont.hpp kRowsPerFlush).
+  // below 2^63 up to M = 15 (1024-bit keys: M = 9 / 10).  At 18 limbs per lane (2048-bit keys) every accumulator is
+  // carried out ONCE, half way through its life: an accumulator is born at index M - 1 and moves down one index per
+  // row, so the one at index M / 2 - 1 has lived M / 2 rows — its upper dword goes to its upper neighbour (2^32 =
+  // 2^(32 - LIMB_BITS) units there: one v_mad_i64_i32 with the factor kept opaque so that it is not turned into a
+  // 64-bit shift and add; exact inside the lane, as in quad_normalize) and it keeps its lower dword.  No accumulator
+  // then ever holds more than M products and a carry (18 * 2^58 < 2^63), also at the end of the product; two
+  // instructions per row instead of a pass over all the accumulators.
   if constexpr (M > 15) {
-    if constexpr ((I & 7) == 7 && I + 1 < NL) {
-#pragma unroll
-      for (int j = 0; j < M - 1; ++j) {
-        acc[j + 1] += acc[j] >> LIMB_BITS;
-        acc[j] &= (long long)LIMB_MASK;
-      }
-    }
+    constexpr int F = M / 2 - 1;
+    int unit = 1 << (32 - LIMB_BITS);
+    asm("" : "+s"(unit));
+    acc[F + 1] = imad((int)(acc[F] >> 32), unit, acc[F + 1]);
+    acc[F] = (long long)(u64)(u32)acc[F];
   }
 }
 

@@ -37,7 +37,7 @@ def programs():
 
 def nl_for(p: int) -> int:
     need = (p.bit_length() + 9 + LIMB - 1) // LIMB
-    return next(x for x in (10, 19, 36, 37) if x >= need)
+    return next(x for x in (10, 19, 36, 37, 72) if x >= need)
 
 
 class QuadValueMachine:
@@ -270,6 +270,11 @@ class QuadLaneMachine(QuadValueMachine):
             up = self.rot_down(lo)                                           # lane s takes the low bits of lane s + 1
             acc = np.concatenate([acc[:, 1:], up.reshape(4, 1)], axis=1)
             acc[:, 0] += c
+            if m > 15:                                                       # quad_row: one mid-life carry per accumulator
+                f = m // 2 - 1
+                acc[:, f + 1] += (acc[:, f] >> I64(32)) * I64(1 << (32 - LIMB))   # upper dword: v_mad_i64_i32
+                acc[:, f] &= I64(0xFFFFFFFF)
+            assert np.all(np.abs(acc) < (1 << 62) + (1 << 61)), "accumulator headroom"
         return acc
 
     def exec_uop(self, u):

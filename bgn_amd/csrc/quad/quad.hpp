@@ -13,8 +13,10 @@
 //     holds limbs s*M .. s*M + M - 1).  A Montgomery product is NL rows of {broadcast one limb of a inside the quad
 //     (DPP quad_perm), M multiply-adds into the lane's accumulators, the quotient digit from lane 0 (broadcast), M
 //     multiply-adds of p, retire the lowest accumulator: its low 29 bits move to the lane below (DPP), the rest
-//     into the next accumulator} — 2 M + 9 instructions per row and lane, 1.1 k per product at a 1024-bit key
-//     against 3.2 k for a lane that multiplies alone;
+//     into the next accumulator} — 2 M + 6 instructions per row and lane (the two masks ride on the DPP moves as
+//     v_and_b32_dpp: LIMB_MASK is kept in a VGPR for that), 0.9 k per product at a 1024-bit key against 2.7 k for a
+//     lane that multiplies alone; at three waves per SIMD the chip does 9.3 x 10^9 such products per second
+//     (tools/ubench/quad_rows.hip), 8.2 x 10^9 with one element per lane at the one wave a 512-register kernel has;
 //   * limbs are signed and lazily normalised as in the cooperative kernel: a carry pass is exact inside a lane and
 //     hands the lane's carry-out to the two lowest limbs of the lane above; lane 3 keeps the whole top limb
 //     (position NL - 1), so no position beyond the NL rows of a product ever holds anything;
@@ -102,6 +104,7 @@ template <int NL>
 struct QuadLane {
   u32 p[QuadDims<NL>::M];   // this lane's limbs of the modulus
   u32 pinv;                 // -p^-1 mod 2^29
+  u32 maskv;                // LIMB_MASK in a VGPR: the masks behind a DPP move fold into v_and_b32_dpp
   u32 keep_top;             // carry pass at index JTOP: bits kept (29; everything in lane 3)
   u32 carry_top;            // ... and whether a carry goes on (not in lane 3)
   u32 base;                 // LDS byte offset of this lane's column of row block 0, quad 0
@@ -233,19 +236,24 @@ __device__ __forceinline__ void quad_row(long long (&acc)[QuadDims<NL>::M], int&
   constexpr int M = QuadDims<NL>::M;
   const int ai = an;
   acc[0] = imad(ai, b[0], acc[0]);
-  u32 q = ((u32)acc[0] * c.pinv) & LIMB_MASK;
+  u32 q = (u32)acc[0] * c.pinv;
   if (I + 1 < NL) an = quad_bcast<(I + 1 < NL ? I + 1 : 0) / M>(a[(I + 1 < NL ? I + 1 : 0) % M]);
 #pragma unroll
   for (int j = 1; j < M; ++j) acc[j] = imad(ai, b[j], acc[j]);
-  q = (u32)quad_bcast<0>((int)q);
+  q = (u32)quad_bcast<0>((int)q) & c.maskv;
 #pragma unroll
   for (int j = 0; j < M; ++j) acc[j] = (long long)((u64)acc[j] + (u64)q * (u64)c.p[j]);
-  const u32 lo = (u32)acc[0] & LIMB_MASK;
+  const u32 lo = (u32)acc[0];
   const long long cy = acc[0] >> LIMB_BITS;
 #pragma unroll
   for (int j = 0; j < M - 1; ++j) acc[j] = acc[j + 1];
   acc[0] += cy;
-  acc[M - 1] = (long long)(u64)(u32)quad_from_above((int)lo);
+  acc[M - 1] = (long long)(u64)((u32)quad_from_above((int)lo) & c.maskv);
+  // The accumulators are pinned at the end of every row (no instruction): left alone, the compiler sums each column of
+  // the unrolled product in ONE register pair — 2 M dependent multiply-adds in a row — and copies the hand-over into it;
+  // row by row the multiply-adds of a row are independent and the hand-over lands where the next row adds to it.
+#pragma unroll
+  for (int j = 0; j < M - 1; ++j) asm volatile("" : "+v"(acc[j]));
   // An accumulator collects two products of up to 2^(2 * LIMB_BITS) per row for the M rows it lives: 2 M * 2^58 stays
   // below 2^63 up to M = 15 (1024-bit keys: M = 9 / 10).  At 18 limbs per lane (2048-bit keys) every accumulator is
   // carried out ONCE, half way through its life: an accumulator is born at index M - 1 and moves down one index per
@@ -349,6 +357,7 @@ __device__ __forceinline__ void quad_lane_init(QuadLane<NL>& c, const FpParams<N
   c.quad = (tid >> 2) & 3;
   c.base = (u32)(((tid & ~15) + (tid & 3)) * 8);
   c.pinv = P->pinv;
+  c.maskv = (u32)opaque_vgpr((int)LIMB_MASK);
   c.keep_top = c.sub == 3 ? 0xFFFFFFFFu : LIMB_MASK;
   c.carry_top = c.sub == 3 ? 0u : 0xFFFFFFFFu;
 #pragma unroll

@@ -211,11 +211,18 @@ def main():
             sa, sb = bytes(a[j * EB: (j + k) * EB].cpu().numpy()), bytes(b[j * EB: (j + k) * EB].cpu().numpy())
             assert bytes(out[j * EB: (j + k) * EB].cpu().numpy()) == K["oracle"].add(1, sa, sb), (name, op, n)
         elif op == "encrypt":
-            force("default")
-            out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
-            eng.encrypt_dev(K["xs"][off: off + n], K["nbytes"], K["rs"][off: off + n], K["r_len"], out, n)
-            torch.cuda.synchronize()
-            assert torch.equal(out, a), (name, op, n)               # the same inputs gave cts at set-up (one launch of 2^18)
+            # the chain kernels and the lane groups (k_g1_fixed_quad): one is the default, the other forced
+            alts = [{}]
+            if name == "k2048":
+                alts += [{"quad_max_enc": 0}] if n <= 4096 else []
+            elif n <= 30000:
+                alts += [{"quad_max_enc": 1 << 20}]
+            for env in alts:
+                force("default", **env)
+                out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+                eng.encrypt_dev(K["xs"][off: off + n], K["nbytes"], K["rs"][off: off + n], K["r_len"], out, n)
+                torch.cuda.synchronize()
+                assert torch.equal(out, a), (name, op, n, env)      # the same inputs gave cts at set-up (one launch of 2^18)
         else:
             d1, d2 = rng.choice([(2, 2), (3, 5), (4, 4), (8, 8), (5, 1), (6, 6), (16, 16), (7, 3)])
             npoly = max(1, min(n // (d1 * d2), NMAX // max(d1, d2) - 1, 3000))

@@ -894,7 +894,7 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // e(C, P) and wins only below ~2000 / ~800 ciphertexts
   if (quad_tw && c->xo.coop[mode] >= 0) return (size_t)c->xo.coop[mode];        // bgn_ctx_calibrate
   if (mode == 2 || (mode == 3 && quad_tw)) {
-    if (quad_tw) return c->nl >= 36 ? 1150 : c->nl >= 19 ? 900 : 512;
+    if (quad_tw) return c->nl >= 36 ? 1300 : c->nl >= 19 ? 740 : 512;
     return tw ? (c->nl >= 36 ? 14000 : c->nl >= 19 ? 4000 : 2048) : (c->nl >= 36 ? 2000 : c->nl >= 19 ? 800 : 512);
   }
   // mode 3: Decrypt's power by the secret key: 1.5 rounds per bit on the waves (≈ 1 ms at 1024 bits, one element
@@ -905,13 +905,15 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // kernels walk P's line table): 1024 bits — 8192: 52.5 against 54.3 ms, 16384: 103 against 54; 512 bits —
   // 4096: 8.7 against 10.6 ms, 8192: 16.7 against 10.6 (general cooperative program: 3000 / 1800).
   if (mode == 1) {
-    if (quad_tw) return c->nl >= 36 ? 900 : c->nl >= 19 ? 700 : 512;
+    if (quad_tw) return c->nl >= 36 ? 850 : c->nl >= 19 ? 640 : 512;
     return tw ? (c->nl >= 36 ? 8000 : c->nl >= 19 ? 4800 : 2048) : (c->nl >= 36 ? 3000 : c->nl >= 19 ? 1800 : 1024);
   }
   // Mult: with the lane-group kernel above it (profiles/r03_mid_batch.csv: 1024 pairs 17.8 ms cooperative against
   // 21.2 ms, 1536: 25.1 against 21.3 at 1024 bits; 512 bits: 1024 pairs 5.3 against 5.2 ms) the crossover is where
   // that kernel's one-round time is reached; without it, the lane kernel's (r02_small_batch.csv)
-  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 1280 : c->nl >= 19 ? 1000 : 800;
+  // (round 4, 24-instruction rows: profiles/r04_mid_batch.csv 1024 pairs 17.0 ms cooperative against 17.8, 512 bits
+  // 5.3 against 4.9; profiles/r04_calibrate.csv puts the crossings at 1100 / 920)
+  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 1100 : c->nl >= 19 ? 920 : 800;
   return c->nl >= 36 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
@@ -929,7 +931,9 @@ static size_t quad_limit(const bgn_ctx* c) {
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
   if (c->xo.quad[0] >= 0) return (size_t)c->xo.quad[0];                // bgn_ctx_calibrate
-  return c->nl >= 36 ? 49000 : c->nl >= 19 ? 40000 : 32768;
+  // profiles/r04_mid_batch.csv: 49152 pairs 149 ms against 157 on the lane kernel (512 bits: 32.1 against 28.5 at
+  // 49152, 22.0 against 28.4 at 32768); profiles/r04_calibrate.csv: 51 300 / 43 000
+  return c->nl >= 36 ? 51000 : c->nl >= 19 ? 43000 : 32768;
 }
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
 // (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts
@@ -943,8 +947,9 @@ static size_t quad_table_limit(const bgn_ctx* c, int mode) {
   // profiles/r03_mid_batch_table.csv, whole calls at 1024 / 512 bits: Decrypt of 16384 ciphertexts 21.0 / 4.3 ms
   // against 36.6 / 6.9 on the lane kernels, of 32768 36.7 / 7.5 against 36.9 / 6.9; makeL2 of 32768 37.4 / 8.5 against
   // 53.2 / 10.6, of 65536 72.2 / 15.9 against 53.7 / 10.8
-  if (mode == 3 || mode == 2) return c->nl >= 36 ? 32000 : c->nl >= 19 ? 28000 : 16384;
-  return c->nl >= 36 ? 46000 : c->nl >= 19 ? 42000 : 16384;
+  // (round 4: profiles/r04_calibrate.csv 33 100 / 30 200 and 48 300 / 43 600)
+  if (mode == 3 || mode == 2) return c->nl >= 36 ? 33000 : c->nl >= 19 ? 30000 : 16384;
+  return c->nl >= 36 ? 48000 : c->nl >= 19 ? 43500 : 16384;
 }
 
 // MultConst with per-element scalars on the lane groups (quad/quad_g1.hpp: sixteen lanes per element, level 1 a
@@ -965,7 +970,9 @@ static size_t quad_mc_limit(const bgn_ctx* c, int level, size_t klen) {
   // 512-bit key, 32768 / 49152 elements: level 1, 256-bit scalars 7.6 / 10.9 against 8.5 / 9.0, 40-bit 1.6 / 2.2 against
   // 2.2 / 2.2; level 2, 256-bit 2.9 / 4.1 against 3.3 / 3.3, 40-bit 0.66 / 0.93 against 0.58 / 0.60.
   const bool short_k = klen < 16;
-  if (c->nl >= 36) return level == 1 ? (short_k ? 65536 : 46000) : (short_k ? 32768 : 46000);
+  // (round 4's 24-instruction rows, same file re-measured: level 1, 1024-bit scalars 49152 elements 96.0 against 93.7 ms;
+  // level 2 35.0 against 35.4)
+  if (c->nl >= 36) return level == 1 ? (short_k ? 65536 : 47000) : (short_k ? 32768 : 49000);
   if (c->nl >= 19) return level == 1 ? (short_k ? 48000 : 38000) : (short_k ? 28000 : 37000);
   return level == 1 ? 32768 : 24576;
 }

@@ -1816,7 +1816,10 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
   const size_t st = round_up(count, 64);
   // the lane groups take up to quad_mc_limit elements (a whole small batch, or the remainder of a large one)
   const size_t qlim = k_len <= 1024 ? quad_mc_limit(c, level, k_len) : 0;
-  const size_t qmax = round_up(count < qlim ? count : qlim, 64);
+  // (where the lane groups take every size — 72 limbs — they take it in pieces of 2^17 elements, ten times what fills the
+  // chip: the ladder's per-element table is 11.5 KB there, and the workspace stays 1.5 GB whatever the batch)
+  const size_t qpiece = qlim > ((size_t)1 << 17) ? (size_t)1 << 17 : qlim;
+  const size_t qmax = round_up(count < qpiece ? count : qpiece, 64);
   const size_t qws_bytes = !qlim ? 0 : 4 * (level == 1 ? quad_g1_mul_ws_words(c->nl, qmax, k_len) : quad_gt_pow_each_ws_words(c->nl, qmax));
   SoA2 A, O, T1, T2;
   uint32_t* prefix = nullptr;
@@ -1850,10 +1853,11 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
     // res.PowBig(c.C, constant), bgn.go:258 / :277.  The lane kernels run one element per lane, rounds of 65536:
     // whole rounds go to them, what the lane groups can take goes there.
     size_t n = count - off;
-    bool quad = qws && n <= qlim;
+    if (qws && qlim >= kMaxBatch && n > qpiece) n = qpiece;
+    bool quad = qws && n <= qpiece;
     if (!quad && qws && opt(c, &Options::split_rounds) != 0) {
       const size_t rem = n % 65536;
-      if (rem && rem <= qlim && n > rem) n -= rem;
+      if (rem && rem <= qpiece && n > rem) n -= rem;
     }
     const SoA2 Av = view(A, off), Ov = view(O, off);
     const uint8_t* kv = k_be + off * k_len;

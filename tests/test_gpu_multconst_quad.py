@@ -99,6 +99,32 @@ def test_multconst_batches_cut_into_lane_rounds_and_a_lane_group_remainder(engop
     assert got[1] == got[0]
 
 
+def test_multconst_lane_groups_at_every_size_run_in_pieces(engopts):
+    """Where the lane groups take every batch size (the default at 72 limbs; here quad_max_mc = 2^28 on a small key)
+    they take it in pieces of 2^17 elements, so that the ladder's per-element tables stay a bounded workspace: 2^17 +
+    300 elements are two pieces, bytes equal to the one-element-per-lane kernels', both levels."""
+    fx = load_fixture("k256")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    rng = np.random.default_rng(9)
+    count = (1 << 17) + 300
+    base = eng.encrypt([int(v) for v in rng.integers(0, fx["msg_space"], 64)], [int(v) + 3 for v in rng.integers(0, 1 << 60, 64)])
+    idx = rng.integers(0, 64, count)
+    wire = base[idx].tobytes()
+    ks = [int(v) for v in rng.integers(0, 1 << 62, count)]
+    l2 = eng.make_l2(base.tobytes())[idx].tobytes()
+    got = {}
+    for lim in (1 << 28, 0):
+        engopts.set("quad_max_mc", lim)
+        before = eng.memory_bytes()
+        got[lim] = (eng.multconst(1, wire, ks).tobytes(), eng.multconst(2, l2, ks).tobytes())
+        assert ("quad" in eng.last_kernel_name()) == (lim != 0)
+        if lim:
+            # the workspace grew by what 2^17 elements need (1.7 KB of table each at 10 limbs), not by the batch
+            assert eng.memory_bytes() - before < (1 << 17) * 8192
+    assert got[1 << 28] == got[0]
+
+
 def test_multconst_default_dispatch():
     """No overrides: a single element and a few thousand go to the lane groups."""
     fx = load_fixture("k256")

@@ -931,9 +931,9 @@ static size_t quad_limit(const bgn_ctx* c) {
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
   if (c->xo.quad[0] >= 0) return (size_t)c->xo.quad[0];                // bgn_ctx_calibrate
-  // profiles/r04_mid_batch.csv: 49152 pairs 149 ms against 157 on the lane kernel (512 bits: 32.1 against 28.5 at
-  // 49152, 22.0 against 28.4 at 32768); profiles/r04_calibrate.csv: 51 300 / 43 000
-  return c->nl >= 36 ? 51000 : c->nl >= 19 ? 43000 : 32768;
+  // profiles/r04_mid_batch.csv (nine-round segments): 49152 pairs 134 ms, 65536 178 ms against 157 on the lane kernel
+  // (512 bits: 65536 pairs 37.9 against 28.6, 32768 19.9 against 28.4); profiles/r04_calibrate.csv: 57 000 / 49 000
+  return c->nl >= 36 ? 57000 : c->nl >= 19 ? 49000 : 32768;
 }
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
 // (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts

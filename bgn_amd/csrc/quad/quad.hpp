@@ -456,8 +456,8 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
       put(QUADM_SLOT_V1);
     }
     // Miller loop over the NAF of n (pairing.hpp miller_loop): a doubling and the addition of +-A that follows it
-    // (one segment, ten rounds) or one doubling per segment (five); the last addition is
-    // skipped as in PBC; then the norms' segment.
+    // (one segment, nine rounds), two plain doublings (nine) or one (five); the last addition is skipped as in PBC;
+    // then the norms' segment.
     const u32* nafw = reinterpret_cast<const u32*>(C->naf);
     auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
     int i = C->naf_len - 2;
@@ -469,10 +469,14 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
         const int d = digit(i);
         if (d != 0 && i != 0) {
           seg = d > 0 ? QUADM_SEG_DAP : QUADM_SEG_DAM;
+          i -= 1;
+        } else if (i >= 1 && (i - 1 == 0 || digit(i - 1) == 0)) {
+          seg = QUADM_SEG_DBL2;                     // the next step is a plain doubling too: 36 products in nine rounds
+          i -= 2;
         } else {
           seg = QUADM_SEG_DBL;
+          i -= 1;
         }
-        i -= 1;
       } else if (!norms) {
         seg = QUADM_SEG_NORM;
         norms = true;

@@ -296,7 +296,7 @@ k_g1_mul_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ bx, co
 // ---- fixed-base products on the lane groups ------------------------------------------------------------------------
 // S = P^x * Q^r (EncryptWithRandomness, bgn.go:344-350; the blinding terms Q^r) from the key's window tables
 // (engine.cpp ensure_fixed_tables: entry (w, d) = d * 2^(wbits*w) * B, x limbs then y limbs, canonical Montgomery,
-// all-zero = the identity), sixteen lanes per element: one GADD per window with the entry as (x, y, 1, 1, 1).
+// all-zero = the identity), sixteen lanes per element: one mixed addition (GADM: four rounds) per window, the entry affine.
 // Every case of the addition is exact INSIDE the kernel: after an addition whose result becomes the state the
 // canonical Z' and X' are tested — Z' = 0 means the accumulator met the entry or its negative (H = 0); then X' = r^2
 // tells which: zero for equal points (the state becomes the entry and one GDBL doubles it, its stores suppressed for
@@ -384,7 +384,7 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
       }
       ent_inf = (note[el][0] | note[el][1]) == 0;      // (same wave: the LDS writes above precede these reads)
       const bool use = d != 0 && !ent_inf;
-      seg = QUADG_SEG_GADD;
+      seg = QUADG_SEG_GADM;                             // the table's entries are affine: the mixed addition, four rounds
       took = use && !acc_inf;
       keep = !took;
       if (use && acc_inf) {                             // identity + T = T (Z, Z^2 = 1 from the entry's slots)
@@ -420,7 +420,7 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
       }
       const bool zx = note[el][2] != 0, zz = note[el][3] != 0;
       if (took && zz) {
-        if (seg == QUADG_SEG_GADD && zx) need_dbl = true;      // acc == entry
+        if (seg == QUADG_SEG_GADM && zx) need_dbl = true;      // acc == entry
         else acc_inf = true;                                   // acc == -entry, or 2 * (a point of order two)
       }
     }

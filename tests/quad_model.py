@@ -112,6 +112,9 @@ class QuadValueMachine:
             if d[i] and i != 0:
                 self.run("DAP" if d[i] > 0 else "DAM")                    # doubling + addition of +-A, one segment
                 i -= 1
+            elif i >= 1 and (d[i - 1] == 0 or i - 1 == 0):
+                self.run("DBL2")                                          # two plain doublings: nine rounds instead of ten
+                i -= 2
             else:
                 self.run("DBL")
                 i -= 1

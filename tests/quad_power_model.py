@@ -164,7 +164,7 @@ class PowerMixin:
                 for s_, t in zip(STATE, ENTRY):
                     self.V[G.phys[s_]] = self.get(t)
                 acc_inf = False
-            self.run_protected("GADD", not took, protect)
+            self.run_protected("GADM", not took, protect)
             if took and self.value(self.get("Z")) % self.p == 0:
                 if self.value(self.get("X")) % self.p == 0:                     # acc == entry: double the entry
                     for s_, t in zip(STATE, ENTRY):

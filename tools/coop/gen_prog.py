@@ -27,6 +27,7 @@ import sys
 W = 8                 # waves per pairing: two per SIMD; slots k and k + 4 of a round share a SIMD
 BASE = 4              # products a round takes freely (one per SIMD); more only when they are on the critical path
 QUAD_W = 4            # lane-group kernel: quads of lanes per pairing (a round costs the same with one product or four)
+QUAD_TRIES = 400      # schedules tried per Miller segment of the lane-group kernel (Program.segment)
 MAX_TERMS = 4         # terms per linear operand
 BOUND_PRODUCT = 512   # bound(A) * bound(B) <= 2^9 <= R/p (engine.cpp chooses NL so)
 MUL_WEIGHT, LIN_WEIGHT = 10, 1
@@ -123,7 +124,7 @@ class Builder:
 ROUND_FIXED, ROUND_PRODUCT, ROUND_HEAVY = 1000, 1700, 1.33
 
 
-def schedule(uops, w=W, base=BASE, anti=None):
+def schedule(uops, w=W, base=BASE, anti=None, rng=None, jitter=0.0):
     """Scheduling into rounds of at most w micro-ops; a micro-op reads only slots written in earlier rounds (or
     never written in this segment).  Products are taken in order of their longest path to a sink.  Two waves on a
     SIMD share its issue slots, so a round with more than `base` products takes about 1.33x as long (measured) as one with at
@@ -148,6 +149,8 @@ def schedule(uops, w=W, base=BASE, anti=None):
     for i in reversed(range(len(uops))):
         wgt = MUL_WEIGHT if uops[i].kind == "mul" else LIN_WEIGHT
         prio[i] = wgt + max((prio[j] for j in users[i]), default=0)
+    if rng is not None:                       # a perturbed order of equally (or nearly equally) urgent micro-ops: Program.segment
+        prio = [p + rng.random() * jitter for p in prio]    # tries several and keeps the one with the fewest temporaries
     n = len(uops)
     best = [None, None]                       # cost, list of rounds (index lists)
 
@@ -224,9 +227,34 @@ class Program:
         self.bound[name] = bound
         return S(name)
 
-    def segment(self, name, build, inplace=None):
+    def temps_of(self, name, rounds):
+        """Temporaries a schedule of segment `name` needs (the count allocate_temps arrives at)."""
+        last_read = {}
+        for r, us in enumerate(rounds):
+            for u in us:
+                for s in u.reads():
+                    last_read[s] = r
+        free, busy, nxt = 0, {}, 0
+        for r, us in enumerate(rounds):
+            for s in [s for s, lr in busy.items() if lr < r or (self.reads_first and lr == r)]:
+                busy.pop(s)
+                free += 1
+            for u in us:
+                if u.dst in self.phys and not u.dst.startswith(name + ".t"):
+                    continue
+                if free:
+                    free -= 1
+                else:
+                    nxt += 1
+                busy[u.dst] = last_read[u.dst]
+        return nxt
+
+    def segment(self, name, build, inplace=None, tries=0):
         """inplace: {new name: old name} — the micro-op writing `new` stores into the slot of `old`, which other
-        micro-ops of the segment still read as the old value (needs reads_first)."""
+        micro-ops of the segment still read as the old value (needs reads_first).
+        tries: beside the schedule of the plain priorities, that many with perturbed priorities (seeds 1 .. tries,
+        deterministic) are made and the one with the fewest rounds, then the fewest temporaries, is kept — a segment
+        packed into whole rounds keeps more values alive, and the LDS has room for so many slots."""
         b = Builder(self.bound, name)
         build(b)
         anti = None
@@ -238,6 +266,18 @@ class Program:
                     anti[i] = [j for j, v in enumerate(b.uops) if inplace[u.dst] in v.reads()]
                     self.phys[u.dst] = self.phys[inplace[u.dst]]
         rounds = schedule(b.uops, self.w, self.base, anti)
+        if tries:
+            import random
+            best = ((len(rounds), self.temps_of(name, rounds)), rounds)
+            for t in range(1, tries + 1):
+                cand = schedule(b.uops, self.w, self.base, anti, rng=random.Random(t), jitter=12.0)
+                k = (len(cand), self.temps_of(name, cand))
+                if k < best[0]:
+                    best = (k, cand)
+            rounds = best[1]
+            for r, us in enumerate(rounds):
+                for u in us:
+                    u.round = r
         if inplace:
             rnd = {u.dst: r for r, us in enumerate(rounds) for u in us}
             for r, us in enumerate(rounds):
@@ -303,7 +343,7 @@ def finish_f(b, F0, F1, cre, cim, so):
     b.mul(F0 + F1, cre + cim, out=name(so["v2"]))
 
 
-def dbl(b, si, so, O, want_w=True):
+def dbl(b, si, so, O, want_w=True, fold=False):
     """pairing.hpp miller_double: f <- f^2 * l_{V,V}(phi(B)), V <- 2V (Jacobian, a = 1), arranged three products
     deep: X3 = M^2 - 2S is never an operand of a product here (Y3 takes M^2 and X*YY directly), the line takes
     ZZ and W from the state.  O: the operand slots ax, ay, bx, by."""
@@ -318,20 +358,26 @@ def dbl(b, si, so, O, want_w=True):
     ZZxB = b.mul(ZZ, bx)
     ZZyB = b.mul(ZZ, by)
     M = 3 * XX + Wq
-    M2 = b.mul(M, M)
+    M2 = None if fold else b.mul(M, M)
     XYY = b.mul(X, YY)
     Y4 = b.mul(YY, YY)
     cre = b.mul(M, ZZxB + X, E=-2 * YY)
     cim = b.mul(Z3, ZZyB)                                            # (Z3 ZZ) yB
     ZZ3 = b.mul(Z3, Z3, out=name(so["ZZ"]))
-    b.lin(M2 - 8 * XYY, out=name(so["X"]))                           # M^2 - 2S, S = 4 X YY
-    b.mul(M, 12 * XYY - M2, E=-8 * Y4, out=name(so["Y"]))            # M (S - X3) - 8 YY^2
+    if fold:
+        # four quads: a linear micro-op takes a quad for a whole round, so X3 is made by the product that squares M
+        # (one micro-op less: 18 in a doubling, 36 in two or in a doubling with its addition — whole rounds of four)
+        X3 = b.mul(M, M, E=-8 * XYY, out=name(so["X"]))              # M^2 - 2S, S = 4 X YY
+        b.mul(M, 4 * XYY - X3, E=-8 * Y4, out=name(so["Y"]))         # M (S - X3) - 8 YY^2
+    else:
+        b.lin(M2 - 8 * XYY, out=name(so["X"]))                       # M^2 - 2S, S = 4 X YY
+        b.mul(M, 12 * XYY - M2, E=-8 * Y4, out=name(so["Y"]))        # M (S - X3) - 8 YY^2
     if want_w:
         b.mul(ZZ3, ZZ3, out=name(so["W"]))
     finish_f(b, g0, 2 * g1h, cre, cim, so)
 
 
-def add(sign, O):
+def add(sign, O, fold=False):
     ax, ay, bx, by = O["ax"], O["ay"], O["bx"], O["by"]
 
     def build(b, si, so):
@@ -350,10 +396,15 @@ def add(sign, O):
         HH = b.mul(H, H)
         HHH = b.mul(H, HH)
         XHH = b.mul(X, HH)
-        rr2 = b.mul(rrr, rrr)
-        b.lin(rr2 - HHH - 2 * XHH, out=name(so["X"]))
-        YH = b.mul(b.mul(Y, H), HH)                                  # Y H^3 without waiting for H^3
-        b.mul(rrr, 3 * XHH + HHH - rr2, E=-YH, out=name(so["Y"]))    # rr (XHH - X3) - Y HHH
+        if fold:                                                     # (see dbl)
+            YH = b.mul(b.mul(Y, H), HH)                              # Y H^3 without waiting for H^3
+            X3 = b.mul(rrr, rrr, E=-HHH - 2 * XHH, out=name(so["X"]))
+            b.mul(rrr, XHH - X3, E=-YH, out=name(so["Y"]))           # rr (XHH - X3) - Y HHH
+        else:
+            rr2 = b.mul(rrr, rrr)
+            b.lin(rr2 - HHH - 2 * XHH, out=name(so["X"]))
+            YH = b.mul(b.mul(Y, H), HH)                              # Y H^3 without waiting for H^3
+            b.mul(rrr, 3 * XHH + HHH - rr2, E=-YH, out=name(so["Y"]))    # rr (XHH - X3) - Y HHH
         Z3y = b.mul(Z3, ysA)
         T = b.mul(rrr, bx + ax)
         cim = b.mul(Z3, by)
@@ -514,11 +565,23 @@ def build_quad_programs(w=QUAD_W):
 
     def seg_dbl(b):
         declare_new(b)
-        dbl(b, st, new, O)
-    M.segment("DBL", seg_dbl, inplace)
+        dbl(b, st, new, O, fold=True)
+    M.segment("DBL", seg_dbl, inplace, tries=QUAD_TRIES)
 
-    # (two plain doublings in one segment take the rounds of two DBL segments here — four quads leave nothing to
-    # overlap across the steps — and would only cost value slots: the controller runs DBL twice.)
+    # Two plain doublings in one segment: 36 products in nine rounds where two DBL segments take ten (the second
+    # step's first products fill the first step's last round).  Two generations per state slot, as in DAP / DAM below.
+    def seg_dbl2(b):
+        declare_new(b)
+        mid = {k: S("DBL2.%s" % k) for k in STATE_BOUNDS}
+        for k, f in mid.items():
+            b.bound[name(f)] = STATE_BOUNDS[k]
+        dbl(b, st, mid, O, fold=True)
+        dbl(b, mid, new, O, fold=True)
+    chain2 = {}
+    for k in STATE_BOUNDS:
+        chain2["DBL2.%s" % k] = k
+        chain2[k + "'"] = "DBL2.%s" % k
+    M.segment("DBL2", seg_dbl2, chain2, tries=QUAD_TRIES)
     # A doubling and the addition after it: ten rounds for the 38 micro-ops, two fewer than DBL and a lone addition
     # take.  The intermediate state (after the doubling) lives in the state's own slots, like the new one after it:
     # two generations per slot in one segment, each written when every reader of the one before it has run.  With
@@ -531,8 +594,8 @@ def build_quad_programs(w=QUAD_W):
             for k, f in mid.items():
                 b.bound[name(f)] = STATE_BOUNDS[k]
             del mid["W"]
-            dbl(b, st, mid, O, want_w=False)
-            add(sign, O)(b, mid, new)
+            dbl(b, st, mid, O, want_w=False, fold=True)
+            add(sign, O, fold=True)(b, mid, new)
         chain = {}
         for k in STATE_BOUNDS:
             if k == "W":
@@ -540,7 +603,7 @@ def build_quad_programs(w=QUAD_W):
             else:
                 chain["%s.%s" % (nm, k)] = k
                 chain[k + "'"] = "%s.%s" % (nm, k)
-        M.segment(nm, seg_da, chain)
+        M.segment(nm, seg_da, chain, tries=QUAD_TRIES)
 
     # the norms go where X, Y, Z were (dead once the loop is over)
     def seg_norm(b):
@@ -708,6 +771,28 @@ def build_quad_g1_programs(w=QUAD_W):
     def seg_gzzz(b):
         b.mul(st["Z"], st["ZZ"], out="zzz")
     G.segment("GZZZ", seg_gzzz)
+
+    def seg_gadm(b):
+        """(X, Y, Z, ZZ) + (tx, ty) affine — the entries of a key's fixed-base window tables (k_g1_fixed_quad): GADD with
+        tz = tzz = tzzz = 1 leaves U1 = X, S1 = Y, Z3 = Z H; twelve products and X' in four rounds instead of five."""
+        declare_new(b)
+        X, Y, Z, ZZ = st["X"], st["Y"], st["Z"], st["ZZ"]
+        U2 = b.mul(T["tx"], ZZ)
+        ZZZ = b.mul(Z, ZZ)
+        S2 = b.mul(T["ty"], ZZZ)
+        H = U2 - X
+        r = S2 - Y
+        Z3 = b.mul(Z, H, out="Z'")
+        HH = b.mul(H, H)
+        YH = b.mul(Y, H)
+        HHH = b.mul(H, HH)
+        XHH = b.mul(X, HH)
+        rr2 = b.mul(r, r)
+        YH3 = b.mul(YH, HH)
+        b.lin(rr2 - HHH - 2 * XHH, out="X'")
+        b.mul(r, 3 * XHH + HHH - rr2, E=-YH3, out="Y'")
+        b.mul(Z3, Z3, out="ZZ'")
+    G.segment("GADM", seg_gadm, inplace, tries=QUAD_TRIES)
     G.allocate_temps()
     # ---- the last launch: affine coordinates from the parked (X, Y) and R / Z of the inversion kernel, then the
     # division by R (plain residues, as the ladder kernel of ops.hpp writes them)

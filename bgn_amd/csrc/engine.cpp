@@ -911,9 +911,9 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // Mult: with the lane-group kernel above it (profiles/r03_mid_batch.csv: 1024 pairs 17.8 ms cooperative against
   // 21.2 ms, 1536: 25.1 against 21.3 at 1024 bits; 512 bits: 1024 pairs 5.3 against 5.2 ms) the crossover is where
   // that kernel's one-round time is reached; without it, the lane kernel's (r02_small_batch.csv)
-  // (round 4, 24-instruction rows: profiles/r04_mid_batch.csv 1024 pairs 17.0 ms cooperative against 17.8, 512 bits
-  // 5.3 against 4.9; profiles/r04_calibrate.csv puts the crossings at 1100 / 920)
-  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 1100 : c->nl >= 19 ? 920 : 800;
+  // (round 4, 24-instruction rows and nine-round segments: profiles/r04_mid_batch.csv 1024 pairs 17.0 ms cooperative
+  // against 16.7, 512 bits 5.3 against 4.6; profiles/r04_calibrate.csv puts the crossings at 1015 / 820)
+  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 1000 : c->nl >= 19 ? 820 : 800;
   return c->nl >= 36 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
@@ -932,8 +932,8 @@ static size_t quad_limit(const bgn_ctx* c) {
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
   if (c->xo.quad[0] >= 0) return (size_t)c->xo.quad[0];                // bgn_ctx_calibrate
   // profiles/r04_mid_batch.csv (nine-round segments): 49152 pairs 134 ms, 65536 178 ms against 157 on the lane kernel
-  // (512 bits: 65536 pairs 37.9 against 28.6, 32768 19.9 against 28.4); profiles/r04_calibrate.csv: 57 000 / 49 000
-  return c->nl >= 36 ? 57000 : c->nl >= 19 ? 49000 : 32768;
+  // (512 bits: 65536 pairs 37.9 against 28.6, 32768 19.9 against 28.4); profiles/r04_calibrate.csv: 56 800 / 48 000
+  return c->nl >= 36 ? 57000 : c->nl >= 19 ? 48000 : 32768;
 }
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
 // (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts

@@ -35,6 +35,22 @@ def programs():
     return _QPROGRAMS
 
 
+def wnaf(n: int, w: int):
+    """Width-w NAF, least significant digit first (hostbig.hpp wnaf): odd digits below 2^(w-1) in absolute value."""
+    d, k = [], n
+    while k:
+        if k & 1:
+            z = k % (1 << w)
+            if z >= 1 << (w - 1):
+                z -= 1 << w
+            k -= z
+        else:
+            z = 0
+        d.append(z)
+        k >>= 1
+    return d
+
+
 def nl_for(p: int) -> int:
     need = (p.bit_length() + 9 + LIMB - 1) // LIMB
     return next(x for x in (10, 19, 36, 37, 72) if x >= need)
@@ -121,6 +137,106 @@ class QuadValueMachine:
         self.run("NORM")
         return [self.get(k) for k in ("n1", "n2", "fm")]
 
+    # -- the width-w loop (pairing.hpp miller_loop_w): quad.hpp k_pairing_quad_wtab stages A and B, the table made
+    # affine and the windowed controller of k_pairing_quad<NL, 1> --
+    def canon(self, x):
+        """What the kernel stores in a table: the canonical representative of a value below 2p."""
+        return self.store(self.value(x) % self.p)
+
+    def inv_of(self, z):
+        """k_coop_invert: R / Z for the Montgomery value z = Z R."""
+        return self.store(self.R * self.R * pow(self.value(z) % self.p, -1, self.p) % self.p)
+
+    def miller_w(self, ax, ay, bx, by, n, w):
+        self.P = self.PM
+        self.V = {}
+        one = self.mont(1)
+        A = (self.mont(ax), self.mont(ay))
+
+        def state(x, y, f0=None, f1=None):
+            self.put("X", x)
+            self.put("Y", y)
+            for k in ("Z", "ZZ", "W"):
+                self.put(k, one)
+            if f0 is None:
+                self.put("v0", one)
+                self.put("v1", 0)
+                self.put("v2", one)
+            else:                                                         # F0 = v0 - v1, F1 = v2 - v0 - v1
+                self.put("v0", f0)
+                self.put("v1", 0)
+                self.put("v2", self.add2(f0, f1))
+
+        def operands(pt):
+            self.put("ax", pt[0])
+            self.put("ay", pt[1])
+
+        self.put("bx", self.mont(bx))
+        self.put("by", self.mont(by))
+        self.put("one", one)
+        d = wnaf(n, w)
+        maxd = (1 << (w - 1)) - 1
+        npts = (maxd - 1) // 2
+        # stage A: (2A, f_2) by one doubling step from (A, 1)
+        operands(A)
+        state(*A)
+        self.run("DBL")
+        X2, Y2, Z2 = self.get("X"), self.get("Y"), self.get("Z")
+        self.run("FOUT")
+        f2 = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
+        # stage B: 2A affine, then (2k+1)A = (2k-1)A + 2A with f_(2k+1) = f_(2k-1) * l * f_2
+        self.put("X", X2)
+        self.put("Y", Y2)
+        self.put("zi", self.inv_of(Z2))
+        self.run("AFM")
+        A2 = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
+        state(*A)
+        jac, fd = {}, {}
+        for k in range(1, npts + 1):
+            operands(A2)
+            self.run("ADDP")
+            operands(f2)
+            self.run("FMP")
+            jac[k] = (self.get("X"), self.get("Y"), self.get("Z"))
+            self.run("FOUT")
+            fd[k] = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
+        # the table made affine (the Miller launch's prologue, after the second inversion launch)
+        aff = {0: A}
+        for k in range(1, npts + 1):
+            self.put("X", jac[k][0])
+            self.put("Y", jac[k][1])
+            self.put("zi", self.inv_of(jac[k][2]))
+            self.run("AFM")
+            aff[k] = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
+        # the loop: from the top digit (1, 3, ..., maxd)
+        top = d[-1]
+        assert top > 0 and top & 1 and top <= maxd
+        if top == 1:
+            state(*A)
+        else:
+            state(*aff[top // 2], *fd[top // 2])
+        i = len(d) - 2
+        while i >= 0:
+            di = d[i]
+            if di and i != 0:
+                operands(aff[abs(di) // 2])
+                self.run("DAP" if di > 0 else "DAM")
+            elif i >= 1 and (d[i - 1] == 0 or i - 1 == 0) and not (abs(di) > 1):
+                self.run("DBL2")
+                i -= 1
+                di = d[i]                                                 # (i == 0: its addition is skipped, not its f_d)
+            else:
+                self.run("DBL")
+            if abs(di) > 1:
+                operands(fd[abs(di) // 2])
+                self.run("FMP" if di > 0 else "FMM")
+            i -= 1
+        self.run("NORM")
+        return [self.get(k) for k in ("n1", "n2", "fm")]
+
+    def add2(self, a, b):
+        return self.store(self.value(a) + self.value(b))
+
     def miller_table(self, xc, yc, table, n):
         """Launch 1 in its table form: e(K, C) over the normalised line table of the key point K (TD / TDA segments;
         the coefficients of a segment's steps are put in their slots before it, as the kernel's prefetch does)."""
@@ -169,6 +285,10 @@ class QuadValueMachine:
     def pairing(self, ax, ay, bx, by, n, l):
         """e(A, B); plain residues in and out."""
         return self._finish(self.miller(ax, ay, bx, by, n), l)
+
+    def pairing_w(self, ax, ay, bx, by, n, l, w):
+        """e(A, B) with the width-w Miller loop."""
+        return self._finish(self.miller_w(ax, ay, bx, by, n, w), l)
 
     def pairing_table(self, xc, yc, table, n, l):
         """e(K, C) from K's line table (coop_model.line_table)."""
@@ -318,8 +438,19 @@ class QuadLaneMachine(QuadValueMachine):
         assert np.all(r >= 0) and np.all(r <= MASK)
         return r
 
+    def canon(self, x):
+        return self.canonical(x)                                  # quad_canonical: tight limbs of the value mod p
+
+    def add2(self, a, b):
+        return (a.astype(I64) + b.astype(I64)).astype(I32)        # limb by limb, as the kernel adds f_d's components
+
+    def pairing_w(self, ax, ay, bx, by, n, l, w):
+        return self._finish_parked(self.miller_w(ax, ay, bx, by, n, w), l)
+
     def pairing(self, ax, ay, bx, by, n, l):
-        parked = self.miller(ax, ay, bx, by, n)
+        return self._finish_parked(self.miller(ax, ay, bx, by, n), l)
+
+    def _finish_parked(self, parked, l):
         nt = self.tight(parked[0].astype(I64) + parked[1].astype(I64))       # what launch 1 hands to the inversion kernel
         N = from_quad(nt)
         assert np.all(nt >= 0) and np.all(nt <= MASK) and 0 <= N < 4 * self.p

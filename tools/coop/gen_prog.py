@@ -614,6 +614,47 @@ def build_quad_programs(w=QUAD_W):
         b.mul(F1, F1, out="n2")
         b.mul(F0, F1, out="fm")
     M.segment("NORM", seg_norm, {"n1": "X", "n2": "Y", "fm": "Z"})
+
+    # ---- the width-w Miller loop (pairing.hpp miller_loop_w) on the lane groups: a digit +-d adds +-dA in one step,
+    # f <- f * l * f_d^(+-1).  The odd multiples dA (affine) and their Miller values f_d are made per pairing by the
+    # table launches (quad.hpp k_pairing_quad_wtab) from these segments: ADDP = a lone addition step V <- V + (ax, ay)
+    # with its line; FMP / FMM = f <- f * (ax + i ay) resp. its conjugate (the operand slots are free between two
+    # additions: the kernel loads f_d into them); FOUT = F0, F1 as single values (for the table: canonical after the
+    # kernel's conditional subtraction); AFM = affine Montgomery coordinates of the state's (X, Y) from R / Z.
+    # Other names — and bounds — for slots whose usual value is dead where these segments run:
+    def alias(nm, of, bound):
+        M.phys[nm] = M.phys[of]
+        M.bound[nm] = bound
+        return S(nm)
+    one = M.fixed("one", 1)                  # R mod p (the twentieth slot)
+    zi = alias("zi", "W", 4)                 # R / Z from the inversion kernel
+    alias("axo", "ax", 2)
+    alias("ayo", "ay", 2)
+
+    def seg_addp(b):
+        declare_new(b)
+        add(1, O, fold=True)(b, st, new)
+    M.segment("ADDP", seg_addp, inplace, tries=QUAD_TRIES)
+    fin = {k + "'": k for k in ("v0", "v1", "v2")}
+    for sign, nm in ((1, "FMP"), (-1, "FMM")):
+        def seg_fm(b, sign=sign):
+            declare_new(b, ("v0", "v1", "v2"))
+            F0, F1 = f_of(st)
+            finish_f(b, F0, F1, O["ax"], sign * O["ay"], new)
+        M.segment(nm, seg_fm, fin)
+
+    def seg_fout(b):
+        F0, F1 = f_of(st)
+        b.mul(F0, one, out="axo")
+        b.mul(F1, one, out="ayo")
+    M.segment("FOUT", seg_fout)
+
+    def seg_afm(b):
+        zi2 = b.mul(zi, zi)
+        zi3 = b.mul(zi2, zi)
+        b.mul(st["X"], zi2, out="axo")
+        b.mul(st["Y"], zi3, out="ayo")
+    M.segment("AFM", seg_afm)
     M.allocate_temps()
     # ---- launch 2: h = conj(f)^2 / N(f), g = h^l, division by R ----
     F = Program(w, w, reads_first=True)
@@ -926,7 +967,7 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, a
     return seg_index
 
 
-QUAD_MILLER_SLOTS = ("ax", "ay", "bx", "by", "X", "Y", "Z", "ZZ", "W", "v0", "v1", "v2", "n1", "n2", "fm")
+QUAD_MILLER_SLOTS = ("ax", "ay", "bx", "by", "X", "Y", "Z", "ZZ", "W", "v0", "v1", "v2", "n1", "n2", "fm", "one")
 QUAD_FINAL_SLOTS = ("n1", "n2", "fm", "inv", "raw1", "h0", "h1", "r0", "r1", "out0", "out1")
 QUAD_TABLE_SLOTS = ("ax", "ay", "ta1", "tb1", "ta2", "tb2", "v0", "v1", "v2", "n1", "n2", "fm")
 

@@ -935,6 +935,17 @@ static size_t quad_limit(const bgn_ctx* c) {
   // (512 bits: 65536 pairs 37.9 against 28.6, 32768 19.9 against 28.4); profiles/r04_calibrate.csv: 56 800 / 48 000
   return c->nl >= 36 ? 57000 : c->nl >= 19 ? 48000 : 32768;
 }
+// The lane-group pairing's Miller loop over the width-w NAF (quad.hpp k_pairing_quad_wtab: per-pairing table of the odd
+// multiples of A and their Miller values, 9 KB per pairing at 1024 bits): 9 % fewer rounds, two more table launches
+// and two more inversion launches.  Returns the width (0: the plain NAF).  Option quad_window: 0 never, 1 always.
+static int quad_window(const bgn_ctx* c, size_t count) {
+  const int64_t o = opt(c, &Options::quad_window);
+  const int w = c->pc_host.wnaf_len > 0 ? c->pc_host.wnaf_w : 0;
+  if (o == 0 || w < 3 || w > 5) return 0;
+  if (o < 0 && quad_ws_words(c->nl, round_up(count, 64), w) * 4 > ((size_t)3 << 30)) return 0;
+  return w;
+}
+
 // The walks over a key's line table (mode 1: makeL2; mode 2: Decrypt's lift) and Decrypt's power by the secret key
 // (mode 3) on the lane-group kernel: above the cooperative crossover of the same mode and up to these counts
 // (profiles/r03_mid_batch_table.csv); BGN_QUAD_MAX_L2 / BGN_QUAD_MAX_DEC / BGN_QUAD_MAX_POW override, 0 disables.
@@ -1065,7 +1076,8 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   const bool coop = !quad && mode <= 1 && count <= coop_limit(c, mode);
   const size_t lane_ws = (size_t)(mode == 1 ? 3 : c->pair_ws_slots) * c->nl * so * 4;
   // (never less than the lane kernel's workspace: it is the fallback when a launcher has no instantiation)
-  const size_t small_ws = quad ? quad_ws_words(c->nl, so) * 4 : coop ? coop_ws_words(c->nl, so) * 4 : 0;
+  const int qwin = (quad && !quad_tab) ? quad_window(c, count) : 0;
+  const size_t small_ws = quad ? quad_ws_words(c->nl, so, qwin) * 4 : coop ? coop_ws_words(c->nl, so) * 4 : 0;
   const size_t ws_bytes = small_ws > lane_ws ? small_ws : lane_ws;
   probe.take(ws_bytes);
   if (r_be) {
@@ -1094,7 +1106,7 @@ static int pairing_chunk(bgn_ctx* c, size_t count, const uint8_t* a, size_t na, 
   // a full pairing's 18 / 36 in 3 / 6); BGN_COOP_TABLE=0 keeps the general program
   const uint32_t* ctab = (mode == 1 && coop_table_walk(c)) ? c->d_fixedpair : nullptr;
   if (quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0, ws, so, c->p_bits + 1,
-                                  quad_tab ? c->d_fixedpair : nullptr)) {
+                                  quad_tab ? c->d_fixedpair : nullptr, qwin)) {
     kname = quad_pairing_kernel_name(c->nl);
   } else if (coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, A, B, O, count, mode, 0, 0,
                                          cf ? nullptr : ws, so, c->p_bits + 1, ctab)) {
@@ -2557,6 +2569,8 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   const size_t tail_pairs = tail_polys * d1 * d2;
   const bool tail_direct = tail_pairs != 0 && tail_pairs <= kLanes;
   const size_t tail_sp = round_up(tail_pairs ? tail_pairs : 1, 64);
+  // (the width-w loop of the lane-group kernel is decided once per stride: the workspace below is sized with it)
+  const int qwin_main = quad ? quad_window(c, np) : 0, qwin_tail = tail_direct ? quad_window(c, tail_pairs) : 0;
   SoA2 E;
   uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
@@ -2564,11 +2578,11 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     E = w.gt(sp);
     size_t ws_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;         // the lane kernel is the fallback
     auto at_least = [&](size_t b) { if (b > ws_b) ws_b = b; };
-    if (quad) at_least(quad_ws_words(c->nl, sp) * 4);
+    if (quad) at_least(quad_ws_words(c->nl, sp, qwin_main) * 4);
     if (coop) at_least(coop_ws_words(c->nl, sp) * 4);
     if (tail_direct) {
       at_least((size_t)c->pair_ws_slots * c->nl * tail_sp * 4);
-      at_least(quad_ws_words(c->nl, tail_sp) * 4);
+      at_least(quad_ws_words(c->nl, tail_sp, qwin_tail) * 4);
       at_least(coop_ws_words(c->nl, tail_sp) * 4);
     }
     pws = (uint32_t*)w.cv.take(ws_b);
@@ -2613,7 +2627,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
                   tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
       tables_used = true;
     } else if (q_quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sw,
-                                             c->p_bits + 1)) {
+                                             c->p_bits + 1, nullptr, tail ? qwin_tail : qwin_main)) {
       c->last_kernel = quad_pairing_kernel_name(c->nl);
     } else if (q_coop && coop_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sw,
                                              c->p_bits + 1)) {

@@ -6,48 +6,92 @@
 
 namespace bgn {
 
-template <int NL>
-static size_t ws_words(size_t sw) { return (size_t)QuadDims<NL>::PARK_WORDS * sw + (size_t)2 * NL * sw; }
+// A large batch runs in pieces of quad_piece pairings — sixteen times what fills the chip at three workgroups per CU (at
+// 72 limbs: at one) — so that the workspace (9 KB per pairing with the width-w loop's table at a 1024-bit key) does not
+// grow with the batch: every piece's launches are queued on the stream one after the other and reuse the same arrays.
+static size_t quad_piece(int nl) { return nl > 40 ? (size_t)65536 : (size_t)196608; }
+static size_t quad_ws_stride(int nl, size_t sw) { return sw < quad_piece(nl) ? sw : quad_piece(nl); }
 
-size_t quad_ws_words(int nl, size_t sw) {
+// workspace: parked F0^2, F1^2, F0 F1 | norms | their inverses — and, for the width-w loop, the per-pairing table
+// records | Z of 2A | its inverse | Z of the odd multiples (limb stride 7 sw) | their inverses
+template <int NL>
+static size_t ws_words(size_t sw_full, int window) {
+  const size_t sw = quad_ws_stride(NL, sw_full);
+  size_t n = (size_t)QuadDims<NL>::PARK_WORDS * sw + (size_t)2 * NL * sw;
+  if (window) n += (size_t)QW_NV * 4 * QuadDims<NL>::M * sw + (size_t)(2 + 2 * QW_PTS) * NL * sw;
+  return n;
+}
+
+size_t quad_ws_words(int nl, size_t sw, int window) {
   switch (nl) {
-    case 10: return ws_words<10>(sw);
-    case 19: return ws_words<19>(sw);
-    case 36: return ws_words<36>(sw);
-    case 37: return ws_words<37>(sw);
-    case 72: return ws_words<72>(sw);
+    case 10: return ws_words<10>(sw, window);
+    case 19: return ws_words<19>(sw, window);
+    case 36: return ws_words<36>(sw, window);
+    case 37: return ws_words<37>(sw, window);
+    case 72: return ws_words<72>(sw, window);
   }
   return 0;
 }
 
 template <int NL>
-static void launch(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out, size_t count,
-                   int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits, const uint32_t* tab) {
+static void launch(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out, size_t total,
+                   int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw_full, int p_bits, const uint32_t* tab, int window) {
   const FpParams<NL>* P = (const FpParams<NL>*)params;
-  const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
+  const size_t sw = quad_ws_stride(NL, sw_full);
+  auto invert = [&](uint32_t* z, uint32_t* zi, size_t stride, size_t n) {
+    hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((n + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P, z, zi, stride, n,
+                       p_bits);
+  };
   uint32_t* park = ws;
   uint32_t* nsoa = ws + (size_t)QuadDims<NL>::PARK_WORDS * sw;
   uint32_t* isoa = nsoa + (size_t)NL * sw;
-  if (tab)
-    hipLaunchKernelGGL((k_pairing_quad_table<NL>), grid, block, 0, s, P, consts, a, count, tab, park, nsoa, sw);
-  else
-    hipLaunchKernelGGL((k_pairing_quad<NL, 1>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, park, nsoa, isoa, sw);
-  hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P, nsoa,
-                     isoa, sw, count, p_bits);
-  hipLaunchKernelGGL((k_pairing_quad<NL, 2>), grid, block, 0, s, P, consts, a, b, out, count, mode, d1, d2, park, nsoa, isoa, sw);
+  uint32_t* wrec = nullptr;
+  uint32_t *zA = nullptr, *iA = nullptr, *z7 = nullptr, *i7 = nullptr;
+  if (window && !tab) {
+    wrec = isoa + (size_t)NL * sw;
+    zA = wrec + (size_t)QW_NV * 4 * QuadDims<NL>::M * sw;
+    iA = zA + (size_t)NL * sw;
+    z7 = iA + (size_t)NL * sw;
+    i7 = z7 + (size_t)QW_PTS * NL * sw;
+  }
+  for (size_t e0 = 0; e0 < total; e0 += quad_piece(NL)) {
+    const size_t count = total - e0 < quad_piece(NL) ? total - e0 : quad_piece(NL);      // pairings of this piece
+    const size_t end = e0 + count;
+    const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
+    if (wrec) {
+      // the width-w loop's table: (2A, f_2), the inverse of its Z, the odd multiples and their Miller values, the
+      // inverses of their Z (made affine by the Miller launch's prologue)
+      const size_t n7 = (size_t)(quad_window_points(window) - 1) * sw + count;
+      (void)hipMemsetAsync(z7, 0, (size_t)QW_PTS * NL * sw * 4, s);      // (the padding between count and sw is inverted too)
+      hipLaunchKernelGGL((k_pairing_quad_wtab<NL, 1>), grid, block, 0, s, P, consts, a, b, end, mode, d1, d2, wrec, zA,
+                         (const uint32_t*)nullptr, sw, e0);
+      invert(zA, iA, sw, count);
+      hipLaunchKernelGGL((k_pairing_quad_wtab<NL, 2>), grid, block, 0, s, P, consts, a, b, end, mode, d1, d2, wrec, z7,
+                         (const uint32_t*)iA, sw, e0);
+      invert(z7, i7, (size_t)QW_PTS * sw, n7);
+    }
+    if (tab)
+      hipLaunchKernelGGL((k_pairing_quad_table<NL>), grid, block, 0, s, P, consts, a, end, tab, park, nsoa, sw, e0);
+    else
+      hipLaunchKernelGGL((k_pairing_quad<NL, 1>), grid, block, 0, s, P, consts, a, b, out, end, mode, d1, d2, park, nsoa, isoa, sw,
+                         wrec, (const uint32_t*)i7, e0);
+    invert(nsoa, isoa, sw, count);
+    hipLaunchKernelGGL((k_pairing_quad<NL, 2>), grid, block, 0, s, P, consts, a, b, out, end, mode, d1, d2, park, nsoa, isoa, sw,
+                       (uint32_t*)nullptr, (const uint32_t*)nullptr, e0);
+  }
 }
 
 bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                          size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits,
-                         const uint32_t* tab) {
+                         const uint32_t* tab, int window) {
   if (!count) return true;
-  if (!ws || (tab && mode != 1)) return false;
+  if (!ws || (tab && mode != 1) || (window && (window < 3 || window > 5))) return false;
   switch (nl) {
-    case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
-    case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
-    case 36: launch<36>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
-    case 37: launch<37>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
-    case 72: launch<72>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab); return true;
+    case 10: launch<10>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab, window); return true;
+    case 19: launch<19>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab, window); return true;
+    case 36: launch<36>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab, window); return true;
+    case 37: launch<37>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab, window); return true;
+    case 72: launch<72>(s, params, consts, a, b, out, count, mode, d1, d2, ws, sw, p_bits, tab, window); return true;
   }
   return false;
 }

@@ -28,6 +28,8 @@ struct Options {
   V quad_max_pow{-1};      // Decrypt's power by the secret key
   V quad_max_mc{-1};       // MultConst (per-element scalars) on the lane groups
   V quad_max_enc{-1};      // the fixed-base products of Encrypt / blinding on the lane groups (-1: 2048-bit keys only)
+  V quad_window{-1};       // the lane-group pairing's Miller loop over the width-w NAF of miller_window with a per-pairing
+                           // table (-1: where its workspace stays below 3 GB; 0: the plain NAF; 1: always)
   V split_rounds{1};       // cut a batch into whole rounds of the lane kernel + a remainder (0: one launch)
   V pairing_run{0};        // pairings per lane of k_pairing (0: ceil(count / 65536), at most 16)
   // ---- algorithm alternatives (identical bytes) ----
@@ -87,6 +89,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"quad_max_pow", &Options::quad_max_pow, true, nullptr},
       {"quad_max_mc", &Options::quad_max_mc, true, nullptr},
       {"quad_max_enc", &Options::quad_max_enc, true, nullptr},
+      {"quad_window", &Options::quad_window, true, nullptr},
       {"split_rounds", &Options::split_rounds, true, nullptr},
       {"pairing_run", &Options::pairing_run, true, nullptr},
       {"coop_table", &Options::coop_table, true, nullptr},

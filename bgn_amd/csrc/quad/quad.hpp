@@ -390,6 +390,42 @@ __device__ __forceinline__ void quad_gstore(u32* __restrict__ base, size_t strid
   }
 }
 
+// ---- the width-w Miller loop (pairing.hpp miller_loop_w) on the lane groups ----------------------------------------
+// A digit +-d of the width-w NAF of n adds +-dA in one step: f <- f * l * f_d^(+-1).  The odd multiples dA (affine)
+// and their Miller values f_d = f_{d,A}(phi(B)) are made per pairing, in the workspace, by two table launches with an
+// inversion launch behind each (k_pairing_quad_wtab below; the second inversion's affine conversion is the prologue of
+// the Miller launch): QW_NV values of 4 * M words per pairing — a value as it lies in the lanes of a quad.
+constexpr int QW_PTS = 7;                            // 3A, 5A .. 15A: width 5 (narrower loops use the first ones)
+enum {
+  QW_X2 = 0, QW_Y2 = 1,                              // 2A, Jacobian X and Y (as they leave the doubling: lazily normalised)
+  QW_F20 = 2, QW_F21 = 3,                            // f_2, canonical
+  QW_A2X = 4, QW_A2Y = 5,                            // 2A affine, canonical
+  QW_JX = 6, QW_JY = QW_JX + QW_PTS,                 // (2k+1)A, Jacobian X and Y, k = 1 .. 7
+  QW_FD0 = QW_JY + QW_PTS, QW_FD1 = QW_FD0 + QW_PTS, // f_(2k+1), canonical
+  QW_AX = QW_FD1 + QW_PTS, QW_AY = QW_AX + QW_PTS,   // (2k+1)A affine, canonical
+  QW_NV = QW_AY + QW_PTS
+};
+__host__ __device__ constexpr int quad_window_points(int w) { return ((1 << (w - 1)) - 2) / 2; }   // 1, 3, 7
+
+template <int NL>
+__device__ __forceinline__ u32* quad_rec(u32* __restrict__ base, size_t el, int v, const QuadLane<NL>& c) {
+  return base + (el * (size_t)QW_NV + (size_t)v) * (size_t)(4 * QuadDims<NL>::M) + (size_t)c.sub * QuadDims<NL>::M;
+}
+template <int NL>
+__device__ __forceinline__ void quad_rec_get(int (&x)[QuadDims<NL>::M], const u32* __restrict__ base, size_t el, int v,
+                                             const QuadLane<NL>& c) {
+  const u32* p = quad_rec<NL>(const_cast<u32*>(base), el, v, c);
+#pragma unroll
+  for (int j = 0; j < QuadDims<NL>::M; ++j) x[j] = (int)p[j];
+}
+template <int NL>
+__device__ __forceinline__ void quad_rec_put(u32* __restrict__ base, size_t el, int v, const QuadLane<NL>& c,
+                                             const int (&x)[QuadDims<NL>::M]) {
+  u32* p = quad_rec<NL>(base, el, v, c);
+#pragma unroll
+  for (int j = 0; j < QuadDims<NL>::M; ++j) p[j] = (u32)x[j];
+}
+
 // Sixteen pairings per workgroup.  Operands: canonical Montgomery SoA; result: plain canonical SoA (what
 // k_pairing<NL, 0> and k_pairing_coop<NL> read and write).  mode 0: e(a[e], b[e]); mode 1: b is one broadcast point;
 // mode 2: the coefficient pairs of polynomial products (d1, d2 coefficients).
@@ -400,7 +436,7 @@ template <int NL, int PHASE>
 __global__ void __launch_bounds__(QUAD_BLOCK)
 k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out, size_t count,
                int mode, size_t d1, size_t d2, u32* __restrict__ park, u32* __restrict__ nsoa,
-               const u32* __restrict__ isoa, size_t ws) {
+               const u32* __restrict__ isoa, size_t ws, u32* __restrict__ wrec, const u32* __restrict__ wi7, size_t e0) {
   constexpr int M = QuadDims<NL>::M;
   using PG = typename std::conditional<PHASE == 1, QuadMiller, QuadFinal>::type;
   __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
@@ -408,9 +444,10 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   char* V = reinterpret_cast<char*>(Vs);
   QuadLane<NL> c;
   quad_lane_init<NL>(c, P);
-  size_t e = (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);
+  size_t e = e0 + (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);   // e0: the first pairing of this piece of the batch
   const bool live = e < count;
   if (!live) e = count - 1;                     // stands in for the last pairing (same wave, lockstep; stores suppressed)
+  const size_t el = e - e0;                     // its index in the workspace arrays
   size_t ea = e, eb = (mode == 1) ? 0 : e;
   if (mode == 2) {                              // MultPoly, poly.go:139-146
     ea = e / d2;
@@ -457,24 +494,63 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     }
     // Miller loop over the NAF of n (pairing.hpp miller_loop): a doubling and the addition of +-A that follows it
     // (one segment, nine rounds), two plain doublings (nine) or one (five); the last addition is skipped as in PBC;
-    // then the norms' segment.
-    const u32* nafw = reinterpret_cast<const u32*>(C->naf);
+    // then the norms' segment.  With a table (wrec != null: pairing.hpp miller_loop_w) the digits are those of the
+    // width-w NAF: the prologue makes the table's points affine from the inverses of their Z (wi7, limb stride
+    // 7 * ws, point k of pairing e at (k - 1) * ws + e), the loop starts from the top digit's multiple and its Miller
+    // value, an addition loads its multiple into the operand slots and, for |d| > 1, is followed by f <- f * f_d^(+-1)
+    // with f_d loaded into the same slots (FMP / FMM: one round).
+    const bool win = wrec != nullptr;
+    const u32* nafw = reinterpret_cast<const u32*>(win ? C->wnaf : C->naf);
     auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
-    int i = C->naf_len - 2;
+    const int ndig = win ? C->wnaf_len : C->naf_len;
+    const int npre = win ? quad_window_points(C->wnaf_w) : 0;
+    int i = ndig - 2;
+    int pc = 0, pend = 0;
     bool norms = false;
+    // (x, y) of the multiple |d| A into two slots, by quads 0 and 1
+    auto load_multiple = [&](int ad, int sx, int sy) {
+      if (c.quad < 2) {
+        if (ad == 1) quad_gload<NL>(x, c.quad == 0 ? a.c0 : a.c1, a.stride, ea, c.sub);
+        else quad_rec_get<NL>(x, wrec, el, (c.quad == 0 ? QW_AX : QW_AY) + ad / 2 - 1, c);
+        put(c.quad == 0 ? sx : sy);
+      }
+    };
 #pragma unroll 1
     for (;;) {
       int seg;
-      if (i >= 0) {
+      if (pc < npre) {                                   // the table's point pc + 1: affine from (X, Y) and R / Z
+        if (c.quad < 2) {
+          quad_rec_get<NL>(x, wrec, el, (c.quad == 0 ? QW_JX : QW_JY) + pc, c);
+          put(c.quad == 0 ? QUADM_SLOT_X : QUADM_SLOT_Y);
+        } else if (c.quad == 2) {
+          quad_gload<NL>(x, wi7, (size_t)QW_PTS * ws, (size_t)pc * ws + el, c.sub);
+          put(QUADM_SLOT_W);
+        }
+        seg = QUADM_SEG_AFM;
+      } else if (pend != 0) {                            // f <- f * f_d or its conjugate
+        const int ad = pend < 0 ? -pend : pend;
+        if (c.quad < 2) {
+          quad_rec_get<NL>(x, wrec, el, (c.quad == 0 ? QW_FD0 : QW_FD1) + ad / 2 - 1, c);
+          put(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY);
+        }
+        seg = pend > 0 ? QUADM_SEG_FMP : QUADM_SEG_FMM;
+        pend = 0;
+      } else if (i >= 0) {
         const int d = digit(i);
+        const int ad = d < 0 ? -d : d;
         if (d != 0 && i != 0) {
+          if (win) load_multiple(ad, QUADM_SLOT_AX, QUADM_SLOT_AY);
           seg = d > 0 ? QUADM_SEG_DAP : QUADM_SEG_DAM;
+          if (ad > 1) pend = d;
           i -= 1;
-        } else if (i >= 1 && (i - 1 == 0 || digit(i - 1) == 0)) {
+        } else if (ad <= 1 && i >= 1 && (i - 1 == 0 || digit(i - 1) == 0)) {
           seg = QUADM_SEG_DBL2;                     // the next step is a plain doubling too: 36 products in nine rounds
+          const int dn = digit(i - 1);              // (step 0 skips its addition, not its f_d)
+          if (dn > 1 || dn < -1) pend = dn;
           i -= 2;
         } else {
           seg = QUADM_SEG_DBL;
+          if (ad > 1) pend = d;
           i -= 1;
         }
       } else if (!norms) {
@@ -484,13 +560,46 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
         break;
       }
       quad_run<NL, PG>(V, seg, c);
+      if (pc < npre) {
+        // the point's affine coordinates (below 2p in the operand slots): canonical, into the table
+        if (c.quad < 2) {
+          quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY), c));
+          quad_canonical<NL>(x, c);
+          if (live) quad_rec_put<NL>(wrec, el, (c.quad == 0 ? QW_AX : QW_AY) + pc, c, x);
+        }
+        pc += 1;
+        if (pc == npre) {
+          // the loop starts from the top digit t: V = tA, f = f_t (the Karatsuba triple of c0 + i c1 is
+          // (c0, 0, c0 + c1)); t = 1: (A, 1) as set above, with W = 1 again (it held the last R / Z)
+          // (a lane reads back, here and in the loop, exactly the words it stored above: program order suffices)
+          const int top = digit(ndig - 1);
+          load_multiple(top, QUADM_SLOT_X, QUADM_SLOT_Y);
+          if (c.quad == 2) {
+            set_one();
+            put(QUADM_SLOT_W);
+            if (top > 1) {
+              quad_rec_get<NL>(x, wrec, el, QW_FD0 + top / 2 - 1, c);
+              put(QUADM_SLOT_V0);
+            }
+          } else if (c.quad == 3 && top > 1) {
+            int y[M];
+            long long acc[M];
+            quad_rec_get<NL>(x, wrec, el, QW_FD0 + top / 2 - 1, c);
+            quad_rec_get<NL>(y, wrec, el, QW_FD1 + top / 2 - 1, c);
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc[j] = (long long)x[j] + (long long)y[j];
+            quad_normalize<NL>(x, acc, c);
+            put(QUADM_SLOT_V2);
+          }
+        }
+      }
     }
     // park F0^2, F1^2, F0*F1 and hand N(f) = F0^2 + F1^2 to the inversion kernel as tight limbs (< 4p)
     if (c.quad < 3) {
       const int slot = c.quad == 0 ? QUADM_SLOT_N1 : c.quad == 1 ? QUADM_SLOT_N2 : QUADM_SLOT_FM;
       quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c));
       if (live) {
-        u32* dst = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+        u32* dst = park + (el * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
 #pragma unroll
         for (int j = 0; j < M; ++j) dst[j] = (u32)x[j];
       }
@@ -501,17 +610,17 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
 #pragma unroll
       for (int j = 0; j < M; ++j) x[j] += y[j];
       quad_tight<NL>(x, c);
-      if (live) quad_gstore<NL>(nsoa, ws, e, c.sub, x);
+      if (live) quad_gstore<NL>(nsoa, ws, el, c.sub, x);
     }
   } else {
     if (c.quad < 3) {
       const int slot = c.quad == 0 ? QUADF_SLOT_N1 : c.quad == 1 ? QUADF_SLOT_N2 : QUADF_SLOT_FM;
-      const u32* src = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+      const u32* src = park + (el * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
 #pragma unroll
       for (int j = 0; j < M; ++j) x[j] = (int)src[j];
       put(slot);
     } else {
-      quad_gload<NL>(x, isoa, ws, e, c.sub);
+      quad_gload<NL>(x, isoa, ws, el, c.sub);
       put(QUADF_SLOT_INV);
       // the inverse of a zero norm is zero: such a pairing yields the identity, as in k_pairing (PBC's SetBytes maps
       // an invalid point to O)
@@ -588,6 +697,147 @@ __device__ __forceinline__ void quad_canonical16(int (&x)[QuadDims<NL>::M], cons
   }
 }
 
+// The table launches of the width-w loop.  STAGE 1: (2A, f_2) by one doubling step from (A, 1); X, Y of 2A and f_2 go to
+// the pairing's record, Z (canonical) to zs for the inversion launch.  STAGE 2: 2A made affine from R / Z (is), then
+// (2k+1)A = (2k-1)A + 2A by addition steps from (A, 1), f_(2k+1) = f_(2k-1) * l * f_2 (ADDP, FMP), k = 1 .. npts; X, Y
+// and f of every multiple go to the record, its Z to zs (limb stride 7 * sw, point k of pairing e at (k - 1) * sw + e).
+// One loop with one call site of the round interpreter, as everywhere.
+template <int NL, int STAGE>
+__global__ void __launch_bounds__(QUAD_BLOCK)
+k_pairing_quad_wtab(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, size_t count, int mode,
+                    size_t d1, size_t d2, u32* __restrict__ wrec, u32* __restrict__ zs, const u32* __restrict__ is, size_t sw,
+                    size_t e0) {
+  constexpr int M = QuadDims<NL>::M;
+  using PG = QuadMiller;
+  __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
+  char* V = reinterpret_cast<char*>(Vs);
+  QuadLane<NL> c;
+  quad_lane_init<NL>(c, P);
+  size_t e = e0 + (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);   // e0: the first pairing of this piece of the batch
+  const bool live = e < count;
+  if (!live) e = count - 1;
+  const size_t el = e - e0;                     // its index in the workspace arrays
+  size_t ea = e, eb = (mode == 1) ? 0 : e;
+  if (mode == 2) {
+    ea = e / d2;
+    eb = (ea / d1) * d2 + e % d2;
+  }
+  int x[M];
+  auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
+  auto get = [&](int slot) { quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c)); };
+  auto set_one = [&]() {
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int pos = c.sub * M + j;
+      x[j] = pos < NL ? (int)P->one[pos < NL ? pos : 0] : 0;
+    }
+  };
+  // V = A, Z = Z^2 = Z^4 = 1, f = 1 as the triple (1, 0, 1); the operand slots of B and the constant R mod p
+  auto start_from_A = [&]() {
+    if (c.quad == 0) {
+      quad_gload<NL>(x, a.c0, a.stride, ea, c.sub);
+      put(QUADM_SLOT_X);
+      set_one();
+      put(QUADM_SLOT_Z);
+      put(QUADM_SLOT_V0);
+    } else if (c.quad == 1) {
+      quad_gload<NL>(x, a.c1, a.stride, ea, c.sub);
+      put(QUADM_SLOT_Y);
+      set_one();
+      put(QUADM_SLOT_ZZ);
+      put(QUADM_SLOT_V2);
+    } else if (c.quad == 2) {
+      set_one();
+      put(QUADM_SLOT_W);
+      put(QUADM_SLOT_ONE);
+    } else {
+#pragma unroll
+      for (int j = 0; j < M; ++j) x[j] = 0;
+      put(QUADM_SLOT_V1);
+    }
+  };
+  if (c.quad == 2) {
+    quad_gload<NL>(x, b.c0, b.stride, eb, c.sub);
+    put(QUADM_SLOT_BX);
+  } else if (c.quad == 3) {
+    quad_gload<NL>(x, b.c1, b.stride, eb, c.sub);
+    put(QUADM_SLOT_BY);
+  }
+  // the operand slots' values (below 2p after FOUT / AFM) made canonical and stored as values va, va + 1 of the record
+  auto store_pair = [&](int va) {
+    if (c.quad < 2) {
+      get(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY);
+      quad_canonical<NL>(x, c);
+      if (live) quad_rec_put<NL>(wrec, el, va + c.quad, c, x);
+    }
+  };
+  if constexpr (STAGE == 1) {
+    start_from_A();
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+      quad_run<NL, PG>(V, step == 0 ? QUADM_SEG_DBL : QUADM_SEG_FOUT, c);
+      if (step == 0) {
+        if (c.quad < 2) {
+          get(c.quad == 0 ? QUADM_SLOT_X : QUADM_SLOT_Y);
+          if (live) quad_rec_put<NL>(wrec, el, QW_X2 + c.quad, c, x);
+        } else if (c.quad == 2) {
+          get(QUADM_SLOT_Z);
+          quad_canonical<NL>(x, c);
+          if (live) quad_gstore<NL>(zs, sw, el, c.sub, x);
+        }
+      } else {
+        store_pair(QW_F20);
+      }
+    }
+  } else {
+    const int npts = quad_window_points(C->wnaf_w);
+    const int last = 3 * npts;
+#pragma unroll 1
+    for (int pc = 0; pc <= last; ++pc) {
+      const int k = (pc + 2) / 3, sub = (pc + 2) % 3;       // pc 0: 2A affine; then k = 1 .. npts with sub 0 (ADDP), 1 (FMP), 2 (FOUT)
+      int seg;
+      if (pc == 0) {
+        if (c.quad < 2) {
+          quad_rec_get<NL>(x, wrec, el, QW_X2 + c.quad, c);
+          put(c.quad == 0 ? QUADM_SLOT_X : QUADM_SLOT_Y);
+        } else if (c.quad == 2) {
+          quad_gload<NL>(x, is, sw, el, c.sub);
+          put(QUADM_SLOT_W);
+        }
+        seg = QUADM_SEG_AFM;
+      } else if (sub == 0 || sub == 1) {
+        if (c.quad < 2) {
+          quad_rec_get<NL>(x, wrec, el, (sub == 0 ? QW_A2X : QW_F20) + c.quad, c);
+          put(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY);
+        }
+        seg = sub == 0 ? QUADM_SEG_ADDP : QUADM_SEG_FMP;
+      } else {
+        seg = QUADM_SEG_FOUT;
+      }
+      quad_run<NL, PG>(V, seg, c);
+      if (pc == 0) {
+        store_pair(QW_A2X);
+        start_from_A();
+      } else if (sub == 1) {
+        if (c.quad < 2) {
+          get(c.quad == 0 ? QUADM_SLOT_X : QUADM_SLOT_Y);
+          if (live) quad_rec_put<NL>(wrec, el, (c.quad == 0 ? QW_JX : QW_JY) + k - 1, c, x);
+        } else if (c.quad == 2) {
+          get(QUADM_SLOT_Z);
+          quad_canonical<NL>(x, c);
+          if (live) quad_gstore<NL>(zs, (size_t)QW_PTS * sw, (size_t)(k - 1) * sw + el, c.sub, x);
+        }
+      } else if (sub == 2) {
+        if (c.quad < 2) {
+          get(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY);
+          quad_canonical<NL>(x, c);
+          if (live) quad_rec_put<NL>(wrec, el, (c.quad == 0 ? QW_FD0 : QW_FD1) + k - 1, c, x);
+        }
+      }
+    }
+  }
+}
+
 // Launch 1 in its table form (fixedpair.hpp miller_loop_fixed on the lane groups): e(K, a[e]) over the NORMALISED line
 // table of the key point K — makeL2 over P's table along the NAF of n (bgn.go:316-321), the level-1 decryption lift
 // over the table of q1*P along the NAF of q2 = n / q1 (bgn.go:222-223).  tab: limb j of value v of step s at
@@ -599,7 +849,7 @@ __device__ __forceinline__ void quad_canonical16(int (&x)[QuadDims<NL>::M], cons
 template <int NL>
 __global__ void __launch_bounds__(QUAD_BLOCK)
 k_pairing_quad_table(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, size_t count,
-                     const u32* __restrict__ tab, u32* __restrict__ park, u32* __restrict__ nsoa, size_t ws) {
+                     const u32* __restrict__ tab, u32* __restrict__ park, u32* __restrict__ nsoa, size_t ws, size_t e0) {
   constexpr int M = QuadDims<NL>::M;
   using PG = QuadTable;
   static_assert(QUADT_SLOT_TB1 == QUADT_SLOT_TA1 + 1 && QUADT_SLOT_TA2 == QUADT_SLOT_TA1 + 2 && QUADT_SLOT_TB2 == QUADT_SLOT_TA1 + 3,
@@ -608,9 +858,10 @@ k_pairing_quad_table(const FpParams<NL>* __restrict__ P, const PairingConsts* __
   char* V = reinterpret_cast<char*>(Vs);
   QuadLane<NL> c;
   quad_lane_init<NL>(c, P);
-  size_t e = (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);
+  size_t e = e0 + (size_t)blockIdx.x * QUAD_PER_BLOCK + (threadIdx.x >> 4);   // e0: the first pairing of this piece of the batch
   const bool live = e < count;
   if (!live) e = count - 1;
+  const size_t el = e - e0;                     // its index in the workspace arrays
   int x[M];
   auto put = [&](int slot) { quad_store<NL>(V, quad_addr<NL>((u32)slot, c), x); };
   // coefficient k = c.quad of the segment that starts at table step s: this lane's limbs
@@ -678,7 +929,7 @@ k_pairing_quad_table(const FpParams<NL>* __restrict__ P, const PairingConsts* __
     const int slot = c.quad == 0 ? QUADT_SLOT_N1 : c.quad == 1 ? QUADT_SLOT_N2 : QUADT_SLOT_FM;
     quad_load<NL>(x, V, quad_addr<NL>((u32)slot, c));
     if (live) {
-      u32* dst = park + (e * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
+      u32* dst = park + (el * 3 + (size_t)c.quad) * (4 * M) + (size_t)c.sub * M;
 #pragma unroll
       for (int j = 0; j < M; ++j) dst[j] = (u32)x[j];
     }
@@ -689,7 +940,7 @@ k_pairing_quad_table(const FpParams<NL>* __restrict__ P, const PairingConsts* __
 #pragma unroll
     for (int j = 0; j < M; ++j) x[j] += y[j];
     quad_tight<NL>(x, c);
-    if (live) quad_gstore<NL>(nsoa, ws, e, c.sub, x);
+    if (live) quad_gstore<NL>(nsoa, ws, el, c.sub, x);
   }
 }
 

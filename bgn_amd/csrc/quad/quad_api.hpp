@@ -10,14 +10,17 @@ namespace bgn {
 // final-exponentiation launch.  Returns false when `nl` has no instantiation (then nothing was launched).
 // tab != nullptr (mode 1 only): e(K, a[e]) over the NORMALISED line table of the key point K (fixedpair.hpp; limb
 // stride 1) built for the scalar whose NAF `consts` holds; b is not read.
+// window = 3, 4, 5 (general pairings only, tab == nullptr): the Miller loop over the width-w NAF that `consts` holds
+// (wnaf, wnaf_w == window) with a per-pairing table of the odd multiples of a[e] and their Miller values — two table
+// launches and two more inversion launches in front of the Miller launch; ws then has quad_ws_words(nl, sw, window) words.
 bool quad_pairing_launch(int nl, hipStream_t s, const void* params, const PairingConsts* consts, SoA2 a, SoA2 b, SoA2 out,
                          size_t count, int mode, size_t d1, size_t d2, uint32_t* ws, size_t sw, int p_bits,
-                         const uint32_t* tab = nullptr);
+                         const uint32_t* tab = nullptr, int window = 0);
 // out[e] = a[e]^k in F_p^2, ONE exponent for all elements (k big-endian, klen <= 256 bytes), sixteen lanes per element;
 // a, out canonical Montgomery SoA (limb strides sa, so; sa == 1 — one base for all — is not served: false).
 bool quad_gt_pow_launch(int nl, hipStream_t s, const void* params, const uint32_t* a0, const uint32_t* a1, size_t sa,
                         const uint8_t* k, size_t klen, uint32_t* o0, uint32_t* o1, size_t so, size_t count);
-size_t quad_ws_words(int nl, size_t sw);
+size_t quad_ws_words(int nl, size_t sw, int window = 0);
 // Per-element powers on the lane groups (quad_g1.hpp): MultConst of mid-size batches.
 // out[e] = k[e] * B[e] in G1: B canonical Montgomery SoA with identity flags (B.stride == 1 — one base — is not
 // served); k big-endian, klen <= 1024 bytes each, kstride apart; O plain canonical affine SoA with identity flags

@@ -4,6 +4,7 @@ kernel by batch size; options quad_min / quad_max move the range of the lane-gro
 it), so every kernel is driven through the same C-ABI calls here."""
 import random
 
+import numpy as np
 import pytest
 
 from conftest import engine_key, load_fixture
@@ -62,9 +63,36 @@ def test_quad_random_pairs_vs_c_oracle_and_the_other_kernels(name, count, engopt
         assert (kernel in eng.last_kernel_name()) == (kernel != "lane"), eng.last_kernel_name()
     assert got["quad"] == got["lane"] == got["coop"]
     assert got["quad"] == o.mult(a, b)
+    # the lane groups' two Miller loops: over the width-5 NAF with the per-pairing table (the default) and the plain NAF
+    force(engopts, "quad")
+    assert eng.get_option("quad_window") == -1
+    for w in (0, 1):
+        engopts.set("quad_window", w)
+        assert eng.mult(a, b).tobytes() == got["lane"], "quad_window = %d" % w
     E = eng.elem_bytes
     one = (1).to_bytes(E // 2, "big") + bytes(E // 2)
     assert got["quad"][5 * E: 6 * E] == one and got["quad"][9 * E: 10 * E] == one
+
+
+def test_quad_large_batch_runs_in_pieces(engopts):
+    """The lane-group launcher cuts a batch into pieces of 196 608 pairings that reuse one workspace (kern_quad.hip
+    quad_piece): 196 608 + 300 pairs at a small key, with and without the width-5 loop's tables, equal the lane kernel's
+    bytes; the workspace stays that of one piece."""
+    fx = load_fixture("k256")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    rng = np.random.default_rng(21)
+    count = 196608 + 300
+    base = eng.encrypt([int(v) for v in rng.integers(0, fx["msg_space"], 96)], [int(v) + 5 for v in rng.integers(0, 1 << 60, 96)])
+    a = base[rng.integers(0, 96, count)].tobytes()
+    b = base[rng.integers(0, 96, count)].tobytes()
+    force(engopts, "lane")
+    want = eng.mult(a, b).tobytes()
+    force(engopts, "quad")
+    for w in (1, 0):
+        engopts.set("quad_window", w)
+        assert eng.mult(a, b).tobytes() == want, "quad_window = %d" % w
+        assert "quad" in eng.last_kernel_name()
 
 
 @pytest.mark.parametrize("name,npoly,d1,d2", [("k256", 3, 4, 3), ("k512", 1, 9, 13), ("k1024", 2, 4, 4)])

@@ -911,9 +911,9 @@ static size_t coop_limit(const bgn_ctx* c, int mode) {
   // Mult: with the lane-group kernel above it (profiles/r03_mid_batch.csv: 1024 pairs 17.8 ms cooperative against
   // 21.2 ms, 1536: 25.1 against 21.3 at 1024 bits; 512 bits: 1024 pairs 5.3 against 5.2 ms) the crossover is where
   // that kernel's one-round time is reached; without it, the lane kernel's (r02_small_batch.csv)
-  // (round 4, 24-instruction rows and nine-round segments: profiles/r04_mid_batch.csv 1024 pairs 17.0 ms cooperative
-  // against 16.7, 512 bits 5.3 against 4.6; profiles/r04_calibrate.csv puts the crossings at 1015 / 820)
-  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 1000 : c->nl >= 19 ? 820 : 800;
+  // (round 4, 24-instruction rows, nine-round segments and the width-5 loop: profiles/r04_mid_batch.csv 1024 pairs
+  // 17.0 ms cooperative against 16.0, 512 bits 5.3 against 4.5; profiles/r04_calibrate.csv puts the crossings at 950 / 815)
+  if (quad_limit(c)) return c->xo.coop[0] >= 0 ? (size_t)c->xo.coop[0] : c->nl >= 36 ? 950 : c->nl >= 19 ? 815 : 800;
   return c->nl >= 36 ? 10000 : c->nl >= 19 ? 6000 : 4096;
 }
 
@@ -931,9 +931,9 @@ static size_t quad_limit(const bgn_ctx* c) {
   if (quad_ws_words(c->nl, 64) == 0) return 0;                        // no instantiation for this limb count
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
   if (c->xo.quad[0] >= 0) return (size_t)c->xo.quad[0];                // bgn_ctx_calibrate
-  // profiles/r04_mid_batch.csv (nine-round segments): 49152 pairs 134 ms, 65536 178 ms against 157 on the lane kernel
-  // (512 bits: 65536 pairs 37.9 against 28.6, 32768 19.9 against 28.4); profiles/r04_calibrate.csv: 56 800 / 48 000
-  return c->nl >= 36 ? 57000 : c->nl >= 19 ? 48000 : 32768;
+  // profiles/r04_mid_batch.csv (nine-round segments, width-5 loop): 49152 pairs 128 ms, 65536 168 ms against 157 on the
+  // lane kernel (512 bits: 65536 pairs 36.1 against 28.6, 49152 27.7 against 28.5); profiles/r04_calibrate.csv: 61 600 / 50 900
+  return c->nl >= 36 ? 61000 : c->nl >= 19 ? 50000 : 32768;
 }
 // The lane-group pairing's Miller loop over the width-w NAF (quad.hpp k_pairing_quad_wtab: per-pairing table of the odd
 // multiples of A and their Miller values, 9 KB per pairing at 1024 bits): 9 % fewer rounds, two more table launches

@@ -6,9 +6,13 @@
 // small to fill the chip with one pairing per lane (pairing.hpp: the latency of one lane's pairing, 166 ms at a
 // 1024-bit key, for anything below 65536).  Here ONE pairing belongs to 16 lanes of a wave:
 //   * four quads of lanes run the four micro-ops of a round of the step programs (tools/coop/gen_prog.py, the
-//     formulas of pairing.hpp scheduled for four workers: a Miller doubling step = 18 products in 5 rounds, a
-//     doubling with the addition after it 36 in 10).  The quads of a pairing sit in one wave, so a round needs no
-//     barrier: its reads precede its writes in the wave's own instruction order;
+//     formulas of pairing.hpp scheduled for four workers: a Miller doubling step = 18 products in 5 rounds, two
+//     doublings or a doubling with the addition after it 36 in 9).  The quads of a pairing sit in one wave, so a
+//     round needs no barrier: its reads precede its writes in the wave's own instruction order;
+//   * the Miller loop runs over the width-5 NAF of n (pairing.hpp miller_loop_w): the odd multiples 3A .. 15A and
+//     their Miller values are made per pairing by two table launches (k_pairing_quad_wtab) with an inversion launch
+//     behind each, kept in the workspace (9 KB per pairing at a 1024-bit key) and loaded into the operand slots by
+//     the step that needs them; a large batch runs in pieces that reuse one workspace (kern_quad.hip);
 //   * inside a quad a field element is split over the four lanes, M = ceil(NL / 4) limbs of 29 bits each (lane s
 //     holds limbs s*M .. s*M + M - 1).  A Montgomery product is NL rows of {broadcast one limb of a inside the quad
 //     (DPP quad_perm), M multiply-adds into the lane's accumulators, the quotient digit from lane 0 (broadcast), M

@@ -22,6 +22,6 @@ for p in 1 2 3; do
 done
 find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
 for f in "$OUT"/*_p*/p_counter_collection.csv; do
-  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 0>|k_pairing_quad<" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
+  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 0>|k_pairing_quad<|k_pairing_quad_wtab<" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
 done
 du -sh "$OUT"

@@ -74,6 +74,30 @@ def test_quad_random_pairs_vs_c_oracle_and_the_other_kernels(name, count, engopt
     assert got["quad"][5 * E: 6 * E] == one and got["quad"][9 * E: 10 * E] == one
 
 
+@pytest.mark.parametrize("width", [3, 4, 0])
+def test_quad_windowed_loop_at_other_widths(width, engopts, monkeypatch):
+    """A context made with miller_window = 3 or 4 (read at bgn_ctx_create: BGN_MILLER_WINDOW) holds a narrower NAF: the
+    lane groups' table then has one resp. three multiples; 0 = no width-w NAF at all: the plain loop.  Golden Mult
+    vectors on the lane-group and the lane kernel."""
+    import bgn_amd
+    monkeypatch.setenv("BGN_MILLER_WINDOW", str(width))
+    fx = load_fixture("k256")
+    pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                           fx["msg_space"], True, fx["poly_base"])
+    monkeypatch.delenv("BGN_MILLER_WINDOW")
+    eng = pk.engine
+    engopts.register(eng)
+    assert eng.get_option("miller_window") == width
+    cts = [e["ct"] for e in fx["encrypt"]]
+    a, b = H([cts[v["a"]] for v in fx["mult"]]), H([cts[v["b"]] for v in fx["mult"]])
+    for kernel in ("quad", "lane"):
+        force(engopts, kernel)
+        out = eng.mult(a, b)
+        assert ("quad" in eng.last_kernel_name()) == (kernel == "quad")
+        for row, v in zip(out, fx["mult"]):
+            assert bytes(row).hex() == v["out"], "miller_window = %d on the %s kernel" % (width, kernel)
+
+
 def test_quad_large_batch_runs_in_pieces(engopts):
     """The lane-group launcher cuts a batch into pieces of 196 608 pairings that reuse one workspace (kern_quad.hip
     quad_piece): 196 608 + 300 pairs at a small key, with and without the width-5 loop's tables, equal the lane kernel's

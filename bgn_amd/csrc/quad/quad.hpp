@@ -24,8 +24,9 @@
 //   * limbs are signed and lazily normalised as in the cooperative kernel: a carry pass is exact inside a lane and
 //     hands the lane's carry-out to the two lowest limbs of the lane above; lane 3 keeps the whole top limb
 //     (position NL - 1), so no position beyond the NL rows of a product ever holds anything;
-//   * values live in LDS, slot v of a pairing in the lanes of quad v & 3, row block v >> 2: 64 value slots per
-//     pairing with one 256-thread workgroup (16 pairings) per CU.
+//   * values live in LDS, slot v of a pairing in the lanes of quad v & 3, row block v >> 2: the Miller program needs
+//     20 value slots per pairing (its state is updated in place and the generator searches its schedules for the
+//     fewest temporaries): five row blocks, 51 KB per 256-thread workgroup of 16 pairings, three workgroups per CU.
 // Outputs are canonical, hence the same bytes as the other two pairing kernels.  tests/quad_model.py holds a
 // lane-level model of this arithmetic; tests/test_gpu_quad.py compares the kernel with the golden vectors.
 #pragma once

@@ -117,6 +117,13 @@ def test_quad_large_batch_runs_in_pieces(engopts):
         engopts.set("quad_window", w)
         assert eng.mult(a, b).tobytes() == want, "quad_window = %d" % w
         assert "quad" in eng.last_kernel_name()
+    # the walk over the key's line table (makeL2) goes through the same launcher
+    res = {}
+    for kernel in ("lane", "quad"):
+        force_table(engopts, kernel)
+        res[kernel] = eng.make_l2(a).tobytes()
+        assert ("quad" in eng.last_kernel_name()) == (kernel == "quad")
+    assert res["quad"] == res["lane"]
 
 
 @pytest.mark.parametrize("name,npoly,d1,d2", [("k256", 3, 4, 3), ("k512", 1, 9, 13), ("k1024", 2, 4, 4)])

@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 
 #include <type_traits>
 #include <utility>
@@ -504,6 +505,7 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     // 7 * ws, point k of pairing e at (k - 1) * ws + e), the loop starts from the top digit's multiple and its Miller
     // value, an addition loads its multiple into the operand slots and, for |d| > 1, is followed by f <- f * f_d^(+-1)
     // with f_d loaded into the same slots (FMP / FMM: one round).
+    static_assert(offsetof(PairingConsts, naf) % 4 == 0 && offsetof(PairingConsts, wnaf) % 4 == 0, "digits are read four at a time");
     const bool win = wrec != nullptr;
     const u32* nafw = reinterpret_cast<const u32*>(win ? C->wnaf : C->naf);
     auto digit = [&](int i) { return (int)(signed char)((nafw[i >> 2] >> (8 * (i & 3))) & 0xFFu); };

@@ -255,6 +255,19 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
                                   "algorithmic_bytes_per_call": alg_add, "kernel": eng.last_kernel_name(),
                                   "kernel_ms": eng.last_kernel_ms(), "call_ms": dt * 1e3}
     del o1, b1
+    # --- Mult at the batch sizes of a MultPoly fan-out (mid-size batches: the lane-group kernel, 16 lanes per pairing):
+    # the first pairs of the headline's operands, device-resident, the default dispatch, best of three
+    mid = {}
+    bm = syn.permuted_copy(cts, EB, seed=7)
+    om = torch.empty((1 << 15) * EB, dtype=torch.uint8, device=dev)
+    for n_mid in (1 << 12, 1 << 14, 1 << 15):
+        best = min(_timed(lambda: eng.mult_dev(cts[: n_mid * EB], bm[: n_mid * EB], om[: n_mid * EB], n_mid), sync, reps=1)
+                   for _ in range(3))
+        mid[str(n_mid)] = {"ms": best * 1e3, "pairings_per_s": n_mid / best, "kernel": eng.last_kernel_name()}
+    out["mult_mid_batch"] = {"unit": "ms per call of that many pairings", "sizes": mid,
+                             "workload": "pk.Mult on 4096 / 16384 / 32768 ciphertext pairs (wire bytes in HBM to wire bytes), "
+                                         "kernel chosen by the engine's batch-size dispatch"}
+    del bm, om
     # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
     npoly, d1, d2 = 1 << 12, 16, 16
     pa = cts[: npoly * d1 * EB]

@@ -13,12 +13,12 @@ static size_t quad_piece(int nl) { return nl > 40 ? (size_t)65536 : (size_t)1966
 static size_t quad_ws_stride(int nl, size_t sw) { return sw < quad_piece(nl) ? sw : quad_piece(nl); }
 
 // workspace: parked F0^2, F1^2, F0 F1 | norms | their inverses — and, for the width-w loop, the per-pairing table
-// records | Z of 2A | its inverse | Z of the odd multiples (limb stride 7 sw) | their inverses
+// records | Z of 2A | its inverse | Z of the odd multiples (limb stride 7 sw) | their product | its inverse
 template <int NL>
 static size_t ws_words(size_t sw_full, int window) {
   const size_t sw = quad_ws_stride(NL, sw_full);
   size_t n = (size_t)QuadDims<NL>::PARK_WORDS * sw + (size_t)2 * NL * sw;
-  if (window) n += (size_t)QW_NV * 4 * QuadDims<NL>::M * sw + (size_t)(2 + 2 * QW_PTS) * NL * sw;
+  if (window) n += (size_t)QW_NV * 4 * QuadDims<NL>::M * sw + (size_t)(4 + QW_PTS) * NL * sw;
   return n;
 }
 
@@ -46,13 +46,14 @@ static void launch(hipStream_t s, const void* params, const PairingConsts* const
   uint32_t* nsoa = ws + (size_t)QuadDims<NL>::PARK_WORDS * sw;
   uint32_t* isoa = nsoa + (size_t)NL * sw;
   uint32_t* wrec = nullptr;
-  uint32_t *zA = nullptr, *iA = nullptr, *z7 = nullptr, *i7 = nullptr;
+  uint32_t *zA = nullptr, *iA = nullptr, *z7 = nullptr, *zP = nullptr, *iP = nullptr;
   if (window && !tab) {
     wrec = isoa + (size_t)NL * sw;
     zA = wrec + (size_t)QW_NV * 4 * QuadDims<NL>::M * sw;
     iA = zA + (size_t)NL * sw;
     z7 = iA + (size_t)NL * sw;
-    i7 = z7 + (size_t)QW_PTS * NL * sw;
+    zP = z7 + (size_t)QW_PTS * NL * sw;
+    iP = zP + (size_t)NL * sw;
   }
   for (size_t e0 = 0; e0 < total; e0 += quad_piece(NL)) {
     const size_t count = total - e0 < quad_piece(NL) ? total - e0 : quad_piece(NL);      // pairings of this piece
@@ -60,24 +61,22 @@ static void launch(hipStream_t s, const void* params, const PairingConsts* const
     const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
     if (wrec) {
       // the width-w loop's table: (2A, f_2), the inverse of its Z, the odd multiples and their Miller values, the
-      // inverses of their Z (made affine by the Miller launch's prologue)
-      const size_t n7 = (size_t)(quad_window_points(window) - 1) * sw + count;
-      (void)hipMemsetAsync(z7, 0, (size_t)QW_PTS * NL * sw * 4, s);      // (the padding between count and sw is inverted too)
+      // inverse of the product of their Z (unfolded, and the points made affine, by the Miller launch's prologue)
       hipLaunchKernelGGL((k_pairing_quad_wtab<NL, 1>), grid, block, 0, s, P, consts, a, b, end, mode, d1, d2, wrec, zA,
-                         (const uint32_t*)nullptr, sw, e0);
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, sw, e0);
       invert(zA, iA, sw, count);
-      hipLaunchKernelGGL((k_pairing_quad_wtab<NL, 2>), grid, block, 0, s, P, consts, a, b, end, mode, d1, d2, wrec, z7,
-                         (const uint32_t*)iA, sw, e0);
-      invert(z7, i7, (size_t)QW_PTS * sw, n7);
+      hipLaunchKernelGGL((k_pairing_quad_wtab<NL, 2>), grid, block, 0, s, P, consts, a, b, end, mode, d1, d2, wrec, zP,
+                         (const uint32_t*)iA, z7, sw, e0);
+      invert(zP, iP, sw, count);
     }
     if (tab)
       hipLaunchKernelGGL((k_pairing_quad_table<NL>), grid, block, 0, s, P, consts, a, end, tab, park, nsoa, sw, e0);
     else
       hipLaunchKernelGGL((k_pairing_quad<NL, 1>), grid, block, 0, s, P, consts, a, b, out, end, mode, d1, d2, park, nsoa, isoa, sw,
-                         wrec, (const uint32_t*)i7, e0);
+                         wrec, (const uint32_t*)iP, (const uint32_t*)z7, e0);
     invert(nsoa, isoa, sw, count);
     hipLaunchKernelGGL((k_pairing_quad<NL, 2>), grid, block, 0, s, P, consts, a, b, out, end, mode, d1, d2, park, nsoa, isoa, sw,
-                       (uint32_t*)nullptr, (const uint32_t*)nullptr, e0);
+                       (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, e0);
   }
 }
 

@@ -399,8 +399,9 @@ __device__ __forceinline__ void quad_gstore(u32* __restrict__ base, size_t strid
 // ---- the width-w Miller loop (pairing.hpp miller_loop_w) on the lane groups ----------------------------------------
 // A digit +-d of the width-w NAF of n adds +-dA in one step: f <- f * l * f_d^(+-1).  The odd multiples dA (affine)
 // and their Miller values f_d = f_{d,A}(phi(B)) are made per pairing, in the workspace, by two table launches with an
-// inversion launch behind each (k_pairing_quad_wtab below; the second inversion's affine conversion is the prologue of
-// the Miller launch): QW_NV values of 4 * M words per pairing — a value as it lies in the lanes of a quad.
+// inversion launch behind each (k_pairing_quad_wtab below; the second inversion — ONE per pairing, of the product of the
+// multiples' Z — is unfolded and the points made affine by the prologue of the Miller launch): QW_NV values of 4 * M
+// words per pairing — a value as it lies in the lanes of a quad.
 constexpr int QW_PTS = 7;                            // 3A, 5A .. 15A: width 5 (narrower loops use the first ones)
 enum {
   QW_X2 = 0, QW_Y2 = 1,                              // 2A, Jacobian X and Y (as they leave the doubling: lazily normalised)
@@ -409,7 +410,8 @@ enum {
   QW_JX = 6, QW_JY = QW_JX + QW_PTS,                 // (2k+1)A, Jacobian X and Y, k = 1 .. 7
   QW_FD0 = QW_JY + QW_PTS, QW_FD1 = QW_FD0 + QW_PTS, // f_(2k+1), canonical
   QW_AX = QW_FD1 + QW_PTS, QW_AY = QW_AX + QW_PTS,   // (2k+1)A affine, canonical
-  QW_NV = QW_AY + QW_PTS
+  QW_PZ = QW_AY + QW_PTS,                            // Z_1 * .. * Z_k of the multiples (Montgomery's trick), canonical
+  QW_NV = QW_PZ + QW_PTS
 };
 __host__ __device__ constexpr int quad_window_points(int w) { return ((1 << (w - 1)) - 2) / 2; }   // 1, 3, 7
 
@@ -438,11 +440,14 @@ __device__ __forceinline__ void quad_rec_put(u32* __restrict__ base, size_t el, 
 // PHASE 1: the Miller loop and F0^2, F1^2, F0*F1, parked in `park` with N(f) written as tight limbs to nsoa — then
 // k_coop_invert (coop.hpp) inverts all the norms of the batch with the division steps of fpinv.hpp, one per lane —
 // PHASE 2: the rest of the final exponentiation from the parked values and the inverse in isoa (limb stride ws).
+// (three waves per SIMD is what the LDS allows at a 1024-bit key: the register allocation is held to it — the controller's
+// loads and canonicalisations around the one interpreter call site would otherwise take a few registers too many)
 template <int NL, int PHASE>
-__global__ void __launch_bounds__(QUAD_BLOCK)
+__global__ void __launch_bounds__(QUAD_BLOCK) __attribute__((amdgpu_waves_per_eu(QuadDims<NL>::M <= 10 ? 3 : 1)))
 k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, SoA2 out, size_t count,
                int mode, size_t d1, size_t d2, u32* __restrict__ park, u32* __restrict__ nsoa,
-               const u32* __restrict__ isoa, size_t ws, u32* __restrict__ wrec, const u32* __restrict__ wi7, size_t e0) {
+               const u32* __restrict__ isoa, size_t ws, u32* __restrict__ wrec, const u32* __restrict__ wip,
+               const u32* __restrict__ wzk, size_t e0) {
   constexpr int M = QuadDims<NL>::M;
   using PG = typename std::conditional<PHASE == 1, QuadMiller, QuadFinal>::type;
   __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
@@ -501,8 +506,10 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
     // Miller loop over the NAF of n (pairing.hpp miller_loop): a doubling and the addition of +-A that follows it
     // (one segment, nine rounds), two plain doublings (nine) or one (five); the last addition is skipped as in PBC;
     // then the norms' segment.  With a table (wrec != null: pairing.hpp miller_loop_w) the digits are those of the
-    // width-w NAF: the prologue makes the table's points affine from the inverses of their Z (wi7, limb stride
-    // 7 * ws, point k of pairing e at (k - 1) * ws + e), the loop starts from the top digit's multiple and its Miller
+    // width-w NAF: the prologue makes the table's points affine, last one first, from the inverse of the product of
+    // their Z (wip; Montgomery's trick: 1 / Z_k = I * (Z_1 .. Z_(k-1)), I <- I * Z_k with the prefix products of the
+    // record and the Z in wzk, limb stride 7 * ws, point k of pairing e at (k - 1) * ws + e); the loop starts from the
+    // top digit's multiple and its Miller
     // value, an addition loads its multiple into the operand slots and, for |d| > 1, is followed by f <- f * f_d^(+-1)
     // with f_d loaded into the same slots (FMP / FMM: one round).
     static_assert(offsetof(PairingConsts, naf) % 4 == 0 && offsetof(PairingConsts, wnaf) % 4 == 0, "digits are read four at a time");
@@ -525,15 +532,24 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
 #pragma unroll 1
     for (;;) {
       int seg;
-      if (pc < npre) {                                   // the table's point pc + 1: affine from (X, Y) and R / Z
+      if (pc < npre) {                                   // the table's point k = npre - pc: affine from (X, Y) and R / Z_k
+        const int k = npre - pc;
         if (c.quad < 2) {
-          quad_rec_get<NL>(x, wrec, el, (c.quad == 0 ? QW_JX : QW_JY) + pc, c);
+          quad_rec_get<NL>(x, wrec, el, (c.quad == 0 ? QW_JX : QW_JY) + k - 1, c);
           put(c.quad == 0 ? QUADM_SLOT_X : QUADM_SLOT_Y);
         } else if (c.quad == 2) {
-          quad_gload<NL>(x, wi7, (size_t)QW_PTS * ws, (size_t)pc * ws + el, c.sub);
-          put(QUADM_SLOT_W);
+          if (pc == 0) {                                 // I = R / (Z_1 .. Z_npre); AFZ leaves R / (Z_1 .. Z_(k-1)) in its slot
+            quad_gload<NL>(x, wip, ws, el, c.sub);
+            put(QUADM_SLOT_W);
+          }
+          if (k == 1) set_one();
+          else quad_rec_get<NL>(x, wrec, el, QW_PZ + k - 2, c);
+          put(QUADM_SLOT_V0);                            // the product of the Z before this one
+        } else {
+          quad_gload<NL>(x, wzk, (size_t)QW_PTS * ws, (size_t)(k - 1) * ws + el, c.sub);
+          put(QUADM_SLOT_V1);                            // Z_k
         }
-        seg = QUADM_SEG_AFM;
+        seg = QUADM_SEG_AFZ;
       } else if (pend != 0) {                            // f <- f * f_d or its conjugate
         const int ad = pend < 0 ? -pend : pend;
         if (c.quad < 2) {
@@ -572,30 +588,36 @@ k_pairing_quad(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
         if (c.quad < 2) {
           quad_load<NL>(x, V, quad_addr<NL>((u32)(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY), c));
           quad_canonical<NL>(x, c);
-          if (live) quad_rec_put<NL>(wrec, el, (c.quad == 0 ? QW_AX : QW_AY) + pc, c, x);
+          if (live) quad_rec_put<NL>(wrec, el, (c.quad == 0 ? QW_AX : QW_AY) + (npre - pc) - 1, c, x);
         }
         pc += 1;
         if (pc == npre) {
           // the loop starts from the top digit t: V = tA, f = f_t (the Karatsuba triple of c0 + i c1 is
-          // (c0, 0, c0 + c1)); t = 1: (A, 1) as set above, with W = 1 again (it held the last R / Z)
+          // (c0, 0, c0 + c1); t = 1: (1, 0, 1)), W = 1 again (the prologue used the slots of W and of f's triple)
           // (a lane reads back, here and in the loop, exactly the words it stored above: program order suffices)
           const int top = digit(ndig - 1);
           load_multiple(top, QUADM_SLOT_X, QUADM_SLOT_Y);
-          if (c.quad == 2) {
+          if (c.quad == 1) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) x[j] = 0;
+            put(QUADM_SLOT_V1);
+          } else if (c.quad == 2) {
             set_one();
             put(QUADM_SLOT_W);
+            if (top > 1) quad_rec_get<NL>(x, wrec, el, QW_FD0 + top / 2 - 1, c);
+            put(QUADM_SLOT_V0);
+          } else if (c.quad == 3) {
             if (top > 1) {
+              int y[M];
+              long long acc[M];
               quad_rec_get<NL>(x, wrec, el, QW_FD0 + top / 2 - 1, c);
-              put(QUADM_SLOT_V0);
-            }
-          } else if (c.quad == 3 && top > 1) {
-            int y[M];
-            long long acc[M];
-            quad_rec_get<NL>(x, wrec, el, QW_FD0 + top / 2 - 1, c);
-            quad_rec_get<NL>(y, wrec, el, QW_FD1 + top / 2 - 1, c);
+              quad_rec_get<NL>(y, wrec, el, QW_FD1 + top / 2 - 1, c);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc[j] = (long long)x[j] + (long long)y[j];
-            quad_normalize<NL>(x, acc, c);
+              for (int j = 0; j < M; ++j) acc[j] = (long long)x[j] + (long long)y[j];
+              quad_normalize<NL>(x, acc, c);
+            } else {
+              set_one();
+            }
             put(QUADM_SLOT_V2);
           }
         }
@@ -707,13 +729,15 @@ __device__ __forceinline__ void quad_canonical16(int (&x)[QuadDims<NL>::M], cons
 // The table launches of the width-w loop.  STAGE 1: (2A, f_2) by one doubling step from (A, 1); X, Y of 2A and f_2 go to
 // the pairing's record, Z (canonical) to zs for the inversion launch.  STAGE 2: 2A made affine from R / Z (is), then
 // (2k+1)A = (2k-1)A + 2A by addition steps from (A, 1), f_(2k+1) = f_(2k-1) * l * f_2 (ADDP, FMP), k = 1 .. npts; X, Y
-// and f of every multiple go to the record, its Z to zs (limb stride 7 * sw, point k of pairing e at (k - 1) * sw + e).
+// and f of every multiple go to the record, its Z to zkb (limb stride 7 * sw, point k of pairing e at (k - 1) * sw + e),
+// the running product Z_1 .. Z_k to the record and the last one to zs: the one value per pairing the second inversion
+// launch inverts (Montgomery's trick; the Miller launch's prologue unfolds it).
 // One loop with one call site of the round interpreter, as everywhere.
 template <int NL, int STAGE>
 __global__ void __launch_bounds__(QUAD_BLOCK)
 k_pairing_quad_wtab(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 a, SoA2 b, size_t count, int mode,
-                    size_t d1, size_t d2, u32* __restrict__ wrec, u32* __restrict__ zs, const u32* __restrict__ is, size_t sw,
-                    size_t e0) {
+                    size_t d1, size_t d2, u32* __restrict__ wrec, u32* __restrict__ zs, const u32* __restrict__ is,
+                    u32* __restrict__ zkb, size_t sw, size_t e0) {
   constexpr int M = QuadDims<NL>::M;
   using PG = QuadMiller;
   __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
@@ -819,7 +843,12 @@ k_pairing_quad_wtab(const FpParams<NL>* __restrict__ P, const PairingConsts* __r
         }
         seg = sub == 0 ? QUADM_SEG_ADDP : QUADM_SEG_FMP;
       } else {
-        seg = QUADM_SEG_FOUT;
+        if (c.quad == 3) {                                  // the product of the Z so far
+          if (k == 1) set_one();
+          else quad_rec_get<NL>(x, wrec, el, QW_PZ + k - 2, c);
+          put(QUADM_SLOT_PZ);
+        }
+        seg = QUADM_SEG_FOUZ;
       }
       quad_run<NL, PG>(V, seg, c);
       if (pc == 0) {
@@ -832,13 +861,20 @@ k_pairing_quad_wtab(const FpParams<NL>* __restrict__ P, const PairingConsts* __r
         } else if (c.quad == 2) {
           get(QUADM_SLOT_Z);
           quad_canonical<NL>(x, c);
-          if (live) quad_gstore<NL>(zs, (size_t)QW_PTS * sw, (size_t)(k - 1) * sw + el, c.sub, x);
+          if (live) quad_gstore<NL>(zkb, (size_t)QW_PTS * sw, (size_t)(k - 1) * sw + el, c.sub, x);
         }
       } else if (sub == 2) {
         if (c.quad < 2) {
           get(c.quad == 0 ? QUADM_SLOT_AX : QUADM_SLOT_AY);
           quad_canonical<NL>(x, c);
           if (live) quad_rec_put<NL>(wrec, el, (c.quad == 0 ? QW_FD0 : QW_FD1) + k - 1, c, x);
+        } else if (c.quad == 3) {
+          get(QUADM_SLOT_PZ);
+          quad_canonical<NL>(x, c);
+          if (live) {
+            quad_rec_put<NL>(wrec, el, QW_PZ + k - 1, c, x);
+            if (k == npts) quad_gstore<NL>(zs, sw, el, c.sub, x);
+          }
         }
       }
     }

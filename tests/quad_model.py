@@ -191,22 +191,26 @@ class QuadValueMachine:
         self.run("AFM")
         A2 = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
         state(*A)
-        jac, fd = {}, {}
+        jac, fd, pzs = {}, {}, {0: self.store(one)}
         for k in range(1, npts + 1):
             operands(A2)
             self.run("ADDP")
             operands(f2)
             self.run("FMP")
-            jac[k] = (self.get("X"), self.get("Y"), self.get("Z"))
-            self.run("FOUT")
+            jac[k] = (self.get("X"), self.get("Y"), self.canon(self.get("Z")))
+            self.put("pz", pzs[k - 1])                                    # the running product of the Z (Montgomery's trick)
+            self.run("FOUZ")
             fd[k] = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
-        # the table made affine (the Miller launch's prologue, after the second inversion launch)
+            pzs[k] = self.canon(self.get("pzo"))
+        # the table made affine (the Miller launch's prologue) from ONE inverse per pairing: that of Z_1 .. Z_npts
         aff = {0: A}
-        for k in range(1, npts + 1):
+        self.put("zi", self.inv_of(pzs[npts]))
+        for k in range(npts, 0, -1):
             self.put("X", jac[k][0])
             self.put("Y", jac[k][1])
-            self.put("zi", self.inv_of(jac[k][2]))
-            self.run("AFM")
+            self.put("pzp", pzs[k - 1])
+            self.put("zk", jac[k][2])
+            self.run("AFZ")
             aff[k] = (self.canon(self.get("axo")), self.canon(self.get("ayo")))
         # the loop: from the top digit (1, 3, ..., maxd)
         top = d[-1]

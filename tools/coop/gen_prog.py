@@ -655,6 +655,34 @@ def build_quad_programs(w=QUAD_W):
         b.mul(st["X"], zi2, out="axo")
         b.mul(st["Y"], zi3, out="ayo")
     M.segment("AFM", seg_afm)
+
+    # One inversion per pairing for the seven multiples (Montgomery's trick): the table launch keeps the running product
+    # of their Z (FOUZ = FOUT and pz <- pz * Z), only the last product is inverted, and the Miller launch's prologue walks
+    # back from the last multiple: 1 / Z_k = I * (Z_1 .. Z_(k-1)), I <- I * Z_k (AFZ = AFM behind those two products).
+    # pz: the first temporary's slot (FOUZ has no temporaries; the kernel loads the product before the segment and
+    # stores it after); pzp, zk: slots of f's triple, whose values the Miller launch sets after its prologue.
+    M.phys["pz"] = M.phys["pzo"] = M.nphys
+    M.bound["pz"] = M.bound["pzo"] = 2
+    pz = S("pz")
+    pzp = alias("pzp", "v0", 2)
+    zk = alias("zk", "v1", 2)
+    alias("zio", "W", 4)
+
+    def seg_fouz(b):
+        F0, F1 = f_of(st)
+        b.mul(F0, one, out="axo")
+        b.mul(F1, one, out="ayo")
+        b.mul(pz, st["Z"], out="pzo")
+    M.segment("FOUZ", seg_fouz)
+
+    def seg_afz(b):
+        z1 = b.mul(zi, pzp)                                  # 1 / Z_k
+        b.mul(zi, zk, out="zio")                             # the inverse of the shorter product
+        z2 = b.mul(z1, z1)
+        z3 = b.mul(z2, z1)
+        b.mul(st["X"], z2, out="axo")
+        b.mul(st["Y"], z3, out="ayo")
+    M.segment("AFZ", seg_afz, {"zio": "zi"})
     M.allocate_temps()
     # ---- launch 2: h = conj(f)^2 / N(f), g = h^l, division by R ----
     F = Program(w, w, reads_first=True)
@@ -967,7 +995,7 @@ def emit(P, path, prefix="COOP", w=None, round_headers=False, slot_names=None, a
     return seg_index
 
 
-QUAD_MILLER_SLOTS = ("ax", "ay", "bx", "by", "X", "Y", "Z", "ZZ", "W", "v0", "v1", "v2", "n1", "n2", "fm", "one")
+QUAD_MILLER_SLOTS = ("ax", "ay", "bx", "by", "X", "Y", "Z", "ZZ", "W", "v0", "v1", "v2", "n1", "n2", "fm", "one", "pz")
 QUAD_FINAL_SLOTS = ("n1", "n2", "fm", "inv", "raw1", "h0", "h1", "r0", "r1", "out0", "out1")
 QUAD_TABLE_SLOTS = ("ax", "ay", "ta1", "tb1", "ta2", "tb2", "v0", "v1", "v2", "n1", "n2", "fm")
 

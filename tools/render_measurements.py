@@ -84,6 +84,10 @@ if sat:
         rows.insert(2, ("the lane-group kernel saturated (2²⁰ pairs) beside the lane kernel",
                         f"{(1 << 20) / q * 1e3:.3g} against {(1 << 20) / l * 1e3:.3g} pairings/s ({q:.0f} against {l:.0f} ms, `profiles/{tag}_quad_saturated.csv`): "
                         f"{q / l:.2f} × the time — it is the mid-batch kernel"))
+mb = ex.get("mult_mid_batch")
+if mb:
+    rows.insert(2, ("the same sizes inside the bench line (`extra.mult_mid_batch`: whole `bgn_mult_batch_dev` calls, wire bytes to wire bytes, default dispatch)",
+                    "; ".join("%s pairs: %.1f ms (`%s`)" % (n, v["ms"], v["kernel"]) for n, v in mb["sizes"].items())))
 # ---- round 4 additions: the files exist from r04 on ----
 def csv_rows(name):
     path = P(name)

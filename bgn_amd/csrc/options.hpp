@@ -27,7 +27,8 @@ struct Options {
   V quad_max_dec{-1};      // Decrypt's lift
   V quad_max_pow{-1};      // Decrypt's power by the secret key
   V quad_max_mc{-1};       // MultConst (per-element scalars) on the lane groups
-  V quad_max_enc{-1};      // the fixed-base products of Encrypt / blinding on the lane groups (-1: 2048-bit keys only)
+  V quad_max_enc{-1};      // the fixed-base products of Encrypt / blinding on the lane groups up to this many elements
+                           // (-1: below one full chip of the chain kernels, every size at 2048-bit keys; 0: never)
   V quad_window{-1};       // the lane-group pairing's Miller loop over the width-w NAF of miller_window with a per-pairing
                            // table (-1: where its workspace stays below 3 GB; 0: the plain NAF; 1: always)
   V split_rounds{1};       // cut a batch into whole rounds of the lane kernel + a remainder (0: one launch)

@@ -205,6 +205,26 @@ def op_rooflines(entry, counts, nl, n_gpus=1):
     return entry
 
 
+def mid_batch_metrics(eng, a, b, dev):
+    """Mult at the batch sizes of a MultPoly fan-out (mid-size batches: the lane-group kernel, 16 lanes per pairing): the
+    first pairs of the headline's operands, device-resident, the default dispatch, best of three whole calls (wire bytes
+    to wire bytes).  Called BEFORE the headline's warm-up: a mid-size request does not arrive behind a minute of full
+    load, and the clocks of a chip that has just run one differ by a few per cent."""
+    import torch
+    EB = eng.elem_bytes
+    sync = torch.cuda.synchronize
+    om = torch.empty((1 << 15) * EB, dtype=torch.uint8, device=dev)
+    mid = {}
+    for n_mid in (1 << 12, 1 << 14, 1 << 15):
+        eng.mult_dev(a[: n_mid * EB], b[: n_mid * EB], om[: n_mid * EB], n_mid)          # warm-up (workspace)
+        best = min(_timed(lambda: eng.mult_dev(a[: n_mid * EB], b[: n_mid * EB], om[: n_mid * EB], n_mid), sync, reps=1)
+                   for _ in range(3))
+        mid[str(n_mid)] = {"ms": best * 1e3, "pairings_per_s": n_mid / best, "kernel": eng.last_kernel_name()}
+    return {"unit": "ms per call of that many pairings", "sizes": mid,
+            "workload": "pk.Mult on 4096 / 16384 / 32768 ciphertext pairs (wire bytes in HBM to wire bytes), kernel chosen "
+                        "by the engine's batch-size dispatch; measured before the headline's warm-up steps"}
+
+
 def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
     """BASELINE configs[1] (Encrypt), EAdd, configs[4]'s shape on one GPU and configs[3] (BSGS Decrypt, T = 2^40),
     on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used.  Inputs resident in HBM; one warm-up pass
@@ -255,19 +275,6 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
                                   "algorithmic_bytes_per_call": alg_add, "kernel": eng.last_kernel_name(),
                                   "kernel_ms": eng.last_kernel_ms(), "call_ms": dt * 1e3}
     del o1, b1
-    # --- Mult at the batch sizes of a MultPoly fan-out (mid-size batches: the lane-group kernel, 16 lanes per pairing):
-    # the first pairs of the headline's operands, device-resident, the default dispatch, best of three
-    mid = {}
-    bm = syn.permuted_copy(cts, EB, seed=7)
-    om = torch.empty((1 << 15) * EB, dtype=torch.uint8, device=dev)
-    for n_mid in (1 << 12, 1 << 14, 1 << 15):
-        best = min(_timed(lambda: eng.mult_dev(cts[: n_mid * EB], bm[: n_mid * EB], om[: n_mid * EB], n_mid), sync, reps=1)
-                   for _ in range(3))
-        mid[str(n_mid)] = {"ms": best * 1e3, "pairings_per_s": n_mid / best, "kernel": eng.last_kernel_name()}
-    out["mult_mid_batch"] = {"unit": "ms per call of that many pairings", "sizes": mid,
-                             "workload": "pk.Mult on 4096 / 16384 / 32768 ciphertext pairs (wire bytes in HBM to wire bytes), "
-                                         "kernel chosen by the engine's batch-size dispatch"}
-    del bm, om
     # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
     npoly, d1, d2 = 1 << 12, 16, 16
     pa = cts[: npoly * d1 * EB]
@@ -552,6 +559,9 @@ def main():
         if use_dist:
             gathered[0] = gather_shards(out, total, EB, world, rank, dist)
 
+    mid_batch = None
+    if not args.no_extra and world == 1 and not use_dist and args.key == "k1024" and args.batch_log2 == 20:
+        mid_batch = mid_batch_metrics(eng, a, b, dev)
     dt = timed_region(step, args.steps, args.warmup)
     kernel_ms = kernel_ms[args.warmup:]
     kernel_name = eng.last_kernel_name()
@@ -600,6 +610,8 @@ def main():
         extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2],
                                        no_cpu=args.no_cpu_baseline)
         extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
+        if mid_batch:
+            extra["mult_mid_batch"] = mid_batch
     elif not args.no_extra and use_dist and args.key == "k1024":
         # the second half of BASELINE's metric on every GPU: Decrypt shards exactly like Mult (bgn.go:205-250 is per
         # ciphertext); plaintexts and statuses are gathered like the result arrays

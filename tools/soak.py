@@ -215,8 +215,10 @@ def main():
             alts = [{}]
             if name == "k2048":
                 alts += [{"quad_max_enc": 0}] if n <= 4096 else []
-            elif n <= 30000:
-                alts += [{"quad_max_enc": 1 << 20}]
+            else:
+                alts += [{"quad_max_enc": 0}]                         # the chain kernels at every size
+                if n <= 100000:
+                    alts += [{"quad_max_enc": 1 << 20}]               # the lane groups beyond their default range too
             for env in alts:
                 force("default", **env)
                 out = torch.empty(n * EB, dtype=torch.uint8, device=dev)

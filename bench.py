@@ -59,6 +59,10 @@ def cpu_budget():
             break
         except (OSError, ValueError, IndexError):
             continue
+    # what a CPU leg can actually run on: the affinity mask, capped by the cgroup's CPU quota (16 on this pool's
+    # boxes, whose affinity mask shows all 256 hardware threads).  cpu_baseline.cores is THIS number and the legs
+    # start that many worker threads (`threads`).
+    info["cores"] = max(1, min(info.get("affinity", info["nproc"] or 1), int(-(-info.get("cgroup_cpus", 1e9) // 1))))
     return info
 
 
@@ -91,7 +95,7 @@ def cpu_baseline(fx, a_host, b_host, gpu_out_host, seconds=12.0, sample_note="")
         res = {"value": n / dt, "unit": "pairings/s", "cores": 1, "kind": "port",
                "sample": f"first {n} pairs of the GPU batch, pure-Python big-int oracle (oracle/bgn_ref.py), "
                          f"single thread, {dt:.1f} s", "matches_gpu_bit_exact": bool(ok)}
-    res["host_cpu"] = cpu_budget()      # `cores` = threads started; the cgroup quota says what they could get
+    res["host_cpu"] = cpu_budget()      # `cores` = min(affinity, cgroup quota) = the worker threads started
     if sample_note:
         res["sample"] = res["sample"].replace("first ", "", 1) + "; " + sample_note
     return res
@@ -118,6 +122,43 @@ def decrypt_cpu_baseline(fx, mixed, want, want_st, n_dec, EB):
     res = oracle_c.bench_decrypt(fx, ct, want[sel].tolist(), want_st[sel].tolist(), int(fx["msg_space"]))
     res["host_cpu"] = cpu_budget()
     return res
+
+
+def secondary_cpu_leg(fx, n_items, call, want, out_bytes, unit, what, **kw):
+    """cpu_baseline of a secondary entry (Encrypt, EAdd, MultPoly): the C oracle on the first items of the very batch
+    the GPU just processed — single thread and one thread per usable core — outputs compared byte for byte
+    (oracle/oracle_c.py bench_slices).  Checker / reported baseline only; None without the built oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c
+        if not oracle_c.available():
+            return None
+    except ImportError:
+        return None
+    res = oracle_c.bench_slices(fx, n_items, call, want, out_bytes, unit, what, **kw)
+    res["host_cpu"] = cpu_budget()
+    return res
+
+
+def committed_traffic(key=None):
+    """HBM-side bytes (FETCH_SIZE / WRITE_SIZE) are hardware counters: rocprofv3 collects them in separate --pmc passes
+    of THIS command (tools/collect_profiles.sh), they cannot be read from inside the process.  The line therefore
+    quotes the newest committed summary under profiles/ and says so: a figure of an earlier run of the same command
+    on the same build family, not of this run."""
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pmc):
+            continue
+        with open(pmc) as f:
+            d = json.load(f)
+        src = "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed — NOT measured in this run" % name
+        if key is None:
+            return d.get("hbm_bytes_per_launch"), src
+        node = d.get(key)
+        if node is None:
+            continue
+        return node, src
+    return None, None
 
 
 def config0_metrics(no_cpu: bool):
@@ -225,7 +266,7 @@ def mid_batch_metrics(eng, a, b, dev):
                         "by the engine's batch-size dispatch; measured before the headline's warm-up steps"}
 
 
-def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
+def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_log2=14):
     """BASELINE configs[1] (Encrypt), EAdd, configs[4]'s shape on one GPU and configs[3] (BSGS Decrypt, T = 2^40),
     on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used.  Inputs resident in HBM; one warm-up pass
     then one timed pass each."""
@@ -251,6 +292,15 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
          "kernel": eng.last_kernel_name(), "kernel_ms_per_step": eng.last_kernel_ms(),
          "algorithmic_bytes_per_unit": xs.shape[1] + rs.shape[1] + EB},
         syn.encrypt_counts(xs.shape[1] * 8, rs.shape[1] * 8), nl)
+    if not no_cpu:
+        ns = 4096                                     # the first 4096 (m, r) of the batch are enough for any host
+        xh = [int.from_bytes(bytes(v), "big") for v in xs[:ns].cpu().numpy()]
+        rh = [int.from_bytes(bytes(v), "big") for v in rs[:ns].cpu().numpy()]
+        cb = secondary_cpu_leg(fx, ns, lambda orc, lo, hi: orc.encrypt(xh[lo:hi], rh[lo:hi]),
+                               cts[: ns * EB].cpu().numpy().tobytes(), EB, "encrypts/s",
+                               "(m, r) pairs (P^m * Q^r by generic scalar multiplication, as PBC's PowBig)", calibrate=4)
+        if cb:
+            out["encrypt"]["cpu_baseline"] = cb
     # --- EAdd (level 1): every ciphertext with its partner in a fixed permutation (the pairs of Config 3)
     n_add = n_enc
     a1, b1 = cts, syn.permuted_copy(cts, EB, seed=11)
@@ -264,31 +314,44 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
     # HBM-side traffic of that call's four launches (k_decode_plain x 2, k_g1_add, k_encode) from the committed PMC
     # passes of this command (tools/summarize_profiles.py), next to its algorithmic bytes
     eadd_traffic, eadd_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
-    if os.path.exists(pmc) and n_add == 1 << 20:
-        with open(pmc) as f:
-            eadd_traffic = json.load(f).get("eadd_l1", {}).get("hbm_bytes_per_call")
-        eadd_src = "profiles/r04_pmc_summary.json eadd_l1 (FETCH_SIZE + WRITE_SIZE of the call's four launches, KB * 1024)"
+    if n_add == 1 << 20:
+        node, eadd_src = committed_traffic("eadd_l1")
+        eadd_traffic = (node or {}).get("hbm_bytes_per_call")
     alg_add = 3 * EB * n_add
     out["eadd_l1"]["roofline"] = {"bound": "hbm", "achieved": alg_add / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": alg_add / dt / 1e9 / HBM_PEAK_GBS, "traffic": eadd_traffic, "traffic_source": eadd_src,
                                   "algorithmic_bytes_per_call": alg_add, "kernel": eng.last_kernel_name(),
                                   "kernel_ms": eng.last_kernel_ms(), "call_ms": dt * 1e3}
+    if not no_cpu:
+        ns = 1 << 16
+        ah, bh = a1[: ns * EB].cpu().numpy().tobytes(), b1[: ns * EB].cpu().numpy().tobytes()
+        cb = secondary_cpu_leg(fx, ns, lambda orc, lo, hi: orc.add(1, ah[lo * EB:hi * EB], bh[lo * EB:hi * EB]),
+                               o1[: ns * EB].cpu().numpy().tobytes(), EB, "adds/s",
+                               "pairs (affine G1 addition, one field inversion each, as PBC's Mul on G1)", calibrate=64)
+        if cb:
+            out["eadd_l1"]["cpu_baseline"] = cb
     del o1, b1
-    # --- MultPoly: configs[4] shape (16x16 coefficient polynomials), 2^12 polynomials = 2^20 coefficient pairs
-    npoly, d1, d2 = 1 << 12, 16, 16
-    pa = cts[: npoly * d1 * EB]
-    pb = cts[npoly * d1 * EB: npoly * (d1 + d2) * EB]
-    po = torch.empty(npoly * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
-    dt = _timed(lambda: eng.poly_mult_dev(npoly, d1, d2, pa, pb, po), sync)
-    out["multpoly"] = op_rooflines(
-        {"value": npoly * d1 * d2 / dt, "unit": "coefficient pairs/s", "polys": npoly, "d1": d1, "d2": d2,
-         "workload": "configs[4] shape on one GPU: MultPoly of 16x16-coefficient ciphertext polynomials "
-                     "(Karatsuba over the bilinear pairing, per-coefficient line tables, segmented GT accumulation), "
-                     "sharded by polynomial across GPUs",
-         "algorithmic_bytes_per_unit": 3 * EB},
-        syn.multpoly_counts_per_pair(fx, d1), nl)
-    del po
+    # --- MultPoly: configs[4] at its stated size on this one GPU — 2^14 products of 16x16 coefficient polynomials
+    # (2^22 coefficient pairs, base-3 digits in {-1, 0, 1}) followed by one AddPoly of the products with each other
+    if polys_log2:
+        job = MultPolyJob(pk, 1 << polys_log2, dev, seed_a=2000, seed_b=3000)
+        dt = _timed(job.step, sync)
+        e = job.entry(fx, dt, 1)
+        if not no_cpu:
+            ah, bh = job.ca.cpu().numpy().tobytes(), job.cb.cpu().numpy().tobytes()
+            d1, d2 = job.d1, job.d2
+            cb = secondary_cpu_leg(
+                fx, job.npoly,
+                lambda orc, lo, hi: orc.poly_mult(hi - lo, d1, d2, ah[lo * d1 * EB:hi * d1 * EB], bh[lo * d2 * EB:hi * d2 * EB]),
+                job.prod.cpu().numpy().tobytes(), (d1 + d2) * EB, "polynomial products/s",
+                "polynomial products of 16x16 coefficients (256 pairings + the accumulation each, poly.go:123-156)",
+                seconds=4.0, calibrate=1, max_per_thread=1)
+            if cb:
+                cb["coefficient_pairs_per_s"] = cb["value"] * d1 * d2
+                cb["single_thread_coefficient_pairs_per_s"] = cb["single_thread_per_s"] * d1 * d2
+                e["cpu_baseline"] = cb
+        out["multpoly"] = e
+        del job
     # --- Decrypt: the first 2^k of those ciphertexts, every 16th negated and every 4096th out of range
     t0 = time.perf_counter()
     pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
@@ -314,16 +377,11 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False):
              "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
             syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
         # the dominant kernel of Decrypt is the lift (k_pairing<NL, 1>), timed by HIP events on its stream
-        traffic = None
-        for pname, key in (("r04_pmc_summary.json", "decrypt_lift_k_pairing_1"), ("r03_pmc_summary.json", "decrypt_lift_k_pairing_1"),
-                           ("r02_pmc_summary.json", "decrypt_lift_k_pairing_38_1")):
-            pmc = os.path.join(ROOT, "profiles", pname)
-            if k == 20 and os.path.exists(pmc):                 # separate rocprofv3 --pmc passes of this command
-                with open(pmc) as f:
-                    traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
-                break
+        node, traffic_src = committed_traffic("decrypt_lift_k_pairing_1" if k == 20 else "decrypt_lift_2^%d" % k)
+        traffic = (node or {}).get("hbm_bytes_per_launch")
         e["roofline"] = {"bound": "hbm", "achieved": alg * n_dec / (lift_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg * n_dec / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src if traffic is not None else None,
                          "kernel": eng.last_aux_kernel_name(), "kernel_ms": lift_ms,
                          "walk_kernel": eng.last_kernel_name(), "walk_kernels_ms": walk_ms,
                          "algorithmic_bytes_per_decrypt": alg}
@@ -608,7 +666,7 @@ def main():
     full = args.key == "k1024" and args.batch_log2 == 20
     if not args.no_extra and world == 1 and not use_dist and full:
         extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2],
-                                       no_cpu=args.no_cpu_baseline)
+                                       no_cpu=args.no_cpu_baseline, polys_log2=args.polys_log2)
         extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
         if mid_batch:
             extra["mult_mid_batch"] = mid_batch
@@ -626,14 +684,9 @@ def main():
         mads = syn.algorithmic_mads_per_pairing(
             fx, run=max(1, min(16, -(-count // 65536))),
             window={0: 2, 3: 3, 4: 4}.get(eng.get_option("miller_window"), 5))
-        traffic, traffic_src = None, None
-        for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc) and full:
-                with open(pmc) as f:
-                    traffic = json.load(f)["hbm_bytes_per_launch"]     # separate rocprofv3 --pmc passes of this command
-                traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE, KB * 1024, per launch of 2^20 pairings)" % name
-                break
+        traffic, traffic_src = committed_traffic() if full else (None, None)
+        if traffic is not None:
+            traffic_src += " (FETCH_SIZE + WRITE_SIZE per launch of 2^20 pairings)"
         mad_rate = mads * count / (k_ms * 1e-3)
         if use_dist:
             assert rccl_ranks == world == args.gpus, "RCCL world differs from --gpus"
@@ -735,36 +788,78 @@ def decrypt_sharded(pk, fx, dev, cts, xs, world, rank, dist, timed_region, args)
     return e
 
 
+class MultPolyJob:
+    """BASELINE configs[4] on one rank's polynomials: `npoly` MultPoly instances of 16x16 level-1 coefficient
+    polynomials (d1*d2 pairings and the GT accumulation into 31 coefficients each, poly.go:123-156) followed by one
+    AddPoly of the products with each other (poly.go:171-207: product q + product q + npoly/2, coefficient-wise GT
+    products).  Coefficients: Encrypt of base-3 digits in {-1, 0, 1} (plaintext.go:209-266) on the GPU, not timed."""
+
+    def __init__(self, pk, npoly, dev, seed_a, seed_b, d1=16, d2=16):
+        import torch
+        import bgn_amd.synthetic as syn
+        self.eng = eng = pk.engine
+        self.EB = EB = eng.elem_bytes
+        self.npoly, self.d1, self.d2 = npoly, d1, d2
+        _, _, self.ca = syn.config2_ciphertexts(pk, npoly * d1, seed=seed_a, device=dev, digits=True)
+        _, _, self.cb = syn.config2_ciphertexts(pk, npoly * d2, seed=seed_b, device=dev, digits=True)
+        self.prod = torch.empty(npoly * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+        self.summ = torch.empty(((npoly + 1) // 2) * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+        self.mult_kernel = ""
+
+    def step(self):
+        eng, EB = self.eng, self.EB
+        eng.poly_mult_dev(self.npoly, self.d1, self.d2, self.ca, self.cb, self.prod)
+        self.mult_kernel = eng.last_kernel_name()
+        half = self.npoly // 2
+        if half:
+            n = half * (self.d1 + self.d2)
+            eng.add_dev(2, self.prod[: n * EB], self.prod[n * EB: 2 * n * EB], self.summ, n)
+
+    def entry(self, fx, dt, world):
+        """The measurement of one step of `dt` seconds over `world` GPUs (npoly = the whole job's polynomials)."""
+        import bgn_amd.synthetic as syn
+        EB, d1, d2 = self.EB, self.d1, self.d2
+        nl = syn.limbs_for(int(fx["p"], 16))
+        pairs = self.npoly * world * d1 * d2
+        # algorithmic bytes of a step: both coefficient arrays in, the product polynomials out, then the AddPoly's two
+        # operand halves in and its sums out (SURVEY 8(d): "780 B + amortised output" per pair, stated exactly here)
+        npo = self.npoly * world
+        alg = (npo * (d1 + d2) + npo * (d1 + d2) + 3 * (npo // 2) * (d1 + d2)) * EB
+        e = op_rooflines(
+            {"value": pairs / dt, "unit": "coefficient pairs/s", "polys": npo, "d1": d1, "d2": d2,
+             "ms_per_step": dt * 1e3,
+             "workload": "configs[4]: MultPoly of 2^%d pairs of 16x16-coefficient level-1 ciphertext polynomials (%d "
+                         "coefficient pairs; Karatsuba over the bilinear pairing, per-coefficient line tables, segmented "
+                         "GT accumulation) + one AddPoly of the products, on %d GPU(s)" %
+                         (npo.bit_length() - 1, pairs, world),
+             "kernel": self.mult_kernel, "algorithmic_bytes_per_unit": alg / pairs},
+            syn.multpoly_counts_per_pair(fx, d1), nl, n_gpus=world)
+        e["roofline"] = {"bound": "hbm", "achieved": alg / dt / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / dt / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_step": alg, "kernel": self.mult_kernel,
+                         "note": "per GPU, over the whole step (table builds, walks, accumulation, AddPoly: several "
+                                 "kernels, none dominant by bytes); the bound that applies is roofline_valu"}
+        return e
+
+
 def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
-    """BASELINE configs[4]: 2^14 MultPoly instances of 16x16 level-1 coefficient polynomials (2^22 coefficient
-    pairs: d1*d2 pairings and the GT accumulation into 31 coefficients each, poly.go:123-156) followed by one
-    AddPoly of the products with each other (poly.go:171-207: 32 GT products per pair of polynomials), sharded by
-    polynomial: rank g owns polynomials [g*N/G, (g+1)*N/G), results all-gathered (RCCL).  Strong scaling: the
-    job is 2^14 polynomials whatever N."""
+    """BASELINE configs[4] as its own workload (--workload multpoly): the 2^14 polynomials sharded by polynomial —
+    rank g owns polynomials [g*N/G, (g+1)*N/G), results all-gathered (RCCL).  Strong scaling: the job is 2^14
+    polynomials whatever N."""
     import torch
     import torch.distributed as dist
-    import bgn_amd.synthetic as syn
     from bgn_amd.sharding import gather_shards, shard_range
-    eng = pk.engine
-    EB = eng.elem_bytes
-    d1 = d2 = 16
+    EB = pk.engine.elem_bytes
     npoly = 1 << args.polys_log2
     lo, hi = shard_range(npoly, world, rank)
     mine = hi - lo
-    # coefficients: Encrypt of base-3 digits in {-1, 0, 1} (plaintext.go:209-266), on the GPU, not timed
-    _, _, ca = syn.config2_ciphertexts(pk, mine * d1, seed=2000 + rank, device=dev, digits=True)
-    _, _, cb = syn.config2_ciphertexts(pk, mine * d2, seed=3000 + rank, device=dev, digits=True)
-    prod = torch.empty(mine * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
-    summ = torch.empty(((mine + 1) // 2) * (d1 + d2) * EB, dtype=torch.uint8, device=dev)
+    job = MultPolyJob(pk, mine, dev, seed_a=2000 + rank, seed_b=3000 + rank)
+    d1, d2, prod = job.d1, job.d2, job.prod
     gathered = None
 
     def step():
         nonlocal gathered
-        eng.poly_mult_dev(mine, d1, d2, ca, cb, prod)
-        half = mine // 2                                  # AddPoly: product q + product q + half, coefficient-wise
-        if half:
-            n = half * (d1 + d2)
-            eng.add_dev(2, prod[: n * EB], prod[n * EB: 2 * n * EB], summ, n)
+        job.step()
         if use_dist:
             gathered = gather_shards(prod, npoly, (d1 + d2) * EB, world, rank, dist)
 
@@ -788,10 +883,10 @@ def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
         dt = float(t.item())
         assert bool((gathered[lo * (d1 + d2) * EB: hi * (d1 + d2) * EB] == prod).all().item()), "gather mismatch"
     if rank == 0:
+        job.npoly = npoly // world if world > 1 else npoly      # entry() prices the whole job over `world` GPUs
+        e = job.entry(fx, dt / args.steps, world) if npoly % world == 0 else None
         pairs = npoly * d1 * d2
         value = pairs * args.steps / dt
-        ppp, sqp = syn.multpoly_counts_per_pair(fx, d1)
-        mpp = syn.mads_from_counts(ppp, sqp, syn.limbs_for(int(fx["p"], 16)))
         line = {"metric": "MultPoly coefficient pairs/sec at 1024-bit (configs[4])", "value": value,
                 "unit": "coefficient pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -800,14 +895,10 @@ def bench_multpoly(args, pk, fx, dev, world, rank, use_dist, rccl_ranks):
                                        "polynomials (2^%d coefficient pairs) + one AddPoly, sharded by polynomial over "
                                        "%d GPU(s) + RCCL all-gather" % (args.polys_log2, args.polys_log2 + 8, world),
                            "key": fx["name"], "polys": npoly, "polys_per_gpu": mine, "d1": d1, "d2": d2,
-                           "rccl_ranks": rccl_ranks},
-                "roofline": {"bound": "hbm", "achieved": value * 3 * EB / 1e9 / world, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": value * 3 * EB / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                             "algorithmic_bytes_per_pair": 3 * EB, "note": "per GPU, over the whole step (several kernels)"},
-                "roofline_valu": {"bound": "v_mad_u64_u32 issue", "products_per_pair": ppp, "mads_per_unit": mpp,
-                                  "achieved": value / world * mpp, "unit": "lane-MAD/s (per GPU)", "peak": VALU_MAD_PEAK_4W,
-                                  "frac": value / world * mpp / VALU_MAD_PEAK_4W, "peak_at_1_wave_per_simd": VALU_MAD_PEAK_1W,
-                                  "frac_at_1_wave_per_simd": value / world * mpp / VALU_MAD_PEAK_1W}}
+                           "rccl_ranks": rccl_ranks}}
+        if e:
+            line["roofline"] = e["roofline"]
+            line["roofline_valu"] = e["roofline_valu"]
         emit_line(line)
     if use_dist:
         dist.destroy_process_group()

@@ -12,7 +12,8 @@
 //     addition: a = rr,    b = rr*xP - Z3*ysP,       c = Z3          (ysP = +-yP for the NAF digit)
 // The table (a_s, b_s, c_s), s over the 1024 doublings and 332 additions of the NAF of n, is built
 // once per key by one lane (k_fixedpair_build); a ciphertext then costs 7 products per doubling
-// step and 5 per addition step instead of 18 and 17.
+// step and 5 per addition step instead of 18 and 17 (since round 5: 8 / 6 multiplications but 6 / 4
+// reductions — f*l is two sums of two products — and 5 / 3 over a normalized table).
 //
 // The same split serves MultPoly (poly.go:123-156): the d1*d2 pairings e(a_i, b_k) of one polynomial
 // product share their first argument d2 times, so a table is built per coefficient a_i (one lane each,
@@ -270,6 +271,8 @@ __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, con
   l_store(LX, r);                          // LX = xC
   g_load(r, op.ay, op.sa, op.ea);
   l_store(LY, r);                          // LY = yC
+  fp_neg<1>(r, r, P);
+  a_store(S.Z, r);                         // Z slot = p - yC: -cim of a normalized table
   fp_set(r, P->one);
   a_store(S.F0, r);
   fp_zero(r);
@@ -288,49 +291,40 @@ __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, con
       g_load(u, e + NL * ts, ts, te);      // b_s <1
       fp_add(r, r, u);                     // cre <3
       a_store(S.X, r);                     // X slot = cre
-      if (normalized) {
-        l_load(u, LY);                     // cim = yC <1: the line was divided by c_s when the table was built
-      } else {
+      if (!normalized) {
         g_load(u, e + 2 * NL * ts, ts, te);  // c_s
         fp_mul(u, LY, u, P);               // cim <2
+        a_store(S.Y, u);                   // Y slot = cim
+        fp_neg<2>(u, u, P);
+        a_store(S.Z, u);                   // Z slot = 2p - cim
       }
-      fp_add(r, r, u);                     // cre + cim <5
-      a_store(S.T, r);
-      a_store(S.Y, u);                     // Y slot = cim
-      // g = f^2 for a doubling step, g = f for an addition step
-      a_load(r, S.F0);                     // <4
-      a_load(u, S.F1);                     // <6
+      // g = f^2 for a doubling step, g = f for an addition step: g0 in L3, g1 in S0
+      a_load(r, S.F0);                     // <2
+      a_load(u, S.F1);                     // <2
       if (k == 0) {
-        fp_add(w, r, u);                   // <10
+        fp_add(w, r, u);                   // <4
         l_store(S0, w);
-        fp_sub<6>(w, r, u, P);             // <10
-        fp_mul(w, S0, w, P);               // g0 <2
+        fp_sub<2>(w, r, u, P);             // <4
+        fp_mul(w, S0, w, P);               // g0 <2   (16)
+        l_store(L3, w);
         fp_mulv(r, r, u, P, S0);           // F0*F1 <2
         fp_dbl(r, r);                      // g1 <4
+        l_store(S0, r);
       } else {
-        w = r;                             // g0 <4
-        r = u;                             // g1 <6
+        l_store(L3, r);
+        l_store(S0, u);
       }
-      fp_add(u, w, r);                     // g0+g1 <10
-      l_store(L3, u);
-      // f = g * (cre + i*cim)
-      {
-        Fp<NL> c;
-        a_load(c, S.X);
-        fp_mulv(w, w, c, P, S0);           // v0 = g0*cre <2   (12)
-        a_load(c, S.Y);
-        fp_mulv(r, r, c, P, S0);           // v1 = g1*cim <2   (12)
-      }
-      a_load(u, S.T);
-      fp_mul(u, L3, u, P);                 // (g0+g1)(cre+cim) <2   (50)
-      {
-        Fp<NL> dd;
-        fp_sub<2>(dd, w, r, P);            // F0 <4
-        a_store(S.F0, dd);
-        fp_add(dd, w, r);                  // <4
-        fp_sub<4>(u, u, dd, P);            // F1 <6
-        a_store(S.F1, u);
-      }
+      // f = g * (cre + i*cim): two sums of two products (fp_mul2), F0 = g0*cre + g1*(-cim), F1 = g0*cim + g1*cre
+      a_load(u, S.X);                      // cre <3
+      a_load(w, S.Z);                      // -cim <=2 (<=1 normalized: p - yC)
+      fp_mul2(r, L3, u, S0, w, P);         // F0 <2   (2*3 + 4*2 = 14)
+      a_store(S.F0, r);
+      if (normalized)
+        l_load(w, LY);                     // cim = yC <1: the line was divided by c_s when the table was built
+      else
+        a_load(w, S.Y);                    // cim <2
+      fp_mul2(r, L3, w, S0, u, P);         // F1 <2   (2*2 + 4*3 = 16)
+      a_store(S.F1, r);
     }
   }
 }

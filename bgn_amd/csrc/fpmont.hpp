@@ -51,6 +51,19 @@
 
 namespace bgn {
 
+// Range checks of the host emulation (tests/emu defines BGN_EMU, bgn_emu_fail and the switch bgn_emu_checks): a
+// carry that leaves the top limb, a difference that went negative (BGN_CHECK: only where the harness has switched
+// them on — the affine-addition kernels compute through placeholder values in lanes whose result a select
+// discards), an accumulator that would wrap (BGN_CHECK_ALWAYS: limbs are tight whatever the value).  On the
+// device they are nothing.
+#if defined(BGN_EMU)
+#define BGN_CHECK(cond, what) do { if (bgn_emu_checks && !(cond)) bgn_emu_fail(what, __FILE__, __LINE__); } while (0)
+#define BGN_CHECK_ALWAYS(cond, what) do { if (!(cond)) bgn_emu_fail(what, __FILE__, __LINE__); } while (0)
+#else
+#define BGN_CHECK(cond, what) do { } while (0)
+#define BGN_CHECK_ALWAYS(cond, what) do { } while (0)
+#endif
+
 template <int NL>
 struct FpParams {
   u32 p[NL];            // modulus
@@ -209,6 +222,7 @@ __device__ __forceinline__ void fp_add(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>&
     r.v[j] = s & LIMB_MASK;
     c = s >> LIMB_BITS;
   }
+  BGN_CHECK(c == 0, "fp_add: carry out of the top limb");
 }
 
 // r = 2a
@@ -221,6 +235,7 @@ __device__ __forceinline__ void fp_dbl(Fp<NL>& r, const Fp<NL>& a) {
     r.v[j] = s & LIMB_MASK;
     c = s >> LIMB_BITS;
   }
+  BGN_CHECK(c == 0, "fp_dbl: carry out of the top limb");
 }
 
 // r = a + K*p - b, needs b < K*p   (bound: B_a + K)
@@ -235,6 +250,7 @@ __device__ __forceinline__ void fp_sub(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>&
     r.v[j] = (u32)s & LIMB_MASK;
     c = s >> LIMB_BITS;   // arithmetic shift: a borrow is -1
   }
+  BGN_CHECK(c == 0, "fp_sub: negative difference or carry out of the top limb");
 }
 
 // r = K*p - a   (negation), needs a <= K*p
@@ -248,6 +264,41 @@ __device__ __forceinline__ void fp_neg(Fp<NL>& r, const Fp<NL>& a, const FpParam
     r.v[j] = (u32)s & LIMB_MASK;
     c = s >> LIMB_BITS;
   }
+  BGN_CHECK(c == 0, "fp_neg: operand above K*p");
+}
+
+// One carry pass for a small linear combination: r = CA*a + CB*b + CC*c + K*p with compile-time integer
+// coefficients (K = 0: no multiple of p).  The step programs of pairing.hpp use it where a chain of fp_dbl /
+// fp_add / fp_sub passes (three instructions per limb each) forms one value.  The VALUE must be non-negative and
+// below 2^(LIMB_BITS*NL) — the caller's bounds, as for fp_sub; per limb the positive part (coefficients > 0, plus
+// one for K*p) may reach 3 * 2^LIMB_BITS and so may the negative part: both fit an i32 with the carry.
+template <int CA, int CB, int CC, int K, int NL>
+__device__ __forceinline__ void fp_lin3(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b, const Fp<NL>& c3,
+                                        const FpParams<NL>* __restrict__ P) {
+  static_assert(K >= 0 && K <= KP_MAX, "K*p table");
+  constexpr int pos = (CA > 0 ? CA : 0) + (CB > 0 ? CB : 0) + (CC > 0 ? CC : 0) + (K > 0 ? 1 : 0);
+  constexpr int neg = (CA < 0 ? -CA : 0) + (CB < 0 ? -CB : 0) + (CC < 0 ? -CC : 0);
+  static_assert(pos <= 3 && neg <= 3, "a limb of the combination must fit 32 bits");
+  i32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    i32 s = c;
+    if (K > 0) s += (i32)P->kp[K > 0 ? K - 1 : 0][j];
+    if (CA != 0) s += CA * (i32)a.v[j];
+    if (CB != 0) s += CB * (i32)b.v[j];
+    if (CC != 0) s += CC * (i32)c3.v[j];
+    r.v[j] = (u32)s & LIMB_MASK;
+    c = s >> LIMB_BITS;
+  }
+  BGN_CHECK(c == 0, "fp_lin: negative value or carry out of the top limb");
+}
+template <int CA, int CB, int K, int NL>
+__device__ __forceinline__ void fp_lin2(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b, const FpParams<NL>* __restrict__ P) {
+  fp_lin3<CA, CB, 0, K, NL>(r, a, b, b, P);
+}
+template <int CA, int K, int NL>
+__device__ __forceinline__ void fp_lin1(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  fp_lin3<CA, 0, 0, K, NL>(r, a, a, a, P);
 }
 
 // Conditional subtraction of p: r = (a >= p) ? a - p : a.  a < 2p -> r < p.
@@ -291,14 +342,21 @@ __device__ __forceinline__ void fp_select(Fp<NL>& r, bool c, const Fp<NL>& a, co
 // ---- Montgomery product -----------------------------------------------------
 // One row: t += ai*b; m = t0*pinv mod 2^LIMB_BITS; t += m*p; t >>= LIMB_BITS.
 // Each row adds two products of < 2^(2*LIMB_BITS) to an accumulator: see fp_flush below.
+// t += a*b (one v_mad_u64_u32); the emulation checks that the 64-bit accumulator does not wrap
+__device__ __forceinline__ void acc_mad(u64& t, u32 a, u32 b) {
+  const u64 x = (u64)a * b;
+  BGN_CHECK_ALWAYS(t <= ~(u64)0 - x, "accumulator wraps: flush interval too long for these operands");
+  t += x;
+}
+
 template <int NL>
 __device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
                                        const FpParams<NL>* __restrict__ P) {
 #pragma unroll
-  for (int j = 0; j < NL; ++j) t[j] += (u64)ai * b.v[j];
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], ai, b.v[j]);
   const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
 #pragma unroll
-  for (int j = 0; j < NL; ++j) t[j] += (u64)m * P->p[j];
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], m, P->p[j]);
   const u64 c = t[0] >> LIMB_BITS;
 #pragma unroll
   for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
@@ -365,6 +423,7 @@ __device__ __forceinline__ void fp_mul_inl(Fp<NL>& r, const LFp<NL>* a, const Fp
     r.v[j] = (u32)s & LIMB_MASK;
     c = s >> LIMB_BITS;
   }
+  BGN_CHECK(c == 0, "fp_mul: result above 2^(LIMB_BITS*NL)");
 }
 
 // Up to 40 limbs every product is inlined into its step program (the hand-scheduled slot machine of pairing.hpp /
@@ -384,6 +443,90 @@ __device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>
     fp_mul_inl<NL>(r, a, b, P);
 }
 
+// ---- sum of two products with ONE reduction ----------------------------------------------------------------
+// r = (a*b + c*d)/R mod p, lazy (r < 2p) when B_a*B_b + B_c*B_d <= 2^9: the interleaved rows add a_i*b and c_i*d
+// to the same accumulators before the row's reduction step, so the second product costs its NL^2 multiply-adds and
+// nothing else — no second reduction (NL^2 multiply-adds more), no second set of row hand-overs, flush and final
+// carry pass.  This is what makes the F_p^2 products of the Miller loop two such sums (re = g0*c0 + g1*(-c1),
+// im = g0*c1 + g1*c0: four multiplications, two reductions, no additions) instead of three Karatsuba products with
+// five carry passes, and Y3 = M*(S - X3) - 8*YY^2 one sum instead of a product, a square and four passes.
+// Both multipliers are streamed from LDS slots, both multiplicands sit in VGPRs (2*NL registers beside the 2*NL of
+// the accumulators): at most ONE further element may be live across the call.  A row adds three products of
+// < 2^(2*LIMB_BITS): 21 rows per flush interval at radix 2^29, so 36 / 37 limbs flush once, as fp_mul does.
+template <int NL>
+__device__ __forceinline__ void fp_row2(u64 (&t)[NL], u32 ai, const Fp<NL>& b, u32 ci, const Fp<NL>& d,
+                                        const FpParams<NL>* __restrict__ P) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], ai, b.v[j]);
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], ci, d.v[j]);
+  const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], m, P->p[j]);
+  const u64 c = t[0] >> LIMB_BITS;
+#pragma unroll
+  for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
+  t[NL - 1] = 0;
+  t[0] += c;
+}
+
+constexpr int kRowsPerFlush2 = LIMB_BITS >= 29 ? 21 : 64;
+
+template <int NL>
+__device__ __forceinline__ void fp_mul2_inl(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b, const LFp<NL>* c,
+                                            const Fp<NL>& d, const FpParams<NL>* __restrict__ P) {
+  const int tid = threadIdx.x;
+  constexpr int NP = NL / 2;
+  constexpr int NI = NL > kRowsPerFlush2 ? (NL + kRowsPerFlush2 - 1) / kRowsPerFlush2 : 1;
+  constexpr int NPI = (NP + NI - 1) / NI;                        // row pairs per interval
+  static_assert(NI == 1 || 2 * NPI + (NL & 1) <= kRowsPerFlush2, "interval too long");
+  u64 t[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] = 0;
+  u64 aa = a->rows[0][tid];
+  u64 cc = c->rows[0][tid];
+#pragma unroll
+  for (int iv = 0; iv < NI; ++iv) {
+    if (iv) fp_flush<NL>(t);
+    const int k1 = (iv + 1) * NPI < NP ? (iv + 1) * NPI : NP;
+#pragma unroll 1
+    for (int k = iv * NPI; k < k1; ++k) {
+      const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
+      const u64 nxa = a->rows[kn][tid];
+      const u64 nxc = c->rows[kn][tid];
+      fp_row2<NL>(t, (u32)aa, b, (u32)cc, d, P);
+      fp_row2<NL>(t, (u32)(aa >> 32), b, (u32)(cc >> 32), d, P);
+      aa = nxa;
+      cc = nxc;
+    }
+  }
+  if (NL & 1) fp_row2<NL>(t, (u32)aa, b, (u32)cc, d, P);
+  u64 cy = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const u64 s = t[j] + cy;
+    r.v[j] = (u32)s & LIMB_MASK;
+    cy = s >> LIMB_BITS;
+  }
+  BGN_CHECK(cy == 0, "fp_mul2: result above 2^(LIMB_BITS*NL)");
+}
+
+template <int NL>
+__device__ __noinline__ void fp_mul2_out(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b, const LFp<NL>* c, const Fp<NL>& d,
+                                         const FpParams<NL>* __restrict__ P) {
+  fp_mul2_inl<NL>(r, a, b, c, d, P);
+}
+
+// r may alias b or d.
+template <int NL>
+__device__ __forceinline__ void fp_mul2(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b, const LFp<NL>* c, const Fp<NL>& d,
+                                        const FpParams<NL>* __restrict__ P) {
+  if constexpr (NL > 40)
+    fp_mul2_out<NL>(r, a, b, c, d, P);
+  else
+    fp_mul2_inl<NL>(r, a, b, c, d, P);
+}
+
 // ---- Montgomery squaring --------------------------------------------------------------------
 // a^2 = sum a_i a_j x^(i+j).  The limb range is cut into four segments; a pair (i, j) with i in an
 // earlier segment than j is taken once, doubled; pairs inside one segment are taken in both orders,
@@ -398,10 +541,10 @@ __device__ __forceinline__ void fp_sqr_row(u64 (&t)[NL], u32 ai, const Fp<NL>& a
                                            const FpParams<NL>* __restrict__ P) {
   const u32 ai2 = ai << 1;
 #pragma unroll
-  for (int j = LO; j < NL; ++j) t[j] += (u64)(j < HI ? ai : ai2) * a1.v[j];
+  for (int j = LO; j < NL; ++j) acc_mad(t[j], j < HI ? ai : ai2, a1.v[j]);
   const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
 #pragma unroll
-  for (int j = 0; j < NL; ++j) t[j] += (u64)m * P->p[j];
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], m, P->p[j]);
   const u64 c = t[0] >> LIMB_BITS;
 #pragma unroll
   for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
@@ -492,6 +635,7 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
       r.v[j] = (u32)s & LIMB_MASK;
       c = s >> LIMB_BITS;
     }
+    BGN_CHECK(c == 0, "fp_sqr: result above 2^(LIMB_BITS*NL)");
   }
 }
 

@@ -13,7 +13,8 @@
 //   * signed-digit (NAF) recoding of n: n is fixed per key, recoded once on
 //     the host; a "-1" digit adds -A and multiplies by the line through V, -A;
 //   * the last addition step (V = -+A, vertical line) is skipped, as PBC does;
-//   * final exponent split as f^(p-1) = conj(f)/f, then ^l  ((p+1)/n = l).
+//   * final exponent split as f^(p-1) = conj(f)/f, then ^l  ((p+1)/n = l);
+//   * sums of two products share one Montgomery reduction (round 5, see miller_double).
 //
 // The steps are written as explicit programs over storage slots (see
 // fpmont.hpp): long-lived state in six AGPR slots, four LDS slots (S0 is the
@@ -41,10 +42,18 @@ struct PairOperands {
 // Running state of the Miller loop, in AGPR slots.
 template <int NL>
 struct Miller {
-  AFp<NL> X, Y, Z;   // V in Jacobian coordinates.  X,Y <18 ; Z <4
-  AFp<NL> F0, F1;    // f = F0 + i*F1.  F0 <4, F1 <6
+  AFp<NL> X, Y, Z;   // V in Jacobian coordinates.  X <8, Y <2 ; Z <4
+  AFp<NL> F0, F1;    // f = F0 + i*F1.  F0 <2, F1 <2
   AFp<NL> T;         // scratch slot
 };
+
+// The step programs below reduce as late as the arithmetic allows (round 5): wherever a formula is a*b +- c*d the
+// two products share ONE Montgomery reduction (fp_mul2, fpmont.hpp) — M = 3X^2 + ZZ^2, Y3 = M*(S - X3) - 8*YY^2,
+// the chord's Y3 and real part, and every F_p^2 product f*l (four multiplications, two reductions, no additions
+// instead of Karatsuba's three products and five carry passes).  A subtrahend enters such a sum as k*p - x (one
+// carry pass), S = 4*X*YY only as its negative Sn = X*(8p - 4YY), and chains of doublings / additions form one
+// value in one pass (fp_lin).  Per doubling step: 19 multiplications (3 of them squarings) and 15 reductions
+// instead of 18 + 18, 12 carry passes instead of 24; per addition step 17 + 14 instead of 17 + 17.
 
 // f <- f^2 * l_{V,V}(phi(B)),  V <- 2V
 template <int NL>
@@ -55,93 +64,71 @@ __device__ __forceinline__ void miller_double(Miller<NL>& S, LFp<NL>* L, const P
   LFp<NL>* L2 = L + 2;
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
-  a_load(r, S.Z);
-  fp_sqrv(r, r, P, S0);                 // ZZ <2            (Z <4: 16)
+  a_load(r, S.Z);                          // <4
+  fp_sqrv(r, r, P, S0);                    // ZZ <2            (16)
   l_store(L1, r);                          // L1 = ZZ
-  fp_sqr(w, L1, r, P);                     // w = ZZ^2 <2
-  a_load(r, S.X);
-  fp_sqrv(u, r, P, S0);                 // u = XX <2        (324)
-  fp_dbl(r, u);
-  fp_add(r, r, u);
-  fp_add(r, r, w);                         // M = 3XX + ZZ^2 <8   (curve a = 1)
-  a_store(S.T, r);                         // T = M
-  a_load(r, S.Y);
-  fp_sqrv(u, r, P, S0);                 // u = YY <2
-  l_store(L2, u);                          // L2 = YY
-  a_load(r, S.X);
-  fp_mulv(r, r, u, P, S0);                 // X*YY <2           (36)
-  fp_dbl(r, r);
-  fp_dbl(r, r);                            // S = 4*X*YY <8
-  l_store(L3, r);                          // L3 = S
-  a_load(r, S.Y);
-  a_load(u, S.Z);
-  fp_mulv(r, r, u, P, S0);                 // Y*Z <2            (72)
-  fp_dbl(r, r);                            // Z3 = 2YZ <4
-  a_store(S.Z, r);
+  a_load(u, S.X);                          // <8
+  l_store(S0, u);                          // S0 = X
+  fp_lin1<3, 0>(u, u, P);                  // 3X <24
+  fp_mul2(w, S0, u, L1, r, P);             // M = X*3X + ZZ*ZZ <2   (8*24 + 2*2 = 196; curve a = 1)
+  a_store(S.T, w);                         // T = M
+  a_load(r, S.Y);                          // <2
+  a_load(u, S.Z);                          // <4
+  l_store(S0, r);                          // S0 = Y
+  fp_mul(u, S0, u, P);                     // Y*Z <2           (8)
+  fp_dbl(u, u);                            // Z3 = 2YZ <4
+  a_store(S.Z, u);
+  fp_sqr(w, S0, r, P);                     // YY <2            (4)
+  fp_dbl(w, w);                            // 2YY <4
+  l_store(L2, w);                          // L2 = 2YY
+  fp_lin1<-2, 8>(r, w, P);                 // 8p - 4YY <=8
+  l_store(L3, r);                          // L3 = 8p - 4YY
   // line, scaled by Z3*ZZ: re = M*(ZZ*xB + X) - 2YY ; im = (Z3*ZZ)*yB
-  fp_mul(u, L1, r, P);                     // Z3*ZZ <2          (8)
+  fp_mul(u, L1, u, P);                     // Z3*ZZ <2         (8)
   g_load(r, op.by, op.sb, op.eb);
   fp_mulv(r, u, r, P, S0);                 // r = cim <2
   g_load(u, op.bx, op.sb, op.eb);
   fp_mul(u, L1, u, P);                     // ZZ*xB <2
   l_store(L1, r);                          // L1 = cim   (ZZ dead)
-  a_load(r, S.X);
-  fp_add(u, u, r);                         // t <20
-  a_load(r, S.T);
-  fp_mulv(u, u, r, P, S0);                 // M*t <2            (160)
-  l_load(r, L2);
-  fp_dbl(r, r);                            // 2YY <4
-  fp_sub<4>(u, u, r, P);                   // cre <6
+  a_load(r, S.X);                          // <8
+  fp_add(u, u, r);                         // t <10
+  a_load(w, S.T);
+  fp_mulv(u, u, w, P, S0);                 // M*t <2           (20)
+  l_load(w, L2);                           // 2YY <4
+  fp_sub<4>(u, u, w, P);                   // cre <6
   a_store(S.Y, u);                         // Y slot = cre  (Y dead)
-  // X3 = M^2 - 2S
-  a_load(r, S.T);
-  fp_sqrv(u, r, P, S0);                 // M^2 <2            (64)
-  l_load(r, L3);                           // S <8
-  fp_dbl(w, r);                            // 2S <16
-  fp_sub<16>(u, u, w, P);                  // X3 <18
-  a_store(S.X, u);
-  // Y3 = M*(S - X3) - 8*YY^2
-  fp_sub<18>(r, r, u, P);                  // S - X3 <26
+  // Sn = X*(8p - 4YY) = -S ;  X3 = M^2 - 2S = M^2 + 2*Sn
+  fp_mul(r, L3, r, P);                     // Sn <2            (64)
   a_load(u, S.T);
-  fp_mulv(r, r, u, P, S0);                 // <2                (208)
-  l_load(u, L2);
-  fp_sqrv(u, u, P, S0);                 // YY^2 <2
-  fp_dbl(u, u);
-  fp_dbl(u, u);
-  fp_dbl(u, u);                            // <16
-  fp_sub<16>(r, r, u, P);                  // Y3 <18
+  fp_sqrv(u, u, P, S0);                    // M^2 <2           (4)
+  fp_lin2<1, 2, 0>(w, u, r, P);            // X3 <6
+  a_store(S.X, w);
+  // Y3 = M*(S - X3) - 8*YY^2 = M*(8p - Sn - X3) + 2YY*(8p - 4YY): one reduction
+  fp_lin2<-1, -1, 8>(r, r, w, P);          // S - X3 <=8
+  l_store(S0, r);
+  a_load(u, S.T);                          // M <2
+  l_load(w, L3);                           // 8p - 4YY <=8
+  fp_mul2(r, S0, u, L2, w, P);             // Y3 <2            (8*2 + 4*8 = 48)
   l_store(L2, r);                          // L2 = Y3 (parked; Y slot holds cre)
   // g = f^2 : g0 = (F0+F1)(F0-F1), g1 = 2*F0*F1
-  a_load(r, S.F0);                         // <4
-  a_load(u, S.F1);                         // <6
-  fp_add(w, r, u);                         // <10
+  a_load(r, S.F0);                         // <2
+  a_load(u, S.F1);                         // <2
+  fp_add(w, r, u);                         // <4
   l_store(S0, w);
-  fp_sub<6>(w, r, u, P);                   // <10
-  fp_mul(w, S0, w, P);                     // g0 <2             (100)
-  fp_mulv(r, r, u, P, S0);                 // F0*F1 <2          (24)
+  fp_sub<2>(w, r, u, P);                   // <4
+  fp_mul(w, S0, w, P);                     // g0 <2            (16)
+  l_store(L3, w);                          // L3 = g0
+  fp_mulv(r, r, u, P, S0);                 // F0*F1 <2         (4)
   fp_dbl(r, r);                            // g1 <4
-  fp_add(u, w, r);                         // g0+g1 <6
-  l_store(L3, u);                          // L3 = g0+g1
-  // f = g * (cre + i*cim)  (Karatsuba)
-  {
-    Fp<NL> c0, c1;
-    a_load(c0, S.Y);                       // cre <6
-    l_load(c1, L1);                        // cim <2
-    fp_add(u, c0, c1);                     // <8
-    a_store(S.T, u);                       // T = cre+cim
-    fp_mulv(w, w, c0, P, S0);              // v0 = g0*cre <2    (12)
-    fp_mulv(r, r, c1, P, S0);              // v1 = g1*cim <2    (8)
-  }
-  a_load(u, S.T);
-  fp_mul(u, L3, u, P);                     // (g0+g1)(cre+cim) <2   (48)
-  {
-    Fp<NL> d;
-    fp_sub<2>(d, w, r, P);                 // F0 = v0 - v1 <4
-    a_store(S.F0, d);
-    fp_add(d, w, r);                       // <4
-    fp_sub<4>(u, u, d, P);                 // F1 <6
-    a_store(S.F1, u);
-  }
+  l_store(S0, r);                          // S0 = g1
+  // f = g * (cre + i*cim): F0 = g0*cre + g1*(2p - cim), F1 = g0*cim + g1*cre
+  a_load(u, S.Y);                          // cre <6
+  l_load(w, L1);                           // cim <2
+  fp_neg<2>(r, w, P);                      // <=2
+  fp_mul2(r, L3, u, S0, r, P);             // F0 <2            (2*6 + 4*2 = 20)
+  a_store(S.F0, r);
+  fp_mul2(r, L3, w, S0, u, P);             // F1 <2            (2*2 + 4*6 = 28)
+  a_store(S.F1, r);
   l_load(r, L2);
   a_store(S.Y, r);                         // Y = Y3
 }
@@ -156,76 +143,62 @@ __device__ __forceinline__ void miller_add(Miller<NL>& S, LFp<NL>* L, const Pair
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
   a_load(r, S.Z);                          // <4
-  fp_sqrv(u, r, P, S0);                 // ZZ <2             (16)
+  fp_sqrv(u, r, P, S0);                    // ZZ <2             (16)
   l_store(L1, u);                          // L1 = ZZ
   fp_mul(r, L1, r, P);                     // Z^3 <2            (8)
-  g_load(u, op.ay, op.sa, op.ea);       // yA <1
+  g_load(u, op.ay, op.sa, op.ea);          // yA <1
   if (sign < 0) fp_neg<1>(u, u, P);        // ysA <=1
   l_store(L2, u);                          // L2 = ysA
   fp_mul(r, L2, r, P);                     // ysA*Z^3 <2
-  a_load(u, S.Y);                          // <18
-  fp_sub<18>(r, r, u, P);                  // rr <20
+  a_load(u, S.Y);                          // <2
+  fp_sub<2>(r, r, u, P);                   // rr <4
   a_store(S.T, r);                         // T = rr
-  g_load(u, op.ax, op.sa, op.ea);       // xA <1
+  l_store(L3, r);                          // L3 = rr
+  g_load(u, op.ax, op.sa, op.ea);          // xA <1
   fp_mul(u, L1, u, P);                     // xA*ZZ <2
-  a_load(w, S.X);                          // <18
-  fp_sub<18>(u, u, w, P);                  // H <20
+  a_load(w, S.X);                          // <8
+  fp_sub<8>(u, u, w, P);                   // H <10
   l_store(L1, u);                          // L1 = H  (ZZ dead)
   a_load(r, S.Z);
-  fp_mul(r, L1, r, P);                     // Z3 = Z*H <2       (80)
+  fp_mul(r, L1, r, P);                     // Z3 = Z*H <2       (40)
   a_store(S.Z, r);
-  fp_sqr(w, L1, u, P);                     // HH <2             (400)
-  fp_mul(u, L1, w, P);                     // HHH <2            (40)
+  fp_sqr(w, L1, u, P);                     // HH <2             (100)
+  fp_mul(u, L1, w, P);                     // HHH <2            (20)
   a_load(r, S.X);
-  fp_mulv(r, r, w, P, S0);                 // XHH <2            (36)
+  fp_mulv(r, r, w, P, S0);                 // XHH <2            (16)
   a_load(w, S.T);
-  fp_sqrv(w, w, P, S0);                 // rr^2 <2           (400)
-  fp_sub<2>(w, w, u, P);                   // <4
-  {
-    Fp<NL> d;
-    fp_dbl(d, r);                          // 2*XHH <4
-    fp_sub<4>(w, w, d, P);                 // X3 <8
-  }
+  fp_sqrv(w, w, P, S0);                    // rr^2 <2           (16)
+  fp_lin3<1, -1, -2, 6>(w, w, u, r, P);    // X3 = rr^2 - HHH - 2*XHH <8
   a_store(S.X, w);
+  // Y3 = rr*(XHH - X3) - Y*HHH = rr*(XHH - X3) + Y*(2p - HHH): one reduction
   fp_sub<8>(r, r, w, P);                   // XHH - X3 <10
-  a_load(w, S.T);
-  fp_mulv(r, r, w, P, S0);                 // rr*(XHH-X3) <2    (200)
-  a_load(w, S.Y);
-  fp_mulv(w, w, u, P, S0);                 // Y*HHH <2          (36)
-  fp_sub<2>(r, r, w, P);                   // Y3 <4
+  fp_neg<2>(u, u, P);                      // <=2
+  a_load(w, S.Y);                          // <2
+  l_store(S0, w);                          // S0 = Y
+  fp_mul2(r, L3, r, S0, u, P);             // Y3 <2             (4*10 + 2*2 = 44)
   a_store(S.Y, r);
   // line through V and sA at phi(B), scaled by Z3:
-  //   re = rr*(xB + xA) - Z3*ysA ; im = Z3*yB
+  //   re = rr*(xB + xA) - Z3*ysA (one reduction) ; im = Z3*yB
   g_load(u, op.bx, op.sb, op.eb);
   g_load(w, op.ax, op.sa, op.ea);
   fp_add(u, u, w);                         // <2
-  a_load(r, S.T);
-  fp_mulv(r, r, u, P, S0);                 // rr*(xB+xA) <2     (40)
-  a_load(u, S.Z);                          // Z3 <2
-  fp_mul(w, L2, u, P);                     // Z3*ysA <2
-  fp_sub<2>(r, r, w, P);                   // cre <4
+  g_load(w, op.ay, op.sa, op.ea);
+  if (sign > 0) fp_neg<1>(w, w, P);        // -ysA <=1
+  a_load(r, S.Z);                          // Z3 <2
+  l_store(S0, r);                          // S0 = Z3
+  fp_mul2(u, L3, u, S0, w, P);             // cre <2            (4*2 + 2*1 = 10)
   g_load(w, op.by, op.sb, op.eb);
-  fp_mulv(w, w, u, P, S0);                 // cim <2
-  // f = f * (cre + i*cim)
-  fp_add(u, r, w);                         // cre+cim <6
-  l_store(L3, u);                          // L3 = cre+cim
-  a_load(u, S.F0);                         // <4
-  fp_mulv(r, u, r, P, S0);                 // v0 = F0*cre <2    (16)
-  {
-    Fp<NL> f1;
-    a_load(f1, S.F1);                      // <6
-    fp_add(u, u, f1);                      // F0+F1 <10
-    fp_mulv(w, f1, w, P, S0);              // v1 = F1*cim <2    (12)
-  }
-  fp_mul(u, L3, u, P);                     // (cre+cim)(F0+F1) <2   (60)
-  {
-    Fp<NL> d;
-    fp_sub<2>(d, r, w, P);                 // F0 <4
-    a_store(S.F0, d);
-    fp_add(d, r, w);                       // <4
-    fp_sub<4>(u, u, d, P);                 // F1 <6
-    a_store(S.F1, u);
-  }
+  fp_mul(w, S0, w, P);                     // cim <2
+  // f = f * (cre + i*cim): F0 = F0*cre + F1*(2p - cim), F1 = F0*cim + F1*cre
+  a_load(r, S.F0);                         // <2
+  l_store(L1, r);
+  a_load(r, S.F1);                         // <2
+  l_store(L2, r);
+  fp_neg<2>(r, w, P);                      // <=2
+  fp_mul2(r, L1, u, L2, r, P);             // F0 <2             (2*2 + 2*2 = 8)
+  a_store(S.F0, r);
+  fp_mul2(r, L1, w, L2, u, P);             // F1 <2             (8)
+  a_store(S.F1, r);
 }
 
 // ---- F_p^2 on LDS-resident elements (used outside the Miller loop) -----------
@@ -384,35 +357,29 @@ template <int NL>
 __device__ __forceinline__ u32* win_slot(const WinTab& W, int k) { return W.base + (size_t)k * NL * W.s; }
 __device__ __forceinline__ int win_point_slot(int d) { return 4 + 4 * ((d - 3) / 2); }   // x; y = +1, f0 = +2, f1 = +3
 
-// f <- f * (c0 + i*c1) with c canonical (<1) in HBM; conj negates c1.
+// f <- f * (c0 + i*c1) with c canonical (<1) in HBM; conj negates c1.  Two sums of two products.
 template <int NL>
 __device__ __forceinline__ void miller_mul_f(Miller<NL>& S, LFp<NL>* L, const u32* c0p, const u32* c1p, size_t cs,
                                              size_t ce, bool conj, const FpParams<NL>* __restrict__ P) {
   LFp<NL>* S0 = L;
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
-  g_load(r, c0p, cs, ce);                  // c0 <1
+  a_load(r, S.F0);                         // <2
+  l_store(L3, r);
+  a_load(r, S.F1);                         // <2
+  l_store(S0, r);
   g_load(w, c1p, cs, ce);                  // c1 <1
-  if (conj) fp_neg<1>(w, w, P);            // <=1
-  fp_add(u, r, w);                         // c0+c1 <2
-  l_store(L3, u);
-  a_load(u, S.F0);                         // <4
-  fp_mulv(r, u, r, P, S0);                 // v0 = F0*c0 <2   (4)
-  {
-    Fp<NL> f1;
-    a_load(f1, S.F1);                      // <6
-    fp_add(u, u, f1);                      // F0+F1 <10
-    fp_mulv(w, f1, w, P, S0);              // v1 = F1*c1 <2   (6)
+  fp_neg<1>(u, w, P);                      // p - c1 <=1
+  if (conj) {                              // wave-uniform: the factor is c0 - i*c1
+    r = u;
+    u = w;
+    w = r;
   }
-  fp_mul(u, L3, u, P);                     // (c0+c1)(F0+F1) <2   (20)
-  {
-    Fp<NL> d;
-    fp_sub<2>(d, r, w, P);                 // F0 <4
-    a_store(S.F0, d);
-    fp_add(d, r, w);                       // <4
-    fp_sub<4>(u, u, d, P);                 // F1 <6
-    a_store(S.F1, u);
-  }
+  g_load(r, c0p, cs, ce);                  // c0 <1
+  fp_mul2(u, L3, r, S0, u, P);             // F0 = F0*c0 - F1*c1 <2   (2 + 2)
+  a_store(S.F0, u);
+  fp_mul2(u, L3, w, S0, r, P);             // F1 = F0*c1 + F1*c0 <2
+  a_store(S.F1, u);
 }
 
 // f (canonical) -> two slots
@@ -482,7 +449,7 @@ __device__ __forceinline__ void miller_loop_w(Miller<NL>& S, LFp<NL>* L, const P
     g_store(win_slot<NL>(W, 5), W.s, W.e, r);
     a_load(r, S.Z);
     fp_inv_mont<NL>(zi, r, C->pm2_bits + 1, P, S0);        // 1/Z <1 (0 for a degenerate operand: results are overridden)
-    // X <18, Y <18 here (not <8 / <4): the products below stay within the bound (18 * 2)
+    // X <6, Y <2 here
     win_make_affine<NL>(W, 0, win_slot<NL>(W, 4), win_slot<NL>(W, 5), zi, L, P);
     g_load(r, win_slot<NL>(W, 0), W.s, W.e);
     a_store(S.X, r);

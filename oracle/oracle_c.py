@@ -133,48 +133,103 @@ class Oracle:
         return out.raw
 
 
-def bench_pairings(fx, a_host: bytes, b_host: bytes, gpu_out_host: bytes, seconds: float = 12.0) -> dict:
-    """Time orc_mult on the first pairs of the GPU's own batch, one worker thread
-    per host core over disjoint slices (ctypes releases the GIL), and compare
-    the outputs with the GPU's byte for byte."""
-    orc = Oracle.from_fixture(fx)
-    E = orc.E
-    npairs = len(a_host) // E
+def host_cores() -> dict:
+    """What this process may use of the host: `cores` = min(CPU affinity, cgroup CPU quota rounded up) — the number
+    bench.py reports as cpu_baseline.cores and the number of worker threads the legs below start."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        aff = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 128))
-    # calibrate on one pairing, then size the sample for ~`seconds` of wall time
-    t0 = time.time()
-    first = orc.mult(a_host[:E], b_host[:E])
-    t1 = max(time.time() - t0, 1e-4)
-    per_thread = max(1, min(npairs // cores, int(seconds / t1)))
-    total = per_thread * cores
-    outs = [None] * cores
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(-(-quota // 1))))
+    return {"cores": cores, "affinity": aff, "cgroup_cpus": quota}
 
-    def work(i):
-        lo, hi = i * per_thread * E, (i + 1) * per_thread * E
-        outs[i] = Oracle.from_fixture(fx).mult(a_host[lo:hi], b_host[lo:hi])
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+def _run_threads(work, threads: int) -> float:
+    """work(i) on `threads` worker threads (ctypes releases the GIL inside the C calls); wall seconds."""
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
     t0 = time.time()
     for t in th:
         t.start()
     for t in th:
         t.join()
-    dt = time.time() - t0
+    return time.time() - t0
+
+
+def bench_pairings(fx, a_host: bytes, b_host: bytes, gpu_out_host: bytes, seconds: float = 12.0) -> dict:
+    """Time orc_mult on the first pairs of the GPU's own batch, one worker thread
+    per usable host core over disjoint slices (ctypes releases the GIL), and compare
+    the outputs with the GPU's byte for byte."""
+    orc = Oracle.from_fixture(fx)
+    E = orc.E
+    npairs = len(a_host) // E
+    hc = host_cores()
+    threads = hc["cores"]
+    # calibrate on one pairing, then size the sample for ~`seconds` of wall time
+    t0 = time.time()
+    first = orc.mult(a_host[:E], b_host[:E])
+    t1 = max(time.time() - t0, 1e-4)
+    per_thread = max(1, min(npairs // threads, int(seconds / t1)))
+    total = per_thread * threads
+    outs = [None] * threads
+
+    def work(i):
+        lo, hi = i * per_thread * E, (i + 1) * per_thread * E
+        outs[i] = Oracle.from_fixture(fx).mult(a_host[lo:hi], b_host[lo:hi])
+
+    dt = _run_threads(work, threads)
     got = b"".join(outs)
     ok = got == gpu_out_host[: total * E] and first == gpu_out_host[:E]
-    return {"value": total / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
+    return {"value": total / dt, "unit": "pairings/s", "cores": hc["cores"], "threads": threads, "kind": "port",
             "single_thread_pairings_per_s": 1.0 / t1,
             "sample": f"first {total} pairs of the GPU batch, C restatement oracle/bgn_oracle.c "
                       f"(64-bit limbs, unsigned __int128 CIOS Montgomery, projective Miller loop), "
-                      f"{cores} threads x {per_thread} pairings, {dt:.1f} s",
+                      f"{threads} threads x {per_thread} pairings, {dt:.1f} s",
             "matches_gpu_bit_exact": bool(ok)}
 
 
-def bench_decrypt(fx, ct_host: bytes, want_m, want_status, T: int, max_threads: int = 32) -> dict:
+def bench_slices(fx, n_items: int, call, want: bytes, out_bytes_per_item: int, unit: str, what: str,
+                 seconds: float = 8.0, calibrate: int = 1, max_per_thread: int = 1 << 20) -> dict:
+    """The shape shared by bench.py's Encrypt / EAdd / MultPoly CPU legs: `call(orc, lo, hi)` returns the oracle's
+    output bytes for items [lo, hi) of the GPU's own batch.  One call of `calibrate` items on one thread gives the
+    single-thread rate and sizes the sample (about `seconds` of wall time on every usable core, one thread per
+    core over disjoint slices); every output byte is compared with the GPU's (`want`, the same items)."""
+    hc = host_cores()
+    threads = hc["cores"]
+    orc = Oracle.from_fixture(fx)
+    calibrate = max(1, min(calibrate, n_items))
+    t0 = time.time()
+    first = call(orc, 0, calibrate)
+    t1 = max(time.time() - t0, 1e-5) / calibrate
+    per_thread = max(1, min(n_items // threads, int(seconds / t1), max_per_thread))
+    total = per_thread * threads
+    outs = [None] * threads
+
+    def work(i):
+        outs[i] = call(Oracle.from_fixture(fx), i * per_thread, (i + 1) * per_thread)
+
+    dt = _run_threads(work, threads)
+    got = b"".join(outs)
+    ok = got == want[: total * out_bytes_per_item] and first == want[: calibrate * out_bytes_per_item]
+    return {"value": total / dt, "unit": unit, "cores": hc["cores"], "threads": threads, "kind": "port",
+            "single_thread_per_s": 1.0 / t1,
+            "sample": f"first {total} {what} of the GPU batch, C restatement oracle/bgn_oracle.c, {threads} threads x "
+                      f"{per_thread}, {dt:.1f} s; single-thread figure from {calibrate} of them",
+            "matches_gpu_bit_exact": bool(ok)}
+
+
+def bench_decrypt(fx, ct_host: bytes, want_m, want_status, T: int, max_threads: int = 0) -> dict:
     """bench.py's CPU leg for the second half of BASELINE's metric (BSGS decrypts/s): a bounded sample of the GPU's own
     mixed batch (positives, negatives, out-of-range) decrypted by the reference's algorithm on the host cores.
 
@@ -191,7 +246,8 @@ def bench_decrypt(fx, ct_host: bytes, want_m, want_status, T: int, max_threads: 
     t0 = time.time()
     orc.setup_decryption_gt(int(fx["q1"], 16), T)
     t_setup = time.time() - t0
-    threads = max(1, min(n, max_threads))
+    hc = host_cores()
+    threads = max(1, min(n, max_threads or hc["cores"]))
     per = (n + threads - 1) // threads
     res = [None] * threads
 
@@ -203,17 +259,11 @@ def bench_decrypt(fx, ct_host: bytes, want_m, want_status, T: int, max_threads: 
         l2 = orc.mult(ct_host[lo * E:hi * E])           # makeL2
         res[i] = orc.decrypt(2, l2)
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
-    t0 = time.time()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.time() - t0
+    dt = _run_threads(work, threads)
     m = [v for r in res for v in r[0]]
     st = [v for r in res for v in r[1]]
     ok = m == [int(v) for v in want_m] and st == [int(v) for v in want_status]
-    return {"value": n / dt, "unit": "decrypts/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "decrypts/s", "cores": hc["cores"], "threads": threads, "kind": "port",
             "sample": f"{n} ciphertexts strided over the GPU's mixed batch ({sum(1 for v in want_m if v < 0)} negative, "
                       f"{sum(1 for v in want_status if v)} out of range), lifted to level 2 (one pairing) and decrypted by "
                       f"the reference's level-2 getDL (up to {int(-(-T ** 0.5 // 1))} GT giant steps) in oracle/bgn_oracle.c — cheaper than "

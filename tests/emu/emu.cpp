@@ -7,6 +7,8 @@
 #include <string.h>
 #include <vector>
 
+thread_local int bgn_emu_checks = 0;
+struct EmuChecks { EmuChecks() { bgn_emu_checks = 1; } ~EmuChecks() { bgn_emu_checks = 0; } };
 thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 1, 1}, blockDim = {256, 1, 1};
 
 #include "ops.hpp"
@@ -75,6 +77,7 @@ struct Emu {
     memcpy(out, r.v, 4 * NL);
   }
   static void pairing(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
+    EmuChecks on;
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};
     Fp<NL> re, im;
@@ -85,6 +88,7 @@ struct Emu {
   // e(P, c) through the precomputed line table: build (one lane) + per-ciphertext loop + final exponentiation
   // table column te of a table with limb stride ts (ts = 1, te = 0: the key's own table)
   static void fixed_build(const u32* params, const PairingConsts* C, const u32* p, u32* tab, size_t ts, size_t te) {
+    EmuChecks on;
     fixed_build_lane<NL>(FixedTabRef{tab, ts, te, true}, p, p + NL, 1, 0, lds(), C, (const FpParams<NL>*)params);
   }
   static void fixed_normalize(const u32* params, const PairingConsts* C, u32* tab, size_t steps) {
@@ -93,6 +97,7 @@ struct Emu {
   }
   static void pairing_fixed(const u32* params, const PairingConsts* C, const u32* tab, size_t ts, size_t te,
                             int normalized, const u32* c, u32* out) {
+    EmuChecks on;
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
     PairOperands op{c, c + NL, 1, 0, nullptr, nullptr, 1, 0};
@@ -109,6 +114,7 @@ struct Emu {
     memcpy(out + NL, im.v, 4 * NL);
   }
   static void pairing_w3(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
+    EmuChecks on;
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     LFp<NL>* L = lds();
     PairOperands op{a, a + NL, 1, 0, b, b + NL, 1, 0};

@@ -21,7 +21,7 @@ def build() -> str:
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
                                                 ("fpmont.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
+        subprocess.check_call(["g++", "-O1", "-g", "-rdynamic", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"), "-include", os.path.join(_HERE, "imad.hpp"),
                                os.path.join(_HERE, "emu.cpp"),
                                "-o", _SO])

@@ -29,3 +29,15 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   return old;
 }
 static inline void __syncthreads() {}   // lanes run one after the other; staged-codec kernels are not emulated
+// range checks of the device headers (fpmont.hpp BGN_CHECK) are live in the emulation
+#define BGN_EMU 1
+extern thread_local int bgn_emu_checks;   // emu.cpp: on inside the pairing entry points
+#include <execinfo.h>
+#include <stdio.h>
+#include <stdlib.h>
+static inline void bgn_emu_fail(const char* what, const char* file, int line) {
+  fprintf(stderr, "BGN_CHECK failed: %s (%s:%d)\n", what, file, line);
+  void* bt[24];
+  backtrace_symbols_fd(bt, backtrace(bt, 24), 2);
+  abort();
+}

@@ -89,14 +89,19 @@ def test_add_is_homomorphic_at_2pow20():
     assert not bool(st.any().item()) and bool((m.cpu() == (a - b)[:k]).all().item())
 
 
-def test_config5_multpoly_shape_decrypts_to_convolution():
-    """configs[4] shape on one GPU: 2^12 polynomial pairs of 16x16 base-3 digits in {-1,0,1} (2^20 pairings);
-    DecryptPoly of every product equals the integer convolution (poly_test.go:172-189)."""
+@pytest.mark.parametrize("polys_log2", [12, 14])
+def test_config5_multpoly_shape_decrypts_to_convolution(polys_log2):
+    """configs[4] on one GPU: 2^12 polynomial pairs of 16x16 base-3 digits in {-1,0,1} (2^20 pairings), and the
+    config's stated size, 2^14 pairs = 2^22 coefficient pairs (poly.go:123-156 sixteen thousand times over);
+    DecryptPoly of every product equals the integer convolution (poly_test.go:172-189), the AddPoly of the products
+    with each other (poly.go:171-207) the sum of the convolutions, and — at the stated size — the first, a middle and
+    the last product equal the C oracle's byte for byte (the chunks of whole table rounds and the directly paired
+    remainder all take part)."""
     fx = load_fixture("k1024")
     pk, sk = engine_key(fx)
     pk.SetupDecryption(sk)
     eng, dev = pk.engine, torch.device("cuda")
-    npoly, d = 1 << 12, 16
+    npoly, d = 1 << polys_log2, 16
     g = torch.Generator().manual_seed(22)
     ca = torch.randint(-1, 2, (npoly, d), generator=g, dtype=torch.int64)
     cb = torch.randint(-1, 2, (npoly, d), generator=g, dtype=torch.int64)
@@ -129,6 +134,33 @@ def test_config5_multpoly_shape_decrypts_to_convolution():
         for k in range(d):
             conv[:, i + k] += ca[:, i] * cb[:, k]
     assert bool((m.cpu().view(npoly, 2 * d) == conv).all().item())
+    # AddPoly of product q with product q + npoly/2: coefficient-wise products in GT
+    half = npoly // 2
+    nh = half * 2 * d
+    summ = torch.empty(nh * EB, dtype=torch.uint8, device=dev)
+    eng.add_dev(2, out[: nh * EB], out[nh * EB: 2 * nh * EB], summ, nh)
+    eng.decrypt_dev(2, summ, m[:nh], st[:nh], nh)
+    torch.cuda.synchronize()
+    assert not bool(st[:nh].any().item())
+    assert bool((m[:nh].cpu().view(half, 2 * d) == conv[:half] + conv[half:]).all().item())
+    if polys_log2 >= 14:
+        import threading
+        import oracle_c
+        W = 2 * d * EB
+        picks = [0, npoly // 2 + 77, npoly - 1]
+        got = [None] * len(picks)
+
+        def work(i):
+            q = picks[i]
+            o = oracle_c.Oracle.from_fixture(fx)
+            got[i] = o.poly_mult(1, d, d, ea[q * d * EB:(q + 1) * d * EB].cpu().numpy().tobytes(),
+                                 eb[q * d * EB:(q + 1) * d * EB].cpu().numpy().tobytes())
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(picks))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for q, ref in zip(picks, got):
+            assert out[q * W:(q + 1) * W].cpu().numpy().tobytes() == ref, "MultPoly product %d differs from the C oracle" % q
 
 
 def test_mult_longer_than_one_piece():

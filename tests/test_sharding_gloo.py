@@ -112,6 +112,92 @@ def test_two_rank_sharded_ops_match_single(total):
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == total
 
 
+class TagEngine:
+    """A stand-in behind the Engine's method signatures whose outputs are a cheap, exact function of ONE unit's
+    inputs (the unit is a polynomial for poly_mult, an element otherwise) — enough to pin the index arithmetic of a
+    sharded call at configs[4]'s size, which the real oracle cannot reach in seconds: a slice that starts one unit
+    early or late, or a gather in the wrong order, changes bytes."""
+
+    def __init__(self, elem_bytes):
+        self.elem_bytes = elem_bytes
+
+    def poly_mult(self, npoly, d1, d2, a, b):
+        E = self.elem_bytes
+        pa = np.asarray(a, dtype=np.uint8).reshape(npoly, d1 * E).astype(np.uint32)
+        pb = np.asarray(b, dtype=np.uint8).reshape(npoly, d2 * E).astype(np.uint32)
+        wa = np.arange(1, d1 * E + 1, dtype=np.uint32)
+        wb = np.arange(3, 3 + d2 * E, dtype=np.uint32)
+        tag = (pa * wa).sum(axis=1) * np.uint32(2654435761) + (pb * wb).sum(axis=1)      # one word per polynomial
+        out = np.empty((npoly, (d1 + d2) * E), dtype=np.uint8)
+        k = np.arange((d1 + d2) * E, dtype=np.uint32)
+        out[:] = ((tag[:, None] >> (k[None, :] % 24)) + k[None, :]).astype(np.uint8)
+        out[:, : d1 * E] ^= pa.astype(np.uint8)                                          # and every input byte
+        out[:, d1 * E: (d1 + d2) * E] ^= pb.astype(np.uint8)
+        return out.reshape(-1, E)
+
+    def mult(self, a, b):
+        n = np.asarray(a).size // self.elem_bytes
+        return self.poly_mult(n, 1, 1, a, b).reshape(n, 2, self.elem_bytes)[:, 0, :]
+
+
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bgn_amd.sharding import ShardedOps, shard_range
+    ok = True
+    # (1) the real oracle behind the sharder at world 8: Mult, Add, MultPoly by polynomial, the packed Decrypt gather,
+    #     with fewer units than ranks in one case (empty shards) and a ragged total in the other
+    fx = load_fixture("toy64")
+    for total in (5, 37):
+        ok &= sharded_checks(lambda: OracleEngine(fx), fx, total, world, rank, dist)
+    # (2) configs[4]'s index arithmetic: 2^14 polynomials of 16x16 coefficients split by polynomial over 8 ranks
+    #     (2048 each: the equal-shard all-gather), and 2^14 + 5 (ragged: five ranks own 2049, the padded gather)
+    E, d = 16, 16
+    tag = TagEngine(E)
+    ranges = {}
+    for npoly in (1 << 14, (1 << 14) + 5):
+        g = torch.Generator().manual_seed(npoly)
+        a = torch.randint(0, 256, (npoly * d * E,), dtype=torch.uint8, generator=g)
+        b = torch.randint(0, 256, (npoly * d * E,), dtype=torch.uint8, generator=g)
+        ops = ShardedOps(tag, E, world, rank, dist)
+        got = ops.poly_mult(npoly, d, d, a, b)
+        want = tag.poly_mult(npoly, d, d, a.numpy(), b.numpy()).reshape(-1)
+        ok &= got.numel() == npoly * 2 * d * E and bool((got.numpy() == want).all())
+        lo, hi = shard_range(npoly, world, rank)
+        # this rank's slice of the coefficient-pair index space is whole polynomials: [lo*d*d, hi*d*d)
+        ok &= (hi - lo) in (npoly // world, npoly // world + 1)
+        ranges[npoly] = (lo, hi)
+    q.put((rank, bool(ok), ranges))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_sharding_configs4_index_arithmetic():
+    """World 8 over gloo (CPU): what the driver's 8-GPU run will do to configs[4] — 2^14 MultPoly instances split by
+    polynomial, and the ragged 2^14 + 5 — plus the oracle-backed checks of every sharded operation at world 8."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    for npoly in (1 << 14, (1 << 14) + 5):
+        rs = sorted(r[npoly] for _, _, r in res)
+        assert rs[0][0] == 0 and rs[-1][1] == npoly and all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+        assert sum(h - l for l, h in rs) * 256 == npoly * 256            # every coefficient pair owned exactly once
+
+
 def test_shard_range_properties():
     import ctypes as C
     from bgn_amd import _lib

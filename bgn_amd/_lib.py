@@ -87,6 +87,7 @@ PROTOTYPES = {
     "bgn_mdecrypt_batch_dev": (C.c_int, [_ctx, _sz, C.c_int, _u8p, _u8p, _u8p, C.c_int, C.c_void_p]),
     "bgn_mpoly_mult_batch_dev": (C.c_int, [_ctx, _sz, _sz, _sz, _u8p, _u8p, _u8p, C.c_int, C.c_void_p]),
     "bgn_field_ops_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p, _u8p]),
+    "bgn_field_sums_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p]),
     "bgn_host_alloc": (C.c_void_p, [_sz]),
     "bgn_host_free": (None, [C.c_void_p]),
     "bgn_last_kernel_ms": (C.c_double, [_ctx]),

@@ -291,6 +291,14 @@ class Engine:
         check(self._lib.bgn_field_ops_batch(self._h, len(A), _ptr(A), _ptr(o1), _ptr(o2)), "bgn_field_ops_batch")
         return o1, o2
 
+    def field_sums(self, xy: BytesLike):
+        """Diagnostics: (x^2 + y^2) || (x*y + y^2), each as one sum of two products with a shared reduction
+        (bgn_field_sums_batch)."""
+        A = _as_u8(xy, self.elem_bytes)
+        o = self._out(len(A))
+        check(self._lib.bgn_field_sums_batch(self._h, len(A), _ptr(A), _ptr(o)), "bgn_field_sums_batch")
+        return o
+
     def memory_bytes(self) -> int:
         """Device memory the context holds now (tables of the key + workspace)."""
         return int(self._lib.bgn_ctx_memory_bytes(self._h))

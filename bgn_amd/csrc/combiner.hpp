@@ -71,6 +71,10 @@ struct CombinerBackend {
   std::function<void(void*)> dev_free;
   std::function<int(void*, const void*, size_t, void*)> upload;     // (dev, host, bytes, stream), asynchronous
   std::function<int(void*, const void*, size_t, void*)> download;   // (host, dev, bytes, stream), asynchronous
+  // optional: zero `bytes` of device memory (synchronous).  The staging arrays carry plaintexts, randomness and
+  // Decrypt's results between calls: they are zeroed before they go back to an allocator and when the context's
+  // secret changes (Combiner::wipe_stage); dev_free should itself wipe (the engine passes ctx_wipe_free).
+  std::function<int(void*, size_t)> dev_zero;
 };
 
 struct Combiner {
@@ -79,6 +83,9 @@ struct Combiner {
   typedef std::function<int(const CombineKey&, size_t, uint8_t* const*, uint8_t* const*, void*)> Launch;
   Launch launch;
   std::function<const char*()> error_text;
+  // optional: put `text` back as the calling thread's last error.  A failing group leaves its message in the
+  // LEADER's thread-local slot; a leader whose own request succeeded gets its previous text back.
+  std::function<void(const char*)> restore_error;
   CombinerBackend be;
 
   std::mutex mu;
@@ -95,9 +102,33 @@ struct Combiner {
   size_t stage_cap = 0;
 
   ~Combiner() {
+    if (stream) (void)be.stream_sync(stream);
+    release_stage();
     if (stream) be.stream_destroy(stream);
-    if (h_stage) be.host_free(h_stage);
-    if (d_stage) be.dev_free(d_stage);
+  }
+
+  // zero both staging arrays (the caller holds no round in flight: set_secret / destroy run under the context's lock
+  // with the device synchronised; a leader that regrows them has just synchronised its stream)
+  static void secure_zero(void* p, size_t n) {
+    volatile uint8_t* v = (volatile uint8_t*)p;
+    for (size_t i = 0; i < n; ++i) v[i] = 0;
+  }
+  void wipe_stage() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (h_stage) secure_zero(h_stage, stage_cap);
+    if (d_stage && be.dev_zero) (void)be.dev_zero(d_stage, stage_cap);
+  }
+  void release_stage() {
+    if (h_stage) {
+      secure_zero(h_stage, stage_cap);
+      be.host_free(h_stage);
+    }
+    if (d_stage) {
+      if (be.dev_zero) (void)be.dev_zero(d_stage, stage_cap);
+      be.dev_free(d_stage);
+    }
+    h_stage = d_stage = nullptr;
+    stage_cap = 0;
   }
 
   struct Group {
@@ -117,13 +148,11 @@ struct Combiner {
     }
     if (bytes <= stage_cap) return 0;
     if (stream) (void)be.stream_sync(stream);
-    if (h_stage) be.host_free(h_stage);
-    if (d_stage) be.dev_free(d_stage);
-    h_stage = d_stage = nullptr;
-    stage_cap = 0;
+    release_stage();
     const size_t want = align_up(bytes + bytes / 2 + 65536);
     if (be.host_alloc((void**)&h_stage, want) != 0 || be.dev_alloc((void**)&d_stage, want) != 0) {
       if (h_stage) be.host_free(h_stage);
+      if (d_stage) be.dev_free(d_stage);
       h_stage = nullptr;
       d_stage = nullptr;
       *err = "combiner: staging buffers: device memory or the context's memory budget exhausted";
@@ -249,43 +278,77 @@ struct Combiner {
         std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
         lk.lock();
       }
+      // Everything between taking requests off the queue and handing them back runs under a guard: an exception in
+      // here (std::bad_alloc from the group vectors or a message copy, anything a backend callback throws) must not
+      // leave leader_active set — every later call on the context would wait for a round nobody runs — nor a taken
+      // request without an answer.
       std::vector<Group> groups;
-      for (auto it = queue.begin(); it != queue.end();) {
-        CombineReq* r = *it;
-        Group* g = nullptr;
-        for (Group& x : groups)
-          if (x.key == r->key) g = &x;
-        if (g && g->total + r->count > max_batch) {      // this kind is full for this round: the request waits for the next
-          ++it;
-          continue;
+      std::vector<CombineReq*> taken;       // what left the queue, in case the groups themselves are lost
+      double round_us = 0;
+      bool failed = false;
+      std::string saved_error;
+      try {
+        taken.reserve(queue.size());
+        for (auto it = queue.begin(); it != queue.end();) {
+          CombineReq* r = *it;
+          Group* g = nullptr;
+          for (Group& x : groups)
+            if (x.key == r->key) g = &x;
+          if (g && g->total + r->count > max_batch) {      // this kind is full for this round: the request waits for the next
+            ++it;
+            continue;
+          }
+          if (!g) {
+            groups.emplace_back();
+            g = &groups.back();
+            g->key = r->key;
+          }
+          g->reqs.push_back(r);
+          g->total += r->count;
+          taken.push_back(r);               // (reserved above: cannot throw)
+          it = queue.erase(it);
         }
-        if (!g) {
-          groups.emplace_back();
-          g = &groups.back();
-          g->key = r->key;
+        stats.rounds++;
+        stats.groups += groups.size();
+        for (const Group& g : groups) {
+          stats.elements += g.total;
+          if (g.total > stats.max_group) stats.max_group = g.total;
         }
-        g->reqs.push_back(r);
-        g->total += r->count;
-        it = queue.erase(it);
+        if (restore_error && error_text) {
+          const char* t = error_text();
+          saved_error = t ? t : "";
+        }
+        lk.unlock();
+        const auto t_round = std::chrono::steady_clock::now();
+        try {
+          run_round(groups);
+        } catch (...) {
+          failed = true;
+        }
+        round_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_round).count();
+        lk.lock();
+      } catch (...) {
+        failed = true;                      // thrown while the lock was held (grouping): lk is still locked
       }
-      stats.rounds++;
-      stats.groups += groups.size();
-      for (const Group& g : groups) {
-        stats.elements += g.total;
-        if (g.total > stats.max_group) stats.max_group = g.total;
+      if (failed) {
+        // a request that was pushed into a group but not yet recorded cannot exist (taken is filled in the same
+        // iteration, without allocating); one that is still queued stays queued for the next leader
+        for (CombineReq* r : taken)
+          if (!r->done) {
+            r->rc = -6;                     // BGN_E_NOMEM
+            try {
+              r->err = "combiner: the round could not be run (out of memory or a failing runtime call)";
+            } catch (...) {
+            }
+          }
       }
-      lk.unlock();
-      const auto t_round = std::chrono::steady_clock::now();
-      run_round(groups);
-      const double round_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_round).count();
-      lk.lock();
       size_t released = 0;
-      for (Group& g : groups)
-        for (CombineReq* r : g.reqs) {
-          r->done = true;
-          released++;
-          if (r != &req) r->cv.notify_one();
-        }
+      for (CombineReq* r : taken) {
+        r->done = true;
+        released++;
+        if (r != &req) r->cv.notify_one();
+      }
+      if (restore_error && req.done && req.rc == 0) restore_error(saved_error.c_str());
       last_round_reqs = released;
       last_round_us = round_us;
       pushed_since_round_end = 0;

@@ -98,9 +98,10 @@ struct HostPipeState {
 // Crossovers between the three pairing-kernel families, in elements per call; index = mode (0 Mult, 1 makeL2,
 // 2 Decrypt's lift, 3 Decrypt's power).  -1: the constants of the committed sweeps (coop_limit / quad_limit below);
 // bgn_ctx_calibrate replaces them by what two timed probes per kernel say on THIS device.
+// (atomics: bgn_ctx_calibrate publishes them while other threads' calls read them in their dispatch)
 struct Crossovers {
-  int64_t coop[4] = {-1, -1, -1, -1};
-  int64_t quad[4] = {-1, -1, -1, -1};
+  std::atomic<int64_t> coop[4] = {{-1}, {-1}, {-1}, {-1}};
+  std::atomic<int64_t> quad[4] = {{-1}, {-1}, {-1}, {-1}};
 };
 
 struct bgn_ctx {
@@ -200,7 +201,14 @@ struct bgn_ctx {
 
 namespace {
 
-inline int64_t opt(const bgn_ctx* c, Options::V Options::*f) { return (c->opt.*f).load(std::memory_order_relaxed); }
+// bgn_ctx_calibrate forces one kernel family per probe: it does so through an override that only ITS thread sees (its
+// probes are `_dev` calls made from that thread), never by rewriting the context's options under other callers.
+thread_local const bgn_ctx* g_opt_override_ctx = nullptr;
+thread_local const Options* g_opt_override = nullptr;
+inline int64_t opt(const bgn_ctx* c, Options::V Options::*f) {
+  if (g_opt_override_ctx == c && g_opt_override) return (g_opt_override->*f).load(std::memory_order_relaxed);
+  return (c->opt.*f).load(std::memory_order_relaxed);
+}
 
 // Device memory of a context goes through these two: bgn_ctx_memory_bytes reports what it holds, and a budget
 // (bgn_ctx_set_memory_budget) is a hard cap — an allocation that would exceed it fails like an exhausted device,
@@ -292,6 +300,30 @@ void release_poly_tables(bgn_ctx* c) {
   c->poly_tab_bytes = 0;
 }
 
+// What a context keeps between calls (include/bgn_amd.h "Device memory"): by default a quarter of the device's
+// memory.  The per-key tables are sized well inside it (52.8 GB for a 1024-bit key with T = 2^40); MultPoly's line
+// tables — scratch of one call, 38 GB for a whole round of 65536 coefficients — stay with the context for the next
+// call only while the total remains under the cap, and go back to the allocator when the call ends otherwise
+// (a fresh hipMalloc of 38 GB costs 1.2 - 2.1 s on MI355X, profiles/r05_alloc_cost.csv: a host that runs large
+// MultPoly calls on a context that also holds decryption tables raises option resident_cap_mb).
+size_t resident_cap(bgn_ctx* c) {
+  const int64_t v = opt(c, &Options::resident_cap_mb);
+  if (v < 0) return ~(size_t)0;
+  if (v > 0) return (size_t)v << 20;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return ~(size_t)0;
+  return tot / 4;
+}
+void trim_to_resident_cap(bgn_ctx* c) {
+  if (!c->poly_tab) return;
+  size_t held;
+  {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    held = c->held;
+  }
+  if (held > resident_cap(c)) release_poly_tables(c);
+}
+
 // Divide every line of a per-key table by its c (fixedpair.hpp fixed_normalize_lane): one product less per
 // Miller step for every ciphertext paired with the key.  BGN_FIXED_NORMALIZE=0 keeps (a, b, c).
 bool fixed_normalize_enabled(const bgn_ctx* c) { return opt(c, &Options::fixed_normalize) != 0; }
@@ -313,7 +345,8 @@ int ensure_arena(bgn_ctx* c, size_t bytes) {
   if (bytes <= c->arena_bytes) return BGN_OK;
   if (c->arena) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(ctx_free(c, c->arena));
+    // (wiped: with a secret installed the workspace has held ct^sk values and Decrypt's intermediate powers)
+    HIP_TRY(c->have_secret ? ctx_wipe_free(c, c->arena) : ctx_free(c, c->arena));
     c->arena = nullptr;
     c->arena_bytes = 0;
   }
@@ -425,10 +458,10 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  delete c->comb;
+  delete c->comb;                       // (its staging arrays are zeroed before they are freed)
   c->comb = nullptr;
   c->pipe.release();
-  if (c->arena) (void)ctx_free(c, c->arena);
+  if (c->arena) (void)(c->have_secret ? ctx_wipe_free(c, c->arena) : ctx_free(c, c->arena));
   if (c->chain_ws) (void)ctx_free(c, c->chain_ws);
   if (c->mul_ws) (void)ctx_free(c, c->mul_ws);
   if (c->poly_tab) (void)ctx_free(c, c->poly_tab);
@@ -655,6 +688,13 @@ int bgn_ctx_set_option(bgn_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return fail(BGN_E_ARG, "null argument");
   const OptionDesc* d = option_find(name);
   if (!d) return fail(BGN_E_ARG, "unknown option '%s'", name);
+  // options that shape a table are read when that table is built; once it exists a new value would change nothing
+  // and is refused instead of being accepted silently
+  if (d->field == &Options::miller_window || d->field == &Options::fixed_normalize)
+    return fail(BGN_E_STATE, "option '%s' is read by bgn_ctx_create only: set BGN_%s in the environment before the context is created",
+                name, d->field == &Options::miller_window ? "MILLER_WINDOW" : "FIXED_NORMALIZE");
+  if ((d->field == &Options::fixed_window_bits || d->field == &Options::fixed_window_bits_q) && c->d_tabP)
+    return fail(BGN_E_STATE, "option '%s': the fixed-base window tables of this context are built already", name);
   (c->opt.*(d->field)).store(value, std::memory_order_relaxed);
   if (d->field == &Options::memory_budget_mb) return bgn_ctx_set_memory_budget(c, value > 0 ? (uint64_t)value << 20 : 0);
   return BGN_OK;
@@ -671,7 +711,9 @@ int bgn_ctx_get_option(const bgn_ctx* c, const char* name, int64_t* value) {
 int bgn_ctx_reset_options(bgn_ctx* c) {
   if (!c) return fail(BGN_E_ARG, "null context");
   options_copy(c->opt, c->opt_initial);
-  return BGN_OK;
+  // options with a side effect are re-applied, not just restored: the budget in force is the restored one
+  const int64_t mb = c->opt.memory_budget_mb.load(std::memory_order_relaxed);
+  return bgn_ctx_set_memory_budget(c, mb > 0 ? (uint64_t)mb << 20 : 0);
 }
 
 const char* bgn_option_name(size_t index) {
@@ -707,6 +749,15 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   (void)ctx_wipe_free(c, c->d_gt);                   // g = e(P,P)^sk and gamma^-1 of the previous secret
   c->d_gt = nullptr;
   if (c->arena) (void)hipMemset(c->arena, 0, c->arena_bytes);   // the workspace held ct^sk values of earlier Decrypts
+  {
+    // ... and the combiner's staging arrays the plaintexts, randomness and results of earlier small calls
+    Combiner* cb = nullptr;
+    {
+      std::lock_guard<std::mutex> lk2(c->mem_mu);
+      cb = c->comb;
+    }
+    if (cb) cb->wipe_stage();
+  }
   HIP_TRY(ctx_malloc(c, (void**)&c->d_sk, q1_len));
   HIP_TRY(hipMemcpy(c->d_sk, q1_be, q1_len, hipMemcpyHostToDevice));
   c->sk_len = q1_len;
@@ -738,13 +789,14 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if ((double)B < sq) B++;
   const uint64_t Mmax = B * B + B + 2;
   uint64_t S = 2;
-  // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Default: at most 2^31 steps
-  // (69 GB; the slot's value field holds j <= 2^31) within a quarter of the device's total memory — on a 288-GB
-  // MI355X that IS 2^31: profiles/r04_decrypt_vs_table.csv has decrypts/s and set-up time for 2^24 .. 2^31 entries at
-  // T = 2^40 (the walk is (T / 2S) products per ciphertext beside a lift of ~3.8 k products, so every halving of the
-  // table below 2^31 is paid in Decrypt's rate).  Free memory — under a budget, what the budget leaves — only clamps.
-  // Option bsgs_max_log2 overrides (4..31).  The build takes 0.73 s at 2^31 entries (two products per entry).
-  int cap_log2 = 31;
+  // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Default since round 5: at most
+  // 2^30 steps (34 GB) — the knee of profiles/r04_decrypt_vs_table.csv (T = 2^40, 2^20 ciphertexts: 2^31 entries /
+  // 69 GB 1.73e6 decrypts/s, 2^30 / 34 GB 1.59e6 (-8 %), 2^29 / 17 GB 1.36e6 (-21 %), 2^28 1.07e6: the walk is (T / 2S)
+  // products per ciphertext beside a lift of ~3.8 k, so the last doubling buys 8 % for 34 GB and the one before it
+  // 17 % for 17 GB) — and never more than a quarter of the device's total memory.  Free memory — under a budget,
+  // what the budget leaves — only clamps.  Option bsgs_max_log2 overrides (4..31: 31 is round 4's default; the
+  // slot's value field holds j <= 2^31).  The build takes 0.56 s at 2^30 entries (two products per entry).
+  int cap_log2 = 30;
   {
     // (the table this call replaces counts as free)
     const size_t old_table = c->d_table ? (size_t)c->bsgs_slots * sizeof(BsgsSlot) : 0;
@@ -1354,10 +1406,11 @@ int fixed_window_bits(bgn_ctx* c) {
 // of it is used by every encryption: 20-bit windows (52 additions instead of 64 at a 1024-bit key) for 17 GB
 // of HBM.  BGN_FIXED_WINDOW_BITS_Q overrides (8..22); never narrower than P's table.
 int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
-  // (22-bit windows: 47 windows instead of 52 at a 1024-bit key, 60 GB; measured +7 % on Encrypt over 20 bits,
-  // profiles/r04_encrypt_vs_window.csv — the default wherever a quarter of the device's total memory holds the table,
-  // which on a 288-GB MI355X it does; free memory or a budget only clamp, by the loop below)
-  int wbits = wbits_p == 16 ? 22 : wbits_p;
+  // (default since round 5: 20 bits, 16 GB at a 1024-bit key — the knee of profiles/r04_encrypt_vs_window.csv:
+  // 22 bits / 58 GB 1.83e7 encrypts/s, 20 bits / 16 GB 1.72e7 (-6 %), 18 bits / 4.4 GB 1.62e7, 16 bits / 1.2 GB
+  // 1.53e7; the last two bits cost 42 GB for 6 %.  Option fixed_window_bits_q = 22 is round 4's default; free memory
+  // or a budget only clamp, by the loop below)
+  int wbits = wbits_p == 16 ? 20 : wbits_p;
   {
     const int64_t v = opt(c, &Options::fixed_window_bits_q);
     if (v >= 8 && v <= 22) wbits = (int)v;
@@ -2787,6 +2840,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   kt->encode(s, nullptr, R[0].c0, R[0].c1, R[0].stride, c->L, npoly * (d1 + d2), out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));            // the scratch arrays are released on return
+  trim_to_resident_cap(c);                     // ... and the line tables, when keeping them would exceed the resident cap
   return BGN_OK;
 }
 
@@ -3065,6 +3119,7 @@ Combiner* get_combiner(bgn_ctx* c) {
       return comb_launch(c, k, n, in, out, (hipStream_t)s);
     };
     cb->error_text = [] { return bgn_last_error(); };
+    cb->restore_error = [](const char* t) { g_err = t ? t : ""; };
     CombinerBackend& be = cb->be;
     be.bind = [c] { return hipSetDevice(c->device) == hipSuccess ? 0 : -1; };
     be.stream_create = [](void** s) { return hipStreamCreateWithFlags((hipStream_t*)s, hipStreamNonBlocking) == hipSuccess ? 0 : -1; };
@@ -3081,7 +3136,8 @@ Combiner* get_combiner(bgn_ctx* c) {
       (void)hipGetLastError();
       return -1;
     };
-    be.dev_free = [c](void* p) { (void)ctx_free(c, p); };
+    be.dev_free = [c](void* p) { (void)ctx_wipe_free(c, p); };
+    be.dev_zero = [](void* p, size_t b) { return hipMemset(p, 0, b) == hipSuccess && hipDeviceSynchronize() == hipSuccess ? 0 : -1; };
     be.upload = [](void* d, const void* h, size_t b, void* s) {
       return hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, (hipStream_t)s) == hipSuccess ? 0 : -1;
     };
@@ -3131,16 +3187,24 @@ int combine_call(bgn_ctx* c, int op, int level, size_t count, CombArr in0, CombA
 // SIMD at 4096 pairs) and is linear above it, the lane kernel costs one pairing's latency for anything up to 65536.
 // Two probes per linear kernel and one of the lane kernel give the two crossovers of an operation.
 namespace {
-struct SavedOptions {
-  bgn_ctx* c;
-  Options keep;
-  explicit SavedOptions(bgn_ctx* c_) : c(c_) { options_copy(keep, c->opt); }
-  ~SavedOptions() { options_copy(c->opt, keep); }
+// A private copy of the context's options that the calling thread's dispatch reads instead (opt()), for the
+// lifetime of the object; the context's own options — what every other thread sees — are not touched.
+struct OptionOverride {
+  Options mine;
+  explicit OptionOverride(bgn_ctx* c) {
+    options_copy(mine, c->opt);
+    g_opt_override = &mine;
+    g_opt_override_ctx = c;
+  }
+  ~OptionOverride() {
+    g_opt_override = nullptr;
+    g_opt_override_ctx = nullptr;
+  }
 };
 
-void force_family(bgn_ctx* c, int mode, int family /* 0 coop, 1 quad, 2 lane */) {
+void force_family(Options& o, int mode, int family /* 0 coop, 1 quad, 2 lane */) {
   const int64_t big = (int64_t)1 << 40;
-  auto set = [&](Options::V Options::*f, int64_t v) { (c->opt.*f).store(v, std::memory_order_relaxed); };
+  auto set = [&](Options::V Options::*f, int64_t v) { (o.*f).store(v, std::memory_order_relaxed); };
   set(&Options::quad_min, 0);
   if (mode == 0) {
     set(&Options::coop_max, family == 0 ? big : 0);
@@ -3187,8 +3251,9 @@ int bgn_ctx_calibrate(bgn_ctx* c, int64_t out[8]) {
     return bgn_decrypt_batch_dev(c, n, 1, a, (int64_t*)dm.p, (uint8_t*)dst.p, s);
   };
   int err = BGN_OK;
+  OptionOverride forced(c);
   auto time_ms = [&](int mode, int family, size_t n) -> double {
-    force_family(c, mode, family);
+    force_family(forced.mine, mode, family);
     double best = 1e30;
     for (int rep = 0; rep < 3 && !err; ++rep) {           // the first run also grows the workspace
       const auto t0 = std::chrono::steady_clock::now();
@@ -3199,16 +3264,15 @@ int bgn_ctx_calibrate(bgn_ctx* c, int64_t out[8]) {
     }
     return best;
   };
-  Crossovers xo;
+  int64_t xo_coop[4] = {-1, -1, -1, -1}, xo_quad[4] = {-1, -1, -1, -1};
   {
-    SavedOptions keep(c);
     const int modes = (c->have_secret && c->have_tables) ? 3 : 2;
     for (int mode = 0; mode < modes && !err; ++mode) {
       const double c1 = time_ms(mode, 0, 256), c2 = time_ms(mode, 0, 1024);
       const double q1 = time_ms(mode, 1, 4096), q2 = time_ms(mode, 1, 16384), q3 = time_ms(mode, 1, 32768);
       const double ln = time_ms(mode, 2, 4096);
       if (err) break;
-      if (keep.keep.test_calibrate_trace.load() != 0)
+      if (c->opt.test_calibrate_trace.load() != 0)
         fprintf(stderr, "[calibrate] mode %d: coop 256 / 1024: %.2f / %.2f ms; quad 4096 / 16384 / 32768: %.2f / %.2f / %.2f ms; lane 4096: %.2f ms\n",
                 mode, c1, c2, q1, q2, q3, ln);
       const double sc = (c2 - c1) / 768.0, ic = c1 - sc * 256.0;               // cooperative: ic + sc * n
@@ -3219,23 +3283,25 @@ int bgn_ctx_calibrate(bgn_ctx* c, int64_t out[8]) {
       if (xc > 4096) xc = 4096;                    // the floor q1 was measured at 4096 pairs
       if (xq < xc) xq = xc;
       if (xq > 65536) xq = 65536;                  // from 65537 on the batch is cut into rounds anyway
-      xo.coop[mode] = xc;
-      xo.quad[mode] = xq;
+      xo_coop[mode] = xc;
+      xo_quad[mode] = xq;
       if (mode == 2) {
-        xo.coop[3] = xc;
-        xo.quad[3] = xq;
+        xo_coop[3] = xc;
+        xo_quad[3] = xq;
       }
     }
   }
   (void)hipStreamSynchronize(s);
   (void)hipStreamDestroy(s);
   if (err) return err;
-  c->xo = xo;
-  if (out)
-    for (int i = 0; i < 4; ++i) {
-      out[i] = xo.coop[i];
-      out[4 + i] = xo.quad[i];
+  for (int i = 0; i < 4; ++i) {
+    c->xo.coop[i].store(xo_coop[i], std::memory_order_relaxed);
+    c->xo.quad[i].store(xo_quad[i], std::memory_order_relaxed);
+    if (out) {
+      out[i] = xo_coop[i];
+      out[4 + i] = xo_quad[i];
     }
+  }
   return BGN_OK;
 }
 
@@ -3258,8 +3324,21 @@ int bgn_ctx_combiner_stats(bgn_ctx* c, uint64_t out[5]) {
 
 // Field arithmetic on its own, for the parity tests: xy holds count elements x||y
 // (L bytes each, big-endian residues below p); prod_inv[e] = x*y || x^-1 (0 for x = 0), sqr[e] = x^2 || y^2.
+namespace {
+int field_ops_common(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* prod_inv, uint8_t* sqr, uint8_t* sums);
+}
 int bgn_field_ops_batch(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* prod_inv, uint8_t* sqr) {
   if (!c || (count && (!xy || !prod_inv || !sqr))) return fail(BGN_E_ARG, "null argument");
+  return field_ops_common(c, count, xy, prod_inv, sqr, nullptr);
+}
+// sums[e] = (x^2 + y^2) || (x*y + y^2), each computed as ONE sum of two products with a shared Montgomery reduction
+// (fpmont.hpp fp_mul2: what the Miller steps' a*b +- c*d run on since round 5).
+int bgn_field_sums_batch(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* sums) {
+  if (!c || (count && (!xy || !sums))) return fail(BGN_E_ARG, "null argument");
+  return field_ops_common(c, count, xy, nullptr, nullptr, sums);
+}
+namespace {
+int field_ops_common(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* prod_inv, uint8_t* sqr, uint8_t* sums) {
   if (!count) return BGN_OK;
   if (count > ((size_t)1 << 24)) return fail(BGN_E_ARG, "at most 2^24 elements");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -3267,30 +3346,42 @@ int bgn_field_ops_batch(bgn_ctx* c, size_t count, const uint8_t* xy, uint8_t* pr
   StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
   const size_t st = round_up(count, 64), eb = (size_t)2 * c->L * count;
-  SoA2 A{}, B{};
-  uint8_t *din = nullptr, *d1 = nullptr, *d2 = nullptr;
+  SoA2 A{}, B{}, S{};
+  uint8_t *din = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     A = w.gt(st);
     B = w.gt(st);
+    S = w.gt(st);
     din = (uint8_t*)w.cv.take(eb);
     d1 = (uint8_t*)w.cv.take(eb);
     d2 = (uint8_t*)w.cv.take(eb);
+    d3 = (uint8_t*)w.cv.take(eb);
     if (!pass) {
       int rc = ensure_arena(c, w.cv.off);
       if (rc) return rc;
     }
   }
+  if (!sums) S = SoA2{};
   HIP_TRY(hipMemcpyAsync(din, xy, eb, hipMemcpyHostToDevice, s));
-  c->kt->field_ops(s, c->d_params, din, c->L, count, c->p_bits + 1, A, B);
-  c->kt->encode(s, nullptr, A.c0, A.c1, A.stride, c->L, count, d1);
-  c->kt->encode(s, nullptr, B.c0, B.c1, B.stride, c->L, count, d2);
-  HIP_TRY(hipMemcpyAsync(prod_inv, d1, eb, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(sqr, d2, eb, hipMemcpyDeviceToHost, s));
+  c->kt->field_ops(s, c->d_params, din, c->L, count, c->p_bits + 1, A, B, S);
+  if (prod_inv) {
+    c->kt->encode(s, nullptr, A.c0, A.c1, A.stride, c->L, count, d1);
+    HIP_TRY(hipMemcpyAsync(prod_inv, d1, eb, hipMemcpyDeviceToHost, s));
+  }
+  if (sqr) {
+    c->kt->encode(s, nullptr, B.c0, B.c1, B.stride, c->L, count, d2);
+    HIP_TRY(hipMemcpyAsync(sqr, d2, eb, hipMemcpyDeviceToHost, s));
+  }
+  if (sums) {
+    c->kt->encode(s, nullptr, S.c0, S.c1, S.stride, c->L, count, d3);
+    HIP_TRY(hipMemcpyAsync(sums, d3, eb, hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   return BGN_OK;
 }
+}  // namespace
 
 // Page-locked host memory for the arrays of the host-buffer entry points: copies from and to it run at the full
 // PCIe rate (a pageable Go slice is staged by the runtime at roughly half of it).  bgn_host_free releases it.

@@ -55,7 +55,8 @@ struct FixedTabRef {
   bool live;
 };
 
-// V <- 2V and the tangent's coefficients
+// V <- 2V and the tangent's coefficients.  State X <8, Y <2, Z <4; the sums M = 3X^2 + ZZ^2 and
+// Y3 = M*(S - X3) - 8*YY^2 take one reduction each (fp_mul2, see miller_double): 12 multiplications, 10 reductions.
 template <int NL>
 __device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, const FixedTabRef& tr, size_t s, LFp<NL>* L,
                                                    const FpParams<NL>* __restrict__ P) {
@@ -64,61 +65,54 @@ __device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, const Fixe
   LFp<NL>* L2 = L + 2;
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
-  a_load(r, S.Z);
-  fp_mulv(r, r, r, P, S0);                 // ZZ <2
+  a_load(r, S.Z);                          // <4
+  fp_sqrv(r, r, P, S0);                    // ZZ <2
   l_store(L1, r);                          // L1 = ZZ
-  fp_mul(w, L1, r, P);                     // ZZ^2 <2
-  a_load(r, S.X);
-  fp_mulv(u, r, r, P, S0);                 // XX <2
-  fp_dbl(r, u);
-  fp_add(r, r, u);
-  fp_add(r, r, w);                         // M <8
-  l_store(L2, r);                          // L2 = M
-  a_load(r, S.Y);
-  fp_mulv(u, r, r, P, S0);                 // YY <2
-  a_store(S.U, u);                         // U = YY
-  a_load(r, S.X);
-  fp_mulv(r, r, u, P, S0);                 // X*YY <2
-  fp_dbl(r, r);
-  fp_dbl(r, r);                            // S <8
-  a_store(S.T, r);                         // T = S
-  // coefficients need the OLD X and the new Z3
-  a_load(r, S.Y);
-  a_load(u, S.Z);
-  fp_mulv(r, r, u, P, S0);                 // YZ <2
-  fp_dbl(r, r);                            // Z3 <4
-  a_store(S.Z, r);
+  a_load(u, S.X);                          // <8
+  l_store(S0, u);
+  fp_lin1<3, 0>(u, u, P);                  // 3X <24
+  fp_mul2(w, S0, u, L1, r, P);             // M = X*3X + ZZ*ZZ <2   (196)
+  l_store(L2, w);                          // L2 = M
+  a_load(r, S.Y);                          // <2
+  a_load(u, S.Z);                          // <4
+  l_store(S0, r);                          // S0 = Y
+  fp_mul(u, S0, u, P);                     // YZ <2
+  fp_dbl(u, u);                            // Z3 <4
+  a_store(S.Z, u);
+  fp_sqr(w, S0, r, P);                     // YY <2
+  fp_dbl(w, w);                            // 2YY <4
+  a_store(S.U, w);                         // U = 2YY
+  fp_lin1<-2, 8>(r, w, P);                 // 8p - 4YY <=8
+  l_store(L3, r);                          // L3 = 8p - 4YY
+  // coefficients need the OLD X and the new Z3 (u)
   {
     Fp<NL> ca, cb, cc;
-    l_load(u, L1);                         // ZZ
-    fp_mul(ca, L2, u, P);                  // a = M*ZZ <2
-    fp_mul(cc, L1, r, P);                  // c = Z3*ZZ <2
-    a_load(u, S.X);
-    fp_mul(cb, L2, u, P);                  // M*X <2   (8*18)
-    a_load(u, S.U);
-    fp_dbl(u, u);                          // 2YY <4
-    fp_sub<4>(cb, cb, u, P);               // b <6
-    l_store(L3, cb);
+    fp_mul(cc, L1, u, P);                  // c = Z3*ZZ <2
+    l_load(r, L1);                         // ZZ
+    fp_mul(ca, L2, r, P);                  // a = M*ZZ <2
+    a_load(r, S.X);
+    fp_mul(cb, L2, r, P);                  // M*X <2   (16)
+    a_load(r, S.U);                        // 2YY <4
+    fp_sub<4>(cb, cb, r, P);               // b <6
+    l_store(L1, r);                        // L1 = 2YY   (ZZ dead)
     fixed_store3<NL>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P, S0);
   }
-  l_load(r, L2);
-  fp_mul(u, L2, r, P);                     // M^2 <2
-  a_load(r, S.T);                          // S
-  fp_dbl(w, r);
-  fp_sub<16>(u, u, w, P);                  // X3 <18
-  a_store(S.X, u);
-  fp_sub<18>(r, r, u, P);                  // S - X3 <26
-  fp_mul(r, L2, r, P);                     // <2
-  a_load(u, S.U);
-  fp_mulv(u, u, u, P, S0);                 // YY^2
-  fp_dbl(u, u);
-  fp_dbl(u, u);
-  fp_dbl(u, u);                            // <16
-  fp_sub<16>(r, r, u, P);                  // Y3 <18
+  a_load(r, S.X);
+  fp_mul(r, L3, r, P);                     // Sn = X*(8p - 4YY) = -S <2   (64)
+  l_load(u, L2);
+  fp_sqr(u, L2, u, P);                     // M^2 <2
+  fp_lin2<1, 2, 0>(w, u, r, P);            // X3 = M^2 - 2S <6
+  a_store(S.X, w);
+  fp_lin2<-1, -1, 8>(r, r, w, P);          // S - X3 <=8
+  l_store(S0, r);
+  l_load(u, L2);                           // M <2
+  l_load(w, L3);                           // 8p - 4YY <=8
+  fp_mul2(r, S0, u, L1, w, P);             // Y3 = M*(S - X3) + 2YY*(8p - 4YY) <2   (48)
   a_store(S.Y, r);
 }
 
-// V <- V + sP and the chord's coefficients (px, py: P canonical Montgomery, limb stride sp, element ep)
+// V <- V + sP and the chord's coefficients (px, py: P canonical Montgomery, limb stride sp, element ep):
+// b = rr*xP - Z3*ysP and Y3 = rr*(XHH - X3) - Y*HHH are one reduction each.
 template <int NL>
 __device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, const FixedTabRef& tr, size_t s, const u32* px,
                                                 const u32* py, size_t sp, size_t ep, int sign, LFp<NL>* L,
@@ -128,57 +122,52 @@ __device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, const FixedTa
   LFp<NL>* L2 = L + 2;
   LFp<NL>* L3 = L + 3;
   Fp<NL> r, u, w;
-  a_load(r, S.Z);
-  fp_mulv(u, r, r, P, S0);                 // ZZ <2
+  a_load(r, S.Z);                          // <4
+  fp_sqrv(u, r, P, S0);                    // ZZ <2
   l_store(L1, u);
   fp_mul(r, L1, r, P);                     // Z^3 <2
   g_load(u, py, sp, ep);
   if (sign < 0) fp_neg<1>(u, u, P);        // ysP
   l_store(L2, u);                          // L2 = ysP
   fp_mul(r, L2, r, P);                     // ysP*Z^3 <2
-  a_load(u, S.Y);
-  fp_sub<18>(r, r, u, P);                  // rr <20
+  a_load(u, S.Y);                          // <2
+  fp_sub<2>(r, r, u, P);                   // rr <4
   a_store(S.T, r);                         // T = rr
+  l_store(L3, r);                          // L3 = rr
   g_load(u, px, sp, ep);
   fp_mul(u, L1, u, P);                     // xP*ZZ <2
-  a_load(w, S.X);
-  fp_sub<18>(u, u, w, P);                  // H <20
+  a_load(w, S.X);                          // <8
+  fp_sub<8>(u, u, w, P);                   // H <10
   l_store(L1, u);                          // L1 = H
   a_load(r, S.Z);
-  fp_mul(r, L1, r, P);                     // Z3 <2
+  fp_mul(r, L1, r, P);                     // Z3 <2   (40)
   a_store(S.Z, r);
   {
     Fp<NL> ca, cb, cc;
-    a_load(ca, S.T);                       // a = rr <20
+    a_load(ca, S.T);                       // a = rr <4
     cc = r;                                // c = Z3 <2
-    fp_mul(w, L2, r, P);                   // Z3*ysP <2
-    g_load(r, px, sp, ep);
-    l_store(L3, ca);
-    fp_mul(cb, L3, r, P);                  // rr*xP <2   (20)
-    fp_sub<2>(cb, cb, w, P);               // b <4
+    l_store(S0, r);                        // S0 = Z3
+    g_load(w, py, sp, ep);
+    if (sign > 0) fp_neg<1>(w, w, P);      // -ysP <=1
+    g_load(r, px, sp, ep);                 // xP <1
+    fp_mul2(cb, L3, r, S0, w, P);          // b = rr*xP - Z3*ysP <2   (4 + 2)
     l_load(r, L1);                         // keep H across the store (it clobbers S0 only)
     fixed_store3<NL>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P, S0);
     u = r;
   }
-  fp_mul(w, L1, u, P);                     // HH <2
+  fp_sqr(w, L1, u, P);                     // HH <2   (100)
   fp_mul(u, L1, w, P);                     // HHH <2
   a_load(r, S.X);
-  fp_mulv(r, r, w, P, S0);                 // XHH <2
+  fp_mulv(r, r, w, P, S0);                 // XHH <2   (16)
   a_load(w, S.T);
-  fp_mulv(w, w, w, P, S0);                 // rr^2 <2
-  fp_sub<2>(w, w, u, P);                   // <4
-  {
-    Fp<NL> d;
-    fp_dbl(d, r);
-    fp_sub<4>(w, w, d, P);                 // X3 <8
-  }
+  fp_sqrv(w, w, P, S0);                    // rr^2 <2   (16)
+  fp_lin3<1, -1, -2, 6>(w, w, u, r, P);    // X3 = rr^2 - HHH - 2*XHH <8
   a_store(S.X, w);
   fp_sub<8>(r, r, w, P);                   // XHH - X3 <10
-  a_load(w, S.T);
-  fp_mulv(r, r, w, P, S0);                 // <2
-  a_load(w, S.Y);
-  fp_mulv(w, w, u, P, S0);                 // Y*HHH <2
-  fp_sub<2>(r, r, w, P);                   // Y3 <4
+  fp_neg<2>(u, u, P);                      // 2p - HHH <=2
+  a_load(w, S.Y);                          // <2
+  l_store(S0, w);                          // S0 = Y
+  fp_mul2(r, L3, r, S0, u, P);             // Y3 <2   (44)
   a_store(S.Y, r);
 }
 

@@ -51,7 +51,7 @@
 
 namespace bgn {
 
-// Range checks of the host emulation (tests/emu defines BGN_EMU, bgn_emu_fail and the switch bgn_emu_checks): a
+// Range checks of the host emulation (the CPU test harness defines BGN_EMU, bgn_emu_fail and the switch bgn_emu_checks): a
 // carry that leaves the top limb, a difference that went negative (BGN_CHECK: only where the harness has switched
 // them on — the affine-addition kernels compute through placeholder values in lanes whose result a select
 // discards), an accumulator that would wrap (BGN_CHECK_ALWAYS: limbs are tight whatever the value).  On the

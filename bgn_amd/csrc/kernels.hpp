@@ -252,9 +252,10 @@ struct KernelTable {
   void (*poly_combine)(hipStream_t s, const void* params, PolyCombineArgs a);
   const char* bsgs_kernel_name;
   // field arithmetic on its own, for the parity tests: wire elements x||y -> prod_inv = (x*y, 1/x), sqr = (x^2, y^2),
+  // sums = (x^2 + y^2, x*y + y^2) through the one-reduction sum of two products (skipped when sums.c0 is null);
   // plain canonical SoA
   void (*field_ops)(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
-                    SoA2 prod_inv, SoA2 sqr);
+                    SoA2 prod_inv, SoA2 sqr, SoA2 sums);
 };
 
 const KernelTable* kernel_table_nl3();

@@ -789,7 +789,7 @@ static void launch_poly_acc(hipStream_t s, const void* params, PolyAccArgs a) {
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_field_ops(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, int L, size_t count, int p_bits,
-            SoA2 prod_inv, SoA2 sqr) {
+            SoA2 prod_inv, SoA2 sqr, SoA2 sums) {
   __shared__ LFp<NL> stage[2];
   __shared__ WireStage<NL> ws;
   const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
@@ -816,14 +816,27 @@ k_field_ops(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire
   fp_sqrv(r, ym, P, stage);
   fp_from_mont<NL>(o, r, P, stage);
   g_store<NL>(sqr.c1, sqr.stride, e, o);
+  if (sums.c0) {
+    // sums of two products with ONE reduction (fp_mul2): x*x + y*y and x*y + y*y
+    l_store(stage, xm);
+    l_store(stage + 1, ym);
+    fp_mul2<NL>(r, stage, xm, stage + 1, ym, P);   // <2
+    fp_from_mont<NL>(o, r, P, stage);
+    g_store<NL>(sums.c0, sums.stride, e, o);
+    l_store(stage, xm);
+    l_store(stage + 1, ym);
+    fp_mul2<NL>(r, stage, ym, stage + 1, ym, P);   // <2
+    fp_from_mont<NL>(o, r, P, stage);
+    g_store<NL>(sums.c1, sums.stride, e, o);
+  }
 }
 
 
 static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* wire, int L, size_t count, int p_bits,
-                             SoA2 prod_inv, SoA2 sqr) {
+                             SoA2 prod_inv, SoA2 sqr, SoA2 sums) {
   if (!count) return;
   hipLaunchKernelGGL(k_field_ops<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, wire, L,
-                     count, p_bits, prod_inv, sqr);
+                     count, p_bits, prod_inv, sqr, sums);
 }
 
 

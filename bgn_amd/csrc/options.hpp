@@ -54,6 +54,8 @@ struct Options {
   V host_pipe_chunk{0};    // elements per chunk (0: default)
   V host_pipe_trace{0};    // stage timestamps on stderr
   V memory_budget_mb{0};   // default of bgn_ctx_set_memory_budget for the context (env: BGN_CTX_MEMORY_BUDGET_MB)
+  V resident_cap_mb{0};    // what the context keeps between calls: per-call scratch above it (MultPoly's line tables) is
+                           // given back when the call ends (0: a quarter of the device's memory; -1: keep everything)
   // ---- combiner of concurrent small host-buffer calls (engine.cpp Combiner) ----
   V combine{1};            // merge concurrent small host-buffer calls of one kind into one launch (0: off)
   V combine_max_count{1024};   // a call of more elements than this goes its own way
@@ -113,6 +115,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"host_pipe_chunk", &Options::host_pipe_chunk, true, nullptr},
       {"host_pipe_trace", &Options::host_pipe_trace, true, nullptr},
       {"memory_budget_mb", &Options::memory_budget_mb, true, "BGN_CTX_MEMORY_BUDGET_MB"},
+      {"resident_cap_mb", &Options::resident_cap_mb, true, nullptr},
       {"combine", &Options::combine, true, nullptr},
       {"combine_max_count", &Options::combine_max_count, true, nullptr},
       {"combine_max_batch", &Options::combine_max_batch, true, nullptr},

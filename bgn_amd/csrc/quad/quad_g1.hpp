@@ -321,7 +321,16 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
   constexpr int M = QuadDims<NL>::M;
   using PG = QuadG1;
   __shared__ u64 Vs[((PG::NSLOTS + 3) / 4) * QuadDims<NL>::MR * QUAD_BLOCK];
-  __shared__ u32 note[QUAD_PER_BLOCK][4];         // per element: entry is all zero (quads 0, 1) | X' = 0 | Z' = 0
+  // per element: entry is all zero (quads 0, 1) | X' = 0 | Z' = 0.  One lane of a quad writes, the sixteen lanes of
+  // the element read: volatile accesses with a wavefront-scope release / acquire pair and a wave barrier between the
+  // write and the reads (note_sync), so that neither the compiler nor the memory model may move a read above the
+  // divergent store it depends on
+  __shared__ volatile u32 note[QUAD_PER_BLOCK][4];
+  auto note_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   char* V = reinterpret_cast<char*>(Vs);
   QuadLane<NL> c;
   quad_lane_init<NL>(c, P);
@@ -382,7 +391,8 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
         any |= (u32)quad_bcast<0>((int)any) | (u32)quad_bcast<2>((int)any);
         if (c.sub == 0) note[el][c.quad] = any;
       }
-      ent_inf = (note[el][0] | note[el][1]) == 0;      // (same wave: the LDS writes above precede these reads)
+      note_sync();
+      ent_inf = (note[el][0] | note[el][1]) == 0;
       const bool use = d != 0 && !ent_inf;
       seg = QUADG_SEG_GADM;                             // the table's entries are affine: the mixed addition, four rounds
       took = use && !acc_inf;
@@ -418,6 +428,7 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
         const bool zero = quad_is_zero<NL>(x);
         if (c.sub == 0) note[el][c.quad == 0 ? 2 : 3] = zero ? 1u : 0u;
       }
+      note_sync();
       const bool zx = note[el][2] != 0, zz = note[el][3] != 0;
       if (took && zz) {
         if (seg == QUADG_SEG_GADM && zx) need_dbl = true;      // acc == entry

@@ -104,14 +104,16 @@ class ShardedOps:
 
     def decrypt(self, level: int, ct):
         """sk.Decrypt over `count` ciphertexts (bgn.go:205-250): returns (m as int64, status as uint8)."""
+        import numpy as np
         import torch
         total = ct.numel() // self.E
 
         def op(x):
             m, st = self.engine.decrypt(level, x.numpy())
             packed = torch.empty(len(m), 9, dtype=torch.uint8)
-            packed[:, :8] = torch.from_numpy(m.copy()).view(torch.uint8).reshape(-1, 8)
-            packed[:, 8] = torch.from_numpy(st.copy())
+            if len(m):                       # (a rank of a batch smaller than the world owns nothing)
+                packed[:, :8] = torch.from_numpy(np.ascontiguousarray(m, dtype=np.int64)).view(torch.uint8).reshape(-1, 8)
+                packed[:, 8] = torch.from_numpy(np.ascontiguousarray(st, dtype=np.uint8))
             return packed.reshape(-1)
 
         full = sharded_apply(op, total, self.E, 9, [ct], self.world, self.rank, self.dist).reshape(total, 9)

@@ -85,19 +85,28 @@ const char* bgn_version(void);
 /* Device memory.  The reference keeps the decryption tables of every key it has seen (gsbs.go:12-15: package
  * globals filled by computeTableG1/GT, gsbs.go:41-51); here every per-key table (BSGS baby table, fixed-base window
  * tables of P and Q, GT window tables, MultPoly's line tables) and the batch workspace belong to the context.
- * Default sizes are a function of the key, of T and of the device's TOTAL memory — not of what happens to be free:
- *   baby-step table   32 B per baby step, 2^ceil(log2(B*B + B + 3)) steps, at most 2^31 and at most 1/4 of the
- *                     device (MI355X, T = 2^40: 2^31 steps = 69 GB; profiles/r04_decrypt_vs_table.csv is the
- *                     decrypts/s and set-up time this buys against 2^24 .. 2^30)
- *   windows of P      16-bit windows, 2 * NL * 4 B per entry (1024-bit key: 1.2 GB); the GT table of e(Q,Q) likewise
- *   windows of Q      22-bit windows where 1/4 of the device holds them (1024-bit key: 60 GB), else the widest that
- *                     fit (20 bits: 17 GB; profiles/r04_encrypt_vs_window.csv)
- *   MultPoly tables   whole rounds of 65536 coefficient tables (38 GB at a 1024-bit key) within 1/6 of the device
- *   workspace         7.4 KB per pairing of the largest batch seen (7.8 GB at 2^20)
+ * Default sizes are a function of the key, of T and of the device's TOTAL memory — not of what happens to be free —
+ * and sit at the knee of the measured curves, not at their end (1024-bit key, T = 2^40, MI355X; round 4 defaulted to
+ * the maxima, 175 GB for one key):
+ *   baby-step table   32 B per baby step, 2^ceil(log2(B*B + B + 3)) steps, at most 2^30 (34 GB): 1.59e6 decrypts/s at
+ *                     2^20 ciphertexts.  What the neighbours buy (profiles/r04_decrypt_vs_table.csv): 2^31 steps, 69 GB,
+ *                     +8 % (option bsgs_max_log2 = 31); 2^29, 17 GB, -14 %; 2^28, 8.6 GB, -33 %
+ *   windows of Q      20-bit windows, 16 GB: 1.72e7 encrypts/s.  22 bits, 58 GB, +6 % (option fixed_window_bits_q =
+ *                     22); 18 bits, 4.4 GB, -6 %; 16 bits, 1.2 GB, -11 % (profiles/r04_encrypt_vs_window.csv)
+ *   windows of P      16-bit windows, 2 * NL * 4 B per entry (1.2 GB); the GT table of e(Q,Q) likewise
+ *   workspace         7.4 KB per pairing of the largest batch seen (7.8 GB at 2^20; larger batches run in pieces)
+ *   => 52.8 GB of tables + workspace: a context that has encrypted, multiplied and decrypted holds about 61 GB.
+ *   MultPoly tables   per-call scratch: whole rounds of 65536 coefficient tables (38 GB) within 1/6 of the device.
+ *                     They stay with the context for the next call only while its total remains under the RESIDENT CAP
+ *                     — a quarter of the device by default (72 GB), option resident_cap_mb; -1: keep everything — and go
+ *                     back to the allocator when the call returns otherwise: a context that also holds decryption
+ *                     tables pays a fresh hipMalloc per large MultPoly call (1.2 - 2.1 s for 38 GB,
+ *                     profiles/r05_alloc_cost.csv) unless its cap is raised; one that only encrypts and multiplies
+ *                     (26 GB + 38 GB) keeps them.
  * What is free at the moment of the call — under a budget, what the budget leaves — only clamps these from above
  * (a table never takes more than half of it), so the same key gets the same tables in whatever order they are
- * built, unless memory is short.  Options bsgs_max_log2, fixed_window_bits, fixed_window_bits_q, poly_table_max_mb
- * choose smaller ones.
+ * built, unless memory is short.  Options bsgs_max_log2, fixed_window_bits, fixed_window_bits_q, poly_table_max_mb,
+ * resident_cap_mb choose other sizes.
  * bgn_ctx_memory_bytes: bytes of device memory the context holds now (the staging buffers of the combiner included;
  * not included: the small per-device pool of staging buffers the host-buffer calls share, at most 32 x 4 MB).
  * bgn_ctx_set_memory_budget: a cap on that figure (0 = none, the default; BGN_CTX_MEMORY_BUDGET_MB sets a default
@@ -114,9 +123,12 @@ int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes);
  * process) cannot race the library, and two contexts of one process may run different settings side by side.
  * bgn_ctx_set_option takes effect from the next call on (options read only while a table is built — miller_window,
  * fixed_normalize at creation; decrypt_order_table by bgn_ctx_set_secret; bsgs_max_log2 by bgn_ctx_setup_decryption;
- * fixed_window_bits* on first Encrypt — must be in place before that step).  bgn_ctx_reset_options goes back to
- * the values the context was created with.  bgn_option_name(i) enumerates the names (null past the end).
- * Unknown name: BGN_E_ARG.  There is no counterpart in the reference (PBC has no tunables on this path); the
+ * fixed_window_bits* on first Encrypt — must be in place before that step; a value that arrives after its table is
+ * built is refused with BGN_E_STATE, never accepted silently: miller_window and fixed_normalize always — they are
+ * creation-time options, set BGN_MILLER_WINDOW / BGN_FIXED_NORMALIZE in the environment —, fixed_window_bits* once the
+ * window tables exist).  bgn_ctx_reset_options goes back to the values the context was created with and re-applies
+ * those with a side effect (memory_budget_mb: the budget in force is the restored one).  bgn_option_name(i)
+ * enumerates the names (null past the end).  Unknown name: BGN_E_ARG.  There is no counterpart in the reference (PBC has no tunables on this path); the
  * nearest is the package-level state of gsbs.go:12-15. */
 int bgn_ctx_set_option(bgn_ctx* ctx, const char* name, int64_t value);
 int bgn_ctx_get_option(const bgn_ctx* ctx, const char* name, int64_t* value);
@@ -353,6 +365,9 @@ void bgn_host_free(void* p);
  * so that parity tests can compare it with big-integer arithmetic directly.  xy: count elements x||y, L bytes
  * each, residues below p; prod_inv[e] = x*y || x^-1 (0 for x = 0); sqr[e] = x^2 || y^2; host buffers. */
 int bgn_field_ops_batch(bgn_ctx* ctx, size_t count, const uint8_t* xy, uint8_t* prod_inv, uint8_t* sqr);
+/* The same for the sum of two products with ONE Montgomery reduction (csrc/fpmont.hpp fp_mul2: the a*b +- c*d of the
+ * Miller steps since round 5): sums[e] = (x^2 + y^2) || (x*y + y^2). */
+int bgn_field_sums_batch(bgn_ctx* ctx, size_t count, const uint8_t* xy, uint8_t* sums);
 
 /* ---- measurement hooks (used by bench.py; not part of the drop-in surface) --- */
 /* Milliseconds spent in the dominant kernel of the most recent *_dev call on

@@ -284,3 +284,32 @@ def test_emu_pairing_at_36_and_37_limbs(name):
     assert E.pairing(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
     E.set_window(5)
     assert E.pairing_w3(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+
+
+@pytest.mark.parametrize("name", ["k512", "k1024", "k1024b", "k2048"])
+def test_emu_step_programs_at_the_product_limb_counts(name):
+    """The Miller step programs at 19, 36, 37 and 72 limbs — the limb counts whose products flush their accumulators
+    (fpmont.hpp: one flush at 36 / 37 limbs, three at 72; a sum of two products adds three product units per row) —
+    with the emulation's range checks on (BGN_CHECK: accumulator capacity, carry-outs, negative differences): the
+    plain NAF loop, the windowed loop at two widths, the walk over a key's line table (plain and normalized) and over
+    a per-coefficient table, against the golden vectors."""
+    fx = load_fixture(name)
+    E = emu.Emu.from_fixture(fx)
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    rows = [v for v in fx["mult"] if any(cts[v["a"]]) and any(cts[v["b"]])][:2]
+    for v in rows:
+        assert E.pairing(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+        for w in (3, 5):
+            E.set_window(w)
+            assert E.pairing_w3(cts[v["a"]], cts[v["b"]]).hex() == v["out"]
+    if name == "k2048":
+        return
+    tab = E.fixed_table(bytes.fromhex(fx["P"]))
+    for v in fx["make_l2"][:2]:
+        assert E.pairing_fixed(tab, cts[v["a"]]).hex() == v["out"]
+    E.fixed_normalize(tab)
+    for v in fx["make_l2"][:2]:
+        assert E.pairing_fixed(tab, cts[v["a"]], normalized=True).hex() == v["out"]
+    v = rows[0]
+    tb = E.fixed_table(cts[v["a"]], 2, 1)
+    assert E.pairing_fixed(tb, cts[v["b"]], 2, 1).hex() == v["out"]

@@ -46,6 +46,12 @@ def test_field_mul_sqr_inv_vs_python_integers(name, count):
         assert pi[i * E:(i + 1) * E] == want, (name, i, "x*y / 1/x")
         want = (x * x % p).to_bytes(L, "big") + (y * y % p).to_bytes(L, "big")
         assert sq[i * E:(i + 1) * E] == want, (name, i, "x^2 / y^2")
+    # the sum of two products with one reduction (fp_mul2) on the same operands: three product units per row and
+    # column, the extreme residues above in both products at once
+    sm = eng.field_sums(buf).tobytes()
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        want = ((x * x + y * y) % p).to_bytes(L, "big") + ((x * y + y * y) % p).to_bytes(L, "big")
+        assert sm[i * E:(i + 1) * E] == want, (name, i, "x^2 + y^2 / x*y + y^2")
 
 
 # ---------------------------------------------------------------- blinded operations, 512 and 1024 bits
@@ -361,3 +367,38 @@ def test_dev_calls_take_operands_at_any_byte_offset(name):
         st = torch.empty(cnt, dtype=torch.uint8, device=dev)
         eng.decrypt_dev(1, a, m, st, cnt)
         assert m.cpu().tolist() == ms and not bool(st.any().item()), (name, off, "decrypt")
+
+
+# ---------------------------------------------------------------- options with a side effect or a build-time meaning
+def test_options_read_at_build_time_are_refused_afterwards_and_reset_reapplies_the_budget():
+    """bgn_ctx_set_option refuses a value that could no longer change anything (BGN_E_STATE): the creation-time options
+    always, the window widths once the window tables exist; bgn_ctx_reset_options puts the creation-time memory
+    budget back IN FORCE, not just back into the option's value."""
+    import bgn_amd
+    from bgn_amd._lib import BGN_E_NOMEM, BGN_E_STATE, BgnError
+    fx = load_fixture("k256")
+    pk = bgn_amd.PublicKey(int(fx["p"], 16), int(fx["n"], 16), fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]),
+                           fx["msg_space"], True, fx["poly_base"])
+    eng = pk.engine
+    for name in ("miller_window", "fixed_normalize"):
+        before = eng.get_option(name)
+        with pytest.raises(BgnError) as ei:
+            eng.set_option(name, 3)
+        assert ei.value.code == BGN_E_STATE and eng.get_option(name) == before
+    eng.set_option("fixed_window_bits_q", 8)                       # before the first Encrypt: accepted
+    eng.encrypt([1, 2, 3], [5, 6, 7])                              # builds the window tables
+    with pytest.raises(BgnError) as ei:
+        eng.set_option("fixed_window_bits_q", 16)
+    assert ei.value.code == BGN_E_STATE and eng.get_option("fixed_window_bits_q") == 8
+    # a budget set through the option is enforced; reset_options lifts it again (the context was created without one)
+    eng.set_option("memory_budget_mb", 1)
+    cts = [e["ct"] for e in fx["encrypt"]]
+    a = b"".join(bytes.fromhex(cts[v["a"]]) for v in fx["mult"]) * 4000
+    b = b"".join(bytes.fromhex(cts[v["b"]]) for v in fx["mult"]) * 4000
+    with pytest.raises(BgnError) as ei:
+        eng.mult(a, b)
+    assert ei.value.code == BGN_E_NOMEM
+    eng.reset_options()
+    assert eng.get_option("memory_budget_mb") == 0
+    out = eng.mult(a, b)                                           # no budget in force any more
+    assert bytes(out[1]).hex() == fx["mult"][1]["out"]

@@ -91,3 +91,80 @@ def test_the_budget_is_a_hard_cap_and_can_be_raised():
     out = eng.mult(a, b)                                        # the context is usable again
     assert bytes(out[1]).hex() == fx["mult"][1]["out"]
     assert np.array_equal(out[: len(fx["mult"])], out[len(fx["mult"]): 2 * len(fx["mult"])])
+
+
+def test_default_footprint_one_key_after_encrypt_decrypt_multpoly_and_two_keys_without_a_budget():
+    """Round 5's defaults sit at the knee of the measured curves (include/bgn_amd.h "Device memory"): with NO budget
+    call a fresh 1024-bit key with T = 2^40 holds at most 64 GB after Encrypt + Decrypt + a MultPoly large enough to
+    build a whole round of line tables (which exceed the resident cap beside the decryption tables and go back to the
+    allocator when the call returns), and a second key sets up beside it with the same table sizes."""
+    import torch
+    fx = load_fixture("k1024")
+    pk, sk = fresh_key(fx)
+    eng = pk.engine
+    dev = torch.device("cuda")
+    EB = eng.elem_bytes
+    n = int(fx["n"], 16)
+    rng = random.Random(5)
+    T = 1 << 40
+    # Encrypt (builds the window tables of P and Q): 20-bit windows of Q by default
+    npoly, d = 4100, 16                                         # 65600 coefficients: one whole round of tables + a remainder
+    cnt = 2 * npoly * d
+    g = torch.Generator().manual_seed(9)
+    xs = torch.randint(0, 2, (cnt, 1), dtype=torch.uint8, generator=g).to(dev)
+    rs = torch.randint(0, 256, (cnt, 128), dtype=torch.uint8, generator=g)
+    rs[:, 0] &= 0x3F
+    rs = rs.to(dev)
+    cts = torch.empty(cnt * EB, dtype=torch.uint8, device=dev)
+    eng.encrypt_dev(xs, 1, rs, 128, cts, cnt)
+    torch.cuda.synchronize()
+    after_encrypt = eng.memory_bytes()
+    assert 14 * GB < after_encrypt < 24 * GB, after_encrypt     # 15.7 GB for Q, 1.2 GB for P, the workspace
+    # Decrypt: the baby-step table is 2^30 entries by default
+    pk.SetupDecryption(sk)
+    assert int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h)) == 1 << 30
+    ms = [0, 1, T - 1, rng.randrange(T), rng.randrange(T)]
+    enc = eng.encrypt(ms, [rng.randrange(n) for _ in ms])
+    m, st = eng.decrypt(1, enc.tobytes())
+    assert st.tolist() == [0] * len(ms) and m.tolist() == ms
+    after_decrypt = eng.memory_bytes()
+    assert after_decrypt <= 62 * GB, after_decrypt
+    # MultPoly over line tables: 38 GB of scratch beside 53 GB of tables is above the resident cap (a quarter of
+    # the device): the tables are there during the call and gone after it
+    out = torch.empty(npoly * 2 * d * EB, dtype=torch.uint8, device=dev)
+    eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
+    torch.cuda.synchronize()
+    assert "fixedpair" in eng.last_kernel_name()
+    held = eng.memory_bytes()
+    assert held <= 64 * GB, held
+    mm = torch.empty(npoly * 2 * d, dtype=torch.int64, device=dev)
+    stt = torch.empty(npoly * 2 * d, dtype=torch.uint8, device=dev)
+    eng.decrypt_dev(2, out, mm, stt, npoly * 2 * d)
+    torch.cuda.synchronize()
+    xv = xs.cpu().view(2, npoly, d).to(torch.int64)
+    conv = torch.zeros((npoly, 2 * d), dtype=torch.int64)
+    for i in range(d):
+        for k in range(d):
+            conv[:, i + k] += xv[0][:, i] * xv[1][:, k]
+    assert not bool(stt.any().item()) and bool((mm.cpu().view(npoly, 2 * d) == conv).all().item())
+    # with the cap lifted the same call keeps its tables (the next call does not pay the allocation again)
+    eng.set_option("resident_cap_mb", -1)
+    eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
+    torch.cuda.synchronize()
+    assert eng.memory_bytes() > held + 30 * GB
+    eng.set_option("resident_cap_mb", 0)
+    eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
+    torch.cuda.synchronize()
+    assert eng.memory_bytes() <= 64 * GB
+    # a second key beside it, no budget call anywhere: the same table sizes
+    fx2 = load_fixture("k1024b")
+    pk2, sk2 = fresh_key(fx2)
+    pk2.SetupDecryption(sk2)
+    assert int(pk2.engine._lib.bgn_ctx_bsgs_baby_steps(pk2.engine._h)) == 1 << 30
+    rows = [dd for dd in fx2["decrypt"] if dd["level"] == 1]
+    m2, st2 = pk2.engine.decrypt(1, H([dd["ct"] for dd in rows]))
+    assert st2.tolist() == [0] * len(rows) and m2.tolist() == [dd["m"] for dd in rows]
+    enc2 = pk2.engine.encrypt(ms, [rng.randrange(int(fx2["n"], 16)) for _ in ms])
+    m3, st3 = pk2.engine.decrypt(1, enc2.tobytes())
+    assert st3.tolist() == [0] * len(ms) and m3.tolist() == ms
+    assert pk2.engine.memory_bytes() <= 64 * GB and eng.memory_bytes() + pk2.engine.memory_bytes() <= 128 * GB

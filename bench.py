@@ -227,16 +227,17 @@ def _timed(fn, sync, reps=2):
 
 
 def op_rooflines(entry, counts, nl, n_gpus=1):
-    """Every secondary entry carries the two bounds: its 32x32->64 multiply-adds — counts = (field products, how
-    many of them are squarings), priced by bgn_amd.synthetic.mads_from_counts — against the measured issue peaks of
+    """Every secondary entry carries the two bounds: its 32x32->64 multiply-adds — counts = (reductions, how many of
+    them end a squaring, how many a sum of two products), priced by bgn_amd.synthetic.mads_from_counts — against the measured issue peaks of
     v_mad_u64_u32 (the VALU bound that applies; both occupancies), and its algorithmic bytes against the HBM peak.
     Aggregate rates over n_gpus ranks are held against n_gpus chips."""
     import bgn_amd.synthetic as syn
-    products, squares = counts
-    mads = syn.mads_from_counts(products, squares, nl)
+    products, squares, sops = counts
+    mads = syn.mads_from_counts(products, squares, sops, nl)
     rate = entry["value"] * mads / n_gpus
-    entry["products_per_unit"] = products
+    entry["products_per_unit"] = products           # everything that ends in a Montgomery reduction
     entry["squarings_per_unit"] = squares
+    entry["sums_of_two_products_per_unit"] = sops   # reductions shared by two multiplications (fp_mul2)
     entry["roofline_valu"] = {"bound": "v_mad_u64_u32 issue", "mads_per_unit": mads, "achieved": rate, "unit": "lane-MAD/s",
                               "peak": VALU_MAD_PEAK_4W, "frac": rate / VALU_MAD_PEAK_4W,
                               "peak_at_1_wave_per_simd": VALU_MAD_PEAK_1W, "frac_at_1_wave_per_simd": rate / VALU_MAD_PEAK_1W}

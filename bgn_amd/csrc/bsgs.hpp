@@ -11,16 +11,17 @@
 //     e(C, P) (the makeL2 kernel), since e(C^sk, P) = (e(P,P)^sk)^m has the same
 //     m and a GT giant step costs 3 field products against ~20 for an affine
 //     G1 step;
-//   * the baby table lives in HBM as an open-addressing hash of 94-bit
-//     fingerprints of the canonical real part; because GT has norm 1,
+//   * the baby table lives in HBM as an open-addressing hash of 8-byte slots: the
+//     94-bit fingerprint of the canonical real part is hashed once, the slot index and a
+//     30-bit tag come from the hash, j and a parity bit fill the word; because GT has norm 1,
 //     conj(g^j) = g^-j shares its real part with g^j, so one probe covers +-j
 //     (the parity of the imaginary part, stored with j, tells which), and the
 //     giant steps are spaced 2*S apart: step i resolves m = 2*i*S +- j for
 //     j in [0, S], so the walk is half as long as one that only adds j; the walk
 //     itself advances the real part alone by the two-term recurrence of the norm-1
 //     group, one field product per giant step;
-//   * baby/giant sizes are re-balanced for 288 GB of HBM: S = up to 2^30 baby
-//     steps, G = floor((Mmax+S)/(2S)) + 1 giant steps, where Mmax = B*B + B + 2,
+//   * baby/giant sizes are re-balanced for 288 GB of HBM: S = up to 2^31 baby
+//     steps (16 B each at two slots per step: 34 GB), G = floor((Mmax+S)/(2S)) + 1 giant steps, where Mmax = B*B + B + 2,
 //     B = ceil(sqrt(T)), is exactly the largest value the reference's loops can
 //     return; candidates outside [1, Mmax] are rejected so the accept / error
 //     behaviour matches gsbs.go:77-105 and the retry rule bgn.go:235-242.
@@ -60,6 +61,15 @@ __device__ __forceinline__ void bsgs_fingerprint(unsigned long long& key, u32& c
   bsgs_fingerprint<NL>(key, check, c);
   key = (key & B.key_keep) | (1ull << 63);
   check &= B.check_keep;
+}
+
+// Slot index and slot word of a fingerprint: one 64-bit hash of its 94 bits; the index takes the low bits (at most 32:
+// 2*S <= 2^32 slots), the tag bits 34..63.
+__device__ __forceinline__ unsigned long long bsgs_hash(unsigned long long key, u32 check) {
+  return bsgs_mix(key ^ bsgs_mix(0x9E3779B97F4A7C15ull * (unsigned long long)(check & 0x7fffffffu) + 1ull));
+}
+__device__ __forceinline__ unsigned long long bsgs_slot_tag(unsigned long long hash) {
+  return (1ull << 63) | ((hash >> 34) << 33);               // occupied | 30 tag bits
 }
 
 // (r0, r1) = (a0 + i a1) * K with the constant K in LDS rows: L[1] = K0, L[2] = K1,
@@ -171,16 +181,13 @@ __device__ __forceinline__ void bsgs_build_lane(const BsgsParams& B, unsigned lo
       unsigned long long key;
       u32 check;
       bsgs_fingerprint<NL>(key, check, c0, B);
-      const u32 val = (u32)j;                                  // j <= S <= 2^31
-      check = (check & 0x7fffffffu) | ((c1.v[0] & 1u) << 31);   // parity of the imaginary part rides in the check word
-      unsigned long long h = bsgs_mix(key) & B.mask;
+      const unsigned long long hs = bsgs_hash(key, check);
+      // occupied | tag | parity of the imaginary part | j  (j <= S <= 2^31): one word, one atomic
+      const unsigned long long word = bsgs_slot_tag(hs) | ((unsigned long long)(c1.v[0] & 1u) << 32) | (unsigned long long)(u32)j;
+      unsigned long long h = hs & B.mask;
       for (;;) {
-        const unsigned long long old = atomicCAS(&B.table[h].key, 0ull, key);
-        if (old == 0ull) {
-          B.table[h].check = check;
-          B.table[h].val = val;
-          break;
-        }
+        const unsigned long long old = atomicCAS(&B.table[h].w, 0ull, word);
+        if (old == 0ull) break;
         h = (h + 1) & B.mask;
       }
     }
@@ -232,10 +239,10 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
   if (i1 > B.G) i1 = B.G;
   bool found = false, finished = !live;
   long long result = 0;
-  // A table hit is a match of 94 fingerprint bits of Re(y_i): the candidate m it decodes to is VERIFIED by
-  // g^|m| == x on all limbs before it is accepted (gsbs.go:83,90 compares whole elements).  A rejected hit —
-  // probability ~2^-94 per probe with the full fingerprint — resumes the walk at the same giant step behind the
-  // rejected slot.  Every pass of this loop is one walk of the wave; kMaxAttempts bounds it.
+  // A table hit is a match of the slot index and 30 tag bits of the hashed fingerprint of Re(y_i): the candidate m
+  // it decodes to is VERIFIED by g^|m| == x on all limbs before it is accepted (gsbs.go:83,90 compares whole
+  // elements).  A rejected hit — probability 2^-30 per occupied slot probed: about one in three batches of 2^20
+  // ciphertexts at T = 2^40 sees one — resumes the walk at the same giant step behind the rejected slot.  Every pass of this loop is one walk of the wave; kMaxAttempts bounds it.
   bool resume = false;
   unsigned long long resume_h = 0;
   constexpr int kMaxAttempts = 64;
@@ -315,12 +322,12 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       bsgs_fingerprint<NL>(key, check, rc, B);
       // the first slot of the probe sequence is fetched before the next step's product and examined after it:
       // at one wave per SIMD nothing else hides the ~2 us of a random HBM access
-      unsigned long long h = bsgs_mix(key) & B.mask;
+      const unsigned long long hs = bsgs_hash(key, check);
+      const unsigned long long want = bsgs_slot_tag(hs) >> 33;  // what bits 63..33 of a matching slot hold
+      unsigned long long h = hs & B.mask;
       if (resume && i == i0) h = (resume_h + 1) & B.mask;       // behind the slot the verification rejected
       BsgsSlot s0;
-      s0.key = 0ull;
-      s0.check = 0;
-      s0.val = 0;
+      s0.w = 0ull;
       if (!done) s0 = B.table[h];
       Fp<NL> nx;
       fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
@@ -330,13 +337,13 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       if (!done) {
         BsgsSlot s = s0;
         for (;;) {
-          if (s.key == 0ull) break;
-          if (s.key == key && ((s.check ^ check) & 0x7fffffffu & B.check_keep) == 0u) {
+          if (s.w == 0ull) break;
+          if ((s.w >> 33) == want) {
             hit = true;
             hit_i = i;
             hit_h = h;
-            hit_j = s.val;
-            hit_par = s.check >> 31;
+            hit_j = (u32)s.w;
+            hit_par = (u32)(s.w >> 32) & 1u;
             done = true;
             break;
           }

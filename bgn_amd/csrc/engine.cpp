@@ -789,20 +789,20 @@ int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
   if ((double)B < sq) B++;
   const uint64_t Mmax = B * B + B + 2;
   uint64_t S = 2;
-  // baby-step cap: the table is 32 B per baby step (2x open addressing, 16-B slots).  Default since round 5: at most
-  // 2^30 steps (34 GB) — the knee of profiles/r04_decrypt_vs_table.csv (T = 2^40, 2^20 ciphertexts: 2^31 entries /
-  // 69 GB 1.73e6 decrypts/s, 2^30 / 34 GB 1.59e6 (-8 %), 2^29 / 17 GB 1.36e6 (-21 %), 2^28 1.07e6: the walk is (T / 2S)
-  // products per ciphertext beside a lift of ~3.8 k, so the last doubling buys 8 % for 34 GB and the one before it
-  // 17 % for 17 GB) — and never more than a quarter of the device's total memory.  Free memory — under a budget,
-  // what the budget leaves — only clamps.  Option bsgs_max_log2 overrides (4..31: 31 is round 4's default; the
-  // slot's value field holds j <= 2^31).  The build takes 0.56 s at 2^30 entries (two products per entry).
-  int cap_log2 = 30;
+  // baby-step cap: the table is 16 B per baby step (2x open addressing, 8-byte slots since round 5: kernels.hpp
+  // BsgsSlot; 32 B until round 4).  Default: at most 2^31 steps = 34 GB — what round 4 paid 69 GB for — and never
+  // more than a quarter of the device's total memory.  profiles/r04_decrypt_vs_table.csv has the curve (T = 2^40,
+  // 2^20 ciphertexts: 2^31 entries 1.73e6 decrypts/s, 2^30 1.59e6 (-8 %), 2^29 1.36e6 (-21 %), 2^28 1.07e6: the walk
+  // is (T / 2S) products per ciphertext beside a lift of ~3.8 k).  Free memory — under a budget, what the budget
+  // leaves — only clamps.  Option bsgs_max_log2 overrides (4..31; the slot's value field holds j <= 2^31).  The
+  // build takes 0.9 s at 2^31 entries (two products per entry).
+  int cap_log2 = 31;
   {
     // (the table this call replaces counts as free)
     const size_t old_table = c->d_table ? (size_t)c->bsgs_slots * sizeof(BsgsSlot) : 0;
     const size_t cap = ctx_table_cap(c, 4, old_table);
     if (cap)
-      while (cap_log2 > 20 && ((uint64_t)32 << cap_log2) > cap) cap_log2--;
+      while (cap_log2 > 20 && ((uint64_t)2 * sizeof(BsgsSlot) << cap_log2) > cap) cap_log2--;
   }
   {
     const int64_t v = opt(c, &Options::bsgs_max_log2);

@@ -364,6 +364,36 @@ __device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
   t[0] += c;
 }
 
+// Build-time switches of the three product trims of round 5 (each measured on its own):
+//   BGN_TRIM_PEEL     the first row of a product creates the accumulators (no zero fill)
+//   BGN_TRIM_FLUSH    the mid-product flush as a carry-save pass (three independent instructions per accumulator)
+//   BGN_TRIM_PARTIAL  a plain product flushes only the accumulators that can overflow
+#ifndef BGN_TRIM_PEEL
+#define BGN_TRIM_PEEL 0
+#endif
+#ifndef BGN_TRIM_FLUSH
+#define BGN_TRIM_FLUSH 0
+#endif
+#ifndef BGN_TRIM_PARTIAL
+#define BGN_TRIM_PARTIAL 1
+#endif
+
+// The first row of a product: the accumulators START as its products (no zero fill of 2*NL registers, no add).
+template <int NL>
+__device__ __forceinline__ void fp_row_first(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
+                                             const FpParams<NL>* __restrict__ P) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] = (u64)ai * b.v[j];
+  const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], m, P->p[j]);
+  const u64 c = t[0] >> LIMB_BITS;
+#pragma unroll
+  for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
+  t[NL - 1] = 0;
+  t[0] += c;
+}
+
 // r = a*b/R mod p, lazy (r < 2p).  The multiplier `a` is an LDS element whose
 // rows are streamed (next row pair prefetched while the current one is
 // multiplied); the multiplicand `b` sits in VGPRs.  r may alias b.
@@ -374,19 +404,71 @@ constexpr int kRowsPerFlush = LIMB_BITS >= 29 ? 19 : 64;
 template <int NL>
 constexpr bool kNeedsFlush = NL > kRowsPerFlush;
 
-// carry pass over the accumulators in place: every one back below 2^LIMB_BITS, the excess moved up
+// the constant 1 in a register the compiler cannot see through: x * one + y stays ONE v_mad_u64_u32 where the compiler
+// would otherwise widen x by materialising a zero high half (a fourth instruction per accumulator of a flush)
+__device__ __forceinline__ u32 opaque_one() {
+  u32 one = 1;
+#if !defined(BGN_EMU)
+  asm("" : "+v"(one));
+#endif
+  return one;
+}
+
+// Carry-save pass over the accumulators LO .. HI in place: every one of LO .. HI-1 keeps its low LIMB_BITS bits and takes
+// the excess of its lower neighbour — no ripple, the value is unchanged and each accumulator is back below
+// 2^LIMB_BITS + 2^(64 - LIMB_BITS), which is all a flush is for; HI receives the excess of HI - 1 on top of what it
+// holds.  Three independent instructions per accumulator (shift, mask, multiply-add by one).
+template <int NL, int LO, int HI>
+__device__ __forceinline__ void fp_flush_range(u64 (&t)[NL]) {
+  static_assert(0 <= LO && LO < HI && HI <= NL - 1, "flush range");
+#if BGN_TRIM_FLUSH
+  const u32 one = opaque_one();
+  t[HI] += t[HI - 1] >> LIMB_BITS;
+#pragma unroll
+  for (int j = HI - 1; j > LO; --j) t[j] = (u64)((u32)t[j] & LIMB_MASK) * one + (t[j - 1] >> LIMB_BITS);
+  t[LO] = (u32)t[LO] & LIMB_MASK;
+#else
+  // the rippling form: every accumulator of LO .. HI-1 back below 2^LIMB_BITS, the excess moved up into HI
+  u64 c = 0;
+#pragma unroll
+  for (int j = LO; j < HI; ++j) {
+    const u64 sum = t[j] + c;
+    t[j] = sum & (u64)LIMB_MASK;
+    c = sum >> LIMB_BITS;
+  }
+  t[HI] += c;
+#endif
+}
+// all of them (the top accumulator's excess stays in it: the value is below 2^(LIMB_BITS*NL) * small)
 template <int NL>
 __device__ __forceinline__ void fp_flush(u64 (&t)[NL]) {
+#if BGN_TRIM_FLUSH
+  fp_flush_range<NL, 0, NL - 1>(t);
+#else
   u64 c = 0;
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const u64 s = t[j] + c;
-    t[j] = s & (u64)LIMB_MASK;
-    c = s >> LIMB_BITS;
+    const u64 sum = t[j] + c;
+    t[j] = sum & (u64)LIMB_MASK;
+    c = sum >> LIMB_BITS;
   }
-  // (the top accumulator's excess stays in it: the value is below 2^(LIMB_BITS*NL) * small)
   t[NL - 1] += c << LIMB_BITS;
+#endif
 }
+
+// Which accumulators a plain product (two product units per row) must flush, when ONE flush after `DONE` rows is
+// all it needs: an accumulator lives from the row that creates it (as the top one) to the row that retires it, and
+// holds 2 units per row of its life; 64 - 1 units is what 64 bits take beside the row carries.  Only the few that
+// live longer than 31 rows are at risk: the initial accumulators LIFE_MAX .. NL-1, now DONE positions lower, and the
+// ones created in rows 1 .. NL - LIFE_MAX - 1 — nine consecutive positions at 36 limbs instead of all 36.
+constexpr int kLifeMax2 = ((1 << (64 - 2 * LIMB_BITS)) - 1) / 2;     // 31 rows at radix 2^29
+template <int NL, int DONE>
+struct MidFlush {
+  static constexpr int LO = kLifeMax2 - DONE > 0 ? kLifeMax2 - DONE : 0;
+  static constexpr int LAST = 2 * NL - kLifeMax2 - 2 - DONE;        // created in row NL - kLifeMax2 - 1, DONE - that row rows ago
+  static constexpr int HI = LAST + 1 < NL - 1 ? LAST + 1 : NL - 1;
+  static constexpr bool ok = LO < HI && DONE <= kLifeMax2 && NL - DONE <= kLifeMax2;   // either half alone never overflows
+};
 
 template <int NL>
 __device__ __forceinline__ void fp_mul_inl(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>& b,
@@ -399,15 +481,29 @@ __device__ __forceinline__ void fp_mul_inl(Fp<NL>& r, const LFp<NL>* a, const Fp
   constexpr int NPI = (NP + NI - 1) / NI;                        // row pairs per interval
   static_assert(2 * NPI + (NL & 1) <= kRowsPerFlush || !kNeedsFlush<NL>, "interval too long");
   u64 t[NL];
-#pragma unroll
-  for (int j = 0; j < NL; ++j) t[j] = 0;
   u64 aa = a->rows[0][tid];
+  constexpr int K_FIRST = (BGN_TRIM_PEEL && NP >= 1) ? 1 : 0;     // first row pair of the loops below
+  if constexpr (K_FIRST) {
+    // row pair 0, peeled: its first row creates the accumulators
+    const u64 nx = a->rows[1 < LFp<NL>::NR ? 1 : 0][tid];
+    fp_row_first<NL>(t, (u32)aa, b, P);
+    fp_row<NL>(t, (u32)(aa >> 32), b, P);
+    aa = nx;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) t[j] = 0;
+  }
 #pragma unroll
   for (int iv = 0; iv < NI; ++iv) {
-    if (iv) fp_flush<NL>(t);
+    if (iv) {
+      if constexpr (BGN_TRIM_PARTIAL && NI == 2 && MidFlush<NL, 2 * NPI>::ok)
+        fp_flush_range<NL, MidFlush<NL, 2 * NPI>::LO, MidFlush<NL, 2 * NPI>::HI>(t);
+      else
+        fp_flush<NL>(t);
+    }
     const int k1 = (iv + 1) * NPI < NP ? (iv + 1) * NPI : NP;
 #pragma unroll 1
-    for (int k = iv * NPI; k < k1; ++k) {
+    for (int k = iv * NPI > K_FIRST ? iv * NPI : K_FIRST; k < k1; ++k) {
       const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
       const u64 nx = a->rows[kn][tid];
       fp_row<NL>(t, (u32)aa, b, P);
@@ -470,6 +566,23 @@ __device__ __forceinline__ void fp_row2(u64 (&t)[NL], u32 ai, const Fp<NL>& b, u
   t[0] += c;
 }
 
+template <int NL>
+__device__ __forceinline__ void fp_row2_first(u64 (&t)[NL], u32 ai, const Fp<NL>& b, u32 ci, const Fp<NL>& d,
+                                              const FpParams<NL>* __restrict__ P) {
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] = (u64)ai * b.v[j];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], ci, d.v[j]);
+  const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], m, P->p[j]);
+  const u64 c = t[0] >> LIMB_BITS;
+#pragma unroll
+  for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
+  t[NL - 1] = 0;
+  t[0] += c;
+}
+
 constexpr int kRowsPerFlush2 = LIMB_BITS >= 29 ? 21 : 64;
 
 template <int NL>
@@ -481,16 +594,26 @@ __device__ __forceinline__ void fp_mul2_inl(Fp<NL>& r, const LFp<NL>* a, const F
   constexpr int NPI = (NP + NI - 1) / NI;                        // row pairs per interval
   static_assert(NI == 1 || 2 * NPI + (NL & 1) <= kRowsPerFlush2, "interval too long");
   u64 t[NL];
-#pragma unroll
-  for (int j = 0; j < NL; ++j) t[j] = 0;
   u64 aa = a->rows[0][tid];
   u64 cc = c->rows[0][tid];
+  constexpr int K_FIRST = (BGN_TRIM_PEEL && NP >= 1) ? 1 : 0;
+  if constexpr (K_FIRST) {
+    const u64 nxa = a->rows[1 < LFp<NL>::NR ? 1 : 0][tid];
+    const u64 nxc = c->rows[1 < LFp<NL>::NR ? 1 : 0][tid];
+    fp_row2_first<NL>(t, (u32)aa, b, (u32)cc, d, P);
+    fp_row2<NL>(t, (u32)(aa >> 32), b, (u32)(cc >> 32), d, P);
+    aa = nxa;
+    cc = nxc;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) t[j] = 0;
+  }
 #pragma unroll
   for (int iv = 0; iv < NI; ++iv) {
     if (iv) fp_flush<NL>(t);
     const int k1 = (iv + 1) * NPI < NP ? (iv + 1) * NPI : NP;
 #pragma unroll 1
-    for (int k = iv * NPI; k < k1; ++k) {
+    for (int k = iv * NPI > K_FIRST ? iv * NPI : K_FIRST; k < k1; ++k) {
       const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
       const u64 nxa = a->rows[kn][tid];
       const u64 nxc = c->rows[kn][tid];
@@ -552,14 +675,31 @@ __device__ __forceinline__ void fp_sqr_row(u64 (&t)[NL], u32 ai, const Fp<NL>& a
   t[0] += c;
 }
 
-// rows LO .. HI-1 (LO even; HI even, or HI == NL odd: the last row is then a single one).
-// `aa` carries the prefetched row pair LO/2 in and the next segment's first pair out.
-template <int NL, int LO, int HI>
+// the first row of a squaring (segment [0, HI)): creates the accumulators
+template <int NL, int HI>
+__device__ __forceinline__ void fp_sqr_row_first(u64 (&t)[NL], u32 ai, const Fp<NL>& a1,
+                                                 const FpParams<NL>* __restrict__ P) {
+  const u32 ai2 = ai << 1;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) t[j] = (u64)(j < HI ? ai : ai2) * a1.v[j];
+  const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) acc_mad(t[j], m, P->p[j]);
+  const u64 c = t[0] >> LIMB_BITS;
+#pragma unroll
+  for (int j = 0; j < NL - 1; ++j) t[j] = t[j + 1];
+  t[NL - 1] = 0;
+  t[0] += c;
+}
+
+// rows LO .. HI-1 (LO even; HI even, or HI == NL odd: the last row is then a single one), from row pair K0 on (K0 =
+// LO/2 + 1 after a peeled first pair).  `aa` carries the prefetched row pair K0 in and the next segment's first pair out.
+template <int NL, int LO, int HI, int K0 = LO / 2>
 __device__ __forceinline__ void fp_sqr_segment(u64 (&t)[NL], u64& aa, const LFp<NL>* a, int tid, const Fp<NL>& a1,
                                                const FpParams<NL>* __restrict__ P) {
   static_assert(LO % 2 == 0 && LO < HI && HI <= NL, "segment bounds");
 #pragma unroll 1
-  for (int k = LO / 2; k < HI / 2; ++k) {
+  for (int k = K0; k < HI / 2; ++k) {
     const int kn = (k + 1 < LFp<NL>::NR) ? k + 1 : k;
     const u64 nx = a->rows[kn][tid];
     fp_sqr_row<NL, LO, HI>(t, (u32)aa, a1, P);
@@ -595,8 +735,6 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
     static_assert((kSquareSegments - 1) * Q < NL, "segment layout");
     const int tid = threadIdx.x;
     u64 t[NL];
-#pragma unroll
-    for (int j = 0; j < NL; ++j) t[j] = 0;
     u64 aa = a->rows[0][tid];
     // A row of a squaring adds at most three product units of 2^(2*LIMB_BITS) to an accumulator (one doubled
     // product and one reduction product) and a 64-bit accumulator holds 2^(64 - 2*LIMB_BITS) of them: at radix 2^29
@@ -604,7 +742,17 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
     constexpr int FS = kSquareSegments / 2;
     static_assert(!kNeedsFlush<NL> || (3 * FS * Q < (1 << (64 - 2 * LIMB_BITS)) && 3 * (NL - FS * Q) < (1 << (64 - 2 * LIMB_BITS))),
                   "one flush is enough for the segmented square");
-    fp_sqr_segment<NL, 0, Q>(t, aa, a, tid, av, P);
+    if constexpr (BGN_TRIM_PEEL) {
+      // row pair 0, peeled: its first row creates the accumulators (Q >= 2: the pair lies inside segment 0)
+      const u64 nx = a->rows[1 < LFp<NL>::NR ? 1 : 0][tid];
+      fp_sqr_row_first<NL, Q>(t, (u32)aa, av, P);
+      fp_sqr_row<NL, 0, Q>(t, (u32)(aa >> 32), av, P);
+      aa = nx;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) t[j] = 0;
+    }
+    fp_sqr_segment<NL, 0, Q, BGN_TRIM_PEEL ? 1 : 0>(t, aa, a, tid, av, P);
     if constexpr (kNeedsFlush<NL> && FS == 1) fp_flush<NL>(t);
     if constexpr (kSquareSegments == 2) {
       fp_sqr_segment<NL, Q, NL>(t, aa, a, tid, av, P);

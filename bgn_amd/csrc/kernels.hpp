@@ -116,10 +116,13 @@ struct GtTabRoundArgs {
 };
 
 // Discrete-log decryption and MultPoly accumulation (bsgs.hpp).
+// One 8-byte word per slot (16-byte slots until round 4: the same table now holds twice the baby steps):
+//   0 = empty; bit 63 = occupied; bits 62..33 = 30 tag bits of the hashed fingerprint (the slot index uses other
+//   bits of the same hash); bit 32 = parity(im); bits 31..0 = j (<= 2^31).
+// A probe that matches tag and slot is a candidate only: every hit is verified on all limbs (bsgs.hpp), so a false
+// match (2^-30 per occupied slot probed) costs one verification, never a wrong plaintext.
 struct BsgsSlot {
-  unsigned long long key;   // 0 = empty; bit 63 forced to 1
-  uint32_t check;                // 31 more fingerprint bits; bit 31 = parity(im)
-  uint32_t val;                  // j
+  unsigned long long w;
 };
 
 struct BsgsParams {

@@ -113,13 +113,27 @@ def miller_schedule(n: int, window: int = 5):
     big = sum(1 for x in d[:-1] if abs(x) > 1)
     if window >= 3:
         npts = (1 << (window - 2)) - 1                       # odd multiples 3A .. (2^(w-1) - 1) A
-        pre = 18 + npts * 17 + (npts - 1) * 3                # doubling step, addition steps, products by f_2
+        pre = STEP_DBL[0] + npts * STEP_ADD[0] + (npts - 1) * STEP_MULF[0]   # doubling step, addition steps, products by f_2
         pre += INVERSION_PRODUCTS + 7 * npts + 4 * npts      # shared inversion, peel + coordinates, canonical f_d
         if window >= 4:
             pre += INVERSION_PRODUCTS + 4 + 4                # 2A made affine, canonical f_2
     else:
         pre = 0
     return dbl, add, big, pre
+
+
+# The Miller steps of pairing.hpp since round 5, as (reductions, of which squarings, of which sums of two products
+# with one reduction): a reduction is what every product, squaring or sum ends with (NL^2 multiply-adds), a sum of
+# two products carries a second multiplication (NL^2 more) under the same reduction.
+STEP_DBL = (15, 3, 4)       # ZZ, YY, M^2 squared; M, Y3, F0, F1 sums; Y*Z, Z3*ZZ, cim, ZZ*xB, M*t, Sn, g0, F0*F1 plain
+STEP_ADD = (14, 3, 4)       # ZZ, HH, rr^2 squared; Y3, cre, F0, F1 sums
+STEP_MULF = (2, 0, 2)       # f * f_d: two sums
+TABLE_DBL = (5, 0, 2)       # walk over a normalised line table: a*xC, g0, F0*F1 plain; F0, F1 sums
+TABLE_ADD = (3, 0, 2)
+TABLE_DBL_C = (6, 0, 2)     # ... over a table that keeps its c (MultPoly's per-coefficient tables): + c*yC
+TABLE_ADD_C = (4, 0, 2)
+BUILD_DBL = (10, 3, 2)      # fixed_build_double: ZZ, YY, M^2 squared; M, Y3 sums; YZ, a, b, c, Sn plain
+BUILD_ADD = (11, 3, 2)      # fixed_build_add: ZZ, HH, rr^2 squared; b, Y3 sums
 
 
 # One F_p inversion by division steps (fpinv.hpp) costs about as much as 55 field products (measured).
@@ -135,12 +149,30 @@ def limbs_for(p: int) -> int:
     return next(x for x in (3, 10, 19, 36, 37, 72) if x >= need)
 
 
-def flush_instructions(nl: int) -> int:
-    """The mid-product carry passes of fp_mul / fp_sqr at radix 2^29 (fpmont.hpp fp_flush: add, mask, shift per
-    accumulator): a product runs in NI = ceil(NL / kRowsPerFlush) intervals of at most 19 rows with a flush between
-    them — none up to 19 limbs, one at 36 / 37, three at 72; counted with the multiply-adds of a product (same issue
-    cost)."""
-    return 3 * nl * (-(-nl // 19) - 1)
+def flush_instructions(nl: int, plain_product: bool = False) -> int:
+    """The mid-product carry passes at radix 2^29 (fpmont.hpp fp_flush: add, mask, shift per accumulator): a product
+    runs in NI = ceil(NL / kRowsPerFlush) intervals of at most 19 rows (21 for a sum of two products) with a flush
+    between them — none up to 19 limbs, one at 36 / 37, three at 72; counted with the multiply-adds of a product (same
+    issue cost).  A plain product with ONE flush (36 / 37 limbs) carries out only the accumulators that live longer
+    than 31 rows (fpmont.hpp MidFlush, BGN_TRIM_PARTIAL: nine at 36 limbs, eleven at 37)."""
+    ni = -(-nl // 19)
+    if ni <= 1:
+        return 0
+    if plain_product and ni == 2:
+        done = 2 * (-(-(nl // 2) // 2))
+        lo, last = max(0, 31 - done), 2 * nl - 33 - done
+        return 3 * (min(last + 1, nl - 1) - lo)
+    return 3 * nl * (ni - 1)
+
+
+def product_mads(nl: int) -> int:
+    """One Montgomery product: NL^2 multiply-adds of a*b, NL^2 of the reduction, its flush."""
+    return 2 * nl * nl + flush_instructions(nl, plain_product=True)
+
+
+def sop_mads(nl: int) -> int:
+    """a*b + c*d with one reduction (fp_mul2): three times NL^2 and one full flush."""
+    return 3 * nl * nl + flush_instructions(nl)
 
 
 def square_mads(nl: int, segments: int = 5) -> int:
@@ -159,18 +191,27 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: i
     (schoolbook product + Montgomery reduction rows; + the 3*NL instructions of the mid-product flush at 36 / 37
     limbs), squarings at the segmented square's count.
     The F_p inversion of the final exponentiation is shared by `run` pairings per lane."""
-    p, n, l = int(fx["p"], 16), int(fx["n"], 16), int(fx["l"])
-    nl = limbs_for(p)
+    return int(mads_from_counts(*pairing_counts(fx, run, window), limbs_for(int(fx["p"], 16)), segments))
+
+
+def pairing_counts(fx, run: int = 16, window: int = 5):
+    """(reductions, squarings, sums of two products) of one pairing of k_pairing<NL, 0>: the windowed Miller loop of
+    pairing.hpp with round 5's step programs (STEP_*), norms (both passes), the shared inversion's peel,
+    conj(f)^2 / N, ^l and the conversions out of Montgomery form."""
+    n, l = int(fx["n"], 16), int(fx["l"])
     dbl, add, threes, pre = miller_schedule(n, window)
     lb = l.bit_length()
     lpow = (lb - 1) * 2 + (bin(l).count("1") - 1) * 3     # F_p^2 squarings / products of ^l (no field squarings)
-    # Miller + norms (both passes) + peel + conj(f)^2/N + ^l + from_mont
-    per_pairing = pre + dbl * 18 + add * 17 + threes * 3 + 2 * 2 + 3 + 5 + lpow + 2
-    # of which field squarings: 6 per doubling step, 3 per addition step (pairing.hpp), 9 in the set-up of the
-    # windowed loop, 4 + 2 in the norms / conj(f)^2
-    squares = dbl * 6 + add * 3 + ((6 + 3 * ((1 << (window - 2)) - 1) + 3) if window >= 3 else 0) + 6
-    products = per_pairing + INVERSION_PRODUCTS / run
-    return int((products - squares) * (2 * nl * nl + flush_instructions(nl)) + squares * square_mads(nl, segments))
+    npts = ((1 << (window - 2)) - 1) if window >= 3 else 0
+    red = pre + dbl * STEP_DBL[0] + add * STEP_ADD[0] + threes * STEP_MULF[0] + 2 * 2 + 3 + 5 + lpow + 2
+    # field squarings: in the steps, in the set-up of the windowed loop (its steps + z^2 of every affine
+    # conversion), 4 + 2 in the norms / conj(f)^2
+    squares = dbl * STEP_DBL[1] + add * STEP_ADD[1] + 6
+    sops = dbl * STEP_DBL[2] + add * STEP_ADD[2] + threes * STEP_MULF[2]
+    if window >= 3:
+        squares += STEP_DBL[1] + npts * STEP_ADD[1] + (npts + 1)
+        sops += STEP_DBL[2] + npts * STEP_ADD[2] + (npts - 1) * STEP_MULF[2]
+    return red + INVERSION_PRODUCTS / run, float(squares), float(sops)
 
 
 # ---- field products per unit of the other operations (DESIGN.md section 5) -----------------------------------------
@@ -178,8 +219,10 @@ def algorithmic_mads_per_pairing(fx, run: int = 16, window: int = 5, segments: i
 # 32x32->64 multiply-adds — a general product at 2*NL^2, a squaring at the segmented square's count — which is what
 # bench.py holds against the measured v_mad_u64_u32 issue peaks (roofline_valu).  An F_p inversion by division steps
 # is priced as INVERSION_PRODUCTS general products (its multiply-adds are of the same instruction, fpinv.hpp).
-def mads_from_counts(products: float, squares: float, nl: int = 36, segments: int = 5) -> float:
-    return (products - squares) * (2 * nl * nl + flush_instructions(nl)) + squares * square_mads(nl, segments)
+def mads_from_counts(products: float, squares: float, sops: float = 0.0, nl: int = 36, segments: int = 5) -> float:
+    """products = everything that ends in a reduction (plain products, squarings, sums of two products); squares and
+    sops say how many of them are which."""
+    return ((products - squares - sops) * product_mads(nl) + squares * square_mads(nl, segments) + sops * sop_mads(nl))
 
 
 def _run_for(count: int) -> int:
@@ -190,7 +233,7 @@ def _run_for(count: int) -> int:
 def eadd_counts(count: int):
     """Affine addition with Montgomery's trick over a lane's run: 7 products (one of them lambda^2) + one inversion
     per run."""
-    return 7 + INVERSION_PRODUCTS / _run_for(count), 1.0
+    return 7 + INVERSION_PRODUCTS / _run_for(count), 1.0, 0.0
 
 
 def eadd_products(count: int) -> float:
@@ -201,7 +244,7 @@ def encrypt_counts(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 2
     """Fixed-base product P^m * Q^r: one affine addition per window (four accumulation chains, runs of 64) and
     three more to sum the chains; one squaring (lambda^2) per addition."""
     windows = -(-x_bits // wbits_p) + -(-r_bits // wbits_q)
-    return (windows + 3) * (7 + INVERSION_PRODUCTS / 64), float(windows + 3)
+    return (windows + 3) * (7 + INVERSION_PRODUCTS / 64), float(windows + 3), 0.0
 
 
 def encrypt_products(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20) -> float:
@@ -215,8 +258,8 @@ def _naf_counts(n: int):
 
 def decrypt_counts(fx, baby_steps: int, level: int = 1):
     """Decrypt (bgn.go:218-250): level 1 lifts with the Miller loop over the normalised line table of q1*P along
-    the NAF of q2 = n/q1 (6 / 4 products per doubling / addition step, none of them a field squaring: f^2 is two
-    general products) and the final exponentiation (F0^2, F1^2 of the norm are squarings); both levels raise to q1
+    the NAF of q2 = n/q1 (5 / 3 reductions per doubling / addition step, two of them sums of two products — f*l —,
+    none of them a field squaring: f^2 is two general products) and the final exponentiation (F0^2, F1^2 of the norm are squarings); both levels raise to q1
     on the norm-1 ladder (per bit one squaring A_j^2 and one product, one inversion for the imaginary part) and
     walk G giant steps at 1.1 products each (bsgs.hpp)."""
     import math
@@ -227,12 +270,14 @@ def decrypt_counts(fx, baby_steps: int, level: int = 1):
     G = (mmax + S) // (2 * S) + 1
     prods = 2 * q1.bit_length() + INVERSION_PRODUCTS + 1.1 * G + 40
     squares = float(q1.bit_length())
+    sops = 0.0
     if level == 1:
         dbl, add = _naf_counts(n // q1)
         lb = l.bit_length()
-        prods += dbl * 6 + add * 4 + 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
+        prods += dbl * TABLE_DBL[0] + add * TABLE_ADD[0] + 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
         squares += 4
-    return prods, squares
+        sops += dbl * TABLE_DBL[2] + add * TABLE_ADD[2]
+    return prods, squares, sops
 
 
 def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
@@ -241,21 +286,23 @@ def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
 
 def multpoly_counts_per_pair(fx, d: int):
     """MultPoly of two d-coefficient polynomials (d a power of two >= 2) per coefficient pair: Karatsuba levels
-    down to 2x2 products, each 4 evaluations over a per-coefficient line table (7 / 5 per step + final
-    exponentiation; squarings only in the norm) and 2 table builds (11.5 per step; the point arithmetic of a
-    doubling has 6 squarings, of an addition 3)."""
+    down to 2x2 products, each 4 evaluations over a per-coefficient line table (6 / 4 reductions per step, two of them
+    sums of two products, + final exponentiation; squarings only in the norm) and 2 table builds (10 / 11 reductions
+    per doubling / addition step, three of them squarings, two of them sums)."""
     n, l = int(fx["n"], 16), int(fx["l"])
     dbl, add = _naf_counts(n)
     lb = l.bit_length()
     fe = 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
-    ev = dbl * 7 + add * 5 + fe
-    build = (dbl + add) * 11.5
+    ev = dbl * TABLE_DBL_C[0] + add * TABLE_ADD_C[0] + fe
+    build = dbl * BUILD_DBL[0] + add * BUILD_ADD[0]
     leaves = 1
     k = d
     while k > 2:
         leaves *= 3
         k //= 2
-    return leaves * (4 * ev + 2 * build) / (d * d), leaves * (4 * 4 + 2 * (dbl * 6 + add * 3)) / (d * d)
+    per = leaves / (d * d)
+    return (per * (4 * ev + 2 * build), per * (4 * 4 + 2 * (dbl * BUILD_DBL[1] + add * BUILD_ADD[1])),
+            per * (4 * (dbl * TABLE_DBL_C[2] + add * TABLE_ADD_C[2]) + 2 * (dbl * BUILD_DBL[2] + add * BUILD_ADD[2])))
 
 
 def multpoly_products_per_pair(fx, d: int) -> float:

@@ -88,9 +88,10 @@ const char* bgn_version(void);
  * Default sizes are a function of the key, of T and of the device's TOTAL memory — not of what happens to be free —
  * and sit at the knee of the measured curves, not at their end (1024-bit key, T = 2^40, MI355X; round 4 defaulted to
  * the maxima, 175 GB for one key):
- *   baby-step table   32 B per baby step, 2^ceil(log2(B*B + B + 3)) steps, at most 2^30 (34 GB): 1.59e6 decrypts/s at
- *                     2^20 ciphertexts.  What the neighbours buy (profiles/r04_decrypt_vs_table.csv): 2^31 steps, 69 GB,
- *                     +8 % (option bsgs_max_log2 = 31); 2^29, 17 GB, -14 %; 2^28, 8.6 GB, -33 %
+ *   baby-step table   16 B per baby step (two 8-byte slots; 32 B until round 4), 2^ceil(log2(B*B + B + 3)) steps, at
+ *                     most 2^31 (34 GB — what round 4 paid 69 GB for).  What fewer steps cost
+ *                     (profiles/r04_decrypt_vs_table.csv, option bsgs_max_log2): 2^30, 17 GB, -8 % decrypts/s;
+ *                     2^29, 8.6 GB, -21 %; 2^28, 4.3 GB, -38 %
  *   windows of Q      20-bit windows, 16 GB: 1.72e7 encrypts/s.  22 bits, 58 GB, +6 % (option fixed_window_bits_q =
  *                     22); 18 bits, 4.4 GB, -6 %; 16 bits, 1.2 GB, -11 % (profiles/r04_encrypt_vs_window.csv)
  *   windows of P      16-bit windows, 2 * NL * 4 B per entry (1.2 GB); the GT table of e(Q,Q) likewise

@@ -76,6 +76,24 @@ struct Emu {
     fp_inv_mont<NL>(r, x, p_bits, P, lds());
     memcpy(out, r.v, 4 * NL);
   }
+  // the three product forms of fpmont.hpp on raw limb patterns (tight limbs, values may exceed p): a*b, a*a, a*b + c*d
+  static void fp_products(const u32* params, const u32* a, const u32* b, const u32* c, const u32* d, u32* out) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    LFp<NL>* L = lds();
+    Fp<NL> x, y, z, w, r;
+    memcpy(x.v, a, 4 * NL);
+    memcpy(y.v, b, 4 * NL);
+    memcpy(z.v, c, 4 * NL);
+    memcpy(w.v, d, 4 * NL);
+    l_store(L, x);
+    fp_mul<NL>(r, L, y, P);
+    memcpy(out, r.v, 4 * NL);
+    fp_sqr<NL>(r, L, x, P);
+    memcpy(out + NL, r.v, 4 * NL);
+    l_store(L + 1, z);
+    fp_mul2<NL>(r, L, y, L + 1, w, P);
+    memcpy(out + 2 * NL, r.v, 4 * NL);
+  }
   static void pairing(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
     EmuChecks on;
     const FpParams<NL>* P = (const FpParams<NL>*)params;
@@ -428,5 +446,6 @@ int emu_fixed_normalize(int nl, const u32* params, const void* C, u32* tab, size
 int emu_fp_inv(int nl, const u32* params, int p_bits, const u32* a, u32* out) { DISPATCH(nl, fp_inv(params, p_bits, a, out)) }
 int emu_gt_tab_build(int nl, const u32* params, int wbits, int windows, const u32* g, u32* tab) { DISPATCH(nl, gt_tab_build(params, wbits, windows, g, tab)) }
 int emu_gt_fixed(int nl, const u32* params, const u32* tab, int wbits, const uint8_t* k, size_t klen, const u32* R, u32* out) { DISPATCH(nl, gt_fixed(params, tab, wbits, k, klen, R, out)) }
+int emu_fp_products(int nl, const u32* params, const u32* a, const u32* b, const u32* c, const u32* d, u32* out) { DISPATCH(nl, fp_products(params, a, b, c, d, out)) }
 size_t emu_consts_size() { return sizeof(PairingConsts); }
 }

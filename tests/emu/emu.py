@@ -103,6 +103,16 @@ class Emu:
     def from_fixture(cls, fx):
         return cls(int(fx["p"], 16), int(fx["n"], 16), fx["l"])
 
+    def fp_products(self, a: int, b: int, c: int, d: int):
+        """(a*b/R, a*a/R, (a*b + c*d)/R) by fp_mul, fp_sqr, fp_mul2 on the raw values a..d < 2^(LIMB*nl) (tight limbs,
+        not necessarily below p); results as integers (lazy: below 2p when the operands' bounds allow)."""
+        nl = self.nl
+        arr = lambda v: (C.c_uint32 * nl)(*limbs(v, nl))
+        out = (C.c_uint32 * (3 * nl))()
+        assert self.lib.emu_fp_products(nl, self.params, arr(a), arr(b), arr(c), arr(d), out) == 0
+        val = lambda k: sum(int(out[k * nl + j]) << (LIMB * j) for j in range(nl))
+        return val(0), val(1), val(2)
+
     # wire <-> internal
     def decode(self, wire: bytes):
         out = (C.c_uint32 * (2 * self.nl))()

@@ -114,3 +114,50 @@ def test_no_gpu_is_an_error_not_a_cpu_run():
                        timeout=300)
     assert r.returncode != 0
     assert "needs a GPU" in r.stderr or "No HIP GPUs" in r.stderr or "BGN_E_HIP" in r.stderr or "hip" in r.stderr.lower()
+
+
+def test_eight_ranks_one_dying_mid_gather_and_one_overrunning_the_cap(monkeypatch, tmp_path):
+    """The driver's 8-GPU shape with real child processes: (1) eight ranks that all finish: rendezvous environment of
+    every rank, one shared port, exit 0; (2) rank 5 dies while the other seven sit in their 'all-gather' (a long
+    sleep): non-zero exit within seconds, all seven gone; (3) rank 6 never finishes: the wall-clock cap ends all eight."""
+    import json
+    import time
+    bench = _load()
+    # (1)
+    script = (
+        "import os, json\n"
+        "d = {k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')}\n"
+        "open(os.path.join(%r, 'rank%%s.json' %% os.environ['RANK']), 'w').write(json.dumps(d))\n" % str(tmp_path))
+    _children(monkeypatch, bench, script)
+    assert bench.spawn_ranks(8, ["--gpus", "8"], timeout_s=120) == 0
+    envs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(8)]
+    assert [e["RANK"] for e in envs] == [str(r) for r in range(8)] and {e["WORLD_SIZE"] for e in envs} == {"8"}
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and {e["MASTER_ADDR"] for e in envs} == {"127.0.0.1"}
+    assert {e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in envs} == {"0"}
+    # (2)
+    script = (
+        "import os, sys, time\n"
+        "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "if os.environ['RANK'] == '5':\n"
+        "    time.sleep(1.0)\n"
+        "    sys.exit(7)\n"
+        "time.sleep(120)\n" % str(tmp_path))
+    _children(monkeypatch, bench, script)
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(8, [], timeout_s=100) == 7
+    assert time.monotonic() - t0 < 30
+    for r in range(8):
+        if r != 5:
+            with pytest.raises(ProcessLookupError):
+                os.kill(int(open(tmp_path / ("pid%d" % r)).read()), 0)
+    # (3)
+    script = (
+        "import os, time\n"
+        "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "time.sleep(120 if os.environ['RANK'] == '6' else 0.2)\n" % str(tmp_path))
+    _children(monkeypatch, bench, script)
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(8, [], timeout_s=3.0) == 124
+    assert time.monotonic() - t0 < 30
+    with pytest.raises(ProcessLookupError):
+        os.kill(int(open(tmp_path / "pid6").read()), 0)

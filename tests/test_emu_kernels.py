@@ -313,3 +313,31 @@ def test_emu_step_programs_at_the_product_limb_counts(name):
     v = rows[0]
     tb = E.fixed_table(cts[v["a"]], 2, 1)
     assert E.pairing_fixed(tb, cts[v["b"]], 2, 1).hex() == v["out"]
+
+
+@pytest.mark.parametrize("name", ["toy64", "k256", "k512", "k1024", "k1024b", "k2048"])
+def test_emu_products_at_extreme_limbs(name):
+    """fp_mul, fp_sqr and fp_mul2 on operands whose limbs are all ones (every column of the schoolbook at its
+    maximum), alternating, and a lone top limb — the patterns that decide whether a flush interval, the partial
+    mid-product flush of fp_mul (nine accumulators at 36 limbs) and the peeled first row are right.  The emulation
+    aborts on an accumulator that would wrap; the values are compared with Python integers."""
+    fx = load_fixture(name)
+    E = emu.Emu.from_fixture(fx)
+    p, nl = E.p, E.nl
+    R = 1 << (emu.LIMB * nl)
+    Rinv = pow(R, -1, p)
+    ones = (1 << (p.bit_length() - 1)) - 1                                # below p, every limb under its top bit all ones
+    full = (1 << p.bit_length()) - 1 if (1 << p.bit_length()) - 1 < 2 * p else 2 * p - 1    # the same one bit longer: < 2p
+    stripes = sum(emu.MASK << (emu.LIMB * j) for j in range(0, nl, 2))
+    alt = ones & stripes
+    lone = 1 << (p.bit_length() - 1)
+    rng = random.Random(nl)
+    pats = [full, ones, alt, ones & ~stripes, lone, p - 1, 2 * p - 1, 1, 0, rng.randrange(p)]
+    assert all(0 <= v < 2 * p for v in pats)
+    for a in pats:
+        for b in pats[:7]:
+            c, d = b, a
+            m, sq, m2 = E.fp_products(a, b, c, d)
+            assert m % p == a * b * Rinv % p and m < 2 * p, (name, "fp_mul")
+            assert sq % p == a * a * Rinv % p and sq < 2 * p, (name, "fp_sqr")
+            assert m2 % p == (a * b + c * d) * Rinv % p and m2 < 2 * p, (name, "fp_mul2")

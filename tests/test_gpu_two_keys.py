@@ -120,9 +120,9 @@ def test_default_footprint_one_key_after_encrypt_decrypt_multpoly_and_two_keys_w
     torch.cuda.synchronize()
     after_encrypt = eng.memory_bytes()
     assert 14 * GB < after_encrypt < 24 * GB, after_encrypt     # 15.7 GB for Q, 1.2 GB for P, the workspace
-    # Decrypt: the baby-step table is 2^30 entries by default
+    # Decrypt: the baby-step table is 2^31 entries of 16 B by default (34 GB)
     pk.SetupDecryption(sk)
-    assert int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h)) == 1 << 30
+    assert int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h)) == 1 << 31
     ms = [0, 1, T - 1, rng.randrange(T), rng.randrange(T)]
     enc = eng.encrypt(ms, [rng.randrange(n) for _ in ms])
     m, st = eng.decrypt(1, enc.tobytes())
@@ -151,7 +151,7 @@ def test_default_footprint_one_key_after_encrypt_decrypt_multpoly_and_two_keys_w
     eng.set_option("resident_cap_mb", -1)
     eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
     torch.cuda.synchronize()
-    assert eng.memory_bytes() > held + 30 * GB
+    assert eng.memory_bytes() > held + 20 * GB        # (the tables of one chunk: 26 - 38 GB, by what is free)
     eng.set_option("resident_cap_mb", 0)
     eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
     torch.cuda.synchronize()
@@ -160,7 +160,9 @@ def test_default_footprint_one_key_after_encrypt_decrypt_multpoly_and_two_keys_w
     fx2 = load_fixture("k1024b")
     pk2, sk2 = fresh_key(fx2)
     pk2.SetupDecryption(sk2)
-    assert int(pk2.engine._lib.bgn_ctx_bsgs_baby_steps(pk2.engine._h)) == 1 << 30
+    # (2^31 baby steps where half of what is free holds them — a fresh process — and 2^30 behind the other tests'
+    # cached contexts: free memory only clamps)
+    assert int(pk2.engine._lib.bgn_ctx_bsgs_baby_steps(pk2.engine._h)) in (1 << 30, 1 << 31)
     rows = [dd for dd in fx2["decrypt"] if dd["level"] == 1]
     m2, st2 = pk2.engine.decrypt(1, H([dd["ct"] for dd in rows]))
     assert st2.tolist() == [0] * len(rows) and m2.tolist() == [dd["m"] for dd in rows]

@@ -2,7 +2,7 @@
 """What the default sizes of the per-key tables buy (include/bgn_amd.h "Device memory"), 1024-bit key, T = 2^40:
 
   * Decrypt against the baby-step table: decrypts/s at 2^16 and 2^20 ciphertexts (level 1, the bench's mixed batch) and
-    the set-up time for tables of 2^24 .. 2^31 entries (option bsgs_max_log2; 32 B per entry) — the walk is
+    the set-up time for tables of 2^24 .. 2^31 entries (option bsgs_max_log2; 16 B per entry since round 5) — the walk is
     T / (2 S) products per ciphertext beside a lift of ~3.8 k products;
   * Encrypt against the window width of Q's table (option fixed_window_bits_q: 16 .. 22 bits; a fresh context each,
     the tables are built on first use).
@@ -66,7 +66,7 @@ def decrypt_sweep(fx, dev):
             dt = best(lambda: eng.decrypt_dev(1, mixed[: cnt * EB], m, st, cnt), 2)
             ok = bool((m[:cnt].cpu() == want[:cnt]).all().item()) and bool((st[:cnt].cpu() == want_st[:cnt]).all().item())
             T = int(fx["msg_space"])
-            print("%s,%d,%d,%.2f,%.2f,%d,%.2f,%.0f,%d,%s" % (fx["name"], T.bit_length() - 1, S.bit_length() - 1, 32.0 * S / 1e9, setup,
+            print("%s,%d,%d,%.2f,%.2f,%d,%.2f,%.0f,%d,%s" % (fx["name"], T.bit_length() - 1, S.bit_length() - 1, 16.0 * S / 1e9, setup,
                                                           cnt, dt * 1e3, cnt / dt, T // (2 * S) + 1, ok), flush=True)
 
 

@@ -20,8 +20,7 @@ def last_json_line(path):
 
 shutil.copy(os.path.join(src, "prof_bench", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "prof_extra", "extra_kernel_stats.csv"), os.path.join(dst, f"{tag}_extra_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "small_batch.csv"), os.path.join(dst, f"{tag}_small_batch.csv"))
-for extra_csv in ("mid_batch.csv", "quad_saturated.csv", "single_op_latency.csv", "concurrent_callers.csv", "multconst_mid_batch.csv",
+for extra_csv in ("small_batch.csv", "mid_batch.csv", "quad_saturated.csv", "single_op_latency.csv", "concurrent_callers.csv", "multconst_mid_batch.csv",
                   "eadd_sweep.csv", "decrypt_vs_table.csv", "encrypt_vs_window.csv", "calibrate.csv"):
     if os.path.exists(os.path.join(src, extra_csv)):
         shutil.copy(os.path.join(src, extra_csv), os.path.join(dst, f"{tag}_{extra_csv}"))
@@ -63,6 +62,31 @@ for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE"
 if len(lift) == 2:
     summary["decrypt_lift_k_pairing_1"] = dict(lift, hbm_bytes_per_launch=(lift["FETCH_SIZE"]["avg"] + lift["WRITE_SIZE"]["avg"]) * 1024,
                                                   note="the longest launches of this kernel in the run: the lift of the 2^20 Decrypt of bench.py's extras")
+# ... and the lift of the 2^16 Decrypt (configs[3]'s own batch size): one launch of 65536 lanes whose duration is the
+# lift time the bench line of the SAME profiled run reports for it (MultPoly's walks use this kernel too, over the
+# 1024-bit loop: about twice as long)
+lift16 = {}
+for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE", "pmc_write_extra", "write")):
+    path = os.path.join(src, sub, f"{stem}_counter_collection.csv")
+    jpath = os.path.join(src, sub + ".json")
+    if not (os.path.exists(path) and os.path.exists(jpath)):
+        continue
+    try:
+        want_ms = last_json_line(jpath)["extra"]["decrypt"]["roofline"]["kernel_ms"]
+    except (KeyError, IndexError):
+        continue
+    rows = [r for r in csv.DictReader(open(path)) if LANE1.match(r["Kernel_Name"]) and r["Counter_Name"] == ctr
+            and int(r["Grid_Size"]) == 65536]
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    sel = [r for r in rows if abs(dur(r) - want_ms) <= 0.2 * want_ms]
+    if sel:
+        vals = [float(r["Counter_Value"]) for r in sel]
+        lift16[ctr] = {"launches": len(vals), "avg": sum(vals) / len(vals), "grid": 65536, "avg_ms": sum(dur(r) for r in sel) / len(sel),
+                       "bench_line_kernel_ms": want_ms}
+if len(lift16) == 2:
+    summary["decrypt_lift_2^16"] = dict(lift16, hbm_bytes_per_launch=(lift16["FETCH_SIZE"]["avg"] + lift16["WRITE_SIZE"]["avg"]) * 1024,
+                                        note="the lift of bench.py's 2^16 Decrypt: the 65536-lane launches of k_pairing<NL, 1> whose duration "
+                                             "matches the lift time of the same run's bench line")
 # One EAdd call of the extras (wire bytes to wire bytes at 2^20): its four launches are k_decode_plain x 2, k_g1_add,
 # k_encode in consecutive dispatches (k_decode_plain is used by Add / Sub / Neg only; Neg has no k_g1_add behind it).
 eadd = {}
@@ -112,10 +136,26 @@ if len(eadd) == 2:
                               hbm_bytes_per_call=(eadd["FETCH_SIZE"]["kb_per_call"] * fetch_factor + eadd["WRITE_SIZE"]["kb_per_call"]) * 1024,
                               note="one bgn_add_batch_dev of 2^20 level-1 ciphertexts (bench.py extras): k_decode_plain x 2, k_g1_add, k_encode; "
                                    "hbm_bytes_per_call = FETCH_SIZE x fetch_calibration.factor + WRITE_SIZE")
-if "decrypt_lift_k_pairing_1" in summary:
-    lf = summary["decrypt_lift_k_pairing_1"]
-    lf["hbm_bytes_per_launch_raw"] = lf["hbm_bytes_per_launch"]
-    lf["hbm_bytes_per_launch"] = (lf["FETCH_SIZE"]["avg"] * fetch_factor + lf["WRITE_SIZE"]["avg"]) * 1024
+for key in ("decrypt_lift_k_pairing_1", "decrypt_lift_2^16"):
+    if key in summary:
+        lf = summary[key]
+        lf["hbm_bytes_per_launch_raw"] = lf["hbm_bytes_per_launch"]
+        lf["hbm_bytes_per_launch"] = (lf["FETCH_SIZE"]["avg"] * fetch_factor + lf["WRITE_SIZE"]["avg"]) * 1024
+# where the headline kernel's requests are served: L1 -> L2 requests, L2 hits / misses, memory-side requests
+cache = {}
+for sub in ("cache_1", "cache_2"):
+    path = os.path.join(src, sub, "c_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    rows = [r for r in csv.DictReader(open(path)) if LANE0.match(r["Kernel_Name"])]
+    for name in sorted({r["Counter_Name"] for r in rows}):
+        vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name]
+        cache[name] = sum(vals) / len(vals)
+if cache:
+    if cache.get("TCC_HIT_sum") is not None and cache.get("TCC_MISS_sum") is not None and cache["TCC_HIT_sum"] + cache["TCC_MISS_sum"] > 0:
+        cache["l2_hit_rate"] = cache["TCC_HIT_sum"] / (cache["TCC_HIT_sum"] + cache["TCC_MISS_sum"])
+    cache["note"] = "per launch of 2^20 pairings of the headline kernel (average over the launches of the pass)"
+    summary["headline_cache_counters"] = cache
 line = last_json_line(os.path.join(src, "bench_line.json"))
 alg = line["roofline"]["algorithmic_bytes_per_pairing"] * line["config"]["batch_per_gpu"]
 total_raw = (summary["FETCH_SIZE"]["avg"] + summary["WRITE_SIZE"]["avg"]) * 1024

@@ -63,8 +63,9 @@ rows = [
      f"{ex['eadd_l1']['value']:.3g} /s = {ex['eadd_l1']['hbm']['achieved_GBps']:.0f} GB/s of wire traffic ({ex['eadd_l1']['hbm']['frac']:.3f} of HBM "
      f"peak), {rv(ex['eadd_l1'])['frac_at_1_wave_per_simd']:.2f} / {rv(ex['eadd_l1'])['frac']:.2f} of the two issue ceilings at "
      f"{ex['eadd_l1']['products_per_unit']:.1f} product-equivalents per addition"),
-    ("MultPoly 16×16, 4096 polynomials", f"{ex['multpoly']['value']:.3g} coefficient pairs/s ({rv(ex['multpoly'])['frac_at_1_wave_per_simd']:.2f} / "
-                                         f"{rv(ex['multpoly'])['frac']:.2f} of the two issue ceilings)"),
+    ("MultPoly 16×16, %d polynomials%s" % (ex['multpoly'].get('polys', 4096), " + one AddPoly (configs[4] at its stated size)" if ex['multpoly'].get('polys', 0) >= 1 << 14 else ""),
+     f"{ex['multpoly']['value']:.3g} coefficient pairs/s ({rv(ex['multpoly'])['frac_at_1_wave_per_simd']:.2f} / "
+     f"{rv(ex['multpoly'])['frac']:.2f} of the two issue ceilings)" + (f", {ex['multpoly']['ms_per_step']:.0f} ms per step" if 'ms_per_step' in ex['multpoly'] else "")),
     ("configs[0]: 512-bit, 128 ciphertexts, host buffers",
      f"EMult **{c0['emult']['value']:.3g} ops/s** ({c0['emult']['wall_ms_for_128']:.2f} ms for the 128; C oracle on one host thread "
      f"{c0['emult'].get('cpu_single_thread_ops_per_s', 0):.0f}); EAdd {c0['eadd']['value']:.3g} ops/s; one Mult: {c0['emult_count1_latency_ms']:.2f} ms"),
@@ -129,6 +130,33 @@ if mc:
                 cells.append("level %d, %d-bit scalars — %s" % (level, bits, ", ".join(seg)))
     rows.append(("MultConst with per-element scalars by batch size, ms: lane groups (cut into lane rounds + remainder above 65536) / one "
                  "element per lane (`profiles/%s_multconst_mid_batch.csv`)" % tag, "; ".join(cells)))
+# ---- round 5 additions ----
+legs = []
+for key, label, unit in (("encrypt", "Encrypt", "encrypts"), ("eadd_l1", "EAdd", "adds"), ("multpoly", "MultPoly", "polynomial products")):
+    b = ex.get(key, {}).get("cpu_baseline")
+    if b:
+        legs.append("%s %.3g %s/s on %d cores (%.3g on one thread; bytes equal: %s)" % (label, b["value"], unit, b["cores"], b["single_thread_per_s"], b["matches_gpu_bit_exact"]))
+if legs:
+    rows.append(("CPU baselines of the secondaries (C oracle on the first items of the GPU's own batch, `cores` = min(affinity, cgroup quota))", "; ".join(legs)))
+cachec = pmc.get("headline_cache_counters")
+if cachec:
+    rows.append(("where `%s`'s memory requests are served, per launch of 2²⁰ pairings (`profiles/%s_pmc_summary.json` `headline_cache_counters`)" % (kern, tag),
+                 "L1 → L2 read requests %.3g, write requests %.3g; L2 hits %.3g / misses %.3g = **%.1f %% hit rate**; memory-side read requests %.3g, write requests %.3g" %
+                 (cachec.get("TCP_TCC_READ_REQ_sum", 0), cachec.get("TCP_TCC_WRITE_REQ_sum", 0), cachec.get("TCC_HIT_sum", 0), cachec.get("TCC_MISS_sum", 0),
+                  100 * cachec.get("l2_hit_rate", 0), cachec.get("TCC_EA0_RDREQ_sum", 0), cachec.get("TCC_EA0_WRREQ_sum", 0))))
+l16 = pmc.get("decrypt_lift_2^16")
+if l16:
+    rows.append(("Decrypt at 2¹⁶ (configs[3]'s own batch), HBM-side traffic of the lift",
+                 "%.3g B per launch of 65 536 lifts = %.1f × the algorithmic bytes (%.1f ms by the counter pass's timestamps, %.1f ms in the same run's bench line)" %
+                 (l16["hbm_bytes_per_launch"], l16["hbm_bytes_per_launch"] / (d["decrypt"]["algorithmic_bytes_per_unit"] * 65536), l16["FETCH_SIZE"]["avg_ms"], l16["FETCH_SIZE"]["bench_line_kernel_ms"])))
+mixp = P("instruction_mix.json")
+if os.path.exists(mixp):
+    mix = json.load(open(mixp)).get("one pairing per lane")
+    if mix:
+        rows.append(("instruction mix of `%s` (`profiles/%s_instruction_mix.json`)" % (kern, tag),
+                     "%.1f M VALU lane-instructions per pairing (%.1f M of them the model's multiply-adds: %.0f %%) at %.0f G wave-instructions/s; wave cycles: VALU issuing %.0f %%, `SQ_WAIT_ANY` %.0f %%, `SQ_WAIT_INST_ANY` %.0f %%" %
+                     (mix["valu_lane_instructions_per_pairing"] / 1e6, rv(d)["mads_per_pairing"] / 1e6, 100 * rv(d)["mads_per_pairing"] / mix["valu_lane_instructions_per_pairing"],
+                      mix["chip_valu_Ginstr_per_s"], 100 * mix["frac_wave_cycles"]["SQ_ACTIVE_INST_VALU"], 100 * mix["frac_wave_cycles"]["SQ_WAIT_ANY"], 100 * mix["frac_wave_cycles"]["SQ_WAIT_INST_ANY"])))
 dcb = d.get("decrypt", {}).get("cpu_baseline")
 if dcb:
     rows.append(("CPU baseline of Decrypt (C oracle, same ciphertexts, plaintexts and statuses equal)",
@@ -166,7 +194,7 @@ cmd_bench = "`rocprofv3 --kernel-trace --stats --output-format csv -- python3 be
 cmd_pmc = "`rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra` (and `WRITE_SIZE`), separate passes, no tracing"
 readme_rows = [
     (f"`{tag}_bench_line.json`, `{tag}_bench_line_profiled.json`, `{tag}_bench_kernel_stats.csv`, `{tag}_extra_kernel_stats.csv`",
-     f"round {int(tag[1:])} (`tools/collect_profiles.sh`): `{kern}` avg {float(kp['AverageNs']) / 1e6:.1f} ms per 2^20 pairings (rocprofv3, {kp['Calls']} launches) / "
+     f"round {int(tag[1:])} (`tools/collect_profiles{'_r05' if tag == 'r05' else ''}.sh`): `{kern}` avg {float(kp['AverageNs']) / 1e6:.1f} ms per 2^20 pairings (rocprofv3, {kp['Calls']} launches) / "
      f"{d['roofline']['kernel_ms']:.1f} ms (HIP events in bench.py): {d['value']:.3g} pairings/s; Decrypt {d['decrypt']['value']:.3g} /s (lift `{lift_kern}` "
      f"{d['decrypt']['roofline']['kernel_ms']:.0f} ms per 2^20); every secondary priced in multiply-adds against both issue ceilings", cmd_bench),
     (f"`{tag}_pmc_summary.json`, `{tag}_pmc_fetch_size_k_pairing.csv`, `{tag}_pmc_write_size_k_pairing.csv`",

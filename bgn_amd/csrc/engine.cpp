@@ -984,8 +984,10 @@ static size_t quad_limit(const bgn_ctx* c) {
   if (c->nl > 40) return kMaxBatch;     // 72 limbs: the lane kernels are the functional fallback, not the fast path
   if (c->xo.quad[0] >= 0) return (size_t)c->xo.quad[0];                // bgn_ctx_calibrate
   // profiles/r04_mid_batch.csv (nine-round segments, width-5 loop): 49152 pairs 128 ms, 65536 168 ms against 157 on the
-  // lane kernel (512 bits: 65536 pairs 36.1 against 28.6, 49152 27.7 against 28.5); profiles/r04_calibrate.csv: 61 600 / 50 900
-  return c->nl >= 36 ? 61000 : c->nl >= 19 ? 50000 : 32768;
+  // lane kernel (512 bits: 65536 pairs 36.1 against 28.6, 49152 27.7 against 28.5); profiles/r04_calibrate.csv: 61 600 / 50 900.
+  // Round 5: the lane kernel's round is 138 ms (lazy reduction), the lane groups are what they were — 49152 pairs
+  // 126 ms, 65536 167 ms (profiles/r05_mid_batch.csv); profiles/r05_calibrate.csv: 55 100 ... 55 400 / 45 500
+  return c->nl >= 36 ? 55000 : c->nl >= 19 ? 45500 : 32768;
 }
 // The lane-group pairing's Miller loop over the width-w NAF (quad.hpp k_pairing_quad_wtab: per-pairing table of the odd
 // multiples of A and their Miller values, 9 KB per pairing at 1024 bits): 9 % fewer rounds, two more table launches
@@ -1010,9 +1012,10 @@ static size_t quad_table_limit(const bgn_ctx* c, int mode) {
   // profiles/r03_mid_batch_table.csv, whole calls at 1024 / 512 bits: Decrypt of 16384 ciphertexts 21.0 / 4.3 ms
   // against 36.6 / 6.9 on the lane kernels, of 32768 36.7 / 7.5 against 36.9 / 6.9; makeL2 of 32768 37.4 / 8.5 against
   // 53.2 / 10.6, of 65536 72.2 / 15.9 against 53.7 / 10.8
-  // (round 4: profiles/r04_calibrate.csv 33 100 / 30 200 and 48 300 / 43 600)
-  if (mode == 3 || mode == 2) return c->nl >= 36 ? 33000 : c->nl >= 19 ? 30000 : 16384;
-  return c->nl >= 36 ? 48000 : c->nl >= 19 ? 43500 : 16384;
+  // (round 4: profiles/r04_calibrate.csv 33 100 / 30 200 and 48 300 / 43 600; round 5, the table walks of the lane
+  // kernel with two sums of two products per step: profiles/r05_calibrate.csv 31 000 / 26 900 and 45 300 / 37 700)
+  if (mode == 3 || mode == 2) return c->nl >= 36 ? 31000 : c->nl >= 19 ? 26900 : 16384;
+  return c->nl >= 36 ? 45300 : c->nl >= 19 ? 37700 : 16384;
 }
 
 // MultConst with per-element scalars on the lane groups (quad/quad_g1.hpp: sixteen lanes per element, level 1 a

@@ -14,8 +14,8 @@ from conftest import load_fixture  # noqa: E402
 import bgn_amd  # noqa: E402
 
 COMMITTED = {   # engine.cpp coop_limit / quad_limit / quad_table_limit (profiles/r04_mid_batch*.csv)
-    "k1024": {"coop": [950, 850, 1300, 1300], "quad": [61000, 48000, 33000, 33000]},
-    "k512": {"coop": [815, 640, 740, 740], "quad": [50000, 43500, 30000, 30000]},
+    "k1024": {"coop": [950, 850, 1300, 1300], "quad": [55000, 45300, 31000, 31000]},
+    "k512": {"coop": [815, 640, 740, 740], "quad": [45500, 37700, 26900, 26900]},
 }
 print("key,run,seconds,operation,coop_up_to_calibrated,coop_up_to_committed,quad_up_to_calibrated,quad_up_to_committed")
 for key in sys.argv[1:] or ["k1024", "k512"]:

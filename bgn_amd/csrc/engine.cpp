@@ -143,6 +143,7 @@ struct bgn_ctx {
   int fixed_wbits = 8;
   int fixed_windows_q = 0;             // table of Q: wider windows (20 bits, 17 GB at a 1024-bit key) — Q's exponents
   int fixed_wbits_q = 8;               // are the full-length random ones
+  int fixed_sbits_q = 8;               // scalar bits per window of Q's table: fixed_wbits_q + 1 with signed windows (ops.hpp scalar_window_digit)
   uint32_t* d_fixedpair = nullptr;     // line table of e(P, .), 3 * nl u32 per Miller step (fixedpair.hpp)
   size_t miller_steps = 0;
   PairingConsts pc_host;               // host image of *d_consts
@@ -693,7 +694,7 @@ int bgn_ctx_set_option(bgn_ctx* c, const char* name, int64_t value) {
   if (d->field == &Options::miller_window || d->field == &Options::fixed_normalize)
     return fail(BGN_E_STATE, "option '%s' is read by bgn_ctx_create only: set BGN_%s in the environment before the context is created",
                 name, d->field == &Options::miller_window ? "MILLER_WINDOW" : "FIXED_NORMALIZE");
-  if ((d->field == &Options::fixed_window_bits || d->field == &Options::fixed_window_bits_q) && c->d_tabP)
+  if ((d->field == &Options::fixed_window_bits || d->field == &Options::fixed_window_bits_q || d->field == &Options::fixed_signed_q) && c->d_tabP)
     return fail(BGN_E_STATE, "option '%s': the fixed-base window tables of this context are built already", name);
   (c->opt.*(d->field)).store(value, std::memory_order_relaxed);
   if (d->field == &Options::memory_budget_mb) return bgn_ctx_set_memory_budget(c, value > 0 ? (uint64_t)value << 20 : 0);
@@ -1408,6 +1409,19 @@ int fixed_window_bits(bgn_ctx* c) {
 // Window width of Q's table.  Q carries the blinding exponents — uniformly random below n — so every window
 // of it is used by every encryption: 20-bit windows (52 additions instead of 64 at a 1024-bit key) for 17 GB
 // of HBM.  BGN_FIXED_WINDOW_BITS_Q overrides (8..22); never narrower than P's table.
+// Scalar bits per window of Q's table: signed windows (option fixed_signed_q, default on) take wbits + 1 bits over
+// 2^wbits entries (ops.hpp scalar_window_digit) — 49 windows instead of 52 for a 1024-bit blinding exponent over the
+// same 20-bit table.  P's table keeps unsigned windows (a 40-bit plaintext takes three either way).
+int fixed_scalar_bits_q(const bgn_ctx* c, int wbits) {
+  return opt(c, &Options::fixed_signed_q) != 0 && wbits + 1 <= 23 ? wbits + 1 : wbits;
+}
+
+// Windows of a table that serves every scalar of the byte length of n (what the operations hand over).
+int fixed_table_windows(const bgn_ctx* c, int wbits, int sbits) {
+  if (sbits == wbits) return (c->n.bits() + wbits - 1) / wbits + 1;
+  return scalar_windows(((size_t)c->n.bits() + 7) / 8, wbits, sbits);
+}
+
 int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
   // (default since round 5: 20 bits, 16 GB at a 1024-bit key — the knee of profiles/r04_encrypt_vs_window.csv:
   // 22 bits / 58 GB 1.83e7 encrypts/s, 20 bits / 16 GB 1.72e7 (-6 %), 18 bits / 4.4 GB 1.62e7, 16 bits / 1.2 GB
@@ -1420,7 +1434,7 @@ int fixed_window_bits_q(bgn_ctx* c, int wbits_p) {
   }
   if (wbits < wbits_p) wbits = wbits_p;
   while (wbits > wbits_p) {
-    const size_t W = (size_t)(c->n.bits() + wbits - 1) / wbits + 1;
+    const size_t W = (size_t)fixed_table_windows(c, wbits, fixed_scalar_bits_q(c, wbits));
     const size_t need = (W << wbits) * 2 * (size_t)c->nl * 4;
     if (ctx_table_cap(c, 4) >= need) break;
     wbits--;
@@ -1432,13 +1446,15 @@ int ensure_fixed_tables(bgn_ctx* c) {
   if (c->d_tabP) return BGN_OK;
   release_poly_tables(c);
   const KernelTable* kt = c->kt;
-  int wb[2], W[2];
+  int wb[2], sb[2], W[2];
   size_t np[2], maxc = 0;
   wb[0] = fixed_window_bits(c);
   wb[1] = fixed_window_bits_q(c, wb[0]);
+  sb[0] = wb[0];
+  sb[1] = fixed_scalar_bits_q(c, wb[1]);
   for (int b = 0; b < 2; ++b) {
-    W[b] = (c->n.bits() + wb[b] - 1) / wb[b] + 1;
-    np[b] = (size_t)W[b] * wb[b];                            // entries that are 2^i * B
+    W[b] = fixed_table_windows(c, wb[b], sb[b]);
+    np[b] = (size_t)W[b] * sb[b];                            // entries that are 2^i * B (signed windows: 2^wbits too, at index 0)
     const size_t mc = (size_t)W[b] * (((size_t)1 << (wb[b] - 1)) - 1);
     if (mc > maxc) maxc = mc;
   }
@@ -1488,7 +1504,7 @@ int ensure_fixed_tables(bgn_ctx* c) {
   }
   kt->to_mont(nullptr, c->d_params, pw.c0, pw.c1, pw.stride, npt);
   for (size_t b = 0, o = 0; b < 2; o += np[b], ++b) {
-    kt->tab_scatter_pow(nullptr, pw.c0 + o, pw.c1 + o, pw.stride, np[b], wb[b], tabs[b]);
+    kt->tab_scatter_pow(nullptr, pw.c0 + o, pw.c1 + o, pw.stride, np[b], wb[b], sb[b], tabs[b]);
     for (int k = 1; k < wb[b]; ++k) {
       G1TabRoundArgs a;
       a.tab = tabs[b]; a.wbits = wb[b]; a.windows = W[b]; a.k = k;
@@ -1506,14 +1522,15 @@ int ensure_fixed_tables(bgn_ctx* c) {
   c->fixed_wbits = wb[0];
   c->fixed_windows_q = W[1];
   c->fixed_wbits_q = wb[1];
+  c->fixed_sbits_q = sb[1];
   (void)base;
   return BGN_OK;
 }
 
 // Does a big-endian scalar of `len` bytes fit the window table of P (of Q)?
 bool fixed_fits(const bgn_ctx* c, size_t len, bool q = false) {
-  const int wbits = q ? c->fixed_wbits_q : c->fixed_wbits;
-  return (len * 8 + wbits - 1) / wbits <= (size_t)(q ? c->fixed_windows_q : c->fixed_windows);
+  const int wbits = q ? c->fixed_wbits_q : c->fixed_wbits, sbits = q ? c->fixed_sbits_q : wbits;
+  return scalar_windows(len, wbits, sbits) <= (q ? c->fixed_windows_q : c->fixed_windows);
 }
 
 // S <- P^x * Q^r (x_be or r_be may be null) by one table entry per window: one k_g1_fixed_step launch per
@@ -1528,9 +1545,9 @@ constexpr int kFixedChains = 4;
 
 int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, const uint8_t* x_be, size_t x_len,
                        const uint8_t* r_be, size_t r_len, size_t count, bool timed) {
-  const int wbp = c->fixed_wbits, wbq = c->fixed_wbits_q;
-  const int wx = x_be ? (int)((x_len * 8 + wbp - 1) / wbp) : 0;
-  const int wr = r_be ? (int)((r_len * 8 + wbq - 1) / wbq) : 0;
+  const int wbp = c->fixed_wbits, wbq = c->fixed_wbits_q, sbq = c->fixed_sbits_q;
+  const int wx = x_be ? scalar_windows(x_len, wbp, wbp) : 0;
+  const int wr = r_be ? scalar_windows(r_len, wbq, sbq) : 0;
   const int steps = wx + wr;
   // The lane groups (quad/quad_g1.hpp k_g1_fixed_quad: one mixed Jacobian addition per window — four rounds —, sixteen
   // lanes per element, exceptional cases resolved in the kernel, one inversion per element at the end).  At 72 limbs
@@ -1560,7 +1577,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
         c->chain_ws_bytes = want;
       }
       if (timed) HIP_TRY(hipEventRecord(c->ev0, s));
-      if (quad_g1_fixed_launch(c->nl, s, c->d_params, c->d_tabP, c->d_tabQ, wbp, wbq, x_be, x_len, wx, r_be, r_len, wr, S, count,
+      if (quad_g1_fixed_launch(c->nl, s, c->d_params, c->d_tabP, c->d_tabQ, wbp, wbq, sbq, x_be, x_len, wx, r_be, r_len, wr, S, count,
                                (uint32_t*)c->chain_ws, sw, c->p_bits + 1)) {
         if (timed) {
           HIP_TRY(hipEventRecord(c->ev1, s));
@@ -1601,7 +1618,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
     for (int i = 0; i < csteps; ++i) {
       G1FixedChainArgs a;
       a.sx = X.c0; a.sy = X.c1; a.sinf = X.inf; a.ss = X.stride;
-      a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.wbits_p = wbp; a.wbits_q = wbq;
+      a.tabP = c->d_tabP; a.tabQ = c->d_tabQ; a.wbits_p = wbp; a.wbits_q = wbq; a.sbits_q = sbq;
       a.x = x_be; a.xlen = x_len; a.wx = wx;
       a.r = r_be; a.rlen = r_len; a.wr = wr;
       a.step = i; a.steps = csteps; a.chains = kFixedChains;
@@ -1642,7 +1659,7 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
     const bool isx = i < wx;
     G1FixedStepArgs a;
     a.sx = S.c0; a.sy = S.c1; a.sinf = S.inf; a.ss = S.stride;
-    a.tab = isx ? c->d_tabP : c->d_tabQ; a.wbits = isx ? wbp : wbq; a.window = isx ? i : i - wx;
+    a.tab = isx ? c->d_tabP : c->d_tabQ; a.wbits = isx ? wbp : wbq; a.sbits = isx ? wbp : sbq; a.window = isx ? i : i - wx;
     a.k = isx ? x_be : r_be; a.klen = isx ? x_len : r_len;
     a.prefix = prefix; a.sp = S.stride;
     a.count = count;

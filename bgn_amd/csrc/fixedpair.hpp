@@ -32,19 +32,19 @@ struct FixedBuild {
   AFp<NL> X, Y, Z, T, U;
 };
 
-template <int NL>
+// Stores the three coefficients canonical; KA, KB, KC are power-of-two bounds (value < K*p) the step programs
+// state for them, so the conditional subtractions are 5 a step (doubling: <2, <8, <2) or 4 (addition: <4, <2, <2)
+// where a blanket "< 32p" took 15.
+template <int NL, int KA, int KB, int KC>
 __device__ __forceinline__ void fixed_store3(u32* __restrict__ tab, size_t ts, size_t te, bool live, size_t s,
                                              const Fp<NL>& a, const Fp<NL>& b, const Fp<NL>& c,
-                                             const FpParams<NL>* __restrict__ P, LFp<NL>* L) {
-  // canonical by conditional subtractions (the coefficients are < 20p): six field products per step
-  // cheaper than the x -> x/R -> x*R round trip, a third of the table build
-  (void)L;
+                                             const FpParams<NL>* __restrict__ P) {
   Fp<NL> t;
-  fp_reduce32<NL>(t, a, P);
+  fp_reduce_lt<NL, KA>(t, a, P);
   if (live) g_store<NL>(tab + (3 * s + 0) * NL * ts, ts, te, t);
-  fp_reduce32<NL>(t, b, P);
+  fp_reduce_lt<NL, KB>(t, b, P);
   if (live) g_store<NL>(tab + (3 * s + 1) * NL * ts, ts, te, t);
-  fp_reduce32<NL>(t, c, P);
+  fp_reduce_lt<NL, KC>(t, c, P);
   if (live) g_store<NL>(tab + (3 * s + 2) * NL * ts, ts, te, t);
 }
 
@@ -95,7 +95,7 @@ __device__ __forceinline__ void fixed_build_double(FixedBuild<NL>& S, const Fixe
     a_load(r, S.U);                        // 2YY <4
     fp_sub<4>(cb, cb, r, P);               // b <6
     l_store(L1, r);                        // L1 = 2YY   (ZZ dead)
-    fixed_store3<NL>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P, S0);
+    fixed_store3<NL, 2, 8, 2>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P);
   }
   a_load(r, S.X);
   fp_mul(r, L3, r, P);                     // Sn = X*(8p - 4YY) = -S <2   (64)
@@ -151,8 +151,8 @@ __device__ __forceinline__ void fixed_build_add(FixedBuild<NL>& S, const FixedTa
     if (sign > 0) fp_neg<1>(w, w, P);      // -ysP <=1
     g_load(r, px, sp, ep);                 // xP <1
     fp_mul2(cb, L3, r, S0, w, P);          // b = rr*xP - Z3*ysP <2   (4 + 2)
-    l_load(r, L1);                         // keep H across the store (it clobbers S0 only)
-    fixed_store3<NL>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P, S0);
+    l_load(r, L1);                         // H
+    fixed_store3<NL, 4, 2, 2>(tr.tab, tr.ts, tr.te, tr.live, s, ca, cb, cc, P);
     u = r;
   }
   fp_sqr(w, L1, u, P);                     // HH <2   (100)

@@ -42,6 +42,7 @@
 //     choice of NL in engine.cpp) and returns V < 2p;
 //   * fp_sub<K>(a, b) computes a + K*p - b and needs B_b <= K (K = 1..32).
 #pragma once
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -839,19 +840,19 @@ __device__ __forceinline__ void fp_to_mont(Fp<NL>& r, const Fp<NL>& a, const FpP
   fp_cond_sub_p<NL>(r, x, P);
 }
 
-// Canonical representative in [0, p) of a value < 32p by conditional subtraction of 16p, 8p, 4p, 2p, p:
-// no product (about a tenth of one).
-template <int NL>
-__device__ __forceinline__ void fp_reduce32(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+// Canonical representative in [0, p) of a value < K*p (K a power of two up to 32) by conditional subtraction of
+// K/2*p, ..., 2p, p: log2(K) passes and no product (a pass is about a fiftieth of one).
+template <int NL, int K>
+__device__ __forceinline__ void fp_reduce_lt(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  static_assert(K >= 2 && K <= 32 && (K & (K - 1)) == 0, "bound must be a power of two in [2, 32]");
   Fp<NL> x = a;
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int K = 16 >> s;   // 16, 8, 4, 2, 1
+  for (int M = K >> 1; M >= 1; M >>= 1) {
     Fp<NL> d;
     i32 c = 0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      const i32 v = (i32)x.v[j] - (i32)P->kp[K - 1][j] + c;
+      const i32 v = (i32)x.v[j] - (i32)P->kp[M - 1][j] + c;
       d.v[j] = (u32)v & LIMB_MASK;
       c = v >> LIMB_BITS;
     }
@@ -859,7 +860,20 @@ __device__ __forceinline__ void fp_reduce32(Fp<NL>& r, const Fp<NL>& a, const Fp
 #pragma unroll
     for (int j = 0; j < NL; ++j) x.v[j] = ge ? d.v[j] : x.v[j];
   }
+#ifdef BGN_EMU
+  {
+    i32 c = 0;
+    for (int j = 0; j < NL; ++j) c = ((i32)x.v[j] - (i32)P->kp[0][j] + c) >> LIMB_BITS;
+    // (switchable: the addition runs reduce don't-care values of flagged lanes too)
+    BGN_CHECK(c != 0, "fp_reduce_lt: operand was not below K*p");
+  }
+#endif
   r = x;
+}
+
+template <int NL>
+__device__ __forceinline__ void fp_reduce32(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  fp_reduce_lt<NL, 32>(r, a, P);
 }
 
 // Canonical Montgomery representative in [0, p) of a lazy value (for

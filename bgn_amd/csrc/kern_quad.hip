@@ -199,14 +199,14 @@ struct FixWs {
 };
 
 template <int NL>
-void launch_g1_fixed(hipStream_t s, const void* params, const uint32_t* tabP, const uint32_t* tabQ, int wbp, int wbq, const uint8_t* x,
-                     size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count, uint32_t* ws, size_t sw,
+void launch_g1_fixed(hipStream_t s, const void* params, const uint32_t* tabP, const uint32_t* tabQ, int wbp, int wbq, int sbq,
+                     const uint8_t* x, size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count, uint32_t* ws, size_t sw,
                      int p_bits) {
   const FpParams<NL>* P = (const FpParams<NL>*)params;
   const FixWs<NL> L(sw);
   uint8_t* flags = reinterpret_cast<uint8_t*>(ws + L.flags);
   const dim3 grid((unsigned)((count + QUAD_PER_BLOCK - 1) / QUAD_PER_BLOCK)), block(QUAD_BLOCK);
-  hipLaunchKernelGGL((k_g1_fixed_quad<NL>), grid, block, 0, s, P, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, ws + L.park,
+  hipLaunchKernelGGL((k_g1_fixed_quad<NL>), grid, block, 0, s, P, tabP, tabQ, wbp, wbq, sbq, x, xlen, wx, r, rlen, wr, ws + L.park,
                      ws + L.zsoa, sw, flags, count);
   hipLaunchKernelGGL((k_coop_invert<NL>), dim3((unsigned)((count + FP_BLOCK - 1) / FP_BLOCK)), dim3(FP_BLOCK), 0, s, P,
                      ws + L.zsoa, ws + L.isoa, sw, count, p_bits);
@@ -227,16 +227,16 @@ size_t quad_g1_fixed_ws_words(int nl, size_t sw) {
 }
 
 bool quad_g1_fixed_launch(int nl, hipStream_t s, const void* params, const uint32_t* tabP, const uint32_t* tabQ, int wbp, int wbq,
-                          const uint8_t* x, size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count,
+                          int sbq, const uint8_t* x, size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count,
                           uint32_t* ws, size_t sw, int p_bits) {
   if (!count) return true;
-  if (!ws || wbp > 24 || wbq > 24 || (wx && !x) || (wr && !r)) return false;
+  if (!ws || wbp > 24 || wbq > 24 || sbq > 24 || (sbq != wbq && sbq != wbq + 1) || (wx && !x) || (wr && !r)) return false;
   switch (nl) {
-    case 10: launch_g1_fixed<10>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
-    case 19: launch_g1_fixed<19>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
-    case 36: launch_g1_fixed<36>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
-    case 37: launch_g1_fixed<37>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
-    case 72: launch_g1_fixed<72>(s, params, tabP, tabQ, wbp, wbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 10: launch_g1_fixed<10>(s, params, tabP, tabQ, wbp, wbq, sbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 19: launch_g1_fixed<19>(s, params, tabP, tabQ, wbp, wbq, sbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 36: launch_g1_fixed<36>(s, params, tabP, tabQ, wbp, wbq, sbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 37: launch_g1_fixed<37>(s, params, tabP, tabQ, wbp, wbq, sbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
+    case 72: launch_g1_fixed<72>(s, params, tabP, tabQ, wbp, wbq, sbq, x, xlen, wx, r, rlen, wr, O, count, ws, sw, p_bits); return true;
   }
   return false;
 }

@@ -32,12 +32,20 @@ struct G1AddArgs {
   int plain_io;                                                             // operands and sum are plain residues (decode_plain)
 };
 
+// How many windows of sbits bits a scalar of klen bytes takes over a table of 2^wbits entries per window (signed
+// windows, sbits = wbits + 1: one more when the bit length is a multiple of sbits, for the carry out of the top
+// window; a top window of fewer than sbits bits cannot carry).
+inline int scalar_windows(size_t klen, int wbits, int sbits) {
+  return sbits == wbits ? (int)((klen * 8 + wbits - 1) / wbits) : (int)(klen * 8 / sbits) + 1;
+}
+
 // One window step of the fixed-base products (ops.hpp): state[e] += tab[window][digit_window(k[e])].
 // Table layout: entry (w, d) at tab + ((w << wbits) + d) * 2*NL : x limbs then y limbs, canonical
-// Montgomery; an all-zero entry is the identity (d = 0 is never read as a point).
+// Montgomery; an all-zero entry is the identity (d = 0 is never read as a point).  sbits = wbits: unsigned windows
+// of wbits bits; sbits = wbits + 1: signed windows (ops.hpp scalar_window_digit; index 0 holds 2^wbits * 2^(sbits*w) * B).
 struct G1FixedStepArgs {
   uint32_t* sx; uint32_t* sy; uint8_t* sinf; size_t ss;                     // state, canonical Montgomery (in place)
-  const uint32_t* tab; int wbits; int window;
+  const uint32_t* tab; int wbits; int sbits; int window;
   const uint8_t* k; size_t klen;                                            // big-endian scalars, klen bytes each
   uint32_t* prefix; size_t sp;
   size_t count;
@@ -53,6 +61,7 @@ struct G1FixedStepArgs {
 struct G1FixedChainArgs {
   uint32_t* sx; uint32_t* sy; uint8_t* sinf; size_t ss;                     // state, canonical Montgomery, chains*pitch slots
   const uint32_t* tabP; const uint32_t* tabQ; int wbits_p; int wbits_q;       // window widths of the two tables
+  int sbits_q;                                                              // scalar bits per window of Q (wbits_q + 1: signed windows)
   const uint8_t* x; size_t xlen; int wx;                                    // x == null: wx = 0
   const uint8_t* r; size_t rlen; int wr;                                    // r == null: wr = 0
   int step; int steps; int chains;
@@ -234,8 +243,8 @@ struct KernelTable {
   void (*g1_fixed_step)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedStepArgs a);
   void (*g1_fixed_chain)(hipStream_t s, const void* params, const PairingConsts* consts, G1FixedChainArgs a);
   void (*g1_tab_round)(hipStream_t s, const void* params, const PairingConsts* consts, G1TabRoundArgs a);
-  // SoA element w*wbits + k (canonical Montgomery) -> table entry (w, 2^k)
-  void (*tab_scatter_pow)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count, int wbits,
+  // SoA element w*sbits + k (canonical Montgomery) -> table entry (w, 2^k mod 2^wbits)
+  void (*tab_scatter_pow)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count, int wbits, int sbits,
                           uint32_t* tab);
   // SoA (stride) -> table entries [e][x limbs | y limbs]
   void (*soa_to_entries)(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,

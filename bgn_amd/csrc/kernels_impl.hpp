@@ -375,18 +375,20 @@ k_g1_tab_round(const FpParams<NL>* __restrict__ P, const PairingConsts* __restri
   g1_add_run<NL>(G1IoTabRound<NL>{A}, A.count, A.run, A.prefix, A.sp, L, C, P);
 }
 
-// SoA element i = w*wbits + k (the point 2^(w*wbits + k) * B) -> table entry (w, 2^k)
+// SoA element i = w*sbits + k (the point 2^(w*sbits + k) * B) -> table entry (w, 2^k); with signed windows
+// (sbits = wbits + 1) the top power 2^wbits of a window goes to index 0 (ops.hpp scalar_window_digit)
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
-k_tab_scatter_pow(const u32* __restrict__ c0, const u32* __restrict__ c1, size_t stride, size_t count, int wbits,
+k_tab_scatter_pow(const u32* __restrict__ c0, const u32* __restrict__ c1, size_t stride, size_t count, int wbits, int sbits,
                   u32* __restrict__ tab) {
   const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
   if (e >= count) return;
   Fp<NL> x, y;
   g_load<NL>(x, c0, stride, e);
   g_load<NL>(y, c1, stride, e);
-  const size_t w = e / (size_t)wbits, k = e % (size_t)wbits;
-  u32* dst = tab + ((w << wbits) + ((size_t)1 << k)) * (size_t)(2 * NL);
+  const size_t w = e / (size_t)sbits;
+  size_t k = e % (size_t)sbits;
+  u32* dst = tab + ((w << wbits) + (((size_t)1 << k) & (((size_t)1 << wbits) - 1))) * (size_t)(2 * NL);
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     dst[j] = x.v[j];
@@ -658,10 +660,10 @@ static void launch_g1_tab_round(hipStream_t s, const void* params, const Pairing
 }
 
 static void launch_tab_scatter_pow(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,
-                                   int wbits, uint32_t* tab) {
+                                   int wbits, int sbits, uint32_t* tab) {
   if (!count) return;
   hipLaunchKernelGGL(k_tab_scatter_pow<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, c0, c1, stride, count, wbits,
-                     tab);
+                     sbits, tab);
 }
 
 static void launch_soa_to_entries(hipStream_t s, const uint32_t* c0, const uint32_t* c1, size_t stride, size_t count,

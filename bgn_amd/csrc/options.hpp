@@ -43,6 +43,7 @@ struct Options {
   V bsgs_max_log2{0};      // cap of the baby-step table, log2 entries (0: the default of bgn_ctx_setup_decryption)
   V fixed_window_bits{0};  // window width of P's table (8 or 16; 0: default)
   V fixed_window_bits_q{0};// window width of Q's table (8..22; 0: default)
+  V fixed_signed_q{1};     // signed windows of window bits + 1 scalar bits over Q's table (0: unsigned windows)
   V fixed_chains{4};       // accumulation chains per element of the fixed-base products (1: one launch per window)
   V g1_mul_window{1};      // 4-bit windows in the variable-base scalar multiplication (0: binary ladder)
   V poly_karatsuba{1};     // Karatsuba levels on square MultPoly products
@@ -104,6 +105,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"bsgs_max_log2", &Options::bsgs_max_log2, true, nullptr},
       {"fixed_window_bits", &Options::fixed_window_bits, true, nullptr},
       {"fixed_window_bits_q", &Options::fixed_window_bits_q, true, nullptr},
+      {"fixed_signed_q", &Options::fixed_signed_q, true, nullptr},
       {"fixed_chains", &Options::fixed_chains, true, nullptr},
       {"g1_mul_window", &Options::g1_mul_window, true, nullptr},
       {"poly_karatsuba", &Options::poly_karatsuba, true, nullptr},

@@ -31,11 +31,12 @@ size_t quad_ws_words(int nl, size_t sw, int window = 0);
 uint8_t* quad_g1_mul_launch(int nl, hipStream_t s, const void* params, SoA2 B, const uint8_t* k, size_t kstride, size_t klen,
                             SoA2 O, size_t count, uint32_t* ws, size_t sw, int p_bits);
 size_t quad_g1_mul_ws_words(int nl, size_t sw, size_t klen);
-// O[e] = P^x[e] * Q^r[e] from the key's window tables (engine.cpp ensure_fixed_tables; wx / wr windows of wbp / wbq bits,
+// O[e] = P^x[e] * Q^r[e] from the key's window tables (engine.cpp ensure_fixed_tables; wx / wr windows over tables of
+// 2^wbp / 2^wbq entries per window, Q's windows taking sbq scalar bits each — wbq, or wbq + 1 for signed windows —,
 // x or r null with 0 windows) on the lane groups: O plain canonical affine SoA with identity flags, every case of the
 // additions exact inside the kernel.  ws: quad_g1_fixed_ws_words(nl, sw) u32.  False: no instantiation (nothing launched).
 bool quad_g1_fixed_launch(int nl, hipStream_t s, const void* params, const uint32_t* tabP, const uint32_t* tabQ, int wbp, int wbq,
-                          const uint8_t* x, size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count,
+                          int sbq, const uint8_t* x, size_t xlen, int wx, const uint8_t* r, size_t rlen, int wr, SoA2 O, size_t count,
                           uint32_t* ws, size_t sw, int p_bits);
 size_t quad_g1_fixed_ws_words(int nl, size_t sw);
 // out[e] = a[e]^k[e] in F_p^2 with per-element exponents (kstride 0: one for all): a canonical Montgomery SoA, out

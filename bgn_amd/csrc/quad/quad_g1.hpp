@@ -313,10 +313,43 @@ __device__ __forceinline__ u32 quad_scalar_window(const uint8_t* __restrict__ k,
   return (v >> (bit0 & 7)) & ((1u << wbits) - 1u);
 }
 
+// Signed windows of sbits = wbits + 1 scalar bits over a table of 2^wbits entries per window, as ops.hpp
+// scalar_window_digit: digits in (-2^wbits, 2^wbits], index = |digit| mod 2^wbits (index 0 holds the magnitude 2^wbits),
+// neg: add the entry with y negated.  sbits = wbits: the unsigned window itself.
+__device__ __forceinline__ void quad_window_digit(const uint8_t* __restrict__ k, size_t klen, int wbits, int sbits, int window,
+                                                  u32& idx, bool& neg, bool& zero) {
+  if (sbits == wbits) {
+    idx = quad_scalar_window(k, klen, wbits, window);
+    neg = false;
+    zero = idx == 0;
+    return;
+  }
+  const u32 H = 1u << wbits;
+  u32 t = quad_scalar_window(k, klen, sbits, window);
+  u32 below = quad_scalar_window(k, klen, sbits, window > 0 ? window - 1 : 0);      // fetched with the window itself
+  if (window == 0) below = 0;
+  if (below == H) {
+    below = 0;
+#pragma unroll 1
+    for (int v = window - 2; v >= 0; --v) {
+      const u32 b = quad_scalar_window(k, klen, sbits, v);
+      if (b != H) {
+        below = b;
+        break;
+      }
+    }
+  }
+  t += below > H ? 1u : 0u;
+  neg = t > H;
+  const u32 mag = neg ? (H << 1) - t : t;
+  zero = mag == 0;
+  idx = mag & (H - 1);
+}
+
 template <int NL>
 __global__ void __launch_bounds__(QUAD_BLOCK)
 k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP, const u32* __restrict__ tabQ, int wbits_p,
-                int wbits_q, const uint8_t* __restrict__ xk, size_t xlen, int wx, const uint8_t* __restrict__ rk, size_t rlen, int wr,
+                int wbits_q, int sbits_q, const uint8_t* __restrict__ xk, size_t xlen, int wx, const uint8_t* __restrict__ rk, size_t rlen, int wr,
                 u32* __restrict__ park, u32* __restrict__ zsoa, size_t sw, uint8_t* __restrict__ flags, size_t count) {
   constexpr int M = QuadDims<NL>::M;
   using PG = QuadG1;
@@ -373,9 +406,12 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
       if (i >= nwin) break;
       const bool isx = i < wx;
       const int lw = isx ? i : i - wx, wb = isx ? wbits_p : wbits_q;
-      const u32 d = isx ? quad_scalar_window(xk + e * xlen, xlen, wb, lw) : quad_scalar_window(rk + e * rlen, rlen, wb, lw);
+      u32 d;
+      bool d_neg, d_zero;
+      if (isx) quad_window_digit(xk + e * xlen, xlen, wb, wb, lw, d, d_neg, d_zero);
+      else quad_window_digit(rk + e * rlen, rlen, wb, sbits_q, lw, d, d_neg, d_zero);
       ++i;
-      if (!__ballot(d != 0)) continue;
+      if (!__ballot(!d_zero)) continue;
       bool ent_inf = true;
       if (c.quad < 2) {
         const u32* ent = (isx ? tabP : tabQ) + ((((size_t)lw) << wb) + d) * (size_t)(2 * NL) + (size_t)c.quad * NL;
@@ -386,6 +422,16 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
           x[j] = pos < NL ? (int)ent[pos < NL ? pos : 0] : 0;
           any |= (u32)x[j];
         }
+        if (c.quad == 1 && __ballot(d_neg)) {
+          // a negative digit: y <- p - y, tight again (an entry is a point of odd order, y != 0); elements whose digit is
+          // not negative keep their limbs
+          int ny[M];
+#pragma unroll
+          for (int j = 0; j < M; ++j) ny[j] = (int)c.p[j] - x[j];
+          quad_tight<NL>(ny, c);
+#pragma unroll
+          for (int j = 0; j < M; ++j) x[j] = d_neg ? ny[j] : x[j];
+        }
         put(QUADG_SLOT_TX + c.quad);
         any |= (u32)quad_from_above((int)any);
         any |= (u32)quad_bcast<0>((int)any) | (u32)quad_bcast<2>((int)any);
@@ -393,7 +439,7 @@ k_g1_fixed_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ tabP
       }
       note_sync();
       ent_inf = (note[el][0] | note[el][1]) == 0;
-      const bool use = d != 0 && !ent_inf;
+      const bool use = !d_zero && !ent_inf;
       seg = QUADG_SEG_GADM;                             // the table's entries are affine: the mixed addition, four rounds
       took = use && !acc_inf;
       keep = !took;

@@ -240,15 +240,19 @@ def eadd_products(count: int) -> float:
     return eadd_counts(count)[0]
 
 
-def encrypt_counts(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20):
-    """Fixed-base product P^m * Q^r: one affine addition per window (four accumulation chains, runs of 64) and
-    three more to sum the chains; one squaring (lambda^2) per addition."""
-    windows = -(-x_bits // wbits_p) + -(-r_bits // wbits_q)
-    return (windows + 3) * (7 + INVERSION_PRODUCTS / 64), float(windows + 3), 0.0
+def encrypt_counts(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20, signed_q: bool = True, chains: int = 4):
+    """Fixed-base product P^m * Q^r: one affine addition per window and accumulation chain slot (four chains advanced
+    together: the windows round up to a multiple of four; runs of 64) and three more to sum the chains; one squaring
+    (lambda^2) per addition.  Q's windows are signed by default since round 5 (wbits_q + 1 scalar bits each over the
+    2^wbits_q-entry table: 49 windows for 1024 bits instead of 52)."""
+    wr = (r_bits // (wbits_q + 1) + 1) if signed_q else -(-r_bits // wbits_q)
+    windows = -(-x_bits // wbits_p) + wr
+    adds = -(-windows // chains) * chains + (chains - 1)
+    return adds * (7 + INVERSION_PRODUCTS / 64), float(adds), 0.0
 
 
-def encrypt_products(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20) -> float:
-    return encrypt_counts(x_bits, r_bits, wbits_p, wbits_q)[0]
+def encrypt_products(x_bits: int, r_bits: int, wbits_p: int = 16, wbits_q: int = 20, signed_q: bool = True) -> float:
+    return encrypt_counts(x_bits, r_bits, wbits_p, wbits_q, signed_q)[0]
 
 
 def _naf_counts(n: int):

@@ -220,15 +220,17 @@ struct Emu {
     }
     threadIdx.x = 0;
   }
-  // window table from its 2^i * B entries (pow: windows*wbits entries of 2*NL Montgomery limbs) -- the
-  // scatter + rounds of ensure_fixed_tables (engine.cpp)
-  static void tab_build(const u32* params, const PairingConsts* C, int wbits, int windows, const u32* pow, u32* tab) {
+  // window table from its 2^i * B entries (pow: windows*sbits entries of 2*NL Montgomery limbs; sbits = wbits, or
+  // wbits + 1 for signed windows, whose top power lands on index 0) -- the scatter + rounds of ensure_fixed_tables
+  // (engine.cpp)
+  static void tab_build(const u32* params, const PairingConsts* C, int wbits, int sbits, int windows, const u32* pow, u32* tab) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     const size_t ne = (size_t)windows << wbits;
     memset(tab, 0, ne * 2 * NL * 4);
     for (int w = 0; w < windows; ++w)
-      for (int k = 0; k < wbits; ++k)
-        memcpy(tab + (((size_t)w << wbits) + ((size_t)1 << k)) * 2 * NL, pow + ((size_t)w * wbits + k) * 2 * NL, 2 * NL * 4);
+      for (int k = 0; k < sbits; ++k)
+        memcpy(tab + (((size_t)w << wbits) + (((size_t)1 << k) & (((size_t)1 << wbits) - 1))) * 2 * NL,
+               pow + ((size_t)w * sbits + k) * 2 * NL, 2 * NL * 4);
     for (int k = 1; k < wbits; ++k) {
       G1TabRoundArgs A;
       A.tab = tab; A.wbits = wbits; A.windows = windows; A.k = k;
@@ -241,20 +243,20 @@ struct Emu {
     }
   }
   // P^x * Q^r for one element: the launch sequence of fixed_base_product (engine.cpp)
-  static void g1_fixed(const u32* params, const PairingConsts* C, const u32* tabP, const u32* tabQ, int wbits,
+  static void g1_fixed(const u32* params, const PairingConsts* C, const u32* tabP, const u32* tabQ, int wbits, int sbits_q,
                        const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
     const size_t st = FP_BLOCK;
     std::vector<u32> sx(NL * st, 0), sy(NL * st, 0), pf(NL * st);
     std::vector<uint8_t> si(st, 1);
-    const int wx = x ? (int)((xlen * 8 + wbits - 1) / wbits) : 0;
-    const int wr = r ? (int)((rlen * 8 + wbits - 1) / wbits) : 0;
+    const int wx = x ? scalar_windows(xlen, wbits, wbits) : 0;
+    const int wr = r ? scalar_windows(rlen, wbits, sbits_q) : 0;
     blockIdx.x = 0; threadIdx.x = 0; gridDim.x = 1;
     for (int i = 0; i < wx + wr; ++i) {
       const bool isx = i < wx;
       G1FixedStepArgs A;
       A.sx = sx.data(); A.sy = sy.data(); A.sinf = si.data(); A.ss = st;
-      A.tab = isx ? tabP : tabQ; A.wbits = wbits; A.window = isx ? i : i - wx;
+      A.tab = isx ? tabP : tabQ; A.wbits = wbits; A.sbits = isx ? wbits : sbits_q; A.window = isx ? i : i - wx;
       A.k = isx ? x : r; A.klen = isx ? xlen : rlen;
       A.prefix = pf.data(); A.sp = st;
       A.count = 1; A.run = 1;
@@ -437,8 +439,19 @@ int emu_gt_pow(int nl, const u32* params, const u32* a, const uint8_t* k, size_t
 int emu_gt_pow_norm1(int nl, const u32* params, int p_bits, const u32* a, const uint8_t* k, size_t klen, u32* out) { DISPATCH(nl, gt_pow_norm1(params, p_bits, a, k, klen, out)) }
 int emu_bsgs(int nl, const u32* params, const u32* g, const u32* gi, unsigned long long S, unsigned long long G, unsigned long long Mmax, const u32* xs, int count, long long* m, uint8_t* status) { DISPATCH(nl, bsgs(params, g, gi, S, G, Mmax, xs, count, m, status)) }
 int emu_poly_acc(int nl, const u32* params, const u32* E, int d1, int d2, u32* out) { DISPATCH(nl, poly_acc(params, E, d1, d2, out)) }
-int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, x, xlen, r, rlen, out, oinf)) }
-int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, windows, pow, tab)) }
+// (range checks on request: valid while no addition of the product is exceptional — flagged lanes carry don't-care values)
+int emu_g1_fixed_checked = 0;
+void emu_set_g1_fixed_checks(int on) { emu_g1_fixed_checked = on; }
+int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, int sbits_q, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { struct Scope { Scope() { bgn_emu_checks = emu_g1_fixed_checked; } ~Scope() { bgn_emu_checks = 0; } } scope; DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, sbits_q, x, xlen, r, rlen, out, oinf)) }
+int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int sbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, sbits, windows, pow, tab)) }
+// the signed recoding of one window on its own (ops.hpp scalar_window_digit): returns the digit, -2^wbits < d <= 2^wbits
+long long emu_window_digit(const uint8_t* k, size_t klen, int wbits, int sbits, int window, unsigned* idx) {
+  const u32 d = bgn::scalar_window_digit(k, klen, wbits, sbits, window);
+  *idx = d & bgn::WD_INDEX;
+  const long long mag = (d & bgn::WD_ZERO) ? 0 : (*idx ? (long long)*idx : (1ll << wbits));
+  return (d & bgn::WD_NEG) ? -mag : mag;
+}
+int emu_scalar_windows(size_t klen, int wbits, int sbits) { return bgn::scalar_windows(klen, wbits, sbits); }
 int emu_poly_lin(int nl, const u32* params, const void* C, int level, const u32* c, const uint8_t* cinf, int d, int dp, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, poly_lin(params, (const PairingConsts*)C, level, c, cinf, d, dp, k, klen, out, oinf)) }
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab, size_t ts, size_t te) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab, ts, te)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, int normalized, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, normalized, c, out)) }

@@ -227,20 +227,32 @@ class Emu:
             tab[2 * self.nl * i:2 * self.nl * (i + 1)] = list(x)
         return tab
 
-    def build_table(self, wbits: int, windows: int, pow_wire):
-        """pow_wire[i] = wire bytes of 2^i * B, i < windows*wbits -> full window table, built the way the engine does."""
-        assert len(pow_wire) == windows * wbits
+    def build_table(self, wbits: int, windows: int, pow_wire, sbits: int = 0):
+        """pow_wire[i] = wire bytes of 2^i * B, i < windows*sbits -> full window table, built the way the engine does
+        (sbits = wbits + 1: signed windows, the top power of a window at index 0)."""
+        sbits = sbits or wbits
+        assert len(pow_wire) == windows * sbits
         pw = self.make_table(pow_wire)
         tab = (C.c_uint32 * (2 * self.nl * (windows << wbits)))()
-        assert self.lib.emu_tab_build(self.nl, self.params, self.consts, wbits, windows, pw, tab) == 0
+        assert self.lib.emu_tab_build(self.nl, self.params, self.consts, wbits, sbits, windows, pw, tab) == 0
         return tab
 
-    def g1_fixed(self, tabP, tabQ, wbits: int, x: int, xlen: int, r=None, rlen: int = 0) -> bytes:
+    def window_digit(self, k: int, klen: int, wbits: int, sbits: int, window: int):
+        """(digit, table index) of one window of the signed recoding (ops.hpp scalar_window_digit)."""
+        idx = C.c_uint()
+        self.lib.emu_window_digit.restype = C.c_longlong
+        d = self.lib.emu_window_digit(k.to_bytes(klen, "big"), C.c_size_t(klen), wbits, sbits, window, C.byref(idx))
+        return int(d), int(idx.value)
+
+    def scalar_windows(self, klen: int, wbits: int, sbits: int) -> int:
+        return int(self.lib.emu_scalar_windows(C.c_size_t(klen), wbits, sbits))
+
+    def g1_fixed(self, tabP, tabQ, wbits: int, x: int, xlen: int, r=None, rlen: int = 0, sbits_q: int = 0) -> bytes:
         out = (C.c_uint32 * (2 * self.nl))()
         oinf = C.c_uint8()
         xb = x.to_bytes(xlen, "big")
         rb = r.to_bytes(rlen, "big") if r is not None else None
-        assert self.lib.emu_g1_fixed(self.nl, self.params, self.consts, tabP, tabQ, wbits, xb, C.c_size_t(xlen), rb,
+        assert self.lib.emu_g1_fixed(self.nl, self.params, self.consts, tabP, tabQ, wbits, sbits_q or wbits, xb, C.c_size_t(xlen), rb,
                                      C.c_size_t(rlen), out, C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 

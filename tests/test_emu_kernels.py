@@ -215,6 +215,84 @@ def test_emu_fixed_base_encrypt(wbits):
     assert E.g1_fixed(tP, tQ, wbits, 0, 1, None, 0) == zero
 
 
+def test_emu_signed_window_recoding():
+    """ops.hpp scalar_window_digit: every window recoded on its own gives digits in (-2^wbits, 2^wbits] that sum to
+    the scalar, the table index is |digit| mod 2^wbits, and scalar_windows() windows are enough — random scalars and
+    the ones that stress the carry rule (windows equal to 2^wbits, runs of all-ones windows, lengths that are a
+    multiple of the window width)."""
+    fx = load_fixture("toy64")
+    E = emu.Emu.from_fixture(fx)
+    rng = random.Random(21)
+    for wbits, klen in [(4, 5), (7, 8), (7, 16), (11, 9), (16, 17), (20, 21), (20, 128), (22, 23), (22, 128)]:
+        s = wbits + 1
+        H = 1 << wbits
+        W = E.scalar_windows(klen, wbits, s)
+        assert W == (8 * klen) // s + 1
+        top = 1 << (8 * klen)
+        full = (8 * klen + s - 1) // s
+        ks = [0, 1, top - 1, H, H + 1, H - 1, sum(H << (s * w) for w in range(full)) % top,
+              (sum(H << (s * w) for w in range(full)) + 1) % top, sum(((1 << s) - 1) << (s * w) for w in range(0, full, 2)) % top,
+              (H << s) | H, ((H + 1) << (2 * s)) | (H << s) | H, ((H - 1) << (2 * s)) | (H << s) | (H + 1)]
+        ks += [rng.randrange(top) for _ in range(12)]
+        for k in ks:
+            k %= top
+            total = 0
+            for w in range(W):
+                d, idx = E.window_digit(k, klen, wbits, s, w)
+                assert -H < d <= H, (wbits, klen, hex(k), w, d)
+                assert idx == abs(d) % H
+                total += d << (s * w)
+            assert total == k, (wbits, klen, hex(k))
+        # unsigned windows are the digits themselves
+        k = rng.randrange(top)
+        assert sum(E.window_digit(k, klen, wbits, wbits, w)[0] << (wbits * w) for w in range(E.scalar_windows(klen, wbits, wbits))) == k
+
+
+@pytest.mark.parametrize("wbits", [8, 11])
+def test_emu_fixed_base_encrypt_signed_windows(wbits):
+    """Encrypt over Q's table with signed windows (wbits + 1 scalar bits per window, index 0 = 2^wbits * 2^(s*w) * Q,
+    negative digits add the negated entry): table entries and products against the oracle, with blinding exponents
+    that hit the digit 2^wbits, its negative neighbour, zero digits after a carry, and the carry out of the top window."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    import oracle_c
+    fx = load_fixture("toy64")
+    E = emu.Emu.from_fixture(fx)
+    o = oracle_c.Oracle.from_fixture(fx)
+    n = int(fx["n"], 16)
+    s = wbits + 1
+    H = 1 << wbits
+    nbytes = (n.bit_length() + 7) // 8
+    WP = (n.bit_length() + wbits - 1) // wbits + 1
+    WQ = E.scalar_windows(nbytes, wbits, s)
+    tP = E.build_table(wbits, WP, [o.encrypt([1 << i], None) for i in range(WP * wbits)])
+    tQ = E.build_table(wbits, WQ, [o.encrypt([0], [1 << i]) for i in range(WQ * s)], sbits=s)
+    rng = random.Random(5)
+    probes = [(w, d) for w in (0, WQ - 1) for d in (0, 1, 2, H - 1)] + [(rng.randrange(WQ), rng.randrange(H)) for _ in range(16)]
+    for w, d in probes:
+        want, _ = E.decode(o.encrypt([0], [(d or H) << (s * w)]))
+        i = (w << wbits) + d
+        assert list(tQ[2 * E.nl * i:2 * E.nl * (i + 1)]) == list(want), (w, d)
+    top = 1 << (8 * nbytes)
+    rs = [0, 1, H, H + 1, H - 1, (1 << s) - 1, 1 << s, (H << s) | H, ((H + 1) << s) | H, n - 1, n + 1, top - 1,
+          sum(H << (s * w) for w in range(WQ)) % top, sum(((1 << s) - 1) << (s * w) for w in range(WQ)) % top]
+    rs += [rng.randrange(n) for _ in range(6)]
+    for r in rs:
+        x = rng.randrange(1 << 16)
+        assert E.g1_fixed(tP, tQ, wbits, x, 2, r, nbytes, sbits_q=s) == o.encrypt([x], [r]), hex(r)
+    assert E.g1_fixed(tP, tQ, wbits, 9, 2, 0x6789ABCDEF, 5, sbits_q=s) == o.encrypt([9], [0x6789ABCDEF])
+    # the same with the emulation's range checks on (carry-outs, and the bounds the canonical stores rely on: x3 < 4p,
+    # y3 < 3p) for products without an exceptional addition: every digit non-zero, so no lane carries don't-care values
+    E.lib.emu_set_g1_fixed_checks(1)
+    try:
+        for _ in range(12):
+            r = sum(rng.choice([rng.randrange(1, H), rng.randrange(H + 1, 1 << s)]) << (s * w) for w in range(WQ - 1))
+            x = sum(rng.randrange(1, 1 << wbits) << (wbits * w) for w in range(2))
+            assert E.g1_fixed(tP, tQ, wbits, x, (2 * wbits + 7) // 8, r, nbytes, sbits_q=s) == o.encrypt([x], [r]), hex(r)
+    finally:
+        E.lib.emu_set_g1_fixed_checks(0)
+
+
 def test_emu_fixed_argument_pairing(ctx):
     """e(P, C) over the precomputed line table == makeL2 golden vectors (= e(C, P): the pairing is symmetric)."""
     fx, E = ctx

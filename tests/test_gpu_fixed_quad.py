@@ -97,3 +97,51 @@ def test_exceptional_additions_are_resolved_in_the_kernel(which, engopts):
         E = eng.elem_bytes
         for i in (0, 1, 2, 4):
             assert res["quad"][i * E: (i + 1) * E] == bytes(E)                     # x P - x P
+
+
+def _stress_exponents(n_bytes, wbits, rng, n):
+    """Blinding exponents that stress the signed recoding of ops.hpp scalar_window_digit (s = wbits + 1 bits a window):
+    windows equal to 2^wbits (the carry is decided further down), just above and below it, runs of all-ones windows
+    (a carry turns them into zero digits), the top of the range, and random ones."""
+    s, H, top = wbits + 1, 1 << wbits, 1 << (8 * n_bytes)
+    full = (8 * n_bytes + s - 1) // s
+    rs = [0, 1, H, H + 1, H - 1, (1 << s) - 1, 1 << s, (H << s) | H, ((H + 1) << s) | H, ((H - 1) << (2 * s)) | (H << s) | (H + 1),
+          sum(H << (s * w) for w in range(full)), sum(((1 << s) - 1) << (s * w) for w in range(full)),
+          sum(((1 << s) - 1) << (s * w) for w in range(0, full, 2)), top - 1, n - 1, n, n + 1]
+    rs += [rng.randrange(n) for _ in range(15)]
+    return [r % top for r in rs]
+
+
+@pytest.mark.parametrize("name,wbits_q", [("k256", 11), ("k512", 16), ("k1024", 0)])
+def test_signed_windows_of_q_on_every_kernel_family(name, wbits_q, engopts):
+    """Q's table with signed windows (the default: one scalar bit more per window over the same entries, index 0 holding
+    2^wbits) against unsigned ones and the C oracle: the lane groups, the chain kernels and the one-launch-per-window
+    kernel each recode every window on their own and give the same bytes, with exponents built to hit the carry rule."""
+    import bgn_amd
+    import oracle_c
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    n = int(fx["n"], 16)
+    n_bytes = (n.bit_length() + 7) // 8
+    rng = random.Random(wbits_q + 1)
+    eff = wbits_q or 20
+    rs = _stress_exponents(n_bytes, eff, rng, n)
+    xs = [rng.randrange(fx["msg_space"]) for _ in rs]
+    want = o.encrypt(xs, rs)
+    for signed in (1, 0):
+        pk = bgn_amd.PublicKey(int(fx["p"], 16), n, fx["l"], bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"]), fx["msg_space"], True,
+                               fx["poly_base"])
+        eng = engopts.register(pk.engine)
+        eng.set_option("fixed_signed_q", signed)
+        if wbits_q:
+            eng.set_option("fixed_window_bits_q", wbits_q)
+        for path in ("quad", "chains", "steps"):
+            eng.set_option("quad_max_enc", (1 << 40) if path == "quad" else 0)
+            eng.set_option("fixed_chains", 1 if path == "steps" else 4)
+            got = eng.encrypt(xs, rs).tobytes()
+            kern = eng.last_kernel_name()
+            assert ("k_g1_fixed_quad" in kern) == (path == "quad") and ("k_g1_fixed_step" in kern) == (path == "steps"), kern
+            assert got == want, (name, signed, path)
+        with pytest.raises(bgn_amd.BgnError):
+            eng.set_option("fixed_signed_q", 1 - signed)              # shapes a table that exists now
+        eng.close()

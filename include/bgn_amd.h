@@ -92,11 +92,16 @@ const char* bgn_version(void);
  *                     most 2^31 (34 GB — what round 4 paid 69 GB for).  What fewer steps cost
  *                     (profiles/r04_decrypt_vs_table.csv, option bsgs_max_log2): 2^30, 17 GB, -8 % decrypts/s;
  *                     2^29, 8.6 GB, -21 %; 2^28, 4.3 GB, -38 %
- *   windows of Q      20-bit windows, 16 GB: 1.72e7 encrypts/s.  22 bits, 58 GB, +6 % (option fixed_window_bits_q =
- *                     22); 18 bits, 4.4 GB, -6 %; 16 bits, 1.2 GB, -11 % (profiles/r04_encrypt_vs_window.csv)
+ *   windows of Q      2^20 entries per window, 14.8 GB: 1.8e7 encrypts/s.  The windows are SIGNED: each takes 21 bits
+ *                     of the blinding exponent as a digit in (-2^20, 2^20] and adds the entry of its magnitude, negated
+ *                     for a negative digit (index 0 holds the magnitude 2^20) — 49 additions for a 1024-bit exponent
+ *                     where unsigned 20-bit windows over the same entries take 52 (option fixed_signed_q = 0: -4 %,
+ *                     profiles/r05_encrypt_signed_windows.csv).  2^22 entries, 54 GB, +8 % (option
+ *                     fixed_window_bits_q = 22); 2^18, 4.1 GB, -10 %; 2^16, 1.2 GB, -15 %
+ *                     (profiles/r05_encrypt_vs_window.csv)
  *   windows of P      16-bit windows, 2 * NL * 4 B per entry (1.2 GB); the GT table of e(Q,Q) likewise
  *   workspace         7.4 KB per pairing of the largest batch seen (7.8 GB at 2^20; larger batches run in pieces)
- *   => 52.8 GB of tables + workspace: a context that has encrypted, multiplied and decrypted holds about 61 GB.
+ *   => 51.6 GB of tables + workspace: a context that has encrypted, multiplied and decrypted holds about 60 GB.
  *   MultPoly tables   per-call scratch: whole rounds of 65536 coefficient tables (38 GB) within 1/6 of the device.
  *                     They stay with the context for the next call only while its total remains under the RESIDENT CAP
  *                     — a quarter of the device by default (72 GB), option resident_cap_mb; -1: keep everything — and go
@@ -106,7 +111,7 @@ const char* bgn_version(void);
  *                     (26 GB + 38 GB) keeps them.
  * What is free at the moment of the call — under a budget, what the budget leaves — only clamps these from above
  * (a table never takes more than half of it), so the same key gets the same tables in whatever order they are
- * built, unless memory is short.  Options bsgs_max_log2, fixed_window_bits, fixed_window_bits_q, poly_table_max_mb,
+ * built, unless memory is short.  Options bsgs_max_log2, fixed_window_bits, fixed_window_bits_q, fixed_signed_q, poly_table_max_mb,
  * resident_cap_mb choose other sizes.
  * bgn_ctx_memory_bytes: bytes of device memory the context holds now (the staging buffers of the combiner included;
  * not included: the small per-device pool of staging buffers the host-buffer calls share, at most 32 x 4 MB).
@@ -124,9 +129,9 @@ int bgn_ctx_set_memory_budget(bgn_ctx* c, uint64_t bytes);
  * process) cannot race the library, and two contexts of one process may run different settings side by side.
  * bgn_ctx_set_option takes effect from the next call on (options read only while a table is built — miller_window,
  * fixed_normalize at creation; decrypt_order_table by bgn_ctx_set_secret; bsgs_max_log2 by bgn_ctx_setup_decryption;
- * fixed_window_bits* on first Encrypt — must be in place before that step; a value that arrives after its table is
+ * fixed_window_bits* and fixed_signed_q on first Encrypt — must be in place before that step; a value that arrives after its table is
  * built is refused with BGN_E_STATE, never accepted silently: miller_window and fixed_normalize always — they are
- * creation-time options, set BGN_MILLER_WINDOW / BGN_FIXED_NORMALIZE in the environment —, fixed_window_bits* once the
+ * creation-time options, set BGN_MILLER_WINDOW / BGN_FIXED_NORMALIZE in the environment —, fixed_window_bits* and fixed_signed_q once the
  * window tables exist).  bgn_ctx_reset_options goes back to the values the context was created with and re-applies
  * those with a side effect (memory_budget_mb: the budget in force is the restored one).  bgn_option_name(i)
  * enumerates the names (null past the end).  Unknown name: BGN_E_ARG.  There is no counterpart in the reference (PBC has no tunables on this path); the

@@ -4,8 +4,8 @@
   * Decrypt against the baby-step table: decrypts/s at 2^16 and 2^20 ciphertexts (level 1, the bench's mixed batch) and
     the set-up time for tables of 2^24 .. 2^31 entries (option bsgs_max_log2; 16 B per entry since round 5) — the walk is
     T / (2 S) products per ciphertext beside a lift of ~3.8 k products;
-  * Encrypt against the window width of Q's table (option fixed_window_bits_q: 16 .. 22 bits; a fresh context each,
-    the tables are built on first use).
+  * Encrypt against the window width of Q's table (option fixed_window_bits_q: 2^16 .. 2^22 entries per window, signed
+    windows of one scalar bit more since round 5; a fresh context each, the tables are built on first use).
 
     python tools/decrypt_vs_table.py > profiles/r04_decrypt_vs_table.csv
     python tools/decrypt_vs_table.py encrypt > profiles/r04_encrypt_vs_window.csv
@@ -71,7 +71,7 @@ def decrypt_sweep(fx, dev):
 
 
 def encrypt_sweep(fx, dev):
-    print("key,q_window_bits,q_table_GB,first_call_s,batch,ms,encrypts_per_s")
+    print("key,q_table_index_bits,signed_windows,q_windows,q_table_GB,first_call_s,batch,ms,encrypts_per_s")
     n = 1 << 20
     ref = None
     for wb in (22, 20, 18, 16):
@@ -91,9 +91,10 @@ def encrypt_sweep(fx, dev):
             ref = cts.clone()
         assert bool((ref == cts).all().item()), "window width changed the ciphertexts"
         nbits = int(fx["n"], 16).bit_length()
-        W = (nbits + wb - 1) // wb + 1
+        signed = int(eng.get_option("fixed_signed_q")) != 0
+        W = (8 * ((nbits + 7) // 8)) // (wb + 1) + 1 if signed else (nbits + wb - 1) // wb + 1     # engine.cpp fixed_table_windows
         tab = (W << wb) * 2 * syn.limbs_for(int(fx["p"], 16)) * 4
-        print("%s,%d,%.2f,%.2f,%d,%.2f,%.0f" % (fx["name"], wb, tab / 1e9, first, n, dt * 1e3, n / dt), flush=True)
+        print("%s,%d,%d,%d,%.2f,%.2f,%d,%.2f,%.0f" % (fx["name"], wb, 1 if signed else 0, W, tab / 1e9, first, n, dt * 1e3, n / dt), flush=True)
         del xs, rs, cts, out
         pk.engine.close()
 

@@ -177,7 +177,9 @@ if dvt:
 evw = csv_rows("encrypt_vs_window.csv")
 if evw:
     rows.append(("Encrypt at 2²⁰ against the window width of Q's table (`profiles/%s_encrypt_vs_window.csv`)" % tag,
-                 "; ".join("%s bits (%.1f GB): %.3g /s" % (r["q_window_bits"], float(r["q_table_GB"]), float(r["encrypts_per_s"])) for r in evw)))
+                 "; ".join(("2^%s entries a window, %s windows (%.1f GB): %.3g /s" % (r["q_table_index_bits"], r["q_windows"], float(r["q_table_GB"]), float(r["encrypts_per_s"])))
+                           if "q_table_index_bits" in r else
+                           ("%s bits (%.1f GB): %.3g /s" % (r["q_window_bits"], float(r["q_table_GB"]), float(r["encrypts_per_s"]))) for r in evw)))
 table = "| | value |\n|---|---|\n" + "".join(f"| {a} | {b} |\n" for a, b in rows)
 
 

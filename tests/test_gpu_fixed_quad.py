@@ -142,6 +142,9 @@ def test_signed_windows_of_q_on_every_kernel_family(name, wbits_q, engopts):
             kern = eng.last_kernel_name()
             assert ("k_g1_fixed_quad" in kern) == (path == "quad") and ("k_g1_fixed_step" in kern) == (path == "steps"), kern
             assert got == want, (name, signed, path)
+        # exponents longer than the table serves (two more bytes than n has) take the general scalar multiplication
+        long_rs = [r + (5 << (8 * n_bytes + 3)) for r in rs[:6]]
+        assert eng.encrypt(xs[:6], long_rs).tobytes() == o.encrypt(xs[:6], long_rs), (name, signed, "long exponents")
         with pytest.raises(bgn_amd.BgnError):
             eng.set_option("fixed_signed_q", 1 - signed)              # shapes a table that exists now
         eng.close()

@@ -60,10 +60,18 @@ namespace bgn {
 #if defined(BGN_EMU)
 #define BGN_CHECK(cond, what) do { if (bgn_emu_checks && !(cond)) bgn_emu_fail(what, __FILE__, __LINE__); } while (0)
 #define BGN_CHECK_ALWAYS(cond, what) do { if (!(cond)) bgn_emu_fail(what, __FILE__, __LINE__); } while (0)
+#define BGN_TALLY(kind, n) do { bgn_emu_tally[kind] += (unsigned long long)(n); } while (0)
 #else
 #define BGN_CHECK(cond, what) do { } while (0)
 #define BGN_CHECK_ALWAYS(cond, what) do { } while (0)
+#define BGN_TALLY(kind, n) do { } while (0)
 #endif
+// What the host emulation tallies per lane (BGN_TALLY: on the device nothing) — the dynamic count of the primitives a
+// kernel is made of, from which tools/op_tally.py prices its instruction budget: multiply-adds; product rows (the
+// Montgomery factor and the row carry); accumulators flushed; limbs of linear passes (add / sub / dbl / neg / lin /
+// conditional subtraction, final carry of a product), of selects, of comparisons, of AGPR moves, of LDS and of
+// global-memory accesses.
+enum : int { T_MAD, T_ROW, T_FLUSH, T_PASS, T_FINAL, T_REDUCE, T_SELECT, T_CMP, T_AGPR, T_LDS, T_GMEM, T_KINDS };
 
 template <int NL>
 struct FpParams {
@@ -97,6 +105,7 @@ struct LFp {
 // is a functional one, not a fast one.)
 template <int NL>
 __device__ __forceinline__ void a_load(Fp<NL>& r, const AFp<NL>& s) {
+  BGN_TALLY(T_AGPR, NL);
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     if constexpr (NL > 40)
@@ -108,6 +117,7 @@ __device__ __forceinline__ void a_load(Fp<NL>& r, const AFp<NL>& s) {
 
 template <int NL>
 __device__ __forceinline__ void a_store(AFp<NL>& s, const Fp<NL>& r) {
+  BGN_TALLY(T_AGPR, NL);
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     if constexpr (NL > 40)
@@ -119,6 +129,7 @@ __device__ __forceinline__ void a_store(AFp<NL>& s, const Fp<NL>& r) {
 
 template <int NL>
 __device__ __forceinline__ void l_store(LFp<NL>* s, const Fp<NL>& r) {
+  BGN_TALLY(T_LDS, NL);
   const int tid = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < NL / 2; ++k) s->rows[k][tid] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
@@ -127,6 +138,7 @@ __device__ __forceinline__ void l_store(LFp<NL>* s, const Fp<NL>& r) {
 
 template <int NL>
 __device__ __forceinline__ void l_load(Fp<NL>& r, const LFp<NL>* s) {
+  BGN_TALLY(T_LDS, NL);
   const int tid = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < NL / 2; ++k) {
@@ -143,6 +155,7 @@ __device__ __forceinline__ void l_load(Fp<NL>& r, const LFp<NL>* s) {
 // index is per lane and below 2^29.
 template <int NL>
 __device__ __forceinline__ void g_load(Fp<NL>& r, const u32* __restrict__ base, size_t stride, size_t e) {
+  BGN_TALLY(T_GMEM, NL);
   const u32 off = (u32)e * 4u;
   // recompute the row descriptors here (a few scalar adds) instead of letting them be hoisted out of the
   // enclosing loops, where 38 descriptors per operand would be spilled to VGPR lanes
@@ -153,6 +166,7 @@ __device__ __forceinline__ void g_load(Fp<NL>& r, const u32* __restrict__ base, 
 
 template <int NL>
 __device__ __forceinline__ void g_store(u32* __restrict__ base, size_t stride, size_t e, const Fp<NL>& a) {
+  BGN_TALLY(T_GMEM, NL);
   const u32 off = (u32)e * 4u;
   const unsigned long long st = gmem_pin_uniform(stride);
 #pragma unroll
@@ -162,6 +176,7 @@ __device__ __forceinline__ void g_store(u32* __restrict__ base, size_t stride, s
 // NL consecutive dwords at a per-lane pointer (table gathers).
 template <int NL>
 __device__ __forceinline__ void v_load(Fp<NL>& r, const u32* __restrict__ lane_ptr) {
+  BGN_TALLY(T_GMEM, NL);
 #pragma unroll
   for (int j = 0; j < NL; ++j) r.v[j] = lane_ptr[j];
 }
@@ -175,6 +190,7 @@ struct alignas(8) GVec2 { u32 v[2]; };
 
 template <int NL>
 __device__ __forceinline__ void v_load2(Fp<NL>& a, Fp<NL>& b, const u32* __restrict__ lane_ptr) {
+  BGN_TALLY(T_GMEM, 2 * NL);
   u32 w[2 * NL];
   if constexpr (NL % 2 == 0) {
     const GVec4* q = reinterpret_cast<const GVec4*>(lane_ptr);
@@ -216,6 +232,7 @@ __device__ __forceinline__ void fp_zero(Fp<NL>& r) {
 // r = a + b      (bound: B_a + B_b)
 template <int NL>
 __device__ __forceinline__ void fp_add(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b) {
+  BGN_TALLY(T_PASS, NL);
   u32 c = 0;
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
@@ -229,6 +246,7 @@ __device__ __forceinline__ void fp_add(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>&
 // r = 2a
 template <int NL>
 __device__ __forceinline__ void fp_dbl(Fp<NL>& r, const Fp<NL>& a) {
+  BGN_TALLY(T_PASS, NL);
   u32 c = 0;
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
@@ -243,6 +261,7 @@ __device__ __forceinline__ void fp_dbl(Fp<NL>& r, const Fp<NL>& a) {
 template <int K, int NL>
 __device__ __forceinline__ void fp_sub(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b,
                                        const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_PASS, NL);
   static_assert(K >= 1 && K <= KP_MAX, "K*p table");
   i32 c = 0;
 #pragma unroll
@@ -257,6 +276,7 @@ __device__ __forceinline__ void fp_sub(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>&
 // r = K*p - a   (negation), needs a <= K*p
 template <int K, int NL>
 __device__ __forceinline__ void fp_neg(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_PASS, NL);
   static_assert(K >= 1 && K <= KP_MAX, "K*p table");
   i32 c = 0;
 #pragma unroll
@@ -276,6 +296,7 @@ __device__ __forceinline__ void fp_neg(Fp<NL>& r, const Fp<NL>& a, const FpParam
 template <int CA, int CB, int CC, int K, int NL>
 __device__ __forceinline__ void fp_lin3(Fp<NL>& r, const Fp<NL>& a, const Fp<NL>& b, const Fp<NL>& c3,
                                         const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_PASS, NL);
   static_assert(K >= 0 && K <= KP_MAX, "K*p table");
   constexpr int pos = (CA > 0 ? CA : 0) + (CB > 0 ? CB : 0) + (CC > 0 ? CC : 0) + (K > 0 ? 1 : 0);
   constexpr int neg = (CA < 0 ? -CA : 0) + (CB < 0 ? -CB : 0) + (CC < 0 ? -CC : 0);
@@ -305,6 +326,7 @@ __device__ __forceinline__ void fp_lin1(Fp<NL>& r, const Fp<NL>& a, const FpPara
 // Conditional subtraction of p: r = (a >= p) ? a - p : a.  a < 2p -> r < p.
 template <int NL>
 __device__ __forceinline__ void fp_cond_sub_p(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_PASS, NL);
   Fp<NL> d;
   i32 c = 0;
 #pragma unroll
@@ -320,6 +342,7 @@ __device__ __forceinline__ void fp_cond_sub_p(Fp<NL>& r, const Fp<NL>& a, const 
 
 template <int NL>
 __device__ __forceinline__ bool fp_is_zero_limbs(const Fp<NL>& a) {
+  BGN_TALLY(T_CMP, NL);
   u32 o = 0;
 #pragma unroll
   for (int j = 0; j < NL; ++j) o |= a.v[j];
@@ -328,6 +351,7 @@ __device__ __forceinline__ bool fp_is_zero_limbs(const Fp<NL>& a) {
 
 template <int NL>
 __device__ __forceinline__ bool fp_eq_limbs(const Fp<NL>& a, const Fp<NL>& b) {
+  BGN_TALLY(T_CMP, NL);
   u32 o = 0;
 #pragma unroll
   for (int j = 0; j < NL; ++j) o |= a.v[j] ^ b.v[j];
@@ -336,6 +360,7 @@ __device__ __forceinline__ bool fp_eq_limbs(const Fp<NL>& a, const Fp<NL>& b) {
 
 template <int NL>
 __device__ __forceinline__ void fp_select(Fp<NL>& r, bool c, const Fp<NL>& a, const Fp<NL>& b) {
+  BGN_TALLY(T_SELECT, NL);
 #pragma unroll
   for (int j = 0; j < NL; ++j) r.v[j] = c ? a.v[j] : b.v[j];
 }
@@ -345,6 +370,7 @@ __device__ __forceinline__ void fp_select(Fp<NL>& r, bool c, const Fp<NL>& a, co
 // Each row adds two products of < 2^(2*LIMB_BITS) to an accumulator: see fp_flush below.
 // t += a*b (one v_mad_u64_u32); the emulation checks that the 64-bit accumulator does not wrap
 __device__ __forceinline__ void acc_mad(u64& t, u32 a, u32 b) {
+  BGN_TALLY(T_MAD, 1);
   const u64 x = (u64)a * b;
   BGN_CHECK_ALWAYS(t <= ~(u64)0 - x, "accumulator wraps: flush interval too long for these operands");
   t += x;
@@ -353,6 +379,7 @@ __device__ __forceinline__ void acc_mad(u64& t, u32 a, u32 b) {
 template <int NL>
 __device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
                                        const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_ROW, 1);
 #pragma unroll
   for (int j = 0; j < NL; ++j) acc_mad(t[j], ai, b.v[j]);
   const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
@@ -383,6 +410,7 @@ __device__ __forceinline__ void fp_row(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
 template <int NL>
 __device__ __forceinline__ void fp_row_first(u64 (&t)[NL], u32 ai, const Fp<NL>& b,
                                              const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_ROW, 1);
 #pragma unroll
   for (int j = 0; j < NL; ++j) t[j] = (u64)ai * b.v[j];
   const u32 m = ((u32)t[0] * P->pinv) & LIMB_MASK;
@@ -421,6 +449,7 @@ __device__ __forceinline__ u32 opaque_one() {
 // holds.  Three independent instructions per accumulator (shift, mask, multiply-add by one).
 template <int NL, int LO, int HI>
 __device__ __forceinline__ void fp_flush_range(u64 (&t)[NL]) {
+  BGN_TALLY(T_FLUSH, HI - LO);
   static_assert(0 <= LO && LO < HI && HI <= NL - 1, "flush range");
 #if BGN_TRIM_FLUSH
   const u32 one = opaque_one();
@@ -443,6 +472,7 @@ __device__ __forceinline__ void fp_flush_range(u64 (&t)[NL]) {
 // all of them (the top accumulator's excess stays in it: the value is below 2^(LIMB_BITS*NL) * small)
 template <int NL>
 __device__ __forceinline__ void fp_flush(u64 (&t)[NL]) {
+  BGN_TALLY(T_FLUSH, NL);
 #if BGN_TRIM_FLUSH
   fp_flush_range<NL, 0, NL - 1>(t);
 #else
@@ -520,6 +550,7 @@ __device__ __forceinline__ void fp_mul_inl(Fp<NL>& r, const LFp<NL>* a, const Fp
     r.v[j] = (u32)s & LIMB_MASK;
     c = s >> LIMB_BITS;
   }
+  BGN_TALLY(T_FINAL, NL);
   BGN_CHECK(c == 0, "fp_mul: result above 2^(LIMB_BITS*NL)");
 }
 
@@ -553,6 +584,7 @@ __device__ __forceinline__ void fp_mul(Fp<NL>& r, const LFp<NL>* a, const Fp<NL>
 template <int NL>
 __device__ __forceinline__ void fp_row2(u64 (&t)[NL], u32 ai, const Fp<NL>& b, u32 ci, const Fp<NL>& d,
                                         const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_ROW, 1);
 #pragma unroll
   for (int j = 0; j < NL; ++j) acc_mad(t[j], ai, b.v[j]);
 #pragma unroll
@@ -570,6 +602,7 @@ __device__ __forceinline__ void fp_row2(u64 (&t)[NL], u32 ai, const Fp<NL>& b, u
 template <int NL>
 __device__ __forceinline__ void fp_row2_first(u64 (&t)[NL], u32 ai, const Fp<NL>& b, u32 ci, const Fp<NL>& d,
                                               const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_ROW, 1);
 #pragma unroll
   for (int j = 0; j < NL; ++j) t[j] = (u64)ai * b.v[j];
 #pragma unroll
@@ -632,6 +665,7 @@ __device__ __forceinline__ void fp_mul2_inl(Fp<NL>& r, const LFp<NL>* a, const F
     r.v[j] = (u32)s & LIMB_MASK;
     cy = s >> LIMB_BITS;
   }
+  BGN_TALLY(T_FINAL, NL);
   BGN_CHECK(cy == 0, "fp_mul2: result above 2^(LIMB_BITS*NL)");
 }
 
@@ -663,6 +697,7 @@ __device__ __forceinline__ void fp_mul2(Fp<NL>& r, const LFp<NL>* a, const Fp<NL
 template <int NL, int LO, int HI>
 __device__ __forceinline__ void fp_sqr_row(u64 (&t)[NL], u32 ai, const Fp<NL>& a1,
                                            const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_ROW, 1);
   const u32 ai2 = ai << 1;
 #pragma unroll
   for (int j = LO; j < NL; ++j) acc_mad(t[j], j < HI ? ai : ai2, a1.v[j]);
@@ -680,6 +715,7 @@ __device__ __forceinline__ void fp_sqr_row(u64 (&t)[NL], u32 ai, const Fp<NL>& a
 template <int NL, int HI>
 __device__ __forceinline__ void fp_sqr_row_first(u64 (&t)[NL], u32 ai, const Fp<NL>& a1,
                                                  const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_ROW, 1);
   const u32 ai2 = ai << 1;
 #pragma unroll
   for (int j = 0; j < NL; ++j) t[j] = (u64)(j < HI ? ai : ai2) * a1.v[j];
@@ -784,6 +820,7 @@ __device__ __forceinline__ void fp_sqr_seg(Fp<NL>& r, const LFp<NL>* a, const Fp
       r.v[j] = (u32)s & LIMB_MASK;
       c = s >> LIMB_BITS;
     }
+    BGN_TALLY(T_FINAL, NL);
     BGN_CHECK(c == 0, "fp_sqr: result above 2^(LIMB_BITS*NL)");
   }
 }
@@ -844,6 +881,7 @@ __device__ __forceinline__ void fp_to_mont(Fp<NL>& r, const Fp<NL>& a, const FpP
 // K/2*p, ..., 2p, p: log2(K) passes and no product (a pass is about a fiftieth of one).
 template <int NL, int K>
 __device__ __forceinline__ void fp_reduce_lt(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_REDUCE, NL * (K >= 32 ? 5 : K >= 16 ? 4 : K >= 8 ? 3 : K >= 4 ? 2 : 1));
   static_assert(K >= 2 && K <= 32 && (K & (K - 1)) == 0, "bound must be a power of two in [2, 32]");
   Fp<NL> x = a;
 #pragma unroll

@@ -89,6 +89,7 @@ __device__ __forceinline__ void fp_inv(Fp<NL>& r, const Fp<NL>& a, LFp<NL>* L, c
 // subtraction of 4p, 2p, p (cheap: no product).
 template <int NL>
 __device__ __forceinline__ void fp_reduce8(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_REDUCE, 3 * NL);
   Fp<NL> x = a;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
@@ -395,14 +396,9 @@ __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp
                                            const Fp<NL>& x2, const Fp<NL>& y2, bool inf2,
                                            const FpParams<NL>* __restrict__ P) {
   const bool xe = fp_eq_limbs(x1, x2);
-  const bool ye = fp_eq_limbs(y1, y2);
-  const bool yz = fp_is_zero_limbs(y1);
-  int cs = G1C_ADD;
-  if (xe) cs = (ye && !yz) ? G1C_DBL : G1C_INF;
-  if (inf2) cs = G1C_A;
-  if (inf1) cs = inf2 ? G1C_INF : G1C_B;
-  Fp<NL> dd, da;
-  fp_dbl(dd, y1);                           // <2
+  const bool both = !inf1 && !inf2;
+  int cs = xe ? G1C_INF : G1C_ADD;
+  Fp<NL> da;
   fp_sub<1>(da, x2, x1, P);                 // <2, != 0 when x1 != x2
   Fp<NL> one;
   if constexpr (PLAIN) {
@@ -411,8 +407,20 @@ __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp
   } else {
     fp_set(one, P->one);
   }
-  fp_select(d, cs == G1C_ADD, da, one);
-  fp_select(d, cs == G1C_DBL, dd, d);
+  // (an identity operand: the denominator is the neutral one whatever the coordinates of the flagged point hold)
+  fp_select(d, both && !xe, da, one);
+  // equal abscissas — a doubling or opposite points — are looked at only when some lane of the wave has them: never,
+  // for operands that are not built to meet (the y comparisons and 2*y1 are a tenth of the addition's passes)
+  if (__ballot(xe && both)) {
+    const bool ye = fp_eq_limbs(y1, y2);
+    const bool yz = fp_is_zero_limbs(y1);
+    if (xe && ye && !yz) cs = G1C_DBL;
+    Fp<NL> dd;
+    fp_dbl(dd, y1);                         // <2
+    fp_select(d, both && cs == G1C_DBL, dd, d);
+  }
+  if (inf2) cs = G1C_A;
+  if (inf1) cs = inf2 ? G1C_INF : G1C_B;
   return cs;
 }
 
@@ -664,17 +672,18 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
       } else {
         fp_sqrv(x3, lam, P, L + 1);         // <2 ; L1 = lambda
       }
-      fp_sub<1>(x3, x3, x1, P);             // <3
-      fp_sub<1>(x3, x3, x2, P);             // <4
+      fp_lin3<1, -1, -1, 2>(x3, x3, x1, x2, P);   // lambda^2 - x1 - x2 <4 (one carry pass)
       fp_sub<4>(y3, x1, x3, P);             // <5
       fp_mul(y3, L + 1, y3, P);             // <2   (10)
       fp_sub<1>(y3, y3, y1, P);             // <3
       // select special cases (same representation as the inputs)
       const bool isA = cs == G1C_A, isB = cs == G1C_B;
-      fp_select(x3, isA, x1, x3);
-      fp_select(y3, isA, y1, y3);
-      fp_select(x3, isB, x2, x3);
-      fp_select(y3, isB, y2, y3);
+      if (__ballot(isA || isB)) {           // (an identity operand somewhere in the wave: a run's first step, zero digits)
+        fp_select(x3, isA, x1, x3);
+        fp_select(y3, isA, y1, y3);
+        fp_select(x3, isB, x2, x3);
+        fp_select(y3, isB, y2, y3);
+      }
       io.store(e, x3, y3, cs == G1C_INF, L, P);
     }
   }

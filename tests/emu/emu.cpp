@@ -8,6 +8,7 @@
 #include <vector>
 
 thread_local int bgn_emu_checks = 0;
+thread_local unsigned long long bgn_emu_tally[16] = {0};
 struct EmuChecks { EmuChecks() { bgn_emu_checks = 1; } ~EmuChecks() { bgn_emu_checks = 0; } };
 thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 1, 1}, blockDim = {256, 1, 1};
 
@@ -444,6 +445,9 @@ int emu_g1_fixed_checked = 0;
 void emu_set_g1_fixed_checks(int on) { emu_g1_fixed_checked = on; }
 int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, int sbits_q, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { struct Scope { Scope() { bgn_emu_checks = emu_g1_fixed_checked; } ~Scope() { bgn_emu_checks = 0; } } scope; DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, sbits_q, x, xlen, r, rlen, out, oinf)) }
 int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int sbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, sbits, windows, pow, tab)) }
+// BGN_TALLY counts of the calling thread since the last reset (fpmont.hpp T_*): tools/op_tally.py
+void emu_tally_reset() { for (auto& t : bgn_emu_tally) t = 0; }
+void emu_tally_read(unsigned long long* out) { for (int i = 0; i < 16; ++i) out[i] = bgn_emu_tally[i]; }
 // the signed recoding of one window on its own (ops.hpp scalar_window_digit): returns the digit, -2^wbits < d <= 2^wbits
 long long emu_window_digit(const uint8_t* k, size_t klen, int wbits, int sbits, int window, unsigned* idx) {
   const u32 d = bgn::scalar_window_digit(k, klen, wbits, sbits, window);

@@ -237,6 +237,17 @@ class Emu:
         assert self.lib.emu_tab_build(self.nl, self.params, self.consts, wbits, sbits, windows, pw, tab) == 0
         return tab
 
+    TALLY_KINDS = ("mad", "row", "flush", "pass", "final", "reduce", "select", "cmp", "agpr", "lds", "gmem")
+
+    def tally_reset(self):
+        self.lib.emu_tally_reset()
+
+    def tally(self) -> dict:
+        """Dynamic counts of the field primitives executed by this thread since tally_reset (fpmont.hpp BGN_TALLY)."""
+        out = (C.c_ulonglong * 16)()
+        self.lib.emu_tally_read(out)
+        return {k: int(out[i]) for i, k in enumerate(self.TALLY_KINDS)}
+
     def window_digit(self, k: int, klen: int, wbits: int, sbits: int, window: int):
         """(digit, table index) of one window of the signed recoding (ops.hpp scalar_window_digit)."""
         idx = C.c_uint()

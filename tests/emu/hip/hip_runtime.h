@@ -32,6 +32,7 @@ static inline void __syncthreads() {}   // lanes run one after the other; staged
 // range checks of the device headers (fpmont.hpp BGN_CHECK) are live in the emulation
 #define BGN_EMU 1
 extern thread_local int bgn_emu_checks;   // emu.cpp: on inside the pairing entry points
+extern thread_local unsigned long long bgn_emu_tally[16];   // emu.cpp: BGN_TALLY counts of the calling thread (fpmont.hpp T_*)
 #include <execinfo.h>
 #include <stdio.h>
 #include <stdlib.h>

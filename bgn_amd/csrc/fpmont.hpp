@@ -216,6 +216,31 @@ __device__ __forceinline__ void v_load2(Fp<NL>& a, Fp<NL>& b, const u32* __restr
   }
 }
 
+// The first of the two elements alone, with the same vector loads (NL % 4 == 0: 16-byte pieces; else 8-byte pieces
+// and, for an odd NL, one dword).
+template <int NL>
+__device__ __forceinline__ void v_load_first(Fp<NL>& a, const u32* __restrict__ lane_ptr) {
+  BGN_TALLY(T_GMEM, NL);
+  if constexpr (NL % 4 == 0) {
+    const GVec4* q = reinterpret_cast<const GVec4*>(lane_ptr);
+#pragma unroll
+    for (int k = 0; k < NL / 4; ++k) {
+      const GVec4 t = q[k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a.v[4 * k + i] = t.v[i];
+    }
+  } else {
+    const GVec2* q = reinterpret_cast<const GVec2*>(lane_ptr);
+#pragma unroll
+    for (int k = 0; k < NL / 2; ++k) {
+      const GVec2 t = q[k];
+      a.v[2 * k] = t.v[0];
+      a.v[2 * k + 1] = t.v[1];
+    }
+    if constexpr (NL % 2 != 0) a.v[NL - 1] = lane_ptr[NL - 1];
+  }
+}
+
 template <int NL>
 __device__ __forceinline__ void fp_set(Fp<NL>& r, const u32* __restrict__ c) {
 #pragma unroll

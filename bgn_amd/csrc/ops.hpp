@@ -391,10 +391,16 @@ constexpr int G1C_ADD = 0, G1C_DBL = 1, G1C_INF = 2, G1C_A = 3, G1C_B = 4;
 
 // Classify and return the denominator (canonical inputs <1).  d <2 (never 0 mod p).  The neutral
 // denominator of the special cases is the multiplicative identity of the inputs' representation.
-template <int NL, bool PLAIN = false>
+struct G1NoFetch {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// need_y: called (by every lane, inside the wave-uniform branch) before the ordinates are looked at — the first pass
+// of an addition run fetches y1, y2 only then (G1NoFetch: they are there already).
+template <int NL, bool PLAIN = false, class NeedY = G1NoFetch>
 __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp<NL>& y1, bool inf1,
                                            const Fp<NL>& x2, const Fp<NL>& y2, bool inf2,
-                                           const FpParams<NL>* __restrict__ P) {
+                                           const FpParams<NL>* __restrict__ P, const NeedY& need_y = NeedY()) {
   const bool xe = fp_eq_limbs(x1, x2);
   const bool both = !inf1 && !inf2;
   int cs = xe ? G1C_INF : G1C_ADD;
@@ -412,6 +418,7 @@ __device__ __forceinline__ int g1_classify(Fp<NL>& d, const Fp<NL>& x1, const Fp
   // equal abscissas — a doubling or opposite points — are looked at only when some lane of the wave has them: never,
   // for operands that are not built to meet (the y comparisons and 2*y1 are a tenth of the addition's passes)
   if (__ballot(xe && both)) {
+    need_y();
     const bool ye = fp_eq_limbs(y1, y2);
     const bool yz = fp_is_zero_limbs(y1);
     if (xe && ye && !yz) cs = G1C_DBL;
@@ -435,6 +442,16 @@ struct G1IoSoA {
     g_load(x, A.ax, A.sa, e);
     g_load(y, A.ay, A.sa, e);
     inf = A.ainf && A.ainf[e];
+  }
+  static constexpr bool kAbscissaLoads = true;
+  __device__ __forceinline__ void loadAx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+    g_load(x, A.ax, A.sa, e);
+    inf = A.ainf && A.ainf[e];
+  }
+  __device__ __forceinline__ void loadBx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+    const size_t eb = (A.sb == 1) ? 0 : e;
+    g_load(x, A.bx, A.sb, eb);
+    inf = A.binf && A.binf[eb];
   }
   __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     const size_t eb = (A.sb == 1) ? 0 : e;
@@ -464,6 +481,14 @@ struct G1IoSoA {
   }
 };
 
+// The abscissa of a table entry alone: no point of the curve has x = 0 but (0, 0), which no table holds, so a zero
+// abscissa is the all-zero entry (the identity).
+template <int NL>
+__device__ __forceinline__ void tab_load_x(Fp<NL>& x, bool& inf, const u32* __restrict__ ent) {
+  v_load_first(x, ent);
+  inf = fp_is_zero_limbs(x);
+}
+
 // Table entry -> coordinates; an all-zero entry stands for the identity (never a subgroup point).
 template <int NL>
 __device__ __forceinline__ void tab_load(Fp<NL>& x, Fp<NL>& y, bool& inf, const u32* __restrict__ ent) {
@@ -480,6 +505,16 @@ struct G1IoFixedStep {
     g_load(x, A.sx, A.ss, e);
     g_load(y, A.sy, A.ss, e);
     inf = A.sinf[e] != 0;
+  }
+  static constexpr bool kAbscissaLoads = true;
+  __device__ __forceinline__ void loadAx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+    g_load(x, A.sx, A.ss, e);
+    inf = A.sinf[e] != 0;
+  }
+  __device__ __forceinline__ void loadBx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+    const u32 d = scalar_window_digit(A.k + e * A.klen, A.klen, A.wbits, A.sbits, A.window);
+    tab_load_x<NL>(x, inf, A.tab + ((((size_t)A.window) << A.wbits) + (d & WD_INDEX)) * (size_t)(2 * NL));
+    inf = inf || (d & WD_ZERO) != 0;
   }
   __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     const u32 d = scalar_window_digit(A.k + e * A.klen, A.klen, A.wbits, A.sbits, A.window);
@@ -519,18 +554,35 @@ struct G1IoFixedChain {
     g_load(y, A.sy, A.ss, v);
     inf = A.sinf[v] != 0;
   }
-  __device__ __forceinline__ void loadB(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+  static constexpr bool kAbscissaLoads = true;
+  __device__ __forceinline__ void loadAx(size_t v, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+    g_load(x, A.sx, A.ss, v);
+    inf = A.sinf[v] != 0;
+  }
+  // the window's table entry of virtual element v and its digit word (scalar_window_digit)
+  __device__ __forceinline__ const u32* entry(size_t v, u32& d) const {
     const size_t c = v / A.pitch, e = v - c * A.pitch;
     const int gw = (int)c * A.steps + A.step;
     const bool live = e < A.count && gw < A.wx + A.wr;
     const bool isx = gw < A.wx;
     const int lw = isx ? gw : gw - A.wx;
-    u32 d = WD_ZERO;
+    d = WD_ZERO;
     const int wb = isx ? A.wbits_p : A.wbits_q;
     if (live) d = scalar_window_digit(isx ? A.x + e * A.xlen : A.r + e * A.rlen, isx ? A.xlen : A.rlen, wb, isx ? wb : A.sbits_q, lw);
     // entry (0, 0) is always mapped: dead lanes and zero digits read it and add the identity
     const u32* tab = isx ? A.tabP : A.tabQ;
-    tab_load<NL>(x, y, inf, tab + ((((size_t)(live ? lw : 0)) << wb) + (d & WD_INDEX)) * (size_t)(2 * NL));
+    return tab + ((((size_t)(live ? lw : 0)) << wb) + (d & WD_INDEX)) * (size_t)(2 * NL);
+  }
+  __device__ __forceinline__ void loadBx(size_t v, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+    u32 d;
+    const u32* ent = entry(v, d);
+    tab_load_x<NL>(x, inf, ent);
+    inf = inf || (d & WD_ZERO) != 0;
+  }
+  __device__ __forceinline__ void loadB(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    u32 d;
+    const u32* ent = entry(v, d);
+    tab_load<NL>(x, y, inf, ent);
     inf = inf || (d & WD_ZERO) != 0;
     if (A.sbits_q != A.wbits_q) {
       Fp<NL> ny;
@@ -554,6 +606,7 @@ struct G1IoFixedChain {
 template <int NL>
 struct G1IoTabRound {
   const G1TabRoundArgs& A;
+  static constexpr bool kAbscissaLoads = false;
   __device__ __forceinline__ void split(size_t e, size_t& w, size_t& j) const {
     const size_t per = ((size_t)1 << A.k) - 1;
     w = e / per;
@@ -610,9 +663,20 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
     if (e < count) {
       Fp<NL> x1, y1, x2, y2, d;
       bool i1, i2;
-      io.loadA(e, x1, y1, i1, P);
-      io.loadB(e, x2, y2, i2, P);
-      g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P);
+      if constexpr (IO::kAbscissaLoads) {
+        // the denominator of an addition is x2 - x1: the ordinates (and the negation of a signed digit's entry) are
+        // fetched only if some lane of the wave has equal abscissas
+        io.loadAx(e, x1, i1, P);
+        io.loadBx(e, x2, i2, P);
+        g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P, [&] {
+          io.loadA(e, x1, y1, i1, P);
+          io.loadB(e, x2, y2, i2, P);
+        });
+      } else {
+        io.loadA(e, x1, y1, i1, P);
+        io.loadB(e, x2, y2, i2, P);
+        g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P);
+      }
       g_store(prefix, sp, e, acc);
       l_store(L, acc);
       fp_mul(acc, L, d, P);                 // <2

@@ -131,6 +131,7 @@ __device__ __forceinline__ void poly_lin_gt_lane(const PolyLinArgs& A, size_t la
 template <int NL>
 struct G1IoPolySplit {
   const PolySplitArgs& A;
+  static constexpr bool kAbscissaLoads = false;
   __device__ __forceinline__ void where(size_t e, size_t& t, size_t& src) const {
     const size_t qp = e / A.h, i = e - qp * A.h;
     t = qp / A.n;

@@ -14,15 +14,40 @@ __device__ __forceinline__ u32 scalar_bit(const uint8_t* __restrict__ k, size_t 
   return (k[len - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u;
 }
 
+// The 64 bits of a big-endian scalar whose least significant byte is the scalar's byte `b_low` (byte 0 = the last one
+// of the array), as ONE load: klen >= 8, b_low <= klen - 8.  (Byte loads behind "is this byte inside the scalar"
+// branches cost a wait each — and a wait on the vector-memory counter waits for every load in flight, the
+// prefetched state of the next addition included.)
+__device__ __forceinline__ u64 scalar_word64(const uint8_t* __restrict__ k, size_t klen, size_t b_low) {
+  u64 v;
+  __builtin_memcpy(&v, k + (klen - 8 - b_low), 8);
+  return __builtin_bswap64(v);
+}
+
+// `nbits` (<= 56) bits of the scalar from bit `bit_lo` up; bits above the scalar read as zero.  klen >= 8.
+__device__ __forceinline__ u64 scalar_bits64(const uint8_t* __restrict__ k, size_t klen, size_t bit_lo, int nbits) {
+  size_t b_low = bit_lo >> 3;
+  if (b_low > klen - 8) b_low = klen - 8;
+  const u64 w = scalar_word64(k, klen, b_low);
+  const size_t sh = bit_lo - 8 * b_low;               // above 7 only for a field that reaches beyond the scalar
+  const u64 f = sh < 64 ? w >> sh : 0;
+  return f & (((u64)1 << nbits) - 1);
+}
+
 // Digit `window` (wbits <= 24 bits wide, counted from the least significant end) of a big-endian scalar; bytes above
 // the scalar read as zero.
 __device__ __forceinline__ u32 scalar_window_any(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
+  if (klen >= 8) return (u32)scalar_bits64(k, klen, (size_t)window * (size_t)wbits, wbits);
   const size_t bit0 = (size_t)window * (size_t)wbits;
   const size_t byte = bit0 >> 3;
   u32 v = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (byte + i < klen) v |= (u32)k[klen - 1 - (byte + i)] << (8 * i);
+  for (int i = 0; i < 4; ++i) {
+    // (a byte above the scalar: some byte of it is read instead and dropped — four loads in flight, no branch)
+    const bool in = byte + i < klen;
+    const u32 b = k[in ? klen - 1 - (byte + i) : 0];
+    v |= (in ? b : 0u) << (8 * i);
+  }
   return (v >> (bit0 & 7)) & ((1u << wbits) - 1u);      // wbits + 7 <= 31 bits of the 32 fetched
 }
 
@@ -31,9 +56,9 @@ __device__ __forceinline__ u32 scalar_window(const uint8_t* __restrict__ k, size
   if (wbits == 8) return k[klen - 1 - (size_t)window];
   if (wbits == 16) {
     const size_t lo = 2 * (size_t)window;
-    u32 d = k[klen - 1 - lo];
-    if (lo + 1 < klen) d |= (u32)k[klen - 2 - lo] << 8;
-    return d;
+    const bool two = lo + 1 < klen;
+    const u32 d = k[klen - 1 - lo], hi = k[two ? klen - 2 - lo : klen - 1 - lo];     // both in flight, no branch
+    return d | ((two ? hi : 0u) << 8);
   }
   return scalar_window_any(k, klen, wbits, window);
 }
@@ -55,11 +80,19 @@ __device__ __forceinline__ u32 scalar_window_digit(const uint8_t* __restrict__ k
     return d | (d == 0 ? WD_ZERO : 0u);
   }
   const u32 H = 1u << wbits;
-  u32 t = scalar_window_any(k, klen, sbits, window);
-  // the window below is fetched with the window itself (independent loads: the table address waits for one round
-  // trip, not two); only when it is exactly 2^wbits does the decision move further down
-  u32 below = scalar_window_any(k, klen, sbits, window > 0 ? window - 1 : 0);
-  if (window == 0) below = 0;
+  // the window and the one below it: one fetch of 2 * sbits bits (two, independent, for scalars shorter than 8 bytes);
+  // only when the window below is exactly 2^wbits does the decision move further down
+  u32 t, below;
+  if (klen >= 8) {
+    const size_t lo = (size_t)(window > 0 ? window - 1 : 0) * (size_t)sbits;
+    const u64 f = scalar_bits64(k, klen, lo, window > 0 ? 2 * sbits : sbits);
+    below = window > 0 ? (u32)f & ((1u << sbits) - 1u) : 0u;
+    t = window > 0 ? (u32)(f >> sbits) : (u32)f;
+  } else {
+    t = scalar_window_any(k, klen, sbits, window);       // (the top window may lie above the scalar)
+    below = scalar_window_any(k, klen, sbits, window > 0 ? window - 1 : 0);
+    if (window == 0) below = 0;
+  }
   if (below == H) {
     below = 0;
 #pragma unroll 1
@@ -443,7 +476,7 @@ struct G1IoSoA {
     g_load(y, A.ay, A.sa, e);
     inf = A.ainf && A.ainf[e];
   }
-  static constexpr bool kAbscissaLoads = true;
+  static constexpr bool kAbscissaLoads = true, kZeroAbscissaIsIdentity = false;
   __device__ __forceinline__ void loadAx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
     g_load(x, A.ax, A.sa, e);
     inf = A.ainf && A.ainf[e];
@@ -482,11 +515,11 @@ struct G1IoSoA {
 };
 
 // The abscissa of a table entry alone: no point of the curve has x = 0 but (0, 0), which no table holds, so a zero
-// abscissa is the all-zero entry (the identity).
+// abscissa is the all-zero entry (the identity) — tested by the consumer (kZeroAbscissaIsIdentity), not here: a load
+// whose value nothing looks at yet can stay in flight behind the previous element's product.
 template <int NL>
-__device__ __forceinline__ void tab_load_x(Fp<NL>& x, bool& inf, const u32* __restrict__ ent) {
+__device__ __forceinline__ void tab_load_x(Fp<NL>& x, const u32* __restrict__ ent) {
   v_load_first(x, ent);
-  inf = fp_is_zero_limbs(x);
 }
 
 // Table entry -> coordinates; an all-zero entry stands for the identity (never a subgroup point).
@@ -506,15 +539,15 @@ struct G1IoFixedStep {
     g_load(y, A.sy, A.ss, e);
     inf = A.sinf[e] != 0;
   }
-  static constexpr bool kAbscissaLoads = true;
+  static constexpr bool kAbscissaLoads = true, kZeroAbscissaIsIdentity = true;
   __device__ __forceinline__ void loadAx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
     g_load(x, A.sx, A.ss, e);
     inf = A.sinf[e] != 0;
   }
   __device__ __forceinline__ void loadBx(size_t e, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
     const u32 d = scalar_window_digit(A.k + e * A.klen, A.klen, A.wbits, A.sbits, A.window);
-    tab_load_x<NL>(x, inf, A.tab + ((((size_t)A.window) << A.wbits) + (d & WD_INDEX)) * (size_t)(2 * NL));
-    inf = inf || (d & WD_ZERO) != 0;
+    tab_load_x<NL>(x, A.tab + ((((size_t)A.window) << A.wbits) + (d & WD_INDEX)) * (size_t)(2 * NL));
+    inf = (d & WD_ZERO) != 0;
   }
   __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     const u32 d = scalar_window_digit(A.k + e * A.klen, A.klen, A.wbits, A.sbits, A.window);
@@ -554,7 +587,7 @@ struct G1IoFixedChain {
     g_load(y, A.sy, A.ss, v);
     inf = A.sinf[v] != 0;
   }
-  static constexpr bool kAbscissaLoads = true;
+  static constexpr bool kAbscissaLoads = true, kZeroAbscissaIsIdentity = true;
   __device__ __forceinline__ void loadAx(size_t v, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
     g_load(x, A.sx, A.ss, v);
     inf = A.sinf[v] != 0;
@@ -576,8 +609,8 @@ struct G1IoFixedChain {
   __device__ __forceinline__ void loadBx(size_t v, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
     u32 d;
     const u32* ent = entry(v, d);
-    tab_load_x<NL>(x, inf, ent);
-    inf = inf || (d & WD_ZERO) != 0;
+    tab_load_x<NL>(x, ent);
+    inf = (d & WD_ZERO) != 0;
   }
   __device__ __forceinline__ void loadB(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     u32 d;
@@ -656,30 +689,51 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
   const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
   Fp<NL> acc;
   fp_set(acc, P->one);
-  // pass 1: prefix products of the denominators
+  // pass 1: prefix products of the denominators.  The denominator of an addition is x2 - x1: policies with
+  // abscissa loads fetch the ordinates (and negate a signed digit's entry) only if some lane of the wave has equal
+  // abscissas, and the abscissas of the NEXT element are requested before this element's product, so that the scalar
+  // bytes, the table gather behind them and the state's load are in flight while the multiply-adds run.
+  if constexpr (IO::kAbscissaLoads) {
+    Fp<NL> x1n, x2n;
+    bool i1n = false, i2n = false;
+    if (t < count && run > 0) {
+      io.loadAx(t, x1n, i1n, P);
+      io.loadBx(t, x2n, i2n, P);
+    }
 #pragma unroll 1
-  for (int j = 0; j < run; ++j) {
-    const size_t e = (size_t)j * T + t;
-    if (e < count) {
-      Fp<NL> x1, y1, x2, y2, d;
-      bool i1, i2;
-      if constexpr (IO::kAbscissaLoads) {
-        // the denominator of an addition is x2 - x1: the ordinates (and the negation of a signed digit's entry) are
-        // fetched only if some lane of the wave has equal abscissas
-        io.loadAx(e, x1, i1, P);
-        io.loadBx(e, x2, i2, P);
+    for (int j = 0; j < run; ++j) {
+      const size_t e = (size_t)j * T + t;
+      Fp<NL> x1 = x1n, x2 = x2n, y1, y2, d;
+      bool i1 = i1n, i2 = i2n;
+      if (j + 1 < run && e + T < count) {
+        io.loadAx(e + T, x1n, i1n, P);
+        io.loadBx(e + T, x2n, i2n, P);
+      }
+      if (e < count) {
+        if constexpr (IO::kZeroAbscissaIsIdentity) i2 = i2 || fp_is_zero_limbs(x2);
         g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P, [&] {
           io.loadA(e, x1, y1, i1, P);
           io.loadB(e, x2, y2, i2, P);
         });
-      } else {
+        g_store(prefix, sp, e, acc);
+        l_store(L, acc);
+        fp_mul(acc, L, d, P);               // <2
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int j = 0; j < run; ++j) {
+      const size_t e = (size_t)j * T + t;
+      if (e < count) {
+        Fp<NL> x1, y1, x2, y2, d;
+        bool i1, i2;
         io.loadA(e, x1, y1, i1, P);
         io.loadB(e, x2, y2, i2, P);
         g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P);
+        g_store(prefix, sp, e, acc);
+        l_store(L, acc);
+        fp_mul(acc, L, d, P);               // <2
       }
-      g_store(prefix, sp, e, acc);
-      l_store(L, acc);
-      fp_mul(acc, L, d, P);                 // <2
     }
   }
   Fp<NL> inv;

@@ -74,26 +74,27 @@ __device__ __forceinline__ u32 scalar_window(const uint8_t* __restrict__ k, size
 // digit is 0: add nothing).
 constexpr u32 WD_NEG = 1u << 30, WD_ZERO = 1u << 31, WD_INDEX = (1u << 24) - 1u;
 
-__device__ __forceinline__ u32 scalar_window_digit(const uint8_t* __restrict__ k, size_t klen, int wbits, int sbits, int window) {
-  if (sbits == wbits) {                       // unsigned windows: the digit is the index
-    const u32 d = scalar_window(k, klen, wbits, window);
-    return d | (d == 0 ? WD_ZERO : 0u);
-  }
+// Fetch and decoding are two calls, so that a kernel can request the bytes of the NEXT element's window before it
+// starts on this element's products and look at them afterwards (a value nobody looks at costs no wait):
+// scalar_digit_prefetchable says whether the one-word fetch applies (signed windows, scalars of 8 bytes and more);
+// scalar_digit_fetch returns the 8 bytes as loaded; scalar_digit_decode makes the digit word of them.
+__device__ __forceinline__ bool scalar_digit_prefetchable(size_t klen, int wbits, int sbits) {
+  return sbits != wbits && klen >= 8;
+}
+
+__device__ __forceinline__ u64 scalar_digit_fetch(const uint8_t* __restrict__ k, size_t klen, int sbits, int window) {
+  const size_t lo = (size_t)(window > 0 ? window - 1 : 0) * (size_t)sbits;
+  size_t b_low = lo >> 3;
+  if (b_low > klen - 8) b_low = klen - 8;
+  u64 v;
+  __builtin_memcpy(&v, k + (klen - 8 - b_low), 8);
+  return v;
+}
+
+__device__ __forceinline__ u32 scalar_signed_digit(u32 t, u32 below, const uint8_t* __restrict__ k, size_t klen, int wbits,
+                                                   int sbits, int window) {
   const u32 H = 1u << wbits;
-  // the window and the one below it: one fetch of 2 * sbits bits (two, independent, for scalars shorter than 8 bytes);
-  // only when the window below is exactly 2^wbits does the decision move further down
-  u32 t, below;
-  if (klen >= 8) {
-    const size_t lo = (size_t)(window > 0 ? window - 1 : 0) * (size_t)sbits;
-    const u64 f = scalar_bits64(k, klen, lo, window > 0 ? 2 * sbits : sbits);
-    below = window > 0 ? (u32)f & ((1u << sbits) - 1u) : 0u;
-    t = window > 0 ? (u32)(f >> sbits) : (u32)f;
-  } else {
-    t = scalar_window_any(k, klen, sbits, window);       // (the top window may lie above the scalar)
-    below = scalar_window_any(k, klen, sbits, window > 0 ? window - 1 : 0);
-    if (window == 0) below = 0;
-  }
-  if (below == H) {
+  if (below == H) {                            // 2^-sbits of the windows: the decision moves further down
     below = 0;
 #pragma unroll 1
     for (int v = window - 2; v >= 0; --v) {
@@ -108,6 +109,33 @@ __device__ __forceinline__ u32 scalar_window_digit(const uint8_t* __restrict__ k
   const bool neg = t > H;
   const u32 mag = neg ? (H << 1) - t : t;     // 0 .. 2^wbits
   return (mag & (H - 1)) | (neg ? WD_NEG : 0u) | (mag == 0 ? WD_ZERO : 0u);
+}
+
+// (raw: what scalar_digit_fetch returned for the same k, klen, sbits, window; scalar_digit_prefetchable holds)
+__device__ __forceinline__ u32 scalar_digit_decode(u64 raw, const uint8_t* __restrict__ k, size_t klen, int wbits, int sbits,
+                                                   int window) {
+  const size_t lo = (size_t)(window > 0 ? window - 1 : 0) * (size_t)sbits;
+  size_t b_low = lo >> 3;
+  if (b_low > klen - 8) b_low = klen - 8;
+  const size_t sh = lo - 8 * b_low;             // above 7 only for a field that reaches beyond the scalar
+  const u64 w = __builtin_bswap64(raw);
+  const u64 f = sh < 64 ? w >> sh : 0;
+  const u32 M = (1u << sbits) - 1u;
+  const u32 below = window > 0 ? (u32)f & M : 0u;
+  const u32 t = window > 0 ? (u32)(f >> sbits) & M : (u32)f & M;
+  return scalar_signed_digit(t, below, k, klen, wbits, sbits, window);
+}
+
+__device__ __forceinline__ u32 scalar_window_digit(const uint8_t* __restrict__ k, size_t klen, int wbits, int sbits, int window) {
+  if (sbits == wbits) {                       // unsigned windows: the digit is the index
+    const u32 d = scalar_window(k, klen, wbits, window);
+    return d | (d == 0 ? WD_ZERO : 0u);
+  }
+  // the window and the one below it: one fetch of 2 * sbits bits (two, independent, for scalars shorter than 8 bytes)
+  if (klen >= 8) return scalar_digit_decode(scalar_digit_fetch(k, klen, sbits, window), k, klen, wbits, sbits, window);
+  const u32 t = scalar_window_any(k, klen, sbits, window);       // (the top window may lie above the scalar)
+  const u32 below = window > 0 ? scalar_window_any(k, klen, sbits, window - 1) : 0u;
+  return scalar_signed_digit(t, below, k, klen, wbits, sbits, window);
 }
 
 // r = 1/a ; a <4 in VGPRs ; result <1 (0 for a = 0).  Uses L[0] (stage).  Division steps (fpinv.hpp), not
@@ -486,6 +514,14 @@ struct G1IoSoA {
     g_load(x, A.bx, A.sb, eb);
     inf = A.binf && A.binf[eb];
   }
+  // (no scalar behind the second operand: nothing to request ahead)
+  __device__ __forceinline__ u64 fetchB(size_t) const { return 0; }
+  __device__ __forceinline__ void loadBx(size_t e, u64, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    loadBx(e, x, inf, P);
+  }
+  __device__ __forceinline__ void loadB(size_t e, u64, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    loadB(e, x, y, inf, P);
+  }
   __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     const size_t eb = (A.sb == 1) ? 0 : e;
     g_load(x, A.bx, A.sb, eb);
@@ -549,6 +585,13 @@ struct G1IoFixedStep {
     tab_load_x<NL>(x, A.tab + ((((size_t)A.window) << A.wbits) + (d & WD_INDEX)) * (size_t)(2 * NL));
     inf = (d & WD_ZERO) != 0;
   }
+  __device__ __forceinline__ u64 fetchB(size_t) const { return 0; }       // (the fallback path decodes on the spot)
+  __device__ __forceinline__ void loadBx(size_t e, u64, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    loadBx(e, x, inf, P);
+  }
+  __device__ __forceinline__ void loadB(size_t e, u64, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    loadB(e, x, y, inf, P);
+  }
   __device__ __forceinline__ void loadB(size_t e, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     const u32 d = scalar_window_digit(A.k + e * A.klen, A.klen, A.wbits, A.sbits, A.window);
     tab_load<NL>(x, y, inf, A.tab + ((((size_t)A.window) << A.wbits) + (d & WD_INDEX)) * (size_t)(2 * NL));
@@ -592,29 +635,53 @@ struct G1IoFixedChain {
     g_load(x, A.sx, A.ss, v);
     inf = A.sinf[v] != 0;
   }
-  // the window's table entry of virtual element v and its digit word (scalar_window_digit)
-  __device__ __forceinline__ const u32* entry(size_t v, u32& d) const {
-    const size_t c = v / A.pitch, e = v - c * A.pitch;
+  // which window of which scalar virtual element v adds
+  struct Where {
+    size_t e;
+    int lw;
+    bool live, isx;
+  };
+  __device__ __forceinline__ Where where(size_t v) const {
+    Where w;
+    const size_t c = v / A.pitch;
+    w.e = v - c * A.pitch;
     const int gw = (int)c * A.steps + A.step;
-    const bool live = e < A.count && gw < A.wx + A.wr;
-    const bool isx = gw < A.wx;
-    const int lw = isx ? gw : gw - A.wx;
-    d = WD_ZERO;
-    const int wb = isx ? A.wbits_p : A.wbits_q;
-    if (live) d = scalar_window_digit(isx ? A.x + e * A.xlen : A.r + e * A.rlen, isx ? A.xlen : A.rlen, wb, isx ? wb : A.sbits_q, lw);
-    // entry (0, 0) is always mapped: dead lanes and zero digits read it and add the identity
-    const u32* tab = isx ? A.tabP : A.tabQ;
-    return tab + ((((size_t)(live ? lw : 0)) << wb) + (d & WD_INDEX)) * (size_t)(2 * NL);
+    w.live = w.e < A.count && gw < A.wx + A.wr;
+    w.isx = gw < A.wx;
+    w.lw = w.isx ? gw : gw - A.wx;
+    return w;
   }
-  __device__ __forceinline__ void loadBx(size_t v, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
+  // the bytes of v's window of r, requested ahead (scalar_digit_fetch); 0 where the digit is decoded on the spot
+  __device__ __forceinline__ u64 fetchB(size_t v) const {
+    const Where w = where(v);
+    if (w.live && !w.isx && scalar_digit_prefetchable(A.rlen, A.wbits_q, A.sbits_q))
+      return scalar_digit_fetch(A.r + w.e * A.rlen, A.rlen, A.sbits_q, w.lw);
+    return 0;
+  }
+  // the window's table entry of virtual element v and its digit word (raw: what fetchB(v) returned)
+  __device__ __forceinline__ const u32* entry(size_t v, u64 raw, u32& d) const {
+    const Where w = where(v);
+    d = WD_ZERO;
+    const int wb = w.isx ? A.wbits_p : A.wbits_q;
+    if (w.live) {
+      if (!w.isx && scalar_digit_prefetchable(A.rlen, A.wbits_q, A.sbits_q))
+        d = scalar_digit_decode(raw, A.r + w.e * A.rlen, A.rlen, wb, A.sbits_q, w.lw);
+      else
+        d = scalar_window_digit(w.isx ? A.x + w.e * A.xlen : A.r + w.e * A.rlen, w.isx ? A.xlen : A.rlen, wb, w.isx ? wb : A.sbits_q, w.lw);
+    }
+    // entry (0, 0) is always mapped: dead lanes and zero digits read it and add the identity
+    const u32* tab = w.isx ? A.tabP : A.tabQ;
+    return tab + ((((size_t)(w.live ? w.lw : 0)) << wb) + (d & WD_INDEX)) * (size_t)(2 * NL);
+  }
+  __device__ __forceinline__ void loadBx(size_t v, u64 raw, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__) const {
     u32 d;
-    const u32* ent = entry(v, d);
+    const u32* ent = entry(v, raw, d);
     tab_load_x<NL>(x, ent);
     inf = (d & WD_ZERO) != 0;
   }
-  __device__ __forceinline__ void loadB(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+  __device__ __forceinline__ void loadB(size_t v, u64 raw, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
     u32 d;
-    const u32* ent = entry(v, d);
+    const u32* ent = entry(v, raw, d);
     tab_load<NL>(x, y, inf, ent);
     inf = inf || (d & WD_ZERO) != 0;
     if (A.sbits_q != A.wbits_q) {
@@ -622,6 +689,12 @@ struct G1IoFixedChain {
       fp_neg<1>(ny, y, P);                   // (an entry is a point of odd order: y != 0, so p - y is canonical)
       fp_select(y, (d & WD_NEG) != 0, ny, y);
     }
+  }
+  __device__ __forceinline__ void loadBx(size_t v, Fp<NL>& x, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    loadBx(v, fetchB(v), x, inf, P);
+  }
+  __device__ __forceinline__ void loadB(size_t v, Fp<NL>& x, Fp<NL>& y, bool& inf, const FpParams<NL>* __restrict__ P) const {
+    loadB(v, fetchB(v), x, y, inf, P);
   }
   __device__ __forceinline__ void store(size_t v, const Fp<NL>& x3, const Fp<NL>& y3, bool inf, LFp<NL>*,
                                         const FpParams<NL>* __restrict__ P) const {
@@ -696,9 +769,11 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
   if constexpr (IO::kAbscissaLoads) {
     Fp<NL> x1n, x2n;
     bool i1n = false, i2n = false;
+    u64 rawn = 0;                           // the scalar bytes of element j + 1's window, requested during element j - 1
     if (t < count && run > 0) {
       io.loadAx(t, x1n, i1n, P);
-      io.loadBx(t, x2n, i2n, P);
+      io.loadBx(t, io.fetchB(t), x2n, i2n, P);
+      if (run > 1 && t + T < count) rawn = io.fetchB(t + T);
     }
 #pragma unroll 1
     for (int j = 0; j < run; ++j) {
@@ -707,7 +782,8 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
       bool i1 = i1n, i2 = i2n;
       if (j + 1 < run && e + T < count) {
         io.loadAx(e + T, x1n, i1n, P);
-        io.loadBx(e + T, x2n, i2n, P);
+        io.loadBx(e + T, rawn, x2n, i2n, P);
+        if (j + 2 < run && e + 2 * T < count) rawn = io.fetchB(e + 2 * T);
       }
       if (e < count) {
         if constexpr (IO::kZeroAbscissaIsIdentity) i2 = i2 || fp_is_zero_limbs(x2);
@@ -736,17 +812,31 @@ __device__ __forceinline__ void g1_add_run(const IO& io, size_t count, int run, 
       }
     }
   }
+  u64 rawp = 0;
+  if constexpr (IO::kAbscissaLoads) {
+    const size_t el = (size_t)(run - 1) * T + t;
+    if (run > 0 && el < count) rawp = io.fetchB(el);
+  }
   Fp<NL> inv;
   fp_inv<NL>(inv, acc, L, C, P);            // <1
-  // pass 2: walk back, peel one inverse per element
+  // pass 2: walk back, peel one inverse per element (the scalar bytes of the element before requested one element
+  // ahead, the first ones above — behind the inversion)
 #pragma unroll 1
   for (int j = run - 1; j >= 0; --j) {
     const size_t e = (size_t)j * T + t;
+    u64 raw = 0;
+    if constexpr (IO::kAbscissaLoads) {
+      raw = rawp;
+      if (j > 0 && e - T < count) rawp = io.fetchB(e - T);
+    }
     if (e < count) {
       Fp<NL> x1, y1, x2, y2, d;
       bool i1, i2;
       io.loadA(e, x1, y1, i1, P);
-      io.loadB(e, x2, y2, i2, P);
+      if constexpr (IO::kAbscissaLoads)
+        io.loadB(e, raw, x2, y2, i2, P);
+      else
+        io.loadB(e, x2, y2, i2, P);
       const int cs = g1_classify<NL, PLAIN>(d, x1, y1, i1, x2, y2, i2, P);
       Fp<NL> dinv;
       {

@@ -92,7 +92,7 @@ const char* bgn_version(void);
  *                     most 2^31 (34 GB — what round 4 paid 69 GB for).  What fewer steps cost
  *                     (profiles/r04_decrypt_vs_table.csv, option bsgs_max_log2): 2^30, 17 GB, -8 % decrypts/s;
  *                     2^29, 8.6 GB, -21 %; 2^28, 4.3 GB, -38 %
- *   windows of Q      2^20 entries per window, 14.8 GB: 1.8e7 encrypts/s.  The windows are SIGNED: each takes 21 bits
+ *   windows of Q      2^20 entries per window, 14.8 GB: 2.0e7 encrypts/s.  The windows are SIGNED: each takes 21 bits
  *                     of the blinding exponent as a digit in (-2^20, 2^20] and adds the entry of its magnitude, negated
  *                     for a negative digit (index 0 holds the magnitude 2^20) — 49 additions for a 1024-bit exponent
  *                     where unsigned 20-bit windows over the same entries take 52 (option fixed_signed_q = 0: -4 %,

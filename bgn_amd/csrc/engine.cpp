@@ -1555,10 +1555,11 @@ int fixed_base_product(bgn_ctx* c, hipStream_t s, SoA2 S, uint32_t* prefix, cons
   // functional one (5.6 x 10^4 encryptions/s, profiles/r04_rates_2048.csv).  At the other key sizes the chain kernels'
   // seventeen launches are latency-bound below a full chip: profiles/r04_encrypt_paths.csv, 1024 bits: one Encrypt
   // 4.7 -> 1.0 ms, 4096 4.8 -> 1.05 ms, 16384 5.0 -> 2.3 ms, 65536 7.5 = 7.5 ms (512 bits: 1.09 -> 0.34, 1.15 -> 0.36,
-  // 1.21 -> 0.65, 1.77 against 1.87), so the lane groups take every batch below the crossing.  Option quad_max_enc overrides.
+  // 1.21 -> 0.65, 1.77 against 1.87), so the lane groups take every batch below the crossing — 55 000 / 49 000 elements
+  // since the chain kernels got faster in round 5 (profiles/r05_encrypt_paths.csv).  Option quad_max_enc overrides.
   {
     const int64_t ov = opt(c, &Options::quad_max_enc);
-    const size_t lim = ov >= 0 ? (size_t)ov : (c->nl > 40 ? kMaxBatch : c->nl >= 36 ? 60000 : c->nl >= 19 ? 56000 : 32768);
+    const size_t lim = ov >= 0 ? (size_t)ov : (c->nl > 40 ? kMaxBatch : c->nl >= 36 ? 55000 : c->nl >= 19 ? 49000 : 32768);
     const size_t sw = round_up(count, 64);
     const size_t need = quad_g1_fixed_ws_words(c->nl, sw) * 4;
     if (count <= lim && need && steps > 0) {

@@ -303,13 +303,30 @@ k_g1_mul_quad(const FpParams<NL>* __restrict__ P, const u32* __restrict__ bx, co
 // the neighbours), non-zero for opposite ones (the sum is the identity).  Ends like k_g1_mul_quad: X, Y parked, Z
 // canonical for the inversion, flags (the identity; never "exceptional").
 // Digit `window` (wbits <= 24) of a big-endian scalar, as ops.hpp scalar_window.
+// (one unaligned 8-byte load for scalars of 8 bytes and more — bytes fetched one by one behind "is it inside the scalar"
+// branches cost a round trip each; the byte path of shorter scalars is branch-free)
+__device__ __forceinline__ u64 quad_scalar_bits64(const uint8_t* __restrict__ k, size_t klen, size_t bit_lo, int nbits) {
+  size_t b_low = bit_lo >> 3;
+  if (b_low > klen - 8) b_low = klen - 8;
+  u64 v;
+  __builtin_memcpy(&v, k + (klen - 8 - b_low), 8);
+  const u64 w = __builtin_bswap64(v);
+  const size_t sh = bit_lo - 8 * b_low;
+  const u64 f = sh < 64 ? w >> sh : 0;
+  return f & (((u64)1 << nbits) - 1);
+}
+
 __device__ __forceinline__ u32 quad_scalar_window(const uint8_t* __restrict__ k, size_t klen, int wbits, int window) {
   const size_t bit0 = (size_t)window * (size_t)wbits;
+  if (klen >= 8) return (u32)quad_scalar_bits64(k, klen, bit0, wbits);
   const size_t byte = bit0 >> 3;
   u32 v = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (byte + i < klen) v |= (u32)k[klen - 1 - (byte + i)] << (8 * i);
+  for (int i = 0; i < 4; ++i) {
+    const bool in = byte + i < klen;
+    const u32 b = k[in ? klen - 1 - (byte + i) : 0];
+    v |= (in ? b : 0u) << (8 * i);
+  }
   return (v >> (bit0 & 7)) & ((1u << wbits) - 1u);
 }
 
@@ -325,9 +342,15 @@ __device__ __forceinline__ void quad_window_digit(const uint8_t* __restrict__ k,
     return;
   }
   const u32 H = 1u << wbits;
-  u32 t = quad_scalar_window(k, klen, sbits, window);
-  u32 below = quad_scalar_window(k, klen, sbits, window > 0 ? window - 1 : 0);      // fetched with the window itself
-  if (window == 0) below = 0;
+  u32 t, below;
+  if (klen >= 8) {                           // the window and the one below it in one fetch
+    const u64 f = quad_scalar_bits64(k, klen, (size_t)(window > 0 ? window - 1 : 0) * (size_t)sbits, window > 0 ? 2 * sbits : sbits);
+    below = window > 0 ? (u32)f & ((1u << sbits) - 1u) : 0u;
+    t = window > 0 ? (u32)(f >> sbits) : (u32)f;
+  } else {
+    t = quad_scalar_window(k, klen, sbits, window);
+    below = window > 0 ? quad_scalar_window(k, klen, sbits, window - 1) : 0u;
+  }
   if (below == H) {
     below = 0;
 #pragma unroll 1

@@ -95,9 +95,9 @@ const char* bgn_version(void);
  *   windows of Q      2^20 entries per window, 14.8 GB: 2.0e7 encrypts/s.  The windows are SIGNED: each takes 21 bits
  *                     of the blinding exponent as a digit in (-2^20, 2^20] and adds the entry of its magnitude, negated
  *                     for a negative digit (index 0 holds the magnitude 2^20) — 49 additions for a 1024-bit exponent
- *                     where unsigned 20-bit windows over the same entries take 52 (option fixed_signed_q = 0: -4 %,
+ *                     where unsigned 20-bit windows over the same entries take 52 (option fixed_signed_q = 0: -10 %,
  *                     profiles/r05_encrypt_signed_windows.csv).  2^22 entries, 54 GB, +8 % (option
- *                     fixed_window_bits_q = 22); 2^18, 4.1 GB, -10 %; 2^16, 1.2 GB, -15 %
+ *                     fixed_window_bits_q = 22); 2^18, 4.1 GB, -12 %; 2^16, 1.2 GB, -17 %
  *                     (profiles/r05_encrypt_vs_window.csv)
  *   windows of P      16-bit windows, 2 * NL * 4 B per entry (1.2 GB); the GT table of e(Q,Q) likewise
  *   workspace         7.4 KB per pairing of the largest batch seen (7.8 GB at 2^20; larger batches run in pieces)

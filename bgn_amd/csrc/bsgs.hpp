@@ -333,7 +333,7 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
       fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
       rp = rc;
-      fp_reduce8(rc, nx, P);
+      fp_reduce_lt<NL, 4>(rc, nx, P);              // nx <3: two conditional subtractions
       if (!done) {
         BsgsSlot s = s0;
         for (;;) {

@@ -316,11 +316,9 @@ __device__ __forceinline__ void gt_pow_norm1_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL
     fp_mulv(t, a, b, P, L);                  // A_j*A_(j+1) <2   (25)
     fp_sqrv(u, u, P, L);                     // <2
     a_load(a, SX);                           // A_1 <1
-    fp_dbl(t, t);                            // <4
-    fp_sub<1>(t, t, a, P);                   // A_(2j+1) <5
+    fp_lin2<2, -1, 1>(t, t, a, P);           // A_(2j+1) = 2*A_j*A_(j+1) - A_1 <5 (one carry pass)
     fp_set(a, P->one);
-    fp_dbl(u, u);                            // <4
-    fp_sub<1>(u, u, a, P);                   // A_(2j) or A_(2j+2) <5
+    fp_lin2<2, -1, 1>(u, u, a, P);           // A_(2j) or A_(2j+2) = 2*u - 1 <5
     fp_select(a, bit, t, u);
     fp_select(b, bit, u, t);
     a_store(SA, a);

@@ -2639,6 +2639,11 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   if (chunk && round_polys && chunk > round_polys) chunk -= chunk % round_polys;
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
+  // the table rounds as multi-pairings (option poly_multi; square leaves): one lane per OUTPUT coefficient walks the
+  // tables of all its terms e(a_i, b_j), i + j = s, with one f^2 per doubling step and one final exponentiation;
+  // operands and tables coefficient-major (kernels.hpp pairing_multi)
+  const bool multi = chunk && d1 == d2 && d1 >= 2 && opt(c, &Options::poly_multi) != 0;
+  const size_t Qp = round_up(cp, 64);
   // (the remainder: what is left below one round of tables once the whole rounds are taken out of the last chunk)
   size_t tail_polys = chunk ? npoly % cp : 0;
   if (round_polys && tail_polys > round_polys) tail_polys %= round_polys;
@@ -2647,11 +2652,15 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   const size_t tail_sp = round_up(tail_pairs ? tail_pairs : 1, 64);
   // (the width-w loop of the lane-group kernel is decided once per stride: the workspace below is sized with it)
   const int qwin_main = quad ? quad_window(c, np) : 0, qwin_tail = tail_direct ? quad_window(c, tail_pairs) : 0;
-  SoA2 E;
+  SoA2 E, Tt, Vt;
   uint32_t* pws = nullptr;
   for (int pass = 0; pass < 2; ++pass) {
     Ws w(c, pass ? c->arena : nullptr);
     E = w.gt(sp);
+    if (multi) {
+      Tt = w.g1(d1 * Qp);
+      Vt = w.g1(d1 * Qp);
+    }
     size_t ws_b = (size_t)(chunk ? 3 : c->pair_ws_slots) * c->nl * sp * 4;         // the lane kernel is the fallback
     auto at_least = [&](size_t b) { if (b > ws_b) ws_b = b; };
     if (quad) at_least(quad_ws_words(c->nl, sp, qwin_main) * 4);
@@ -2668,7 +2677,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     }
   }
   uint32_t* tab = nullptr;
-  const size_t ts = round_up(cp * dt, 64);
+  const size_t ts = multi ? d1 * Qp : round_up(cp * dt, 64);
   if (chunk) {
     const size_t need = c->miller_steps * 3 * (size_t)c->nl * 4 * ts;
     if (need > c->poly_tab_bytes) {
@@ -2696,6 +2705,23 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     const size_t sw = tail ? tail_sp : sp;
     const bool q_quad = tail ? use_quad(c, pairs, coop_limit(c, 0)) : quad;
     const bool q_coop = tail ? (!q_quad && pairs <= coop_limit(c, 0)) : coop;
+    if (!direct && multi) {
+      const size_t Qq = round_up(nq, 64);                                          // (the last chunk may be shorter)
+      kt->soa_coeff_major(s, Aq, Tt, nq, d1, Qq);
+      kt->soa_coeff_major(s, Bq, Vt, nq, d1, Qq);
+      kt->fixedpair_build_batch(s, c->d_params, c->d_consts, Tt, d1 * Qq, tab, d1 * Qq);
+      kt->pairing_multi(s, c->d_params, c->d_consts, Vt, Tt.inf, E, nq, Qq, d1, tab, d1 * Qq);
+      tables_used = true;
+      const size_t outs = nq * (2 * d1 - 1);
+      kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, outs);
+      PolyAccArgs pa;                                                              // out[q][s] = E[q][s], out[q][2d-1] = 1
+      pa.e0 = E.c0; pa.e1 = E.c1; pa.se = E.stride;
+      pa.o0 = O.c0 + q0 * (d1 + d2); pa.o1 = O.c1 + q0 * (d1 + d2); pa.so = O.stride;
+      pa.npoly = nq; pa.d1 = 1; pa.d2 = 2 * d1 - 1;
+      pa.mont_out = mont_out ? 1 : 0;
+      kt->poly_acc(s, c->d_params, pa);
+      continue;
+    }
     if (!direct) {
       const SoA2 T = tab_on_a ? Aq : Bq, V = tab_on_a ? Bq : Aq;
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);

@@ -318,4 +318,99 @@ __device__ __forceinline__ void miller_loop_fixed(Miller<NL>& S, LFp<NL>* L, con
   }
 }
 
+// ---- several pairings into ONE Miller value (MultPoly as a multi-pairing) -------------------------------------
+// f = prod_k f_(T_(i0+k)) (phi(V_(j0-k))), k < terms: the terms e(a_i, b_j), i + j = s, of one output coefficient of a
+// polynomial product share the f^2 of every doubling step (2 of the 6 reductions of a step over an un-normalised
+// table) and one final exponentiation; a term costs the line value and f*l only.  Tables and operands are
+// COEFFICIENT-MAJOR — column i*Qp + q of the line table, element j*Qp + q of the operand arrays — so that the lanes
+// of a wave (consecutive q, the same s) read neighbouring dwords.  A term with an identity operand (tinf / vinf)
+// contributes the factor 1: its line product is computed and dropped.  `terms` is wave-uniform.
+template <int NL>
+__device__ __forceinline__ void miller_loop_fixed_multi(Miller<NL>& S, LFp<NL>* L, const u32* __restrict__ vx,
+                                                        const u32* __restrict__ vy, size_t sv,
+                                                        const uint8_t* __restrict__ vinf, const uint8_t* __restrict__ tinf,
+                                                        size_t q, size_t Qp, size_t i0, size_t j0, int terms,
+                                                        const u32* __restrict__ tab, size_t ts,
+                                                        const PairingConsts* __restrict__ C,
+                                                        const FpParams<NL>* __restrict__ P) {
+  LFp<NL>* S0 = L;
+  LFp<NL>* LX = L + 1;
+  LFp<NL>* LY = L + 2;
+  LFp<NL>* L3 = L + 3;
+  Fp<NL> r, u, w;
+  fp_set(r, P->one);
+  a_store(S.F0, r);
+  fp_zero(r);
+  a_store(S.F1, r);
+  // (Measured and dropped: a software pipeline over the (step, term) sequence — the next term's point requested before
+  // the first sum of products and staged after it, its a_s, b_s before the second: the values held across the sums
+  // cost more in spills than the round trip they hide, 1.42 -> 1.13 x 10^6 coefficient pairs/s.)
+  size_t s = 0;
+#pragma unroll 1
+  for (int i = C->naf_len - 2; i >= 0; --i) {
+    const int d = C->naf[i];
+    const int nsteps = (d != 0 && i != 0) ? 2 : 1;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k, ++s) {
+      const u32* e = tab + 3 * s * NL * ts;
+#pragma unroll 1
+      for (int m = 0; m < terms; ++m) {
+        const size_t te = (i0 + (size_t)m) * Qp + q, ev = (j0 - (size_t)m) * Qp + q;
+        const bool ident = (tinf && tinf[te]) || (vinf && vinf[ev]);
+        // this term's point and line coefficients: five loads in flight together (one round trip, not five)
+        {
+          Fp<NL> la, lb, lc;
+          g_load(r, vx, sv, ev);               // xC
+          g_load(u, vy, sv, ev);               // yC
+          g_load(la, e, ts, te);               // a_s
+          g_load(lb, e + NL * ts, ts, te);     // b_s <1
+          g_load(lc, e + 2 * NL * ts, ts, te); // c_s
+          l_store(LX, r);
+          l_store(LY, u);
+          // line value
+          fp_mul(r, LX, la, P);                // a*xC <2
+          fp_add(r, r, lb);                    // cre <3
+          a_store(S.X, r);                     // X slot = cre
+          fp_mul(u, LY, lc, P);                // cim <2
+          a_store(S.Y, u);                     // Y slot = cim
+          fp_neg<2>(u, u, P);
+          a_store(S.Z, u);                     // Z slot = 2p - cim
+        }
+        // g = f^2 before the first term of a doubling step, g = f otherwise: g0 in L3, g1 in S0
+        a_load(r, S.F0);                     // <2
+        a_load(u, S.F1);                     // <2
+        if (k == 0 && m == 0) {
+          fp_add(w, r, u);                   // <4
+          l_store(S0, w);
+          fp_sub<2>(w, r, u, P);             // <4
+          fp_mul(w, S0, w, P);               // g0 <2
+          l_store(L3, w);
+          fp_mulv(r, r, u, P, S0);           // F0*F1 <2
+          fp_dbl(r, r);                      // g1 <4
+          l_store(S0, r);
+        } else {
+          l_store(L3, r);
+          l_store(S0, u);
+        }
+        // f = g * (cre + i*cim)
+        a_load(u, S.X);                      // cre <3
+        a_load(w, S.Z);                      // -cim <=2
+        Fp<NL> n0, n1;
+        fp_mul2(n0, L3, u, S0, w, P);        // F0 <2
+        a_load(w, S.Y);                      // cim <2
+        fp_mul2(n1, L3, w, S0, u, P);        // F1 <2
+        if (__ballot(ident)) {               // an identity operand: f = g (g1 of a squaring is below 4p: made canonical)
+          l_load(u, L3);
+          l_load(w, S0);
+          fp_reduce_lt<NL, 4>(w, w, P);
+          fp_select(n0, ident, u, n0);
+          fp_select(n1, ident, w, n1);
+        }
+        a_store(S.F0, n0);
+        a_store(S.F1, n1);
+      }
+    }
+  }
+}
+
 }  // namespace bgn

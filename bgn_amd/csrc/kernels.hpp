@@ -262,6 +262,13 @@ struct KernelTable {
   void (*poly_lin)(hipStream_t s, const void* params, const PairingConsts* consts, int level, PolyLinArgs a);
   void (*poly_split)(hipStream_t s, const void* params, const PairingConsts* consts, PolySplitArgs a);
   void (*poly_combine)(hipStream_t s, const void* params, PolyCombineArgs a);
+  // MultPoly as a multi-pairing (fixedpair.hpp miller_loop_fixed_multi).  soa_coeff_major: dst[i*Qp + q] = src[q*d + i]
+  // (points with identity flags; q < nq, i < d; Qp a multiple of 64).  pairing_multi: out[q*(2d-1) + s] =
+  // prod_{i+j=s} e(T[i*Qp+q], V[j*Qp+q]) — plain canonical, 1 where every term has an identity operand — over the line
+  // table `tab` (column i*Qp + q, limb stride ts) of the points T, of which only the identity flags are read here.
+  void (*soa_coeff_major)(hipStream_t s, SoA2 src, SoA2 dst, size_t nq, size_t d, size_t Qp);
+  void (*pairing_multi)(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 V, const uint8_t* tinf, SoA2 out,
+                        size_t nq, size_t Qp, size_t d, const uint32_t* tab, size_t ts);
   const char* bsgs_kernel_name;
   // field arithmetic on its own, for the parity tests: wire elements x||y -> prod_inv = (x*y, 1/x), sqr = (x^2, y^2),
   // sums = (x^2 + y^2, x*y + y^2) through the one-reduction sum of two products (skipped when sums.c0 is null);

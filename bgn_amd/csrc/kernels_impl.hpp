@@ -842,6 +842,87 @@ static void launch_field_ops(hipStream_t s, const void* params, const uint8_t* w
 }
 
 
+// ---- MultPoly as a multi-pairing ---------------------------------------------------------------------------------
+// dst[i*Qp + q] = src[q*d + i]: the operands of a round of polynomial products coefficient-major, so that lanes that
+// work on the same coefficient of neighbouring products read neighbouring dwords.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_soa_coeff_major(SoA2 src, SoA2 dst, size_t nq, size_t d, size_t Qp) {
+  const size_t e = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;      // destination index
+  if (e >= d * Qp) return;
+  const size_t i = e / Qp, q = e - i * Qp;
+  const bool live = q < nq;
+  const size_t from = live ? q * d + i : 0;
+  Fp<NL> x, y;
+  g_load<NL>(x, src.c0, src.stride, from);
+  g_load<NL>(y, src.c1, src.stride, from);
+  g_store<NL>(dst.c0, dst.stride, e, x);
+  g_store<NL>(dst.c1, dst.stride, e, y);
+  dst.inf[e] = live ? (src.inf ? src.inf[from] : 0) : 1;             // (padding lanes: identity operands)
+}
+
+// One lane = one output coefficient s of one product q: lanes [c*Qp, (c+1)*Qp) hold class c, classes ordered by
+// falling term count (s = d-1 first, then d-2, d, d-3, d+1, ...), so that the long lanes start first and a wave's
+// term count is uniform.  out[q*(2d-1) + s], plain canonical.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_pairing_multi(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, SoA2 V,
+                const uint8_t* __restrict__ tinf, SoA2 out, size_t nq, size_t Qp, size_t d, const u32* __restrict__ tab,
+                size_t ts) {
+  __shared__ LFp<NL> L[4];
+  const size_t lane = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const size_t c = lane / Qp;
+  size_t q = lane - c * Qp;
+  const bool live = c < 2 * d - 1 && q < nq;
+  if (!__ballot(live)) return;
+  if (!live) q = 0;                          // keep the wave's control flow uniform; results are discarded
+  const size_t cc = c < 2 * d - 1 ? c : 0;
+  const size_t m = (cc + 1) / 2;
+  const size_t s = (cc & 1) ? d - 1 - m : d - 1 + m;
+  const size_t i0 = s > d - 1 ? s - (d - 1) : 0;
+  const size_t i1 = s < d - 1 ? s : d - 1;
+  const int terms = (int)(i1 - i0 + 1);
+  Miller<NL> S;
+  miller_loop_fixed_multi<NL>(S, L, V.c0, V.c1, V.stride, V.inf, tinf, q, Qp, i0, s - i0, terms, tab, ts, C, P);
+  Fp<NL> N, ninv, g0, g1, re, im;
+  miller_norm<NL>(N, S, L, P);
+  bool ident;
+  {
+    // a norm of zero (only an operand that is not on the curve produces one) yields the identity
+    Fp<NL> nc;
+    fp_reduce8(nc, N, P);
+    ident = fp_is_zero_limbs(nc);
+    fp_set(re, P->one);
+    fp_select(N, ident, re, N);
+  }
+  fp_inv_mont<NL>(ninv, N, C->pm2_bits + 1, P, L);
+  final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
+  fp_from_mont<NL>(im, g1, P, L);
+  fp_from_mont<NL>(re, g0, P, L);
+  if (ident) {
+    fp_zero(re);
+    fp_zero(im);
+    re.v[0] = 1;
+  }
+  if (live) {
+    const size_t o = q * (2 * d - 1) + s;
+    g_store<NL>(out.c0, out.stride, o, re);
+    g_store<NL>(out.c1, out.stride, o, im);
+  }
+}
+
+static void launch_soa_coeff_major(hipStream_t s, SoA2 src, SoA2 dst, size_t nq, size_t d, size_t Qp) {
+  if (!nq || !d) return;
+  hipLaunchKernelGGL(k_soa_coeff_major<NL_>, dim3(grid_for(d * Qp)), dim3(FP_BLOCK), 0, s, src, dst, nq, d, Qp);
+}
+
+static void launch_pairing_multi(hipStream_t s, const void* params, const PairingConsts* consts, SoA2 V, const uint8_t* tinf,
+                                 SoA2 out, size_t nq, size_t Qp, size_t d, const uint32_t* tab, size_t ts) {
+  if (!nq || !d) return;
+  hipLaunchKernelGGL(k_pairing_multi<NL_>, dim3(grid_for((2 * d - 1) * Qp)), dim3(FP_BLOCK), 0, s,
+                     (const FpParams<NL_>*)params, consts, V, tinf, out, nq, Qp, d, tab, ts);
+}
+
 const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
   static const KernelTable t = {
       NL_,
@@ -876,6 +957,8 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_poly_lin,
       launch_poly_split,
       launch_poly_combine,
+      launch_soa_coeff_major,
+      launch_pairing_multi,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
       launch_field_ops,
   };

@@ -50,6 +50,7 @@ struct Options {
   V poly_levels{-1};       // forced number of levels (-1: planned)
   V poly_tables{-1};       // per-coefficient line tables: 0 never, 1 always, -1 by size
   V poly_table_max_mb{0};  // cap of those tables (0: default)
+  V poly_multi{1};         // MultPoly's table rounds as multi-pairings: one lane per OUTPUT coefficient, one f^2 per doubling step for all its terms (0: one lane per coefficient pair)
   V poly_round{0};         // the round size of MultPoly's planning (tests; 0: 65536)
   V host_pipe{1};          // chunked upload / launch / download pipeline for Add / Sub / Neg on large host arrays
   V host_pipe_chunk{0};    // elements per chunk (0: default)
@@ -112,6 +113,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"poly_levels", &Options::poly_levels, true, nullptr},
       {"poly_tables", &Options::poly_tables, true, nullptr},
       {"poly_table_max_mb", &Options::poly_table_max_mb, true, nullptr},
+      {"poly_multi", &Options::poly_multi, true, nullptr},
       {"poly_round", &Options::poly_round, true, nullptr},
       {"host_pipe", &Options::host_pipe, true, nullptr},
       {"host_pipe_chunk", &Options::host_pipe_chunk, true, nullptr},

@@ -132,6 +132,27 @@ struct Emu {
     memcpy(out, re.v, 4 * NL);
     memcpy(out + NL, im.v, 4 * NL);
   }
+  // prod_k e(T_(i0+k), V_(j0-k)), k < terms, as one Miller value (fixedpair.hpp miller_loop_fixed_multi): `tab` holds the
+  // line tables of the T's in columns i*Qp + q (limb stride ts), v the points V as SoA of stride sv (x limbs, then y
+  // limbs from v + NL*sv) at elements j*Qp + q, vinf / tinf their identity flags (may be null)
+  static void pairing_fixed_multi(const u32* params, const PairingConsts* C, const u32* tab, size_t ts, const u32* v, size_t sv,
+                                  const uint8_t* vinf, const uint8_t* tinf, size_t q, size_t Qp, size_t i0, size_t j0, int terms,
+                                  u32* out) {
+    EmuChecks on;
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    LFp<NL>* L = lds();
+    Miller<NL> S;
+    miller_loop_fixed_multi<NL>(S, L, v, v + (size_t)NL * sv, sv, vinf, tinf, q, Qp, i0, j0, terms, tab, ts, C, P);
+    Fp<NL> N, ninv, g0, g1, re, im;
+    miller_norm<NL>(N, S, L, P);
+    l_store(L + 1, N);
+    fp_pow_uniform<NL>(ninv, L + 1, C->pm2, C->pm2_bits, P, L);
+    final_exp_with_inverse<NL>(g0, g1, S, ninv, L, C, P);
+    fp_from_mont<NL>(im, g1, P, L);
+    fp_from_mont<NL>(re, g0, P, L);
+    memcpy(out, re.v, 4 * NL);
+    memcpy(out + NL, im.v, 4 * NL);
+  }
   static void pairing_w3(const u32* params, const PairingConsts* C, const u32* a, const u32* b, u32* out) {
     EmuChecks on;
     const FpParams<NL>* P = (const FpParams<NL>*)params;
@@ -457,6 +478,7 @@ long long emu_window_digit(const uint8_t* k, size_t klen, int wbits, int sbits, 
 }
 int emu_scalar_windows(size_t klen, int wbits, int sbits) { return bgn::scalar_windows(klen, wbits, sbits); }
 int emu_poly_lin(int nl, const u32* params, const void* C, int level, const u32* c, const uint8_t* cinf, int d, int dp, const uint8_t* k, size_t klen, u32* out, uint8_t* oinf) { DISPATCH(nl, poly_lin(params, (const PairingConsts*)C, level, c, cinf, d, dp, k, klen, out, oinf)) }
+int emu_pairing_fixed_multi(int nl, const u32* params, const void* C, const u32* tab, size_t ts, const u32* v, size_t sv, const uint8_t* vinf, const uint8_t* tinf, size_t q, size_t Qp, size_t i0, size_t j0, int terms, u32* out) { DISPATCH(nl, pairing_fixed_multi(params, (const PairingConsts*)C, tab, ts, v, sv, vinf, tinf, q, Qp, i0, j0, terms, out)) }
 int emu_fixed_build(int nl, const u32* params, const void* C, const u32* p, u32* tab, size_t ts, size_t te) { DISPATCH(nl, fixed_build(params, (const PairingConsts*)C, p, tab, ts, te)) }
 int emu_pairing_fixed(int nl, const u32* params, const void* C, const u32* tab, size_t ts, size_t te, int normalized, const u32* c, u32* out) { DISPATCH(nl, pairing_fixed(params, (const PairingConsts*)C, tab, ts, te, normalized, c, out)) }
 int emu_fixed_normalize(int nl, const u32* params, const void* C, u32* tab, size_t steps) { DISPATCH(nl, fixed_normalize(params, (const PairingConsts*)C, tab, steps)) }

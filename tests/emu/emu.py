@@ -176,6 +176,32 @@ class Emu:
                                           1 if normalized else 0, Cm, out) == 0
         return self.encode(out)
 
+    def pairing_fixed_multi(self, tab, ts: int, Qp: int, q: int, t_wires, v_wires, s: int) -> bytes:
+        """Output coefficient s of the product of the polynomials T (d points, their line tables in columns i*Qp + q of
+        `tab`) and V (d points): prod_{i+j=s} e(T_i, V_j) by ONE Miller loop (fixedpair.hpp miller_loop_fixed_multi).
+        Identity points (None in the lists) contribute the factor 1."""
+        d = len(t_wires)
+        assert len(v_wires) == d and 0 <= s <= 2 * d - 2
+        sv = d * Qp
+        v = (C.c_uint32 * (2 * self.nl * sv))()
+        vinf = (C.c_uint8 * sv)()
+        tinf = (C.c_uint8 * sv)()
+        some = next(w for w in v_wires if w is not None)
+        for j, w in enumerate(v_wires):
+            m, _ = self.decode(w if w is not None else some)
+            for l in range(self.nl):
+                v[l * sv + j * Qp + q] = m[l]
+                v[(self.nl + l) * sv + j * Qp + q] = m[self.nl + l]
+            vinf[j * Qp + q] = 1 if w is None else 0
+        for i, w in enumerate(t_wires):
+            tinf[i * Qp + q] = 1 if w is None else 0
+        i0 = max(0, s - (d - 1))
+        i1 = min(s, d - 1)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_pairing_fixed_multi(self.nl, self.params, self.consts, tab, C.c_size_t(ts), v, C.c_size_t(sv), vinf, tinf,
+                                                C.c_size_t(q), C.c_size_t(Qp), C.c_size_t(i0), C.c_size_t(s - i0), i1 - i0 + 1, out) == 0
+        return self.encode(out)
+
     def g1_mul(self, base: bytes, k: int, klen: int = None, window: bool = False) -> bytes:
         B, ib = self.decode(base)
         klen = klen or max(1, (k.bit_length() + 7) // 8)

@@ -323,6 +323,53 @@ def test_emu_per_coefficient_line_tables(ctx):
     assert E.pairing_fixed(tb, cts[v["a"]], 2, 1).hex() == v["out"]
 
 
+def test_emu_multi_pairing_output_coefficients():
+    """MultPoly as a multi-pairing (fixedpair.hpp miller_loop_fixed_multi): every output coefficient of a 3 x 3 product —
+    prod_{i+j=s} e(a_i, b_j) from ONE Miller loop with a shared f^2 and one final exponentiation, tables and operands
+    coefficient-major — equals the product of the oracle's single pairings, in a column other than 0, with identity
+    coefficients on either side (their terms contribute the factor 1) and for the single-term coefficients s = 0, 2d-2."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    import oracle_c
+    from conftest import oracle_key
+    fx = load_fixture("toy64")
+    E = emu.Emu.from_fixture(fx)
+    o = oracle_c.Oracle.from_fixture(fx)
+    opk, _ = oracle_key(fx)
+    d, Qp, q = 3, 4, 2
+    rng = random.Random(31)
+    A = [o.encrypt([rng.randrange(1000)], [rng.randrange(1 << 40)]) for _ in range(d)]
+    B = [o.encrypt([rng.randrange(1000)], [rng.randrange(1 << 40)]) for _ in range(d)]
+    ts = d * Qp
+    dec = lambda w: R.elem_from_bytes(w, opk.p)
+
+    def want(a_list, b_list, s):
+        acc = None
+        for i in range(d):
+            j = s - i
+            if 0 <= j < d and a_list[i] is not None and b_list[j] is not None:
+                e = opk.e(dec(a_list[i]), dec(b_list[j]))
+                acc = e if acc is None else R.f2_mul(acc, e, opk.p)
+        if acc is None:
+            return (1).to_bytes(E.L, "big") + bytes(E.L)
+        return R.elem_to_bytes(acc, opk.p)
+
+    def table(a_list):
+        tab = None
+        for i, w in enumerate(a_list):
+            tab = E.fixed_table(w if w is not None else A[0], ts, i * Qp + q, tab)     # (an identity's column: any table)
+        return tab
+
+    tab = table(A)
+    for s in range(2 * d - 1):
+        assert E.pairing_fixed_multi(tab, ts, Qp, q, A, B, s) == want(A, B, s), s
+    A2 = [A[0], None, A[2]]
+    B2 = [None, B[1], B[2]]
+    tab2 = table(A2)
+    for s in range(2 * d - 1):
+        assert E.pairing_fixed_multi(tab2, ts, Qp, q, A2, B2, s) == want(A2, B2, s), ("identities", s)
+
+
 @pytest.mark.parametrize("nl", [3, 10, 19, 36, 37])
 def test_emu_dword_codec_matches_the_byte_codec(nl):
     """codec.hpp's dword forms (wire_element_dw: two-dword reads + byte permutes, odd lanes two bytes into a dword

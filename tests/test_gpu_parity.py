@@ -327,6 +327,10 @@ T1 = {"poly_tables": "1"}                    # the table path whatever the size 
     (8, 8, {**T1, "poly_levels": "1"}),      # one level where two are possible (engine.cpp poly_plan_levels picks by cost)
     (16, 16, {"poly_levels": "2", "npoly": "5"}), (16, 16, {"npoly": "5"}),
     (4, 4, {"poly_tables": "0"}),            # Karatsuba over direct pairings at the leaves
+    # square leaves run as multi-pairings by default (one lane per output coefficient, fixedpair.hpp
+    # miller_loop_fixed_multi): the one-lane-per-pair walk behind option poly_multi = 0 stays covered
+    (4, 4, {**T1, "poly_multi": "0"}), (8, 8, {**T1, "poly_multi": "0"}), (3, 3, {**T1, "poly_multi": "0"}),
+    (3, 3, T1), (5, 5, {**T1, "npoly": "67"}),   # odd square leaves as multi-pairings; a ragged last group of 64 products
 ])
 def test_poly_mult_table_paths_vs_c_oracle(d1, d2, env, engopts):
     """MultPoly over per-coefficient line tables (fixedpair.hpp) == the oracle's d1*d2 full pairings +

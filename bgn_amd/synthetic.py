@@ -288,25 +288,35 @@ def decrypt_products(fx, baby_steps: int, level: int = 1) -> float:
     return decrypt_counts(fx, baby_steps, level)[0]
 
 
-def multpoly_counts_per_pair(fx, d: int):
-    """MultPoly of two d-coefficient polynomials (d a power of two >= 2) per coefficient pair: Karatsuba levels
-    down to 2x2 products, each 4 evaluations over a per-coefficient line table (6 / 4 reductions per step, two of them
-    sums of two products, + final exponentiation; squarings only in the norm) and 2 table builds (10 / 11 reductions
-    per doubling / addition step, three of them squarings, two of them sums)."""
+def multpoly_counts_per_pair(fx, d: int, levels: int = None, multi: bool = True):
+    """MultPoly of two d-coefficient polynomials (d a power of two >= 4) per coefficient pair, the way the engine runs
+    2^14 of them (engine.cpp poly_plan_levels picks two Karatsuba levels for 16 x 16 there: 9 leaves of 4 x 4): per leaf
+    of k x k coefficients k table builds (10 / 11 reductions per doubling / addition step, three of them squarings, two
+    of them sums) and, since round 5, 2k - 1 multi-pairing lanes — per lane one f^2 per doubling step (2 reductions) and
+    one final exponentiation, per term e(a_i, b_j) the line value and f*l (4 reductions a step, two of them sums of two
+    products).  multi = False: the one-lane-per-pair walk (6 / 4 reductions per step and a final exponentiation per pair).
+    levels: Karatsuba levels (default: down to leaves of 4 x 4)."""
     n, l = int(fx["n"], 16), int(fx["l"])
     dbl, add = _naf_counts(n)
     lb = l.bit_length()
-    fe = 4 + 5 + INVERSION_PRODUCTS / 16 + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
-    ev = dbl * TABLE_DBL_C[0] + add * TABLE_ADD_C[0] + fe
-    build = dbl * BUILD_DBL[0] + add * BUILD_ADD[0]
-    leaves = 1
-    k = d
-    while k > 2:
-        leaves *= 3
-        k //= 2
+    fe = 4 + 5 + INVERSION_PRODUCTS + (lb - 1) * 2 + (bin(l).count("1") - 1) * 3 + 2
+    if levels is None:
+        levels = 0
+        while (d >> levels) > 4:
+            levels += 1
+    k = d >> levels
+    leaves = 3 ** levels
+    build = (dbl * BUILD_DBL[0] + add * BUILD_ADD[0], dbl * BUILD_DBL[1] + add * BUILD_ADD[1], dbl * BUILD_DBL[2] + add * BUILD_ADD[2])
+    if multi:
+        lane = (dbl * 2 + fe, 4.0, 0.0)
+        term = ((dbl + add) * 4, 0.0, (dbl + add) * 2)
+        leaf = tuple(k * build[t] + (2 * k - 1) * lane[t] + k * k * term[t] for t in range(3))
+    else:
+        fe16 = fe - INVERSION_PRODUCTS + INVERSION_PRODUCTS / 16
+        ev = (dbl * TABLE_DBL_C[0] + add * TABLE_ADD_C[0] + fe16, 4.0, dbl * TABLE_DBL_C[2] + add * TABLE_ADD_C[2])
+        leaf = tuple(k * build[t] + k * k * ev[t] for t in range(3))
     per = leaves / (d * d)
-    return (per * (4 * ev + 2 * build), per * (4 * 4 + 2 * (dbl * BUILD_DBL[1] + add * BUILD_ADD[1])),
-            per * (4 * (dbl * TABLE_DBL_C[2] + add * TABLE_ADD_C[2]) + 2 * (dbl * BUILD_DBL[2] + add * BUILD_ADD[2])))
+    return per * leaf[0], per * leaf[1], per * leaf[2]
 
 
 def multpoly_products_per_pair(fx, d: int) -> float:

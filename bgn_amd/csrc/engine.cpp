@@ -2637,6 +2637,9 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   // first; a remainder of at most 65536 pairs then pairs directly on the kernel that is fastest at its size.
   const size_t round_polys = kLanes / dt;
   if (chunk && round_polys && chunk > round_polys) chunk -= chunk % round_polys;
+  // (the multi-pairing rounds pad the products of a pass to a multiple of 64: whole groups keep the tables inside the
+  // budget the chunk was sized for)
+  if (chunk >= 64 && chunk < npoly && d1 == d2 && opt(c, &Options::poly_multi) != 0) chunk -= chunk % 64;
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
   // the table rounds as multi-pairings (option poly_multi; square leaves): one lane per OUTPUT coefficient walks the

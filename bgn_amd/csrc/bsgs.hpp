@@ -327,29 +327,59 @@ __device__ __forceinline__ void bsgs_search_lane(const BsgsParams& B, const Bsgs
       const unsigned long long want = bsgs_slot_tag(hs) >> 33;  // what bits 63..33 of a matching slot hold
       unsigned long long h = hs & B.mask;
       if (resume && i == i0) h = (resume_h + 1) & B.mask;       // behind the slot the verification rejected
-      BsgsSlot s0;
-      s0.w = 0ull;
-      if (!done) s0 = B.table[h];
+      // ... and not the first slot alone.  A probe that finds nothing (all but one of a walk's) looks at 2.5 slots of the
+      // half-full table on average, but a WAVE waits for its slowest lane: one lane in ten needs a fifth slot, one in
+      // sixty a ninth — every step has such a lane, and each further slot is a dependent round trip.  The first
+      // kProbeAhead slots of the sequence (128 adjacent bytes) are requested together; a run of sixteen occupied slots
+      // without the key is rare enough (3 in 10^4 probes) for most steps of a wave to need nothing more.
+      constexpr int kProbeAhead = 16;
+      unsigned long long pw[kProbeAhead];
+#pragma unroll
+      for (int k = 0; k < kProbeAhead; ++k) pw[k] = 0ull;
+      if (!done) {
+#pragma unroll
+        for (int k = 0; k < kProbeAhead; ++k) pw[k] = B.table[(h + (unsigned long long)k) & B.mask].w;
+      }
       Fp<NL> nx;
       fp_mul(nx, L, rc, P);                        // T * Re(y_i) <2          aux.Div(aux, gamma), gsbs.go:102
       fp_sub<1>(nx, nx, rp, P);                    // - Re(y_(i-1)) <3
       rp = rc;
       fp_reduce_lt<NL, 4>(rc, nx, P);              // nx <3: two conditional subtractions
       if (!done) {
-        BsgsSlot s = s0;
-        for (;;) {
-          if (s.w == 0ull) break;
-          if ((s.w >> 33) == want) {
+        // the slots in hand, in order, without a branch per slot: the first empty one ends the probe, a tag match before it
+        // is the hit
+        bool open = true;
+#pragma unroll
+        for (int k = 0; k < kProbeAhead; ++k) {
+          const unsigned long long sw = pw[k];
+          const bool match = open && sw != 0ull && (sw >> 33) == want;
+          if (match) {
             hit = true;
             hit_i = i;
-            hit_h = h;
-            hit_j = (u32)s.w;
-            hit_par = (u32)(s.w >> 32) & 1u;
+            hit_h = (h + (unsigned long long)k) & B.mask;
+            hit_j = (u32)sw;
+            hit_par = (u32)(sw >> 32) & 1u;
             done = true;
-            break;
           }
-          h = (h + 1) & B.mask;
-          s = B.table[h];
+          open = open && sw != 0ull && !match;
+        }
+        if (open) {                                // sixteen occupied slots without the key: on, one by one
+          h = (h + (unsigned long long)kProbeAhead) & B.mask;
+          BsgsSlot s = B.table[h];
+          for (;;) {
+            if (s.w == 0ull) break;
+            if ((s.w >> 33) == want) {
+              hit = true;
+              hit_i = i;
+              hit_h = h;
+              hit_j = (u32)s.w;
+              hit_par = (u32)(s.w >> 32) & 1u;
+              done = true;
+              break;
+            }
+            h = (h + 1) & B.mask;
+            s = B.table[h];
+          }
         }
       }
     }

@@ -2615,7 +2615,7 @@ namespace {
 // Montgomery with identity flags; O (npoly*(d1+d2) GT elements) plain canonical, or canonical Montgomery when
 // the result feeds a Karatsuba combination.  Uses the arena for the pairing values; c->mu held.
 int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2, SoA2 A, SoA2 Bv, SoA2 O, bool mont_out,
-                   bool* used_tables) {
+                   int* used_tables /* 1: one lane per pair over line tables; 2: multi-pairing rounds */) {
   // tables on the operand with fewer coefficients (each table is then shared by more pairs)
   const bool tab_on_a = d1 <= d2;
   const size_t dt = tab_on_a ? d1 : d2;
@@ -2697,7 +2697,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
     if (v.inf) v.inf += off;
     return v;
   };
-  bool tables_used = false;
+  int tables_used = 0;
   for (size_t q0 = 0, nq = 0; q0 < npoly; q0 += nq) {
     nq = (npoly - q0 < cp) ? npoly - q0 : cp;
     if (tail_direct && nq < cp && nq > tail_polys) nq -= tail_polys;              // the last chunk: its whole rounds first
@@ -2714,7 +2714,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
       kt->soa_coeff_major(s, Bq, Vt, nq, d1, Qq);
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, Tt, d1 * Qq, tab, d1 * Qq);
       kt->pairing_multi(s, c->d_params, c->d_consts, Vt, Tt.inf, E, nq, Qq, d1, tab, d1 * Qq);
-      tables_used = true;
+      tables_used = 2;
       const size_t outs = nq * (2 * d1 - 1);
       kt->to_mont(s, c->d_params, E.c0, E.c1, E.stride, outs);
       PolyAccArgs pa;                                                              // out[q][s] = E[q][s], out[q][2d-1] = 1
@@ -2730,7 +2730,7 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
       kt->fixedpair_build_batch(s, c->d_params, c->d_consts, T, nq * dt, tab, ts);
       kt->pairing(s, c->d_params, c->d_consts, V, T, E, pairs, tab_on_a ? 3 : 4, d1, d2, pairing_run(c, pairs), pws, sp,
                   tab, ts, 0);                                                     // pk.Mult(coeff1, coeff2), poly.go:146
-      tables_used = true;
+      if (!tables_used) tables_used = 1;
     } else if (q_quad && quad_pairing_launch(c->nl, s, c->d_params, c->d_consts, Aq, Bq, E, pairs, 2, d1, d2, pws, sw,
                                              c->p_bits + 1, nullptr, tail ? qwin_tail : qwin_main)) {
       c->last_kernel = quad_pairing_kernel_name(c->nl);
@@ -2870,7 +2870,7 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
       kt->poly_split(s, c->d_params, c->d_consts, ps);
     }
   }
-  bool used_tables = false;
+  int used_tables = 0;
   {
     const size_t da = levels ? dk[levels] : d1, db = levels ? dk[levels] : d2;
     int rc = poly_mult_core(c, s, n[levels], da, db, A[levels], B[levels], R[levels], levels != 0, &used_tables);
@@ -2886,7 +2886,8 @@ int bgn_poly_mult_batch_dev(bgn_ctx* c, size_t npoly, size_t d1, size_t d2, cons
   }
   HIP_TRY(hipEventRecord(c->ev1, s));
   c->ev_valid = true;
-  if (used_tables) c->last_kernel = "k_fixedpair_build_batch + k_pairing<.,1>";      // (else: the pairing kernel the core chose)
+  if (used_tables == 2) c->last_kernel = "k_fixedpair_build_batch + k_pairing_multi";
+  else if (used_tables) c->last_kernel = "k_fixedpair_build_batch + k_pairing<.,1>";      // (else: the pairing kernel the core chose)
   kt->encode(s, nullptr, R[0].c0, R[0].c1, R[0].stride, c->L, npoly * (d1 + d2), out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));            // the scratch arrays are released on return

@@ -291,6 +291,59 @@ struct Emu {
     }
     *oinf = si[0];
   }
+  // P^x * Q^r for `count` elements over four accumulation chains: the launch sequence of fixed_base_product's chain path
+  // (engine.cpp) — csteps launches of k_g1_fixed_chain over chains*pitch virtual elements (one workgroup, so every
+  // lane owns a run of several: the first pass's requests one and two elements ahead are exercised), then the two
+  // additions that sum the chains.  out: plain limbs x||y per element, oinf: identity flags.
+  static void g1_fixed_chains(const u32* params, const PairingConsts* C, const u32* tabP, const u32* tabQ, int wbits_p,
+                              int wbits_q, int sbits_q, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen,
+                              size_t count, u32* out, uint8_t* oinf) {
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    constexpr int kChains = 4;
+    const size_t pitch = (count + 63) / 64 * 64, slots = kChains * pitch;
+    std::vector<u32> X0(NL * slots, 0), X1(NL * slots, 0), Y0(NL * 2 * pitch, 0), Y1(NL * 2 * pitch, 0), S0(NL * pitch, 0),
+        S1(NL * pitch, 0), pf(NL * slots);
+    std::vector<uint8_t> Xi(slots, 1), Yi(2 * pitch, 0), Si(pitch, 0);
+    const int wx = x ? scalar_windows(xlen, wbits_p, wbits_p) : 0;
+    const int wr = r ? scalar_windows(rlen, wbits_q, sbits_q) : 0;
+    const int steps = wx + wr, csteps = (steps + kChains - 1) / kChains;
+    const int run = (int)((slots + FP_BLOCK - 1) / FP_BLOCK);
+    for (int i = 0; i < csteps; ++i) {
+      G1FixedChainArgs A;
+      A.sx = X0.data(); A.sy = X1.data(); A.sinf = Xi.data(); A.ss = slots;
+      A.tabP = tabP; A.tabQ = tabQ; A.wbits_p = wbits_p; A.wbits_q = wbits_q; A.sbits_q = sbits_q;
+      A.x = x; A.xlen = xlen; A.wx = wx;
+      A.r = r; A.rlen = rlen; A.wr = wr;
+      A.step = i; A.steps = csteps; A.chains = kChains;
+      A.pitch = pitch; A.count = count;
+      A.prefix = pf.data(); A.sp = slots;
+      A.run = run;
+      each_lane([&] { g1_add_run<NL>(G1IoFixedChain<NL>{A}, (size_t)A.chains * A.pitch, A.run, A.prefix, A.sp, lds(), C, P); });
+    }
+    auto add = [&](u32* ax, u32* ay, uint8_t* ai, size_t sa, size_t offa, size_t offb, u32* ox, u32* oy, uint8_t* oi, size_t so,
+                   size_t n, bool mont) {
+      G1AddArgs g;
+      g.ax = ax + offa; g.ay = ay + offa; g.ainf = ai + offa; g.sa = sa;
+      g.bx = ax + offb; g.by = ay + offb; g.binf = ai + offb; g.sb = sa;
+      g.ox = ox; g.oy = oy; g.oinf = oi; g.so = so;
+      g.prefix = pf.data(); g.sp = slots;
+      g.count = n;
+      g.run = (int)((n + FP_BLOCK - 1) / FP_BLOCK);
+      g.negate_b = 0;
+      g.mont_out = mont ? 1 : 0;
+      g.plain_io = 0;
+      each_lane([&] { g1_add_batch_lane<NL>(g, lds(), C, P); });
+    };
+    add(X0.data(), X1.data(), Xi.data(), slots, 0, 2 * pitch, Y0.data(), Y1.data(), Yi.data(), 2 * pitch, 2 * pitch, true);
+    add(Y0.data(), Y1.data(), Yi.data(), 2 * pitch, 0, pitch, S0.data(), S1.data(), Si.data(), pitch, count, false);
+    for (size_t e = 0; e < count; ++e) {
+      for (int l = 0; l < NL; ++l) {
+        out[(2 * e) * NL + l] = S0[l * pitch + e];
+        out[(2 * e + 1) * NL + l] = S1[l * pitch + e];
+      }
+      oinf[e] = Si[e];
+    }
+  }
   // window table of g in GT, built like ensure_gt_table (engine.cpp): squarings, then doubling rounds
   static void gt_tab_build(const u32* params, int wbits, int windows, const u32* g, u32* tab) {
     const FpParams<NL>* P = (const FpParams<NL>*)params;
@@ -466,6 +519,7 @@ int emu_g1_fixed_checked = 0;
 void emu_set_g1_fixed_checks(int on) { emu_g1_fixed_checked = on; }
 int emu_g1_fixed(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits, int sbits_q, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, u32* out, uint8_t* oinf) { struct Scope { Scope() { bgn_emu_checks = emu_g1_fixed_checked; } ~Scope() { bgn_emu_checks = 0; } } scope; DISPATCH(nl, g1_fixed(params, (const PairingConsts*)C, tabP, tabQ, wbits, sbits_q, x, xlen, r, rlen, out, oinf)) }
 int emu_tab_build(int nl, const u32* params, const void* C, int wbits, int sbits, int windows, const u32* pow, u32* tab) { DISPATCH(nl, tab_build(params, (const PairingConsts*)C, wbits, sbits, windows, pow, tab)) }
+int emu_g1_fixed_chains(int nl, const u32* params, const void* C, const u32* tabP, const u32* tabQ, int wbits_p, int wbits_q, int sbits_q, const uint8_t* x, size_t xlen, const uint8_t* r, size_t rlen, size_t count, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_fixed_chains(params, (const PairingConsts*)C, tabP, tabQ, wbits_p, wbits_q, sbits_q, x, xlen, r, rlen, count, out, oinf)) }
 // BGN_TALLY counts of the calling thread since the last reset (fpmont.hpp T_*): tools/op_tally.py
 void emu_tally_reset() { for (auto& t : bgn_emu_tally) t = 0; }
 void emu_tally_read(unsigned long long* out) { for (int i = 0; i < 16; ++i) out[i] = bgn_emu_tally[i]; }

@@ -293,6 +293,22 @@ class Emu:
                                      C.c_size_t(rlen), out, C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 
+    def g1_fixed_chains(self, tabP, tabQ, wbits_p: int, wbits_q: int, sbits_q: int, xs, xlen: int, rs, rlen: int):
+        """P^x * Q^r for a list of elements on the chain kernels (four accumulation chains, then the chain sums):
+        the launch sequence of engine.cpp fixed_base_product above the lane groups' range."""
+        n = len(xs)
+        xb = b"".join(int(v).to_bytes(xlen, "big") for v in xs)
+        rb = b"".join(int(v).to_bytes(rlen, "big") for v in rs)
+        out = (C.c_uint32 * (2 * self.nl * n))()
+        oinf = (C.c_uint8 * n)()
+        assert self.lib.emu_g1_fixed_chains(self.nl, self.params, self.consts, tabP, tabQ, wbits_p, wbits_q, sbits_q, xb,
+                                            C.c_size_t(xlen), rb, C.c_size_t(rlen), C.c_size_t(n), out, oinf) == 0
+        res = []
+        for e in range(n):
+            one = (C.c_uint32 * (2 * self.nl))(*out[2 * self.nl * e:2 * self.nl * (e + 1)])
+            res.append(self.encode(one, oinf[e]))
+        return res
+
     def gt_mul(self, a: bytes, b: bytes, conj_b=False, plain_a=False) -> bytes:
         if plain_a:
             pl, _ = self.decode_plain(a)

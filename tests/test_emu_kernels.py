@@ -293,6 +293,43 @@ def test_emu_fixed_base_encrypt_signed_windows(wbits):
         E.lib.emu_set_g1_fixed_checks(0)
 
 
+def test_emu_fixed_base_chain_kernels():
+    """Encrypt on the chain kernels (k_g1_fixed_chain over four accumulation chains + the two chain-sum additions, the
+    launch sequence of engine.cpp fixed_base_product): 70 elements on one workgroup, so a lane owns runs of several
+    virtual elements and the first pass's requests one and two elements ahead, the abscissa-only loads and the
+    digit bytes fetched ahead in the second pass are all exercised — signed and unsigned windows of Q, zero scalars and
+    zero windows (identity operands) among them — against the oracle."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    import oracle_c
+    fx = load_fixture("toy64")
+    E = emu.Emu.from_fixture(fx)
+    o = oracle_c.Oracle.from_fixture(fx)
+    n = int(fx["n"], 16)
+    nbytes = (n.bit_length() + 7) // 8
+    wb = 5
+    WP = (n.bit_length() + wb - 1) // wb + 1
+    tP = E.build_table(wb, WP, [o.encrypt([1 << i], None) for i in range(WP * wb)])
+    rng = random.Random(77)
+    count = 70
+    xs = [rng.randrange(1 << 16) for _ in range(count)]
+    for sbits in (wb + 1, wb):
+        WQ = E.scalar_windows(nbytes, wb, sbits)
+        tQ = E.build_table(wb, WQ, [o.encrypt([0], [1 << i]) for i in range(WQ * sbits)], sbits=sbits)
+        rs = [rng.randrange(n) for _ in range(count)]
+        xs2 = list(xs)
+        xs2[0], rs[0] = 0, 0                     # the identity
+        xs2[1] = 0
+        rs[2] = 0
+        rs[3] = (1 << (8 * nbytes)) - 1
+        rs[4] = sum((1 << wb) << (sbits * w) for w in range(WQ - 1)) % (1 << (8 * nbytes))
+        got = E.g1_fixed_chains(tP, tQ, wb, wb, sbits, xs2, 2, rs, nbytes)
+        E_bytes = 2 * E.L
+        want = o.encrypt(xs2, rs)
+        assert b"".join(got) == want, sbits
+        assert got[0] == bytes(E_bytes)
+
+
 def test_emu_fixed_argument_pairing(ctx):
     """e(P, C) over the precomputed line table == makeL2 golden vectors (= e(C, P): the pairing is symmetric)."""
     fx, E = ctx

@@ -50,6 +50,21 @@ def main():
     tab = {}
     run("k_fixedpair_build_batch: one line table (MultPoly)", "table", lambda: tab.setdefault("t", E.fixed_table(a)))
     run("k_pairing<.,1>: one walk over a coefficient's table (MultPoly)", "walk", lambda: E.pairing_fixed(tab["t"], b))
+    # a four-term lane of the multi-pairing rounds (MultPoly, leaves of 4 x 4: the coefficient s = 3), per term
+    A4 = [o.encrypt([3 + i], [777 + i]) for i in range(4)]
+    B4 = [o.encrypt([9 + i], [555 + i]) for i in range(4)]
+    Qp, q = 2, 1
+    mt = {}
+
+    def multi_tables():
+        t = None
+        for i, w in enumerate(A4):
+            t = E.fixed_table(w, 4 * Qp, i * Qp + q, t)
+        mt["t"] = t
+
+    multi_tables()
+    run("k_pairing_multi: one output coefficient of four terms (MultPoly, multi-pairing rounds), per term", "term",
+        lambda: E.pairing_fixed_multi(mt["t"], 4 * Qp, Qp, q, A4, B4, 3), 4)
     run("k_g1_add: affine additions, one run of 16 (EAdd at 2^20)", "addition",
         lambda: E.g1_add([a] * 16, [b] * 16, plain=True), 16)
     print("# tools/op_tally.py %s: primitives of ONE lane by the host emulation, priced in VALU instructions (see the tool's header)" % name)

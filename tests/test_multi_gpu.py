@@ -236,3 +236,71 @@ def test_bench_two_ranks_over_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["value"] > 0
+
+
+def _bench_line(argv, spawn):
+    """One run of bench.py as a child process (fresh: this test process has initialised the GPU and never re-execs).
+    spawn=True goes through bench.py's own rank spawner (BGN_BENCH_SPAWN=1: a parent that never touches the GPU starts
+    rank 0 with RANK / WORLD_SIZE / MASTER_* set, exactly as for --gpus N)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BGN_BENCH_TIMEOUT_S="600")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if spawn:
+        env["BGN_BENCH_SPAWN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py must print ONE JSON line on stdout, got %d:\n%s" % (len(lines), r.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+def _keep(name, line):
+    """Leave the line under gpurun_out/ (scratch that travels back from the GPU box) so that the one committed under
+    profiles/ is the one this test produced.  Best effort: the driver's box may not want it."""
+    import json
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(line, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_bench_one_rank_over_rccl():
+    """The rank path of bench.py on the final build with ONE rank: spawned child, `nccl` (= RCCL) process group,
+    all_gather_into_tensor of the result shards, the strong-scaling block, the sharded Decrypt with its gather of
+    plaintexts and statuses — everything the driver's 2/4/8-GPU runs execute except a second GPU.  The rate has to
+    be that of the undistributed call (the gather of one shard is a device copy)."""
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch-log2", "16", "--no-cpu-baseline"]
+    line = _bench_line(argv + ["--force-dist"], spawn=True)
+    _keep("r06_bench_dist1_line.json", line)
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 1 << 16 and line["value"] > 0
+    strong = line["strong_2^16"]
+    assert strong["scaling"] == "strong" and strong["batch_per_gpu"] == 1 << 16 and strong["value"] > 0
+    dec = line["decrypt"]
+    assert dec["plaintexts_and_statuses_exact"] is True and dec["global_batch"] == 1 << 16 and dec["value"] > 0
+    assert dec["roofline"]["kernel_ms"] > 0 and line["roofline"]["kernel_ms"] > 0
+    plain = _bench_line(argv + ["--no-extra"], spawn=False)
+    assert plain["config"]["rccl_ranks"] == 0 and "strong_2^16" not in plain
+    assert plain["roofline"]["kernel"] == line["roofline"]["kernel"]
+    for v in (line["value"], strong["value"]):
+        assert abs(v / plain["value"] - 1) < 0.03, (line["value"], strong["value"], plain["value"])
+
+
+def test_bench_multpoly_one_rank_over_rccl():
+    """--workload multpoly through the same rank path: polynomials sharded by polynomial (one shard here), product
+    polynomials all-gathered over RCCL, strong scaling."""
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "multpoly", "--polys-log2", "8"]
+    line = _bench_line(argv + ["--force-dist"], spawn=True)
+    _keep("r06_bench_multpoly_dist1_line.json", line)
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["scaling"] == "strong"
+    assert line["config"]["polys"] == 256 and line["config"]["polys_per_gpu"] == 256 and line["value"] > 0
+    assert line["roofline"]["kernel"] and line["roofline_valu"]["frac"] > 0
+    plain = _bench_line(argv, spawn=False)
+    assert plain["config"]["rccl_ranks"] == 0
+    assert abs(line["value"] / plain["value"] - 1) < 0.03, (line["value"], plain["value"])

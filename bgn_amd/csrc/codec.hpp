@@ -139,6 +139,125 @@ __device__ __forceinline__ void limbs_to_wire_dw(u32* __restrict__ we, int L, co
   }
 }
 
+// ---- dword-stream codec (any L >= 4, either parity) ------------------------------------------------
+// The forms above index the stage with compile-time byte offsets and therefore serve the element lengths that
+// are whole dwords; with L odd (a 1024-bit key whose p has 1025..1032 bits: L = 129) an element is 2 mod 4 bytes
+// long, decoding ran both lane parities one after the other and encoding went byte by byte.  Here the alignment is
+// a per-lane quantity and costs nothing: the little-endian dwords of the value are cut out of the stage's aligned
+// words with ONE v_perm_b32 each — its selector (a VGPR) does the byte swap and the lane's byte shift at once —
+// and the limbs are funnel shifts of those dwords with compile-time amounts.  ~3 instructions per limb instead of
+// ten, for every L and every misalignment of the slice.
+
+// selector that picks bytes r+3, r+2, r+1, r (most significant last) out of a (hi:lo) pair: the 32-bit number
+// whose big-endian bytes sit at byte offset r of the pair
+__device__ __forceinline__ u32 stream_sel(u32 r) { return 0x00010203u + r * 0x01010101u; }
+
+// Limbs of the big-endian L-byte value whose first byte is byte `B` (per lane, any alignment) of the stage `w`;
+// L >= 4.  Reads the aligned words that hold the value and at most one word past it (the stage has the slack).
+template <int NL>
+__device__ __forceinline__ void wire_to_limbs_stream(Fp<NL>& r, const u32* __restrict__ w, u32 B, int L) {
+  constexpr int ND = (LIMB_BITS * NL + 31) / 32;          // dwords that hold NL limbs
+  const int full = L >> 2;                                // whole dwords of the value (wave-uniform)
+  const int top = L & 3;                                  // bytes of the partial top dword
+  u32 d[ND + 1];
+  // dword i < full: the four bytes at string offset L - 4 - 4i, i.e. at stage byte B + L - 4 - 4i
+  const u32 end = B + (u32)L;
+  const u32 q0 = (end - 4u) >> 2;
+  const u32 sel = stream_sel(end & 3u);
+  u32 hi = w[q0 + 1];
+#pragma unroll
+  for (int i = 0; i < ND + 1; ++i) {
+    d[i] = 0;
+    if (i < full) {                                       // wave-uniform
+      const u32 lo = w[q0 - (u32)i];
+      d[i] = codec_perm(hi, lo, sel);
+      hi = lo;
+    }
+  }
+  if (top) {                                              // the value's first `top` bytes: the number at offset 0, shifted down
+    const u32 qb = B >> 2;
+    const u32 e = codec_perm(w[qb + 1], w[qb], stream_sel(B & 3u));
+    const u32 t = e >> (8 * (4 - top));
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      if (i == full) d[i] = t;
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int j = (LIMB_BITS * k) >> 5, sh = (LIMB_BITS * k) & 31;
+    const u64 both = ((u64)d[j + 1] << 32) | d[j];
+    r.v[k] = (u32)(both >> sh) & LIMB_MASK;
+  }
+}
+
+// The element x || y (canonical values, each big-endian in L bytes) into the 2L bytes of lane `tid`'s element in a
+// stage that holds the slice dword-aligned: the element starts at byte B = tid * 2L — a multiple of 4 when L is even,
+// 0 or 2 mod 4 with the lane's parity when L is odd.  Read backwards the element is the little-endian number
+// V = y + x * 2^(8L); aligned word m of the element is the big-endian 32-bit number at byte 2L - 4 - h - 4m of V
+// (h = bytes before the lane's first aligned word), i.e. one v_perm_b32 of two adjacent dwords of V whose indices
+// are the same on every lane.  Register indices are compile-time (the loops run over V's dwords); what depends on
+// L is the word's address (scalar arithmetic) and whether it exists (wave-uniform).  With L odd an element has one
+// half word besides: its last two bytes on even lanes, its first two on odd ones.  No byte of a neighbouring lane
+// is written.
+template <int NL>
+__device__ __forceinline__ void limbs_to_wire_stream(u32* __restrict__ w, u32 tid, int L, const Fp<NL>& x, const Fp<NL>& y) {
+  constexpr int ND = (LIMB_BITS * NL + 31) / 32;          // dwords a value can occupy
+  const int ws = L >> 2, bs = 8 * (L & 3);                // x starts ws dwords and bs bits up in V (wave-uniform)
+  const u32 B = tid * (u32)(2 * L);
+  const u32 h = (0u - B) & 3u;
+  const u32 sel = stream_sel(((u32)(2 * L) - h) & 3u);
+  const int nfull = (2 * L - ((L & 1) ? 2 : 0)) >> 2;     // whole words of an element
+  const int i0 = (2 * L - 4 - ((2 * L) & 3)) >> 2;        // word m pairs V's dwords i0 - m and i0 - m + 1
+  u32* __restrict__ wq = w + ((B + h) >> 2);
+  // x's dwords and V's dwords above the boundary: F(k) = V[ws + k] = (x << bs) dword k, k >= 1
+  u32 xd[ND + 2];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) xd[i] = limbs_dword<NL>(x, i);
+  xd[ND] = 0;
+  xd[ND + 1] = 0;
+  u32 yd[ND + 1];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) yd[i] = limbs_dword<NL>(y, i);
+  yd[ND] = 0;
+  u32 ytop = 0;                                            // y's dword ws: its top 8 * (L & 3) bits
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+    if (i == ws) ytop = yd[i];
+  const u32 bnd = ytop | (xd[0] << bs);                    // V[ws]  (bs = 0: ytop = 0)
+  // V[i], i < ws: y's dwords
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int m = i0 - i;
+    if (i < ws && m >= 0 && m < nfull) {
+      const u32 hi = (i + 1 == ws) ? bnd : yd[i + 1];
+      wq[m] = codec_perm(hi, yd[i], sel);
+    }
+  }
+  // V[ws + k], k >= 0
+  u32 cur = bnd;
+#pragma unroll
+  for (int k = 0; k <= ND; ++k) {
+    const u32 nxt = (u32)(((((u64)xd[k + 1]) << 32) | xd[k]) >> (32 - bs));     // F(k + 1)
+    const int m = i0 - (ws + k);
+    if (m >= 0 && m < nfull) wq[m] = codec_perm(nxt, cur, sel);
+    cur = nxt;
+  }
+  if (L & 1) {
+    // V's bytes 2L-2 (low) and 2L-1 (high) = x's top 16 bits; V's bytes 0, 1 = y's low 16 bits
+    u32 topv = 0;
+    const int tb = 8 * L - 16;                             // bit of x where they start
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      if (i == (tb >> 5)) topv = (u32)(((((u64)xd[i + 1]) << 32) | xd[i]) >> (tb & 31));
+    topv &= 0xFFFFu;
+    const bool odd = h != 0;
+    const u32 hv = odd ? topv : (yd[0] & 0xFFFFu);
+    const u32 half = ((hv & 0xFFu) << 8) | (hv >> 8);      // the more significant byte first
+    uint16_t* w16 = (uint16_t*)w;
+    w16[odd ? (B >> 1) : ((B + (u32)(2 * L) - 2u) >> 1)] = (uint16_t)half;
+  }
+}
+
 // ---- LDS staging of a workgroup's slice of a wire array ---------------------------------------
 // Element e of a wire array starts at byte e*2L: a lane walking its own element touches a different
 // cache line than its neighbours on every byte.  The workgroup therefore moves its contiguous slice

@@ -120,6 +120,7 @@ struct bgn_ctx {
   uint64_t l = 0;
 
   void* d_params = nullptr;            // FpParams<NL>
+  void* d_barrett = nullptr;           // BarrettParams<NL> (barrett.hpp); null: the fused level-2 Add / Sub is not offered
   PairingConsts* d_consts = nullptr;
   uint32_t* d_keypts = nullptr;        // P.x, P.y, Q.x, Q.y, eQQ.re, eQQ.im, one, zero : 8 * nl limbs, stride 1, Montgomery
   uint8_t* d_keywire = nullptr;        // P | Q | e(Q,Q) wire bytes
@@ -444,6 +445,21 @@ std::vector<uint32_t> build_params(const BigU& p, int nl) {
   return img;
 }
 
+// Host image of BarrettParams<NL> (barrett.hpp): mu = floor(2^(2*LIMB_BITS*nl) / p) as nl + 2 limbs, two words of
+// padding.  Empty when p < 2^(LIMB_BITS*(nl-2)) — mu would not fit, and the quotient estimate's error bound needs it;
+// cannot happen for the limb count pick_table chooses (29 nl - bits(p) < 38), checked all the same.
+std::vector<uint32_t> build_barrett(const BigU& p, int nl) {
+  std::vector<uint32_t> img;
+  if (p.bits() <= LIMB_BITS * (nl - 2)) return img;
+  BigU top((uint64_t)1), q, r;
+  for (int i = 0; i < 2 * LIMB_BITS * nl; ++i) top.shl1();
+  BigU::divmod(top, p, q, r);
+  if (q.bits() > LIMB_BITS * (nl + 2)) return img;
+  img.assign((size_t)nl + 4, 0);
+  q.to_limbs(img.data(), nl + 2, LIMB_BITS);
+  return img;
+}
+
 }  // namespace
 
 extern "C" {
@@ -467,6 +483,7 @@ void bgn_ctx_destroy(bgn_ctx* c) {
   if (c->mul_ws) (void)ctx_free(c, c->mul_ws);
   if (c->poly_tab) (void)ctx_free(c, c->poly_tab);
   if (c->d_params) (void)ctx_free(c, c->d_params);
+  if (c->d_barrett) (void)ctx_free(c, c->d_barrett);
   if (c->d_consts) (void)ctx_free(c, c->d_consts);
   if (c->d_keypts) (void)ctx_free(c, c->d_keypts);
   if (c->d_keywire) (void)ctx_free(c, c->d_keywire);
@@ -547,6 +564,13 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   }
     HIP_BRK(ctx_malloc(c, (void**)&c->d_params, kt->params_bytes));
     HIP_BRK(hipMemcpy(c->d_params, img.data(), kt->params_bytes, hipMemcpyHostToDevice));
+    if (kt->gt_mul_wire) {
+      const std::vector<uint32_t> bimg = build_barrett(p, c->nl);
+      if (!bimg.empty()) {
+        HIP_BRK(ctx_malloc(c, (void**)&c->d_barrett, bimg.size() * 4));
+        HIP_BRK(hipMemcpy(c->d_barrett, bimg.data(), bimg.size() * 4, hipMemcpyHostToDevice));
+      }
+    }
 
     PairingConsts pc;
     memset(&pc, 0, sizeof pc);
@@ -1799,6 +1823,16 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   if (r_be) {                          // blinding base tables (G1 ones use the arena: before any carving)
     int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
     if (rc) return rc;
+  }
+  if (level == 2 && !r_be && c->d_barrett && c->kt->gt_mul_wire && opt(c, &Options::l2_fused)) {
+    // deterministic Add / Sub of level-2 ciphertexts: one wire-to-wire launch, no workspace (barrett.hpp)
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    c->kt->gt_mul_wire(s, c->d_params, c->d_barrett, a, b, c->L, count, subtract ? 1 : 0, out);
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->last_kernel = "k_gt_mul_wire";
+    c->ev_valid = true;
+    HIP_TRY(hipGetLastError());
+    return BGN_OK;
   }
   const size_t st = round_up(count, 64);
   SoA2 A, B, O, T1, T2;

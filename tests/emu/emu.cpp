@@ -18,6 +18,7 @@ thread_local EmuDim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, gridDim = {1, 
 #include "fixedpair.hpp"
 #include "polyops.hpp"
 #include "fpinv.hpp"
+#include "barrett.hpp"
 
 using namespace bgn;
 
@@ -68,6 +69,52 @@ struct Emu {
       }
     }
     memcpy(wire_out, out.data(), (size_t)n * 2 * Lb);
+  }
+  // the dword-stream codec: `n` elements of 2L bytes staged `mis` bytes into a dword-aligned stage; lane i decodes
+  // element i at its own byte offset (any alignment); the encoder (slice staged dword-aligned) writes them into a
+  // second stage pre-filled with a pattern, which comes back whole: bytes outside the n elements must keep it
+  static void codec_stream(const uint8_t* wire, int Lb, int n, int mis, u32* limbs_out, uint8_t* stage_out, int stage_bytes) {
+    std::vector<u32> in(((size_t)n * 2 * Lb + mis + 3) / 4 + 4, 0xA5A5A5A5u);
+    memcpy((uint8_t*)in.data() + mis, wire, (size_t)n * 2 * Lb);
+    std::vector<u32> out((size_t)stage_bytes / 4, 0x5A5A5A5Au);
+    for (int i = 0; i < n; ++i) {
+      Fp<NL> x, y;
+      const u32 B = (u32)mis + (u32)i * (u32)(2 * Lb);
+      wire_to_limbs_stream<NL>(x, in.data(), B, Lb);
+      wire_to_limbs_stream<NL>(y, in.data(), B + (u32)Lb, Lb);
+      memcpy(limbs_out + (size_t)i * 2 * NL, x.v, 4 * NL);
+      memcpy(limbs_out + (size_t)i * 2 * NL + NL, y.v, 4 * NL);
+      limbs_to_wire_stream<NL>(out.data(), (u32)i, Lb, x, y);
+    }
+    memcpy(stage_out, out.data(), (size_t)stage_bytes);
+  }
+  // (re, im) = a * b or a * conj(b) on plain residues (barrett.hpp); mu = floor(2^(2*LIMB_BITS*NL) / p)
+  static void fp2_mul_plain_(const u32* params, const u32* mu, const u32* a, const u32* b, int conj_b, u32* out) {
+    EmuChecks on;
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    BarrettParams<NL> Bp;
+    memcpy(Bp.mu, mu, 4 * (NL + 2));
+    Fp<NL> a0, a1, b0, b1, re, im;
+    memcpy(a0.v, a, 4 * NL);
+    memcpy(a1.v, a + NL, 4 * NL);
+    memcpy(b0.v, b, 4 * NL);
+    memcpy(b1.v, b + NL, 4 * NL);
+    u32 sc[NL];
+    fp2_mul_plain<NL>(re, im, a0, a1, b0, b1, conj_b != 0, P, &Bp, sc, 1);
+    memcpy(out, re.v, 4 * NL);
+    memcpy(out + NL, im.v, 4 * NL);
+  }
+  // T (2 NL limbs, any value below B^(2 NL)) mod p
+  static void barrett(const u32* params, const u32* mu, const u32* t, u32* out) {
+    EmuChecks on;
+    const FpParams<NL>* P = (const FpParams<NL>*)params;
+    BarrettParams<NL> Bp;
+    memcpy(Bp.mu, mu, 4 * (NL + 2));
+    u32 T[2 * NL];
+    memcpy(T, t, sizeof T);
+    Fp<NL> r;
+    barrett_reduce<NL>(r, T, P, &Bp);
+    memcpy(out, r.v, 4 * NL);
   }
   // Montgomery-form inverse of a Montgomery-form value (limbs in, limbs out)
   static void fp_inv(const u32* params, int p_bits, const u32* a, u32* out) {
@@ -505,6 +552,19 @@ extern "C" {
 int emu_decode(int nl, const u32* params, const uint8_t* wire, int Lb, u32* out, uint8_t* inf) { DISPATCH(nl, decode(params, wire, Lb, out, inf)) }
 int emu_encode(int nl, const u32* plain, int Lb, uint8_t inf, uint8_t* wire) { DISPATCH(nl, encode(plain, Lb, inf, wire)) }
 int emu_codec_dw(int nl, const uint8_t* wire, int Lb, int n, u32* limbs_out, uint8_t* wire_out) { DISPATCH(nl, codec_dw(wire, Lb, n, limbs_out, wire_out)) }
+int emu_codec_stream(int nl, const uint8_t* wire, int Lb, int n, int mis, u32* limbs_out, uint8_t* stage_out, int stage_bytes) { DISPATCH(nl, codec_stream(wire, Lb, n, mis, limbs_out, stage_out, stage_bytes)) }
+#define DISPATCH40(nl, call)          \
+  switch (nl) {                       \
+    case 3: Emu<3>::call; break;      \
+    case 10: Emu<10>::call; break;    \
+    case 19: Emu<19>::call; break;    \
+    case 36: Emu<36>::call; break;    \
+    case 37: Emu<37>::call; break;    \
+    default: return -1;               \
+  }                                   \
+  return 0;
+int emu_fp2_mul_plain(int nl, const u32* params, const u32* mu, const u32* a, const u32* b, int conj_b, u32* out) { DISPATCH40(nl, fp2_mul_plain_(params, mu, a, b, conj_b, out)) }
+int emu_barrett(int nl, const u32* params, const u32* mu, const u32* t, u32* out) { DISPATCH40(nl, barrett(params, mu, t, out)) }
 int emu_pairing(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing(params, (const PairingConsts*)C, a, b, out)) }
 int emu_pairing_w3(int nl, const u32* params, const void* C, const u32* a, const u32* b, u32* out) { DISPATCH(nl, pairing_w3(params, (const PairingConsts*)C, a, b, out)) }
 int emu_g1_mul(int nl, const u32* params, const void* C, const u32* base, uint8_t binf, const uint8_t* k, size_t klen, int window, u32* out, uint8_t* oinf) { DISPATCH(nl, g1_mul(params, (const PairingConsts*)C, base, binf, k, klen, window, out, oinf)) }

@@ -19,7 +19,7 @@ KP_MAX, MAX_NAF, MAX_EXP_LIMBS, MASK = 32, 2112, 80, (1 << LIMB) - 1
 def build() -> str:
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in
-                                                ("fpmont.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp")]
+                                                ("fpmont.hpp", "pairing.hpp", "ops.hpp", "codec.hpp", "consts.hpp", "bsgs.hpp", "fixedpair.hpp", "polyops.hpp", "kernels.hpp", "fpinv.hpp", "imad.hpp", "barrett.hpp")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-g", "-rdynamic", "-std=c++17", "-fPIC", "-shared", "-I" + _HERE, "-I" + _CSRC,
                                "-include", os.path.join(_HERE, "agpr.hpp"), "-include", os.path.join(_HERE, "gmem.hpp"), "-include", os.path.join(_HERE, "imad.hpp"),
@@ -319,6 +319,26 @@ class Emu:
         out = (C.c_uint32 * (2 * self.nl))()
         assert self.lib.emu_gt_mul(self.nl, self.params, A, B, 1 if conj_b else 0, 1 if plain_a else 0, out) == 0
         return self.encode(out)
+
+    def barrett_mu(self):
+        return (C.c_uint32 * (self.nl + 2))(*limbs((1 << (2 * LIMB * self.nl)) // self.p, self.nl + 2))
+
+    def gt_mul_plain(self, a: bytes, b: bytes, conj_b=False) -> bytes:
+        """barrett.hpp fp2_mul_plain on the plain residues of two wire elements (the fused level-2 Add / Sub)."""
+        A, _ = self.decode_plain(a)
+        B, _ = self.decode_plain(b)
+        A = (C.c_uint32 * (2 * self.nl))(*A)
+        B = (C.c_uint32 * (2 * self.nl))(*B)
+        out = (C.c_uint32 * (2 * self.nl))()
+        assert self.lib.emu_fp2_mul_plain(self.nl, self.params, self.barrett_mu(), A, B, 1 if conj_b else 0, out) == 0
+        return self.encode(out)
+
+    def barrett(self, t: int) -> int:
+        nl = self.nl
+        T = (C.c_uint32 * (2 * nl))(*limbs(t, 2 * nl))
+        out = (C.c_uint32 * nl)()
+        assert self.lib.emu_barrett(nl, self.params, self.barrett_mu(), T, out) == 0
+        return sum(int(out[j]) << (LIMB * j) for j in range(nl))
 
     def gt_table(self, g_wire: bytes, wbits: int, windows: int):
         g, _ = self.decode(g_wire)

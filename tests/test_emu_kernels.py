@@ -503,3 +503,65 @@ def test_emu_products_at_extreme_limbs(name):
             assert m % p == a * b * Rinv % p and m < 2 * p, (name, "fp_mul")
             assert sq % p == a * a * Rinv % p and sq < 2 * p, (name, "fp_sqr")
             assert m2 % p == (a * b + c * d) * Rinv % p and m2 < 2 * p, (name, "fp_mul2")
+
+
+@pytest.mark.parametrize("nl", [3, 10, 19, 36, 37, 72])
+def test_emu_stream_codec_every_length_and_alignment(nl):
+    """codec.hpp's dword-stream forms (wire_to_limbs_stream: per-lane alignment folded into one v_perm_b32 selector,
+    any misalignment of the slice; limbs_to_wire_stream: whole aligned words plus, with L odd, one half word per
+    element) against Python integers for every L the limb count serves: limbs of edge patterns and random values, the
+    re-encoded stage equal to the input bytes, and not one byte written outside the elements."""
+    import ctypes as C
+    lib = emu.Emu.from_fixture(load_fixture("toy64")).lib
+    rng = random.Random(100 + nl)
+    lmax = (emu.LIMB * nl - 9 + 7) // 8
+    lmin = max(4, (emu.LIMB * (nl - 1) + 7) // 8 - 6)
+    for L in range(lmin, lmax + 1):
+        n = 7
+        top = min(8 * L, emu.LIMB * nl)
+        vals = [0, 1, (1 << top) - 1, (1 << (top - 1)) + 1, int.from_bytes(bytes((i % 255) + 1 for i in range(L)), "big") & ((1 << top) - 1)]
+        vals += [rng.getrandbits(top) for _ in range(2 * n - len(vals))]
+        wire = b"".join(v.to_bytes(L, "big") for v in vals)
+        stage_bytes = (2 * L * n + 3) // 4 * 4 + 16
+        for mis in range(4):
+            limbs_out = (C.c_uint32 * (2 * nl * n))()
+            stage = C.create_string_buffer(stage_bytes)
+            assert lib.emu_codec_stream(nl, wire, L, n, mis, limbs_out, stage, stage_bytes) == 0
+            for i, v in enumerate(vals):
+                got = sum(int(limbs_out[i * nl + j]) << (emu.LIMB * j) for j in range(nl))
+                assert all(int(limbs_out[i * nl + j]) < (1 << emu.LIMB) for j in range(nl))
+                assert got == v, (nl, L, mis, i, hex(v), hex(got))
+            assert stage.raw[:2 * L * n] == wire, (nl, L)
+            assert stage.raw[2 * L * n:] == b"\x5a" * (stage_bytes - 2 * L * n), (nl, L, "bytes past the slice written")
+
+
+@pytest.mark.parametrize("name", ["toy64", "k256", "k512", "k1024", "k1024b"])
+def test_emu_barrett_product_of_plain_residues(name):
+    """barrett.hpp: T mod p for edge values of T (0, p - 1, p, p^2, 2 p^2, the largest number of its domain, numbers one
+    off a multiple of p) and random ones; the fused level-2 Add / Sub (a*b and a*conj(b) in F_p^2 on plain residues,
+    operands incl. 0, 1, p - 1) against Python integers and the fixture's L2 add / sub rows."""
+    fx = load_fixture(name)
+    E = emu.Emu.from_fixture(fx)
+    p, nl = E.p, E.nl
+    assert p >= 1 << (emu.LIMB * (nl - 2)), "the fused kernel's precondition (engine.cpp checks the same)"
+    rng = random.Random(7)
+    top = p << (emu.LIMB * nl)          # barrett_reduce's domain: T < p * B^NL (the quotient then has NL limbs)
+    ts = [0, 1, p - 1, p, p + 1, p * p, 2 * p * p, top - 1, top - p, (top // p) * p - 1, (top // p - 1) * p, 3 * p - 1, 4 * p - 1,
+          (1 << (emu.LIMB * nl)) - 1]
+    ts += [rng.randrange(top) for _ in range(20)] + [rng.randrange(p) * rng.randrange(p) for _ in range(20)]
+    for t in ts:
+        assert E.barrett(t) == t % p, (name, hex(t))
+    Lb = E.L
+    enc = lambda re, im: re.to_bytes(Lb, "big") + im.to_bytes(Lb, "big")
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2]
+    cases = [(a0, a1, b0, b1) for a0 in edge[:4] for a1 in edge[:4] for b0 in (0, 1, p - 1) for b1 in (0, 1, p - 1)]
+    cases += [tuple(rng.randrange(p) for _ in range(4)) for _ in range(24)]
+    for a0, a1, b0, b1 in cases:
+        want = enc((a0 * b0 - a1 * b1) % p, (a0 * b1 + a1 * b0) % p)
+        assert E.gt_mul_plain(enc(a0, a1), enc(b0, b1)) == want
+        want = enc((a0 * b0 + a1 * b1) % p, (a1 * b0 - a0 * b1) % p)
+        assert E.gt_mul_plain(enc(a0, a1), enc(b0, b1), True) == want
+    l2 = [bytes.fromhex(v["out"]) for v in fx["mult"]]
+    for v in fx["l2"][:6]:
+        assert E.gt_mul_plain(l2[v["a"]], l2[v["b"]]).hex() == v["add"]
+        assert E.gt_mul_plain(l2[v["a"]], l2[v["b"]], True).hex() == v["sub"]

@@ -11,11 +11,13 @@
 // one 64-bit accumulator per column, register indices static), so the operands stay in VGPRs and the kernel needs
 // LDS for the wire staging only — two workgroups per CU.
 //
-// Radix B = 2^LIMB_BITS, limbs tight.  mu = floor(B^(2 NL) / p) has at most NL + 2 limbs when p >= B^(NL-2)
-// (engine.cpp checks that before it offers the fused kernel).  Error of the quotient estimate: with
-// A = floor(T / B^(NL-2)) and T < B^(2 NL), T/p - A*mu/B^(NL+2) < T/B^(2NL) + B^(NL-2)/p < 2, and the columns of
-// A*mu below NL that are not computed are worth less than NL/B of one unit: q >= floor(T/p) - 3, so
-// 0 <= T - q*p < 4p < B^NL (p < B^NL / 2^9) and only the low NL limbs of q*p are needed.
+// Radix B = 2^LIMB_BITS, limbs tight.  mu = floor(B^(2 NL) / p) has at most NL + 2 limbs when p >= B^(NL-2).
+// Error of the quotient estimate: with A = floor(T / B^(NL-2)) and T <= 2 p^2 < B^(2 NL) / 2^17,
+//     T/p - A*mu/B^(NL+2)  <  T/B^(2NL) + B^(NL-2)/p  <  2^-17 + 1/2     when p >= 2 * B^(NL-2),
+// and the columns of A*mu below NL that are not computed are worth less than NL/B of one unit: the estimate is
+// floor(T/p) or one less, so 0 <= T - q*p < 2p < B^NL (p < B^NL / 2^9), only the low NL limbs of q*p are needed
+// and ONE conditional subtraction of p finishes.  engine.cpp offers the fused kernel only when p >= 2 * B^(NL-2)
+// (always, for the limb count it picks: LIMB_BITS * NL - bits(p) < LIMB_BITS + 9).
 #pragma once
 #include "fpmont.hpp"
 
@@ -28,30 +30,52 @@ struct BarrettParams {
 };
 
 // T = a*b + c*d, 2 NL tight limbs; a, b, c, d tight limbs of any value (T < B^(2 NL) always).
-// A column holds up to 2 NL products of < 2^58: one accumulator per product (NL * 2^58 < 2^64 up to NL = 63).
+// A column holds up to 2 NL products of < 2^58.  63 of them plus the carry fit 64 bits ((2^29 - 1)^2 * 63 + 2^37 <
+// 2^64): the columns of at most 31 index pairs run on one accumulator, the middle ones on one per product.
 template <int NL>
 __device__ __forceinline__ void wide_mul2(u32 (&T)[2 * NL], const Fp<NL>& a, const Fp<NL>& b, const Fp<NL>& c,
                                           const Fp<NL>& d) {
   static_assert(NL <= 62, "a column of NL products plus the carry must fit 64 bits");
+  static_assert(LIMB_BITS <= 29, "63 products of two limbs must fit 64 bits");
   u64 carry = 0;
 #pragma unroll
   for (int col = 0; col < 2 * NL - 1; ++col) {
     const int i0 = col < NL ? 0 : col - NL + 1;
     const int i1 = col < NL ? col : NL - 1;
-    u64 s1 = carry, s2 = 0;
+    if (i1 - i0 + 1 <= 31) {
+      u64 s = carry;
 #pragma unroll
-    for (int i = i0; i <= i1; ++i) {
-      acc_mad(s1, a.v[i], b.v[col - i]);
-      acc_mad(s2, c.v[i], d.v[col - i]);
+      for (int i = i0; i <= i1; ++i) {
+        acc_mad(s, a.v[i], b.v[col - i]);
+        acc_mad(s, c.v[i], d.v[col - i]);
+      }
+      T[col] = (u32)s & LIMB_MASK;
+      carry = s >> LIMB_BITS;
+    } else {
+      u64 s1 = carry, s2 = 0;
+#pragma unroll
+      for (int i = i0; i <= i1; ++i) {
+        acc_mad(s1, a.v[i], b.v[col - i]);
+        acc_mad(s2, c.v[i], d.v[col - i]);
+      }
+      const u32 lo = ((u32)s1 & LIMB_MASK) + ((u32)s2 & LIMB_MASK);       // < 2^30
+      T[col] = lo & LIMB_MASK;
+      carry = (s1 >> LIMB_BITS) + (s2 >> LIMB_BITS) + (u64)(lo >> LIMB_BITS);
     }
-    const u32 lo = ((u32)s1 & LIMB_MASK) + ((u32)s2 & LIMB_MASK);       // < 2^30
-    T[col] = lo & LIMB_MASK;
-    carry = (s1 >> LIMB_BITS) + (s2 >> LIMB_BITS) + (u64)(lo >> LIMB_BITS);
   }
   T[2 * NL - 1] = (u32)carry;
   BGN_TALLY(T_FINAL, 2 * NL);
   BGN_CHECK_ALWAYS((carry >> LIMB_BITS) == 0, "wide_mul2: value above B^(2 NL)");
 }
+
+#ifdef BGN_EMU
+template <int NL>
+inline bool fp_lt_p_emu(const Fp<NL>& v, const FpParams<NL>* P) {
+  i32 c = 0;
+  for (int j = 0; j < NL; ++j) c = ((i32)v.v[j] - (i32)P->p[j] + c) >> LIMB_BITS;
+  return c != 0;
+}
+#endif
 
 // Quotient estimate of T / p from T's upper limbs: q = floor(A * mu / B^(NL+2)), A = T[NL-2 ..] (NL + 2 limbs).
 // Columns NL .. 2 NL + 1 of the product (two guard columns below the first kept one); T < p * B^NL, so the
@@ -90,7 +114,10 @@ __device__ __forceinline__ void barrett_rem(Fp<NL>& r, TLO tlo, const u32 (&q)[N
     s >>= LIMB_BITS;
   }
   BGN_TALLY(T_FINAL, NL);
-  fp_reduce_lt<NL, 4>(r, x, P);
+  fp_cond_sub_p<NL>(r, x, P);             // x < 2p
+#ifdef BGN_EMU
+  BGN_CHECK_ALWAYS(fp_lt_p_emu(r, P), "barrett_rem: remainder not below 2p");
+#endif
 }
 
 // r = T mod p, canonical.  T: 2 NL tight limbs, T < p * B^NL (the quotient then has NL limbs: a sum of two

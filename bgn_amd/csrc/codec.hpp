@@ -148,6 +148,17 @@ __device__ __forceinline__ void limbs_to_wire_dw(u32* __restrict__ we, int L, co
 // and the limbs are funnel shifts of those dwords with compile-time amounts.  ~3 instructions per limb instead of
 // ten, for every L and every misalignment of the slice.
 
+// low 32 bits of (hi:lo) >> sh, sh in 0..31: v_alignbit_b32.  (Written as a 64-bit shift of two adjacent array
+// elements the compiler merges the two loads into one 8-byte load at a 4-byte offset, cannot split the array into
+// registers any more and keeps it in scratch memory.)
+__device__ __forceinline__ u32 codec_funnel(u32 hi, u32 lo, u32 sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+  return (u32)((((u64)hi << 32) | lo) >> (sh & 31u));
+#endif
+}
+
 // selector that picks bytes r+3, r+2, r+1, r (most significant last) out of a (hi:lo) pair: the 32-bit number
 // whose big-endian bytes sit at byte offset r of the pair
 __device__ __forceinline__ u32 stream_sel(u32 r) { return 0x00010203u + r * 0x01010101u; }
@@ -164,29 +175,29 @@ __device__ __forceinline__ void wire_to_limbs_stream(Fp<NL>& r, const u32* __res
   const u32 end = B + (u32)L;
   const u32 q0 = (end - 4u) >> 2;
   const u32 sel = stream_sel(end & 3u);
+  // the value's first `top` bytes (when L is not a multiple of 4): the 32-bit number at offset 0, shifted down
+  u32 t = 0;
+  if (top) {
+    const u32 qb = B >> 2;
+    t = codec_perm(w[qb + 1], w[qb], stream_sel(B & 3u)) >> (8 * (4 - top));
+  }
   u32 hi = w[q0 + 1];
+  // (every d[i] is written exactly once, at a compile-time index: a conditional store at index `full` would make
+  // the array dynamically indexed and send it to scratch memory)
 #pragma unroll
   for (int i = 0; i < ND + 1; ++i) {
-    d[i] = 0;
+    u32 v = (i == full) ? t : 0u;
     if (i < full) {                                       // wave-uniform
       const u32 lo = w[q0 - (u32)i];
-      d[i] = codec_perm(hi, lo, sel);
+      v = codec_perm(hi, lo, sel);
       hi = lo;
     }
-  }
-  if (top) {                                              // the value's first `top` bytes: the number at offset 0, shifted down
-    const u32 qb = B >> 2;
-    const u32 e = codec_perm(w[qb + 1], w[qb], stream_sel(B & 3u));
-    const u32 t = e >> (8 * (4 - top));
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-      if (i == full) d[i] = t;
+    d[i] = v;
   }
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
     const int j = (LIMB_BITS * k) >> 5, sh = (LIMB_BITS * k) & 31;
-    const u64 both = ((u64)d[j + 1] << 32) | d[j];
-    r.v[k] = (u32)(both >> sh) & LIMB_MASK;
+    r.v[k] = codec_funnel(d[j + 1], d[j], (u32)sh) & LIMB_MASK;
   }
 }
 
@@ -237,7 +248,7 @@ __device__ __forceinline__ void limbs_to_wire_stream(u32* __restrict__ w, u32 ti
   u32 cur = bnd;
 #pragma unroll
   for (int k = 0; k <= ND; ++k) {
-    const u32 nxt = (u32)(((((u64)xd[k + 1]) << 32) | xd[k]) >> (32 - bs));     // F(k + 1)
+    const u32 nxt = bs ? codec_funnel(xd[k + 1], xd[k], (u32)(32 - bs)) : xd[k + 1];     // F(k + 1)
     const int m = i0 - (ws + k);
     if (m >= 0 && m < nfull) wq[m] = codec_perm(nxt, cur, sel);
     cur = nxt;
@@ -248,7 +259,7 @@ __device__ __forceinline__ void limbs_to_wire_stream(u32* __restrict__ w, u32 ti
     const int tb = 8 * L - 16;                             // bit of x where they start
 #pragma unroll
     for (int i = 0; i < ND; ++i)
-      if (i == (tb >> 5)) topv = (u32)(((((u64)xd[i + 1]) << 32) | xd[i]) >> (tb & 31));
+      if (i == (tb >> 5)) topv = codec_funnel(xd[i + 1], xd[i], (u32)(tb & 31));
     topv &= 0xFFFFu;
     const bool odd = h != 0;
     const u32 hv = odd ? topv : (yd[0] & 0xFFFFu);
@@ -295,10 +306,13 @@ __device__ __forceinline__ u32 wire_stage_in(WireStage<NL>* st, const uint8_t* _
       for (int k = 0; k < 8; ++k) s4[i + k * FP_BLOCK] = v[k];
     }
     {                                                     // up to seven more rows, again all loads first
-      uint4 v[7];
+      uint4 v[7];                                         // (each written once, unconditionally: stays in registers)
 #pragma unroll
-      for (int k = 0; k < 7; ++k)
-        if (i + k * FP_BLOCK < n4) v[k] = g4[i + k * FP_BLOCK];
+      for (int k = 0; k < 7; ++k) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (i + k * FP_BLOCK < n4) t = g4[i + k * FP_BLOCK];
+        v[k] = t;
+      }
 #pragma unroll
       for (int k = 0; k < 7; ++k)
         if (i + k * FP_BLOCK < n4) s4[i + k * FP_BLOCK] = v[k];

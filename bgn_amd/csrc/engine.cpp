@@ -446,11 +446,12 @@ std::vector<uint32_t> build_params(const BigU& p, int nl) {
 }
 
 // Host image of BarrettParams<NL> (barrett.hpp): mu = floor(2^(2*LIMB_BITS*nl) / p) as nl + 2 limbs, two words of
-// padding.  Empty when p < 2^(LIMB_BITS*(nl-2)) — mu would not fit, and the quotient estimate's error bound needs it;
-// cannot happen for the limb count pick_table chooses (29 nl - bits(p) < 38), checked all the same.
+// padding.  Empty when p < 2 * 2^(LIMB_BITS*(nl-2)) — mu would not fit and the quotient estimate's error bound (one
+// conditional subtraction) needs it; cannot happen for the limb count pick_table chooses (29 nl - bits(p) < 38),
+// checked all the same.
 std::vector<uint32_t> build_barrett(const BigU& p, int nl) {
   std::vector<uint32_t> img;
-  if (p.bits() <= LIMB_BITS * (nl - 2)) return img;
+  if (p.bits() < LIMB_BITS * (nl - 2) + 2) return img;
   BigU top((uint64_t)1), q, r;
   for (int i = 0; i < 2 * LIMB_BITS * nl; ++i) top.shl1();
   BigU::divmod(top, p, q, r);

@@ -31,8 +31,10 @@ k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, i
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
   Fp<NL> x, y;
-  if (mis == 0 && L >= 4) {                    // wave-uniform: the slice is staged dword-aligned
-    wire_element_dw<NL>(x, y, ws.w, threadIdx.x, L);
+  if (L >= 4) {                                // wave-uniform; any misalignment of the slice (codec.hpp)
+    const u32 B = mis + threadIdx.x * (u32)EB;
+    wire_to_limbs_stream<NL>(x, ws.w, B, L);
+    wire_to_limbs_stream<NL>(y, ws.w, B + (u32)L, L);
   } else {
     const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
     wire_to_limbs<NL>(x, src, L);
@@ -68,8 +70,10 @@ k_validate(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire,
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
   Fp<NL> x, y;
-  if (mis == 0 && L >= 4) {                    // wave-uniform: the slice is staged dword-aligned
-    wire_element_dw<NL>(x, y, ws.w, threadIdx.x, L);
+  if (L >= 4) {                                // wave-uniform; any misalignment of the slice (codec.hpp)
+    const u32 B = mis + threadIdx.x * (u32)EB;
+    wire_to_limbs_stream<NL>(x, ws.w, B, L);
+    wire_to_limbs_stream<NL>(y, ws.w, B + (u32)L, L);
   } else {
     const uint8_t* src = (const uint8_t*)ws.w + mis + threadIdx.x * EB;
     wire_to_limbs<NL>(x, src, L);
@@ -126,8 +130,8 @@ k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32*
       fp_zero(x);
       fp_zero(y);
     }
-    if (codec_dword_ok(L, (u32)((uintptr_t)g & 3u))) {
-      limbs_to_wire_dw<NL>(ws.w + threadIdx.x * (u32)(EB / 4), L, x, y);
+    if (((uintptr_t)g & 3u) == 0 && L >= 4) {    // wave-uniform: the slice is staged dword-aligned
+      limbs_to_wire_stream<NL>(ws.w, threadIdx.x, L, x, y);
     } else {
       uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
       limbs_to_wire<NL>(dst, L, x);
@@ -461,11 +465,18 @@ k_gt_mul_wire(const FpParams<NL>* __restrict__ P, const BarrettParams<NL>* __res
   // residues at or above p (the wire format allows them; valid ciphertexts never have one): reduced first, so
   // that the result is the product of the residues mod p whatever came in.  Wave-uniform branch, not taken in
   // practice.
-  if (__any(!(fp_lt_p(a0, P) && fp_lt_p(a1, P) && fp_lt_p(b0, P) && fp_lt_p(b1, P)))) {
-    barrett_canon<NL>(a0, a0, P, Bp);
-    barrett_canon<NL>(a1, a1, P, Bp);
-    barrett_canon<NL>(b0, b0, P, Bp);
-    barrett_canon<NL>(b1, b1, P, Bp);
+  // The test that costs nothing first: a top limb below p's means a value below p (a residue that shares p's top
+  // limb — one in 2^16 at the 1031-bit key — sends its wave through the full comparison).
+  {
+    const u32 pt = P->p[NL - 1];
+    if (__any(!(a0.v[NL - 1] < pt && a1.v[NL - 1] < pt && b0.v[NL - 1] < pt && b1.v[NL - 1] < pt))) {
+      if (__any(!(fp_lt_p(a0, P) && fp_lt_p(a1, P) && fp_lt_p(b0, P) && fp_lt_p(b1, P)))) {
+        barrett_canon<NL>(a0, a0, P, Bp);
+        barrett_canon<NL>(a1, a1, P, Bp);
+        barrett_canon<NL>(b0, b0, P, Bp);
+        barrett_canon<NL>(b1, b1, P, Bp);
+      }
+    }
   }
   __syncthreads();                                       // every lane has read b's slice: the stage is scratch now
   Fp<NL> re, im;

@@ -15,6 +15,7 @@
 #define __restrict__
 struct EmuDim3 { unsigned x, y, z; };
 struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 extern thread_local EmuDim3 threadIdx, blockIdx, gridDim, blockDim;
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 typedef void* hipStream_t;

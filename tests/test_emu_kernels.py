@@ -543,7 +543,7 @@ def test_emu_barrett_product_of_plain_residues(name):
     fx = load_fixture(name)
     E = emu.Emu.from_fixture(fx)
     p, nl = E.p, E.nl
-    assert p >= 1 << (emu.LIMB * (nl - 2)), "the fused kernel's precondition (engine.cpp checks the same)"
+    assert p.bit_length() >= emu.LIMB * (nl - 2) + 2, "the fused kernel's precondition (engine.cpp build_barrett checks the same)"
     rng = random.Random(7)
     top = p << (emu.LIMB * nl)          # barrett_reduce's domain: T < p * B^NL (the quotient then has NL limbs)
     ts = [0, 1, p - 1, p, p + 1, p * p, 2 * p * p, top - 1, top - p, (top // p) * p - 1, (top // p - 1) * p, 3 * p - 1, 4 * p - 1,

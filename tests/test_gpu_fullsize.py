@@ -292,10 +292,12 @@ def test_batches_that_do_not_fill_lane_kernel_rounds_are_cut(engopts):
             prod = torch.empty(count * EB, dtype=torch.uint8, device=dev)
             eng.mult_dev(ca, cb, prod, count)                                    # (also grows the workspace)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            eng.mult_dev(ca, cb, prod, count)
-            torch.cuda.synchronize()
-            t_mult = time.perf_counter() - t0
+            t_mult = 1e9
+            for _ in range(3):                                                   # best of three: a timing, on a shared box
+                t0 = time.perf_counter()
+                eng.mult_dev(ca, cb, prod, count)
+                torch.cuda.synchronize()
+                t_mult = min(t_mult, time.perf_counter() - t0)
             k_mult = eng.last_kernel_name()
             l2 = torch.empty_like(prod)
             eng.make_l2_dev(ca, l2, count)

@@ -35,6 +35,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Round 1's table (ubench_valu_rates_r01.txt: 378 / 455 G) did not pin its occupancy and read low at 4 waves.
 VALU_MAD_PEAK_4W = 526.4e9 * 64    # lane-MADs/s at 4 waves per SIMD (the chip's ceiling)
 VALU_MAD_PEAK_1W = 398.4e9 * 64    # at 1 wave per SIMD — the occupancy these 512-register kernels run at
+VALU_MAD_PEAK_2W = 466.8e9 * 64    # at 2 waves per SIMD (same file: 424.1 / 509.4 G): the fused level-2 Add
+
+
+def check_rc(rc):
+    if rc != 0:
+        raise RuntimeError("engine call failed with %d" % rc)
 
 
 def cpu_budget():
@@ -145,7 +151,7 @@ def committed_traffic(key=None):
     of THIS command (tools/collect_profiles.sh), they cannot be read from inside the process.  The line therefore
     quotes the newest committed summary under profiles/ and says so: a figure of an earlier run of the same command
     on the same build family, not of this run."""
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01e_pmc_summary.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue
@@ -274,9 +280,10 @@ def mid_batch_metrics(eng, a, b, dev):
                         "by the engine's batch-size dispatch; measured before the headline's warm-up steps"}
 
 
-def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_log2=14):
-    """BASELINE configs[1] (Encrypt), EAdd, configs[4]'s shape on one GPU and configs[3] (BSGS Decrypt, T = 2^40),
-    on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used.  Inputs resident in HBM; one warm-up pass
+def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_log2=14, prods=None):
+    """BASELINE configs[1] (Encrypt), EAdd on both levels, MultConst, configs[4]'s shape on one GPU and configs[3]
+    (BSGS Decrypt, T = 2^40), on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used and on its products
+    `prods` (level-2 ciphertexts).  Inputs resident in HBM; one warm-up pass
     then one timed pass each (the median of five for calls shorter than a quarter of a second, _timed)."""
     import numpy as np
     import torch
@@ -339,12 +346,93 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
         if cb:
             out["eadd_l1"]["cpu_baseline"] = cb
     del o1, b1
+    # --- EAdd (level 2, bgn.go:455-475): every product of the headline with its partner in a fixed permutation; one
+    # wire-to-wire launch (k_gt_mul_wire: Barrett F_p^2 product of plain residues, csrc/barrett.hpp)
+    if prods is not None:
+        n2a = prods.numel() // EB
+        b2 = syn.permuted_copy(prods, EB, seed=13)
+        o2 = torch.empty(n2a * EB, dtype=torch.uint8, device=dev)
+        dt = _timed(lambda: eng.add_dev(2, prods, b2, o2, n2a), sync)
+        k_ms, k_name = eng.last_kernel_ms(), eng.last_kernel_name()
+        mads2 = syn.l2_add_mads(nl)
+        alg2 = 3 * EB * n2a
+        node, src2 = committed_traffic("eadd_l2") if n2a == 1 << 20 else (None, None)
+        rate2 = n2a / dt * mads2
+        out["eadd_l2"] = {
+            "value": n2a / dt, "unit": "adds/s", "batch": n2a,
+            "workload": "pk.Add on level-2 ciphertexts (the headline's products; one F_p^2 product each), wire bytes to "
+                        "wire bytes in one launch", "kernel": k_name, "algorithmic_bytes_per_unit": 3 * EB,
+            "roofline": {"bound": "hbm", "achieved": alg2 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": (node or {}).get("hbm_bytes_per_launch"), "traffic_source": src2 if node else None,
+                         "algorithmic_bytes_per_launch": alg2, "kernel": k_name, "kernel_ms": k_ms, "call_ms": dt * 1e3},
+            "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_unit": mads2, "achieved": rate2, "unit": "lane-MAD/s",
+                              "peak": VALU_MAD_PEAK_4W, "frac": rate2 / VALU_MAD_PEAK_4W,
+                              "peak_at_2_waves_per_simd": VALU_MAD_PEAK_2W, "frac_at_2_waves_per_simd": rate2 / VALU_MAD_PEAK_2W,
+                              "note": "two workgroups per CU (LDS: the wire stage only), i.e. two waves per SIMD"}}
+        if not no_cpu:
+            ns = n2a                                      # the whole batch: a third of a second on sixteen cores
+            ah, bh = prods[: ns * EB].cpu().numpy().tobytes(), b2[: ns * EB].cpu().numpy().tobytes()
+            cb = secondary_cpu_leg(fx, ns, lambda orc, lo, hi: orc.add(2, ah[lo * EB:hi * EB], bh[lo * EB:hi * EB]),
+                                   o2[: ns * EB].cpu().numpy().tobytes(), EB, "adds/s",
+                                   "pairs (one F_p^2 product each, as PBC's Mul on GT)", calibrate=64)
+            if cb:
+                out["eadd_l2"]["cpu_baseline"] = cb
+        del o2, b2
+    # --- MultConst (bgn.go:253-291, BenchmarkMultConstant bgn_test.go:112-125) with per-element scalars: 2^16
+    # ciphertexts of each level, 40-bit scalars (a plaintext-sized constant) and 1024-bit ones (the width of n)
+    n_mc = 1 << 16
+    g = torch.Generator(device="cpu")
+    g.manual_seed(4242)
+    mc_src = {1: cts[: n_mc * EB], 2: (prods[: n_mc * EB] if prods is not None else None)}
+    omc = torch.empty(n_mc * EB, dtype=torch.uint8, device=dev)
+    for kb in (5, 128):
+        ks = torch.randint(0, 256, (n_mc, kb), dtype=torch.uint8, generator=g)
+        if kb == 128:
+            ks[:, 0] &= 0x3F                                            # below n (1023 bits and more)
+        ks = ks.to(dev)
+        for level in (1, 2):
+            src = mc_src[level]
+            if src is None:
+                continue
+            call = lambda: check_rc(eng._lib.bgn_multconst_batch_dev(eng._h, n_mc, level, src.data_ptr(), ks.data_ptr(), kb,
+                                                                     None, 0, omc.data_ptr(), eng._stream()))
+            dt = _timed(call, sync)
+            e = op_rooflines(
+                {"value": n_mc / dt, "unit": "multconsts/s", "batch": n_mc, "level": level, "scalar_bits": kb * 8,
+                 "workload": "pk.MultConst on 2^16 level-%d ciphertexts, one uniformly random %d-bit scalar per element "
+                             "(device-resident wire bytes in and out)" % (level, kb * 8),
+                 "kernel": eng.last_kernel_name(), "kernel_ms": eng.last_kernel_ms(), "call_ms": dt * 1e3,
+                 "algorithmic_bytes_per_unit": 2 * EB + kb},
+                syn.multconst_counts(level, kb * 8), nl)
+            if not no_cpu:
+                ns = 2048 if kb == 5 else 256
+                ah = src[: ns * EB].cpu().numpy().tobytes()
+                kh = [int.from_bytes(bytes(v), "big") for v in ks[:ns].cpu().numpy()]
+                cb = secondary_cpu_leg(fx, ns, lambda orc, lo, hi, lv=level: orc.multconst(lv, ah[lo * EB:hi * EB], kh[lo:hi]),
+                                       omc[: ns * EB].cpu().numpy().tobytes(), EB, "multconsts/s",
+                                       "ciphertexts (generic scalar multiplication / power by a %d-bit scalar, as PBC's "
+                                       "PowBig)" % (kb * 8), seconds=3.0, calibrate=2)
+                if cb:
+                    e["cpu_baseline"] = cb
+            out["multconst_l%d_%db" % (level, kb * 8)] = e
+    del omc
+    # --- the decryption tables first (one-off per key, like SetupDecryption): MultPoly below is then measured on a
+    # context that can also decrypt — 53 GB of tables beside its 38 GB of line tables, the state of a real service
+    # (until round 6 the line tables of such a context went back to the allocator after every call: engine.cpp
+    # trim_to_resident_cap)
+    t0 = time.perf_counter()
+    pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+    sync()
+    t_setup = time.perf_counter() - t0
     # --- MultPoly: configs[4] at its stated size on this one GPU — 2^14 products of 16x16 coefficient polynomials
     # (2^22 coefficient pairs, base-3 digits in {-1, 0, 1}) followed by one AddPoly of the products with each other
     if polys_log2:
         job = MultPolyJob(pk, 1 << polys_log2, dev, seed_a=2000, seed_b=3000)
         dt = _timed(job.step, sync)
         e = job.entry(fx, dt, 1)
+        e["context_memory_bytes_after_the_call"] = int(eng.memory_bytes())
+        e["context"] = "holds the decryption tables of T = 2^40 (bgn_ctx_setup_decryption ran first)"
         if not no_cpu:
             ah, bh = job.ca.cpu().numpy().tobytes(), job.cb.cpu().numpy().tobytes()
             d1, d2 = job.d1, job.d2
@@ -361,10 +449,6 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
         out["multpoly"] = e
         del job
     # --- Decrypt: the first 2^k of those ciphertexts, every 16th negated and every 4096th out of range
-    t0 = time.perf_counter()
-    pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
-    sync()
-    t_setup = time.perf_counter() - t0
     mixed, want, want_st = syn.decrypt_mix(pk, fx, cts, xs, dev)
     dec = {}
     for k in sorted(set(dec_log2s)):
@@ -674,7 +758,7 @@ def main():
     full = args.key == "k1024" and args.batch_log2 == 20
     if not args.no_extra and world == 1 and not use_dist and full:
         extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2],
-                                       no_cpu=args.no_cpu_baseline, polys_log2=args.polys_log2)
+                                       no_cpu=args.no_cpu_baseline, polys_log2=args.polys_log2, prods=out)
         extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
         if mid_batch:
             extra["mult_mid_batch"] = mid_batch

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "bgn_last_aux_kernel_ms": (C.c_double, [_ctx]),
     "bgn_last_aux_kernel_name": (C.c_char_p, [_ctx]),
     "bgn_ctx_bsgs_baby_steps": (C.c_uint64, [_ctx]),
+    "bgn_last_kernel_resources": (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -372,6 +372,13 @@ class Engine:
     def last_kernel_ms(self) -> float:
         return float(self._lib.bgn_last_kernel_ms(self._h))
 
+    def last_kernel_resources(self) -> dict:
+        """Registers, scratch and LDS of the kernel last_kernel_name names (bgn_last_kernel_resources)."""
+        out = (C.c_int64 * 4)()
+        check(self._lib.bgn_last_kernel_resources(self._h, out), "bgn_last_kernel_resources")
+        return {"vgprs": int(out[0]), "scratch_bytes_per_lane": int(out[1]), "lds_bytes_per_workgroup": int(out[2]),
+                "max_threads_per_workgroup": int(out[3])}
+
     def last_kernel_name(self) -> str:
         return self._lib.bgn_last_kernel_name(self._h).decode()
 

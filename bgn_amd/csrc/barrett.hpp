@@ -83,13 +83,14 @@ inline bool fp_lt_p_emu(const Fp<NL>& v, const FpParams<NL>* P) {
 template <int NL>
 __device__ __forceinline__ void barrett_quot(u32 (&q)[NL], const u32 (&A)[NL + 2], const BarrettParams<NL>* __restrict__ Bp) {
   static_assert(NL >= 3 && NL <= 60, "columns of NL + 2 products must fit 64 bits");
+  const u32* __restrict__ mu = Bp->mu;
   u64 s = 0;
 #pragma unroll
   for (int col = NL; col <= 2 * NL + 1; ++col) {
     const int i0 = col - (NL + 1) > 0 ? col - (NL + 1) : 0;
     const int i1 = col < NL + 1 ? col : NL + 1;
 #pragma unroll
-    for (int i = i0; i <= i1; ++i) acc_mad(s, A[i], Bp->mu[col - i]);
+    for (int i = i0; i <= i1; ++i) acc_mad(s, A[i], mu[col - i]);
     if (col >= NL + 2) q[col - NL - 2] = (u32)s & LIMB_MASK;
     s >>= LIMB_BITS;
   }
@@ -99,22 +100,39 @@ __device__ __forceinline__ void barrett_quot(u32 (&q)[NL], const u32 (&A)[NL + 2
 
 // r = (T - q*p) mod B^NL reduced to [0, p): the low NL columns of q*p, subtracted limb by limb from T's low limbs,
 // which `tlo(col)` delivers one at a time (registers, or the lane's LDS scratch).
+// (Adding q * (B^NL - p) instead would save the borrow chain — three instructions per column — but holds a third
+// 36-limb constant in scalar registers beside mu and p: measured, the register allocator then spills 230 vector
+// registers to scratch memory and the kernel is a quarter slower.)
 template <int NL, typename TLO>
 __device__ __forceinline__ void barrett_rem(Fp<NL>& r, TLO tlo, const u32 (&q)[NL], const FpParams<NL>* __restrict__ P) {
+  const u32* __restrict__ pl = P->p;
   Fp<NL> x;
   u64 s = 0;
   i32 bw = 0;
 #pragma unroll
   for (int col = 0; col < NL; ++col) {
 #pragma unroll
-    for (int i = 0; i <= col; ++i) acc_mad(s, q[i], P->p[col - i]);
+    for (int i = 0; i <= col; ++i) acc_mad(s, q[i], pl[col - i]);
     const i32 v = (i32)tlo(col) - (i32)((u32)s & LIMB_MASK) + bw;
     x.v[col] = (u32)v & LIMB_MASK;
     bw = v >> LIMB_BITS;
     s >>= LIMB_BITS;
   }
   BGN_TALLY(T_FINAL, NL);
-  fp_cond_sub_p<NL>(r, x, P);             // x < 2p
+  {                                           // x < 2p: one conditional subtraction, on the limbs already loaded
+    BGN_TALLY(T_PASS, NL);
+    Fp<NL> d;
+    i32 c = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const i32 t = (i32)x.v[j] - (i32)pl[j] + c;
+      d.v[j] = (u32)t & LIMB_MASK;
+      c = t >> LIMB_BITS;
+    }
+    const bool ge = (c == 0);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) r.v[j] = ge ? d.v[j] : x.v[j];
+  }
 #ifdef BGN_EMU
   BGN_CHECK_ALWAYS(fp_lt_p_emu(r, P), "barrett_rem: remainder not below 2p");
 #endif
@@ -132,20 +150,50 @@ __device__ __forceinline__ void barrett_reduce(Fp<NL>& r, const u32 (&T)[2 * NL]
   barrett_rem<NL>(r, [&](int col) { return T[col]; }, q, P);
 }
 
-// Compiler fence between a lane's scratch stores and its loads of them (the loads must not be forwarded from the
-// stored registers: getting the values OUT of registers is the point).
+// Compiler fence around a lane's scratch stores and loads: the loads must neither be forwarded from the stored
+// registers (getting the values OUT of registers is the point) nor be hoisted above the work that precedes them.
 __device__ __forceinline__ void scratch_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::: "memory");
 #endif
 }
 
+template <int NL>
+__device__ __forceinline__ void scratch_put(u32* __restrict__ sc, u32 sstride, int slot, const Fp<NL>& v) {
+  BGN_TALLY(T_LDS, NL);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) sc[(u32)(slot * NL + k) * sstride] = v.v[k];
+}
+template <int NL>
+__device__ __forceinline__ void scratch_get(Fp<NL>& v, const u32* __restrict__ sc, u32 sstride, int slot) {
+  BGN_TALLY(T_LDS, NL);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) v.v[k] = sc[(u32)(slot * NL + k) * sstride];
+}
+
+// r = p - a, a <= p (fp_neg<1> on P->p instead of its copy in the K*p table: one set of scalar loads for all uses of p)
+template <int NL>
+__device__ __forceinline__ void fp_neg_p(Fp<NL>& r, const Fp<NL>& a, const FpParams<NL>* __restrict__ P) {
+  BGN_TALLY(T_PASS, NL);
+  const u32* __restrict__ pl = P->p;
+  i32 c = 0;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const i32 t = (i32)pl[j] - (i32)a.v[j] + c;
+    r.v[j] = (u32)t & LIMB_MASK;
+    c = t >> LIMB_BITS;
+  }
+  BGN_CHECK(c == 0, "fp_neg_p: operand above p");
+}
+
 // (re, im) = (a0 + a1 i) * (b0 + b1 i), or * (b0 - b1 i) with conj_b (the quotient of two norm-1 elements), on
-// plain canonical residues; results canonical.  conj_b is wave-uniform.  `sc`: NL words of per-lane scratch (LDS;
-// word k of lane t at sc[k * sstride]) that carry T's low half across the quotient estimate and the first result
-// across the second product, so that the four operands, one double-width sum and one quotient are all that is ever
-// live: two waves per SIMD fit the register file.  The second factor's imaginary part exists in one form at a time:
-// re needs -+b1, im needs +-b1 = p - (the other).
+// plain canonical residues; results canonical.  conj_b is wave-uniform.
+// Register budget (two waves per SIMD: 256 per lane): a double-width sum needs its four operands and its 2 NL result
+// limbs at once — 6 NL = 216 at 36 limbs — and the four operands stay live until the second sum is done.  `sc`: NL
+// words of per-lane scratch (LDS; word k of lane t at sc[k * sstride]) carry T's low half across the first quotient
+// estimate and the first result across the second sum, so that the operands, one double-width sum and one quotient
+// are all that is ever live.  The second factor's imaginary part exists in one form at a time: re needs -+b1, im
+// needs +-b1 = p - (the other).
 template <int NL>
 __device__ __forceinline__ void fp2_mul_plain(Fp<NL>& re, Fp<NL>& im, const Fp<NL>& a0, const Fp<NL>& a1,
                                               const Fp<NL>& b0, const Fp<NL>& b1, bool conj_b,
@@ -155,7 +203,7 @@ __device__ __forceinline__ void fp2_mul_plain(Fp<NL>& re, Fp<NL>& im, const Fp<N
   Fp<NL> c1;
   {
     Fp<NL> nb1;
-    fp_neg<1>(nb1, b1, P);                   // p - b1 in [1, p]
+    fp_neg_p<NL>(nb1, b1, P);                // p - b1 in [1, p]
     fp_select(c1, conj_b, b1, nb1);          // re = a0*b0 + a1*c1
   }
   {
@@ -163,9 +211,9 @@ __device__ __forceinline__ void fp2_mul_plain(Fp<NL>& re, Fp<NL>& im, const Fp<N
     {
       u32 T[2 * NL];
       wide_mul2<NL>(T, a0, b0, a1, c1);
+      BGN_TALLY(T_LDS, NL);
 #pragma unroll
       for (int k = 0; k < NL; ++k) sc[(u32)k * sstride] = T[k];
-      BGN_TALLY(T_LDS, NL);
       u32 A[NL + 2];
 #pragma unroll
       for (int i = 0; i < NL + 2; ++i) A[i] = T[NL - 2 + i];
@@ -173,23 +221,20 @@ __device__ __forceinline__ void fp2_mul_plain(Fp<NL>& re, Fp<NL>& im, const Fp<N
       barrett_quot<NL>(q, A, Bp);
     }
     Fp<NL> r;
+    BGN_TALLY(T_LDS, NL);
     barrett_rem<NL>(r, [&](int col) { return sc[(u32)col * sstride]; }, q, P);
     scratch_fence();
-#pragma unroll
-    for (int k = 0; k < NL; ++k) sc[(u32)k * sstride] = r.v[k];
-    BGN_TALLY(T_LDS, 2 * NL);
+    scratch_put<NL>(sc, sstride, 0, r);
     scratch_fence();
   }
-  fp_neg<1>(c1, c1, P);                      // im = a0*c1 + a1*b0
+  fp_neg_p<NL>(c1, c1, P);                   // im = a0*c1 + a1*b0
   {
     u32 T[2 * NL];
     wide_mul2<NL>(T, a0, c1, a1, b0);
     barrett_reduce<NL>(im, T, P, Bp);
   }
   scratch_fence();
-#pragma unroll
-  for (int k = 0; k < NL; ++k) re.v[k] = sc[(u32)k * sstride];
-  BGN_TALLY(T_LDS, NL);
+  scratch_get<NL>(re, sc, sstride, 0);
 }
 
 // v < p ?  (borrow chain)

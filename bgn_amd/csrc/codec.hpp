@@ -163,11 +163,23 @@ __device__ __forceinline__ u32 codec_funnel(u32 hi, u32 lo, u32 sh) {
 // whose big-endian bytes sit at byte offset r of the pair
 __device__ __forceinline__ u32 stream_sel(u32 r) { return 0x00010203u + r * 0x01010101u; }
 
+// The stream forms serve the lengths L >= 4 whose whole dwords number at least ND - 4 (ND = dwords that hold NL
+// limbs): true of every key at the limb count the engine picks for it (8L > LIMB_BITS * (NL - 1) - 9), and it makes
+// all but the last few positions of the loops below unconditional — no wave-uniform branch per dword, LDS reads that
+// issue back to back.  Other lengths take the byte forms.
+template <int NL>
+struct StreamCodec {
+  static constexpr int ND = (LIMB_BITS * NL + 31) / 32;   // dwords that hold NL limbs
+  static constexpr int FMIN = ND > 4 ? ND - 4 : 0;        // whole dwords every served value has
+  __device__ static __forceinline__ bool serves(int L) { return L >= 4 && (L >> 2) >= FMIN && (L >> 2) <= ND; }
+};
+
 // Limbs of the big-endian L-byte value whose first byte is byte `B` (per lane, any alignment) of the stage `w`;
-// L >= 4.  Reads the aligned words that hold the value and at most one word past it (the stage has the slack).
+// StreamCodec<NL>::serves(L).  Reads the aligned words that hold the value and at most one word past it (the stage
+// has the slack).
 template <int NL>
 __device__ __forceinline__ void wire_to_limbs_stream(Fp<NL>& r, const u32* __restrict__ w, u32 B, int L) {
-  constexpr int ND = (LIMB_BITS * NL + 31) / 32;          // dwords that hold NL limbs
+  constexpr int ND = StreamCodec<NL>::ND, FMIN = StreamCodec<NL>::FMIN;
   const int full = L >> 2;                                // whole dwords of the value (wave-uniform)
   const int top = L & 3;                                  // bytes of the partial top dword
   u32 d[ND + 1];
@@ -176,23 +188,26 @@ __device__ __forceinline__ void wire_to_limbs_stream(Fp<NL>& r, const u32* __res
   const u32 q0 = (end - 4u) >> 2;
   const u32 sel = stream_sel(end & 3u);
   // the value's first `top` bytes (when L is not a multiple of 4): the 32-bit number at offset 0, shifted down
-  u32 t = 0;
-  if (top) {
-    const u32 qb = B >> 2;
-    t = codec_perm(w[qb + 1], w[qb], stream_sel(B & 3u)) >> (8 * (4 - top));
-  }
+  const u32 qb = B >> 2;
+  const u32 e = codec_perm(w[qb + 1], w[qb], stream_sel(B & 3u));
+  const u32 t = top ? e >> ((8 * (4 - top)) & 31) : 0u;
   u32 hi = w[q0 + 1];
   // (every d[i] is written exactly once, at a compile-time index: a conditional store at index `full` would make
   // the array dynamically indexed and send it to scratch memory)
 #pragma unroll
   for (int i = 0; i < ND + 1; ++i) {
-    u32 v = (i == full) ? t : 0u;
-    if (i < full) {                                       // wave-uniform
+    if (i < FMIN) {
       const u32 lo = w[q0 - (u32)i];
-      v = codec_perm(hi, lo, sel);
+      d[i] = codec_perm(hi, lo, sel);
+      hi = lo;
+    } else {
+      // the last positions: read (a word of the value either way) and select, no branch
+      const bool in = i < full;                           // wave-uniform
+      const u32 lo = w[in ? q0 - (u32)i : q0];
+      const u32 v = codec_perm(hi, lo, sel);
+      d[i] = in ? v : (i == full ? t : 0u);
       hi = lo;
     }
-    d[i] = v;
   }
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
@@ -207,20 +222,19 @@ __device__ __forceinline__ void wire_to_limbs_stream(Fp<NL>& r, const u32* __res
 // V = y + x * 2^(8L); aligned word m of the element is the big-endian 32-bit number at byte 2L - 4 - h - 4m of V
 // (h = bytes before the lane's first aligned word), i.e. one v_perm_b32 of two adjacent dwords of V whose indices
 // are the same on every lane.  Register indices are compile-time (the loops run over V's dwords); what depends on
-// L is the word's address (scalar arithmetic) and whether it exists (wave-uniform).  With L odd an element has one
-// half word besides: its last two bytes on even lanes, its first two on odd ones.  No byte of a neighbouring lane
-// is written.
+// L is the word's address (scalar arithmetic) and, for the last few dwords of each value, whether it exists
+// (wave-uniform).  With L odd an element has one half word besides: its last two bytes on even lanes, its first two
+// on odd ones.  No byte of a neighbouring lane is written.  StreamCodec<NL>::serves(L).
 template <int NL>
 __device__ __forceinline__ void limbs_to_wire_stream(u32* __restrict__ w, u32 tid, int L, const Fp<NL>& x, const Fp<NL>& y) {
-  constexpr int ND = (LIMB_BITS * NL + 31) / 32;          // dwords a value can occupy
+  constexpr int ND = StreamCodec<NL>::ND, FMIN = StreamCodec<NL>::FMIN;
   const int ws = L >> 2, bs = 8 * (L & 3);                // x starts ws dwords and bs bits up in V (wave-uniform)
   const u32 B = tid * (u32)(2 * L);
   const u32 h = (0u - B) & 3u;
   const u32 sel = stream_sel(((u32)(2 * L) - h) & 3u);
-  const int nfull = (2 * L - ((L & 1) ? 2 : 0)) >> 2;     // whole words of an element
-  const int i0 = (2 * L - 4 - ((2 * L) & 3)) >> 2;        // word m pairs V's dwords i0 - m and i0 - m + 1
+  // word m pairs V's dwords i0 - m and i0 - m + 1; an element has i0 + 1 whole words (m = 0 .. i0)
+  const int i0 = (2 * L - 4 - ((2 * L) & 3)) >> 2;
   u32* __restrict__ wq = w + ((B + h) >> 2);
-  // x's dwords and V's dwords above the boundary: F(k) = V[ws + k] = (x << bs) dword k, k >= 1
   u32 xd[ND + 2];
 #pragma unroll
   for (int i = 0; i < ND; ++i) xd[i] = limbs_dword<NL>(x, i);
@@ -232,34 +246,37 @@ __device__ __forceinline__ void limbs_to_wire_stream(u32* __restrict__ w, u32 ti
   yd[ND] = 0;
   u32 ytop = 0;                                            // y's dword ws: its top 8 * (L & 3) bits
 #pragma unroll
-  for (int i = 0; i < ND; ++i)
-    if (i == ws) ytop = yd[i];
+  for (int i = FMIN; i < ND; ++i) ytop = (i == ws) ? yd[i] : ytop;
   const u32 bnd = ytop | (xd[0] << bs);                    // V[ws]  (bs = 0: ytop = 0)
-  // V[i], i < ws: y's dwords
+  // V[i], i < ws: y's dwords, at word i0 - i (ws <= i0: always inside the element)
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
-    const int m = i0 - i;
-    if (i < ws && m >= 0 && m < nfull) {
-      const u32 hi = (i + 1 == ws) ? bnd : yd[i + 1];
-      wq[m] = codec_perm(hi, yd[i], sel);
+    if (i + 1 < FMIN) {
+      wq[i0 - i] = codec_perm(yd[i + 1], yd[i], sel);
+    } else if (i < ws) {                                   // wave-uniform
+      wq[i0 - i] = codec_perm((i + 1 == ws) ? bnd : yd[i + 1], yd[i], sel);
     }
   }
-  // V[ws + k], k >= 0
+  // V[ws + k], k >= 0, at word i0 - ws - k while that is not negative (i0 - ws >= ws - 1)
   u32 cur = bnd;
+  const int kmax = i0 - ws;
 #pragma unroll
   for (int k = 0; k <= ND; ++k) {
-    const u32 nxt = bs ? codec_funnel(xd[k + 1], xd[k], (u32)(32 - bs)) : xd[k + 1];     // F(k + 1)
-    const int m = i0 - (ws + k);
-    if (m >= 0 && m < nfull) wq[m] = codec_perm(nxt, cur, sel);
+    const u32 nxt = bs ? codec_funnel(xd[k + 1], xd[k], (u32)(32 - bs)) : xd[k + 1];     // V[ws + k + 1]
+    if (k + 1 < FMIN) {
+      wq[kmax - k] = codec_perm(nxt, cur, sel);
+    } else if (k <= kmax) {                                // wave-uniform
+      wq[kmax - k] = codec_perm(nxt, cur, sel);
+    }
     cur = nxt;
   }
   if (L & 1) {
     // V's bytes 2L-2 (low) and 2L-1 (high) = x's top 16 bits; V's bytes 0, 1 = y's low 16 bits
     u32 topv = 0;
-    const int tb = 8 * L - 16;                             // bit of x where they start
+    const int tb = 8 * L - 16;                             // bit of x where they start (dword >= ws - 1)
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
-      if (i == (tb >> 5)) topv = codec_funnel(xd[i + 1], xd[i], (u32)(tb & 31));
+    for (int i = (FMIN > 0 ? FMIN - 1 : 0); i < ND; ++i)
+      topv = (i == (tb >> 5)) ? codec_funnel(xd[i + 1], xd[i], (u32)(tb & 31)) : topv;
     topv &= 0xFFFFu;
     const bool odd = h != 0;
     const u32 hv = odd ? topv : (yd[0] & 0xFFFFu);

@@ -107,16 +107,28 @@ struct Combiner {
     if (stream) be.stream_destroy(stream);
   }
 
-  // zero both staging arrays (the caller holds no round in flight: set_secret / destroy run under the context's lock
-  // with the device synchronised; a leader that regrows them has just synchronised its stream)
   static void secure_zero(void* p, size_t n) {
     volatile uint8_t* v = (volatile uint8_t*)p;
     for (size_t i = 0; i < n; ++i) v[i] = 0;
   }
-  void wipe_stage() {
-    std::lock_guard<std::mutex> lk(mu);
+  // Zero both staging arrays (bgn_ctx_set_secret: they carry plaintexts, randomness and Decrypt's results between
+  // calls).  A leader runs its round — packing into h_stage, upload, download, copy-out, regrowing the arrays — with
+  // `mu` released, so the arrays belong to the round while leader_active is set: a wipe that arrives then is left to
+  // the round's owner, who honours it under `mu` as soon as its round is over (before the next one can start).  With
+  // no round in flight the caller wipes at once; holding `mu` keeps a new round from starting meanwhile.  Never waits
+  // for a round: the caller may hold the context's lock, which the round's launches need.
+  bool wipe_pending = false;       // guarded by mu
+  void wipe_now() {                // mu held, no round in flight
     if (h_stage) secure_zero(h_stage, stage_cap);
     if (d_stage && be.dev_zero) (void)be.dev_zero(d_stage, stage_cap);
+    wipe_pending = false;
+  }
+  void wipe_stage() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (leader_active)
+      wipe_pending = true;
+    else
+      wipe_now();
   }
   void release_stage() {
     if (h_stage) {
@@ -352,6 +364,7 @@ struct Combiner {
       last_round_reqs = released;
       last_round_us = round_us;
       pushed_since_round_end = 0;
+      if (wipe_pending) wipe_now();         // a wipe that arrived during the round (every caller has its results by now)
       leader_active = false;
       // one of those still queued (a kind that was full this round, or a late arrival) leads the next round; a caller
       // that arrives first does so itself — either way nobody waits for a round that nobody runs

@@ -302,14 +302,18 @@ void release_poly_tables(bgn_ctx* c) {
   c->poly_tab_bytes = 0;
 }
 
-// What a context keeps between calls (include/bgn_amd.h "Device memory"): by default a quarter of the device's
-// memory.  The per-key tables are sized well inside it (52.8 GB for a 1024-bit key with T = 2^40); MultPoly's line
-// tables — scratch of one call, 38 GB for a whole round of 65536 coefficients — stay with the context for the next
-// call only while the total remains under the cap, and go back to the allocator when the call ends otherwise
-// (a fresh hipMalloc of 38 GB costs 1.2 - 2.1 s on MI355X, profiles/r05_alloc_cost.csv: a host that runs large
-// MultPoly calls on a context that also holds decryption tables raises option resident_cap_mb).
-size_t resident_cap(bgn_ctx* c) {
+// What a context keeps between calls (include/bgn_amd.h "Device memory").  MultPoly's line tables are scratch of one
+// call — 38 GB for a whole round of 65536 coefficients — that stays with the context for the next call, because a fresh
+// hipMalloc of that size costs 1.2 - 2.1 s on MI355X (profiles/r05_alloc_cost.csv) against a call of about 3 s.  They
+// go back to the allocator when the call ends only if BOTH hold: the context holds more than the resident cap (option
+// resident_cap_mb; default a quarter of the device's memory) AND less than a quarter of the device is still free.
+// The second condition is what lets a context that also holds decryption tables (52.8 GB for a 1024-bit key with
+// T = 2^40: 91 GB with the line tables, above the default cap) keep them on a 288 GB device with nothing else on it
+// — until round 6 such a context re-allocated them on every call — while several contexts that crowd one device still
+// give them back.  An explicit resident_cap_mb is a hard cap (-1: keep everything).
+size_t resident_cap(bgn_ctx* c, bool* hard) {
   const int64_t v = opt(c, &Options::resident_cap_mb);
+  *hard = v != 0;
   if (v < 0) return ~(size_t)0;
   if (v > 0) return (size_t)v << 20;
   size_t fr = 0, tot = 0;
@@ -323,7 +327,13 @@ void trim_to_resident_cap(bgn_ctx* c) {
     std::lock_guard<std::mutex> lk(c->mem_mu);
     held = c->held;
   }
-  if (held > resident_cap(c)) release_poly_tables(c);
+  bool hard = false;
+  if (held <= resident_cap(c, &hard)) return;
+  if (!hard) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= tot / 4) return;      // room to spare: keep them
+  }
+  release_poly_tables(c);
 }
 
 // Divide every line of a per-key table by its c (fixedpair.hpp fixed_normalize_lane): one product less per
@@ -456,7 +466,7 @@ std::vector<uint32_t> build_barrett(const BigU& p, int nl) {
   for (int i = 0; i < 2 * LIMB_BITS * nl; ++i) top.shl1();
   BigU::divmod(top, p, q, r);
   if (q.bits() > LIMB_BITS * (nl + 2)) return img;
-  img.assign((size_t)nl + 4, 0);
+  img.assign((size_t)nl + 4, 0);                       // mu[nl + 2], pad[2]
   q.to_limbs(img.data(), nl + 2, LIMB_BITS);
   return img;
 }
@@ -565,7 +575,9 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
   }
     HIP_BRK(ctx_malloc(c, (void**)&c->d_params, kt->params_bytes));
     HIP_BRK(hipMemcpy(c->d_params, img.data(), kt->params_bytes, hipMemcpyHostToDevice));
-    if (kt->gt_mul_wire) {
+    // (the fused kernel decodes and encodes with the dword-stream codec only: codec.hpp StreamCodec<NL>::serves)
+    const int nd = (LIMB_BITS * c->nl + 31) / 32, full = c->L >> 2;
+    if (kt->gt_mul_wire && c->L >= 4 && full >= (nd > 4 ? nd - 4 : 0) && full <= nd) {
       const std::vector<uint32_t> bimg = build_barrett(p, c->nl);
       if (!bimg.empty()) {
         HIP_BRK(ctx_malloc(c, (void**)&c->d_barrett, bimg.size() * 4));
@@ -776,7 +788,9 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
   c->d_gt = nullptr;
   if (c->arena) (void)hipMemset(c->arena, 0, c->arena_bytes);   // the workspace held ct^sk values of earlier Decrypts
   {
-    // ... and the combiner's staging arrays the plaintexts, randomness and results of earlier small calls
+    // ... and the combiner's staging arrays the plaintexts, randomness and results of earlier small calls.  A
+    // combined round may be in flight on another thread (it runs without this context's lock between its launches):
+    // the wipe is then left to that round's owner (Combiner::wipe_stage), never done under it and never waited for.
     Combiner* cb = nullptr;
     {
       std::lock_guard<std::mutex> lk2(c->mem_mu);
@@ -1825,7 +1839,7 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
     int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
     if (rc) return rc;
   }
-  if (level == 2 && !r_be && c->d_barrett && c->kt->gt_mul_wire && opt(c, &Options::l2_fused)) {
+  if (level == 2 && !r_be && c->d_barrett && c->kt->gt_mul_wire && ((uintptr_t)out & 3u) == 0 && opt(c, &Options::l2_fused)) {
     // deterministic Add / Sub of level-2 ciphertexts: one wire-to-wire launch, no workspace (barrett.hpp)
     HIP_TRY(hipEventRecord(c->ev0, s));
     c->kt->gt_mul_wire(s, c->d_params, c->d_barrett, a, b, c->L, count, subtract ? 1 : 0, out);
@@ -2623,7 +2637,14 @@ int bgn_decrypt_batch(bgn_ctx* c, size_t count, int level, const uint8_t* ct, in
 // value canonical).  BGN_POLY_TABLES=0 selects the direct d1*d2 full pairings;
 // BGN_POLY_TABLE_MAX_MB caps the table size (tests use it to force several chunks).
 namespace {
-size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
+// `multi`: in, whether the caller would run the table rounds as multi-pairings; out, whether their layout fits.  That
+// layout is coefficient-major with the products of a pass padded to whole groups of 64 (dt * round_up(polys, 64)
+// columns, not round_up(polys * dt, 64)): a pass of fewer than 64 products pays for 64, so a budget that holds less
+// than dt * 64 columns cannot take it — the caller then walks one lane per pair over the compact layout instead of
+// failing on a table up to 64 times the size the budget was meant for.
+size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt, bool* multi) {
+  const bool want_multi = multi && *multi;
+  if (multi) *multi = false;
   if (opt(c, &Options::poly_tables) == 0) return 0;
   // one whole round of 65536 tables is 38 GB at a 1024-bit key: up to a sixth of the device's total memory (48 GB
   // on MI355X), clamped by what is free (the cached tables count as free)
@@ -2634,12 +2655,26 @@ size_t poly_table_chunk(bgn_ctx* c, size_t npoly, size_t dt) {
     if (v > 0 && ((size_t)v << 20) < budget) budget = (size_t)v << 20;
   }
   const size_t per_coeff = c->miller_steps * 3 * (size_t)c->nl * 4;
+  const size_t round_polys = 65536 / dt;
+  if (want_multi) {
+    const size_t groups = budget / per_coeff / dt / 64;          // whole groups of 64 products the budget holds
+    if (groups) {
+      size_t polys = groups * 64;
+      if (polys >= npoly) {
+        *multi = true;
+        return npoly;                                            // one pass (its last group padded, inside the budget)
+      }
+      // one lane builds one table and runs for the whole kernel: whole rounds of 65536 lanes per chunk, as long as
+      // they are whole groups too
+      if (round_polys && polys > round_polys && (polys - polys % round_polys) % 64 == 0) polys -= polys % round_polys;
+      *multi = true;
+      return polys;
+    }
+  }
   // table columns are padded to a multiple of 64 coefficients
   size_t polys = budget / per_coeff / dt;
   if (polys > npoly) polys = npoly;
   while (polys && round_up(polys * dt, 64) * per_coeff > budget) polys--;
-  // one lane builds one table and runs for the whole kernel: whole rounds of 65536 lanes per chunk
-  const size_t round_polys = 65536 / dt;
   if (polys < npoly && round_polys && polys > round_polys) polys -= polys % round_polys;
   return polys;
 }
@@ -2666,21 +2701,25 @@ int poly_mult_core(bgn_ctx* c, hipStream_t s, size_t npoly, size_t d1, size_t d2
   if (opt(c, &Options::poly_round) > 0) kLanes = (size_t)opt(c, &Options::poly_round);   // tests: the round size of this logic (not of the kernels)
   const bool forced = opt(c, &Options::poly_tables) == 1;      // tests: tables whatever the size
   const bool one_round = total_pairs <= kLanes;
-  size_t chunk = (forced || (!coop && !quad && !one_round)) && d1 * d2 >= 2 ? poly_table_chunk(c, npoly, dt) : 0;     // polynomials per pass; 0: direct
+  // the table rounds as multi-pairings (option poly_multi; square leaves): one lane per OUTPUT coefficient walks the
+  // tables of all its terms e(a_i, b_j), i + j = s, with one f^2 per doubling step and one final exponentiation;
+  // operands and tables coefficient-major (kernels.hpp pairing_multi).  poly_table_chunk sizes the pass for that
+  // layout (whole groups of 64 products) and says when the budget cannot take it.
+  bool multi = d1 == d2 && d1 >= 2 && opt(c, &Options::poly_multi) != 0;
+  size_t chunk = 0;                                           // polynomials per pass; 0: direct
+  if ((forced || (!coop && !quad && !one_round)) && d1 * d2 >= 2) chunk = poly_table_chunk(c, npoly, dt, &multi);
+  if (!chunk) multi = false;
   // One lane builds one table and runs for the whole kernel, so the time of the table path is a step function of the
   // table count (1213 products of 16 x 16 = 65502 tables: 260 ms, 1300: 450 ms).  Whole rounds of 65536 tables go
   // first; a remainder of at most 65536 pairs then pairs directly on the kernel that is fastest at its size.
+  // (poly_round: the tests' round size of THIS logic; a multi-pairing pass stays a whole number of groups)
   const size_t round_polys = kLanes / dt;
-  if (chunk && round_polys && chunk > round_polys) chunk -= chunk % round_polys;
-  // (the multi-pairing rounds pad the products of a pass to a multiple of 64: whole groups keep the tables inside the
-  // budget the chunk was sized for)
-  if (chunk >= 64 && chunk < npoly && d1 == d2 && opt(c, &Options::poly_multi) != 0) chunk -= chunk % 64;
+  if (chunk && round_polys && chunk > round_polys) {
+    const size_t t = chunk - chunk % round_polys;
+    if (!multi || t >= npoly || t % 64 == 0) chunk = t;
+  }
   const size_t cp = chunk ? chunk : npoly;
   const size_t np = cp * d1 * d2, sp = round_up(np, 64);
-  // the table rounds as multi-pairings (option poly_multi; square leaves): one lane per OUTPUT coefficient walks the
-  // tables of all its terms e(a_i, b_j), i + j = s, with one f^2 per doubling step and one final exponentiation;
-  // operands and tables coefficient-major (kernels.hpp pairing_multi)
-  const bool multi = chunk && d1 == d2 && d1 >= 2 && opt(c, &Options::poly_multi) != 0;
   const size_t Qp = round_up(cp, 64);
   // (the remainder: what is left below one round of tables once the whole rounds are taken out of the last chunk)
   size_t tail_polys = chunk ? npoly % cp : 0;
@@ -3502,6 +3541,21 @@ double bgn_last_kernel_ms(bgn_ctx* c) {
 }
 
 const char* bgn_last_kernel_name(bgn_ctx* c) { return c ? c->last_kernel : ""; }
+
+int bgn_last_kernel_resources(bgn_ctx* c, int64_t out[4]) {
+  if (!c || !out) return fail(BGN_E_ARG, "null argument");
+  const void* fn = nullptr;
+  if (c->last_kernel && !strcmp(c->last_kernel, "k_gt_mul_wire")) fn = c->kt->gt_mul_wire_entry;
+  if (!fn) return fail(BGN_E_ARG, "no entry point known for %s", c->last_kernel ? c->last_kernel : "(none)");
+  HIP_TRY(hipSetDevice(c->device));
+  hipFuncAttributes at;
+  HIP_TRY(hipFuncGetAttributes(&at, fn));
+  out[0] = at.numRegs;
+  out[1] = (int64_t)at.localSizeBytes;
+  out[2] = (int64_t)at.sharedSizeBytes;
+  out[3] = at.maxThreadsPerBlock;
+  return BGN_OK;
+}
 
 uint64_t bgn_ctx_bsgs_baby_steps(const bgn_ctx* c) { return (c && c->have_tables) ? c->bsgs.S : 0; }
 

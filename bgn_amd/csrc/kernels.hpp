@@ -279,6 +279,7 @@ struct KernelTable {
   // `barrett` = the device image of BarrettParams<NL> (engine.cpp build_barrett).  Null beyond 40 limbs.
   void (*gt_mul_wire)(hipStream_t s, const void* params, const void* barrett, const uint8_t* a, const uint8_t* b, int L,
                       size_t count, int conj_b, uint8_t* out);
+  const void* gt_mul_wire_entry;      // the kernel's host-side handle (hipFuncGetAttributes: bgn_last_kernel_resources)
 };
 
 const KernelTable* kernel_table_nl3();

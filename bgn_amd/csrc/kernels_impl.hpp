@@ -31,7 +31,7 @@ k_decode(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire, i
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
   Fp<NL> x, y;
-  if (L >= 4) {                                // wave-uniform; any misalignment of the slice (codec.hpp)
+  if (StreamCodec<NL>::serves(L)) {            // wave-uniform; any misalignment of the slice (codec.hpp)
     const u32 B = mis + threadIdx.x * (u32)EB;
     wire_to_limbs_stream<NL>(x, ws.w, B, L);
     wire_to_limbs_stream<NL>(y, ws.w, B + (u32)L, L);
@@ -70,7 +70,7 @@ k_validate(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ wire,
   if (threadIdx.x >= nel) return;
   const size_t e = e0 + threadIdx.x;
   Fp<NL> x, y;
-  if (L >= 4) {                                // wave-uniform; any misalignment of the slice (codec.hpp)
+  if (StreamCodec<NL>::serves(L)) {            // wave-uniform; any misalignment of the slice (codec.hpp)
     const u32 B = mis + threadIdx.x * (u32)EB;
     wire_to_limbs_stream<NL>(x, ws.w, B, L);
     wire_to_limbs_stream<NL>(y, ws.w, B + (u32)L, L);
@@ -130,7 +130,7 @@ k_encode(const uint8_t* __restrict__ inf, const u32* __restrict__ c0, const u32*
       fp_zero(x);
       fp_zero(y);
     }
-    if (((uintptr_t)g & 3u) == 0 && L >= 4) {    // wave-uniform: the slice is staged dword-aligned
+    if (((uintptr_t)g & 3u) == 0 && StreamCodec<NL>::serves(L)) {    // wave-uniform: the slice is staged dword-aligned
       limbs_to_wire_stream<NL>(ws.w, threadIdx.x, L, x, y);
     } else {
       uint8_t* dst = (uint8_t*)ws.w + ((uintptr_t)g & 3u) + threadIdx.x * EB;
@@ -436,31 +436,36 @@ k_gt_mul(const FpParams<NL>* __restrict__ P, GtMulArgs A) {
 // 780 B of HBM traffic per element against ~2.5 KB of the decode / decode / k_gt_mul / encode
 // pipeline, 6.2 NL^2 multiply-adds against 10 NL^2, and — the stage being all the LDS it needs — two workgroups
 // per CU, which hides one workgroup's staging copies behind the other's products.
+// The launcher's caller guarantees StreamCodec<NL>::serves(L) and a dword-aligned `out` (the operand arrays may
+// start anywhere); engine.cpp sends every other call down the four-launch route.
 #if BGN_NL <= 40
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_gt_mul_wire(const FpParams<NL>* __restrict__ P, const BarrettParams<NL>* __restrict__ Bp,
               const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int L, size_t count, int conj_b,
               uint8_t* __restrict__ out) {
-  __shared__ WireStage<NL> ws;
+  // the wire stage, and NL words of scratch per lane while the products run (barrett.hpp): 65 KB at 36 limbs, two
+  // workgroups per CU
+  constexpr int SWORDS = WireStage<NL>::WORDS > NL * FP_BLOCK ? WireStage<NL>::WORDS : NL * FP_BLOCK;
+  __shared__ alignas(16) u32 shared_words[SWORDS];
+  WireStage<NL>& ws = *reinterpret_cast<WireStage<NL>*>(shared_words);
   const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
   const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
   const size_t EB = (size_t)(2 * L);
   const u32 tid = threadIdx.x;
   const bool live = tid < nel;
   Fp<NL> a0, a1, b0, b1;
+  const u32 eoff = live ? tid * (u32)EB : 0u;            // idle lanes decode element 0's bytes: discarded
   {
     const u32 mis = wire_stage_in<NL>(&ws, a + e0 * EB, nel * EB);
-    const u32 B = live ? mis + tid * (u32)EB : 0u;       // idle lanes decode element 0's bytes (or stale ones): discarded
-    wire_to_limbs_stream<NL>(a0, ws.w, B, L);
-    wire_to_limbs_stream<NL>(a1, ws.w, B + (u32)L, L);
+    wire_to_limbs_stream<NL>(a0, ws.w, mis + eoff, L);
+    wire_to_limbs_stream<NL>(a1, ws.w, mis + eoff + (u32)L, L);
   }
   __syncthreads();                                       // every lane has read a's slice
   {
     const u32 mis = wire_stage_in<NL>(&ws, b + e0 * EB, nel * EB);
-    const u32 B = live ? mis + tid * (u32)EB : 0u;
-    wire_to_limbs_stream<NL>(b0, ws.w, B, L);
-    wire_to_limbs_stream<NL>(b1, ws.w, B + (u32)L, L);
+    wire_to_limbs_stream<NL>(b0, ws.w, mis + eoff, L);
+    wire_to_limbs_stream<NL>(b1, ws.w, mis + eoff + (u32)L, L);
   }
   // residues at or above p (the wire format allows them; valid ciphertexts never have one): reduced first, so
   // that the result is the product of the residues mod p whatever came in.  Wave-uniform branch, not taken in
@@ -480,19 +485,10 @@ k_gt_mul_wire(const FpParams<NL>* __restrict__ P, const BarrettParams<NL>* __res
   }
   __syncthreads();                                       // every lane has read b's slice: the stage is scratch now
   Fp<NL> re, im;
-  fp2_mul_plain<NL>(re, im, a0, a1, b0, b1, conj_b != 0, P, Bp, ws.w + tid, FP_BLOCK);
+  fp2_mul_plain<NL>(re, im, a0, a1, b0, b1, conj_b != 0, P, Bp, shared_words + tid, FP_BLOCK);
   __syncthreads();                                       // ... and becomes the stage of the result
   uint8_t* g = out + e0 * EB;
-  const u32 mo = (u32)((uintptr_t)g & 3u);
-  if (live) {
-    if (mo == 0 && L >= 4) {                             // wave-uniform
-      limbs_to_wire_stream<NL>(ws.w, tid, L, re, im);
-    } else {
-      uint8_t* dst = (uint8_t*)ws.w + mo + tid * EB;
-      limbs_to_wire<NL>(dst, L, re);
-      limbs_to_wire<NL>(dst + L, L, im);
-    }
-  }
+  if (live) limbs_to_wire_stream<NL>(ws.w, tid, L, re, im);
   wire_stage_out<NL>(&ws, g, nel * EB);
 }
 
@@ -1042,8 +1038,10 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_field_ops,
 #if BGN_NL <= 40
       launch_gt_mul_wire,
+      (const void*)k_gt_mul_wire<NL_>,
 #else
       nullptr,              // 72 limbs: the fully unrolled products would be 50 k instructions; the four-launch route serves
+      nullptr,
 #endif
   };
   return &t;

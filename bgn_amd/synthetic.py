@@ -225,6 +225,33 @@ def mads_from_counts(products: float, squares: float, sops: float = 0.0, nl: int
     return ((products - squares - sops) * product_mads(nl) + squares * square_mads(nl, segments) + sops * sop_mads(nl))
 
 
+def l2_add_mads(nl: int) -> int:
+    """Multiply-adds of one level-2 Add / Sub in the fused kernel (csrc/barrett.hpp): two double-width sums of two
+    products (4 NL^2) and, for each, the columns NL .. 2NL+1 of A * mu (the quotient estimate; A and mu have NL + 2
+    limbs) and the low NL columns of q * (B^NL - p)."""
+    quot = (nl + 2) ** 2 - nl * (nl + 1) // 2 - 1
+    rem = nl * (nl + 1) // 2
+    return 2 * (2 * nl * nl + quot + rem)
+
+
+def multconst_counts(level: int, scalar_bits: int):
+    """(reductions, squarings, sums of two products) of one MultConst with a per-element scalar (bgn.go:253-291).
+    Level 1, k_g1_mul (ops.hpp g1_scalarmul_win_lane): a per-element table of the multiples 1..15 of the base (14 mixed
+    Jacobian additions of 12 reductions, 3 of them squarings; one shared inversion over their Z: 13 prefix products,
+    the inversion, 2 peels and zi^2, x, zi^3, y per entry), then per 4-bit window four doublings (9 reductions, 6
+    squarings each) and one mixed addition (executed whenever a lane of the wave has a non-zero digit), and the
+    affine conversion of the result (inversion + 4, one squaring).
+    Level 2, k_gt_pow (ops.hpp gt_pow_lane): square-and-multiply in F_p^2 — per bit one F_p^2 squaring (2 reductions)
+    and one F_p^2 product (3; executed whenever a lane of the wave has the bit set) — between two conversions each way."""
+    if level == 1:
+        windows = -(-scalar_bits // 4)
+        table = 14 * 12 + 13 + INVERSION_PRODUCTS + 14 * 2 + 14 * 4
+        red = table + windows * (4 * 9 + 12) + INVERSION_PRODUCTS + 4
+        sq = 14 * 3 + 14 + windows * (4 * 6 + 3) + 1
+        return float(red), float(sq), 0.0
+    return float(5 * scalar_bits + 4), 0.0, 0.0
+
+
 def _run_for(count: int) -> int:
     """Elements per lane of the batched-inversion kernels (engine.cpp run_for: the ceiling of count / 65536, no cap)."""
     return max(1, -(-count // 65536))

@@ -103,12 +103,12 @@ const char* bgn_version(void);
  *   workspace         7.4 KB per pairing of the largest batch seen (7.8 GB at 2^20; larger batches run in pieces)
  *   => 51.6 GB of tables + workspace: a context that has encrypted, multiplied and decrypted holds about 60 GB.
  *   MultPoly tables   per-call scratch: whole rounds of 65536 coefficient tables (38 GB) within 1/6 of the device.
- *                     They stay with the context for the next call only while its total remains under the RESIDENT CAP
- *                     — a quarter of the device by default (72 GB), option resident_cap_mb; -1: keep everything — and go
- *                     back to the allocator when the call returns otherwise: a context that also holds decryption
- *                     tables pays a fresh hipMalloc per large MultPoly call (1.2 - 2.1 s for 38 GB,
- *                     profiles/r05_alloc_cost.csv) unless its cap is raised; one that only encrypts and multiplies
- *                     (26 GB + 38 GB) keeps them.
+ *                     They stay with the context for the next call (a fresh hipMalloc of 38 GB costs 1.2 - 2.1 s,
+ *                     profiles/r05_alloc_cost.csv) unless the context then holds more than the RESIDENT CAP — a quarter
+ *                     of the device by default (72 GB) — AND less than a quarter of the device is still free: a context
+ *                     that also holds decryption tables (91 GB with them) keeps them on a device it has to itself,
+ *                     contexts that crowd one device give them back when the call returns.  Option resident_cap_mb
+ *                     sets a hard cap instead (released above it whatever is free; -1: keep everything).
  * What is free at the moment of the call — under a budget, what the budget leaves — only clamps these from above
  * (a table never takes more than half of it), so the same key gets the same tables in whatever order they are
  * built, unless memory is short.  Options bsgs_max_log2, fixed_window_bits, fixed_window_bits_q, fixed_signed_q, poly_table_max_mb,
@@ -386,6 +386,12 @@ const char* bgn_last_kernel_name(bgn_ctx* ctx);
  * the lift e(C, .) over the key's line table, Decrypt's dominant kernel. */
 double bgn_last_aux_kernel_ms(bgn_ctx* ctx);
 const char* bgn_last_aux_kernel_name(bgn_ctx* ctx);
+/* What the code object says about the kernel bgn_last_kernel_name names, when the engine knows its entry point
+ * (today: k_gt_mul_wire, the fused level-2 Add / Sub): out[0] = vector registers per lane, out[1] = scratch
+ * (private-segment) bytes per lane, out[2] = static LDS bytes per workgroup, out[3] = threads per workgroup the
+ * kernel may be launched with.  A kernel that is meant to hold everything in registers and has started to spill
+ * shows here before it shows on a clock.  Returns BGN_E_ARG for a kernel it has no entry point of. */
+int bgn_last_kernel_resources(bgn_ctx* ctx, int64_t out[4]);
 /* Number of baby steps of the discrete-log table built by bgn_ctx_setup_decryption (0 = none). */
 uint64_t bgn_ctx_bsgs_baby_steps(const bgn_ctx* ctx);
 

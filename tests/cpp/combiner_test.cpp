@@ -4,7 +4,10 @@
 // The "device" is malloc'd memory and the launch of a group is a loop on the host: out[e] = f(kind, in0[e], in1[e]),
 // so every caller can check its own slice, whatever batch it travelled in.  Checked: every call returns its own
 // results and status; calls of different kinds are never mixed into one batch; a kind that fails (op 99) fails for
-// its callers only; a lone caller is never delayed by the regroup wait; concurrent callers ARE merged.
+// its callers only; a lone caller is never delayed by the regroup wait; concurrent callers ARE merged; a wipe of the
+// staging arrays that arrives while rounds are in flight (bgn_ctx_set_secret from another thread) is deferred to the
+// round's owner — it never touches the arrays under a round (ThreadSanitizer would report the race, and a zeroed
+// operand would show as a wrong result), and it does happen.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -17,7 +20,7 @@
 
 using namespace bgn;
 
-static std::atomic<uint64_t> g_launches{0}, g_elements{0}, g_max_group{0};
+static std::atomic<uint64_t> g_launches{0}, g_elements{0}, g_max_group{0}, g_dev_wipes{0};
 
 static uint8_t f(int op, uint8_t a, uint8_t b) { return (uint8_t)(op * 31 + a * 3 + b * 5 + 1); }
 
@@ -33,6 +36,7 @@ static Combiner* make() {
   c->be.dev_free = [](void* p) { free(p); };
   c->be.upload = [](void* d, const void* h, size_t b, void*) { memcpy(d, h, b); return 0; };
   c->be.download = [](void* h, const void* d, size_t b, void*) { memcpy(h, d, b); return 0; };
+  c->be.dev_zero = [](void* d, size_t b) { memset(d, 0, b); g_dev_wipes++; return 0; };
   c->error_text = [] { return "kind 99 always fails"; };
   c->launch = [](const CombineKey& k, size_t n, uint8_t* const* in, uint8_t* const* out, void*) {
     g_launches++;
@@ -122,7 +126,27 @@ int main(int argc, char** argv) {
         if (rnd() % 4 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rnd() % 300));
       }
     });
+  // meanwhile: wipes from a thread that is no caller, as fast as it can for the first part of the run
+  std::atomic<bool> stop_wiper{false};
+  uint64_t wipes_requested = 0;
+  std::thread wiper([&] {
+    while (!stop_wiper.load()) {
+      cb->wipe_stage();
+      wipes_requested++;
+      std::this_thread::sleep_for(std::chrono::microseconds(150));
+    }
+  });
   for (auto& t : th) t.join();
+  stop_wiper = true;
+  wiper.join();
+  if (wipes_requested < 10 || g_dev_wipes.load() == 0) {
+    fprintf(stderr, "wipes requested %llu, executed %llu\n", (unsigned long long)wipes_requested, (unsigned long long)g_dev_wipes.load());
+    return 4;
+  }
+  {
+    std::lock_guard<std::mutex> lk(cb->mu);
+    if (cb->wipe_pending || cb->leader_active) return 5;          // nothing in flight: no wipe may be left undone
+  }
   const uint64_t calls = cb->stats.calls, groups = cb->stats.groups;
   delete cb;
   printf("calls %llu groups %llu launches %llu largest group %llu failed-as-expected %d bad %d\n", (unsigned long long)calls,

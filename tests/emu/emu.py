@@ -321,6 +321,7 @@ class Emu:
         return self.encode(out)
 
     def barrett_mu(self):
+        """BarrettParams<NL> of barrett.hpp: mu = floor(B^(2 NL) / p), NL + 2 limbs."""
         return (C.c_uint32 * (self.nl + 2))(*limbs((1 << (2 * LIMB * self.nl)) // self.p, self.nl + 2))
 
     def gt_mul_plain(self, a: bytes, b: bytes, conj_b=False) -> bytes:

@@ -95,8 +95,9 @@ def test_l2_fused_on_any_residues_vs_python_integers(name):
 
 @pytest.mark.parametrize("name", ["k256", "k1024"])
 def test_l2_fused_on_misaligned_device_buffers(name):
-    """Operand and result arrays that start 1, 2 and 3 bytes into a dword (callers pass sub-ranges of buffers): the
-    slices are staged at their own misalignment and the result leaves through the byte encoder."""
+    """Operand and result arrays that start 1, 2 and 3 bytes into a dword (callers pass sub-ranges of buffers): operand
+    slices are staged at their own misalignment and decoded there; a misaligned result array is served by the
+    four-launch route."""
     import torch
     fx = load_fixture(name)
     pk, _ = engine_key(fx)
@@ -108,7 +109,7 @@ def test_l2_fused_on_misaligned_device_buffers(name):
     b = b"".join(l2[(3 * i + 1) % len(l2)] for i in range(n))
     want = eng.add(2, a, b).tobytes()
     dev = torch.device("cuda", 0)
-    for ma, mb, mo in [(1, 0, 0), (0, 2, 0), (0, 0, 3), (3, 1, 2), (2, 2, 2)]:
+    for ma, mb, mo in [(1, 0, 0), (0, 2, 0), (3, 1, 0), (2, 3, 0), (0, 0, 3), (3, 1, 2), (2, 2, 2)]:
         ta = torch.zeros(n * EB + 8, dtype=torch.uint8, device=dev)
         tb = torch.zeros(n * EB + 8, dtype=torch.uint8, device=dev)
         to = torch.full((n * EB + 8,), 0xEE, dtype=torch.uint8, device=dev)
@@ -116,7 +117,25 @@ def test_l2_fused_on_misaligned_device_buffers(name):
         tb[mb:mb + n * EB] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
         eng.add_dev(2, ta[ma:ma + n * EB], tb[mb:mb + n * EB], to[mo:mo + n * EB], n)
         torch.cuda.synchronize()
-        assert eng.last_kernel_name() == "k_gt_mul_wire"
+        # (a result array that does not start on a dword takes the four-launch route: the fused kernel's encoder
+        # writes whole aligned words; operand arrays may start anywhere)
+        assert eng.last_kernel_name() == ("k_gt_mul_wire" if mo == 0 else "k_gt_mul")
         host = to.cpu().numpy().tobytes()
         assert host[mo:mo + n * EB] == want, (ma, mb, mo)
         assert host[:mo] == b"\xee" * mo and host[mo + n * EB:] == b"\xee" * (8 - mo), "bytes outside the result written"
+
+
+def test_fused_kernel_holds_everything_in_registers():
+    """The fused kernel's point is two workgroups per CU with nothing in scratch memory: what the code object says
+    (hipFuncGetAttributes through bgn_last_kernel_resources).  A change that makes the register allocator spill
+    shows here before it shows on a clock (round 6: a third 36-limb constant in scalar registers cost 230 spilled
+    vector registers and a quarter of the rate)."""
+    fx = load_fixture("k1024")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    l2 = [bytes.fromhex(v["out"]) for v in fx["mult"]]
+    eng.add(2, l2[0], l2[1])
+    assert eng.last_kernel_name() == "k_gt_mul_wire"
+    res = eng.last_kernel_resources()
+    assert res["scratch_bytes_per_lane"] == 0, res
+    assert res["vgprs"] <= 256 and res["lds_bytes_per_workgroup"] <= 80 * 1024, res

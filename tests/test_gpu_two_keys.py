@@ -129,8 +129,10 @@ def test_default_footprint_one_key_after_encrypt_decrypt_multpoly_and_two_keys_w
     assert st.tolist() == [0] * len(ms) and m.tolist() == ms
     after_decrypt = eng.memory_bytes()
     assert after_decrypt <= 62 * GB, after_decrypt
-    # MultPoly over line tables: 38 GB of scratch beside 53 GB of tables is above the resident cap (a quarter of
-    # the device): the tables are there during the call and gone after it
+    # MultPoly over line tables: 38 GB of scratch beside 53 GB of tables is above a resident cap of a quarter of the
+    # device.  Set as a HARD cap (the default keeps them while a quarter of the device is free, below): the tables are
+    # there during the call and gone after it
+    eng.set_option("resident_cap_mb", 72 * 1024)
     out = torch.empty(npoly * 2 * d * EB, dtype=torch.uint8, device=dev)
     eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
     torch.cuda.synchronize()
@@ -152,10 +154,21 @@ def test_default_footprint_one_key_after_encrypt_decrypt_multpoly_and_two_keys_w
     eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
     torch.cuda.synchronize()
     assert eng.memory_bytes() > held + 20 * GB        # (the tables of one chunk: 26 - 38 GB, by what is free)
+    # the default: above the cap the tables stay only while a quarter of the device is still free — a Decrypt-capable
+    # context alone on a 288 GB device keeps them (no 1.2 - 2.1 s hipMalloc per call), crowded contexts give them back
     eng.set_option("resident_cap_mb", 0)
     eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
     torch.cuda.synchronize()
+    free, tot = torch.cuda.mem_get_info()
+    if free >= tot // 4:
+        assert eng.memory_bytes() > held + 20 * GB, (eng.memory_bytes(), free, tot)
+    else:
+        assert eng.memory_bytes() <= 64 * GB, (eng.memory_bytes(), free, tot)
+    eng.set_option("resident_cap_mb", 72 * 1024)
+    eng.poly_mult_dev(npoly, d, d, cts[: npoly * d * EB], cts[npoly * d * EB:], out)
+    torch.cuda.synchronize()
     assert eng.memory_bytes() <= 64 * GB
+    eng.set_option("resident_cap_mb", 0)
     # a second key beside it, no budget call anywhere: the same table sizes
     fx2 = load_fixture("k1024b")
     pk2, sk2 = fresh_key(fx2)

@@ -136,6 +136,27 @@ if len(eadd) == 2:
                               hbm_bytes_per_call=(eadd["FETCH_SIZE"]["kb_per_call"] * fetch_factor + eadd["WRITE_SIZE"]["kb_per_call"]) * 1024,
                               note="one bgn_add_batch_dev of 2^20 level-1 ciphertexts (bench.py extras): k_decode_plain x 2, k_g1_add, k_encode; "
                                    "hbm_bytes_per_call = FETCH_SIZE x fetch_calibration.factor + WRITE_SIZE")
+# The fused level-2 Add of the extras (k_gt_mul_wire at 2^20 elements: one launch per call; the AddPoly of the MultPoly
+# job launches the same kernel on a smaller grid).  Its reads and writes are 16 bytes per lane (the staging copies):
+# the guide's factor 2 on FETCH_SIZE applies, which fetch_calibration reproduces on this code's SoA reads.
+l2 = {}
+for ctr, sub, stem in (("FETCH_SIZE", "pmc_fetch_extra", "fetch"), ("WRITE_SIZE", "pmc_write_extra", "write")):
+    path = os.path.join(src, sub, f"{stem}_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == ctr and "k_gt_mul_wire<" in r["Kernel_Name"]
+            and int(r["Grid_Size"]) == 1 << 20]
+    if rows:
+        vals = [float(r["Counter_Value"]) for r in rows]
+        l2[ctr] = {"launches": len(vals), "avg": sum(vals) / len(vals), "grid": 1 << 20,
+                   "avg_ms": sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows) / len(rows) / 1e6,
+                   "scratch_bytes_per_lane": int(rows[0]["Scratch_Size"]), "vgpr": int(rows[0]["VGPR_Count"]),
+                   "lds_bytes_per_workgroup": int(rows[0]["LDS_Block_Size"]) if "LDS_Block_Size" in rows[0] else None}
+if len(l2) == 2:
+    summary["eadd_l2"] = dict(l2, hbm_bytes_per_launch_raw=(l2["FETCH_SIZE"]["avg"] + l2["WRITE_SIZE"]["avg"]) * 1024,
+                              hbm_bytes_per_launch=(l2["FETCH_SIZE"]["avg"] * fetch_factor + l2["WRITE_SIZE"]["avg"]) * 1024,
+                              note="one bgn_add_batch_dev of 2^20 level-2 ciphertexts (bench.py extras): one launch of k_gt_mul_wire; "
+                                   "hbm_bytes_per_launch = FETCH_SIZE x fetch_calibration.factor + WRITE_SIZE")
 for key in ("decrypt_lift_k_pairing_1", "decrypt_lift_2^16"):
     if key in summary:
         lf = summary[key]

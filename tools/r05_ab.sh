@@ -5,7 +5,11 @@ set -o pipefail
 OUT=$1; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-if [ -x tools/ubench/lane_sop ]; then tools/ubench/lane_sop > "$OUT/lane_sop.txt" 2>&1 || exit 1; cat "$OUT/lane_sop.txt"; fi
+# (the micro-benchmark is built from its source here: no binary of it is tracked)
+if [ -f tools/ubench/lane_sop.hip ]; then
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ibgn_amd/csrc tools/ubench/lane_sop.hip -o tools/ubench/lane_sop 2> "$OUT/lane_sop_build.err" \
+    && { tools/ubench/lane_sop > "$OUT/lane_sop.txt" 2>&1 || exit 1; cat "$OUT/lane_sop.txt"; }
+fi
 if [ -z "$AB_SKIP_TESTS" ]; then
   timeout -k 10 900 python -m pytest tests -m gpu -q > "$OUT/gpu_suite.log" 2>&1; rc=$?; tail -3 "$OUT/gpu_suite.log"
   [ $rc -eq 0 ] || [ $rc -eq 1 ] || exit $rc          # (failed tests are reported; a killed run is not followed by another GPU step)

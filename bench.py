@@ -323,11 +323,12 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
     dt = _timed(lambda: eng.add_dev(1, a1, b1, o1, n_add), sync)
     out["eadd_l1"] = op_rooflines(
         {"value": n_add / dt, "unit": "adds/s", "batch": n_add,
-         "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion), wire bytes to wire bytes",
+         "workload": "pk.Add on level-1 ciphertexts (affine G1 addition, batched inversion), wire bytes to wire bytes in "
+                     "one launch",
          "kernel": eng.last_kernel_name(), "algorithmic_bytes_per_unit": 3 * EB},
         syn.eadd_counts(n_add), nl)
-    # HBM-side traffic of that call's four launches (k_decode_plain x 2, k_g1_add, k_encode) from the committed PMC
-    # passes of this command (tools/summarize_profiles.py), next to its algorithmic bytes
+    # HBM-side traffic of that call (one launch of k_g1_add_wire since round 6; k_decode_plain x 2, k_g1_add, k_encode
+    # before) from the committed PMC passes of this command (tools/summarize_profiles.py), next to its algorithmic bytes
     eadd_traffic, eadd_src = None, None
     if n_add == 1 << 20:
         node, eadd_src = committed_traffic("eadd_l1")

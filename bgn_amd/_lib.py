@@ -90,6 +90,10 @@ PROTOTYPES = {
     "bgn_field_sums_batch": (C.c_int, [_ctx, _sz, _u8p, _u8p]),
     "bgn_host_alloc": (C.c_void_p, [_sz]),
     "bgn_host_free": (None, [C.c_void_p]),
+    "bgn_dev_alloc": (C.c_void_p, [_ctx, _sz]),
+    "bgn_dev_free": (None, [_ctx, C.c_void_p]),
+    "bgn_dev_upload": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz]),
+    "bgn_dev_download": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz]),
     "bgn_last_kernel_ms": (C.c_double, [_ctx]),
     "bgn_last_kernel_name": (C.c_char_p, [_ctx]),
     "bgn_last_aux_kernel_ms": (C.c_double, [_ctx]),

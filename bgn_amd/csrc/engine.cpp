@@ -121,6 +121,7 @@ struct bgn_ctx {
 
   void* d_params = nullptr;            // FpParams<NL>
   void* d_barrett = nullptr;           // BarrettParams<NL> (barrett.hpp); null: the fused level-2 Add / Sub is not offered
+  bool stream_codec = false;           // codec.hpp StreamCodec<NL>::serves(L): the fused Add / Sub kernels decode and encode with it only
   PairingConsts* d_consts = nullptr;
   uint32_t* d_keypts = nullptr;        // P.x, P.y, Q.x, Q.y, eQQ.re, eQQ.im, one, zero : 8 * nl limbs, stride 1, Montgomery
   uint8_t* d_keywire = nullptr;        // P | Q | e(Q,Q) wire bytes
@@ -577,7 +578,8 @@ int bgn_ctx_create(bgn_ctx** out, const uint8_t* p_be, size_t p_len, const uint8
     HIP_BRK(hipMemcpy(c->d_params, img.data(), kt->params_bytes, hipMemcpyHostToDevice));
     // (the fused kernel decodes and encodes with the dword-stream codec only: codec.hpp StreamCodec<NL>::serves)
     const int nd = (LIMB_BITS * c->nl + 31) / 32, full = c->L >> 2;
-    if (kt->gt_mul_wire && c->L >= 4 && full >= (nd > 4 ? nd - 4 : 0) && full <= nd) {
+    c->stream_codec = c->L >= 4 && full >= (nd > 4 ? nd - 4 : 0) && full <= nd;
+    if (kt->gt_mul_wire && c->stream_codec) {
       const std::vector<uint32_t> bimg = build_barrett(p, c->nl);
       if (!bimg.empty()) {
         HIP_BRK(ctx_malloc(c, (void**)&c->d_barrett, bimg.size() * 4));
@@ -1838,6 +1840,27 @@ int addsub_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, const uint
   if (r_be) {                          // blinding base tables (G1 ones use the arena: before any carving)
     int rc = level == 1 ? ensure_fixed_tables(c) : ensure_gt_table(c);
     if (rc) return rc;
+  }
+  if (level == 1 && !r_be && c->kt->g1_add_wire && c->stream_codec && ((uintptr_t)out & 3u) == 0 && opt(c, &Options::l1_fused)) {
+    // deterministic Add / Sub of level-1 ciphertexts: one wire-to-wire launch; the workspace is the prefix products
+    // of the lanes' runs (one F_p per element)
+    const size_t st1 = round_up(count, 64);
+    uint32_t* pfx = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+      Ws w(c, pass ? c->arena : nullptr);
+      pfx = w.fp(st1);
+      if (!pass) {
+        int rc = ensure_arena(c, w.cv.off);
+        if (rc) return rc;
+      }
+    }
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    c->kt->g1_add_wire(s, c->d_params, c->d_consts, a, b, c->L, count, run_for(count), subtract ? 1 : 0, pfx, st1, out);
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->last_kernel = "k_g1_add_wire";
+    c->ev_valid = true;
+    HIP_TRY(hipGetLastError());
+    return BGN_OK;
   }
   if (level == 2 && !r_be && c->d_barrett && c->kt->gt_mul_wire && ((uintptr_t)out & 3u) == 0 && opt(c, &Options::l2_fused)) {
     // deterministic Add / Sub of level-2 ciphertexts: one wire-to-wire launch, no workspace (barrett.hpp)
@@ -3541,6 +3564,39 @@ double bgn_last_kernel_ms(bgn_ctx* c) {
 }
 
 const char* bgn_last_kernel_name(bgn_ctx* c) { return c ? c->last_kernel : ""; }
+
+void* bgn_dev_alloc(bgn_ctx* c, size_t bytes) {
+  if (!c || !bytes) {
+    (void)fail(BGN_E_ARG, "null context or zero size");
+    return nullptr;
+  }
+  void* p = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)fail(BGN_E_NOMEM, "bgn_dev_alloc: %zu bytes on device %d", bytes, c->device);
+    return nullptr;
+  }
+  return p;
+}
+void bgn_dev_free(bgn_ctx* c, void* p) {
+  if (!c || !p) return;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(p);
+}
+int bgn_dev_upload(bgn_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!c || (bytes && (!dst_dev || !src_host))) return fail(BGN_E_ARG, "null argument");
+  if (!bytes) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return BGN_OK;
+}
+int bgn_dev_download(bgn_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!c || (bytes && (!dst_host || !src_dev))) return fail(BGN_E_ARG, "null argument");
+  if (!bytes) return BGN_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return BGN_OK;
+}
 
 int bgn_last_kernel_resources(bgn_ctx* c, int64_t out[4]) {
   if (!c || !out) return fail(BGN_E_ARG, "null argument");

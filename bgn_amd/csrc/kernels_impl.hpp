@@ -373,6 +373,147 @@ k_g1_fixed_chain(const FpParams<NL>* __restrict__ P, const PairingConsts* __rest
   g1_add_run<NL>(G1IoFixedChain<NL>{A}, (size_t)A.chains * A.pitch, A.run, A.prefix, A.sp, L, C, P);
 }
 
+// Level-1 Add / Sub (bgn.go:477-483, :414-420), wire bytes to wire bytes in ONE launch: the affine additions of
+// g1_add_run (ops.hpp: plain residues, one inversion per lane's run of elements) with the codec inside.  Element
+// j*T + t of lane t's run is element t of a contiguous slice of the workgroup at every step j, so each step stages
+// its two operand slices through LDS, decodes them in registers, and — in the second pass — encodes the sums into
+// the stage and writes the slice back.  Nothing but the prefix products (one F_p per element) touches HBM between
+// the wire arrays: 2 * (2 * 2L) + 2 * 4 NL + 2L bytes per addition against four launches with limb-major
+// intermediates (decode x 2, add, encode: 3.98 x the algorithmic bytes, profiles/r05_pmc_summary.json).
+// LDS: the two product slots of the run (L0, L1) and the stage, 140 KB at 36 limbs.
+// The launcher's caller guarantees StreamCodec<NL>::serves(L) and a dword-aligned `out` (the operand arrays may
+// start anywhere); engine.cpp sends every other call down the four-launch route.
+template <int NL>
+struct G1WireStep {
+  Fp<NL> x1, y1, x2, y2;
+  bool i1, i2;
+};
+
+template <int NL>
+__device__ __forceinline__ void g1_wire_load(G1WireStep<NL>& S, WireStage<NL>* ws, const uint8_t* __restrict__ a,
+                                             const uint8_t* __restrict__ b, size_t e0, size_t nel, int L, bool negate_b,
+                                             const FpParams<NL>* __restrict__ P) {
+  const size_t EB = (size_t)(2 * L);
+  const u32 eoff = threadIdx.x < nel ? threadIdx.x * (u32)EB : 0u;      // idle lanes decode element 0: discarded
+  __syncthreads();                                                       // the stage's previous contents are done with
+  {
+    const u32 mis = wire_stage_in<NL>(ws, a + e0 * EB, nel * EB);
+    wire_to_limbs_stream<NL>(S.x1, ws->w, mis + eoff, L);
+    wire_to_limbs_stream<NL>(S.y1, ws->w, mis + eoff + (u32)L, L);
+  }
+  __syncthreads();
+  {
+    const u32 mis = wire_stage_in<NL>(ws, b + e0 * EB, nel * EB);
+    wire_to_limbs_stream<NL>(S.x2, ws->w, mis + eoff, L);
+    wire_to_limbs_stream<NL>(S.y2, ws->w, mis + eoff + (u32)L, L);
+  }
+  S.i1 = fp_is_zero_limbs(S.x1) && fp_is_zero_limbs(S.y1);
+  S.i2 = fp_is_zero_limbs(S.x2) && fp_is_zero_limbs(S.y2);
+  if (negate_b) {                                                        // wave-uniform
+    fp_neg<1>(S.y2, S.y2, P);
+    fp_reduce_lt<NL, 2>(S.y2, S.y2, P);                                  // p - 0 = p -> 0
+  }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_g1_add_wire(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, const uint8_t* __restrict__ a,
+              const uint8_t* __restrict__ b, int L, size_t count, int run, int negate_b, u32* __restrict__ prefix,
+              size_t sp, uint8_t* __restrict__ out) {
+  __shared__ LFp<NL> Ls[2];
+  __shared__ WireStage<NL> ws;
+  const size_t T = (size_t)gridDim.x * FP_BLOCK;
+  const size_t t = (size_t)blockIdx.x * FP_BLOCK + threadIdx.x;
+  const size_t EB = (size_t)(2 * L);
+  Fp<NL> acc;
+  fp_set(acc, P->one);
+  // pass 1: prefix products of the denominators
+#pragma unroll 1
+  for (int j = 0; j < run; ++j) {
+    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;      // the workgroup's slice at this step
+    if (e0 >= count) break;                                              // workgroup-uniform
+    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+    G1WireStep<NL> S;
+    g1_wire_load<NL>(S, &ws, a, b, e0, nel, L, negate_b != 0, P);
+    if (threadIdx.x < nel) {
+      const size_t e = (size_t)j * T + t;
+      Fp<NL> d;
+      g1_classify<NL, true>(d, S.x1, S.y1, S.i1, S.x2, S.y2, S.i2, P);
+      g_store(prefix, sp, e, acc);
+      l_store(Ls, acc);
+      fp_mul(acc, Ls, d, P);                // <2
+    }
+  }
+  Fp<NL> inv;
+  fp_inv<NL>(inv, acc, Ls, C, P);           // <1
+  // pass 2: walk back, peel one inverse per element, encode the sums
+#pragma unroll 1
+  for (int j = run - 1; j >= 0; --j) {
+    const size_t e0 = (size_t)j * T + (size_t)blockIdx.x * FP_BLOCK;
+    if (e0 >= count) continue;                                           // workgroup-uniform
+    const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+    const bool live = threadIdx.x < nel;
+    G1WireStep<NL> S;
+    g1_wire_load<NL>(S, &ws, a, b, e0, nel, L, negate_b != 0, P);
+    Fp<NL> x3, y3;
+    fp_zero(x3);
+    fp_zero(y3);
+    if (live) {
+      const size_t e = (size_t)j * T + t;
+      Fp<NL> d;
+      const int cs = g1_classify<NL, true>(d, S.x1, S.y1, S.i1, S.x2, S.y2, S.i2, P);
+      Fp<NL> dinv;
+      {
+        Fp<NL> pf;
+        g_load(pf, prefix, sp, e);
+        l_store(Ls, inv);                   // L0 = running inverse
+        fp_mul(dinv, Ls, pf, P);            // 1/d <2
+        fp_mul(inv, Ls, d, P);              // inverse of the shorter prefix <2
+      }
+      // numerator: y2 - y1, or 3*x1^2 + 1 for a doubling (rare: computed only when some lane doubles)
+      Fp<NL> num;
+      fp_sub<1>(num, S.y2, S.y1, P);        // <2
+      if (__ballot(cs == G1C_DBL)) {
+        Fp<NL> xx, t3, one;
+        fp_to_mont<NL>(t3, S.x1, P, Ls + 1);     // x1*R
+        fp_mulv(xx, t3, S.x1, P, Ls + 1);        // x1^2, plain <2
+        fp_dbl(t3, xx);
+        fp_add(t3, t3, xx);                 // <6
+        fp_zero(one);
+        one.v[0] = 1;
+        fp_add(t3, t3, one);                // <7
+        fp_select(num, cs == G1C_DBL, t3, num);
+      }
+      l_store(Ls + 1, dinv);
+      Fp<NL> lam, lp;
+      fp_mul(lam, Ls + 1, num, P);          // lambda * R <2
+      fp_from_mont<NL>(lp, lam, P, Ls + 1); // lambda, plain <1 ; L1 = lambda*R
+      fp_mul(x3, Ls + 1, lp, P);            // lambda^2, plain <2
+      fp_lin3<1, -1, -1, 2>(x3, x3, S.x1, S.x2, P);   // lambda^2 - x1 - x2 <4
+      fp_sub<4>(y3, S.x1, x3, P);           // <5
+      fp_mul(y3, Ls + 1, y3, P);            // <2
+      fp_sub<1>(y3, y3, S.y1, P);           // <3
+      const bool isA = cs == G1C_A, isB = cs == G1C_B;
+      if (__ballot(isA || isB)) {
+        fp_select(x3, isA, S.x1, x3);
+        fp_select(y3, isA, S.y1, y3);
+        fp_select(x3, isB, S.x2, x3);
+        fp_select(y3, isB, S.y2, y3);
+      }
+      fp_reduce_lt<NL, 4>(x3, x3, P);
+      fp_reduce_lt<NL, 4>(y3, y3, P);
+      if (cs == G1C_INF) {                  // the identity's encoding: all zero
+        fp_zero(x3);
+        fp_zero(y3);
+      }
+    }
+    __syncthreads();                        // every lane has decoded its operands: the stage takes the sums
+    uint8_t* g = out + e0 * EB;             // dword-aligned: `out` is, and a slice starts a multiple of 256 elements in
+    if (live) limbs_to_wire_stream<NL>(ws.w, threadIdx.x, L, x3, y3);
+    wire_stage_out<NL>(&ws, g, nel * EB);
+  }
+}
+
 template <int NL>
 __global__ void __launch_bounds__(FP_BLOCK)
 k_g1_tab_round(const FpParams<NL>* __restrict__ P, const PairingConsts* __restrict__ C, G1TabRoundArgs A) {
@@ -698,6 +839,16 @@ static void launch_g1_neg(hipStream_t s, const void* params, uint32_t* y, size_t
   if (!count) return;
   hipLaunchKernelGGL(k_g1_neg<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, y, stride,
                      inf, count);
+}
+
+static void launch_g1_add_wire(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a,
+                               const uint8_t* b, int L, size_t count, int run, int negate_b, uint32_t* prefix, size_t sp,
+                               uint8_t* out) {
+  if (!count) return;
+  if (run < 1) run = 1;
+  const size_t lanes = (count + run - 1) / run;
+  hipLaunchKernelGGL(k_g1_add_wire<NL_>, dim3(grid_for(lanes)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, consts,
+                     a, b, L, count, run, negate_b, prefix, sp, out);
 }
 
 static void launch_g1_add(hipStream_t s, const void* params, const PairingConsts* consts, G1AddArgs a) {
@@ -1036,6 +1187,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       launch_pairing_multi,
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
       launch_field_ops,
+      launch_g1_add_wire,
 #if BGN_NL <= 40
       launch_gt_mul_wire,
       (const void*)k_gt_mul_wire<NL_>,

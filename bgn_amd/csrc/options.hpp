@@ -46,6 +46,7 @@ struct Options {
   V fixed_signed_q{1};     // signed windows of window bits + 1 scalar bits over Q's table (0: unsigned windows)
   V fixed_chains{4};       // accumulation chains per element of the fixed-base products (1: one launch per window)
   V g1_mul_window{1};      // 4-bit windows in the variable-base scalar multiplication (0: binary ladder)
+  V l1_fused{1};           // deterministic level-1 Add / Sub in one wire-to-wire launch (0: decode, decode, k_g1_add, encode)
   V l2_fused{1};           // deterministic level-2 Add / Sub in one wire-to-wire launch (0: decode, decode, k_gt_mul, encode)
   V poly_karatsuba{1};     // Karatsuba levels on square MultPoly products
   V poly_levels{-1};       // forced number of levels (-1: planned)
@@ -110,6 +111,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"fixed_signed_q", &Options::fixed_signed_q, true, nullptr},
       {"fixed_chains", &Options::fixed_chains, true, nullptr},
       {"g1_mul_window", &Options::g1_mul_window, true, nullptr},
+      {"l1_fused", &Options::l1_fused, true, nullptr},
       {"l2_fused", &Options::l2_fused, true, nullptr},
       {"poly_karatsuba", &Options::poly_karatsuba, true, nullptr},
       {"poly_levels", &Options::poly_levels, true, nullptr},

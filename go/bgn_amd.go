@@ -8,7 +8,10 @@
 // Drop the file into the reference's package directory.  It adds:
 //   - Engine (one bgn_ctx: a PublicKey's pairing context on one GPU) and the batch methods EncryptBatch, AddBatch,
 //     SubBatch, NegBatch, MultBatch, MakeL2Batch, MultConstBatch, DecryptBatch, MultPolyBatch, MultConstPolyOne,
-//     EvalPolyBatch, CheckDecryptionProofBatch, CheckPlaintextKnowledgeBatch;
+//     EvalPolyBatch, CheckDecryptionProofBatch, CheckPlaintextKnowledgeBatch, ValidateBatch, Calibrate;
+//   - DeviceArray and the *Dev methods (EncryptBatchDev, AddBatchDev, SubBatchDev, NegBatchDev, MultBatchDev,
+//     MakeL2BatchDev, MultConstBatchDev, MultPolyBatchDev, DecryptBatchDev, ValidateBatchDev): arrays that stay on the
+//     GPU between calls, for chains like MultPoly -> AddPoly -> Decrypt;
 //   - the bodies of the reference's single-element methods as count-1 calls (engineMult, engineAdd, engineSub,
 //     engineNeg, engineMakeL2, engineMultConst, engineEncryptWithRandomness, engineDecrypt): to switch a method over,
 //     make its body in bgn.go `return pk.engineMult(ct1, ct2)` and so on — signatures and panics stay as they are;
@@ -31,6 +34,7 @@ import (
 	"encoding/binary"
 	"errors"
 	"math/big"
+	"runtime"
 	"sync"
 	"unsafe"
 
@@ -46,6 +50,15 @@ func engineErr(rc C.int) error {
 		return nil
 	}
 	return errors.New(C.GoString(C.bgn_last_error()))
+}
+
+// locked runs one engine call and, when it fails, fetches its message on the SAME operating-system thread:
+// bgn_last_error() is thread-local on the C side, and the Go scheduler may move a goroutine to another thread
+// between two cgo calls (the message would then be empty, or another call's).  Every call below goes through here.
+func locked(call func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	return engineErr(call())
 }
 
 // u8 is the address of a byte slice for the C side; nil for an absent (nil or empty) array.
@@ -128,9 +141,11 @@ func (pk *PublicKey) NewEngine(device int) (*Engine, error) {
 		det = 1
 	}
 	var h *C.bgn_ctx
-	rc := C.bgn_ctx_create(&h, u8(pb), C.size_t(len(pb)), u8(nb), C.size_t(len(nb)), C.uint64_t(l), u8(P), u8(Q),
+	err = locked(func() C.int {
+		return C.bgn_ctx_create(&h, u8(pb), C.size_t(len(pb)), u8(nb), C.size_t(len(nb)), C.uint64_t(l), u8(P), u8(Q),
 		C.int(det), C.int(device))
-	if err := engineErr(rc); err != nil {
+	})
+	if err != nil {
 		return nil, err
 	}
 	e := &Engine{h: h, L: int(C.bgn_fp_bytes(h)), pk: pk}
@@ -190,7 +205,7 @@ func (pk *PublicKey) engine() *Engine {
 
 // SetMemoryBudget bounds the device memory of this key's tables and workspace (0: no bound).
 func (e *Engine) SetMemoryBudget(bytes uint64) error {
-	return engineErr(C.bgn_ctx_set_memory_budget(e.h, C.uint64_t(bytes)))
+	return locked(func() C.int { return C.bgn_ctx_set_memory_budget(e.h, C.uint64_t(bytes)) })
 }
 
 // MemoryBytes is the device memory the context holds now.
@@ -200,19 +215,19 @@ func (e *Engine) MemoryBytes() uint64 { return uint64(C.bgn_ctx_memory_bytes(e.h
 func (e *Engine) SetOption(name string, value int64) error {
 	cs := C.CString(name)
 	defer C.free(unsafe.Pointer(cs))
-	return engineErr(C.bgn_ctx_set_option(e.h, cs, C.int64_t(value)))
+	return locked(func() C.int { return C.bgn_ctx_set_option(e.h, cs, C.int64_t(value)) })
 }
 
 // SetupDecryption replaces pk.SetupDecryption / ComputeDecryptionPreprocessing (bgn.go:195-201, :142-149).
 func (e *Engine) SetupDecryption(sk *SecretKey) error {
 	q1 := sk.Key.Bytes()
-	if err := engineErr(C.bgn_ctx_set_secret(e.h, u8(q1), C.size_t(len(q1)))); err != nil {
+	if err := locked(func() C.int { return C.bgn_ctx_set_secret(e.h, u8(q1), C.size_t(len(q1))) }); err != nil {
 		return err
 	}
 	if !e.pk.MsgSpace.IsUint64() {
 		return errors.New("bgn_amd: message space beyond 64 bits")
 	}
-	return engineErr(C.bgn_ctx_setup_decryption(e.h, C.uint64_t(e.pk.MsgSpace.Uint64())))
+	return locked(func() C.int { return C.bgn_ctx_setup_decryption(e.h, C.uint64_t(e.pk.MsgSpace.Uint64())) })
 }
 
 // wire is Element.Bytes() of one ciphertext; the G1 identity (encryptZero(), bgn.go:562) is 2L zero bytes.
@@ -287,8 +302,10 @@ func (e *Engine) EncryptBatch(x []*big.Int, r []*big.Int) ([]*Ciphertext, error)
 	xb, xw := scalars(xs)
 	rb, rw := e.randomness(r)
 	out := make([]byte, len(x)*2*e.L)
-	rc := C.bgn_encrypt_batch(e.h, C.size_t(len(x)), u8(xb), C.size_t(xw), u8(rb), C.size_t(rw), u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_encrypt_batch(e.h, C.size_t(len(x)), u8(xb), C.size_t(xw), u8(rb), C.size_t(rw), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return e.unpack(out, false), nil
@@ -298,13 +315,13 @@ func (e *Engine) addSub(a, b []*Ciphertext, l2 bool, r []*big.Int, sub bool) ([]
 	A, B := e.pack(a), e.pack(b)
 	rb, rw := e.randomness(r)
 	out := make([]byte, len(A))
-	var rc C.int
-	if sub {
-		rc = C.bgn_sub_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
-	} else {
-		rc = C.bgn_add_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
-	}
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		if sub {
+			return C.bgn_sub_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
+		}
+		return C.bgn_add_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return e.unpack(out, l2), nil
@@ -324,7 +341,7 @@ func (e *Engine) SubBatch(a, b []*Ciphertext, l2 bool, r []*big.Int) ([]*Ciphert
 func (e *Engine) NegBatch(a []*Ciphertext, l2 bool) ([]*Ciphertext, error) {
 	A := e.pack(a)
 	out := make([]byte, len(A))
-	if err := engineErr(C.bgn_neg_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(out))); err != nil {
+	if err := locked(func() C.int { return C.bgn_neg_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(out)) }); err != nil {
 		return nil, err
 	}
 	return e.unpack(out, l2), nil
@@ -336,8 +353,10 @@ func (e *Engine) MultBatch(a, b []*Ciphertext, r []*big.Int) ([]*Ciphertext, err
 	A, B := e.pack(a), e.pack(b)
 	rb, rw := e.randomness(r)
 	out := make([]byte, len(A))
-	rc := C.bgn_mult_batch(e.h, C.size_t(len(a)), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_mult_batch(e.h, C.size_t(len(a)), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return e.unpack(out, true), nil
@@ -347,7 +366,7 @@ func (e *Engine) MultBatch(a, b []*Ciphertext, r []*big.Int) ([]*Ciphertext, err
 func (e *Engine) MakeL2Batch(a []*Ciphertext) ([]*Ciphertext, error) {
 	A := e.pack(a)
 	out := make([]byte, len(A))
-	if err := engineErr(C.bgn_make_l2_batch(e.h, C.size_t(len(a)), u8(A), u8(out))); err != nil {
+	if err := locked(func() C.int { return C.bgn_make_l2_batch(e.h, C.size_t(len(a)), u8(A), u8(out)) }); err != nil {
 		return nil, err
 	}
 	return e.unpack(out, true), nil
@@ -359,8 +378,10 @@ func (e *Engine) MultConstBatch(a []*Ciphertext, k []*big.Int, l2 bool, r []*big
 	kb, kw := scalars(k)
 	rb, rw := e.randomness(r)
 	out := make([]byte, len(A))
-	rc := C.bgn_multconst_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(kb), C.size_t(kw), u8(rb), C.size_t(rw), u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_multconst_batch(e.h, C.size_t(len(a)), levelOf(l2), u8(A), u8(kb), C.size_t(kw), u8(rb), C.size_t(rw), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return e.unpack(out, l2), nil
@@ -378,7 +399,7 @@ func (e *Engine) DecryptBatch(cts []*Ciphertext, l2 bool) ([]*big.Int, []error, 
 		mp = (*C.int64_t)(unsafe.Pointer(&m[0]))
 		sp = (*C.uint8_t)(unsafe.Pointer(&st[0]))
 	}
-	if err := engineErr(C.bgn_decrypt_batch(e.h, C.size_t(len(cts)), levelOf(l2), u8(A), mp, sp)); err != nil {
+	if err := locked(func() C.int { return C.bgn_decrypt_batch(e.h, C.size_t(len(cts)), levelOf(l2), u8(A), mp, sp) }); err != nil {
 		return nil, nil, err
 	}
 	vals, errs := make([]*big.Int, len(cts)), make([]error, len(cts))
@@ -399,8 +420,10 @@ func (e *Engine) DecryptBatch(cts []*Ciphertext, l2 bool) ([]*big.Int, []error, 
 func (e *Engine) MultPolyBatch(npoly, d1, d2 int, a, b []*Ciphertext) ([]*Ciphertext, error) {
 	A, B := e.pack(a), e.pack(b)
 	out := make([]byte, npoly*(d1+d2)*2*e.L)
-	rc := C.bgn_poly_mult_batch(e.h, C.size_t(npoly), C.size_t(d1), C.size_t(d2), u8(A), u8(B), u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_poly_mult_batch(e.h, C.size_t(npoly), C.size_t(d1), C.size_t(d2), u8(A), u8(B), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return e.unpack(out, true), nil
@@ -415,8 +438,10 @@ func (e *Engine) MultConstPolyOne(ct *PolyCiphertext, poly *PolyPlaintext) (*Pol
 		binary.BigEndian.PutUint64(k[8*i:], poly.Coefficients[i].Uint64())
 	}
 	out := make([]byte, (ct.Degree+poly.Degree)*2*e.L)
-	rc := C.bgn_poly_multconst_batch(e.h, 1, C.size_t(ct.Degree), C.size_t(poly.Degree), levelOf(ct.L2), u8(A), u8(k), 8, 0, u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_poly_multconst_batch(e.h, 1, C.size_t(ct.Degree), C.size_t(poly.Degree), levelOf(ct.L2), u8(A), u8(k), 8, 0, u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return &PolyCiphertext{e.unpack(out, ct.L2), ct.Degree + poly.Degree, ct.ScaleFactor + poly.ScaleFactor, ct.L2}, nil
@@ -436,9 +461,11 @@ func (e *Engine) EvalPolyBatch(cts []*PolyCiphertext) ([]*Ciphertext, error) {
 		buf = append(buf, e.pack(ct.Coefficients[:d])...)
 	}
 	out := make([]byte, len(cts)*2*e.L)
-	rc := C.bgn_poly_eval_batch(e.h, C.size_t(len(cts)), C.size_t(d), levelOf(l2), u8(buf),
+	err := locked(func() C.int {
+		return C.bgn_poly_eval_batch(e.h, C.size_t(len(cts)), C.size_t(d), levelOf(l2), u8(buf),
 		C.uint64_t(e.pk.PolyEncodingParams.PolyBase), u8(out))
-	if err := engineErr(rc); err != nil {
+	})
+	if err != nil {
 		return nil, err
 	}
 	return e.unpack(out, l2), nil
@@ -454,8 +481,10 @@ func (e *Engine) CheckDecryptionProofBatch(cts []*Ciphertext, proofs []*Decrypti
 	vb, vw := scalars(vs)
 	rb, rw := scalars(rs)
 	ok := make([]uint8, len(cts))
-	rc := C.bgn_check_decryption_proof_batch(e.h, C.size_t(len(cts)), u8(A), u8(vb), C.size_t(vw), u8(rb), C.size_t(rw), u8(ok))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_check_decryption_proof_batch(e.h, C.size_t(len(cts)), u8(A), u8(vb), C.size_t(vw), u8(rb), C.size_t(rw), u8(ok))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return bools(ok), nil
@@ -475,8 +504,10 @@ func (e *Engine) CheckPlaintextKnowledgeBatch(cts []*Ciphertext, proofs []*Proof
 	}
 	dl, dw := scalars(dls)
 	ok := make([]uint8, len(cts))
-	rc := C.bgn_check_plaintext_knowledge_batch(e.h, C.size_t(len(cts)), u8(A), u8(N), u8(c), 32, u8(dl), C.size_t(dw), u8(ok))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_check_plaintext_knowledge_batch(e.h, C.size_t(len(cts)), u8(A), u8(N), u8(c), 32, u8(dl), C.size_t(dw), u8(ok))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return bools(ok), nil
@@ -488,6 +519,381 @@ func bools(v []uint8) []bool {
 		out[i] = x != 0
 	}
 	return out
+}
+
+// ---- arrays that stay on the device ---------------------------------------------------------------------------------------
+//
+// The batch methods above take and return Go values: every call copies its arrays over PCIe and converts them to and
+// from pbc.Elements.  A chain like MultPoly -> AddPoly -> Decrypt (poly.go:123-207 -> bgn.go:205) only needs the
+// plaintexts at its end: DeviceArray keeps the wire bytes of level-uniform ciphertexts on the GPU between calls.  The
+// `_dev` entry points of the C ABI run on the null stream here (stream = nil), so calls on one engine execute in the
+// order they are made and Download sees their results.  tests/cpp/cgo_shape.c runs the same chain from C.
+
+// DeviceArray is `Count` elements of 2L wire bytes each (or any other fixed width: scalars, plaintexts) in the memory
+// of the engine's GPU.  Free it when done; it is not garbage collected.
+type DeviceArray struct {
+	e     *Engine
+	p     unsafe.Pointer
+	Count int
+	Width int // bytes per element
+	L2    bool
+}
+
+// NewDeviceArray allocates count elements of width bytes on the engine's device (bgn_dev_alloc).
+func (e *Engine) NewDeviceArray(count, width int, l2 bool) (*DeviceArray, error) {
+	if count <= 0 || width <= 0 {
+		return nil, errors.New("bgn_amd: empty device array")
+	}
+	var p unsafe.Pointer
+	err := locked(func() C.int {
+		p = C.bgn_dev_alloc(e.h, C.size_t(count*width))
+		if p == nil {
+			return C.BGN_E_NOMEM
+		}
+		return 0
+	})
+	if err != nil {
+		return nil, err
+	}
+	return &DeviceArray{e: e, p: p, Count: count, Width: width, L2: l2}, nil
+}
+
+// Free gives the array back (bgn_dev_free).
+func (d *DeviceArray) Free() {
+	if d != nil && d.p != nil {
+		C.bgn_dev_free(d.e.h, d.p)
+		d.p = nil
+	}
+}
+
+func (d *DeviceArray) u8() *C.uint8_t { return (*C.uint8_t)(d.p) }
+
+// UploadBytes copies host bytes (Count * Width of them) into the array.
+func (d *DeviceArray) UploadBytes(b []byte) error {
+	if len(b) != d.Count*d.Width {
+		return errors.New("bgn_amd: upload size does not match the device array")
+	}
+	return locked(func() C.int { return C.bgn_dev_upload(d.e.h, d.p, unsafe.Pointer(&b[0]), C.size_t(len(b))) })
+}
+
+// DownloadBytes copies the array to host memory, after every call issued on this engine before it.
+func (d *DeviceArray) DownloadBytes() ([]byte, error) {
+	b := make([]byte, d.Count*d.Width)
+	err := locked(func() C.int { return C.bgn_dev_download(d.e.h, unsafe.Pointer(&b[0]), d.p, C.size_t(len(b))) })
+	return b, err
+}
+
+// Upload packs ciphertexts of one level (Element.Bytes(), ciphertext.go:79) into a new device array.
+func (e *Engine) Upload(cts []*Ciphertext, l2 bool) (*DeviceArray, error) {
+	d, err := e.NewDeviceArray(len(cts), 2*e.L, l2)
+	if err != nil {
+		return nil, err
+	}
+	if err := d.UploadBytes(e.pack(cts)); err != nil {
+		d.Free()
+		return nil, err
+	}
+	return d, nil
+}
+
+// Download unpacks the array into ciphertexts (NewCiphertextFromBytes' element part, ciphertext.go:100).
+func (d *DeviceArray) Download() ([]*Ciphertext, error) {
+	b, err := d.DownloadBytes()
+	if err != nil {
+		return nil, err
+	}
+	return d.e.unpack(b, d.L2), nil
+}
+
+func (e *Engine) likeOut(n int, l2 bool) (*DeviceArray, error) { return e.NewDeviceArray(n, 2*e.L, l2) }
+
+// uploadScalars puts big-endian scalars of one width into a device array (nil for a nil slice: deterministic mode).
+func (e *Engine) uploadScalars(b []byte, count, width int) (*DeviceArray, error) {
+	if b == nil {
+		return nil, nil
+	}
+	d, err := e.NewDeviceArray(count, width, false)
+	if err != nil {
+		return nil, err
+	}
+	if err := d.UploadBytes(b); err != nil {
+		d.Free()
+		return nil, err
+	}
+	return d, nil
+}
+
+func (d *DeviceArray) ptrOrNil() *C.uint8_t {
+	if d == nil {
+		return nil
+	}
+	return d.u8()
+}
+
+// EncryptBatchDev is EncryptBatch with the ciphertexts left on the device (bgn.go:340-353; bgn_encrypt_batch_dev).
+func (e *Engine) EncryptBatchDev(x []*big.Int, r []*big.Int) (*DeviceArray, error) {
+	xs := make([]*big.Int, len(x))
+	for i, v := range x {
+		xs[i] = new(big.Int).Mod(v, e.pk.N)
+	}
+	xb, xw := scalars(xs)
+	rb, rw := e.randomness(r)
+	dx, err := e.uploadScalars(xb, len(x), xw)
+	if err != nil {
+		return nil, err
+	}
+	defer dx.Free()
+	dr, err := e.uploadScalars(rb, len(x), rw)
+	if err != nil {
+		return nil, err
+	}
+	defer dr.Free()
+	out, err := e.likeOut(len(x), false)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int {
+		return C.bgn_encrypt_batch_dev(e.h, C.size_t(len(x)), dx.u8(), C.size_t(xw), dr.ptrOrNil(), C.size_t(rw), out.u8(), nil)
+	})
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+func (e *Engine) addSubDev(a, b *DeviceArray, r []*big.Int, sub bool) (*DeviceArray, error) {
+	if a.Count != b.Count || a.L2 != b.L2 {
+		return nil, errors.New("bgn_amd: operand arrays differ in count or level")
+	}
+	rb, rw := e.randomness(r)
+	dr, err := e.uploadScalars(rb, a.Count, rw)
+	if err != nil {
+		return nil, err
+	}
+	defer dr.Free()
+	out, err := e.likeOut(a.Count, a.L2)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int {
+		if sub {
+			return C.bgn_sub_batch_dev(e.h, C.size_t(a.Count), levelOf(a.L2), a.u8(), b.u8(), dr.ptrOrNil(), C.size_t(rw), out.u8(), nil)
+		}
+		return C.bgn_add_batch_dev(e.h, C.size_t(a.Count), levelOf(a.L2), a.u8(), b.u8(), dr.ptrOrNil(), C.size_t(rw), out.u8(), nil)
+	})
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+// AddBatchDev is pk.Add over device arrays (bgn.go:442-497; bgn_add_batch_dev).  Operands of one level: lift with
+// MakeL2BatchDev first where the reference would (bgn.go:444-452).
+func (e *Engine) AddBatchDev(a, b *DeviceArray, r []*big.Int) (*DeviceArray, error) {
+	return e.addSubDev(a, b, r, false)
+}
+
+// SubBatchDev is pk.Sub over device arrays (bgn.go:375-432; bgn_sub_batch_dev).
+func (e *Engine) SubBatchDev(a, b *DeviceArray, r []*big.Int) (*DeviceArray, error) {
+	return e.addSubDev(a, b, r, true)
+}
+
+// NegBatchDev is pk.Neg over a device array (bgn.go:436-438; bgn_neg_batch_dev).
+func (e *Engine) NegBatchDev(a *DeviceArray) (*DeviceArray, error) {
+	out, err := e.likeOut(a.Count, a.L2)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int { return C.bgn_neg_batch_dev(e.h, C.size_t(a.Count), levelOf(a.L2), a.u8(), out.u8(), nil) })
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+// MultBatchDev is pk.Mult over device arrays of level-1 ciphertexts (bgn.go:294-314; bgn_mult_batch_dev).
+func (e *Engine) MultBatchDev(a, b *DeviceArray, r []*big.Int) (*DeviceArray, error) {
+	if a.Count != b.Count || a.L2 || b.L2 {
+		return nil, errors.New("bgn_amd: Mult takes two level-1 arrays of one length")
+	}
+	rb, rw := e.randomness(r)
+	dr, err := e.uploadScalars(rb, a.Count, rw)
+	if err != nil {
+		return nil, err
+	}
+	defer dr.Free()
+	out, err := e.likeOut(a.Count, true)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int {
+		return C.bgn_mult_batch_dev(e.h, C.size_t(a.Count), a.u8(), b.u8(), dr.ptrOrNil(), C.size_t(rw), out.u8(), nil)
+	})
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+// MakeL2BatchDev is pk.makeL2 over a device array (bgn.go:316-321; bgn_make_l2_batch_dev).
+func (e *Engine) MakeL2BatchDev(a *DeviceArray) (*DeviceArray, error) {
+	out, err := e.likeOut(a.Count, true)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int { return C.bgn_make_l2_batch_dev(e.h, C.size_t(a.Count), a.u8(), out.u8(), nil) })
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+// MultConstBatchDev is pk.MultConst with one scalar per element (bgn.go:253-291; bgn_multconst_batch_dev).
+func (e *Engine) MultConstBatchDev(a *DeviceArray, k []*big.Int, r []*big.Int) (*DeviceArray, error) {
+	if len(k) != a.Count {
+		return nil, errors.New("bgn_amd: one scalar per element")
+	}
+	ks := make([]*big.Int, len(k))
+	for i, v := range k {
+		ks[i] = new(big.Int).Mod(v, e.pk.N)
+	}
+	kb, kw := scalars(ks)
+	rb, rw := e.randomness(r)
+	dk, err := e.uploadScalars(kb, a.Count, kw)
+	if err != nil {
+		return nil, err
+	}
+	defer dk.Free()
+	dr, err := e.uploadScalars(rb, a.Count, rw)
+	if err != nil {
+		return nil, err
+	}
+	defer dr.Free()
+	out, err := e.likeOut(a.Count, a.L2)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int {
+		return C.bgn_multconst_batch_dev(e.h, C.size_t(a.Count), levelOf(a.L2), a.u8(), dk.u8(), C.size_t(kw), dr.ptrOrNil(),
+			C.size_t(rw), out.u8(), nil)
+	})
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+// MultPolyBatchDev is MultPoly over npoly pairs of coefficient polynomials resident on the device: a holds npoly*d1
+// level-1 coefficients, b npoly*d2; the result holds npoly*(d1+d2) level-2 coefficients, the last one of every
+// polynomial the GT identity (poly.go:123-156; bgn_poly_mult_batch_dev).
+func (e *Engine) MultPolyBatchDev(npoly, d1, d2 int, a, b *DeviceArray) (*DeviceArray, error) {
+	if a.Count != npoly*d1 || b.Count != npoly*d2 || a.L2 || b.L2 {
+		return nil, errors.New("bgn_amd: coefficient arrays do not match npoly*d1 / npoly*d2 level-1 elements")
+	}
+	out, err := e.likeOut(npoly*(d1+d2), true)
+	if err != nil {
+		return nil, err
+	}
+	err = locked(func() C.int {
+		return C.bgn_poly_mult_batch_dev(e.h, C.size_t(npoly), C.size_t(d1), C.size_t(d2), a.u8(), b.u8(), out.u8(), nil)
+	})
+	if err != nil {
+		out.Free()
+		return nil, err
+	}
+	return out, nil
+}
+
+// DecryptBatchDev is sk.Decrypt over a device array: plaintexts and per-element errors as DecryptBatch returns them
+// (bgn.go:205-250, gsbs.go:105; bgn_decrypt_batch_dev).  Only 9 bytes per ciphertext cross PCIe.
+func (e *Engine) DecryptBatchDev(cts *DeviceArray) ([]*big.Int, []error, error) {
+	dm, err := e.NewDeviceArray(cts.Count, 8, false)
+	if err != nil {
+		return nil, nil, err
+	}
+	defer dm.Free()
+	ds, err := e.NewDeviceArray(cts.Count, 1, false)
+	if err != nil {
+		return nil, nil, err
+	}
+	defer ds.Free()
+	err = locked(func() C.int {
+		return C.bgn_decrypt_batch_dev(e.h, C.size_t(cts.Count), levelOf(cts.L2), cts.u8(), (*C.int64_t)(dm.p), ds.u8(), nil)
+	})
+	if err != nil {
+		return nil, nil, err
+	}
+	mb, err := dm.DownloadBytes()
+	if err != nil {
+		return nil, nil, err
+	}
+	sb, err := ds.DownloadBytes()
+	if err != nil {
+		return nil, nil, err
+	}
+	vals := make([]*big.Int, cts.Count)
+	errs := make([]error, cts.Count)
+	for i := range vals {
+		if sb[i] != 0 {
+			errs[i] = errNoDL
+			continue
+		}
+		vals[i] = big.NewInt(int64(binary.LittleEndian.Uint64(mb[8*i : 8*i+8]))) // the device writes native int64 (little-endian hosts)
+	}
+	return vals, errs, nil
+}
+
+// ValidateBatch says for every element whether it is a valid encoding for its level — components below p and on the
+// curve (level 1) or of norm 1 (level 2).  The reference accepts any bytes (Element.SetBytes, ciphertext.go:100;
+// PBC maps an invalid point to the identity without telling) and the batch operations do not validate: ciphertexts
+// from an untrusted source go through this call first (bgn_validate_batch).
+func (e *Engine) ValidateBatch(cts []*Ciphertext, l2 bool) ([]bool, error) {
+	A := e.pack(cts)
+	ok := make([]uint8, len(cts))
+	err := locked(func() C.int { return C.bgn_validate_batch(e.h, C.size_t(len(cts)), levelOf(l2), u8(A), u8(ok)) })
+	if err != nil {
+		return nil, err
+	}
+	return bools(ok), nil
+}
+
+// ValidateBatchDev is ValidateBatch on a device array (bgn_validate_batch_dev).
+func (e *Engine) ValidateBatchDev(a *DeviceArray) ([]bool, error) {
+	dok, err := e.NewDeviceArray(a.Count, 1, false)
+	if err != nil {
+		return nil, err
+	}
+	defer dok.Free()
+	err = locked(func() C.int {
+		return C.bgn_validate_batch_dev(e.h, C.size_t(a.Count), levelOf(a.L2), a.u8(), dok.u8(), nil)
+	})
+	if err != nil {
+		return nil, err
+	}
+	ok, err := dok.DownloadBytes()
+	if err != nil {
+		return nil, err
+	}
+	return bools(ok), nil
+}
+
+// Calibrate re-derives the batch-size crossovers between the pairing-kernel families from timed probes on this
+// device (about a second at a 1024-bit key; call it once, after SetupDecryption, not concurrently with other calls):
+// the eight crossovers in elements, -1 where not calibrated (bgn_ctx_calibrate).
+func (e *Engine) Calibrate() ([8]int64, error) {
+	var out [8]C.int64_t
+	err := locked(func() C.int { return C.bgn_ctx_calibrate(e.h, &out[0]) })
+	var res [8]int64
+	for i := range res {
+		res[i] = int64(out[i])
+	}
+	return res, err
 }
 
 // ---- the reference's single-element methods as count-1 calls --------------------------------------------------------------
@@ -602,9 +1008,11 @@ func (pk *PublicKey) NewMultiEngine(devices []int) (*MultiEngine, error) {
 		devs[i] = C.int(d)
 	}
 	var h *C.bgn_mctx
-	rc := C.bgn_mctx_create(&h, u8(pb), C.size_t(len(pb)), u8(nb), C.size_t(len(nb)), C.uint64_t(l), u8(P), u8(Q),
+	err = locked(func() C.int {
+		return C.bgn_mctx_create(&h, u8(pb), C.size_t(len(pb)), u8(nb), C.size_t(len(nb)), C.uint64_t(l), u8(P), u8(Q),
 		C.int(det), (*C.int)(unsafe.Pointer(&devs[0])), C.int(len(devs)))
-	if err := engineErr(rc); err != nil {
+	})
+	if err != nil {
 		return nil, err
 	}
 	c0 := C.bgn_mctx_ctx(h, 0)
@@ -615,10 +1023,10 @@ func (m *MultiEngine) Close() { C.bgn_mctx_destroy(m.h) }
 
 func (m *MultiEngine) SetupDecryption(sk *SecretKey) error {
 	q1 := sk.Key.Bytes()
-	if err := engineErr(C.bgn_mctx_set_secret(m.h, u8(q1), C.size_t(len(q1)))); err != nil {
+	if err := locked(func() C.int { return C.bgn_mctx_set_secret(m.h, u8(q1), C.size_t(len(q1))) }); err != nil {
 		return err
 	}
-	return engineErr(C.bgn_mctx_setup_decryption(m.h, C.uint64_t(m.e0.pk.MsgSpace.Uint64())))
+	return locked(func() C.int { return C.bgn_mctx_setup_decryption(m.h, C.uint64_t(m.e0.pk.MsgSpace.Uint64())) })
 }
 
 // MultBatch: pk.Mult over len(a) pairs, sharded over the GPUs (bgn.go:294-314).
@@ -626,8 +1034,10 @@ func (m *MultiEngine) MultBatch(a, b []*Ciphertext, r []*big.Int) ([]*Ciphertext
 	A, B := m.e0.pack(a), m.e0.pack(b)
 	rb, rw := m.e0.randomness(r)
 	out := make([]byte, len(A))
-	rc := C.bgn_mmult_batch(m.h, C.size_t(len(a)), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_mmult_batch(m.h, C.size_t(len(a)), u8(A), u8(B), u8(rb), C.size_t(rw), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return m.e0.unpack(out, true), nil
@@ -644,7 +1054,7 @@ func (m *MultiEngine) DecryptBatch(cts []*Ciphertext, l2 bool) ([]*big.Int, []er
 		mp = (*C.int64_t)(unsafe.Pointer(&vals64[0]))
 		sp = (*C.uint8_t)(unsafe.Pointer(&st[0]))
 	}
-	if err := engineErr(C.bgn_mdecrypt_batch(m.h, C.size_t(len(cts)), levelOf(l2), u8(A), mp, sp)); err != nil {
+	if err := locked(func() C.int { return C.bgn_mdecrypt_batch(m.h, C.size_t(len(cts)), levelOf(l2), u8(A), mp, sp) }); err != nil {
 		return nil, nil, err
 	}
 	vals, errs := make([]*big.Int, len(cts)), make([]error, len(cts))
@@ -662,8 +1072,10 @@ func (m *MultiEngine) DecryptBatch(cts []*Ciphertext, l2 bool) ([]*big.Int, []er
 func (m *MultiEngine) MultPolyBatch(npoly, d1, d2 int, a, b []*Ciphertext) ([]*Ciphertext, error) {
 	A, B := m.e0.pack(a), m.e0.pack(b)
 	out := make([]byte, npoly*(d1+d2)*2*m.e0.L)
-	rc := C.bgn_mpoly_mult_batch(m.h, C.size_t(npoly), C.size_t(d1), C.size_t(d2), u8(A), u8(B), u8(out))
-	if err := engineErr(rc); err != nil {
+	err := locked(func() C.int {
+		return C.bgn_mpoly_mult_batch(m.h, C.size_t(npoly), C.size_t(d1), C.size_t(d2), u8(A), u8(B), u8(out))
+	})
+	if err != nil {
 		return nil, err
 	}
 	return m.e0.unpack(out, true), nil

@@ -365,6 +365,19 @@ int bgn_mpoly_mult_batch_dev(bgn_mctx* m, size_t npoly, size_t d1, size_t d2, co
 void* bgn_host_alloc(size_t bytes);
 void bgn_host_free(void* p);
 
+/* ---- device arrays for callers without a HIP binding --------------------------------------------------------
+ * The `_dev` entry points take device pointers.  A host language that does not link the HIP runtime itself (the Go
+ * shim: go/bgn_amd.go DeviceArray) gets its arrays here, so that chains like MultPoly -> AddPoly -> Decrypt
+ * (poly.go:123-207 -> bgn.go:205) stay on the device between calls.
+ * bgn_dev_alloc: `bytes` of memory on the context's device, owned by the caller — not part of bgn_ctx_memory_bytes,
+ * not subject to the context's budget; NULL on failure (bgn_last_error says why).  bgn_dev_free takes NULL.
+ * bgn_dev_upload / bgn_dev_download: synchronous copies between host memory and device memory of the context's
+ * device.  They run on the null stream: after every `_dev` call issued with stream = NULL before them. */
+void* bgn_dev_alloc(bgn_ctx* ctx, size_t bytes);
+void bgn_dev_free(bgn_ctx* ctx, void* p);
+int bgn_dev_upload(bgn_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int bgn_dev_download(bgn_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
 /* ---- diagnostics ------------------------------------------------------------------------------------------
  * Field arithmetic on its own (Montgomery product, squaring, division-step inversion of csrc/fpmont.hpp and
  * fpinv.hpp — what stands in for the mpz / PBC field calls behind every pbc.Element method),

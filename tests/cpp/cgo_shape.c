@@ -4,7 +4,13 @@
  * command line as hex (the Python test computes them with the batch calls); exit 0 iff every call returned the
  * expected bytes.  Compiled with `gcc -std=c99` by tests/test_cgo_shape.py: the header must be valid C.
  *
- *   cgo_shape P_HEX N_HEX L P_WIRE Q_WIRE Q1_HEX T  A_HEX B_HEX K_HEX  WANT_MULT WANT_ADD WANT_MC WANT_M
+ *
+ * Then the calls a Go caller makes to keep arrays on the device (go/bgn_amd.go DeviceArray and the *Dev methods): device
+ * arrays from bgn_dev_alloc, the chain Mult -> Add (level 2) -> Decrypt through the `_dev` entry points on the null
+ * stream with only the plaintexts downloaded (poly.go:123-207 -> bgn.go:205 in miniature), bgn_validate_batch on good
+ * and broken encodings, bgn_validate_batch_dev, bgn_ctx_calibrate.
+ *
+ *   cgo_shape P_HEX N_HEX L P_WIRE Q_WIRE Q1_HEX T  A_HEX B_HEX K_HEX  WANT_MULT WANT_ADD WANT_MC WANT_M  WANT_CHAIN_M
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -30,7 +36,7 @@ static size_t unhex(const char* s, uint8_t** out) {
 static bgn_ctx* ctx;
 static uint8_t *A, *B, *K, *want_mult, *want_add, *want_mc;
 static size_t E, klen;
-static long long want_m;
+static long long want_m, want_chain_m;
 static int failures;
 static pthread_mutex_t fail_mu = PTHREAD_MUTEX_INITIALIZER;
 
@@ -78,7 +84,7 @@ int main(int argc, char** argv) {
   uint64_t stats[5];
   int64_t v = 0;
   int t;
-  if (argc != 15) {
+  if (argc != 16) {
     fprintf(stderr, "usage: see the header of cgo_shape.c\n");
     return 2;
   }
@@ -99,11 +105,63 @@ int main(int argc, char** argv) {
   unhex(argv[12], &want_add);
   unhex(argv[13], &want_mc);
   want_m = atoll(argv[14]);
+  want_chain_m = atoll(argv[15]);
   /* the options surface from C: an unknown name is an error, a known one reads back */
   if (bgn_ctx_set_option(ctx, "no_such_option", 1) != BGN_E_ARG) return 6;
   if (bgn_ctx_set_option(ctx, "combine_max_batch", 4096) || bgn_ctx_get_option(ctx, "combine_max_batch", &v) || v != 4096) return 7;
   for (t = 0; t < NTHREADS; ++t) pthread_create(&th[t], NULL, goroutine, (void*)(size_t)t);
   for (t = 0; t < NTHREADS; ++t) pthread_join(th[t], NULL);
+  /* ---- arrays that stay on the device: the twin of go/bgn_amd.go's DeviceArray chain ---- */
+  {
+    enum { NCH = 5 };
+    uint8_t *hA = (uint8_t*)malloc(NCH * E), *hB = (uint8_t*)malloc(NCH * E), ok[NCH + 1], st[NCH];
+    int64_t m[NCH], cal[8];
+    uint8_t *dA, *dB, *dP, *dS, *dSt, *dOk;
+    int64_t* dM;
+    int i, rc;
+    for (i = 0; i < NCH; ++i) {
+      memcpy(hA + i * E, A, E);
+      memcpy(hB + i * E, B, E);
+    }
+    dA = (uint8_t*)bgn_dev_alloc(ctx, NCH * E);
+    dB = (uint8_t*)bgn_dev_alloc(ctx, NCH * E);
+    dP = (uint8_t*)bgn_dev_alloc(ctx, NCH * E);
+    dS = (uint8_t*)bgn_dev_alloc(ctx, NCH * E);
+    dM = (int64_t*)bgn_dev_alloc(ctx, NCH * sizeof(int64_t));
+    dSt = (uint8_t*)bgn_dev_alloc(ctx, NCH);
+    dOk = (uint8_t*)bgn_dev_alloc(ctx, NCH);
+    if (!dA || !dB || !dP || !dS || !dM || !dSt || !dOk) return 9;
+    if (bgn_dev_alloc(ctx, 0) != NULL) return 10;                                  /* a refused request says so */
+    if (bgn_dev_upload(ctx, dA, hA, NCH * E) || bgn_dev_upload(ctx, dB, hB, NCH * E)) return 11;
+    rc = bgn_mult_batch_dev(ctx, NCH, dA, dB, NULL, 0, dP, NULL);                  /* MultBatchDev */
+    if (!rc) rc = bgn_add_batch_dev(ctx, NCH, 2, dP, dP, NULL, 0, dS, NULL);       /* AddBatchDev on the products */
+    if (!rc) rc = bgn_decrypt_batch_dev(ctx, NCH, 2, dS, dM, dSt, NULL);           /* DecryptBatchDev */
+    if (!rc) rc = bgn_dev_download(ctx, m, dM, sizeof m);
+    if (!rc) rc = bgn_dev_download(ctx, st, dSt, sizeof st);
+    if (rc) {
+      fail_note("device chain", rc);
+    } else {
+      for (i = 0; i < NCH; ++i)
+        if (st[i] != BGN_DL_OK || (long long)m[i] != want_chain_m) fail_note("device chain: plaintext", 0);
+    }
+    /* the product array comes back as the bytes of the host-buffer Mult */
+    if (bgn_dev_download(ctx, hB, dP, NCH * E) || memcmp(hB + (NCH - 1) * E, want_mult, E)) fail_note("device chain: products", 0);
+    /* ValidateBatch / ValidateBatchDev: valid points, then one with a broken ordinate */
+    if (bgn_validate_batch(ctx, NCH, 1, hA, ok) || ok[0] != 1 || ok[NCH - 1] != 1) fail_note("validate", 0);
+    hA[E - 1] ^= 1;
+    if (bgn_validate_batch(ctx, 1, 1, hA, ok) || ok[0] != 0) fail_note("validate (broken point accepted)", 0);
+    if (bgn_validate_batch_dev(ctx, NCH, 2, dS, dOk, NULL) || bgn_dev_download(ctx, ok, dOk, NCH) || ok[0] != 1 || ok[NCH - 1] != 1)
+      fail_note("validate_dev", 0);
+    /* Calibrate: the eight crossovers come back, every one -1 or a count */
+    if (bgn_ctx_calibrate(ctx, cal)) fail_note("calibrate", 0);
+    for (i = 0; i < 8; ++i)
+      if (cal[i] < -1) fail_note("calibrate: crossover", 0);
+    bgn_dev_free(ctx, dA); bgn_dev_free(ctx, dB); bgn_dev_free(ctx, dP); bgn_dev_free(ctx, dS);
+    bgn_dev_free(ctx, dM); bgn_dev_free(ctx, dSt); bgn_dev_free(ctx, dOk);
+    bgn_dev_free(ctx, NULL);
+    free(hA);
+    free(hB);
+  }
   bgn_ctx_combiner_stats(ctx, stats);
   printf("calls %llu rounds %llu groups %llu largest group %llu failures %d\n", (unsigned long long)stats[0],
          (unsigned long long)stats[1], (unsigned long long)stats[2], (unsigned long long)stats[4], failures);

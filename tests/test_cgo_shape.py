@@ -1,7 +1,8 @@
 """The C ABI from plain C, in the call shape of the cgo binding: tests/cpp/cgo_shape.c is
 compiled with gcc -std=c99 against include/bgn_amd.h (cgo compiles C, not C++) — on the CPU it must build, link and fail
 loudly without a GPU; on the GPU 24 pthreads of single-element Mult / Add / MultConst / Decrypt calls on one context
-return the bytes of the batch calls."""
+return the bytes of the batch calls, and the device-array chain of go/bgn_amd.go's *Dev methods (bgn_dev_alloc, Mult -> Add
+-> Decrypt through the `_dev` entry points, validate, calibrate) gives the plaintext of the host-buffer calls."""
 import os
 import subprocess
 
@@ -35,7 +36,7 @@ def test_header_is_c99_and_the_c_caller_fails_loudly_without_gpu():
     fx = load_fixture("toy64")
     z = "00" * (2 * fx["fp_bytes"])
     r = subprocess.run([BIN, h(fx["p"]), h(fx["n"]), str(fx["l"]), fx["P"], fx["Q"], h(fx["q1"]), str(fx["msg_space"]),
-                        z, z, "05", z, z, z, "0"], capture_output=True, text=True)
+                        z, z, "05", z, z, z, "0", "0"], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stdout, r.stdout + r.stderr
 
 
@@ -47,14 +48,18 @@ def test_c_callers_in_the_cgo_call_shape():
     pk.SetupDecryption(sk)
     eng = pk.engine
     a = bytes.fromhex(fx["encrypt"][3]["ct"])
-    b = bytes.fromhex(fx["encrypt"][4]["ct"])
+    b = bytes.fromhex(fx["encrypt"][7]["ct"])                   # 5 * 36 * 2 stays inside the message space of 1021
     k = 0x1234567
     want_mult = eng.mult(a, b).tobytes().hex()
     want_add = eng.add(1, a, b).tobytes().hex()
     want_mc = eng.multconst(1, a, [k]).tobytes().hex()
     m, st = eng.decrypt(1, a)
     assert int(st[0]) == 0
+    # the device-resident chain of the C caller: Mult -> Add on level 2 (the product with itself) -> Decrypt
+    prod = eng.mult(a, b).tobytes()
+    m2, st2 = eng.decrypt(2, eng.add(2, prod, prod).tobytes())
+    assert int(st2[0]) == 0
     r = subprocess.run([BIN, h(fx["p"]), h(fx["n"]), str(fx["l"]), fx["P"], fx["Q"], h(fx["q1"]), str(fx["msg_space"]),
-                        a.hex(), b.hex(), "%08x" % k, want_mult, want_add, want_mc, str(int(m[0]))],
+                        a.hex(), b.hex(), "%08x" % k, want_mult, want_add, want_mc, str(int(m[0])), str(int(m2[0]))],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "cgo shape ok" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,91 @@
+"""GPU: level-1 Add / Sub in one wire-to-wire launch (k_g1_add_wire: the affine additions of g1_add_run with the
+dword-stream codec inside, one staged slice per step of a lane's run) — bgn.go:477-483 (Add, level-1 branch),
+:414-420 (Sub).  Against the golden vectors, the C oracle and the four-launch route it replaces."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import KEYS, engine_key, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def H(hexes):
+    return b"".join(bytes.fromhex(h) for h in hexes)
+
+
+@pytest.mark.parametrize("name", KEYS + ["k1024b", "k2048"])
+def test_l1_add_sub_golden_through_the_fused_kernel(name):
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    cts = [e["ct"] for e in fx["encrypt"]]
+    a, b = H([cts[v["a"]] for v in fx["l1"]]), H([cts[v["b"]] for v in fx["l1"]])
+    for fn, key in [(eng.add, "add"), (eng.sub, "sub")]:
+        got = fn(1, a, b)
+        assert eng.last_kernel_name() == "k_g1_add_wire"
+        for row, v in zip(got, fx["l1"]):
+            assert bytes(row).hex() == v[key], f"{name}: L1 {key}({v['a']},{v['b']})"
+
+
+@pytest.mark.parametrize("name,count", [("toy64", 70001), ("toy64", 150001), ("k256", 3000), ("k1024", 700), ("k1024b", 300)])
+def test_l1_fused_ragged_runs_vs_c_oracle_and_the_four_launch_route(name, count):
+    """Several workgroups, a ragged tail, runs of more than one element per lane (count > 65536: element j*T + t of a
+    lane's run is staged with its workgroup's slice at step j), identities, doublings (a + a) and cancellations
+    (a - a) sprinkled in: bytes equal to the C oracle's and to the four-launch route's."""
+    import oracle_c
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    rng = random.Random(45)
+    n = int(fx["n"], 16)
+    pool = [o.encrypt([rng.randrange(1 << 30)], [rng.randrange(n)]) for _ in range(9)]
+    pool.append(bytes(EB))                                   # identity
+    P = np.frombuffer(b"".join(pool), dtype=np.uint8).reshape(len(pool), EB)
+    ia = np.array([rng.randrange(len(pool)) for _ in range(count)])
+    ib = np.array([rng.randrange(len(pool)) for _ in range(count)])
+    a, b = P[ia].reshape(-1).tobytes(), P[ib].reshape(-1).tobytes()
+    want = {(i, k): (o.add(1, pool[i], pool[k]), o.add(1, pool[i], pool[k], True))
+            for i in range(len(pool)) for k in range(len(pool))}
+    wa = b"".join(want[(int(i), int(k))][0] for i, k in zip(ia, ib))
+    ws = b"".join(want[(int(i), int(k))][1] for i, k in zip(ia, ib))
+    assert eng.add(1, a, b).tobytes() == wa and eng.last_kernel_name() == "k_g1_add_wire"
+    assert eng.sub(1, a, b).tobytes() == ws
+    eng.set_option("l1_fused", 0)
+    try:
+        assert eng.add(1, a, b).tobytes() == wa and eng.last_kernel_name() == "k_g1_add"
+        assert eng.sub(1, a, b).tobytes() == ws
+    finally:
+        eng.set_option("l1_fused", 1)
+
+
+@pytest.mark.parametrize("name", ["k256", "k1024"])
+def test_l1_fused_on_misaligned_device_buffers(name):
+    """Operand arrays that start 1, 2 and 3 bytes into a dword are staged at their own misalignment; a result array
+    that does not start on a dword takes the four-launch route."""
+    import torch
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    n = 517
+    a = b"".join(cts[i % len(cts)] for i in range(n))
+    b = b"".join(cts[(3 * i + 1) % len(cts)] for i in range(n))
+    want = eng.add(1, a, b).tobytes()
+    dev = torch.device("cuda", 0)
+    for ma, mb, mo in [(1, 0, 0), (0, 2, 0), (3, 1, 0), (2, 3, 0), (0, 0, 3), (3, 1, 2)]:
+        ta = torch.zeros(n * EB + 8, dtype=torch.uint8, device=dev)
+        tb = torch.zeros(n * EB + 8, dtype=torch.uint8, device=dev)
+        to = torch.full((n * EB + 8,), 0xEE, dtype=torch.uint8, device=dev)
+        ta[ma:ma + n * EB] = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+        tb[mb:mb + n * EB] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        eng.add_dev(1, ta[ma:ma + n * EB], tb[mb:mb + n * EB], to[mo:mo + n * EB], n)
+        torch.cuda.synchronize()
+        assert eng.last_kernel_name() == ("k_g1_add_wire" if mo == 0 else "k_g1_add")
+        host = to.cpu().numpy().tobytes()
+        assert host[mo:mo + n * EB] == want, (ma, mb, mo)
+        assert host[:mo] == b"\xee" * mo and host[mo + n * EB:] == b"\xee" * (8 - mo), "bytes outside the result written"

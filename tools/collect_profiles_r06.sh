@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 trim() {
   find "$OUT" -name "*kernel_trace.csv" -size +2M -delete
   for f in "$OUT"/pmc_fetch_extra/fetch_counter_collection.csv "$OUT"/pmc_write_extra/write_counter_collection.csv; do
-    [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 1>|k_g1_add<|k_decode<[0-9]+, true>|k_encode<|k_gt_mul_wire<" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
+    [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 1>|k_g1_add<|k_decode<[0-9]+, true>|k_encode<|k_gt_mul_wire<|k_g1_add_wire<" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
   done
   for f in "$OUT"/*_p*/p_counter_collection.csv "$OUT"/cache_*/c_counter_collection.csv; do
     [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep -E "k_pairing<[0-9]+, 0>" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }

@@ -811,7 +811,7 @@ int bgn_ctx_set_secret(bgn_ctx* c, const uint8_t* q1_be, size_t q1_len) {
 namespace {
 void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t count, bool conj_b, bool plain_a = false);
 void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
-                   size_t count);
+                   size_t count, bool expect_norm1 = false);
 }
 
 int bgn_ctx_setup_decryption(bgn_ctx* c, uint64_t msg_space) {
@@ -1080,8 +1080,15 @@ static size_t quad_mc_limit(const bgn_ctx* c, int level, size_t klen) {
   const bool short_k = klen < 16;
   // (round 4's 24-instruction rows, same file re-measured: level 1, 1024-bit scalars 49152 elements 96.0 against 93.7 ms;
   // level 2 35.0 against 35.4)
-  if (c->nl >= 36) return level == 1 ? (short_k ? 65536 : 47000) : (short_k ? 32768 : 49000);
-  if (c->nl >= 19) return level == 1 ? (short_k ? 48000 : 38000) : (short_k ? 28000 : 37000);
+  // Round 6: on level 2 the lane kernel takes the norm-1 ladder (two products per scalar bit instead of five,
+  // kernels_impl.hpp k_gt_pow) and the lane groups still square and multiply, so the lane groups win a smaller range
+  // (profiles/r06_multconst_l2_crossover.csv: 1024-bit key, lane groups against lane kernel in ms,
+  // 16384 / 20480 elements: 1024-bit scalars 12.6 / 15.4 against 13.6; 256-bit 3.3 / 4.0 against 3.7; 40-bit 0.72 /
+  // 0.86 against 0.87 / 0.89.  512-bit key, 24576 / 32768: 256-bit 2.17 / 2.81 against 2.27; 40-bit 0.48 / 0.61
+  // against 0.48 / 0.50).
+  const bool ladder = level == 2 && opt(c, &Options::multconst_l2_ladder) != 0;
+  if (c->nl >= 36) return level == 1 ? (short_k ? 65536 : 47000) : ladder ? (short_k ? 21000 : 17500) : (short_k ? 32768 : 49000);
+  if (c->nl >= 19) return level == 1 ? (short_k ? 48000 : 38000) : ladder ? (short_k ? 24000 : 26000) : (short_k ? 28000 : 37000);
   return level == 1 ? 32768 : 24576;
 }
 
@@ -1730,14 +1737,16 @@ void gt_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 A, SoA2 B, SoA2 O, size_t cou
 }
 
 void gt_pow_launch(bgn_ctx* c, hipStream_t s, SoA2 A, const uint8_t* k, size_t kstride, size_t klen, SoA2 O,
-                   size_t count) {
+                   size_t count, bool expect_norm1) {
   GtPowArgs a;
   a.a0 = A.c0; a.a1 = A.c1; a.sa = A.stride;
   a.k = k; a.kstride = kstride; a.klen = klen;
   a.o0 = O.c0; a.o1 = O.c1; a.so = O.stride;
   a.count = count;
-  a.norm1 = 0;
-  a.p_bits = c->p_bits;
+  // expect_norm1: the bases are level-2 ciphertexts (MultConst, bgn.go:270-288) — the kernel checks their norm and
+  // takes the two-products-per-bit ladder where it is 1 (option multconst_l2_ladder = 0: always the general power)
+  a.norm1 = (expect_norm1 && opt(c, &Options::multconst_l2_ladder)) ? 2 : 0;
+  a.p_bits = a.norm1 ? c->p_bits + 1 : c->p_bits;   // (the division-step cap of the ladder's one inversion)
   c->kt->gt_pow(s, c->d_params, a);
 }
 
@@ -2056,7 +2065,7 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
     }
     if (!quad) {
       if (level == 1) g1_mul_launch(c, s, Av, kv, k_len, k_len, Ov, n);
-      else gt_pow_launch(c, s, Av, kv, k_len, k_len, Ov, n);
+      else gt_pow_launch(c, s, Av, kv, k_len, k_len, Ov, n, true);
       kname = level == 1 ? "k_g1_mul" : "k_gt_pow";
     }
     if (off == 0) c->last_kernel = kname;

@@ -107,8 +107,10 @@ struct GtPowArgs {
   const uint8_t* k; size_t kstride; size_t klen;
   uint32_t* o0; uint32_t* o1; size_t so;                                    // plain canonical out
   size_t count;
-  int norm1;                                                                // bases have norm 1: Lucas-type ladder, canonical
-  int p_bits;                                                               // *Montgomery* out (ops.hpp gt_pow_norm1_lane)
+  int norm1;                                                                // 1: bases have norm 1 — Lucas-type ladder, canonical
+  int p_bits;                                                               // *Montgomery* out (ops.hpp gt_pow_norm1_lane);
+                                                                            // 2: bases SHOULD have norm 1 (level-2 ciphertexts):
+                                                                            // checked per wave, ladder or general power, plain out
 };
 
 // Fixed-base GT power from a window table (ops.hpp): e(Q,Q)^r, optionally multiplied into R in place.

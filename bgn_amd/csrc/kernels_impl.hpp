@@ -649,7 +649,7 @@ k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
   const bool live = e < A.count;
   if (!live) e = A.count - 1;
   const size_t ea = (A.sa == 1) ? 0 : e;
-  if (A.norm1) {                                   // wave-uniform
+  if (A.norm1 == 1) {                              // wave-uniform
     Fp<NL> b0, b1, r0, r1, o;
     g_load<NL>(b0, A.a0, A.sa, ea);
     g_load<NL>(b1, A.a1, A.sa, ea);
@@ -664,6 +664,29 @@ k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
     Fp<NL> b0, b1, s;
     g_load<NL>(b0, A.a0, A.sa, ea);
     g_load<NL>(b1, A.a1, A.sa, ea);
+    if (A.norm1 == 2) {                            // wave-uniform: MultConst on level-2 ciphertexts
+      // A level-2 ciphertext is an element of GT, i.e. of norm 1 (every output of the final exponentiation is), and
+      // powers of a norm-1 base cost two field products per scalar bit on the Lucas-type ladder instead of two
+      // plus three per bit some lane has set.  The norm is CHECKED (two squarings): a wave in which some base is not
+      // of norm 1 — bytes that are no ciphertext — takes the general square-and-multiply below, so the result is
+      // base^k in F_p^2 whatever came in.
+      Fp<NL> n0, n1, c;
+      fp_sqrv(n0, b0, P, L);                       // <2
+      fp_sqrv(n1, b1, P, L);                       // <2
+      fp_add(n0, n0, n1);                          // <4
+      fp_set(n1, P->one);
+      fp_sub<1>(n0, n0, n1, P);                    // re^2 + im^2 - 1 <5
+      fp_from_mont<NL>(c, n0, P, L);               // canonical: zero iff the norm is 1
+      if (__all(fp_is_zero_limbs(c))) {
+        Fp<NL> r0, r1, o;
+        gt_pow_norm1_lane<NL>(r0, r1, L, b0, b1, A.k + e * A.kstride, A.klen, (int)(A.klen * 8), A.p_bits, P);
+        fp_from_mont<NL>(o, r0, P, L);             // r0 <5
+        if (live) g_store<NL>(A.o0, A.so, e, o);
+        fp_from_mont<NL>(o, r1, P, L);             // r1 <2
+        if (live) g_store<NL>(A.o1, A.so, e, o);
+        return;
+      }
+    }
     fp_add(s, b0, b1);
     l_store(L + 1, b0);
     l_store(L + 2, b1);

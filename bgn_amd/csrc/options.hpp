@@ -48,6 +48,7 @@ struct Options {
   V g1_mul_window{1};      // 4-bit windows in the variable-base scalar multiplication (0: binary ladder)
   V l1_fused{1};           // deterministic level-1 Add / Sub in one wire-to-wire launch (0: decode, decode, k_g1_add, encode)
   V l2_fused{1};           // deterministic level-2 Add / Sub in one wire-to-wire launch (0: decode, decode, k_gt_mul, encode)
+  V multconst_l2_ladder{1};// MultConst on level-2 ciphertexts by the norm-1 ladder where the norm is 1 (0: general power)
   V poly_karatsuba{1};     // Karatsuba levels on square MultPoly products
   V poly_levels{-1};       // forced number of levels (-1: planned)
   V poly_tables{-1};       // per-coefficient line tables: 0 never, 1 always, -1 by size
@@ -113,6 +114,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"g1_mul_window", &Options::g1_mul_window, true, nullptr},
       {"l1_fused", &Options::l1_fused, true, nullptr},
       {"l2_fused", &Options::l2_fused, true, nullptr},
+      {"multconst_l2_ladder", &Options::multconst_l2_ladder, true, nullptr},
       {"poly_karatsuba", &Options::poly_karatsuba, true, nullptr},
       {"poly_levels", &Options::poly_levels, true, nullptr},
       {"poly_tables", &Options::poly_tables, true, nullptr},

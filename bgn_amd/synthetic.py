@@ -241,15 +241,17 @@ def multconst_counts(level: int, scalar_bits: int):
     the inversion, 2 peels and zi^2, x, zi^3, y per entry), then per 4-bit window four doublings (9 reductions, 6
     squarings each) and one mixed addition (executed whenever a lane of the wave has a non-zero digit), and the
     affine conversion of the result (inversion + 4, one squaring).
-    Level 2, k_gt_pow (ops.hpp gt_pow_lane): square-and-multiply in F_p^2 — per bit one F_p^2 squaring (2 reductions)
-    and one F_p^2 product (3; executed whenever a lane of the wave has the bit set) — between two conversions each way."""
+    Level 2, k_gt_pow on bases of norm 1 (ops.hpp gt_pow_norm1_lane; every level-2 ciphertext is one, checked with two
+    squarings and a conversion): per bit one product and one squaring on the real parts, then one inversion and two
+    products for the imaginary part and two conversions out.  (The general square-and-multiply in F_p^2 it replaces
+    since round 6 took 5 reductions per bit.)"""
     if level == 1:
         windows = -(-scalar_bits // 4)
         table = 14 * 12 + 13 + INVERSION_PRODUCTS + 14 * 2 + 14 * 4
         red = table + windows * (4 * 9 + 12) + INVERSION_PRODUCTS + 4
         sq = 14 * 3 + 14 + windows * (4 * 6 + 3) + 1
         return float(red), float(sq), 0.0
-    return float(5 * scalar_bits + 4), 0.0, 0.0
+    return float(2 * scalar_bits + 3 + INVERSION_PRODUCTS + 2 + 2), float(scalar_bits + 2), 0.0
 
 
 def _run_for(count: int) -> int:

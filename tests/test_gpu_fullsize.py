@@ -384,3 +384,52 @@ def test_short_device_arrays_are_refused_by_the_host_mirror():
         eng.mult_dev(a, a[: 5 * EB], torch.empty_like(a), 12)
     with pytest.raises(ValueError, match="status"):
         eng.decrypt_dev(1, a, torch.empty(12, dtype=torch.int64, device=dev), torch.empty(11, dtype=torch.uint8, device=dev), 12)
+
+
+def test_level2_add_sub_at_2pow20():
+    """EAdd / ESub on level 2 at 2^20 (the fused wire-to-wire kernel): Sub(Add(x, y), y) gives x back byte for byte
+    (every product is an element of GT, whose inverse is the conjugate), Add(x, x') commutes, and a slice decrypts to
+    the sum and the difference of the plaintext products."""
+    fx = load_fixture("k1024")
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng, dev = pk.engine, torch.device("cuda")
+    n = 1 << 20
+    g = torch.Generator().manual_seed(23)
+    a = torch.randint(0, 1 << 19, (n,), generator=g, dtype=torch.int64)
+    b = torch.randint(0, 1 << 19, (n,), generator=g, dtype=torch.int64)
+    EB = eng.elem_bytes
+    ca = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+    cb = torch.empty_like(ca)
+    eng.encrypt_dev(_scalars(a.to(dev), 4), 4, _rand_r(n, g, dev), 128, ca, n)
+    eng.encrypt_dev(_scalars(b.to(dev), 4), 4, _rand_r(n, g, dev), 128, cb, n)
+    x = torch.empty_like(ca)
+    eng.mult_dev(ca, cb, x, n)                                   # x[i] = Enc2(a[i] * b[i])
+    perm = torch.randperm(n, generator=g).to(dev)
+    y = x.view(n, EB)[perm].contiguous().view(-1)                # y[i] = x[perm[i]]
+    s = torch.empty_like(x)
+    eng.add_dev(2, x, y, s, n)
+    assert eng.last_kernel_name() == "k_gt_mul_wire"
+    s2 = torch.empty_like(x)
+    eng.add_dev(2, y, x, s2, n)
+    assert torch.equal(s, s2)
+    from bgn_amd._lib import check
+    back = torch.empty_like(x)
+    check(eng._lib.bgn_sub_batch_dev(eng._h, n, 2, s.data_ptr(), y.data_ptr(), None, 0, back.data_ptr(), eng._stream()),
+          "bgn_sub_batch_dev")
+    torch.cuda.synchronize()
+    assert torch.equal(back, x)
+    k = 1 << 16
+    m = torch.empty(k, dtype=torch.int64, device=dev)
+    st = torch.empty(k, dtype=torch.uint8, device=dev)
+    eng.decrypt_dev(2, s[: k * EB], m, st, k)
+    torch.cuda.synchronize()
+    prod = a * b
+    want = prod + prod[perm.cpu()]
+    assert not bool(st.any().item()) and bool((m.cpu() == want[:k]).all().item())
+    d = torch.empty(k * EB, dtype=torch.uint8, device=dev)
+    check(eng._lib.bgn_sub_batch_dev(eng._h, k, 2, x.data_ptr(), y.data_ptr(), None, 0, d.data_ptr(), eng._stream()),
+          "bgn_sub_batch_dev")
+    eng.decrypt_dev(2, d, m, st, k)
+    torch.cuda.synchronize()
+    assert not bool(st.any().item()) and bool((m.cpu() == (prod - prod[perm.cpu()])[:k]).all().item())

@@ -86,8 +86,8 @@ def main():
         name = rng.choice(list(keys))
         K = keys[name]
         eng, EB = K["eng"], K["EB"]
-        op = rng.choice(["mult", "mult", "make_l2", "decrypt_l1", "decrypt_l2", "multpoly", "add_l1", "encrypt", "multconst_l1",
-                         "multconst_l2", "callers"])
+        op = rng.choice(["mult", "mult", "make_l2", "decrypt_l1", "decrypt_l2", "multpoly", "add_l1", "add_l2", "encrypt",
+                         "multconst_l1", "multconst_l2", "callers"])
         hi = {"k256": 18, "k512": 17.6, "k1024": 17.2, "k1024b": 16.5, "k2048": 12.5}[name]
         n = max(1, int(2 ** rng.uniform(0, hi)))
         if rng.random() < 0.25 and name != "k2048":          # around the round boundaries
@@ -150,8 +150,13 @@ def main():
                 ks[i] = torch.tensor(list(int(v % (1 << (8 * klen))).to_bytes(klen, "big")), dtype=torch.uint8)
             ksd = ks.to(dev)
             kvs = ["default"] + (["quad", "lane"] if (name != "k2048" or n <= 48) else [])
+            if lvl == 2 and name != "k2048":
+                kvs += ["lane, general power"]                # the lane kernel without the norm-1 ladder (round 6)
             for kv in kvs:
-                force(kv)
+                if kv == "lane, general power":
+                    force("lane", multconst_l2_ladder=0)
+                else:
+                    force(kv)
                 out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
                 eng._lib.bgn_multconst_batch_dev(eng._h, n, lvl, src.data_ptr(), ksd.data_ptr(), klen, None, 0, out.data_ptr(), eng._stream())
                 torch.cuda.synchronize()
@@ -201,15 +206,28 @@ def main():
             for t in th:
                 t.join()
             assert not errs, (name, op, errs[:2])
-        elif op == "add_l1":
-            force("default")
-            out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
-            eng.add_dev(1, a, b, out, n)
-            torch.cuda.synchronize()
-            k = min(n, 4)
-            j = rng.randrange(0, n - k + 1)
-            sa, sb = bytes(a[j * EB: (j + k) * EB].cpu().numpy()), bytes(b[j * EB: (j + k) * EB].cpu().numpy())
-            assert bytes(out[j * EB: (j + k) * EB].cpu().numpy()) == K["oracle"].add(1, sa, sb), (name, op, n)
+        elif op in ("add_l1", "add_l2"):
+            # Add and Sub on both levels: the one-launch wire-to-wire kernels (round 6) against the decode / decode /
+            # add / encode routes they replace, and a sample against the C oracle
+            lvl = 1 if op == "add_l1" else 2
+            sa_dev = a if lvl == 1 else K["l2"][off * EB: (off + n) * EB]
+            o2 = rng.randrange(0, NMAX - n + 1)
+            sb_dev = b if lvl == 1 else K["l2"][o2 * EB: (o2 + n) * EB]
+            sub = rng.random() < 0.5
+            fn = eng._lib.bgn_sub_batch_dev if sub else eng._lib.bgn_add_batch_dev
+            for env in ({}, {"l1_fused": 0, "l2_fused": 0}):
+                force("default", **env)
+                out = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+                assert fn(eng._h, n, lvl, sa_dev.data_ptr(), sb_dev.data_ptr(), None, 0, out.data_ptr(), eng._stream()) == 0
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = out
+                    k = min(n, 4)
+                    j = rng.randrange(0, n - k + 1)
+                    ha, hb = bytes(sa_dev[j * EB: (j + k) * EB].cpu().numpy()), bytes(sb_dev[j * EB: (j + k) * EB].cpu().numpy())
+                    assert bytes(out[j * EB: (j + k) * EB].cpu().numpy()) == K["oracle"].add(lvl, ha, hb, sub), (name, op, n, sub)
+                else:
+                    assert torch.equal(ref, out), (name, op, n, sub, env)
         elif op == "encrypt":
             # the chain kernels and the lane groups (k_g1_fixed_quad): one is the default, the other forced
             alts = [{}]

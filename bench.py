@@ -380,6 +380,29 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
             if cb:
                 out["eadd_l2"]["cpu_baseline"] = cb
         del o2, b2
+    # --- Neg (bgn.go:436-438: Sub(encryptZero(), c)): one coordinate negated, no field product — one wire-to-wire launch
+    # (k_neg_wire) whose only bound is HBM: 2 * 2L bytes per element
+    n_neg = n_enc
+    o_neg = torch.empty(n_neg * EB, dtype=torch.uint8, device=dev)
+    dt = _timed(lambda: check_rc(eng._lib.bgn_neg_batch_dev(eng._h, n_neg, 1, cts.data_ptr(), o_neg.data_ptr(), eng._stream())), sync)
+    k_ms, k_name = eng.last_kernel_ms(), eng.last_kernel_name()
+    alg_neg = 2 * EB * n_neg
+    out["neg_l1"] = {
+        "value": n_neg / dt, "unit": "negs/s", "batch": n_neg,
+        "workload": "pk.Neg on level-1 ciphertexts (y -> p - y), wire bytes to wire bytes in one launch", "kernel": k_name,
+        "algorithmic_bytes_per_unit": 2 * EB,
+        "roofline": {"bound": "hbm", "achieved": alg_neg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_neg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_neg, "kernel": k_name, "kernel_ms": k_ms, "call_ms": dt * 1e3}}
+    if not no_cpu:
+        ns = 1 << 18
+        zh, ch = bytes(ns * EB), cts[: ns * EB].cpu().numpy().tobytes()
+        cb = secondary_cpu_leg(fx, ns, lambda orc, lo, hi: orc.add(1, zh[lo * EB:hi * EB], ch[lo * EB:hi * EB], True),
+                               o_neg[: ns * EB].cpu().numpy().tobytes(), EB, "negs/s",
+                               "ciphertexts (Sub(encryptZero(), c), as the reference's Neg)", calibrate=64)
+        if cb:
+            out["neg_l1"]["cpu_baseline"] = cb
+    del o_neg
     # --- MultConst (bgn.go:253-291, BenchmarkMultConstant bgn_test.go:112-125) with per-element scalars: 2^16
     # ciphertexts of each level, 40-bit scalars (a plaintext-sized constant) and 1024-bit ones (the width of n)
     n_mc = 1 << 16

@@ -1947,6 +1947,16 @@ int bgn_neg_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* a, uin
   std::lock_guard<std::mutex> lk(c->mu);
   StreamOrder order(c, s);
   HIP_TRY(hipSetDevice(c->device));
+  if (c->kt->neg_wire && c->stream_codec && ((uintptr_t)out & 3u) == 0 && opt(c, &Options::l1_fused)) {
+    // one wire-to-wire launch, no workspace (option l1_fused = 0 keeps decode / negate / encode, like Add's)
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    c->kt->neg_wire(s, c->d_params, a, c->L, count, out);
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    c->last_kernel = "k_neg_wire";
+    c->ev_valid = true;
+    HIP_TRY(hipGetLastError());
+    return BGN_OK;
+  }
   const size_t st = round_up(count, 64);
   SoA2 A;
   for (int pass = 0; pass < 2; ++pass) {

@@ -281,6 +281,8 @@ struct KernelTable {
   // prefix: one F_p per element (limb stride sp), run: elements per lane
   void (*g1_add_wire)(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a, const uint8_t* b,
                       int L, size_t count, int run, int negate_b, uint32_t* prefix, size_t sp, uint8_t* out);
+  // Neg of either level wire bytes -> wire bytes in one launch (one coordinate negated, no field product)
+  void (*neg_wire)(hipStream_t s, const void* params, const uint8_t* in, int L, size_t count, uint8_t* out);
   // level-2 Add / Sub wire bytes -> wire bytes in one launch (barrett.hpp: F_p^2 product of plain residues);
   // `barrett` = the device image of BarrettParams<NL> (engine.cpp build_barrett).  Null beyond 40 limbs.
   void (*gt_mul_wire)(hipStream_t s, const void* params, const void* barrett, const uint8_t* a, const uint8_t* b, int L,

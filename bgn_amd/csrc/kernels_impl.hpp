@@ -373,6 +373,35 @@ k_g1_fixed_chain(const FpParams<NL>* __restrict__ P, const PairingConsts* __rest
   g1_add_run<NL>(G1IoFixedChain<NL>{A}, (size_t)A.chains * A.pitch, A.run, A.prefix, A.sp, L, C, P);
 }
 
+// Neg on either level (bgn.go:436-438: Sub(encryptZero(), c)), wire bytes to wire bytes in ONE launch: (x, y) ->
+// (x, p - y) on G1, (re, im) -> (re, p - im) on GT (norm 1: the inverse is the conjugate).  No field product at all:
+// the slice is staged, each lane decodes its element, negates one coordinate (0 stays 0: the identity's all-zero
+// encoding and a real GT element keep their bytes), encodes it back into the stage, and the slice is written out —
+// 2 * 2L bytes of HBM traffic per element and ~700 instructions: the one operation of this path that is bound by
+// HBM.  The launcher's caller guarantees StreamCodec<NL>::serves(L) and a dword-aligned `out`.
+template <int NL>
+__global__ void __launch_bounds__(FP_BLOCK)
+k_neg_wire(const FpParams<NL>* __restrict__ P, const uint8_t* __restrict__ in, int L, size_t count,
+           uint8_t* __restrict__ out) {
+  __shared__ WireStage<NL> ws;
+  const size_t e0 = (size_t)blockIdx.x * FP_BLOCK;
+  const size_t nel = (count - e0 < (size_t)FP_BLOCK) ? count - e0 : (size_t)FP_BLOCK;
+  const size_t EB = (size_t)(2 * L);
+  const bool live = threadIdx.x < nel;
+  const u32 eoff = live ? threadIdx.x * (u32)EB : 0u;
+  Fp<NL> x, y;
+  {
+    const u32 mis = wire_stage_in<NL>(&ws, in + e0 * EB, nel * EB);
+    wire_to_limbs_stream<NL>(x, ws.w, mis + eoff, L);
+    wire_to_limbs_stream<NL>(y, ws.w, mis + eoff + (u32)L, L);
+  }
+  fp_neg<1>(y, y, P);                     // p - y in [1, p] for a canonical y
+  fp_cond_sub_p<NL>(y, y, P);             // y = 0 -> 0
+  __syncthreads();                        // every lane has read its element: the stage takes the results
+  if (live) limbs_to_wire_stream<NL>(ws.w, threadIdx.x, L, x, y);
+  wire_stage_out<NL>(&ws, out + e0 * EB, nel * EB);
+}
+
 // Level-1 Add / Sub (bgn.go:477-483, :414-420), wire bytes to wire bytes in ONE launch: the affine additions of
 // g1_add_run (ops.hpp: plain residues, one inversion per lane's run of elements) with the codec inside.  Element
 // j*T + t of lane t's run is element t of a contiguous slice of the workgroup at every step j, so each step stages
@@ -864,6 +893,12 @@ static void launch_g1_neg(hipStream_t s, const void* params, uint32_t* y, size_t
                      inf, count);
 }
 
+static void launch_neg_wire(hipStream_t s, const void* params, const uint8_t* in, int L, size_t count, uint8_t* out) {
+  if (!count) return;
+  hipLaunchKernelGGL(k_neg_wire<NL_>, dim3(grid_for(count)), dim3(FP_BLOCK), 0, s, (const FpParams<NL_>*)params, in, L, count,
+                     out);
+}
+
 static void launch_g1_add_wire(hipStream_t s, const void* params, const PairingConsts* consts, const uint8_t* a,
                                const uint8_t* b, int L, size_t count, int run, int negate_b, uint32_t* prefix, size_t sp,
                                uint8_t* out) {
@@ -1211,6 +1246,7 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       "k_bsgs_search<" BGN_STR(BGN_NL) ">",
       launch_field_ops,
       launch_g1_add_wire,
+      launch_neg_wire,
 #if BGN_NL <= 40
       launch_gt_mul_wire,
       (const void*)k_gt_mul_wire<NL_>,

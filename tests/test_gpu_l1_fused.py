@@ -89,3 +89,37 @@ def test_l1_fused_on_misaligned_device_buffers(name):
         host = to.cpu().numpy().tobytes()
         assert host[mo:mo + n * EB] == want, (ma, mb, mo)
         assert host[:mo] == b"\xee" * mo and host[mo + n * EB:] == b"\xee" * (8 - mo), "bytes outside the result written"
+
+
+@pytest.mark.parametrize("name", KEYS + ["k1024b"])
+def test_neg_in_one_launch_both_levels(name):
+    """Neg (bgn.go:436-438) wire to wire in one launch (k_neg_wire): golden vectors of both levels, the identity and a
+    real GT element keep their bytes, Neg(Neg(c)) == c on a ragged batch, equal to the decode / negate / encode route,
+    and Add(c, Neg(c)) is the identity."""
+    import numpy as np
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    cts = [e["ct"] for e in fx["encrypt"]]
+    l2 = [v["out"] for v in fx["mult"]]
+    a1 = H([cts[v["a"]] for v in fx["l1"]])
+    a2 = H([l2[v["a"]] for v in fx["l2"]])
+    for lvl, a, rows in ((1, a1, fx["l1"]), (2, a2, fx["l2"])):
+        got = eng.neg(lvl, a)
+        assert eng.last_kernel_name() == "k_neg_wire"
+        for row, v in zip(got, rows):
+            assert bytes(row).hex() == v["neg"], f"{name}: L{lvl} neg({v['a']})"
+    one = (1).to_bytes(EB // 2, "big") + bytes(EB // 2)
+    assert eng.neg(1, bytes(EB)).tobytes() == bytes(EB) and eng.neg(2, one).tobytes() == one
+    pool = [bytes.fromhex(c) for c in cts]
+    n = 1237
+    big = b"".join(pool[(5 * i + 1) % len(pool)] for i in range(n))
+    neg = eng.neg(1, big).tobytes()
+    assert eng.neg(1, neg).tobytes() == big
+    assert eng.add(1, big, neg).tobytes() == bytes(n * EB)
+    eng.set_option("l1_fused", 0)
+    try:
+        assert eng.neg(1, big).tobytes() == neg and eng.last_kernel_name() != "k_neg_wire"
+    finally:
+        eng.set_option("l1_fused", 1)

@@ -85,6 +85,12 @@ rows.append(("EAdd level 1, 2^20, one launch of `%s`" % l1["kernel"],
              (e3(l1["value"]), l1["roofline"]["call_ms"], l1["roofline"]["achieved"], l1["roofline"]["frac"],
               "; PMC traffic %.3g B per call = %.2f × algorithmic" % (t1, t1 / l1["roofline"]["algorithmic_bytes_per_call"]) if t1 else "",
               frac(l1), frac(l1, "frac_at_1_wave_per_simd"), l1["products_per_unit"], cpu(l1))))
+if "neg_l1" in ex:
+    ng = ex["neg_l1"]
+    rows.append(("Neg level 1, 2^20, one launch of `%s`" % ng["kernel"],
+                 "**%s negs/s**; kernel %.3f ms → %.0f GB/s of algorithmic bytes = **%.3f of HBM peak** (no field product: the "
+                 "one HBM-bound operation of the path).  CPU: %s" %
+                 (e3(ng["value"]), ng["roofline"]["kernel_ms"], ng["roofline"]["achieved"], ng["roofline"]["frac"], cpu(ng))))
 enc = ex["encrypt"]
 rows.append(("Encrypt, 2^20", "%s encrypts/s; %.3f / %.3f of the two ceilings.  CPU: %s" %
              (e3(enc["value"]), frac(enc), frac(enc, "frac_at_1_wave_per_simd"), cpu(enc))))

@@ -60,8 +60,9 @@ def test_multconst_l2_on_bytes_that_are_no_ciphertext(name):
     l2 = [bytes.fromhex(v["out"]) for v in fx["mult"]]
     bases = [enc(1, 0), enc(p - 1, 0), enc(0, 1), enc(0, 0), enc(2, 3), enc(rng.randrange(p), rng.randrange(p))]
     rows = [bases[i % len(bases)] if i % 3 == 0 else l2[i % len(l2)] for i in range(200)]
-    # ... and one wave of GT elements only (takes the ladder) behind them
-    rows += [l2[i % len(l2)] for i in range(128)]
+    # ... and waves of norm-1 elements only behind them (elements 256 .. 319 and 320 .. 383: they take the ladder),
+    # the bases 1 and -1 among them: their imaginary part is 0, which the ladder's last division must survive
+    rows += [l2[i % len(l2)] if i % 5 else (enc(1, 0) if i % 10 else enc(p - 1, 0)) for i in range(192)]
     ks = [rng.choice([0, 1, 2, 5, n - 1, rng.randrange(1 << 40), rng.randrange(n)]) for _ in rows]
     got = eng.multconst(2, b"".join(rows), ks)
     for row, base, k in zip(got, rows, ks):

@@ -114,6 +114,14 @@ def load() -> C.CDLL:
         raise OSError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C bgn_amd/csrc).  There is no CPU fallback.")
+    # A process that also uses PyTorch-ROCm (device buffers, streams: every caller of this binding does) must have
+    # torch's copy of the HIP runtime loaded FIRST: the library then binds to that one.  The other order leaves two HIP
+    # runtimes of different versions in the process, and this library's sees no device (bgn_ctx_create: "no HIP
+    # device available") — python __graft_entry__.py smoke, which builds and loads before it imports torch, hit it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete

@@ -3,7 +3,7 @@
 lane (the host emulation of the device headers tallies them, fpmont.hpp BGN_TALLY), priced in instructions per unit
 as the gfx950 code objects have them, beside the SQ_INSTS_VALU the counters measured for the same kernel.
 
-    python tools/op_tally.py [k1024] > profiles/r05_op_tally.csv        (CPU only; the emulator is tests/emu)
+    python tools/op_tally.py [k1024] > profiles/r06_op_tally.csv        (CPU only; the emulator is tests/emu)
 
 Prices (instructions per unit, read off the disassembly of kern_nl36): a multiply-add 1; a product row 5 (Montgomery
 factor: multiply + mask, the 64-bit row carry: shift + add, the loop's share); an accumulator flushed 3; a limb of a
@@ -67,6 +67,10 @@ def main():
         lambda: E.pairing_fixed_multi(mt["t"], 4 * Qp, Qp, q, A4, B4, 3), 4)
     run("k_g1_add: affine additions, one run of 16 (EAdd at 2^20)", "addition",
         lambda: E.g1_add([a] * 16, [b] * 16, plain=True), 16)
+    # the fused level-2 Add (barrett.hpp fp2_mul_plain): one F_p^2 product of plain residues, no codec
+    l2a, l2b = o.mult(a, b), o.mult(b, b)
+    run("k_gt_mul_wire: one level-2 Add (Barrett F_p^2 product of plain residues; the codec around it is not tallied)", "addition",
+        lambda: E.gt_mul_plain(l2a, l2b))
     print("# tools/op_tally.py %s: primitives of ONE lane by the host emulation, priced in VALU instructions (see the tool's header)" % name)
     print("kernel,unit," + ",".join("n_" + k for k in PRICE) + ",mad_instructions,other_instructions,other_share," +
           ",".join("instr_" + k for k in PRICE if k != "mad"))

@@ -123,3 +123,34 @@ def test_neg_in_one_launch_both_levels(name):
         assert eng.neg(1, big).tobytes() == neg and eng.last_kernel_name() != "k_neg_wire"
     finally:
         eng.set_option("l1_fused", 1)
+
+
+@pytest.mark.parametrize("name", ["k256", "k1024"])
+def test_one_launch_kernels_in_place(name):
+    """The result array may be one of the operand arrays (accumulating into a device array): every workgroup has read
+    its slices before it writes them (the level-1 kernel's two passes read a slice again only before that slice's own
+    write).  Add / Sub on both levels into the first and into the second operand, Neg into its operand."""
+    import torch
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    dev = torch.device("cuda", 0)
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    l2 = [bytes.fromhex(v["out"]) for v in fx["mult"]]
+    n = 70003 if name == "k256" else 1031
+    for lvl, pool in ((1, cts), (2, l2)):
+        a = b"".join(pool[(2 * i + 1) % len(pool)] for i in range(n))
+        b = b"".join(pool[(3 * i) % len(pool)] for i in range(n))
+        want = eng.add(lvl, a, b).tobytes()
+        want_neg = eng.neg(lvl, a).tobytes()
+        for which in (0, 1):
+            ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+            tb = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+            eng.add_dev(lvl, ta, tb, ta if which == 0 else tb, n)
+            torch.cuda.synchronize()
+            assert (ta if which == 0 else tb).cpu().numpy().tobytes() == want, (lvl, which)
+        ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+        assert eng._lib.bgn_neg_batch_dev(eng._h, n, lvl, ta.data_ptr(), ta.data_ptr(), eng._stream()) == 0
+        torch.cuda.synchronize()
+        assert ta.cpu().numpy().tobytes() == want_neg, lvl

@@ -292,6 +292,34 @@ __device__ __forceinline__ void limbs_to_wire_stream(u32* __restrict__ w, u32 ti
 // (FP_BLOCK elements) between HBM and LDS with coalesced dword accesses, and the lanes pick their
 // bytes out of LDS.  The array base need not be dword aligned (callers pass sub-ranges of buffers):
 // the slice is staged at its own misalignment `mis`, so the aligned dwords of HBM and LDS coincide.
+// The staging copies are non-temporal loads / stores (-DBGN_STAGE_NT=0: plain ones): a wire array is streamed
+// once per launch, and a non-temporal load lands sooner — which is what a one-wave-per-SIMD kernel that waits for its
+// own staging feels.  Same box, both builds in one call (profiles/r06_stage_nt_ab.csv): the fused level-1 Add at 2^20
+// 1.59 -> 1.38 ms (+15 %), the fused level-2 Add 0.431 -> 0.415 ms, Neg at 2^22 0.40 -> 0.36 ms (at 2^20: 0.095 ->
+// 0.100), nothing slower from 2^14 elements up.
+#ifndef BGN_STAGE_NT
+#define BGN_STAGE_NT 1
+#endif
+__device__ __forceinline__ uint4 stage_ld(const uint4* p) {
+#if BGN_STAGE_NT && defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void stage_st(uint4* p, const uint4& v) {
+#if BGN_STAGE_NT && defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  v4u t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(p));
+#else
+  *p = v;
+#endif
+}
+
 template <int NL>
 struct WireStage {
   static constexpr int LMAX = (LIMB_BITS * NL - 9 + 7) / 8;            // largest L this limb count serves
@@ -318,7 +346,7 @@ __device__ __forceinline__ u32 wire_stage_in(WireStage<NL>* st, const uint8_t* _
     for (; i + 7 * FP_BLOCK < n4; i += 8 * FP_BLOCK) {
       uint4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = g4[i + k * FP_BLOCK];
+      for (int k = 0; k < 8; ++k) v[k] = stage_ld(g4 + i + k * FP_BLOCK);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s4[i + k * FP_BLOCK] = v[k];
     }
@@ -327,7 +355,7 @@ __device__ __forceinline__ u32 wire_stage_in(WireStage<NL>* st, const uint8_t* _
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         uint4 t = make_uint4(0, 0, 0, 0);
-        if (i + k * FP_BLOCK < n4) t = g4[i + k * FP_BLOCK];
+        if (i + k * FP_BLOCK < n4) t = stage_ld(g4 + i + k * FP_BLOCK);
         v[k] = t;
       }
 #pragma unroll
@@ -354,7 +382,7 @@ __device__ __forceinline__ void wire_stage_out(const WireStage<NL>* st, uint8_t*
     uint4* __restrict__ g4 = (uint4*)ga;
     const uint4* s4 = (const uint4*)st->w;
     const u32 n4 = (u32)(nbytes / 16);
-    for (u32 i = threadIdx.x; i < n4; i += FP_BLOCK) g4[i] = s4[i];
+    for (u32 i = threadIdx.x; i < n4; i += FP_BLOCK) stage_st(g4 + i, s4[i]);
     first = 4 * n4;
   }
   for (u32 i = first + threadIdx.x; i < nw; i += FP_BLOCK) {

@@ -187,6 +187,32 @@ __device__ __forceinline__ void v_load(Fp<NL>& r, const u32* __restrict__ lane_p
 // those lines 16 times per wave instruction stream, and 64 lanes * 304 B exceed the 16 KB L1 of a CU.
 struct alignas(16) GVec4 { u32 v[4]; };
 struct alignas(8) GVec2 { u32 v[2]; };
+// -DBGN_TAB_NT=1: the gathers of window-table entries as non-temporal loads (an entry of a 16 GB table is read once).
+#ifndef BGN_TAB_NT
+#define BGN_TAB_NT 0
+#endif
+__device__ __forceinline__ GVec4 tab_ld4(const GVec4* p) {
+#if BGN_TAB_NT && defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+  GVec4 r;
+  r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+  return r;
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ GVec2 tab_ld2(const GVec2* p) {
+#if BGN_TAB_NT && defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));
+  GVec2 r;
+  r.v[0] = v.x; r.v[1] = v.y;
+  return r;
+#else
+  return *p;
+#endif
+}
 
 template <int NL>
 __device__ __forceinline__ void v_load2(Fp<NL>& a, Fp<NL>& b, const u32* __restrict__ lane_ptr) {
@@ -196,7 +222,7 @@ __device__ __forceinline__ void v_load2(Fp<NL>& a, Fp<NL>& b, const u32* __restr
     const GVec4* q = reinterpret_cast<const GVec4*>(lane_ptr);
 #pragma unroll
     for (int k = 0; k < NL / 2; ++k) {
-      const GVec4 t = q[k];
+      const GVec4 t = tab_ld4(q + k);
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[4 * k + i] = t.v[i];
     }
@@ -204,7 +230,7 @@ __device__ __forceinline__ void v_load2(Fp<NL>& a, Fp<NL>& b, const u32* __restr
     const GVec2* q = reinterpret_cast<const GVec2*>(lane_ptr);
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      const GVec2 t = q[k];
+      const GVec2 t = tab_ld2(q + k);
       w[2 * k] = t.v[0];
       w[2 * k + 1] = t.v[1];
     }
@@ -225,7 +251,7 @@ __device__ __forceinline__ void v_load_first(Fp<NL>& a, const u32* __restrict__ 
     const GVec4* q = reinterpret_cast<const GVec4*>(lane_ptr);
 #pragma unroll
     for (int k = 0; k < NL / 4; ++k) {
-      const GVec4 t = q[k];
+      const GVec4 t = tab_ld4(q + k);
 #pragma unroll
       for (int i = 0; i < 4; ++i) a.v[4 * k + i] = t.v[i];
     }
@@ -233,7 +259,7 @@ __device__ __forceinline__ void v_load_first(Fp<NL>& a, const u32* __restrict__ 
     const GVec2* q = reinterpret_cast<const GVec2*>(lane_ptr);
 #pragma unroll
     for (int k = 0; k < NL / 2; ++k) {
-      const GVec2 t = q[k];
+      const GVec2 t = tab_ld2(q + k);
       a.v[2 * k] = t.v[0];
       a.v[2 * k + 1] = t.v[1];
     }

@@ -11,6 +11,11 @@
 #define BGN_GMEM_HPP
 #include <stdint.h>
 
+// -DBGN_SOA_NT=1: the limb-major loads with the non-temporal hint (experiment of round 6)
+#ifndef BGN_SOA_NT
+#define BGN_SOA_NT 0
+#endif
+
 namespace bgn {
 
 // Returns its wave-uniform argument, opaque to the optimiser: address arithmetic that depends on it is
@@ -23,7 +28,7 @@ __device__ __forceinline__ unsigned long long gmem_pin_uniform(unsigned long lon
 __device__ __forceinline__ uint32_t gmem_load_u32(const uint32_t* row /* wave-uniform */, uint32_t byte_off) {
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), 0, 0x7fffffff, 0x00020000);
-  return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0);
+  return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, BGN_SOA_NT ? 2 : 0);
 }
 
 __device__ __forceinline__ void gmem_store_u32(uint32_t* row /* wave-uniform */, uint32_t byte_off, uint32_t v) {

@@ -182,7 +182,7 @@ int bgn_encrypt_batch(bgn_ctx* ctx, size_t count, const uint8_t* x_be, size_t x_
 /* out[i] = a[i] + b[i] (level 1: G1 point addition; level 2: F_p^2 product),
  * followed by blinding with Q^r[i] resp. e(Q,Q)^r[i] when r != NULL.
  * With r == NULL a call is ONE kernel launch from wire bytes to wire bytes on either level (and so are Sub and
- * Neg): level 2 at 2e9 /s, level 1 at 6.4e8 /s, Neg at 8.7e9 /s for 2^20 device-resident elements of a 1024-bit
+ * Neg): level 2 at 2.2e9 /s, level 1 at 7.2e8 /s, Neg at 8.7e9 /s for 2^20 device-resident elements of a 1024-bit
  * key; a result array that does not start on a 4-byte boundary takes a four-launch route (same bytes).
  * Replaces Add (bgn.go:442-497). */
 int bgn_add_batch(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,

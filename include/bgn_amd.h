@@ -264,7 +264,10 @@ int bgn_check_plaintext_knowledge_batch(bgn_ctx* ctx, size_t count, const uint8_
                                         const uint8_t* c_be, size_t c_len, const uint8_t* dl_be, size_t dl_len,
                                         uint8_t* ok);
 
-/* ---- batch operations, device buffers (same semantics; asynchronous) -------- */
+/* ---- batch operations, device buffers (same semantics; asynchronous) --------
+ * Aliasing: for Add / Sub / Neg / MultConst the result array may BE an operand array (out == a or out == b, the
+ * accumulate-in-place of poly.go:171-207; tests/test_gpu_l1_fused.py::test_one_launch_kernels_in_place); an `out`
+ * that overlaps an operand at any other offset is undefined, as is any overlap for the other operations. */
 int bgn_encrypt_batch_dev(bgn_ctx* ctx, size_t count, const uint8_t* x_be, size_t x_len, const uint8_t* r_be,
                           size_t r_len, uint8_t* out, void* stream);
 int bgn_add_batch_dev(bgn_ctx* ctx, size_t count, int level, const uint8_t* a, const uint8_t* b, const uint8_t* r_be,

@@ -67,3 +67,34 @@ def test_multconst_l2_on_bytes_that_are_no_ciphertext(name):
     got = eng.multconst(2, b"".join(rows), ks)
     for row, base, k in zip(got, rows, ks):
         assert dec(bytes(row)) == fp2_pow(dec(base), k, p), (dec(base), k)
+
+
+@pytest.mark.parametrize("name,count", [("k256", 30011), ("k1024", 257)])
+def test_multconst_in_place_on_device_arrays(name, count):
+    """include/bgn_amd.h (device buffers, aliasing): MultConst may write its result over its operand array — the
+    codec reads the whole operand before the first result byte is written on every route (lane kernel, lane groups,
+    both levels)."""
+    import numpy as np
+    import torch
+    fx = load_fixture(name)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    dev = torch.device("cuda", 0)
+    rng = random.Random(17)
+    n = int(fx["n"], 16)
+    pools = {1: [bytes.fromhex(e["ct"]) for e in fx["encrypt"]], 2: [bytes.fromhex(v["out"]) for v in fx["mult"]]}
+    for lvl in (1, 2):
+        pool = pools[lvl]
+        for cnt in (count, 33):
+            a = b"".join(pool[(3 * i + 1) % len(pool)] for i in range(cnt))
+            ks = [rng.choice([0, 1, rng.randrange(1 << 40), rng.randrange(n)]) for _ in range(cnt)]
+            want = eng.multconst(lvl, a, ks).tobytes()
+            klen = max(1, (max(ks).bit_length() + 7) // 8)
+            kb = np.frombuffer(b"".join(k.to_bytes(klen, "big") for k in ks), dtype=np.uint8)
+            ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+            tk = torch.from_numpy(kb.copy()).to(dev)
+            rc = eng._lib.bgn_multconst_batch_dev(eng._h, cnt, lvl, ta.data_ptr(), tk.data_ptr(), klen, None, 0,
+                                                  ta.data_ptr(), eng._stream())
+            assert rc == 0, eng.last_error() if hasattr(eng, "last_error") else rc
+            torch.cuda.synchronize()
+            assert ta.cpu().numpy().tobytes() == want, (lvl, cnt)

@@ -1087,8 +1087,19 @@ static size_t quad_mc_limit(const bgn_ctx* c, int level, size_t klen) {
   // 0.86 against 0.87 / 0.89.  512-bit key, 24576 / 32768: 256-bit 2.17 / 2.81 against 2.27; 40-bit 0.48 / 0.61
   // against 0.48 / 0.50).
   const bool ladder = level == 2 && opt(c, &Options::multconst_l2_ladder) != 0;
-  if (c->nl >= 36) return level == 1 ? (short_k ? 65536 : 47000) : ladder ? (short_k ? 21000 : 17500) : (short_k ? 32768 : 49000);
-  if (c->nl >= 19) return level == 1 ? (short_k ? 48000 : 38000) : ladder ? (short_k ? 24000 : 26000) : (short_k ? 28000 : 37000);
+  // Round 6, level 1 with short scalars: the lane kernel takes 2-bit windows from 3 scalar bytes on (g1_mul_launch) and
+  // is 1.3x the binary ladder it replaces (profiles/r06_multconst_short.csv: 1024-bit key, lane groups against lane
+  // kernel in ms at 49152 / 57344 elements: 40-bit 4.98 / 5.74 against 5.18; 64-bit 7.19 / 8.31 against 7.75; 120-bit
+  // 12.3 / 14.2 against 13.7; 8-bit (binary ladder) at 32768: 1.57 against 1.54.  512-bit key at 40960: 40-bit 1.82
+  // against 1.81, 120-bit 4.40 against 4.75; 8-bit at 16384 / 32768: 0.42 / 0.65 against 0.53).
+  const bool tiny_k = klen < 3;
+  const bool short_win = short_k && !tiny_k && opt(c, &Options::g1_mul_window_short) != 0;
+  if (c->nl >= 36)
+    return level == 1 ? (tiny_k ? 32768 : short_win ? 51000 : short_k ? 65536 : 47000)
+                      : ladder ? (short_k ? 21000 : 17500) : (short_k ? 32768 : 49000);
+  if (c->nl >= 19)
+    return level == 1 ? (tiny_k ? 24000 : short_win ? 41000 : short_k ? 48000 : 38000)
+                      : ladder ? (short_k ? 24000 : 26000) : (short_k ? 28000 : 37000);
   return level == 1 ? 32768 : 24576;
 }
 
@@ -1397,14 +1408,18 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
   a.k = k; a.kstride = kstride; a.klen = klen;
   a.ox = O.c0; a.oy = O.c1; a.oinf = O.inf; a.so = O.stride;
   a.count = count;
-  a.wtab = nullptr; a.winf = nullptr; a.wcap = 0;
+  a.wtab = nullptr; a.winf = nullptr; a.wcap = 0; a.wbits = 4;
   a.only = nullptr; a.only_mask = 0;
-  // per-element bases with scalars of 128 bits and more: 4-bit windows over a table of 1*B .. 15*B per element
-  // (ops.hpp), 12 KB of scratch each (measured at 2^16 elements: 1.4x at 256 bits, 1.67x at 1024 bits, 0.9x at
-  // 64 bits); BGN_G1_MUL_WINDOW=0 keeps the binary ladder
+  // per-element bases: fixed windows over a table of 1*B .. (2^w - 1)*B per element (ops.hpp).  Scalars of 128 bits and
+  // more: w = 4, 12 KB of scratch each (measured at 2^16 elements against the binary ladder: 1.4x at 256 bits, 1.67x at
+  // 1024 bits; option g1_mul_window = 0 keeps the binary ladder); shorter ones (plaintext-sized constants, the
+  // common case of MultConst) from 3 bytes on: w = 2, 3 KB each, 1.3x the binary ladder at 40 .. 120 bits and 0.9x at
+  // 8 bits, whose scalars keep the ladder (option g1_mul_window_short; profiles/r06_multconst_short.csv)
   const bool fail_ws = opt(c, &Options::test_fail_mul_ws) != 0;
-  const size_t per = (size_t)5 * c->nl * 16 * 4 + 16;
-  if (opt(c, &Options::g1_mul_window) != 0 && B.stride != 1 && klen >= 16 && count * per <= ((size_t)24 << 30)) {
+  const int wbits = klen >= 16 ? (opt(c, &Options::g1_mul_window) != 0 ? 4 : 0) : (klen >= 3 && opt(c, &Options::g1_mul_window_short) != 0 ? 2 : 0);
+  const size_t E = (size_t)1 << wbits;
+  const size_t per = (size_t)5 * c->nl * E * 4 + E;
+  if (wbits != 0 && B.stride != 1 && count * per <= ((size_t)24 << 30)) {
     const size_t cap = round_up(count, 64), need = cap * per + 4096;
     bool ok = true;
     if (need > c->mul_ws_bytes || fail_ws) {
@@ -1426,8 +1441,9 @@ void g1_mul_launch(bgn_ctx* c, hipStream_t s, SoA2 B, const uint8_t* k, size_t k
     }
     if (ok) {
       a.wtab = (uint32_t*)c->mul_ws;
-      a.winf = c->mul_ws + (size_t)5 * c->nl * 16 * 4 * cap;
+      a.winf = c->mul_ws + (size_t)5 * c->nl * E * 4 * cap;
       a.wcap = cap;
+      a.wbits = wbits;
     }
   }
   c->kt->g1_mul(s, c->d_params, c->d_consts, a);
@@ -1546,8 +1562,8 @@ int ensure_fixed_tables(bgn_ctx* c) {
     a.k = k1 + o * klen; a.kstride = klen; a.klen = klen;
     a.ox = pw.c0 + o; a.oy = pw.c1 + o; a.oinf = pw.inf + o; a.so = pw.stride;
     a.count = np[b];
-    a.wtab = nullptr; a.winf = nullptr; a.wcap = 0;
-  a.only = nullptr; a.only_mask = 0;
+    a.wtab = nullptr; a.winf = nullptr; a.wcap = 0; a.wbits = 4;
+    a.only = nullptr; a.only_mask = 0;
     kt->g1_mul(nullptr, c->d_params, c->d_consts, a);
   }
   kt->to_mont(nullptr, c->d_params, pw.c0, pw.c1, pw.stride, npt);
@@ -2051,7 +2067,7 @@ int bgn_multconst_batch_dev(bgn_ctx* c, size_t count, int level, const uint8_t* 
         g.k = kv; g.kstride = k_len; g.klen = k_len;
         g.ox = Ov.c0; g.oy = Ov.c1; g.oinf = Ov.inf; g.so = Ov.stride;
         g.count = n;
-        g.wtab = nullptr; g.winf = nullptr; g.wcap = 0;
+        g.wtab = nullptr; g.winf = nullptr; g.wcap = 0; g.wbits = 4;
         g.only = flags; g.only_mask = 2u;
         const int64_t hook = opt(c, &Options::test_mc_fallback);
         if (hook == 2) {                               // tests: how many elements did the lane groups flag?

@@ -85,9 +85,10 @@ struct G1MulArgs {
   const uint8_t* k; size_t kstride; size_t klen;                            // big-endian scalars (kstride 0: one for all)
   uint32_t* ox; uint32_t* oy; uint8_t* oinf; size_t so;                     // plain canonical affine out
   size_t count;
-  // 4-bit fixed windows over a per-element table of 1*B .. 15*B (ops.hpp g1_scalarmul_win_lane): five arrays of
-  // NL rows x 16*wcap u32 (x, y, Z, prefix, spare) behind wtab, 16*wcap identity flags behind winf; null: binary ladder
-  uint32_t* wtab; uint8_t* winf; size_t wcap;
+  // fixed windows of wbits (4 or 2) bits over a per-element table of 1*B .. (E-1)*B, E = 2^wbits (ops.hpp
+  // g1_scalarmul_win_lane): five arrays of NL rows x E*wcap u32 (x, y, Z, prefix, spare) behind wtab, E*wcap identity
+  // flags behind winf; null: binary ladder
+  uint32_t* wtab; uint8_t* winf; size_t wcap; int wbits;
   // non-null: only the elements e with only[e] & only_mask are computed and written (the exact lane kernel as the
   // fallback of the lane-group scalar multiplication for the elements that kernel flagged: quad/quad_g1.hpp)
   const uint8_t* only; unsigned only_mask;

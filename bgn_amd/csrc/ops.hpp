@@ -1179,19 +1179,25 @@ __device__ __forceinline__ void g1_scalarmul_bin_lane(const G1MulArgs& A, size_t
 // table of element e sits at column e*16 + d of five limb-major arrays (x, y, Z, prefix; the fifth is spare),
 // so a lane reaches its own multiple d through its per-lane offset.  Exceptional cases (a base of small order,
 // the identity) are exact: every table entry carries an identity flag.
+// G1MulArgs::wbits == 2 (scalars below 128 bits, where the 15-entry table costs more than it saves): the same with
+// 2-bit windows over 1*B .. 3*B in columns e*4 + d — two additions and one inversion in front, then two doublings
+// and one mixed addition per window: 15 products per bit + 93 against the binary ladder's 21 (a wave executes the
+// addition at every position where ANY of its lanes has a digit, so a sparse signed form buys nothing here).
 template <int NL>
 __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t e, bool live, LFp<NL>* L,
                                                       const PairingConsts* __restrict__ C,
                                                       const FpParams<NL>* __restrict__ P) {
   const size_t eb = (A.sb == 1) ? 0 : (A.bdiv > 1 ? e / A.bdiv : e);
   const uint8_t* k = A.k + e * A.kstride;
-  const size_t ts = 16 * A.wcap;                       // limb stride of the table arrays
+  const int wb = A.wbits == 2 ? 2 : 4;                 // wave-uniform
+  const int E = 1 << wb;                               // columns per element: the multiples 0 (unused) .. E-1
+  const size_t ts = (size_t)E * A.wcap;                // limb stride of the table arrays
   u32* tx = A.wtab;
   u32* ty = tx + (size_t)NL * ts;
   u32* tz = ty + (size_t)NL * ts;
   u32* tp = tz + (size_t)NL * ts;
   uint8_t* tinf = A.winf;
-  const size_t col = e * 16;
+  const size_t col = e * (size_t)E;
   JacAcc<NL> S;
   bool acc_inf = false;
   {
@@ -1210,9 +1216,9 @@ __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t
     g_store(ty, ts, col + 1, t);
     tinf[col + 1] = 0;
   }
-  // multiples 2B .. 15B in Jacobian coordinates
+  // multiples 2B .. (E-1)B in Jacobian coordinates
 #pragma unroll 1
-  for (int m = 2; m < 16; ++m) {
+  for (int m = 2; m < E; ++m) {
     jac_add_affine<NL>(S, acc_inf, true, L, P);
     Fp<NL> t;
     a_load(t, S.X);
@@ -1229,14 +1235,14 @@ __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t
     g_store(tz, ts, col + m, t);
     tinf[col + m] = acc_inf ? 1 : 0;
   }
-  // one inversion for the 14 Z (Montgomery's trick), then affine coordinates
+  // one inversion for the E-2 Z (Montgomery's trick), then affine coordinates
   {
     LFp<NL>* S0 = L;
     LFp<NL>* L1 = L + 1;
     Fp<NL> acc, r, u, inv;
     fp_set(acc, P->one);
 #pragma unroll 1
-    for (int m = 2; m < 16; ++m) {
+    for (int m = 2; m < E; ++m) {
       g_store(tp, ts, col + m, acc);
       g_load(u, tz, ts, col + m);
       l_store(L1, acc);
@@ -1245,7 +1251,7 @@ __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t
     }
     fp_inv<NL>(inv, acc, L, C, P);                     // <1   (uses L0, L1)
 #pragma unroll 1
-    for (int m = 15; m >= 2; --m) {
+    for (int m = E - 1; m >= 2; --m) {
       Fp<NL> zi;
       g_load(u, tp, ts, col + m);
       l_store(L1, inv);
@@ -1266,7 +1272,7 @@ __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t
       g_store(ty, ts, col + m, r);
     }
   }
-  // the walk: four doublings and one table addition per window, from the top
+  // the walk: wb doublings and one table addition per window, from the top
   {
     Fp<NL> t;
     fp_set(t, P->one);
@@ -1276,13 +1282,14 @@ __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t
     a_store(S.Z, t);
   }
   acc_inf = true;
-  const int nwin = (int)(A.klen * 2);
+  const int per = 8 / wb;                              // windows per scalar byte
+  const int nwin = (int)A.klen * per;
 #pragma unroll 1
   for (int w = nwin - 1; w >= 0; --w) {
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) jac_double_checked<NL>(S, acc_inf, L, P);
-    const u32 byte = k[A.klen - 1 - (size_t)(w >> 1)];
-    const u32 d = (w & 1) ? (byte >> 4) : (byte & 15u);
+    for (int j = 0; j < wb; ++j) jac_double_checked<NL>(S, acc_inf, L, P);
+    const u32 byte = k[A.klen - 1 - (size_t)(w / per)];
+    const u32 d = (byte >> (wb * (w % per))) & (u32)(E - 1);
     bool take = d != 0;
     if (__ballot(take)) {
       const size_t idx = col + (take ? d : 1);

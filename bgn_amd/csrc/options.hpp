@@ -46,6 +46,7 @@ struct Options {
   V fixed_signed_q{1};     // signed windows of window bits + 1 scalar bits over Q's table (0: unsigned windows)
   V fixed_chains{4};       // accumulation chains per element of the fixed-base products (1: one launch per window)
   V g1_mul_window{1};      // 4-bit windows in the variable-base scalar multiplication (0: binary ladder)
+  V g1_mul_window_short{1};  // 2-bit windows for scalars of 3 .. 15 bytes (0: binary ladder for those)
   V l1_fused{1};           // deterministic level-1 Add / Sub in one wire-to-wire launch (0: decode, decode, k_g1_add, encode)
   V l2_fused{1};           // deterministic level-2 Add / Sub in one wire-to-wire launch (0: decode, decode, k_gt_mul, encode)
   V multconst_l2_ladder{1};// MultConst on level-2 ciphertexts by the norm-1 ladder where the norm is 1 (0: general power)
@@ -112,6 +113,7 @@ inline const OptionDesc* option_table(size_t* n) {
       {"fixed_signed_q", &Options::fixed_signed_q, true, nullptr},
       {"fixed_chains", &Options::fixed_chains, true, nullptr},
       {"g1_mul_window", &Options::g1_mul_window, true, nullptr},
+      {"g1_mul_window_short", &Options::g1_mul_window_short, true, nullptr},
       {"l1_fused", &Options::l1_fused, true, nullptr},
       {"l2_fused", &Options::l2_fused, true, nullptr},
       {"multconst_l2_ladder", &Options::multconst_l2_ladder, true, nullptr},

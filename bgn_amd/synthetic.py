@@ -237,19 +237,24 @@ def l2_add_mads(nl: int) -> int:
 def multconst_counts(level: int, scalar_bits: int):
     """(reductions, squarings, sums of two products) of one MultConst with a per-element scalar (bgn.go:253-291).
     Level 1, k_g1_mul (ops.hpp g1_scalarmul_win_lane): a per-element table of the multiples 1..15 of the base (14 mixed
-    Jacobian additions of 12 reductions, 3 of them squarings; one shared inversion over their Z: 13 prefix products,
+    Jacobian additions of 12 reductions, 3 of them squarings; one shared inversion over their Z: 14 prefix products,
     the inversion, 2 peels and zi^2, x, zi^3, y per entry), then per 4-bit window four doublings (9 reductions, 6
     squarings each) and one mixed addition (executed whenever a lane of the wave has a non-zero digit), and the
-    affine conversion of the result (inversion + 4, one squaring).
+    affine conversion of the result (inversion + 4, one squaring).  Scalars below 128 bits: the same with 2-bit
+    windows over the multiples 1..3.
     Level 2, k_gt_pow on bases of norm 1 (ops.hpp gt_pow_norm1_lane; every level-2 ciphertext is one, checked with two
     squarings and a conversion): per bit one product and one squaring on the real parts, then one inversion and two
     products for the imaginary part and two conversions out.  (The general square-and-multiply in F_p^2 it replaces
     since round 6 took 5 reductions per bit.)"""
     if level == 1:
-        windows = -(-scalar_bits // 4)
-        table = 14 * 12 + 13 + INVERSION_PRODUCTS + 14 * 2 + 14 * 4
-        red = table + windows * (4 * 9 + 12) + INVERSION_PRODUCTS + 4
-        sq = 14 * 3 + 14 + windows * (4 * 6 + 3) + 1
+        if scalar_bits < 24:                         # the binary ladder: a doubling and (in some lane of the wave) an addition per bit
+            return float(scalar_bits * 21 + INVERSION_PRODUCTS + 4), float(scalar_bits * 9 + 1), 0.0
+        wb = 4 if scalar_bits >= 128 else 2          # engine.cpp g1_mul_launch: 2-bit windows for 3 .. 15 scalar bytes
+        ent = (1 << wb) - 2                          # table entries beside the base itself
+        windows = -(-scalar_bits // wb)
+        table = ent * 12 + ent + INVERSION_PRODUCTS + ent * 2 + ent * 4
+        red = table + windows * (wb * 9 + 12) + INVERSION_PRODUCTS + 4
+        sq = ent * 3 + ent + windows * (wb * 6 + 3) + 1
         return float(red), float(sq), 0.0
     return float(2 * scalar_bits + 3 + INVERSION_PRODUCTS + 2 + 2), float(scalar_bits + 2), 0.0
 

@@ -229,11 +229,12 @@ struct Emu {
     A.count = 1;
     std::vector<u32> wtab;
     std::vector<uint8_t> winf;
-    A.wtab = nullptr; A.winf = nullptr; A.wcap = 0;
-    if (window) {                                   // the 4-bit windowed variant with its per-element table
-      wtab.assign((size_t)5 * NL * 16, 0);
-      winf.assign(16, 0);
-      A.wtab = wtab.data(); A.winf = winf.data(); A.wcap = 1;
+    A.wtab = nullptr; A.winf = nullptr; A.wcap = 0; A.wbits = 4;
+    if (window) {                                   // the windowed variant with its per-element table (window == 2: 2-bit)
+      const int E = window == 2 ? 4 : 16;
+      wtab.assign((size_t)5 * NL * E, 0);
+      winf.assign(E, 0);
+      A.wtab = wtab.data(); A.winf = winf.data(); A.wcap = 1; A.wbits = window == 2 ? 2 : 4;
     }
     g1_scalarmul_lane<NL>(A, 0, true, lds(), C, P);
   }

@@ -202,13 +202,13 @@ class Emu:
                                                 C.c_size_t(q), C.c_size_t(Qp), C.c_size_t(i0), C.c_size_t(s - i0), i1 - i0 + 1, out) == 0
         return self.encode(out)
 
-    def g1_mul(self, base: bytes, k: int, klen: int = None, window: bool = False) -> bytes:
+    def g1_mul(self, base: bytes, k: int, klen: int = None, window: int = 0) -> bytes:
         B, ib = self.decode(base)
         klen = klen or max(1, (k.bit_length() + 7) // 8)
         kb = k.to_bytes(klen, "big")
         out = (C.c_uint32 * (2 * self.nl))()
         oinf = C.c_uint8()
-        assert self.lib.emu_g1_mul(self.nl, self.params, self.consts, B, ib, kb, C.c_size_t(klen), 1 if window else 0, out,
+        assert self.lib.emu_g1_mul(self.nl, self.params, self.consts, B, ib, kb, C.c_size_t(klen), int(window), out,
                                    C.byref(oinf)) == 0
         return self.encode(out, oinf.value)
 

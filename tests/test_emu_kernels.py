@@ -46,11 +46,11 @@ def test_emu_windowed_miller_loop(ctx, w):
     E.set_window(5)
 
 
-@pytest.mark.parametrize("window", [False, True])
+@pytest.mark.parametrize("window", [0, 4, 2])
 def test_emu_scalar_mult_exceptional_cases(ctx, window):
     """acc == +-base inside the ladder: k = n, n+-1, n+2 for P; multiples of q1 (+-1, +2) for Q of order q1; a base
     of order 2 and of order 4 (points of the curve outside the ciphertext subgroup), the identity — for the binary
-    ladder and for the 4-bit windows over a per-element table of multiples."""
+    ladder and for the 4-bit and the 2-bit windows over a per-element table of multiples."""
     fx, E = ctx
     p, n, q1 = int(fx["p"], 16), int(fx["n"], 16), int(fx["q1"], 16)
     Pw, Qw = bytes.fromhex(fx["P"]), bytes.fromhex(fx["Q"])

@@ -39,8 +39,11 @@ def main():
             ks = torch.randint(0, 256, (nmax, kb), dtype=torch.uint8, generator=g).to(dev)
             ref = {}
             for level, src in ((1, cts), (2, l2)):
-                for kernel in ("quad", "lane"):
+                for kernel in ("quad", "lane", "lane_binary"):
+                    if kernel == "lane_binary" and (level != 1 or kb >= 16):
+                        continue                                      # only short scalars on level 1 have that alternative
                     eng.set_option("quad_max_mc", (1 << 40) if kernel == "quad" else 0)
+                    eng.set_option("g1_mul_window_short", 0 if kernel == "lane_binary" else 1)
                     for n in counts:
                         if kernel == "quad" and n > 65536:
                             eng.set_option("quad_max_mc", -1)         # the default cut: lane rounds + a lane-group remainder
@@ -58,9 +61,10 @@ def main():
                         if kk in ref:
                             assert bool((ref[kk] == r).all().item()), "kernels differ"
                         ref[kk] = r
-                        print("%s,%d,%d,%d,%s,%.3f,%.1f,%s" % (key, level, kb * 8, n, kernel if n <= 65536 or kernel == "lane" else "default",
+                        print("%s,%d,%d,%d,%s,%.3f,%.1f,%s" % (key, level, kb * 8, n, kernel if n <= 65536 or kernel != "quad" else "default",
                                                                best * 1e3, n / best, eng.last_kernel_name()), flush=True)
                     eng.set_option("quad_max_mc", -1)
+                    eng.set_option("g1_mul_window_short", 1)
 
 
 if __name__ == "__main__":

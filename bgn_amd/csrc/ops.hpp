@@ -14,6 +14,18 @@ __device__ __forceinline__ u32 scalar_bit(const uint8_t* __restrict__ k, size_t 
   return (k[len - 1 - (size_t)(i >> 3)] >> (i & 7)) & 1u;
 }
 
+// The highest bit index that is set in the scalar of ANY lane of the wave, or -1.  The leading zero bits of a whole
+// wave change nothing in a ladder that starts from the identity (or from (A_0, A_1) on the norm-1 ladder) and are
+// skipped: a small constant in a long scalar field (MultConst by plaintext-sized constants, bgn_test.go:112-125
+// multiplies by 1) costs its own length.  Whole zero bytes first, then bits.
+__device__ __forceinline__ int wave_top_bit(const uint8_t* __restrict__ k, size_t len) {
+  size_t b = 0;
+  while (b < len && !__ballot(k[b] != 0)) ++b;
+  int i = (int)((len - b) * 8) - 1;
+  while (i >= 0 && !__ballot(scalar_bit(k, len, i) != 0)) --i;
+  return i;
+}
+
 // The 64 bits of a big-endian scalar whose least significant byte is the scalar's byte `b_low` (byte 0 = the last one
 // of the array), as ONE load: klen >= 8, b_low <= klen - 8.  (Byte loads behind "is this byte inside the scalar"
 // branches cost a wait each — and a wait on the vector-memory counter waits for every load in flight, the
@@ -306,8 +318,9 @@ __device__ __forceinline__ void gt_pow_norm1_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL
     a_store(SX, x0);
     a_store(SY, x1);
   }
+  const int top = wave_top_bit(k, klen);      // (A_0, A_1) is a fixed point of a zero bit
 #pragma unroll 1
-  for (int i = nbits - 1; i >= 0; --i) {
+  for (int i = (top < nbits ? top : nbits - 1); i >= 0; --i) {
     const bool bit = scalar_bit(k, klen, i) != 0;
     Fp<NL> a, b, t, u;
     a_load(a, SA);                           // <5
@@ -1162,9 +1175,8 @@ __device__ __forceinline__ void g1_scalarmul_bin_lane(const G1MulArgs& A, size_t
     l_store(L + 3, t);
   }
   bool acc_inf = true;
-  const int nbits = (int)(A.klen * 8);
 #pragma unroll 1
-  for (int i = nbits - 1; i >= 0; --i) {
+  for (int i = wave_top_bit(k, A.klen); i >= 0; --i) {
     jac_double_checked<NL>(S, acc_inf, L, P);
     const bool bit = scalar_bit(k, A.klen, i) != 0;
     if (__ballot(bit)) jac_add_affine<NL>(S, acc_inf, bit, L, P);
@@ -1283,9 +1295,9 @@ __device__ __forceinline__ void g1_scalarmul_win_lane(const G1MulArgs& A, size_t
   }
   acc_inf = true;
   const int per = 8 / wb;                              // windows per scalar byte
-  const int nwin = (int)A.klen * per;
+  const int top = wave_top_bit(k, A.klen);             // windows above it: zero digits on an identity accumulator
 #pragma unroll 1
-  for (int w = nwin - 1; w >= 0; --w) {
+  for (int w = top < 0 ? -1 : top / wb; w >= 0; --w) {
 #pragma unroll 1
     for (int j = 0; j < wb; ++j) jac_double_checked<NL>(S, acc_inf, L, P);
     const u32 byte = k[A.klen - 1 - (size_t)(w / per)];

@@ -70,3 +70,44 @@ def test_short_scalars_with_bases_of_small_order():
         assert eng.last_kernel_name() == "k_g1_mul"
     finally:
         eng.set_option("quad_max_mc", -1)
+
+
+@pytest.mark.parametrize("name,count", [("k256", 700), ("k1024", 200)])
+def test_small_constants_in_long_scalar_fields(name, count):
+    """A wave whose scalars all have leading zero bytes / bits skips them (ops.hpp wave_top_bit): constants below 2^8,
+    2^20 and 0 carried in fields of 3, 16, 40 and 130 bytes, waves of zeros beside waves of full-length scalars, on
+    both levels of the lane kernel and on the default dispatch — the bytes of the C oracle."""
+    import numpy as np
+    import oracle_c
+    from bgn_amd.api import _as_u8, _ptr, _scalars
+    from bgn_amd._lib import check
+    fx = load_fixture(name)
+    o = oracle_c.Oracle.from_fixture(fx)
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    rng = random.Random(29)
+    pools = {1: [bytes.fromhex(e["ct"]) for e in fx["encrypt"]], 2: [bytes.fromhex(v["out"]) for v in fx["mult"]]}
+    for lvl in (1, 2):
+        a = b"".join(pools[lvl][rng.randrange(len(pools[lvl]))] for _ in range(count))
+        A = _as_u8(a, eng.elem_bytes)
+        for klen in (3, 16, 40, 130):
+            for shape in ("bytes", "bits20", "zeros", "mixed"):
+                if shape == "bytes":
+                    ks = [rng.randrange(256) for _ in range(count)]
+                elif shape == "bits20":
+                    ks = [rng.randrange(1 << 20) for _ in range(count)]
+                elif shape == "zeros":
+                    ks = [0] * count
+                else:                                   # the first wave small, the second zero, the rest full length
+                    ks = [rng.randrange(16) for _ in range(64)] + [0] * 64 + [rng.randrange(1 << (8 * klen)) for _ in range(count - 128)]
+                want = o.multconst(lvl, a, ks)
+                K = _scalars(ks, klen)
+                for quad_max in (0, -1):
+                    eng.set_option("quad_max_mc", quad_max)
+                    try:
+                        out = np.empty((count, eng.elem_bytes), dtype=np.uint8)
+                        check(eng._lib.bgn_multconst_batch(eng._h, count, lvl, _ptr(A), _ptr(K), klen, None, 0, _ptr(out)),
+                              "bgn_multconst_batch")
+                        assert out.tobytes() == want, (name, lvl, klen, shape, quad_max)
+                    finally:
+                        eng.set_option("quad_max_mc", -1)

@@ -138,7 +138,7 @@ def main():
             # multiples of the group order: the ladder's flagged fallback); lane groups against one element per lane
             lvl = 1 if op == "multconst_l1" else 2
             nn = int(K["fx"]["n"], 16)
-            klen = rng.choice([1, 5, 8, 16, 32, (nn.bit_length() + 7) // 8, (nn.bit_length() + 7) // 8 + 1])
+            klen = rng.choice([1, 3, 5, 8, 15, 16, 32, (nn.bit_length() + 7) // 8, (nn.bit_length() + 7) // 8 + 1])
             n = min(n, 70000 if klen <= 16 else 8192 if name != "k2048" else 64)
             src = (a if lvl == 1 else K["l2"][off * EB: (off + n) * EB])[: n * EB]
             g = torch.Generator().manual_seed(rng.randrange(1 << 30))
@@ -152,9 +152,13 @@ def main():
             kvs = ["default"] + (["quad", "lane"] if (name != "k2048" or n <= 48) else [])
             if lvl == 2 and name != "k2048":
                 kvs += ["lane, general power"]                # the lane kernel without the norm-1 ladder (round 6)
+            if lvl == 1 and 3 <= klen < 16 and name != "k2048":
+                kvs += ["lane, binary ladder"]                # the lane kernel without its 2-bit windows (round 6)
             for kv in kvs:
                 if kv == "lane, general power":
                     force("lane", multconst_l2_ladder=0)
+                elif kv == "lane, binary ladder":
+                    force("lane", g1_mul_window_short=0)
                 else:
                     force(kv)
                 out = torch.empty(n * EB, dtype=torch.uint8, device=dev)

@@ -708,7 +708,8 @@ k_gt_pow(const FpParams<NL>* __restrict__ P, GtPowArgs A) {
       fp_from_mont<NL>(c, n0, P, L);               // canonical: zero iff the norm is 1
       if (__all(fp_is_zero_limbs(c))) {
         Fp<NL> r0, r1, o;
-        gt_pow_norm1_lane<NL>(r0, r1, L, b0, b1, A.k + e * A.kstride, A.klen, (int)(A.klen * 8), A.p_bits, P);
+        const uint8_t* ke = A.k + e * A.kstride;
+        gt_pow_norm1_lane<NL>(r0, r1, L, b0, b1, ke, A.klen, wave_top_bit(ke, A.klen) + 1, A.p_bits, P);
         fp_from_mont<NL>(o, r0, P, L);             // r0 <5
         if (live) g_store<NL>(A.o0, A.so, e, o);
         fp_from_mont<NL>(o, r1, P, L);             // r1 <2

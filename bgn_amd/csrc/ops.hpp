@@ -318,9 +318,11 @@ __device__ __forceinline__ void gt_pow_norm1_lane(Fp<NL>& r0, Fp<NL>& r1, LFp<NL
     a_store(SX, x0);
     a_store(SY, x1);
   }
-  const int top = wave_top_bit(k, klen);      // (A_0, A_1) is a fixed point of a zero bit
+  // (callers pass wave_top_bit(k, klen) + 1 as nbits where small scalars in long fields are expected: (A_0, A_1) is a
+  // fixed point of a zero bit.  Computed HERE the same skip made the loop 4.5 % slower — same registers, no scratch, a
+  // different layout of a loop body the size of the instruction cache: profiles/r06_topskip_ab.txt)
 #pragma unroll 1
-  for (int i = (top < nbits ? top : nbits - 1); i >= 0; --i) {
+  for (int i = nbits - 1; i >= 0; --i) {
     const bool bit = scalar_bit(k, klen, i) != 0;
     Fp<NL> a, b, t, u;
     a_load(a, SA);                           // <5

@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 _, _, cts = syn.config2_ciphertexts(pk, 1 << 20, seed=7, device=dev)
 pool = cts.view(-1, EB)
-print("log2,count,run,ms,adds_per_s,k_g1_add_ms,products_per_add,frac_of_product_ceiling,four_launch_ms,same_bytes")
+print("log2,count,run,ms,adds_per_s,k_g1_add_ms,products_per_add,frac_of_one_wave_mad_ceiling,four_launch_ms,same_bytes")
 for lg in range(14, top + 1):
     n = 1 << lg
     g = torch.Generator(device="cpu"); g.manual_seed(lg)
@@ -43,5 +43,5 @@ for lg in range(14, top + 1):
     same = bool(torch.equal(o, o4))
     del o4
     print("%d,%d,%d,%.3f,%.4e,%.3f,%.2f,%.3f,%.3f,%s" % (lg, n, max(1, min(64, -(-n // 65536))), best * 1e3, n / best, kms, ppa,
-                                                      n / best * ppa / 8.15e9, best4 * 1e3, same), flush=True)
+                                                      n / best * syn.mads_from_counts(*syn.eadd_counts(n), nl=36) / 2.55e13, best4 * 1e3, same), flush=True)
     del a, b, o, ia, ib

@@ -167,6 +167,82 @@ def committed_traffic(key=None):
     return None, None
 
 
+def live_traffic(timeout_s=150.0):
+    """roofline.traffic of the headline kernel measured by THIS run (verdict r05, weak 6): before this process touches
+    the GPU, two child passes of this command's own timed step — `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
+    separate passes, no tracing domain, the program itself after `--` (MI355X_MICROARCH.md, HBM section) — over
+    `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`.  FETCH_SIZE is calibrated in the same pass on
+    k_encode's known read volume (2 NL x 4 bytes per element of limb-major SoA at 2^20 elements), as
+    tools/summarize_profiles.py does for the committed summaries.  Returns None — and the line falls back to the
+    committed summary, labelled as such — when rocprofv3 is missing, this process is itself being profiled, or a pass
+    fails or runs over its time; the children are started in their own process group and that group is ended on a
+    timeout."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None                                     # under a profiler already: no nested passes
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("BGN_BENCH_SPAWN", "BGN_BENCH_FORCE_DIST", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tmp = tempfile.mkdtemp(prefix="bgn_pmc_", dir="/tmp")
+    t0 = time.perf_counter()
+    kb, calib = {}, None
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr.lower())
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                   "--no-extra", "--no-live-traffic"]
+            proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)          # the group started above: rocprofv3 and its python child
+                except OSError:
+                    pass
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    rows += [r for r in csv.DictReader(fh) if r.get("Counter_Name") == ctr]
+            head = [float(r["Counter_Value"]) for r in rows if re.match(r"void bgn::k_pairing<\d+, 0>", r["Kernel_Name"])]
+            if not head:
+                return None
+            kb[ctr] = (sum(head) / len(head), len(head))
+            if ctr == "FETCH_SIZE":
+                enc = [r for r in rows if int(r["Grid_Size"]) == 1 << 20 and re.match(r"void bgn::k_encode<(\d+)>", r["Kernel_Name"])]
+                if enc:
+                    nl = int(re.match(r"void bgn::k_encode<(\d+)>", enc[0]["Kernel_Name"]).group(1))
+                    seen = sum(float(r["Counter_Value"]) for r in enc) / len(enc) * 1024
+                    if seen > 0:
+                        calib = {"kernel": "k_encode<%d>, 2^20 elements" % nl, "known_read_bytes": 2 * nl * 4 * (1 << 20),
+                                 "FETCH_SIZE_bytes": seen, "factor": 2 * nl * 4 * (1 << 20) / seen, "launches": len(enc)}
+    except Exception as e:                              # a measurement aid must never take the bench line down
+        print("bench.py: live PMC passes failed (%s): quoting the committed summary" % e, file=sys.stderr, flush=True)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    factor = calib["factor"] if calib else 2.0          # the guide's factor for FETCH_SIZE on gfx950 where no calibration ran
+    return {"hbm_bytes_per_launch": (kb["FETCH_SIZE"][0] * factor + kb["WRITE_SIZE"][0]) * 1024,
+            "FETCH_SIZE_KB": kb["FETCH_SIZE"][0], "WRITE_SIZE_KB": kb["WRITE_SIZE"][0], "launches": kb["FETCH_SIZE"][1],
+            "fetch_calibration": calib, "seconds": time.perf_counter() - t0,
+            "source": "measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; no tracing) of this "
+                      "command's timed step, before the timed region; FETCH_SIZE x %.3f (%s) + WRITE_SIZE, KB -> bytes"
+                      % (factor, "calibrated on k_encode's known read volume in the same pass" if calib else "the guide's factor")}
+
+
 def config0_metrics(no_cpu: bool):
     """BASELINE configs[0]: 512-bit params, 128 ciphertexts, pk.Add and pk.Mult over 128 independent pairs — the
     shape of BenchmarkAdd / BenchmarkMult (bgn_test.go:97-140), which the reference runs on one goroutine.  Host
@@ -640,6 +716,8 @@ def main():
     ap.add_argument("--decrypt-log2", type=int, nargs="+", default=[16, 20],
                     help="batch sizes (log2, at most 20) of the Decrypt measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and gather even with one rank")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="quote roofline.traffic from the committed PMC summary instead of measuring it in two child passes")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
@@ -652,6 +730,13 @@ def main():
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if args.gpus != world:
             sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N")
+
+    # roofline.traffic of the headline kernel, measured before this process touches the GPU (one GPU, the headline
+    # workload at its BASELINE size only; the children run without it)
+    live = None
+    if (world == 1 and not args.force_dist and os.environ.get("BGN_BENCH_FORCE_DIST") != "1" and not args.no_live_traffic
+            and args.workload == "emult" and args.key == "k1024" and args.batch_log2 == 20):
+        live = live_traffic()
 
     start_watchdog()
     # stdout carries ONE JSON line: native libraries that write to file descriptor 1 (RCCL prints a version banner
@@ -803,6 +888,8 @@ def main():
         traffic, traffic_src = committed_traffic() if full else (None, None)
         if traffic is not None:
             traffic_src += " (FETCH_SIZE + WRITE_SIZE per launch of 2^20 pairings)"
+        if live is not None and full:
+            traffic, traffic_src = live["hbm_bytes_per_launch"], live["source"]
         mad_rate = mads * count / (k_ms * 1e-3)
         if use_dist:
             assert rccl_ranks == world == args.gpus, "RCCL world differs from --gpus"
@@ -822,6 +909,8 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_passes": ({k: live[k] for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "launches", "fetch_calibration", "seconds")}
+                                            if live is not None and full else None),
                          "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_pairing": alg_bytes, "note": "per GPU (rank 0's kernel)"},
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_pairing": mads, "achieved": mad_rate,

@@ -161,3 +161,28 @@ def test_eight_ranks_one_dying_mid_gather_and_one_overrunning_the_cap(monkeypatc
     assert time.monotonic() - t0 < 30
     with pytest.raises(ProcessLookupError):
         os.kill(int(open(tmp_path / "pid6").read()), 0)
+
+
+def test_live_traffic_falls_back_quietly(monkeypatch, tmp_path):
+    """bench.py measures roofline.traffic itself in two rocprofv3 --pmc child passes; where that cannot work — no GPU
+    here, so the child bench exits non-zero; no rocprofv3; a profiler already around this process; a pass that hangs
+    — it returns None (the line then quotes the committed summary and says so) and leaves nothing behind in /tmp."""
+    import glob
+    bench = _load()
+    before = set(glob.glob("/tmp/bgn_pmc_*"))
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")                  # being profiled: no nested passes, nothing started
+    assert bench.live_traffic(timeout_s=5) is None
+    monkeypatch.delenv("ROCPROFILER_SOMETHING")
+    import shutil
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert bench.live_traffic(timeout_s=120) is None              # the child finds no GPU and exits non-zero
+    # a pass that never ends: a stand-in for rocprofv3 that sleeps; the whole process group is ended at the timeout
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\nsleep 600\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    import time
+    t0 = time.time()
+    assert bench.live_traffic(timeout_s=2) is None
+    assert time.time() - t0 < 30
+    assert set(glob.glob("/tmp/bgn_pmc_*")) == before

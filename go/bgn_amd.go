@@ -573,12 +573,18 @@ func (d *DeviceArray) UploadBytes(b []byte) error {
 	if len(b) != d.Count*d.Width {
 		return errors.New("bgn_amd: upload size does not match the device array")
 	}
+	if len(b) == 0 {
+		return nil
+	}
 	return locked(func() C.int { return C.bgn_dev_upload(d.e.h, d.p, unsafe.Pointer(&b[0]), C.size_t(len(b))) })
 }
 
 // DownloadBytes copies the array to host memory, after every call issued on this engine before it.
 func (d *DeviceArray) DownloadBytes() ([]byte, error) {
 	b := make([]byte, d.Count*d.Width)
+	if len(b) == 0 {
+		return b, nil
+	}
 	err := locked(func() C.int { return C.bgn_dev_download(d.e.h, unsafe.Pointer(&b[0]), d.p, C.size_t(len(b))) })
 	return b, err
 }

@@ -364,6 +364,54 @@ inline std::vector<uint64_t> UnbalancedEncode(uint64_t m, uint64_t base) {
 }
 
 class SecretKey;
+class PublicKey;
+
+// An array of wire elements (or scalars, plaintexts, status bytes) that stays on the key's device between calls — the
+// C++ twin of go/bgn_amd.go's DeviceArray over bgn_dev_alloc / _free / _upload / _download (include/bgn_amd.h), for
+// chains like MultPoly -> AddPoly -> Decrypt (poly.go:123-207 -> bgn.go:205) without a host round trip per step.
+// Owned by the caller (not counted in the context's memory, not subject to its budget); movable, not copyable.
+class DeviceArray {
+ public:
+  size_t Count = 0, Width = 0;   // elements, bytes per element
+  bool L2 = false;
+  DeviceArray() = default;
+  DeviceArray(bgn_ctx* h, size_t count, size_t width, bool l2) : Count(count), Width(width), L2(l2), h_(h) {
+    if (count * width == 0) throw Error(BGN_E_ARG, "empty device array");
+    p_ = bgn_dev_alloc(h, count * width);
+    if (!p_) throw Error(BGN_E_NOMEM, "bgn_dev_alloc");
+  }
+  ~DeviceArray() { reset(); }
+  DeviceArray(const DeviceArray&) = delete;
+  DeviceArray& operator=(const DeviceArray&) = delete;
+  DeviceArray(DeviceArray&& o) noexcept { *this = std::move(o); }
+  DeviceArray& operator=(DeviceArray&& o) noexcept {
+    if (this != &o) {
+      reset();
+      Count = o.Count; Width = o.Width; L2 = o.L2; h_ = o.h_; p_ = o.p_;
+      o.p_ = nullptr;
+    }
+    return *this;
+  }
+  uint8_t* data() const { return static_cast<uint8_t*>(p_); }
+  void UploadBytes(const Bytes& b) const {
+    if (b.size() != Count * Width) throw Error(BGN_E_ARG, "upload size does not match the device array");
+    check(bgn_dev_upload(h_, p_, b.data(), b.size()), "bgn_dev_upload");
+  }
+  // after every call issued on this key before it (the copies run on the null stream, as the `_dev` calls below)
+  Bytes DownloadBytes() const {
+    Bytes b(Count * Width);
+    check(bgn_dev_download(h_, b.data(), p_, b.size()), "bgn_dev_download");
+    return b;
+  }
+
+ private:
+  void reset() {
+    if (p_) bgn_dev_free(h_, p_);
+    p_ = nullptr;
+  }
+  bgn_ctx* h_ = nullptr;
+  void* p_ = nullptr;
+};
 
 // bgn.go:28-41 (hot-path members)
 class PublicKey {
@@ -415,6 +463,82 @@ class PublicKey {
     if (r) rb = pack(*r, rl);
     check(bgn_mult_batch(h_, a.size(), A.data(), B.data(), r ? rb.data() : nullptr, rl, out.data()), "bgn_mult_batch");
     return split(out, true);
+  }
+
+  // ---- the same over arrays that stay on the device (bgn_*_batch_dev on the null stream) ----
+  DeviceArray Upload(const std::vector<Ciphertext>& cts) const {
+    DeviceArray d(h_, cts.size(), E_, !cts.empty() && cts[0].L2);
+    d.UploadBytes(join(cts));
+    return d;
+  }
+  std::vector<Ciphertext> Download(const DeviceArray& d) const { return split(d.DownloadBytes(), d.L2); }
+  DeviceArray EncryptBatchDev(const std::vector<Scalar>& x, const std::vector<Scalar>* r) const {
+    size_t xl = 0, rl = 0;
+    DeviceArray dx = scalars_dev(x, xl), dr, out(h_, x.size(), E_, false);
+    if (r) dr = scalars_dev(*r, rl);
+    check(bgn_encrypt_batch_dev(h_, x.size(), dx.data(), xl, r ? dr.data() : nullptr, rl, out.data(), nullptr),
+          "bgn_encrypt_batch_dev");
+    return out;
+  }
+  // operands of one level (lift with MakeL2BatchDev first where the reference would, bgn.go:444-452); the result may
+  // be written over an operand with the *Into forms (accumulating, poly.go:171-207)
+  DeviceArray AddBatchDev(const DeviceArray& a, const DeviceArray& b, const std::vector<Scalar>* r = nullptr,
+                          bool subtract = false) const {
+    DeviceArray out(h_, a.Count, E_, a.L2);
+    AddBatchDevInto(out, a, b, r, subtract);
+    return out;
+  }
+  void AddBatchDevInto(const DeviceArray& out, const DeviceArray& a, const DeviceArray& b,
+                       const std::vector<Scalar>* r = nullptr, bool subtract = false) const {
+    if (a.Count != b.Count || a.L2 != b.L2 || out.Count != a.Count) throw Error(BGN_E_ARG, "operand arrays differ in count or level");
+    size_t rl = 0;
+    DeviceArray dr;
+    if (r) dr = scalars_dev(*r, rl);
+    check((subtract ? bgn_sub_batch_dev : bgn_add_batch_dev)(h_, a.Count, a.L2 ? 2 : 1, a.data(), b.data(),
+                                                             r ? dr.data() : nullptr, rl, out.data(), nullptr),
+          subtract ? "bgn_sub_batch_dev" : "bgn_add_batch_dev");
+  }
+  DeviceArray NegBatchDev(const DeviceArray& a) const {
+    DeviceArray out(h_, a.Count, E_, a.L2);
+    check(bgn_neg_batch_dev(h_, a.Count, a.L2 ? 2 : 1, a.data(), out.data(), nullptr), "bgn_neg_batch_dev");
+    return out;
+  }
+  DeviceArray MultBatchDev(const DeviceArray& a, const DeviceArray& b, const std::vector<Scalar>* r = nullptr) const {
+    if (a.Count != b.Count || a.L2 || b.L2) throw Error(BGN_E_ARG, "Mult takes level-1 arrays of one length");
+    size_t rl = 0;
+    DeviceArray dr, out(h_, a.Count, E_, true);
+    if (r) dr = scalars_dev(*r, rl);
+    check(bgn_mult_batch_dev(h_, a.Count, a.data(), b.data(), r ? dr.data() : nullptr, rl, out.data(), nullptr),
+          "bgn_mult_batch_dev");
+    return out;
+  }
+  DeviceArray MakeL2BatchDev(const DeviceArray& a) const {
+    DeviceArray out(h_, a.Count, E_, true);
+    check(bgn_make_l2_batch_dev(h_, a.Count, a.data(), out.data(), nullptr), "bgn_make_l2_batch_dev");
+    return out;
+  }
+  DeviceArray MultConstBatchDev(const DeviceArray& a, const std::vector<Scalar>& k, const std::vector<Scalar>* r = nullptr) const {
+    if (k.size() != a.Count) throw Error(BGN_E_ARG, "one scalar per element");
+    size_t kl = 0, rl = 0;
+    DeviceArray dk = scalars_dev(k, kl), dr, out(h_, a.Count, E_, a.L2);
+    if (r) dr = scalars_dev(*r, rl);
+    check(bgn_multconst_batch_dev(h_, a.Count, a.L2 ? 2 : 1, a.data(), dk.data(), kl, r ? dr.data() : nullptr, rl,
+                                  out.data(), nullptr),
+          "bgn_multconst_batch_dev");
+    return out;
+  }
+  // npoly products of d1 x d2 level-1 coefficient vectors (poly.go:123-156), a and b polynomial after polynomial:
+  // npoly * (d1 + d2) level-2 coefficients
+  DeviceArray MultPolyBatchDev(size_t npoly, size_t d1, size_t d2, const DeviceArray& a, const DeviceArray& b) const {
+    if (a.Count != npoly * d1 || b.Count != npoly * d2 || a.L2 || b.L2) throw Error(BGN_E_ARG, "coefficient arrays do not match npoly*d1 / npoly*d2");
+    DeviceArray out(h_, npoly * (d1 + d2), E_, true);
+    check(bgn_poly_mult_batch_dev(h_, npoly, d1, d2, a.data(), b.data(), out.data(), nullptr), "bgn_poly_mult_batch_dev");
+    return out;
+  }
+  std::vector<uint8_t> ValidateBatchDev(const DeviceArray& a) const {
+    DeviceArray ok(h_, a.Count, 1, false);
+    check(bgn_validate_batch_dev(h_, a.Count, a.L2 ? 2 : 1, a.data(), ok.data(), nullptr), "bgn_validate_batch_dev");
+    return ok.DownloadBytes();
   }
 
   // ---- bgn.go:325-353 ----
@@ -656,6 +780,12 @@ class PublicKey {
     }
     return AddBatch({a}, {b}, nullptr, subtract)[0];
   }
+  DeviceArray scalars_dev(const std::vector<Scalar>& v, size_t& len) const {
+    Bytes b = pack(v, len);
+    DeviceArray d(h_, v.size(), len, false);
+    d.UploadBytes(b);
+    return d;
+  }
   static Bytes pack(const std::vector<Scalar>& v, size_t& len) {
     len = 1;
     for (const auto& s : v) len = s.size() > len ? s.size() : len;
@@ -695,6 +825,17 @@ class SecretKey {
     Bytes A = pk.join(cts);
     check(bgn_decrypt_batch(pk.h_, cts.size(), cts[0].L2 ? 2 : 1, A.data(), m.data(), st.data()), "bgn_decrypt_batch");
     return {m, st};
+  }
+  // the same for an array on the device: plaintexts and statuses come back to the host (8 + 1 bytes per element)
+  std::pair<std::vector<int64_t>, std::vector<uint8_t>> DecryptBatchDev(const DeviceArray& cts, const PublicKey& pk) const {
+    DeviceArray dm(pk.h_, cts.Count, 8, false), ds(pk.h_, cts.Count, 1, false);
+    check(bgn_decrypt_batch_dev(pk.h_, cts.Count, cts.L2 ? 2 : 1, cts.data(), reinterpret_cast<int64_t*>(dm.data()), ds.data(),
+                                nullptr),
+          "bgn_decrypt_batch_dev");
+    Bytes mb = dm.DownloadBytes();
+    std::vector<int64_t> m(cts.Count);
+    std::memcpy(m.data(), mb.data(), mb.size());
+    return {m, ds.DownloadBytes()};
   }
   int64_t Decrypt(const Ciphertext& ct, const PublicKey& pk) const {
     auto r = DecryptBatch({ct}, pk);

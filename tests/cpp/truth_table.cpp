@@ -154,6 +154,45 @@ int main(int argc, char** argv) {
       expect("validate good", ok[0] + ok[1] + ok[2], 3);
       expect("validate off-curve", pk.Validate({broken})[0], 0);
     }
+    // chains on arrays that stay on the device (DeviceArray: the C++ twin of go/bgn_amd.go's, over bgn_dev_* and the
+    // `_dev` entry points): Encrypt -> Mult -> Add -> Add in place -> Neg -> makeL2 -> MultConst -> Decrypt with one
+    // upload of scalars per step and one download of plaintexts at the end; MultPoly on device coefficient arrays
+    {
+      std::vector<Scalar> xs, rs3, ks;
+      for (uint64_t i = 1; i <= 6; ++i) {
+        xs.push_back(scalar_u64(i));
+        rs3.push_back(scalar_u64(100 + i));
+        ks.push_back(scalar_u64(i % 4 + 1));
+      }
+      DeviceArray c = pk.EncryptBatchDev(xs, &rs3);
+      std::vector<Ciphertext> host = pk.EncryptBatch(xs, &rs3), back = pk.Download(c);
+      for (size_t i = 0; i < host.size(); ++i)
+        if (back[i].C != host[i].C || back[i].L2) { printf("MISMATCH EncryptBatchDev element %zu\n", i); bad++; }
+      DeviceArray prod = pk.MultBatchDev(c, c);                       // x^2
+      DeviceArray sum = pk.AddBatchDev(prod, prod);                   // 2 x^2
+      pk.AddBatchDevInto(sum, sum, prod);                             // 3 x^2, accumulated in place
+      DeviceArray tot = pk.AddBatchDev(sum, pk.MakeL2BatchDev(pk.NegBatchDev(c)));   // 3 x^2 - x
+      DeviceArray mc = pk.MultConstBatchDev(tot, ks);
+      auto dec = sk.DecryptBatchDev(mc, pk);
+      for (uint64_t i = 1; i <= 6; ++i)
+        expect("device chain (3x^2 - x) * k", dec.second[i - 1] ? -1 : dec.first[i - 1], (int64_t)((3 * i * i - i) * (i % 4 + 1)));
+      std::vector<uint8_t> ok = pk.ValidateBatchDev(c);
+      expect("ValidateBatchDev", ok[0] + ok[1] + ok[2] + ok[3] + ok[4] + ok[5], 6);
+      // two products of 2 x 2 coefficient vectors: elements 0..3 times elements 2..5
+      std::vector<Ciphertext> pa(host.begin(), host.begin() + 4), pb(host.begin() + 2, host.begin() + 6);
+      DeviceArray da = pk.Upload(pa), db = pk.Upload(pb);
+      std::vector<Ciphertext> pd = pk.Download(pk.MultPolyBatchDev(2, 2, 2, da, db));
+      Bytes A, B, ref(2 * 4 * pk.ElementBytes());
+      for (auto& x : pa) A.insert(A.end(), x.C.begin(), x.C.end());
+      for (auto& x : pb) B.insert(B.end(), x.C.begin(), x.C.end());
+      int rc = bgn_poly_mult_batch(pk.handle(), 2, 2, 2, A.data(), B.data(), ref.data());
+      if (rc != BGN_OK) throw Error(rc, "bgn_poly_mult_batch");
+      for (size_t i = 0; i < pd.size(); ++i)
+        if (!pd[i].L2 || memcmp(pd[i].C.data(), ref.data() + i * pk.ElementBytes(), pk.ElementBytes()) != 0) {
+          printf("MISMATCH MultPolyBatchDev coefficient %zu\n", i);
+          bad++;
+        }
+    }
     // one key on several devices from one process through the C ABI (bgn_mctx_*): the device list names GPU 0
     // three times, which gives real multi-context sharding on a one-GPU box; ragged shards, MultPoly by polynomial
     {

@@ -254,6 +254,44 @@ class Engine:
                                           r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
                                           self._stream()), "bgn_add_batch_dev")
 
+    def sub_dev(self, level: int, a, b, out, count: Optional[int] = None, r=None, r_len: int = 0) -> None:
+        """Device-resident Sub (bgn.go:375-433); `out` may be `a` or `b` itself, as for add_dev."""
+        count = a.numel() // self.elem_bytes if count is None else count
+        for what, t in (("a", a), ("b", b), ("out", out)):
+            self._need(what, t, count * self.elem_bytes)
+        self._need("r", r, count * r_len)
+        check(self._lib.bgn_sub_batch_dev(self._h, count, level, a.data_ptr(), b.data_ptr(),
+                                          r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
+                                          self._stream()), "bgn_sub_batch_dev")
+
+    def neg_dev(self, level: int, a, out, count: Optional[int] = None) -> None:
+        """Device-resident Neg (bgn.go:436-438); `out` may be `a` itself."""
+        count = a.numel() // self.elem_bytes if count is None else count
+        self._need("a", a, count * self.elem_bytes)
+        self._need("out", out, count * self.elem_bytes)
+        check(self._lib.bgn_neg_batch_dev(self._h, count, level, a.data_ptr(), out.data_ptr(), self._stream()),
+              "bgn_neg_batch_dev")
+
+    def multconst_dev(self, level: int, a, k, k_len: int, out, count: Optional[int] = None, r=None, r_len: int = 0) -> None:
+        """Device-resident MultConst (bgn.go:253-291): k holds count x k_len big-endian scalar bytes on the device;
+        `out` may be `a` itself."""
+        count = a.numel() // self.elem_bytes if count is None else count
+        self._need("a", a, count * self.elem_bytes)
+        self._need("k", k, count * k_len)
+        self._need("r", r, count * r_len)
+        self._need("out", out, count * self.elem_bytes)
+        check(self._lib.bgn_multconst_batch_dev(self._h, count, level, a.data_ptr(), k.data_ptr(), k_len,
+                                                r.data_ptr() if r is not None else None, r_len, out.data_ptr(),
+                                                self._stream()), "bgn_multconst_batch_dev")
+
+    def validate_dev(self, level: int, a, ok, count: Optional[int] = None) -> None:
+        """ok[i] = 1 per element that is a valid encoding (bgn_validate_batch_dev)."""
+        count = a.numel() // self.elem_bytes if count is None else count
+        self._need("a", a, count * self.elem_bytes)
+        self._need("ok", ok, count)
+        check(self._lib.bgn_validate_batch_dev(self._h, count, level, a.data_ptr(), ok.data_ptr(), self._stream()),
+              "bgn_validate_batch_dev")
+
     def decrypt_dev(self, level: int, ct, m, status, count: Optional[int] = None) -> None:
         count = ct.numel() // self.elem_bytes if count is None else count
         self._need("ct", ct, count * self.elem_bytes)

@@ -151,6 +151,38 @@ def test_one_launch_kernels_in_place(name):
             torch.cuda.synchronize()
             assert (ta if which == 0 else tb).cpu().numpy().tobytes() == want, (lvl, which)
         ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
-        assert eng._lib.bgn_neg_batch_dev(eng._h, n, lvl, ta.data_ptr(), ta.data_ptr(), eng._stream()) == 0
+        eng.neg_dev(lvl, ta, ta, n)
         torch.cuda.synchronize()
         assert ta.cpu().numpy().tobytes() == want_neg, lvl
+
+
+def test_sub_and_validate_on_device_arrays():
+    """The host mirror's sub_dev / validate_dev (bgn_sub_batch_dev, bgn_validate_batch_dev) against the host-buffer forms,
+    both levels; a device array shorter than the call needs is refused before any pointer reaches the C side."""
+    import torch
+    fx = load_fixture("k256")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    dev = torch.device("cuda", 0)
+    pools = {1: [bytes.fromhex(e["ct"]) for e in fx["encrypt"]], 2: [bytes.fromhex(v["out"]) for v in fx["mult"]]}
+    n = 777
+    for lvl, pool in pools.items():
+        a = b"".join(pool[(2 * i + 1) % len(pool)] for i in range(n))
+        b = b"".join(pool[(5 * i) % len(pool)] for i in range(n))
+        ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+        tb = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        to = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+        eng.sub_dev(lvl, ta, tb, to, n)
+        torch.cuda.synchronize()
+        assert to.cpu().numpy().tobytes() == eng.sub(lvl, a, b).tobytes(), lvl
+        broken = bytearray(a)
+        broken[EB - 1] ^= 1                                          # element 0 leaves the curve / the norm-1 set
+        tv = torch.frombuffer(broken, dtype=torch.uint8).to(dev)
+        ok = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        eng.validate_dev(lvl, tv, ok, n)
+        torch.cuda.synchronize()
+        got = ok.cpu().numpy()
+        assert got[0] == 0 and got[1:].tolist() == eng.validate(lvl, bytes(broken))[1:].tolist() and got[1:].min() == 1, lvl
+        with pytest.raises(ValueError):
+            eng.sub_dev(lvl, ta, tb, to[: n * EB - 1], n)

@@ -93,8 +93,6 @@ def test_multconst_in_place_on_device_arrays(name, count):
             kb = np.frombuffer(b"".join(k.to_bytes(klen, "big") for k in ks), dtype=np.uint8)
             ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
             tk = torch.from_numpy(kb.copy()).to(dev)
-            rc = eng._lib.bgn_multconst_batch_dev(eng._h, cnt, lvl, ta.data_ptr(), tk.data_ptr(), klen, None, 0,
-                                                  ta.data_ptr(), eng._stream())
-            assert rc == 0, eng.last_error() if hasattr(eng, "last_error") else rc
+            eng.multconst_dev(lvl, ta, tk, klen, ta, cnt)
             torch.cuda.synchronize()
             assert ta.cpu().numpy().tobytes() == want, (lvl, cnt)

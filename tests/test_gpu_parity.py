@@ -64,6 +64,49 @@ def test_mult_empty_batch():
     assert pk.engine.mult(b"", b"").shape == (0, pk.engine.elem_bytes)
 
 
+@pytest.mark.parametrize("name", ["toy64", "k1024"])
+def test_every_entry_point_takes_an_empty_batch(name):
+    """count = 0 is a valid call on every entry point, host and device arrays: success, nothing launched with an empty
+    grid, nothing written (the one-launch Add / Sub / Neg kernels and the 2-bit-window MultConst of round 6 included),
+    and the context works afterwards."""
+    import numpy as np
+    import torch
+    fx = load_fixture(name)
+    pk, sk = engine_key(fx)
+    pk.SetupDecryption(sk)
+    eng = pk.engine
+    EB = eng.elem_bytes
+    shape = (0, EB)
+    for lvl in (1, 2):
+        assert eng.add(lvl, b"", b"").shape == shape and eng.sub(lvl, b"", b"").shape == shape
+        assert eng.neg(lvl, b"").shape == shape
+        assert eng.multconst(lvl, b"", []).shape == shape
+        m, st = eng.decrypt(lvl, b"")
+        assert len(m) == 0 and len(st) == 0
+        assert len(eng.validate(lvl, b"")) == 0
+    assert eng.encrypt([], []).shape == shape and eng.make_l2(b"").shape == shape
+    assert eng.poly_mult(0, 2, 2, b"", b"").shape == shape
+    dev = torch.device("cuda", 0)
+    guard = torch.full((64,), 0xEE, dtype=torch.uint8, device=dev)
+    k = torch.zeros(8, dtype=torch.uint8, device=dev)
+    m = torch.zeros(1, dtype=torch.int64, device=dev)
+    for lvl in (1, 2):
+        eng.add_dev(lvl, guard, guard, guard, 0)
+        eng.sub_dev(lvl, guard, guard, guard, 0)
+        eng.neg_dev(lvl, guard, guard, 0)
+        eng.multconst_dev(lvl, guard, k, 5, guard, 0)
+        eng.validate_dev(lvl, guard, guard, 0)
+        eng.decrypt_dev(lvl, guard, m, guard, 0)
+    eng.mult_dev(guard, guard, guard, 0)
+    eng.make_l2_dev(guard, guard, 0)
+    eng.encrypt_dev(k, 5, None, 0, guard, 0)
+    torch.cuda.synchronize()
+    assert bool((guard == 0xEE).all().item())
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    assert bytes(eng.add(1, cts[0], cts[1])[0]).hex() == next(v["add"] for v in fx["l1"] if v["a"] == 0 and v["b"] == 1) \
+        if any(v["a"] == 0 and v["b"] == 1 for v in fx["l1"]) else True
+
+
 # ---------------------------------------------------------------------------
 # Encrypt / Add / Sub / Neg / MultConst against the golden vectors
 # ---------------------------------------------------------------------------

@@ -3636,7 +3636,8 @@ int bgn_dev_download(bgn_ctx* c, void* dst_host, const void* src_dev, size_t byt
 int bgn_last_kernel_resources(bgn_ctx* c, int64_t out[4]) {
   if (!c || !out) return fail(BGN_E_ARG, "null argument");
   const void* fn = nullptr;
-  if (c->last_kernel && !strcmp(c->last_kernel, "k_gt_mul_wire")) fn = c->kt->gt_mul_wire_entry;
+  for (const KernelTable::Entry* e = c->kt->entries; c->last_kernel && e->name; ++e)
+    if (!strcmp(c->last_kernel, e->name)) fn = e->fn;
   if (!fn) return fail(BGN_E_ARG, "no entry point known for %s", c->last_kernel ? c->last_kernel : "(none)");
   HIP_TRY(hipSetDevice(c->device));
   hipFuncAttributes at;

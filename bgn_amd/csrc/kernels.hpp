@@ -289,6 +289,9 @@ struct KernelTable {
   void (*gt_mul_wire)(hipStream_t s, const void* params, const void* barrett, const uint8_t* a, const uint8_t* b, int L,
                       size_t count, int conj_b, uint8_t* out);
   const void* gt_mul_wire_entry;      // the kernel's host-side handle (hipFuncGetAttributes: bgn_last_kernel_resources)
+  // host-side handles of the lane kernels by the name bgn_last_kernel_name reports (the same query); null-terminated
+  struct Entry { const char* name; const void* fn; };
+  Entry entries[12];
 };
 
 const KernelTable* kernel_table_nl3();

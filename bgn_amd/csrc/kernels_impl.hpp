@@ -1255,6 +1255,19 @@ const KernelTable* BGN_CAT(kernel_table_nl, BGN_NL)() {
       nullptr,              // 72 limbs: the fully unrolled products would be 50 k instructions; the four-launch route serves
       nullptr,
 #endif
+      {{"k_pairing<" BGN_STR(BGN_NL) ", 0>", (const void*)k_pairing<NL_, 0>},
+       {"k_pairing<" BGN_STR(BGN_NL) ", 1>", (const void*)k_pairing<NL_, 1>},
+       {"k_g1_add_wire", (const void*)k_g1_add_wire<NL_>},
+       {"k_neg_wire", (const void*)k_neg_wire<NL_>},
+#if BGN_NL <= 40
+       {"k_gt_mul_wire", (const void*)k_gt_mul_wire<NL_>},
+#endif
+       {"k_g1_add", (const void*)k_g1_add<NL_>},
+       {"k_gt_mul", (const void*)k_gt_mul<NL_>},
+       {"k_g1_mul", (const void*)k_g1_mul<NL_>},
+       {"k_gt_pow", (const void*)k_gt_pow<NL_>},
+       {"k_g1_fixed_chain", (const void*)k_g1_fixed_chain<NL_>},
+       {nullptr, nullptr}},
   };
   return &t;
 }

@@ -139,3 +139,50 @@ def test_fused_kernel_holds_everything_in_registers():
     res = eng.last_kernel_resources()
     assert res["scratch_bytes_per_lane"] == 0, res
     assert res["vgprs"] <= 256 and res["lds_bytes_per_workgroup"] <= 80 * 1024, res
+
+
+def test_code_object_resources_of_the_lane_kernels():
+    """What the code objects of the kernels behind the bench line say (hipFuncGetAttributes through
+    bgn_last_kernel_resources, by the name bgn_last_kernel_name reports): the 512-register kernels hold at most the
+    known few hundred bytes of scratch, the one-launch codec kernels none.  Written to
+    gpurun_out/r06_kernel_resources.json (tracked copy: profiles/)."""
+    import json
+    import os
+    import random
+    from conftest import ROOT
+    fx = load_fixture("k1024")
+    pk, _ = engine_key(fx)
+    eng = pk.engine
+    rng = random.Random(5)
+    cts = [bytes.fromhex(e["ct"]) for e in fx["encrypt"]]
+    l2 = [bytes.fromhex(v["out"]) for v in fx["mult"]]
+    n = 66000                                                    # past every lane-group crossover: the lane kernels
+    a1 = b"".join(cts[i % len(cts)] for i in range(n))
+    a2 = b"".join(l2[i % len(l2)] for i in range(n))
+    ks = [rng.randrange(1 << 40) for _ in range(n)]
+    order = int(fx["n"], 16)
+    rs = [rng.randrange(order) for _ in range(n)]                # full-length randomness: the chain kernel
+    calls = {
+        "mult": lambda: eng.mult(a1, a1),
+        "add_l1": lambda: eng.add(1, a1, a1),
+        "add_l2": lambda: eng.add(2, a2, a2),
+        "neg_l1": lambda: eng.neg(1, a1),
+        "multconst_l1": lambda: eng.multconst(1, a1, ks),
+        "multconst_l2": lambda: eng.multconst(2, a2, ks),
+        "encrypt": lambda: eng.encrypt(ks, rs),
+    }
+    want = {"mult": "k_pairing<36, 0>", "add_l1": "k_g1_add_wire", "add_l2": "k_gt_mul_wire", "neg_l1": "k_neg_wire",
+            "multconst_l1": "k_g1_mul", "multconst_l2": "k_gt_pow", "encrypt": "k_g1_fixed_chain"}
+    out = {}
+    for op, fn in calls.items():
+        fn()
+        name = eng.last_kernel_name()
+        assert name == want[op], (op, name)
+        out[op] = dict(eng.last_kernel_resources(), kernel=name)
+    for op in ("add_l2", "neg_l1"):
+        assert out[op]["scratch_bytes_per_lane"] == 0, out[op]
+    for op, r in out.items():
+        assert r["scratch_bytes_per_lane"] <= 1024 and r["lds_bytes_per_workgroup"] <= 160 * 1024, (op, r)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r06_kernel_resources.json"), "w") as f:
+        json.dump(out, f, indent=1)

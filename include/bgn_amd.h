@@ -406,7 +406,8 @@ const char* bgn_last_kernel_name(bgn_ctx* ctx);
 double bgn_last_aux_kernel_ms(bgn_ctx* ctx);
 const char* bgn_last_aux_kernel_name(bgn_ctx* ctx);
 /* What the code object says about the kernel bgn_last_kernel_name names, when the engine knows its entry point
- * (today: k_gt_mul_wire, the fused level-2 Add / Sub): out[0] = vector registers per lane, out[1] = scratch
+ * (the lane kernels: k_pairing<NL, 0|1>, k_g1_add_wire, k_gt_mul_wire, k_neg_wire, k_g1_add, k_gt_mul, k_g1_mul,
+ * k_gt_pow, k_g1_fixed_chain): out[0] = vector registers per lane, out[1] = scratch
  * (private-segment) bytes per lane, out[2] = static LDS bytes per workgroup, out[3] = threads per workgroup the
  * kernel may be launched with.  A kernel that is meant to hold everything in registers and has started to spill
  * shows here before it shows on a clock.  Returns BGN_E_ARG for a kernel it has no entry point of. */

@@ -167,11 +167,13 @@ def committed_traffic(key=None):
     return None, None
 
 
-def live_traffic(timeout_s=150.0):
+def live_traffic(timeout_s=150.0, extras=False):
     """roofline.traffic of the headline kernel measured by THIS run (verdict r05, weak 6): before this process touches
     the GPU, two child passes of this command's own timed step — `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
     separate passes, no tracing domain, the program itself after `--` (MI355X_MICROARCH.md, HBM section) — over
-    `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`.  FETCH_SIZE is calibrated in the same pass on
+    `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra` (with `extras`: `--pmc-extras`, which adds ONE launch
+    each of the secondary kernels whose traffic the line quotes — the two Adds of 2^20, Decrypt's lifts at 2^16 and
+    2^20: pmc_extras).  FETCH_SIZE is calibrated in the same pass on
     k_encode's known read volume (2 NL x 4 bytes per element of limb-major SoA at 2^20 elements), as
     tools/summarize_profiles.py does for the committed summaries.  Returns None — and the line falls back to the
     committed summary, labelled as such — when rocprofv3 is missing, this process is itself being profiled, or a pass
@@ -193,13 +195,13 @@ def live_traffic(timeout_s=150.0):
         env.pop(k, None)
     tmp = tempfile.mkdtemp(prefix="bgn_pmc_", dir="/tmp")
     t0 = time.perf_counter()
-    kb, calib = {}, None
+    kb, calib, sec = {}, None, {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr.lower())
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-                   "--no-extra", "--no-live-traffic"]
+                   "--no-extra", "--no-live-traffic"] + (["--pmc-extras"] if extras else [])
             proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                     start_new_session=True)
             try:
@@ -221,6 +223,20 @@ def live_traffic(timeout_s=150.0):
             if not head:
                 return None
             kb[ctr] = (sum(head) / len(head), len(head))
+            if extras:
+                # the launches --pmc-extras adds after the timed step (pmc_extras below): ONE level-1 Add and ONE level-2
+                # Add of 2^20, Decrypt of 2^16 and of 2^20 (their lifts: the two launches of k_pairing<NL, 1> on 65536
+                # lanes, the shorter one the 2^16 batch)
+                def avg(sel):
+                    v = [float(r["Counter_Value"]) for r in sel]
+                    return sum(v) / len(v) if v else None
+                dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                sec.setdefault("eadd_l1", {})[ctr] = avg([r for r in rows if "k_g1_add_wire<" in r["Kernel_Name"] and int(r["Grid_Size"]) == 65536])
+                sec.setdefault("eadd_l2", {})[ctr] = avg([r for r in rows if "k_gt_mul_wire<" in r["Kernel_Name"] and int(r["Grid_Size"]) == 1 << 20])
+                lifts = sorted((r for r in rows if re.match(r"void bgn::k_pairing<\d+, 1>", r["Kernel_Name"]) and int(r["Grid_Size"]) == 65536), key=dur)
+                if len(lifts) >= 2 and dur(lifts[-1]) > 4 * dur(lifts[0]):
+                    sec.setdefault("decrypt_lift_2^16", {})[ctr] = float(lifts[0]["Counter_Value"])
+                    sec.setdefault("decrypt_lift_k_pairing_1", {})[ctr] = float(lifts[-1]["Counter_Value"])
             if ctr == "FETCH_SIZE":
                 enc = [r for r in rows if int(r["Grid_Size"]) == 1 << 20 and re.match(r"void bgn::k_encode<(\d+)>", r["Kernel_Name"])]
                 if enc:
@@ -235,12 +251,46 @@ def live_traffic(timeout_s=150.0):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     factor = calib["factor"] if calib else 2.0          # the guide's factor for FETCH_SIZE on gfx950 where no calibration ran
-    return {"hbm_bytes_per_launch": (kb["FETCH_SIZE"][0] * factor + kb["WRITE_SIZE"][0]) * 1024,
+    secondary = {k: (v["FETCH_SIZE"] * factor + v["WRITE_SIZE"]) * 1024 for k, v in sec.items()
+                 if v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None}
+    return {"hbm_bytes_per_launch": (kb["FETCH_SIZE"][0] * factor + kb["WRITE_SIZE"][0]) * 1024, "secondary": secondary,
             "FETCH_SIZE_KB": kb["FETCH_SIZE"][0], "WRITE_SIZE_KB": kb["WRITE_SIZE"][0], "launches": kb["FETCH_SIZE"][1],
             "fetch_calibration": calib, "seconds": time.perf_counter() - t0,
             "source": "measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; no tracing) of this "
-                      "command's timed step, before the timed region; FETCH_SIZE x %.3f (%s) + WRITE_SIZE, KB -> bytes"
-                      % (factor, "calibrated on k_encode's known read volume in the same pass" if calib else "the guide's factor")}
+                      "command's timed step%s, before the timed region; FETCH_SIZE x %.3f (%s) + WRITE_SIZE, KB -> bytes"
+                      % (" and of one launch each of the secondary kernels (--pmc-extras)" if extras else "", factor, "calibrated on k_encode's known read volume in the same pass" if calib else "the guide's factor")}
+
+
+def secondary_traffic(live, key, committed_field):
+    """(bytes, source) of a secondary kernel's HBM traffic: from this run's own PMC passes when they covered it
+    (live_traffic(extras=True)), else from the committed summary, labelled."""
+    if live and key in live.get("secondary", {}):
+        return live["secondary"][key], live["source"]
+    node, src = committed_traffic(key)
+    v = (node or {}).get(committed_field)
+    return v, (src if v is not None else None)
+
+
+def pmc_extras(pk, fx, dev, cts, xs, prods):
+    """--pmc-extras (the child passes of live_traffic only): after the timed step, ONE launch each of the secondary
+    kernels whose `traffic` the line quotes — the level-1 and the level-2 Add of 2^20, Decrypt of 2^16 and of 2^20 on the
+    mixed batch of secondary_metrics — untimed, unchecked (the parent measures and checks them itself)."""
+    import torch
+    import bgn_amd
+    import bgn_amd.synthetic as syn
+    eng = pk.engine
+    EB = eng.elem_bytes
+    n = cts.numel() // EB
+    o = torch.empty(n * EB, dtype=torch.uint8, device=dev)
+    eng.add_dev(1, cts, syn.permuted_copy(cts, EB, seed=11), o, n)
+    eng.add_dev(2, prods, syn.permuted_copy(prods, EB, seed=13), o, n)
+    pk.SetupDecryption(bgn_amd.SecretKey(int(fx["q1"], 16)))
+    mixed, _, _ = syn.decrypt_mix(pk, fx, cts, xs, dev)
+    for k in (16, 20):
+        m = torch.empty(1 << k, dtype=torch.int64, device=dev)
+        st = torch.empty(1 << k, dtype=torch.uint8, device=dev)
+        eng.decrypt_dev(1, mixed[: (EB << k)], m, st, 1 << k)
+    torch.cuda.synchronize()
 
 
 def config0_metrics(no_cpu: bool):
@@ -356,7 +406,7 @@ def mid_batch_metrics(eng, a, b, dev):
                         "by the engine's batch-size dispatch; measured before the headline's warm-up steps"}
 
 
-def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_log2=14, prods=None):
+def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_log2=14, prods=None, live=None):
     """BASELINE configs[1] (Encrypt), EAdd on both levels, MultConst, configs[4]'s shape on one GPU and configs[3]
     (BSGS Decrypt, T = 2^40), on the Config-2 ciphertexts `cts` = Encrypt(xs, rs) the headline used and on its products
     `prods` (level-2 ciphertexts).  Inputs resident in HBM; one warm-up pass
@@ -407,8 +457,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
     # before) from the committed PMC passes of this command (tools/summarize_profiles.py), next to its algorithmic bytes
     eadd_traffic, eadd_src = None, None
     if n_add == 1 << 20:
-        node, eadd_src = committed_traffic("eadd_l1")
-        eadd_traffic = (node or {}).get("hbm_bytes_per_call")
+        eadd_traffic, eadd_src = secondary_traffic(live, "eadd_l1", "hbm_bytes_per_call")
     alg_add = 3 * EB * n_add
     out["eadd_l1"]["roofline"] = {"bound": "hbm", "achieved": alg_add / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": alg_add / dt / 1e9 / HBM_PEAK_GBS, "traffic": eadd_traffic, "traffic_source": eadd_src,
@@ -433,7 +482,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
         k_ms, k_name = eng.last_kernel_ms(), eng.last_kernel_name()
         mads2 = syn.l2_add_mads(nl)
         alg2 = 3 * EB * n2a
-        node, src2 = committed_traffic("eadd_l2") if n2a == 1 << 20 else (None, None)
+        t2, src2 = secondary_traffic(live, "eadd_l2", "hbm_bytes_per_launch") if n2a == 1 << 20 else (None, None)
         rate2 = n2a / dt * mads2
         out["eadd_l2"] = {
             "value": n2a / dt, "unit": "adds/s", "batch": n2a,
@@ -441,7 +490,7 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
                         "wire bytes in one launch", "kernel": k_name, "algorithmic_bytes_per_unit": 3 * EB,
             "roofline": {"bound": "hbm", "achieved": alg2 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": (node or {}).get("hbm_bytes_per_launch"), "traffic_source": src2 if node else None,
+                         "traffic": t2, "traffic_source": src2,
                          "algorithmic_bytes_per_launch": alg2, "kernel": k_name, "kernel_ms": k_ms, "call_ms": dt * 1e3},
             "roofline_valu": {"bound": "v_mad_u64_u32 issue", "mads_per_unit": mads2, "achieved": rate2, "unit": "lane-MAD/s",
                               "peak": VALU_MAD_PEAK_4W, "frac": rate2 / VALU_MAD_PEAK_4W,
@@ -569,8 +618,8 @@ def secondary_metrics(pk, fx, dev, cts, xs, rs, dec_log2s, no_cpu=False, polys_l
              "table_setup_s": t_setup, "plaintexts_and_statuses_exact": ok, "algorithmic_bytes_per_unit": alg},
             syn.decrypt_counts(fx, int(eng._lib.bgn_ctx_bsgs_baby_steps(eng._h))), nl)
         # the dominant kernel of Decrypt is the lift (k_pairing<NL, 1>), timed by HIP events on its stream
-        node, traffic_src = committed_traffic("decrypt_lift_k_pairing_1" if k == 20 else "decrypt_lift_2^%d" % k)
-        traffic = (node or {}).get("hbm_bytes_per_launch")
+        traffic, traffic_src = secondary_traffic(live, "decrypt_lift_k_pairing_1" if k == 20 else "decrypt_lift_2^%d" % k,
+                                                 "hbm_bytes_per_launch")
         e["roofline"] = {"bound": "hbm", "achieved": alg * n_dec / (lift_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg * n_dec / (lift_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src if traffic is not None else None,
@@ -716,6 +765,7 @@ def main():
     ap.add_argument("--decrypt-log2", type=int, nargs="+", default=[16, 20],
                     help="batch sizes (log2, at most 20) of the Decrypt measurement")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and gather even with one rank")
+    ap.add_argument("--pmc-extras", action="store_true", help=argparse.SUPPRESS)   # the child passes of live_traffic only
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="quote roofline.traffic from the committed PMC summary instead of measuring it in two child passes")
     args = ap.parse_args()
@@ -736,7 +786,7 @@ def main():
     live = None
     if (world == 1 and not args.force_dist and os.environ.get("BGN_BENCH_FORCE_DIST") != "1" and not args.no_live_traffic
             and args.workload == "emult" and args.key == "k1024" and args.batch_log2 == 20):
-        live = live_traffic()
+        live = live_traffic(extras=not args.no_extra)
 
     start_watchdog()
     # stdout carries ONE JSON line: native libraries that write to file descriptor 1 (RCCL prints a version banner
@@ -865,9 +915,11 @@ def main():
 
     extra = dec = None
     full = args.key == "k1024" and args.batch_log2 == 20
+    if args.pmc_extras and world == 1 and not use_dist and full:
+        pmc_extras(pk, fx, dev, cts, xs, out)
     if not args.no_extra and world == 1 and not use_dist and full:
         extra, dec = secondary_metrics(pk, fx, dev, cts, xs, rs, [min(k, 20) for k in args.decrypt_log2],
-                                       no_cpu=args.no_cpu_baseline, polys_log2=args.polys_log2, prods=out)
+                                       no_cpu=args.no_cpu_baseline, polys_log2=args.polys_log2, prods=out, live=live)
         extra["config0_512bit_128"] = config0_metrics(args.no_cpu_baseline)
         if mid_batch:
             extra["mult_mid_batch"] = mid_batch

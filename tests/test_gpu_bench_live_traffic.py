@@ -31,3 +31,36 @@ def test_bench_line_carries_a_live_pmc_measurement():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r06_bench_live_traffic_line.json"), "w") as f:
         json.dump(line, f, indent=1)
+
+
+def test_live_passes_cover_the_secondary_kernels():
+    """With the extras on, the same two child passes also launch the secondary kernels whose traffic the line quotes
+    (--pmc-extras): the level-1 and level-2 Add of 2^20 and Decrypt's lifts at 2^16 and 2^20 come out of THIS run's
+    counters, next to the committed figures they replace (same command, another box: within 15 %)."""
+    import importlib.util
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    spec = importlib.util.spec_from_file_location("bench_live", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    env_keys = [k for k in os.environ if k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BGN_BENCH_SPAWN")]
+    saved = {k: os.environ.pop(k) for k in env_keys}
+    try:
+        live = bench.live_traffic(timeout_s=300, extras=True)
+    finally:
+        os.environ.update(saved)
+    assert live is not None, "the PMC child passes failed"
+    sec = live["secondary"]
+    assert set(sec) == {"eadd_l1", "eadd_l2", "decrypt_lift_2^16", "decrypt_lift_k_pairing_1"}, sec
+    alg = 3 * 258 * (1 << 20)
+    assert 0.9 * alg < sec["eadd_l2"] < 1.3 * alg, sec["eadd_l2"] / alg                # one launch, wire to wire
+    assert 1.5 * alg < sec["eadd_l1"] < 2.6 * alg, sec["eadd_l1"] / alg                # two passes over the slices + the prefix products
+    assert sec["decrypt_lift_k_pairing_1"] > 8 * sec["decrypt_lift_2^16"] > 0
+    for key, field in (("eadd_l1", "hbm_bytes_per_call"), ("eadd_l2", "hbm_bytes_per_launch"),
+                       ("decrypt_lift_2^16", "hbm_bytes_per_launch"), ("decrypt_lift_k_pairing_1", "hbm_bytes_per_launch")):
+        node, _ = bench.committed_traffic(key)
+        if node and node.get(field):
+            assert abs(sec[key] / node[field] - 1) < 0.15, (key, sec[key], node[field])
+    with open(os.path.join(ROOT, "gpurun_out", "r06_live_traffic_secondary.json"), "w") as f:
+        json.dump(live, f, indent=1)

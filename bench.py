@@ -193,7 +193,10 @@ def live_traffic(timeout_s=150.0, extras=False):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("BGN_BENCH_SPAWN", "BGN_BENCH_FORCE_DIST", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    tmp = tempfile.mkdtemp(prefix="bgn_pmc_", dir="/tmp")
+    try:
+        tmp = tempfile.mkdtemp(prefix="bgn_pmc_", dir="/tmp")
+    except OSError:
+        return None
     t0 = time.perf_counter()
     kb, calib, sec = {}, None, {}
     try:

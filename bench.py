@@ -16,6 +16,9 @@ Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--workload emult|mul
   environment and --gpus must agree with WORLD_SIZE.
   --workload multpoly: BASELINE configs[4] — 2^14 MultPoly instances of 16x16 coefficient polynomials (2^22
   coefficient pairs) per job plus one AddPoly, sharded by polynomial across the GPUs (strong scaling).
+  On one GPU at the BASELINE size the run first measures the HBM-side traffic its line quotes: two child passes of
+  its own timed step under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, started before this process touches
+  the GPU (live_traffic; about 13 s; --no-live-traffic quotes the committed summary under profiles/ instead).
 """
 import argparse
 import json
